@@ -1,0 +1,390 @@
+"""CPU ORACLE (test infrastructure — NOT part of the product path).
+
+A numpy / scipy-HiGHS restatement of the per-price-scenario multi-period dispatch LPs that the reference
+builds with Pyomo + IDAES and hands to CBC / IPOPT / Xpress.  Only ``tests/``, ``__graft_entry__.smoke()``
+and ``bench.py``'s ``cpu_baseline`` leg may import this module; ``dispatches_amd`` never does.
+
+Why a restatement: the reference's own stack (pyomo 6.5, idaes-pse 2.0, cbc, ipopt — ``setup.py:64-73``) is
+absent from the build container and cannot be installed, and the LP construction + solve lives in those
+third-party packages.  Each function below cites the reference file:line whose equations it restates.
+
+Parity status: PINNED against every known-answer vector the reference holds for this path
+(``tests/golden/reference_vectors.json``, checked by ``tests/test_oracle_golden.py``):
+  G1/G2  SelfScheduler / Bidder 48-h day-ahead bids   (test_multiperiod_wind_battery_doubleloop.py:168-175,245-252)
+  G3     wind+battery Tracker, 4 h                     (same file :88-111)
+  G3b    wind+PEM Tracker, 4 h                         (test_wind_PEM_double_loop.py:88-119)
+  G4     nuclear DA bidding objective (IPOPT log)      (nuclear_flowsheet_double_loop.ipynb:716)
+  G5/G6  wind+battery DA / RT objectives (Xpress log)  (DoubleLoopOptimization.ipynb:657,726,1139)
+  G7     battery unit-model rows                       (unit_models/tests/test_battery.py:57-58,119)
+UNPINNED (no reference vector exists): n_scenario > 1 with *different* scenarios (cross-scenario coupling
+rows of the upstream Bidder), and the QP ramp-cost variant (our extension).
+
+The formulation here is deliberately the UN-reduced one (every physical variable and row of the flowsheet,
+including the never-binding 1e8 ramp rows) and is written independently of ``dispatches_amd``'s flattener,
+so that a parity test compares two separately-derived standard forms, not one builder against itself.
+"""
+from __future__ import annotations
+
+import numpy as np
+import scipy.sparse as sp
+from scipy.optimize import linprog
+
+# ---- constants --------------------------------------------------------------------------------------------
+# renewables_case/load_parameters.py:24-79 + wind_battery_cost_parameter.json
+WIND_OP_COST = 41.78            # $/kW-yr   (load_parameters.py:45)
+BATT_REP_COST_KWH = 29.545625   # $/kWh     (load_parameters.py:41,48: 236.365 * 0.5 / 4)
+PEM_OP_COST = 0.03 * 1200       # $/kW-yr   (load_parameters.py:49-50)
+PEM_VAR_COST = 0.0              # $/kWh     (load_parameters.py:51)
+BATTERY_RAMP_RATE = 1e8         # kWh       (load_parameters.py:75)
+ETA_C = 0.95                    # RE_flowsheet.py:151
+ETA_D = 0.95                    # RE_flowsheet.py:152
+DEGRADATION = 1e-4              # battery.py:91-95
+H2_MOLS_PER_KG = 500.0          # load_parameters.py:26
+PEM_MOL_PER_KW_S = 0.00275984   # RE_flowsheet.py:131
+UNDERBID_PENALTY = 1e4          # upstream idaes Bidder default `real_time_underbid_penalty`
+TRACK_PENALTY = 1e4             # upstream idaes Tracker deviation penalty
+
+
+class _LP:
+    """Tiny named-variable LP assembler:  min c.x + c0  s.t.  lo <= A x <= hi,  lb <= x <= ub."""
+
+    def __init__(self):
+        self.names, self.lb, self.ub = [], [], []
+        self.rows, self.lo, self.hi = [], [], []
+        self.c = {}
+        self.c0 = 0.0
+
+    def var(self, name, lb=0.0, ub=np.inf):
+        self.names.append(name)
+        self.lb.append(lb)
+        self.ub.append(ub)
+        return len(self.names) - 1
+
+    def row(self, coeffs, lo, hi):
+        self.rows.append(dict(coeffs))
+        self.lo.append(lo)
+        self.hi.append(hi)
+
+    def add_cost(self, expr, scale=1.0):
+        """expr = (dict col->coef, const)"""
+        d, k = expr
+        for j, v in d.items():
+            self.c[j] = self.c.get(j, 0.0) + scale * v
+        self.c0 += scale * k
+
+    def arrays(self):
+        n, m = len(self.names), len(self.rows)
+        c = np.zeros(n)
+        for j, v in self.c.items():
+            c[j] = v
+        ri, ci, vv = [], [], []
+        for i, r in enumerate(self.rows):
+            for j, v in r.items():
+                ri.append(i), ci.append(j), vv.append(v)
+        A = sp.csr_matrix((vv, (ri, ci)), shape=(m, n))
+        return (c, self.c0, A, np.asarray(self.lo, float), np.asarray(self.hi, float),
+                np.asarray(self.lb, float), np.asarray(self.ub, float))
+
+
+def _lin(*terms, const=0.0):
+    d = {}
+    for j, v in terms:
+        d[j] = d.get(j, 0.0) + v
+    return d, const
+
+
+def _scale(expr, s):
+    d, k = expr
+    return {j: v * s for j, v in d.items()}, k * s
+
+
+def _add(*exprs):
+    d, k = {}, 0.0
+    for e in exprs:
+        for j, v in e[0].items():
+            d[j] = d.get(j, 0.0) + v
+        k += e[1]
+    return d, k
+
+
+# ---- LP #1: wind + battery --------------------------------------------------------------------------------
+def wind_battery_rows(lp, T, cf, wind_kw, batt_kw, batt_kwh, soc0=0.0, e0=None,
+                      wind_op_cost=WIND_OP_COST, batt_rep_cost_kwh=BATT_REP_COST_KWH,
+                      wind_waste_penalty=1e3):
+    """Per-period rows of the wind+battery flowsheet.
+
+    wind_power.py:120-122      0 <= W_t <= C_w cf_t
+    elec_splitter.py:115-117   W_t = G_t + I_t       (arcs RE_flowsheet.py:389,396)
+    battery.py:145-149         S_t = S_{t-1} + eta_c I_t - O_t / eta_d      (link wind_battery_LMP.py:33)
+    battery.py:151-153         E_t = E_{t-1} + (I_t + O_t)/2                (link wind_battery_LMP.py:34)
+    battery.py:155-157         S_t <= E_b - d E_t
+    battery.py:159-165         I_t, O_t <= P_b
+    wind_battery_LMP.py:139-142  |S_t - S_{t-1}| <= 1e8
+    wind_battery_double_loop.py:76-81  SOC_init fixed at t=0, periodic row deactivated; throughput_init free
+                                       (>= 0) until the first update_model fixes it (:197-200)
+    wind_battery_double_loop.py:175-177  P_T, wind_waste, tot_cost
+    """
+    v = {}
+    e_init = lp.var("E_init", 0.0, np.inf) if e0 is None else None
+    P_T, cost, waste = [], [], []
+    for t in range(T):
+        W = lp.var(f"W{t}", 0.0, wind_kw * cf[t])
+        G = lp.var(f"G{t}")
+        I = lp.var(f"I{t}", 0.0, batt_kw)
+        O = lp.var(f"O{t}", 0.0, batt_kw)
+        S = lp.var(f"S{t}")
+        E = lp.var(f"E{t}")
+        v[t] = dict(W=W, G=G, I=I, O=O, S=S, E=E)
+        lp.row({W: 1, G: -1, I: -1}, 0.0, 0.0)
+        if t == 0:
+            lp.row({S: 1, I: -ETA_C, O: 1 / ETA_D}, soc0, soc0)
+            if e0 is None:
+                lp.row({E: 1, e_init: -1, I: -0.5, O: -0.5}, 0.0, 0.0)
+            else:
+                lp.row({E: 1, I: -0.5, O: -0.5}, e0, e0)
+            lp.row({S: 1}, soc0 - BATTERY_RAMP_RATE, soc0 + BATTERY_RAMP_RATE)
+        else:
+            Sp, Ep = v[t - 1]["S"], v[t - 1]["E"]
+            lp.row({S: 1, Sp: -1, I: -ETA_C, O: 1 / ETA_D}, 0.0, 0.0)
+            lp.row({E: 1, Ep: -1, I: -0.5, O: -0.5}, 0.0, 0.0)
+            lp.row({S: 1, Sp: -1}, -BATTERY_RAMP_RATE, BATTERY_RAMP_RATE)
+        lp.row({S: 1, E: DEGRADATION}, -np.inf, batt_kwh)
+        P_T.append(_lin((G, 1e-3), (O, 1e-3)))
+        w = _lin((W, -1e-3), const=wind_kw * cf[t] * 1e-3)       # MW
+        waste.append(w)
+        if t == 0:
+            dE = _lin((E, 1.0), (e_init, -1.0)) if e0 is None else _lin((E, 1.0), const=-e0)
+        else:
+            dE = _lin((E, 1.0), (v[t - 1]["E"], -1.0))
+        cost.append(_add(_lin(const=wind_kw * wind_op_cost / 8760),
+                         _scale(dE, DEGRADATION * batt_rep_cost_kwh),
+                         _scale(w, wind_waste_penalty)))
+    return dict(vars=v, P_T=P_T, cost=cost, waste=waste, e_init=e_init)
+
+
+# ---- LP #2: wind + PEM ------------------------------------------------------------------------------------
+def wind_pem_rows(lp, T, cf, wind_kw, wind_op_cost=WIND_OP_COST):
+    """wind_PEM_double_loop.py:59-85 (free NonNegative `pem_system_capacity`, row X_t <= K at :80),
+    :172-182 (P_T = grid_elec*1e-3; wind_waste in kW with unit weight; tot_cost with K*pem_op_cost/8760)."""
+    v = {}
+    K = lp.var("K")
+    P_T, cost, waste = [], [], []
+    for t in range(T):
+        W = lp.var(f"W{t}", 0.0, wind_kw * cf[t])
+        G = lp.var(f"G{t}")
+        X = lp.var(f"X{t}")
+        v[t] = dict(W=W, G=G, X=X)
+        lp.row({W: 1, G: -1, X: -1}, 0.0, 0.0)
+        lp.row({X: 1, K: -1}, -np.inf, 0.0)
+        P_T.append(_lin((G, 1e-3)))
+        w = _lin((W, -1.0), const=wind_kw * cf[t])                 # kW
+        waste.append(w)
+        cost.append(_add(_lin(const=wind_kw * wind_op_cost / 8760),
+                         _lin((K, PEM_OP_COST / 8760)),
+                         _lin((X, PEM_VAR_COST)),
+                         w))
+    return dict(vars=v, P_T=P_T, cost=cost, waste=waste, K=K)
+
+
+# ---- LP #3: nuclear + PEM + tank --------------------------------------------------------------------------
+NP_CAPACITY_KW = 500e3          # nuclear_flowsheet.py:125, multiperiod_class.py:98
+PEM_CAPACITY_KW = 100e3         # nuclear_flowsheet.py:137-138, :100
+TANK_CAPACITY_KG = 5000.0       # nuclear_flowsheet.py:155-156, :101
+MW_H2 = 2.016e-3                # nuclear_flowsheet.py:116
+NUC_PEM_MOL_PER_KW_S = 0.002527406   # nuclear_flowsheet.py:269
+NPP_VOM, NUC_PEM_VOM, TANK_VOM = 2.3, 1.3, 0.01   # multiperiod_class.py:131-135
+
+
+def nuclear_rows(lp, T, holdup0=0.0, h2_price=4.0, h2_demand=0.35):
+    """nuclear_flowsheet.py:119-156 splitter/PEM/tank; hydrogen_tank_simplified.py:177-183 holdup balance;
+    nuclear_flowsheet_multiperiod_class.py:47-49 link, :140-141 demand bound, :149-153 operating cost,
+    :203 holdup_previous fixed, :211-212 P_T / tot_cost."""
+    v = {}
+    P_T, cost = [], []
+    hmax = TANK_CAPACITY_KG / MW_H2
+    for t in range(T):
+        g = lp.var(f"g{t}")
+        p = lp.var(f"p{t}", 0.0, PEM_CAPACITY_KW)
+        # tank_holdup_previous carries the capacity bound; h_t feeds holdup_previous[t+1]
+        h = lp.var(f"h{t}", 0.0, hmax if t < T - 1 else np.inf)
+        f = lp.var(f"f{t}", 0.0, h2_demand / MW_H2)
+        v[t] = dict(g=g, p=p, h=h, f=f)
+        lp.row({g: 1, p: 1}, NP_CAPACITY_KW, NP_CAPACITY_KW)
+        if t == 0:
+            lp.row({h: 1, p: -3600 * NUC_PEM_MOL_PER_KW_S, f: 3600}, holdup0, holdup0)
+        else:
+            lp.row({h: 1, v[t - 1]["h"]: -1, p: -3600 * NUC_PEM_MOL_PER_KW_S, f: 3600}, 0.0, 0.0)
+        P_T.append(_lin((g, 1e-3)))
+        cost.append(_add(_lin(const=NP_CAPACITY_KW * 1e-3 * NPP_VOM),
+                         _lin((p, 1e-3 * NUC_PEM_VOM)),
+                         _lin((h, MW_H2 * TANK_VOM)),
+                         _lin((f, -MW_H2 * 3600 * h2_price))))
+    return dict(vars=v, P_T=P_T, cost=cost)
+
+
+# ---- wrappers: upstream idaes Bidder / SelfScheduler / Tracker ---------------------
+def add_da_bidding(lp, fs, da, rt, cost_weight=1.0):
+    """max sum_t DA pda + RT (P_T - pda) - w cost - 1e4 u,  u >= pda - P_T   (minimised as the negative)."""
+    T = len(fs["P_T"])
+    pda, u = [], []
+    for t in range(T):
+        a = lp.var(f"pda{t}")
+        b = lp.var(f"u{t}")
+        pda.append(a), u.append(b)
+        d, k = fs["P_T"][t]
+        r = {a: 1.0, b: -1.0}
+        for j, vv in d.items():
+            r[j] = r.get(j, 0.0) - vv
+        lp.row(r, -np.inf, k)
+        lp.add_cost(_lin((a, -(da[t] - rt[t]))))
+        lp.add_cost(fs["P_T"][t], -rt[t])
+        lp.add_cost(fs["cost"][t], cost_weight)
+        lp.add_cost(_lin((b, UNDERBID_PENALTY)))
+    return pda, u
+
+
+def add_rt_bidding(lp, fs, rt, realized_da_dispatch, cost_weight=1.0):
+    """max sum_t RT (P_T - pda_fixed) - w cost - 1e4 u,  u >= pda_fixed - P_T."""
+    T = len(fs["P_T"])
+    u = []
+    for t in range(T):
+        b = lp.var(f"u{t}")
+        u.append(b)
+        d, k = fs["P_T"][t]
+        r = {b: 1.0}
+        for j, vv in d.items():
+            r[j] = r.get(j, 0.0) + vv
+        lp.row(r, realized_da_dispatch[t] - k, np.inf)
+        lp.add_cost(fs["P_T"][t], -rt[t])
+        lp.add_cost(_lin(const=rt[t] * realized_da_dispatch[t]))
+        lp.add_cost(fs["cost"][t], cost_weight)
+        lp.add_cost(_lin((b, UNDERBID_PENALTY)))
+    return u
+
+
+def add_tracking(lp, fs, dispatch, cost_weight=1.0):
+    """min sum_t w cost + 1e4 (under + over),  P_T + under - over = D_t."""
+    T = len(fs["P_T"])
+    under, over = [], []
+    for t in range(T):
+        a = lp.var(f"under{t}")
+        b = lp.var(f"over{t}")
+        under.append(a), over.append(b)
+        d, k = fs["P_T"][t]
+        r = dict(d)
+        r[a] = 1.0
+        r[b] = -1.0
+        lp.row(r, dispatch[t] - k, dispatch[t] - k)
+        lp.add_cost(fs["cost"][t], cost_weight)
+        lp.add_cost(_lin((a, TRACK_PENALTY), (b, TRACK_PENALTY)))
+    return under, over
+
+
+# ---- HiGHS solve ------------------------------------------------------------------------------------------
+class PreparedLP:
+    """Arrays split the way scipy.optimize.linprog wants them; `solve(c=...)` re-solves with a new cost."""
+
+    def __init__(self, lp: _LP):
+        self.lp = lp
+        c, c0, A, lo, hi, lb, ub = lp.arrays()
+        self.c, self.c0, self.A, self.lo, self.hi, self.lb, self.ub = c, c0, A, lo, hi, lb, ub
+        eq = np.isfinite(lo) & np.isfinite(hi) & (lo == hi)
+        ub_rows = np.isfinite(hi) & ~eq
+        lb_rows = np.isfinite(lo) & ~eq
+        self.A_eq, self.b_eq = (A[eq], hi[eq]) if eq.any() else (None, None)
+        parts, rhs = [], []
+        if ub_rows.any():
+            parts.append(A[ub_rows]), rhs.append(hi[ub_rows])
+        if lb_rows.any():
+            parts.append(-A[lb_rows]), rhs.append(-lo[lb_rows])
+        self.A_ub = sp.vstack(parts).tocsr() if parts else None
+        self.b_ub = np.concatenate(rhs) if parts else None
+        self.bounds = np.stack([lb, ub], axis=1)
+
+    def solve(self, c=None):
+        c = self.c if c is None else c
+        res = linprog(c, A_ub=self.A_ub, b_ub=self.b_ub, A_eq=self.A_eq, b_eq=self.b_eq,
+                      bounds=self.bounds, method="highs")
+        if res.status != 0:
+            raise RuntimeError(f"HiGHS did not solve: {res.message}")
+        return res.x, float(res.fun + self.c0)
+
+    def value(self, expr, x):
+        d, k = expr
+        return k + sum(v * x[j] for j, v in d.items())
+
+
+# ---- convenience end-to-end problems used by tests and the CPU baseline -----------------------------------
+def wind_battery_da(T, cf, da, rt, wind_kw=200e3, batt_kw=25e3, batt_kwh=100e3, soc0=0.0, e0=None, **kw):
+    lp = _LP()
+    fs = wind_battery_rows(lp, T, cf, wind_kw, batt_kw, batt_kwh, soc0, e0, **kw)
+    pda, u = add_da_bidding(lp, fs, da, rt)
+    return PreparedLP(lp), fs, pda, u
+
+
+def wind_battery_rt(T, cf, rt, realized_da, wind_kw=200e3, batt_kw=25e3, batt_kwh=100e3, soc0=0.0, e0=None, **kw):
+    lp = _LP()
+    fs = wind_battery_rows(lp, T, cf, wind_kw, batt_kw, batt_kwh, soc0, e0, **kw)
+    u = add_rt_bidding(lp, fs, rt, realized_da)
+    return PreparedLP(lp), fs, u
+
+
+def wind_battery_track(T, cf, dispatch, wind_kw=200e3, batt_kw=25e3, batt_kwh=100e3, soc0=0.0, e0=None, **kw):
+    lp = _LP()
+    fs = wind_battery_rows(lp, T, cf, wind_kw, batt_kw, batt_kwh, soc0, e0, **kw)
+    under, over = add_tracking(lp, fs, dispatch)
+    return PreparedLP(lp), fs, under, over
+
+
+def wind_pem_da(T, cf, da, rt, wind_kw=200e3, **kw):
+    lp = _LP()
+    fs = wind_pem_rows(lp, T, cf, wind_kw, **kw)
+    pda, u = add_da_bidding(lp, fs, da, rt)
+    return PreparedLP(lp), fs, pda, u
+
+
+def wind_pem_track(T, cf, dispatch, wind_kw=200e3, **kw):
+    lp = _LP()
+    fs = wind_pem_rows(lp, T, cf, wind_kw, **kw)
+    under, over = add_tracking(lp, fs, dispatch)
+    return PreparedLP(lp), fs, under, over
+
+
+def nuclear_da(T, da, rt, holdup0=0.0, **kw):
+    lp = _LP()
+    fs = nuclear_rows(lp, T, holdup0, **kw)
+    pda, u = add_da_bidding(lp, fs, da, rt)
+    return PreparedLP(lp), fs, pda, u
+
+
+def nuclear_track(T, dispatch, holdup0=0.0, **kw):
+    lp = _LP()
+    fs = nuclear_rows(lp, T, holdup0, **kw)
+    under, over = add_tracking(lp, fs, dispatch)
+    return PreparedLP(lp), fs, under, over
+
+
+def backcast_one_sample(hist, horizon):
+    """Upstream idaes Backcaster with ONE sample and `len(hist)//24` stored days: the forecast for hour t is
+    taken from the most recent stored day first, wrapping over the history (pinned by G1)."""
+    hist = np.asarray(hist, float)
+    n_days = len(hist) // 24
+    out = np.empty(horizon)
+    for t in range(horizon):
+        day = (n_days - 1 + t // 24) % n_days
+        out[t] = hist[24 * day + t % 24]
+    return out
+
+
+def marginal_to_actual_costs(pairs):
+    """idaes.apps.grid_integration.utils.convert_marginal_costs_to_actual_costs (call sites
+    coordinator.py:65, PEM_parametrized_bidder.py:65): cumulative sum of marginal cost x delta power."""
+    out, cost, prev = [], 0.0, None
+    for k, (p, mc) in enumerate(pairs):
+        if k == 0:
+            cost = p * mc
+        else:
+            cost += (p - prev) * mc
+        out.append((p, cost))
+        prev = p
+    return out

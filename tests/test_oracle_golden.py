@@ -1,0 +1,113 @@
+"""Pins the CPU oracle (oracle/dispatch_lp_oracle.py) to every known-answer vector the reference holds for
+the double-loop LP path.  CPU only."""
+import numpy as np
+import pytest
+
+from oracle import dispatch_lp_oracle as orc
+
+
+def test_G1_G2_day_ahead_bids(golden, rts309):
+    # test_multiperiod_wind_battery_doubleloop.py:114-175 (SelfScheduler) and :178-252 (Bidder)
+    T = 48
+    da = orc.backcast_one_sample(rts309["da_lmp"][:48], T)
+    rt = orc.backcast_one_sample(rts309["rt_lmp"][:48], T)
+    P, fs, pda, u = orc.wind_battery_da(T, rts309["rt_cf"][:T], da, rt)
+    x, obj = P.solve()
+    p_max = np.round(x[pda], 4)
+    g1 = np.array(golden["G1_self_schedule_p_max_mw"]["values"])
+    assert np.max(np.abs(p_max - g1)) < 5e-5          # reference test: reltol 1e-2
+    last_cost = np.round(x[pda], 2) * np.round(da, 2)
+    g2 = np.array(golden["G2_bidder_last_point_cost"]["values"])
+    assert np.max(np.abs(last_cost - g2)) < 5e-3
+
+
+def test_G3_tracker_wind_battery(golden, rts309):
+    g = golden["G3_tracker_wind_battery"]
+    D = g["market_dispatch_mw"]
+    P, fs, under, over = orc.wind_battery_track(4, rts309["rt_cf"][:4], D)
+    x, obj = P.solve()
+    W = np.array([x[fs["vars"][t]["W"]] for t in range(4)])
+    assert W == pytest.approx(g["expected_wind_power_kw"], rel=g["rel"])
+    PT = np.array([P.value(fs["P_T"][t], x) for t in range(4)])
+    assert PT == pytest.approx(D, abs=g["abs"])
+    I = np.array([x[fs["vars"][t]["I"]] for t in range(4)])
+    assert I == pytest.approx(np.array(g["expected_wind_power_kw"]) - 1e3 * np.array(D), rel=g["rel"])
+
+
+def test_G3b_tracker_wind_pem(golden, rts309):
+    g = golden["G3b_tracker_wind_pem"]
+    D = g["market_dispatch_mw"]
+    assert rts309["rt_cf"][0] == pytest.approx(g["cap_factor0"], rel=1e-3)
+    P, fs, under, over = orc.wind_pem_track(4, rts309["rt_cf"][:4], D)
+    x, obj = P.solve()
+    W = np.array([x[fs["vars"][t]["W"]] for t in range(4)])
+    assert W == pytest.approx(g["expected_wind_power_kw"], rel=g["rel"])
+    waste = np.array([P.value(fs["waste"][t], x) for t in range(4)])
+    assert waste == pytest.approx(0, abs=g["abs"])
+    X = np.array([x[fs["vars"][t]["X"]] for t in range(4)])
+    assert X == pytest.approx(np.array(g["expected_wind_power_kw"]) - 1e3 * np.array(D), rel=g["rel"])
+
+
+def test_G4_nuclear_da_objective(golden):
+    g = golden["G4_nuclear_da_objective"]
+    T = 48
+    da = np.array([g["da_lmp"][t % 24] for t in range(T)])
+    rt = np.array([g["rt_lmp"][t % 24] for t in range(T)])
+    P, fs, pda, u = orc.nuclear_da(T, da, rt)
+    x, obj = P.solve()
+    assert 3 * obj == pytest.approx(g["ipopt_objective_3_scenarios"], rel=g["rel"])
+    assert obj == pytest.approx(-555562.7659005648, rel=1e-9)
+
+
+def test_G5_G6_wind_battery_xpress_objectives(golden, rts309):
+    g = golden["G5_wind_battery_da_objective_xpress"]
+    T = g["horizon"]
+    da = np.array([rts309["da_lmp"][t % 24] for t in range(T)])
+    rt = np.array([rts309["rt_lmp"][t % 24] for t in range(T)])
+    kw = dict(wind_kw=g["wind_mw"] * 1e3, batt_kw=g["battery_mw"] * 1e3, batt_kwh=g["battery_mwh"] * 1e3,
+              wind_op_cost=g["wind_op_cost"], batt_rep_cost_kwh=g["batt_rep_cost_kwh"])
+    P, fs, pda, u = orc.wind_battery_da(T, rts309["rt_cf"][:T], da, rt, **kw)
+    x, obj = P.solve()
+    assert -3 * obj == pytest.approx(g["xpress_objective_3_scenarios"], rel=1e-10)
+
+    g6 = golden["G6_wind_battery_rt_objective_xpress"]
+    T = g6["horizon"]
+    P, fs, u = orc.wind_battery_rt(T, rts309["rt_cf"][:T], rts309["rt_lmp"][:T], np.zeros(T), **kw)
+    x, obj = P.solve()
+    assert -3 * obj == pytest.approx(g6["xpress_objective_3_scenarios_hour0"], rel=1e-10)
+    P, fs, u = orc.wind_battery_rt(T, rts309["rt_cf"][:T], np.zeros(T), np.zeros(T), **kw)
+    x, obj = P.solve()
+    assert -3 * obj == pytest.approx(g6["xpress_objective_3_scenarios_zero_price"], rel=1e-10)
+
+
+def test_G7_battery_rows(golden):
+    # unit_models/tests/test_battery.py:41-121 -- the battery rows alone
+    g = golden["G7_battery_rows"]
+    a = g["case_a"]
+    lp = orc._LP()
+    fs = orc.wind_battery_rows(lp, 1, [1.0], 100.0, 5.0, 20.0, soc0=a["soc0"], e0=a["e0"])
+    v = fs["vars"][0]
+    lp.lb[v["I"]] = lp.ub[v["I"]] = a["elec_in"]
+    lp.lb[v["O"]] = lp.ub[v["O"]] = a["elec_out"]
+    x, _ = orc.PreparedLP(lp).solve()
+    assert x[v["S"]] == pytest.approx(a["soc"]) and x[v["E"]] == pytest.approx(a["throughput"])
+    b = g["case_b"]
+    lp = orc._LP()
+    fs = orc.wind_battery_rows(lp, 1, [1.0], 100.0, 5.0, 20.0, soc0=b["soc0"], e0=b["e0"])
+    v = fs["vars"][0]
+    lp.lb[v["O"]] = lp.ub[v["O"]] = b["elec_out"]
+    lp.lb[v["S"]] = lp.ub[v["S"]] = b["soc"]
+    x, _ = orc.PreparedLP(lp).solve()
+    assert x[v["I"]] == pytest.approx(b["elec_in"], rel=1e-3)
+    assert x[v["E"]] == pytest.approx(b["throughput"], rel=1e-3)
+
+
+def test_marginal_to_actual_costs(golden, rts309):
+    # test_wind_PEM_double_loop.py:211-213 pins cumulative sum(mc * dP)
+    g = golden["G3d_pem_parametrized_rt_last_cost"]["values"]
+    out = []
+    for t in range(4):
+        rt_wind = rts309["rt_cf"][t] * 200
+        grid = max(0, rt_wind - 25)
+        out.append(orc.marginal_to_actual_costs([(0, 0), (grid, 0), (rt_wind, 30)])[-1][1])
+    assert out == pytest.approx(g, rel=1e-2)
