@@ -1,0 +1,70 @@
+"""Linear unit-model rows (the equations of the reference's IDAES unit models, restated on a LinearBlock).
+
+Units follow the reference: power kW, energy kWh, dt = 1 h inside the flowsheet; P_T and bids in MW.
+Every function appends columns/rows for ONE time period `t` and returns the handles.
+"""
+from __future__ import annotations
+
+from ..lp import INF, LinearBlock
+
+
+def wind_power(b: LinearBlock, t: int, system_capacity_kw: float, capacity_factor: float):
+    """Wind plant: 0 <= electricity <= system_capacity * capacity_factor (curtailment allowed).
+    Reference: dispatches/unit_models/wind_power.py:120-122.  The availability is a mutable column bound
+    (`update_wind_capacity_factor`, wind_battery_double_loop.py:86-98)."""
+    return b.var(f"windpower.electricity[{t}]", 0.0, system_capacity_kw * capacity_factor,
+                 mutable=True, hull=(0.0, system_capacity_kw))
+
+
+def splitter(b: LinearBlock, t: int, inlet, outlet_names):
+    """Electrical splitter: inlet = sum(outlets).  Reference: dispatches/unit_models/elec_splitter.py:115-117."""
+    outs = [b.var(f"splitter.{nm}[{t}]") for nm in outlet_names]
+    body = inlet
+    for o in outs:
+        body = body - o
+    b.equality(f"splitter.sum_split[{t}]", body, 0.0)
+    return outs
+
+
+def battery(b: LinearBlock, t: int, elec_in, soc_prev, thr_prev, nameplate_power_kw, nameplate_energy_kwh,
+            charging_eta=0.95, discharging_eta=0.95, degradation_rate=1e-4, ramp_rate=None):
+    """Battery storage rows for one period (dt = 1 h).
+
+    Reference: dispatches/unit_models/battery.py
+      :145-149 state_evolution         soc = soc_prev + eta_c*elec_in - elec_out/eta_d
+      :151-153 accumulate_throughput   thr = thr_prev + (elec_in + elec_out)/2
+      :155-157 state_of_charge_bounds  soc <= nameplate_energy - degradation_rate*thr
+      :159-165 power bounds            elec_in, elec_out <= nameplate_power   (column bounds here)
+    and the (never-binding, 1e8) energy ramp rows of wind_battery_LMP.py:139-142 when `ramp_rate` is given.
+    `elec_in` is an existing column (the splitter outlet; arcs RE_flowsheet.py:389,396 equate them).
+    """
+    if elec_in.ub > nameplate_power_kw:
+        elec_in.setub(nameplate_power_kw)
+    elec_out = b.var(f"battery.elec_out[{t}]", 0.0, nameplate_power_kw)
+    soc = b.var(f"battery.state_of_charge[{t}]")
+    thr = b.var(f"battery.energy_throughput[{t}]")
+    b.equality(f"battery.state_evolution[{t}]",
+               soc - soc_prev - charging_eta * elec_in + elec_out / discharging_eta, 0.0)
+    b.equality(f"battery.accumulate_energy_throughput[{t}]",
+               thr - thr_prev - 0.5 * elec_in - 0.5 * elec_out, 0.0)
+    b.constraint(f"battery.state_of_charge_bounds[{t}]", soc + degradation_rate * thr, -INF, nameplate_energy_kwh)
+    if ramp_rate is not None:
+        b.constraint(f"battery.energy_ramp[{t}]", soc - soc_prev, -ramp_rate, ramp_rate)
+    return dict(elec_out=elec_out, state_of_charge=soc, energy_throughput=thr)
+
+
+def pem_electrolyzer(b: LinearBlock, t: int, electricity, system_capacity):
+    """PEM: electricity <= pem_system_capacity (a free NonNegative column shared by all periods,
+    wind_PEM_double_loop.py:76-80); H2 flow = electricity_to_mol * electricity is an output-only expression
+    (dispatches/unit_models/pem_electrolyzer.py:111-114)."""
+    b.constraint(f"pem.max_p[{t}]", electricity - system_capacity, -INF, 0.0)
+
+
+def hydrogen_tank(b: LinearBlock, t: int, holdup_prev, inlet_mol_per_s, dt_s=3600.0, demand_ub_mol_s=INF,
+                  holdup_ub_mol=INF):
+    """Simplified tank: holdup - holdup_prev = dt * (inlet - outlet_to_pipeline - outlet_to_turbine[=0]).
+    Reference: dispatches/unit_models/hydrogen_tank_simplified.py:177-183."""
+    holdup = b.var(f"h2_tank.tank_holdup[{t}]", 0.0, holdup_ub_mol)
+    out = b.var(f"h2_tank.outlet_to_pipeline.flow_mol[{t}]", 0.0, demand_ub_mol_s)
+    b.equality(f"h2_tank.tank_material_balance[{t}]", holdup - holdup_prev - dt_s * inlet_mol_per_s + dt_s * out, 0.0)
+    return dict(tank_holdup=holdup, outlet_to_pipeline=out)

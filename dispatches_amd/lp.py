@@ -1,0 +1,343 @@
+"""Flatten-once linear modelling layer.
+
+The reference builds every scenario's multi-period flowsheet as a tree of Pyomo blocks and re-writes an LP/NL
+file on every ``solver.solve``.  Here a model object populates ONE :class:`LinearBlock`
+(named columns, rows, and named linear expressions such as ``P_T[t]`` / ``tot_cost[t]``); the block is
+flattened ONCE to a :class:`StandardFormLP` (shared CSR constraint matrix + template vectors) and the only
+things that ever change afterwards are dense per-scenario vectors (objective, column bounds, row bounds) that
+are handed to the HIP solver as ``[B, n]`` / ``[B, m]`` arrays.
+
+Standard form:   min c.x + c0   s.t.  rlo <= A x <= rhi,   lb <= x <= ub.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+
+INF = float("inf")
+
+
+class LinExpr:
+    """Sparse affine expression  sum_j coef_j x_j + const  over the columns of one LinearBlock."""
+
+    __slots__ = ("coef", "const")
+
+    def __init__(self, coef: Optional[Dict[int, float]] = None, const: float = 0.0):
+        self.coef = coef if coef is not None else {}
+        self.const = float(const)
+
+    @staticmethod
+    def _as(x) -> "LinExpr":
+        if isinstance(x, LinExpr):
+            return x
+        if isinstance(x, Var):
+            return LinExpr({x.index: 1.0})
+        return LinExpr(None, float(x))
+
+    def copy(self):
+        return LinExpr(dict(self.coef), self.const)
+
+    def __add__(self, other):
+        o = LinExpr._as(other)
+        r = self.copy()
+        for j, v in o.coef.items():
+            r.coef[j] = r.coef.get(j, 0.0) + v
+        r.const += o.const
+        return r
+
+    __radd__ = __add__
+
+    def __neg__(self):
+        return self * -1.0
+
+    def __sub__(self, other):
+        return self + (LinExpr._as(other) * -1.0)
+
+    def __rsub__(self, other):
+        return (self * -1.0) + other
+
+    def __mul__(self, s):
+        s = float(s)
+        return LinExpr({j: v * s for j, v in self.coef.items()}, self.const * s)
+
+    __rmul__ = __mul__
+
+    def __truediv__(self, s):
+        return self * (1.0 / float(s))
+
+    def value(self, x: np.ndarray) -> float:
+        return self.const + sum(v * x[j] for j, v in self.coef.items())
+
+    def dense(self, n: int) -> np.ndarray:
+        out = np.zeros(n)
+        for j, v in self.coef.items():
+            out[j] = v
+        return out
+
+
+class Var:
+    """Handle of one column of a LinearBlock."""
+
+    __slots__ = ("block", "index", "name")
+
+    def __init__(self, block, index, name):
+        self.block, self.index, self.name = block, index, name
+
+    # arithmetic promotes to LinExpr
+    def __add__(self, o):
+        return LinExpr._as(self) + o
+
+    __radd__ = __add__
+
+    def __sub__(self, o):
+        return LinExpr._as(self) - o
+
+    def __rsub__(self, o):
+        return LinExpr._as(o) - self
+
+    def __mul__(self, s):
+        return LinExpr._as(self) * s
+
+    __rmul__ = __mul__
+
+    def __truediv__(self, s):
+        return LinExpr._as(self) / s
+
+    def __neg__(self):
+        return LinExpr._as(self) * -1.0
+
+    # pyomo-flavoured conveniences used by the model objects
+    @property
+    def lb(self):
+        return self.block.col_lb[self.index]
+
+    @property
+    def ub(self):
+        return self.block.col_ub[self.index]
+
+    def setlb(self, v):
+        self.block.set_bounds(self, lb=v)
+
+    def setub(self, v):
+        self.block.set_bounds(self, ub=v)
+
+    def fix(self, value):
+        self.block.set_bounds(self, lb=value, ub=value)
+
+    @property
+    def value(self):
+        x = self.block.solution
+        return None if x is None else float(x[self.index])
+
+
+@dataclass
+class StandardFormLP:
+    """One scenario's LP in standard form; `indptr/indices/data` is the CSR of A shared by the whole batch."""
+
+    n: int
+    m: int
+    indptr: np.ndarray      # int32 [m+1]
+    indices: np.ndarray     # int32 [nnz]
+    data: np.ndarray        # float64 [nnz]
+    c: np.ndarray           # [n]
+    c0: float
+    lb: np.ndarray          # [n]  (-inf allowed)
+    ub: np.ndarray          # [n]  (+inf allowed)
+    rlo: np.ndarray         # [m]  (-inf allowed)
+    rhi: np.ndarray         # [m]  (+inf allowed)
+    col_names: List[str] = field(default_factory=list)
+    row_names: List[str] = field(default_factory=list)
+
+    @property
+    def nnz(self) -> int:
+        return int(self.indptr[-1])
+
+    def csr(self):
+        import scipy.sparse as sp
+
+        return sp.csr_matrix((self.data, self.indices, self.indptr), shape=(self.m, self.n))
+
+    def objective(self, x: np.ndarray, c: Optional[np.ndarray] = None, c0: Optional[float] = None):
+        c = self.c if c is None else c
+        c0 = self.c0 if c0 is None else c0
+        return float(c @ x + c0)
+
+    def max_violation(self, x, lb=None, ub=None, rlo=None, rhi=None):
+        lb = self.lb if lb is None else lb
+        ub = self.ub if ub is None else ub
+        rlo = self.rlo if rlo is None else rlo
+        rhi = self.rhi if rhi is None else rhi
+        ax = self.csr() @ x
+        v = max(np.max(np.maximum(lb - x, 0)), np.max(np.maximum(x - ub, 0)))
+        if self.m:
+            v = max(v, np.max(np.maximum(rlo - ax, 0)), np.max(np.maximum(ax - rhi, 0)))
+        return float(v)
+
+
+class LinearBlock:
+    """The block a model object's ``populate_model(b, horizon)`` fills (stand-in for a Pyomo Block).
+
+    Columns, rows and named expression families are appended in call order.  ``flatten()`` produces the
+    StandardFormLP after a light presolve (drops rows that bound propagation proves can never bind, e.g. the
+    1e8 battery ramp rows of wind_battery_LMP.py:139-142).  Bounds / row bounds stay mutable afterwards and
+    are re-read through ``current_bounds()`` at every solve.
+    """
+
+    def __init__(self, name: str = "fs"):
+        self.name = name
+        self.col_names: List[str] = []
+        self.col_lb: List[float] = []
+        self.col_ub: List[float] = []
+        self.col_mutable: List[bool] = []
+        self.col_hull: List[tuple] = []       # widest bounds a mutable column may ever take
+        self.row_names: List[str] = []
+        self.row_expr: List[Dict[int, float]] = []
+        self.row_lo: List[float] = []
+        self.row_hi: List[float] = []
+        self.row_mutable: List[bool] = []
+        self.expressions: Dict[str, Dict[int, LinExpr]] = {}
+        self.solution: Optional[np.ndarray] = None
+        self._constructed = False
+        self._kept_rows: Optional[np.ndarray] = None
+        self._version = 0            # bumped on every bound change (solver re-uploads the template)
+
+    # -- pyomo-protocol shims ------------------------------------------------------------------------------
+    def is_constructed(self):
+        return self._constructed
+
+    def construct(self):
+        self._constructed = True
+
+    # -- building ------------------------------------------------------------------------------------------
+    def var(self, name: str, lb: float = 0.0, ub: float = INF, mutable: bool = False, hull=None) -> Var:
+        """New column.  `mutable` columns may have their bounds changed after flatten(); `hull` is the widest
+        interval they will ever be given (presolve only trusts the hull, never the current value)."""
+        self.col_names.append(name)
+        self.col_lb.append(float(lb))
+        self.col_ub.append(float(ub))
+        self.col_mutable.append(bool(mutable))
+        self.col_hull.append((float(hull[0]), float(hull[1])) if hull is not None else
+                             ((-INF, INF) if mutable else (float(lb), float(ub))))
+        return Var(self, len(self.col_names) - 1, name)
+
+    def constraint(self, name: str, body, lo: float = -INF, hi: float = INF, mutable: bool = False):
+        """lo <= body <= hi ; the constant of `body` is moved to the bounds.  Rows whose bounds will be rewritten
+        after flatten() (tracker dispatch rows) must be declared `mutable` so presolve never removes them."""
+        e = LinExpr._as(body)
+        self.row_names.append(name)
+        self.row_mutable.append(bool(mutable))
+        self.row_expr.append({j: v for j, v in e.coef.items() if v != 0.0})
+        self.row_lo.append(lo - e.const if np.isfinite(lo) else -INF)
+        self.row_hi.append(hi - e.const if np.isfinite(hi) else INF)
+        return len(self.row_names) - 1
+
+    def equality(self, name, body, rhs=0.0):
+        return self.constraint(name, body, rhs, rhs)
+
+    def set_row_bounds(self, row: int, lo: float, hi: float):
+        if self._kept_rows is not None and not self.row_mutable[row]:
+            raise ValueError(f"row {self.row_names[row]} was not declared mutable before flatten()")
+        self.row_lo[row], self.row_hi[row] = float(lo), float(hi)
+        self._version += 1
+
+    def set_bounds(self, v: Var, lb=None, ub=None):
+        j = v.index
+        if self._kept_rows is not None and not self.col_mutable[j]:
+            raise ValueError(f"column {v.name} was not declared mutable before flatten()")
+        if lb is not None:
+            self.col_lb[j] = float(lb)
+        if ub is not None:
+            self.col_ub[j] = float(ub)
+        if self._kept_rows is None and not self.col_mutable[j]:
+            self.col_hull[j] = (self.col_lb[j], self.col_ub[j])
+        h = self.col_hull[j]
+        if self.col_lb[j] < h[0] - 1e-9 * max(1, abs(h[0])) or self.col_ub[j] > h[1] + 1e-9 * max(1, abs(h[1])):
+            raise ValueError(f"bounds of {v.name} leave the declared hull {h}")
+        self._version += 1
+
+    def expression(self, family: str, index: int, expr):
+        self.expressions.setdefault(family, {})[index] = LinExpr._as(expr)
+
+    def __getattr__(self, item):
+        # `b.P_T[t]`, `b.tot_cost[t]` like the Pyomo Expression families of the reference
+        ex = self.__dict__.get("expressions", {})
+        if item in ex:
+            return ex[item]
+        raise AttributeError(item)
+
+    def value(self, expr) -> float:
+        return LinExpr._as(expr).value(self.solution)
+
+    # -- flattening ----------------------------------------------------------------------------------------
+    def _propagate_bounds(self):
+        """Implied column bounds from rows (bound propagation), trusting only immutable bounds / declared hulls."""
+        lb = np.array([h[0] for h in self.col_hull])
+        ub = np.array([h[1] for h in self.col_hull])
+        for _ in range(3):
+            for r, lo, hi in zip(self.row_expr, self.row_lo, self.row_hi):
+                items = list(r.items())
+                mins = [(a * lb[j] if a > 0 else a * ub[j]) for j, a in items]
+                maxs = [(a * ub[j] if a > 0 else a * lb[j]) for j, a in items]
+                for k, (j, a) in enumerate(items):
+                    if self.col_mutable[j]:
+                        continue
+                    if np.isfinite(hi):
+                        rest = sum(mins[:k]) + sum(mins[k + 1:])
+                        if np.isfinite(rest):
+                            b = (hi - rest) / a
+                            if a > 0:
+                                ub[j] = min(ub[j], b)
+                            else:
+                                lb[j] = max(lb[j], b)
+                    if np.isfinite(lo):
+                        rest = sum(maxs[:k]) + sum(maxs[k + 1:])
+                        if np.isfinite(rest):
+                            b = (lo - rest) / a
+                            if a > 0:
+                                lb[j] = max(lb[j], b)
+                            else:
+                                ub[j] = min(ub[j], b)
+        return lb, ub
+
+    def flatten(self, objective: Optional[LinExpr] = None, presolve: bool = True) -> StandardFormLP:
+        n, m_all = len(self.col_names), len(self.row_names)
+        keep = np.ones(m_all, bool)
+        if presolve and m_all:
+            lb, ub = self._propagate_bounds()
+            for i, (r, lo, hi) in enumerate(zip(self.row_expr, self.row_lo, self.row_hi)):
+                amin = sum((a * lb[j] if a > 0 else a * ub[j]) for j, a in r.items())
+                amax = sum((a * ub[j] if a > 0 else a * lb[j]) for j, a in r.items())
+                tol = 1e-9 * max(1.0, abs(lo) if np.isfinite(lo) else 0.0, abs(hi) if np.isfinite(hi) else 0.0)
+                if self.row_mutable[i]:
+                    continue
+                if amin >= lo - tol and amax <= hi + tol and not (lo == hi):
+                    keep[i] = False
+        self._kept_rows = np.nonzero(keep)[0]
+        indptr, indices, data = [0], [], []
+        for i in self._kept_rows:
+            for j in sorted(self.row_expr[i]):
+                indices.append(j)
+                data.append(self.row_expr[i][j])
+            indptr.append(len(indices))
+        obj = LinExpr._as(objective) if objective is not None else LinExpr()
+        lbv, ubv, rlo, rhi = self.current_bounds()
+        return StandardFormLP(
+            n=n, m=len(self._kept_rows),
+            indptr=np.asarray(indptr, np.int32), indices=np.asarray(indices, np.int32),
+            data=np.asarray(data, np.float64), c=obj.dense(n), c0=obj.const,
+            lb=lbv, ub=ubv, rlo=rlo, rhi=rhi,
+            col_names=list(self.col_names), row_names=[self.row_names[i] for i in self._kept_rows],
+        )
+
+    def current_bounds(self):
+        """Current (lb, ub, rlo, rhi) in flattened row order."""
+        kr = self._kept_rows if self._kept_rows is not None else np.arange(len(self.row_names))
+        return (np.asarray(self.col_lb, np.float64), np.asarray(self.col_ub, np.float64),
+                np.asarray(self.row_lo, np.float64)[kr], np.asarray(self.row_hi, np.float64)[kr])
+
+    def kept_row_index(self, row: int) -> int:
+        """Position of original row `row` in the flattened LP (-1 if presolved away)."""
+        pos = np.nonzero(self._kept_rows == row)[0]
+        return int(pos[0]) if len(pos) else -1

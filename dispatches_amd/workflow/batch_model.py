@@ -1,0 +1,106 @@
+"""The object a Bidder / Tracker hands to ``solver.solve(model)``.
+
+The reference hands a Pyomo ConcreteModel with one block per scenario (``model.fs[i]``, ``model.SCENARIOS``;
+``parametrized_bidder.py:146-149``).  Here the scenarios share ONE flattened LP; what differs per scenario are
+dense vectors stored as ``[B, n]`` / ``[B, m]`` arrays.  ``model.fs[i]`` still works: it returns the shared
+LinearBlock positioned on scenario i's solution, so model objects' ``record_results(model.fs[i], ...)`` and
+``get_implemented_profile(model.fs[i], ...)`` run unchanged.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import numpy as np
+
+from ..lp import LinearBlock, LinExpr, StandardFormLP
+
+# per-scenario termination codes written by the solver (include/dsp_hip.h)
+STATUS_OPTIMAL, STATUS_ITERATION_LIMIT, STATUS_PRIMAL_INFEASIBLE, STATUS_DUAL_INFEASIBLE, STATUS_NUMERICAL = range(5)
+
+
+class _ScenarioIndexer:
+    def __init__(self, model):
+        self._model = model
+
+    def __getitem__(self, i):
+        m = self._model
+        if not 0 <= i < m.n_scenario:
+            raise KeyError(i)
+        m.block.solution = None if m.x is None else m.x[i]
+        return m.block
+
+    def index_set(self):
+        return self._model.SCENARIOS
+
+    def __len__(self):
+        return self._model.n_scenario
+
+    def __iter__(self):
+        return iter(self._model.SCENARIOS)
+
+
+class SolveResults:
+    """Minimal stand-in for a Pyomo results object (status / termination_condition strings)."""
+
+    def __init__(self, status, termination_condition, **info):
+        self.solver = type("SolverInfo", (), dict(status=status, termination_condition=termination_condition))()
+        self.info = info
+
+    def __repr__(self):
+        return f"SolveResults(status={self.solver.status}, termination={self.solver.termination_condition}, {self.info})"
+
+
+class ScenarioBatchModel:
+    def __init__(self, block: LinearBlock, n_scenario: int, horizon: int, indexed: bool = True):
+        self.block = block
+        self.n_scenario = int(n_scenario)
+        self.SCENARIOS = range(self.n_scenario)
+        self.HOUR = range(horizon)
+        self.lp: Optional[StandardFormLP] = None
+        self._indexed = indexed
+        # per-scenario data (None -> template)
+        self.c = None
+        self.c0 = None
+        self.lb = self.ub = self.rlo = self.rhi = None
+        # results
+        self.x = self.y = self.objective = self.status = self.iterations = None
+        self.solve_handle = None      # solver-owned cache (device copy of A, scaling, workspace)
+
+    # model.fs[i] (bidder) or model.fs (tracker: a single block)
+    @property
+    def fs(self):
+        if self._indexed:
+            return _ScenarioIndexer(self)
+        self.block.solution = None if self.x is None else self.x[0]
+        return self.block
+
+    def finalize(self, objective: LinExpr):
+        """Flatten once; afterwards only vectors change."""
+        self.lp = self.block.flatten(objective)
+        self.c = np.tile(self.lp.c, (self.n_scenario, 1))
+        self.c0 = np.full(self.n_scenario, self.lp.c0)
+        return self.lp
+
+    def scenario_bounds(self):
+        """Current (lb, ub, rlo, rhi): per-scenario arrays where set, otherwise the block's current template."""
+        tlb, tub, trlo, trhi = self.block.current_bounds()
+        pick = lambda a, t: t if a is None else a
+        return pick(self.lb, tlb), pick(self.ub, tub), pick(self.rlo, trlo), pick(self.rhi, trhi)
+
+    def store_solution(self, x, y, objective, status, iterations=None):
+        self.x, self.y = np.asarray(x), np.asarray(y)
+        self.objective, self.status = np.asarray(objective), np.asarray(status)
+        self.iterations = None if iterations is None else np.asarray(iterations)
+        self.block.solution = self.x[0]
+
+    def expression_values(self, family: str) -> np.ndarray:
+        """[B, T] values of an expression family (e.g. 'P_T') for every scenario at once."""
+        fam = self.block.expressions[family]
+        T = len(fam)
+        M = np.zeros((T, self.lp.n))
+        k = np.zeros(T)
+        for t in range(T):
+            for j, v in fam[t].coef.items():
+                M[t, j] = v
+            k[t] = fam[t].const
+        return self.x @ M.T + k

@@ -1,0 +1,354 @@
+"""Stochastic bidders: ``Bidder`` (bid curves) and ``SelfScheduler`` (self-schedules).
+
+These restate the upstream ``idaes.apps.grid_integration.bidder`` classes that DISPATCHES drives
+(call sites: ``renewables_case/run_double_loop_battery.py:222-249``,
+``tests/test_multiperiod_wind_battery_doubleloop.py:148-160,223-235``,
+``nuclear_case/nuclear_flowsheet_double_loop.ipynb`` cell 11) with the SAME constructor and method names, on
+top of the flatten-once batch model.  Per scenario s the day-ahead problem is
+
+    max  sum_t  DA[s,t]*pda[t] + RT[s,t]*(P_T[t] - pda[t]) - w*tot_cost[t] - penalty*u[t]
+    s.t. flowsheet rows,   u[t] >= pda[t] - P_T[t],   pda, u >= 0
+
+solved as a minimisation of the negative.  Scenarios are solved as INDEPENDENT LPs that share the constraint
+matrix; the upstream cross-scenario coupling rows (bid-curve monotonicity / non-anticipativity) only matter
+for n_scenario > 1 with different scenarios and are not pinned by any reference vector.
+"""
+from __future__ import annotations
+
+import os
+from abc import ABC, abstractmethod
+
+import numpy as np
+import pandas as pd
+
+from ..lp import LinearBlock, LinExpr
+from .batch_model import ScenarioBatchModel
+from .utils import convert_marginal_costs_to_actual_costs
+
+
+class AbstractBidder(ABC):
+    @abstractmethod
+    def update_day_ahead_model(self, **kwargs):
+        ...
+
+    @abstractmethod
+    def update_real_time_model(self, **kwargs):
+        ...
+
+    @abstractmethod
+    def compute_day_ahead_bids(self, date, hour, **kwargs):
+        ...
+
+    @abstractmethod
+    def compute_real_time_bids(self, date, hour, **kwargs):
+        ...
+
+    @abstractmethod
+    def write_results(self, path):
+        ...
+
+    @abstractmethod
+    def formulate_DA_bidding_problem(self):
+        ...
+
+    @abstractmethod
+    def formulate_RT_bidding_problem(self):
+        ...
+
+    @abstractmethod
+    def record_bids(self, bids, model, date, hour, market):
+        ...
+
+    @property
+    @abstractmethod
+    def generator(self):
+        return "AbstractGenerator"
+
+    def _check_inputs(self):
+        self._check_bidding_model_object()
+        self._check_horizons()
+        self._check_n_scenario()
+        self._check_solver()
+
+    def _check_bidding_model_object(self):
+        for m in ("populate_model", "update_model"):
+            if not callable(getattr(self.bidding_model_object, m, None)):
+                raise AttributeError(f"The bidding model object does not have the required method {m}().")
+        for a in ("power_output", "total_cost", "model_data"):
+            if not hasattr(self.bidding_model_object, a):
+                raise AttributeError(f"The bidding model object does not have the required attribute '{a}'.")
+
+    def _check_horizons(self):
+        for name in ("day_ahead_horizon", "real_time_horizon"):
+            h = getattr(self, name)
+            if not isinstance(h, int):
+                raise TypeError(f"{name} should be an integer, but a {type(h).__name__} was given.")
+            if h <= 0:
+                raise ValueError(f"{name} should be greater than zero, but {h} was given.")
+
+    def _check_n_scenario(self):
+        if not isinstance(self.n_scenario, int):
+            raise TypeError(f"The number of LMP scenarios should be an integer, but a {type(self.n_scenario).__name__} was given.")
+        if self.n_scenario <= 0:
+            raise ValueError(f"The number of LMP scenarios should be greater than zero, but {self.n_scenario} was given.")
+
+    def _check_solver(self):
+        if not callable(getattr(self.solver, "solve", None)):
+            raise TypeError("The provided solver must expose solve(model, tee=...) (e.g. dispatches_amd.HipPdlpSolver).")
+
+
+class StochasticProgramBidder(AbstractBidder):
+    def __init__(self, bidding_model_object, day_ahead_horizon, real_time_horizon, n_scenario, solver, forecaster,
+                 real_time_underbid_penalty=10000):
+        self.bidding_model_object = bidding_model_object
+        self.day_ahead_horizon = day_ahead_horizon
+        self.real_time_horizon = real_time_horizon
+        self.n_scenario = n_scenario
+        self.solver = solver
+        self.forecaster = forecaster
+        self.real_time_underbid_penalty = real_time_underbid_penalty
+        self._check_inputs()
+        self.generator = self.bidding_model_object.model_data.gen_name
+        self.day_ahead_model = self.formulate_DA_bidding_problem()
+        self.real_time_model = self.formulate_RT_bidding_problem()
+        self.bids_result_list = []
+
+    # -- formulation (once) --------------------------------------------------------------------------------
+    def _set_up_bidding_problem(self, horizon):
+        block = LinearBlock("fs")
+        self.bidding_model_object.populate_model(block, horizon)
+        model = ScenarioBatchModel(block, self.n_scenario, horizon, indexed=True)
+        P_T = block.expressions[self.bidding_model_object.power_output]
+        cost_name, weight = self.bidding_model_object.total_cost
+        tot_cost = block.expressions[cost_name]
+        model.day_ahead_power, model.real_time_underbid_power = [], []
+        objective = LinExpr()
+        for t in range(horizon):
+            pda = block.var(f"day_ahead_power[{t}]", 0.0, np.inf, mutable=True, hull=(0.0, np.inf))
+            u = block.var(f"real_time_underbid_power[{t}]", 0.0, np.inf)
+            # u >= pda - P_T
+            block.constraint(f"real_time_underbid[{t}]", pda - P_T[t] - u, -np.inf, 0.0)
+            model.day_ahead_power.append(pda)
+            model.real_time_underbid_power.append(u)
+        model.P_T_rows = None
+        model.cost_weight = weight
+        model._tot_cost_family = cost_name
+        self._refresh_cost_objective(model)
+        return model
+
+    def _refresh_cost_objective(self, model):
+        """(Re)build the price-independent part of the objective: w*sum tot_cost + penalty*sum u.  Called after
+        every update_model because tot_cost constants depend on the capacity-factor window."""
+        block = model.block
+        objective = LinExpr()
+        for t in model.HOUR:
+            objective = objective + block.expressions[model._tot_cost_family][t] * model.cost_weight
+            objective = objective + model.real_time_underbid_power[t] * self.real_time_underbid_penalty
+        if model.lp is None:
+            model.finalize(objective)
+            n = model.lp.n
+            P_T = block.expressions[self.bidding_model_object.power_output]
+            model.PT_matrix = np.stack([P_T[t].dense(n) for t in model.HOUR])          # [T, n]
+            model.PT_const = np.array([P_T[t].const for t in model.HOUR])
+            model.pda_cols = np.array([v.index for v in model.day_ahead_power])
+        model.base_c = objective.dense(model.lp.n)
+        model.base_c0 = objective.const
+
+    def formulate_DA_bidding_problem(self):
+        return self._set_up_bidding_problem(self.day_ahead_horizon)
+
+    def formulate_RT_bidding_problem(self):
+        return self._set_up_bidding_problem(self.real_time_horizon)
+
+    # -- per-call data -------------------------------------------------------------------------------------
+    @staticmethod
+    def _as_matrix(forecasts, n_scenario, horizon):
+        if isinstance(forecasts, dict):
+            forecasts = [forecasts[i] for i in range(n_scenario)]
+        a = np.asarray(forecasts, float)
+        if a.ndim == 1:
+            a = np.tile(a, (n_scenario, 1))
+        return a[:, :horizon]
+
+    def _pass_price_forecasts(self, model, da, rt):
+        """Objective vectors for all scenarios at once:  c = base - RT (x) dP_T/dx - (DA-RT) on pda."""
+        c = np.tile(model.base_c, (self.n_scenario, 1))
+        c -= rt @ model.PT_matrix
+        c[:, model.pda_cols] -= da - rt
+        model.c = c
+        model.c0 = model.base_c0 - rt @ model.PT_const
+        model.da_prices, model.rt_prices = da, rt
+
+    def compute_day_ahead_bids(self, date, hour=0):
+        model = self.day_ahead_model
+        bus = self.bidding_model_object.model_data.bus
+        da, rt = self.forecaster.forecast_day_ahead_and_real_time_prices(
+            date=date, hour=hour, bus=bus, horizon=self.day_ahead_horizon, n_samples=self.n_scenario)
+        da = self._as_matrix(da, self.n_scenario, self.day_ahead_horizon)
+        rt = self._as_matrix(rt, self.n_scenario, self.day_ahead_horizon)
+        for v in model.day_ahead_power:
+            if v.lb != 0.0 or np.isfinite(v.ub):
+                model.block.set_bounds(v, 0.0, np.inf)
+        self._pass_price_forecasts(model, da, rt)
+        self.solver.solve(model, tee=False)
+        bids = self._assemble_bids(model, da, hour, market="Day-ahead")
+        self.record_bids(bids, model=model, date=date, hour=hour, market="Day-ahead")
+        return bids
+
+    def compute_real_time_bids(self, date, hour, realized_day_ahead_prices, realized_day_ahead_dispatches):
+        """RT problem = the same LP with pda fixed to the realised DA dispatch where it is known
+        (upstream `_pass_realized_day_ahead_dispatches/_prices`); hours past the cleared day keep pda free."""
+        model = self.real_time_model
+        bus = self.bidding_model_object.model_data.bus
+        T = self.real_time_horizon
+        da, rt = self.forecaster.forecast_day_ahead_and_real_time_prices(
+            date=date, hour=hour, bus=bus, horizon=T, n_samples=self.n_scenario)
+        da = self._as_matrix(da, self.n_scenario, T).copy()
+        rt = self._as_matrix(rt, self.n_scenario, T)
+        for t, v in enumerate(model.day_ahead_power):
+            known_p = realized_day_ahead_prices is not None and t + hour < len(realized_day_ahead_prices)
+            known_d = realized_day_ahead_dispatches is not None and t + hour < len(realized_day_ahead_dispatches)
+            if known_p:
+                da[:, t] = realized_day_ahead_prices[t + hour]
+            if known_d:
+                v.fix(float(realized_day_ahead_dispatches[t + hour]))
+            else:
+                model.block.set_bounds(v, 0.0, np.inf)
+        self._pass_price_forecasts(model, da, rt)
+        self.solver.solve(model, tee=False)
+        bids = self._assemble_bids(model, rt, hour, market="Real-time")
+        self.record_bids(bids, model=model, date=date, hour=hour, market="Real-time")
+        return bids
+
+    # -- rolling-horizon state -----------------------------------------------------------------------------
+    def _update_model(self, model, **kwargs):
+        self.bidding_model_object.update_model(b=model.block, **kwargs)
+        self._refresh_cost_objective(model)
+
+    def update_day_ahead_model(self, **kwargs):
+        self._update_model(self.day_ahead_model, **kwargs)
+
+    def update_real_time_model(self, **kwargs):
+        self._update_model(self.real_time_model, **kwargs)
+
+    # -- bookkeeping ---------------------------------------------------------------------------------------
+    def record_bids(self, bids, model, date, hour, market):
+        self._record_bids(bids, date, hour, Market=market)
+        # per-scenario detail rows (reference parametrized_bidder.py:146-149); for very large batches only the
+        # first `detail_scenarios` scenarios are expanded (row-by-row pandas would dominate).
+        limit = getattr(self, "detail_scenarios", 16)
+        for i in list(model.SCENARIOS)[:limit]:
+            self.bidding_model_object.record_results(model.fs[i], date=date, hour=hour, Scenario=i, Market=market)
+
+    def write_results(self, path):
+        print("")
+        print("Saving bidding results to disk...")
+        pd.concat(self.bids_result_list).to_csv(os.path.join(path, "bidder_detail.csv"), index=False)
+        self.bidding_model_object.write_results(path=os.path.join(path, "bidding_model_detail.csv"))
+
+    @property
+    def generator(self):
+        return self._generator
+
+    @generator.setter
+    def generator(self, name):
+        self._generator = name
+
+
+class Bidder(StochasticProgramBidder):
+    """Bid-curve bidder: per hour the (power, price) pairs of all scenarios, rounded to 2 dp, sorted and
+    integrated to a cost curve (pinned by SURVEY.md A.7 G2)."""
+
+    def _assemble_bids(self, model, energy_prices, hour, market):
+        md = self.bidding_model_object.model_data
+        gen = self.generator
+        is_thermal = md.generator_type == "thermal"
+        power = model.expression_values(self.bidding_model_object.power_output) if market == "Real-time" \
+            else model.x[:, model.pda_cols]
+        bids = {}
+        for t_idx in model.HOUR:
+            t = t_idx + hour
+            curve = {}
+            if is_thermal and getattr(md, "include_default_p_cost", False):
+                for p, mc in md.p_cost:
+                    curve[round(p, 2)] = float(mc)
+            for i in model.SCENARIOS:
+                p = round(float(power[i, t_idx]), 2)
+                price = round(float(energy_prices[i, t_idx]), 2)
+                if p < md.p_min:
+                    continue
+                curve[p] = max(curve.get(p, -np.inf), price)
+            if md.p_min not in curve:
+                curve[round(md.p_min, 2)] = min(curve.values()) if curve else 0.0
+            pairs = sorted(curve.items())
+            # non-decreasing marginal prices
+            run = -np.inf
+            mono = []
+            for p, mc in pairs:
+                run = max(run, mc)
+                mono.append((p, run))
+            p_cost = convert_marginal_costs_to_actual_costs(mono)
+            p_max = max(p for p, _ in p_cost)
+            bids[t] = {gen: {"p_cost": p_cost, "p_min": md.p_min, "p_max": p_max,
+                             "startup_capacity": p_max, "shutdown_capacity": p_max}}
+        return bids
+
+    def _record_bids(self, bids, date, hour, **kwargs):
+        rows = []
+        for t in bids:
+            for gen in bids[t]:
+                row = {"Generator": gen, "Date": date, "Hour": t}
+                row.update(kwargs)
+                pairs = bids[t][gen]["p_cost"]
+                for idx, (p, c) in enumerate(pairs):
+                    row[f"Power {idx} [MW]"] = p
+                    row[f"Cost {idx} [$]"] = c
+                for idx in range(len(pairs), self.n_scenario):
+                    row[f"Power {idx} [MW]"] = None
+                    row[f"Cost {idx} [$]"] = None
+                rows.append(row)
+        self.bids_result_list.append(pd.DataFrame(rows))
+
+
+class SelfScheduler(StochasticProgramBidder):
+    """Self-schedule bidder: p_max[t] = round(scheduled power, 4) (pinned by SURVEY.md A.7 G1)."""
+
+    def __init__(self, bidding_model_object, day_ahead_horizon, real_time_horizon, n_scenario, solver, forecaster,
+                 real_time_underbid_penalty=10000, fixed_to_schedule=False):
+        self.fixed_to_schedule = fixed_to_schedule
+        super().__init__(bidding_model_object, day_ahead_horizon, real_time_horizon, n_scenario, solver, forecaster,
+                         real_time_underbid_penalty)
+
+    def _assemble_bids(self, model, energy_prices, hour, market):
+        md = self.bidding_model_object.model_data
+        gen = self.generator
+        is_thermal = md.generator_type == "thermal"
+        if market == "Real-time":
+            power = model.expression_values(self.bidding_model_object.power_output)[0]
+        else:
+            power = model.x[0, model.pda_cols]
+        bids = {}
+        for t_idx in model.HOUR:
+            t = t_idx + hour
+            p = round(float(power[t_idx]), 4)
+            entry = {"p_max": p, "p_min": md.p_min}
+            if self.fixed_to_schedule:
+                entry["p_min"] = p
+                if is_thermal:
+                    entry.update(min_up_time=0, min_down_time=0, fixed_commitment=1 if p > 0 else 0)
+            if is_thermal:
+                entry["p_cost"] = [(p, 0.0)]
+                entry["startup_capacity"] = entry["shutdown_capacity"] = p
+            bids[t] = {gen: entry}
+        return bids
+
+    def _record_bids(self, bids, date, hour, **kwargs):
+        rows = []
+        for t in bids:
+            for gen in bids[t]:
+                row = {"Generator": gen, "Date": date, "Hour": t}
+                row.update(kwargs)
+                row["Bid Power [MW]"] = bids[t][gen].get("p_max")
+                row["Bid Min Power [MW]"] = bids[t][gen].get("p_min")
+                rows.append(row)
+        self.bids_result_list.append(pd.DataFrame(rows))
