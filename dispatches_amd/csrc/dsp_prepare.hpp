@@ -1,0 +1,151 @@
+// dsp_prepare.hpp — host-side, once-per-(flowsheet, horizon) preparation of the shared problem data:
+//   * diagonal preconditioner  (Ruiz inf-norm equilibration, then Pock-Chambolle alpha = 1)
+//   * step size eta = step_scale / ||D_r A D_c||_2   (power iteration)
+//   * lane-major ELL storage of the scaled A (rows) and A^T (columns) for a 64-lane wave that owns
+//     columns {lane, lane+64, ...} and rows {lane, lane+64, ...}; vectors longer than the ELL width go to a
+//     "long vector" list that the whole wave reduces cooperatively.
+// Everything the reference delegates to CBC / IPOPT presolve+scaling lives here; there is no reference source
+// for it (K5), the algorithm is PDLP's published preconditioning.
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <numeric>
+#include <vector>
+
+namespace dsp {
+
+struct HostCSR {
+  int m = 0, n = 0;
+  std::vector<int32_t> ptr, idx;
+  std::vector<double> val;
+  int64_t nnz() const { return (int64_t)idx.size(); }
+};
+
+inline HostCSR transpose(const HostCSR &A) {
+  HostCSR T;
+  T.m = A.n; T.n = A.m;
+  T.ptr.assign(A.n + 1, 0);
+  for (int32_t j : A.idx) T.ptr[j + 1]++;
+  for (int j = 0; j < A.n; ++j) T.ptr[j + 1] += T.ptr[j];
+  T.idx.resize(A.idx.size()); T.val.resize(A.val.size());
+  std::vector<int32_t> pos(T.ptr.begin(), T.ptr.end() - 1);
+  for (int i = 0; i < A.m; ++i)
+    for (int p = A.ptr[i]; p < A.ptr[i + 1]; ++p) {
+      int q = pos[A.idx[p]]++;
+      T.idx[q] = i; T.val[q] = A.val[p];
+    }
+  return T;
+}
+
+// Ruiz (inf-norm, `iters` passes) followed by Pock-Chambolle (alpha = 1).  A is scaled in place:
+// A <- diag(dr) A diag(dc).
+inline void equilibrate(HostCSR &A, int ruiz_iters, std::vector<double> &dr, std::vector<double> &dc) {
+  dr.assign(A.m, 1.0); dc.assign(A.n, 1.0);
+  std::vector<double> rs(A.m), cs(A.n);
+  auto apply = [&]() {
+    for (int i = 0; i < A.m; ++i)
+      for (int p = A.ptr[i]; p < A.ptr[i + 1]; ++p) A.val[p] *= rs[i] * cs[A.idx[p]];
+    for (int i = 0; i < A.m; ++i) dr[i] *= rs[i];
+    for (int j = 0; j < A.n; ++j) dc[j] *= cs[j];
+  };
+  for (int it = 0; it < ruiz_iters; ++it) {
+    std::fill(rs.begin(), rs.end(), 0.0); std::fill(cs.begin(), cs.end(), 0.0);
+    for (int i = 0; i < A.m; ++i)
+      for (int p = A.ptr[i]; p < A.ptr[i + 1]; ++p) {
+        double a = std::fabs(A.val[p]);
+        rs[i] = std::max(rs[i], a); cs[A.idx[p]] = std::max(cs[A.idx[p]], a);
+      }
+    for (auto &v : rs) v = v > 0 ? 1.0 / std::sqrt(v) : 1.0;
+    for (auto &v : cs) v = v > 0 ? 1.0 / std::sqrt(v) : 1.0;
+    apply();
+  }
+  // Pock-Chambolle, alpha = 1: row scale 1/sqrt(sum_j |a_ij|), column scale 1/sqrt(sum_i |a_ij|)
+  std::fill(rs.begin(), rs.end(), 0.0); std::fill(cs.begin(), cs.end(), 0.0);
+  for (int i = 0; i < A.m; ++i)
+    for (int p = A.ptr[i]; p < A.ptr[i + 1]; ++p) {
+      double a = std::fabs(A.val[p]);
+      rs[i] += a; cs[A.idx[p]] += a;
+    }
+  for (auto &v : rs) v = v > 0 ? 1.0 / std::sqrt(v) : 1.0;
+  for (auto &v : cs) v = v > 0 ? 1.0 / std::sqrt(v) : 1.0;
+  apply();
+}
+
+inline double spectral_norm(const HostCSR &A, const HostCSR &AT, int iters = 300) {
+  if (A.nnz() == 0) return 1.0;
+  std::vector<double> v(A.n), u(A.m);
+  uint64_t s = 0x9E3779B97F4A7C15ull;                       // fixed-seed xorshift start vector
+  for (auto &x : v) { s ^= s << 13; s ^= s >> 7; s ^= s << 17; x = (double)(s >> 11) / 9007199254740992.0 - 0.5; }
+  double nrm = 0;
+  auto normalise = [&](std::vector<double> &w) {
+    double t = 0; for (double x : w) t += x * x; t = std::sqrt(t);
+    if (t > 0) for (double &x : w) x /= t;
+    return t;
+  };
+  normalise(v);
+  for (int it = 0; it < iters; ++it) {
+    for (int i = 0; i < A.m; ++i) { double t = 0; for (int p = A.ptr[i]; p < A.ptr[i + 1]; ++p) t += A.val[p] * v[A.idx[p]]; u[i] = t; }
+    for (int j = 0; j < AT.m; ++j) { double t = 0; for (int p = AT.ptr[j]; p < AT.ptr[j + 1]; ++p) t += AT.val[p] * u[AT.idx[p]]; v[j] = t; }
+    nrm = std::sqrt(normalise(v));                           // ||A^T A v|| -> sigma_max^2
+  }
+  return nrm > 0 ? nrm : 1.0;
+}
+
+// Lane-major ELL of a CSR whose "rows" are the vectors owned by lanes: vector v is owned by lane v % 64,
+// slot v / 64.  Entry (slot, e, lane) lives at ((slot*W + e)*64 + lane).  Vectors with more than W entries are
+// moved WHOLE to the long list (their ELL entries stay zero).
+struct LaneELL {
+  int slots = 0, W = 0;
+  std::vector<double> val;       // [slots*W*64]
+  std::vector<uint16_t> idx;     // [slots*W*64] element index into the gathered vector
+  // long vectors
+  std::vector<int32_t> long_owner;   // vector id
+  std::vector<int32_t> long_start;   // offset into tail arrays (multiple of 64)
+  std::vector<int32_t> long_len;     // padded length (multiple of 64)
+  std::vector<double> tail_val;
+  std::vector<uint16_t> tail_idx;
+};
+
+inline LaneELL build_lane_ell(const HostCSR &M, int slots) {
+  LaneELL E;
+  E.slots = slots;
+  std::vector<int> len(M.m);
+  int maxlen = 0;
+  for (int v = 0; v < M.m; ++v) { len[v] = M.ptr[v + 1] - M.ptr[v]; maxlen = std::max(maxlen, len[v]); }
+  // cost model: per-iteration lane work = W*slots (ELL) + sum over long vectors (ceil(len/64) + reduction ~8)
+  int bestW = std::max(maxlen, 1); double bestCost = 1e300;
+  for (int W = 1; W <= std::max(maxlen, 1); ++W) {
+    double cost = (double)W * slots;
+    int nlong = 0;
+    for (int v = 0; v < M.m; ++v) if (len[v] > W) { cost += (len[v] + 63) / 64 + 8; ++nlong; }
+    if (nlong > 32) continue;
+    if (cost < bestCost) { bestCost = cost; bestW = W; }
+  }
+  E.W = bestW;
+  E.val.assign((size_t)slots * E.W * 64, 0.0);
+  E.idx.assign((size_t)slots * E.W * 64, 0);
+  for (int v = 0; v < M.m; ++v) {
+    int lane = v & 63, slot = v >> 6;
+    if (len[v] <= E.W) {
+      for (int e = 0; e < len[v]; ++e) {
+        size_t at = ((size_t)(slot * E.W + e)) * 64 + lane;
+        E.val[at] = M.val[M.ptr[v] + e];
+        E.idx[at] = (uint16_t)M.idx[M.ptr[v] + e];
+      }
+    } else {
+      int padded = ((len[v] + 63) / 64) * 64;
+      E.long_owner.push_back(v);
+      E.long_start.push_back((int32_t)E.tail_val.size());
+      E.long_len.push_back(padded);
+      for (int e = 0; e < padded; ++e) {
+        E.tail_val.push_back(e < len[v] ? M.val[M.ptr[v] + e] : 0.0);
+        E.tail_idx.push_back(e < len[v] ? (uint16_t)M.idx[M.ptr[v] + e] : (uint16_t)0);
+      }
+    }
+  }
+  return E;
+}
+
+}  // namespace dsp

@@ -1,0 +1,260 @@
+"""ctypes binding of libdsp_hip.so (C ABI: include/dsp_hip.h) + the solver object the Bidder / Tracker call.
+
+``HipPdlpSolver().solve(model, tee=False)`` is the drop-in for the reference's ``pyo.SolverFactory(...).solve``
+(SURVEY.md 8(b)-4): it uploads the flattened LP once per model (``dsp_create``), then per call only the dense
+per-scenario vectors, runs the fused HIP PDLP kernel and writes x / y / objective / status back into the model.
+PyTorch is used only as the device-memory container and stream provider.  There is NO CPU fallback: a missing
+library or GPU raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+import os
+from typing import Optional
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libdsp_hip.so")
+_lib = None
+
+
+class DspOptions(C.Structure):
+    _fields_ = [("eps_rel", C.c_double), ("max_iter", C.c_int32), ("check_every", C.c_int32),
+                ("restart_sufficient", C.c_double), ("restart_necessary", C.c_double),
+                ("restart_artificial", C.c_double), ("pid_kp", C.c_double), ("max_dlog_weight", C.c_double),
+                ("step_scale", C.c_double), ("ruiz_iters", C.c_int32), ("waves_per_block", C.c_int32)]
+
+
+class DspStats(C.Structure):
+    _fields_ = [("total_iterations", C.c_int64), ("max_iterations", C.c_int32), ("n_optimal", C.c_int32),
+                ("grid_blocks", C.c_int32), ("block_threads", C.c_int32), ("lds_bytes", C.c_int32),
+                ("cols_per_lane", C.c_int32), ("rows_per_lane", C.c_int32), ("kernel_ms", C.c_float)]
+
+
+class DspLpDesc(C.Structure):
+    _fields_ = [("n", C.c_int32), ("m", C.c_int32), ("nnz", C.c_int64),
+                ("A_rowptr", C.POINTER(C.c_int32)), ("A_colidx", C.POINTER(C.c_int32)),
+                ("A_val", C.POINTER(C.c_double))]
+
+
+EXPORTED_SYMBOLS = ("dsp_default_options", "dsp_create", "dsp_solve", "dsp_spmv_step", "dsp_get_dims",
+                    "dsp_get_scaling", "dsp_destroy", "dsp_strerror", "dsp_last_hip_error", "dsp_version")
+
+
+def load_library(path: Optional[str] = None):
+    """Load libdsp_hip.so (after torch, so both share one HIP runtime).  Raises if it has not been built."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    path = path or _LIB_PATH
+    if not os.path.exists(path):
+        raise RuntimeError(f"{path} not found: build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()')")
+    try:
+        import torch  # noqa: F401  (loads libamdhip64 first)
+    except Exception:
+        pass
+    lib = C.CDLL(path)
+    vp, i32, i64, dp = C.c_void_p, C.c_int32, C.c_int64, C.c_void_p
+    lib.dsp_default_options.argtypes = [C.POINTER(DspOptions)]
+    lib.dsp_default_options.restype = None
+    lib.dsp_create.argtypes = [C.POINTER(DspLpDesc), C.c_int, C.POINTER(DspOptions), C.POINTER(vp)]
+    lib.dsp_create.restype = C.c_int
+    lib.dsp_solve.argtypes = [vp, i32, dp, i64, dp, i64, dp, i64, dp, i64, dp, i64, dp, dp, C.POINTER(DspOptions),
+                              dp, dp, dp, dp, dp, C.POINTER(DspStats), C.c_int, vp]
+    lib.dsp_solve.restype = C.c_int
+    lib.dsp_spmv_step.argtypes = [vp, i32, dp, dp, dp, dp, vp]
+    lib.dsp_spmv_step.restype = C.c_int
+    lib.dsp_get_dims.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i64)]
+    lib.dsp_get_dims.restype = C.c_int
+    lib.dsp_get_scaling.argtypes = [vp, dp, dp, C.POINTER(C.c_double)]
+    lib.dsp_get_scaling.restype = C.c_int
+    lib.dsp_destroy.argtypes = [vp]
+    lib.dsp_destroy.restype = C.c_int
+    lib.dsp_strerror.argtypes = [C.c_int]
+    lib.dsp_strerror.restype = C.c_char_p
+    lib.dsp_last_hip_error.restype = C.c_int
+    lib.dsp_version.restype = C.c_int
+    if path == _LIB_PATH:
+        _lib = lib
+    return lib
+
+
+class DspError(RuntimeError):
+    pass
+
+
+def _check(lib, rc, what):
+    if rc != 0:
+        raise DspError(f"{what} failed: {lib.dsp_strerror(rc).decode()} (code {rc}, hip error {lib.dsp_last_hip_error()})")
+
+
+def default_options(**overrides) -> DspOptions:
+    lib = load_library()
+    o = DspOptions()
+    lib.dsp_default_options(C.byref(o))
+    for k, v in overrides.items():
+        if not hasattr(o, k):
+            raise TypeError(f"unknown solver option {k!r}")
+        setattr(o, k, v)
+    return o
+
+
+class DeviceLP:
+    """Device-resident shared data of one flattened LP (wraps a dsp_handle)."""
+
+    def __init__(self, lp, device: int = 0, options: Optional[DspOptions] = None):
+        import torch
+
+        if not torch.cuda.is_available():
+            raise DspError("no MI355X visible: the dispatch solver has no CPU path")
+        self.lib = load_library()
+        self.lp = lp
+        self.device = device
+        self._rowptr = np.ascontiguousarray(lp.indptr, np.int32)
+        self._colidx = np.ascontiguousarray(lp.indices, np.int32)
+        self._val = np.ascontiguousarray(lp.data, np.float64)
+        desc = DspLpDesc(lp.n, lp.m, int(self._rowptr[-1]),
+                         self._rowptr.ctypes.data_as(C.POINTER(C.c_int32)),
+                         self._colidx.ctypes.data_as(C.POINTER(C.c_int32)),
+                         self._val.ctypes.data_as(C.POINTER(C.c_double)))
+        h = C.c_void_p()
+        torch.cuda.set_device(device)
+        _check(self.lib, self.lib.dsp_create(C.byref(desc), device, C.byref(options) if options else None, C.byref(h)),
+               "dsp_create")
+        self.handle = h
+        self.last_stats: Optional[DspStats] = None
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.dsp_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def scaling(self):
+        dr = np.zeros(self.lp.m)
+        dc = np.zeros(self.lp.n)
+        eta = C.c_double()
+        _check(self.lib, self.lib.dsp_get_scaling(self.handle, dr.ctypes.data, dc.ctypes.data, C.byref(eta)), "dsp_get_scaling")
+        return dr, dc, eta.value
+
+    @staticmethod
+    def _ptr_stride(t, width):
+        """(device pointer, scenario stride) of a [B,width] (dense) or [width] (broadcast) tensor, or (None, 0)."""
+        if t is None:
+            return None, 0
+        assert t.is_cuda and t.dtype.is_floating_point and t.element_size() == 8 and t.is_contiguous()
+        if t.dim() == 1:
+            assert t.shape[0] == width
+            return t.data_ptr(), 0
+        assert t.shape[1] == width
+        return t.data_ptr(), width
+
+    def solve(self, B, c, lb=None, ub=None, rlo=None, rhi=None, x0=None, y0=None, options=None, out=None,
+              sync_stats=True):
+        """All arguments are CUDA(HIP) float64 torch tensors; returns dict of output tensors (+ stats)."""
+        import torch
+
+        n, m = self.lp.n, self.lp.m
+        dev = torch.device("cuda", self.device)
+        if out is None:
+            out = dict(x=torch.empty((B, n), dtype=torch.float64, device=dev),
+                       y=torch.empty((B, max(m, 1)), dtype=torch.float64, device=dev),
+                       obj=torch.empty(B, dtype=torch.float64, device=dev),
+                       status=torch.empty(B, dtype=torch.int32, device=dev),
+                       iters=torch.empty(B, dtype=torch.int32, device=dev))
+        pc, sc = self._ptr_stride(c, n)
+        plb, slb = self._ptr_stride(lb, n)
+        pub, sub = self._ptr_stride(ub, n)
+        prl, srl = self._ptr_stride(rlo, m)
+        prh, srh = self._ptr_stride(rhi, m)
+        stats = DspStats()
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        rc = self.lib.dsp_solve(self.handle, B, pc, sc, plb, slb, pub, sub, prl, srl, prh, srh,
+                                x0.data_ptr() if x0 is not None else None, y0.data_ptr() if y0 is not None else None,
+                                C.byref(options) if options is not None else None,
+                                out["x"].data_ptr(), out["y"].data_ptr(), out["obj"].data_ptr(),
+                                out["status"].data_ptr(), out["iters"].data_ptr(), C.byref(stats),
+                                1 if sync_stats else 0, C.c_void_p(stream))
+        _check(self.lib, rc, "dsp_solve")
+        self.last_stats = stats
+        out["stats"] = stats
+        return out
+
+    def spmv_step(self, X, Y, AX=None, ATY=None):
+        import torch
+
+        B = X.shape[0]
+        AX = torch.empty((B, self.lp.m), dtype=torch.float64, device=X.device) if AX is None else AX
+        ATY = torch.empty((B, self.lp.n), dtype=torch.float64, device=X.device) if ATY is None else ATY
+        stream = torch.cuda.current_stream(X.device).cuda_stream
+        _check(self.lib, self.lib.dsp_spmv_step(self.handle, B, X.data_ptr(), Y.data_ptr(), AX.data_ptr(),
+                                                ATY.data_ptr(), C.c_void_p(stream)), "dsp_spmv_step")
+        return AX, ATY
+
+
+class HipPdlpSolver:
+    """Solver object for Bidder / SelfScheduler / Tracker: `solver.solve(model, tee=False)`.
+
+    Options (keyword arguments) are the fields of ``dsp_options`` (include/dsp_hip.h), e.g. ``eps_rel=1e-9``.
+    """
+
+    def __init__(self, device: int = 0, **options):
+        self.device = device
+        self._option_overrides = options
+        self.options = None
+        self.last_stats = None
+
+    def available(self, exception_flag=False):
+        try:
+            import torch
+            load_library()
+            ok = torch.cuda.is_available()
+        except Exception:
+            ok = False
+        if not ok and exception_flag:
+            raise DspError("HIP dispatch solver unavailable (library not built or no GPU)")
+        return ok
+
+    def _device_lp(self, model) -> DeviceLP:
+        if self.options is None:
+            self.options = default_options(**self._option_overrides)
+        h = model.solve_handle
+        if h is None or h.lp is not model.lp:
+            h = DeviceLP(model.lp, self.device, self.options)
+            model.solve_handle = h
+        return h
+
+    def solve(self, model, tee=False, warm_start=False):
+        import torch
+
+        from .workflow.batch_model import SolveResults
+
+        dlp = self._device_lp(model)
+        dev = torch.device("cuda", self.device)
+        B = model.n_scenario
+        lb, ub, rlo, rhi = model.scenario_bounds()
+        up = lambda a: torch.as_tensor(np.ascontiguousarray(a, np.float64)).to(dev, non_blocking=False)
+        x0 = y0 = None
+        if warm_start and model.x is not None and model.y is not None and model.x.shape == (B, model.lp.n):
+            x0, y0 = up(model.x), up(model.y)
+        out = dlp.solve(B, up(model.c), up(lb), up(ub), up(rlo) if model.lp.m else None,
+                        up(rhi) if model.lp.m else None, x0=x0, y0=y0, options=self.options)
+        st = out["stats"]
+        self.last_stats = st
+        status = out["status"].cpu().numpy()
+        model.store_solution(out["x"].cpu().numpy(), out["y"].cpu().numpy()[:, :model.lp.m],
+                             out["obj"].cpu().numpy() + model.c0, status, out["iters"].cpu().numpy())
+        if tee:
+            print(f"[dsp_hip] B={B} n={model.lp.n} m={model.lp.m} nnz={model.lp.nnz} optimal={st.n_optimal}/{B} "
+                  f"iters(sum/max)={st.total_iterations}/{st.max_iterations} kernel={st.kernel_ms:.3f} ms "
+                  f"grid={st.grid_blocks}x{st.block_threads} lds={st.lds_bytes}B")
+        all_ok = bool((status == 0).all())
+        return SolveResults("ok" if all_ok else "warning", "optimal" if all_ok else "maxIterations",
+                            iterations=int(st.total_iterations), kernel_ms=float(st.kernel_ms))

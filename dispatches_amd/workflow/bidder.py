@@ -177,6 +177,8 @@ class StochasticProgramBidder(AbstractBidder):
         c[:, model.pda_cols] -= da - rt
         model.c = c
         model.c0 = model.base_c0 - rt @ model.PT_const
+        if getattr(model, "c0_shift", None) is not None:      # per-scenario objective constants (scenarios.py)
+            model.c0 = model.c0 + model.c0_shift
         model.da_prices, model.rt_prices = da, rt
 
     def compute_day_ahead_bids(self, date, hour=0):

@@ -1,0 +1,128 @@
+/* dsp_hip.h — C ABI of the MI355X batched dispatch-LP solver (libdsp_hip.so).
+ *
+ * Drop-in seam: the reference has no FFI; its solve boundary is the Python call
+ *     solver.solve(model, tee=...)                       (UPSTREAM pyomo SolverFactory object)
+ * made from Bidder.compute_day_ahead_bids / compute_real_time_bids and Tracker.track_market_dispatch
+ * (reference call sites: dispatches/case_studies/renewables_case/run_double_loop_battery.py:123,222-285,
+ *  dispatches/case_studies/renewables_case/tests/test_multiperiod_wind_battery_doubleloop.py:47,81,140,160,235,
+ *  dispatches/workflow/parametrized_bidder.py:73-119).  Where Pyomo writes an LP/NL file and spawns
+ * cbc / ipopt, a binding of this library hands over the flattened standard form
+ *
+ *     min c.x   s.t.  row_lb <= A x <= row_ub,   var_lb <= x <= var_ub          (one scenario)
+ *
+ * once (dsp_create: the CSR of A shared by every scenario) and then, per call, B dense per-scenario vectors
+ * (dsp_solve).  Plain C, opaque handle, caller-owned buffers, int return codes, stream-ordered.
+ * All per-scenario pointers passed to dsp_solve / dsp_spmv_step are DEVICE pointers (e.g. torch.Tensor.data_ptr());
+ * everything in dsp_lp_desc is a HOST pointer that is copied during dsp_create.
+ */
+#ifndef DSP_HIP_H
+#define DSP_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DSP_VERSION 1
+
+/* return codes (0 = ok, < 0 = API misuse / HIP error; text via dsp_strerror) */
+#define DSP_OK                 0
+#define DSP_ERR_INVALID       -1   /* bad argument (NULL, negative size, unsorted CSR, ...)            */
+#define DSP_ERR_TOO_LARGE     -2   /* one scenario does not fit the LDS-resident kernel               */
+#define DSP_ERR_HIP           -3   /* a HIP runtime call failed (dsp_last_hip_error())                */
+#define DSP_ERR_NO_DEVICE     -4   /* no gfx950 device visible                                        */
+#define DSP_ERR_ALLOC         -5
+
+/* per-scenario termination status written to status[B] */
+#define DSP_STATUS_OPTIMAL            0
+#define DSP_STATUS_ITERATION_LIMIT    1
+#define DSP_STATUS_PRIMAL_INFEASIBLE  2   /* reserved: not detected by v1 (dispatch LPs carry slack columns) */
+#define DSP_STATUS_DUAL_INFEASIBLE    3   /* reserved */
+#define DSP_STATUS_NUMERICAL          4   /* NaN / Inf met in the iteration                                  */
+
+typedef struct dsp_handle dsp_handle;
+
+/* One scenario's LP template.  Replaces the model Pyomo would write to disk on every solve. */
+typedef struct dsp_lp_desc {
+  int32_t n;                 /* columns                                  */
+  int32_t m;                 /* rows                                     */
+  int64_t nnz;               /* nonzeros of A                            */
+  const int32_t *A_rowptr;   /* [m+1]  CSR, column indices ascending within a row */
+  const int32_t *A_colidx;   /* [nnz]  */
+  const double  *A_val;      /* [nnz]  */
+} dsp_lp_desc;
+
+/* Solver options (restarted, reflected Halpern PDHG).  Zero-initialise then call
+ * dsp_default_options() to get the defaults. */
+typedef struct dsp_options {
+  double  eps_rel;           /* relative KKT tolerance (primal, dual, gap)          default 1e-9  */
+  int32_t max_iter;          /* iteration limit per scenario                        default 200000 */
+  int32_t check_every;       /* restart / termination test period                   default 32    */
+  double  restart_sufficient;/* beta_1: restart when r <= beta_1 r0                 default 0.2   */
+  double  restart_necessary; /* beta_2: ... or r <= beta_2 r0 and r increased       default 0.8   */
+  double  restart_artificial;/* beta_3: ... or k >= beta_3 * total iterations       default 0.36  */
+  double  pid_kp;            /* proportional gain of the primal-weight controller   default 0.7   */
+  double  max_dlog_weight;   /* clamp on |delta log(primal weight)| per restart     default log(30) */
+  double  step_scale;        /* eta = step_scale / ||A_scaled||_2                   default 0.998 */
+  int32_t ruiz_iters;        /* Ruiz passes before Pock-Chambolle (create time)     default 10    */
+  int32_t waves_per_block;   /* scenarios per workgroup (1 wave each); 0 = auto                    */
+} dsp_options;
+
+/* Aggregate statistics of one dsp_solve call (filled after the call's stream work completes when
+ * `sync_stats` is non-zero; otherwise only the launch geometry is filled). */
+typedef struct dsp_stats {
+  int64_t total_iterations;  /* sum over scenarios                                  */
+  int32_t max_iterations;    /* slowest scenario                                    */
+  int32_t n_optimal;         /* scenarios with status 0                             */
+  int32_t grid_blocks;       /* launch geometry                                     */
+  int32_t block_threads;
+  int32_t lds_bytes;         /* dynamic LDS per block                               */
+  int32_t cols_per_lane;     /* CPL template parameter chosen                       */
+  int32_t rows_per_lane;     /* RPL template parameter chosen                       */
+  float   kernel_ms;         /* hipEvent time of the solve kernel on `stream` (sync_stats only) */
+} dsp_stats;
+
+void dsp_default_options(dsp_options *opt);
+
+/* Build the shared, device-resident problem data for one (flowsheet, horizon): diagonal preconditioner
+ * (Ruiz + Pock-Chambolle), scaled A in ELL + long-vector form for A and A^T, step size.  `opt` may be NULL. */
+int dsp_create(const dsp_lp_desc *desc, int device, const dsp_options *opt, dsp_handle **out);
+
+/* Solve B scenarios.  c is required; every other input may be NULL (= no bound: -inf / +inf) and each has its
+ * own scenario stride in ELEMENTS: stride 0 broadcasts one template vector to all scenarios, stride n (or m)
+ * is a dense [B][n] array.  x0 / y0 (optional warm start, may be NULL) and x / y use dense strides n / m.
+ *   obj[B]    c.x at the returned x (the caller adds its own objective constant)
+ *   status[B] DSP_STATUS_*        iters[B] iterations used (may be NULL)
+ * hipStream: a hipStream_t (NULL = default stream).  The call enqueues work and returns; if `stats` is non-NULL
+ * and sync_stats != 0 it synchronises the stream and fills the statistics. */
+int dsp_solve(dsp_handle *h, int32_t B,
+              const double *c, int64_t c_stride,
+              const double *var_lb, int64_t var_lb_stride,
+              const double *var_ub, int64_t var_ub_stride,
+              const double *row_lb, int64_t row_lb_stride,
+              const double *row_ub, int64_t row_ub_stride,
+              const double *x0, const double *y0,
+              const dsp_options *opt,
+              double *x, double *y, double *obj, int32_t *status, int32_t *iters,
+              dsp_stats *stats, int sync_stats, void *hipStream);
+
+/* The PDLP SpMV step in streaming form (vectors in HBM): AX[B][m] = A X[b],  ATY[B][n] = A^T Y[b] with the
+ * UNSCALED A.  This is the kernel the HBM roofline of SURVEY.md 8(d) is quoted on
+ * (bytes = B*2*8*(n+m) + shared CSR), and the building block for LPs too large for the LDS-resident solve. */
+int dsp_spmv_step(dsp_handle *h, int32_t B, const double *X, const double *Y, double *AX, double *ATY,
+                  void *hipStream);
+
+/* Introspection */
+int dsp_get_dims(const dsp_handle *h, int32_t *n, int32_t *m, int64_t *nnz);
+int dsp_get_scaling(const dsp_handle *h, double *row_scale /*[m]*/, double *col_scale /*[n]*/, double *step_eta);
+
+int dsp_destroy(dsp_handle *h);
+const char *dsp_strerror(int code);
+int dsp_last_hip_error(void);
+int dsp_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DSP_HIP_H */

@@ -1,0 +1,58 @@
+"""CPU-side checks of the C-ABI library: it loads, exports every symbol include/dsp_hip.h declares, and its
+option defaults are sane.  No compute call is made without a GPU (dsp_create must refuse cleanly)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import __graft_entry__ as g
+    g.build()
+    from dispatches_amd import hip_solver
+    return hip_solver.load_library()
+
+
+def test_header_symbols_exported(lib):
+    hdr = open(os.path.join(ROOT, "include", "dsp_hip.h")).read()
+    declared = set(re.findall(r"\b(dsp_[a-z_]+)\s*\(", hdr))
+    assert declared >= {"dsp_create", "dsp_solve", "dsp_spmv_step", "dsp_destroy", "dsp_strerror"}
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/dsp_hip.h but not exported"
+
+
+def test_default_options(lib):
+    from dispatches_amd import hip_solver
+    o = hip_solver.default_options()
+    assert o.eps_rel == 1e-9 and o.check_every == 32 and o.max_iter == 200000
+    with pytest.raises(TypeError):
+        hip_solver.default_options(not_an_option=1)
+    assert lib.dsp_strerror(0) == b"ok" and b"invalid" in lib.dsp_strerror(-1)
+
+
+def test_create_rejects_bad_input_without_gpu(lib):
+    from dispatches_amd.hip_solver import DspLpDesc
+    h = C.c_void_p()
+    assert lib.dsp_create(None, 0, None, C.byref(h)) == -1
+    rowptr = np.array([0, 2], np.int32); col = np.array([1, 0], np.int32); val = np.array([1.0, 2.0])
+    d = DspLpDesc(2, 1, 2, rowptr.ctypes.data_as(C.POINTER(C.c_int32)), col.ctypes.data_as(C.POINTER(C.c_int32)),
+                  val.ctypes.data_as(C.POINTER(C.c_double)))
+    assert lib.dsp_create(C.byref(d), 0, None, C.byref(h)) == -1        # unsorted column indices
+
+
+def test_solver_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from dispatches_amd import scenarios
+    from dispatches_amd.hip_solver import DspError, HipPdlpSolver
+    solver = HipPdlpSolver()
+    assert solver.available() is False
+    bidder, model = scenarios.make_batch("nuclear_24h", 2, solver)
+    with pytest.raises(DspError):
+        solver.solve(model)

@@ -1,0 +1,233 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle and the reference's golden vectors.
+
+Tolerances: objective within 1e-6 relative of the HiGHS oracle (BASELINE.json north_star); golden bid vectors at the
+reference's own rounding (4 dp for self-schedules, 2 dp x 2 dp for bid costs)."""
+import numpy as np
+import pytest
+
+gpu = pytest.mark.gpu
+
+
+def _solver(**kw):
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("GPU test selected but no GPU visible")
+    from dispatches_amd.hip_solver import HipPdlpSolver
+    return HipPdlpSolver(device=0, **kw)
+
+
+def _kkt_certificate(model):
+    """Independent numpy optimality certificate for every scenario: (primal infeasibility, dual infeasibility,
+    relative gap) in the original space.  Valid at any batch size -- needs no oracle solve."""
+    lp = model.lp
+    A = lp.csr()
+    lb, ub, rlo, rhi = [np.broadcast_to(a, (model.n_scenario, a.shape[-1])) for a in model.scenario_bounds()]
+    X, Y, Cm = model.x, model.y, model.c
+    fin = lambda a: np.where(np.isfinite(a), a, 0.0)
+    AX = X @ A.T
+    pres = np.maximum(rlo - AX, 0) + np.maximum(AX - rhi, 0)
+    bres = np.maximum(lb - X, 0) + np.maximum(X - ub, 0)
+    rc = Cm - Y @ A
+    lp_ = np.where(np.isfinite(lb), np.maximum(rc, 0), 0.0)
+    lm_ = np.where(np.isfinite(ub), np.maximum(-rc, 0), 0.0)
+    dres = rc - lp_ + lm_
+    ysign = np.where(np.isfinite(rlo), 0, np.maximum(Y, 0)) + np.where(np.isfinite(rhi), 0, np.maximum(-Y, 0))
+    pobj = np.sum(Cm * X, 1)
+    dobj = np.sum(np.maximum(Y, 0) * fin(rlo) - np.maximum(-Y, 0) * fin(rhi), 1) + np.sum(lp_ * fin(lb) - lm_ * fin(ub), 1)
+    qn = np.sqrt(np.sum(np.maximum(np.abs(fin(rlo)), np.abs(fin(rhi))) ** 2, 1) + np.sum(fin(lb) ** 2 + fin(ub) ** 2, 1))
+    cn = np.linalg.norm(Cm, axis=1)
+    rp = np.sqrt(np.sum(pres ** 2, 1) + np.sum(bres ** 2, 1)) / (1 + qn)
+    rd = np.sqrt(np.sum(dres ** 2, 1) + np.sum(ysign ** 2, 1)) / (1 + cn)
+    rg = np.abs(pobj - dobj) / (1 + np.abs(pobj) + np.abs(dobj))
+    return rp, rd, rg
+
+
+@gpu
+def test_spmv_step_matches_scipy():
+    import torch
+    from dispatches_amd import scenarios
+    from dispatches_amd.hip_solver import DeviceLP
+    for wl in ("wind_battery_24h", "wind_pem_48h", "nuclear_48h", "wind_battery_48h"):
+        bidder, model = scenarios.make_batch(wl, 4, _solver())
+        lp = model.lp
+        dlp = DeviceLP(lp, 0)
+        rng = np.random.default_rng(1)
+        B = 257
+        X = rng.standard_normal((B, lp.n)); Y = rng.standard_normal((B, lp.m))
+        AX, ATY = dlp.spmv_step(torch.as_tensor(X).cuda(), torch.as_tensor(Y).cuda())
+        A = lp.csr()
+        np.testing.assert_allclose(AX.cpu().numpy(), X @ A.T, rtol=1e-13, atol=1e-12)
+        np.testing.assert_allclose(ATY.cpu().numpy(), Y @ A, rtol=1e-13, atol=1e-12)
+
+
+def _wind_battery_objects(rts309, thermal):
+    from dispatches_amd.flowsheets import MultiPeriodWindBattery
+    from dispatches_amd.workflow import RenewableGeneratorModelData, ThermalGeneratorModelData
+    from tests.test_workflow_cpu import generator_params, thermal_params
+    md = ThermalGeneratorModelData(**thermal_params()) if thermal else RenewableGeneratorModelData(**generator_params)
+    return MultiPeriodWindBattery(model_data=md, wind_capacity_factors=rts309["rt_cf"], wind_pmax_mw=200,
+                                  battery_pmax_mw=25, battery_energy_capacity_mwh=100)
+
+
+@gpu
+def test_golden_self_schedule_and_bid_curves(golden, rts309):
+    """Reference goldens G1 / G2 through the real boundary classes with the HIP solver."""
+    from dispatches_amd.workflow import Backcaster, Bidder, SelfScheduler
+    bc = Backcaster({"Carter": rts309["da_lmp"][:48].tolist()}, {"Carter": rts309["rt_lmp"][:48].tolist()})
+    ss = SelfScheduler(bidding_model_object=_wind_battery_objects(rts309, False), day_ahead_horizon=48,
+                       real_time_horizon=4, n_scenario=1, solver=_solver(), forecaster=bc)
+    bids = ss.compute_day_ahead_bids(date="2020-01-02")
+    p_max = np.array([b["309_WIND_1"]["p_max"] for b in bids.values()])
+    g1 = np.array(golden["G1_self_schedule_p_max_mw"]["values"])
+    np.testing.assert_allclose(p_max, g1, rtol=1e-2, atol=2e-4)       # reference test tolerance: reltol 1e-2
+    assert np.max(np.abs(p_max - g1)) < 2e-4                           # and far tighter than that
+    bd = Bidder(bidding_model_object=_wind_battery_objects(rts309, True), day_ahead_horizon=48,
+                real_time_horizon=4, n_scenario=1, solver=_solver(), forecaster=bc)
+    bids = bd.compute_day_ahead_bids(date="2020-01-02")
+    last = np.array([b["309_WIND_1"]["p_cost"][-1][1] for b in bids.values()])
+    g2 = np.array(golden["G2_bidder_last_point_cost"]["values"])
+    np.testing.assert_allclose(last, g2, rtol=1e-2, atol=0.5)
+
+
+@gpu
+def test_golden_trackers(golden, rts309):
+    from dispatches_amd.flowsheets import MultiPeriodWindPEM
+    from dispatches_amd.workflow import RenewableGeneratorModelData, Tracker
+    from tests.test_workflow_cpu import generator_params
+    g = golden["G3_tracker_wind_battery"]
+    D = g["market_dispatch_mw"]
+    tr = Tracker(tracking_model_object=_wind_battery_objects(rts309, False), tracking_horizon=4, n_tracking_hour=1,
+                 solver=_solver())
+    tr.track_market_dispatch(market_dispatch=D, date="2020-01-02", hour="00:00")
+    per = tr.model.fs.windBattery["periods"]
+    assert [p["wind"].value for p in per] == pytest.approx(g["expected_wind_power_kw"], rel=1e-3)
+    assert [tr.model.fs.value(tr.power_output[t]) for t in range(4)] == pytest.approx(D, abs=1e-3)
+    exp = [g["expected_wind_power_kw"][i] - D[i] * 1e3 for i in range(4)]
+    assert [p["elec_in"].value for p in per] == pytest.approx(exp, rel=1e-3)
+
+    g = golden["G3b_tracker_wind_pem"]
+    mp = MultiPeriodWindPEM(model_data=RenewableGeneratorModelData(**generator_params),
+                            wind_capacity_factors=rts309["rt_cf"], wind_pmax_mw=200, pem_pmax_mw=25)
+    tr = Tracker(tracking_model_object=mp, tracking_horizon=4, n_tracking_hour=1, solver=_solver())
+    tr.track_market_dispatch(market_dispatch=D, date="2020-01-02", hour="00:00")
+    per = tr.model.fs.windPEM["periods"]
+    fs = tr.model.fs
+    assert [p["wind"].value for p in per] == pytest.approx(g["expected_wind_power_kw"], rel=1e-3)
+    assert [fs.value(fs.wind_waste[i]) for i in range(4)] == pytest.approx([0] * 4, abs=1e-3)
+    assert [fs.value(tr.power_output[t]) for t in range(4)] == pytest.approx(D, abs=1e-3)
+    assert [p["pem_elec"].value for p in per] == pytest.approx(exp, rel=1e-3)
+
+
+@gpu
+def test_golden_nuclear_objective(golden):
+    from dispatches_amd.flowsheets import MultiPeriodNuclear
+    from dispatches_amd.workflow import Backcaster, Bidder, ThermalGeneratorModelData
+    g = golden["G4_nuclear_da_objective"]
+    md = ThermalGeneratorModelData(
+        gen_name="121_NUCLEAR_1", bus="Attlee", p_min=400, p_max=500, min_down_time=48, min_up_time=24,
+        ramp_up_60min=100, ramp_down_60min=100, shutdown_capacity=500, startup_capacity=500, initial_status=-1,
+        initial_p_output=0, production_cost_bid_pairs=[(400, 15), (450, 17.5), (500, 20)],
+        startup_cost_pairs=[(48, 7355.42)], fixed_commitment=1)
+    bidder = Bidder(bidding_model_object=MultiPeriodNuclear(model_data=md), n_scenario=3, solver=_solver(),
+                    forecaster=Backcaster({"Attlee": g["da_lmp"]}, {"Attlee": g["rt_lmp"]}),
+                    day_ahead_horizon=48, real_time_horizon=12)
+    bidder.compute_day_ahead_bids(date="2020-07-10", hour=0)
+    assert bidder.day_ahead_model.objective.sum() == pytest.approx(g["ipopt_objective_3_scenarios"], rel=1e-6)
+
+
+def _oracle_objectives(workload, model, count):
+    """Objectives of the first `count` scenarios from the INDEPENDENT oracle restatement (un-reduced LP + HiGHS)."""
+    from dispatches_amd import scenarios
+    from oracle import dispatch_lp_oracle as orc
+    T = len(model.HOUR)
+    out = []
+    if workload.startswith("wind"):
+        s = scenarios.load_series("rts_gmlc_309.npz" if "battery" in workload else "rts_gmlc_303.npz")
+        N = len(s["rt_lmp"])
+        stride = 17 if "battery" in workload else 37
+        for k in range(count):
+            h0 = (stride * k) % (N - T)
+            da, rt = np.clip(s["da_lmp"][h0:h0 + T], 0, 500), np.clip(s["rt_lmp"][h0:h0 + T], 0, 500)
+            cf = s["rt_cf"][h0:h0 + T]
+            if "battery" in workload:
+                P, *_ = orc.wind_battery_da(T, cf, da, rt)
+            else:
+                P, *_ = orc.wind_pem_da(T, cf, da, rt, wind_kw=847e3)
+            out.append(P.solve()[1])
+    else:
+        for k in range(count):
+            P, *_ = orc.nuclear_da(T, model.da_prices[k], model.rt_prices[k])
+            out.append(P.solve()[1])
+    return np.array(out)
+
+
+@gpu
+@pytest.mark.parametrize("workload", ["wind_battery_24h", "wind_battery_48h", "wind_pem_48h", "nuclear_24h", "nuclear_48h"])
+def test_batch_objective_parity_vs_oracle(workload):
+    from dispatches_amd import scenarios
+    solver = _solver()
+    B = 96
+    bidder, model = scenarios.make_batch(workload, B, solver)
+    solver.solve(model)
+    assert (model.status == 0).all(), np.bincount(model.status)
+    ref = _oracle_objectives(workload, model, B)
+    err = np.abs(model.objective - ref) / np.maximum(1.0, np.abs(ref))
+    assert err.max() < 1e-6, (err.max(), int(err.argmax()))
+    rp, rd, rg = _kkt_certificate(model)
+    assert max(rp.max(), rd.max(), rg.max()) < 5e-9
+
+
+@gpu
+def test_full_size_batch_certificate_and_invariances():
+    """BASELINE batch size (4096 x 24 h): optimality certificate for every scenario, permutation invariance,
+    and warm-start idempotence (size-independent properties; no oracle solve needed)."""
+    import torch
+    from dispatches_amd import scenarios
+    solver = _solver()
+    B = 4096
+    bidder, model = scenarios.make_batch("wind_battery_24h", B, solver)
+    solver.solve(model, tee=True)
+    assert (model.status == 0).all(), np.bincount(model.status)
+    rp, rd, rg = _kkt_certificate(model)
+    assert max(rp.max(), rd.max(), rg.max()) < 5e-9
+    obj = model.objective.copy()
+    x_first = model.x.copy()
+    iters_cold = model.iterations.copy()
+    # permutation invariance: scenario k's answer does not depend on its position in the batch
+    perm = np.random.default_rng(0).permutation(B)
+    model.c, model.c0, model.ub = model.c[perm], model.c0[perm], model.ub[perm]
+    model.x = model.y = None
+    solver.solve(model)
+    assert np.max(np.abs(model.objective - obj[perm]) / np.maximum(1, np.abs(obj[perm]))) < 1e-9
+    # idempotence: re-solving from the returned (x, y) terminates almost immediately at the same objective
+    solver.solve(model, warm_start=True)
+    assert np.max(np.abs(model.objective - obj[perm]) / np.maximum(1, np.abs(obj[perm]))) < 1e-8
+    assert model.iterations.mean() < 0.25 * iters_cold.mean()
+
+
+@gpu
+def test_edge_cases():
+    """Ragged / degenerate inputs: B=1, B not a multiple of the block, zero prices, a free row, warm start."""
+    from dispatches_amd import scenarios
+    solver = _solver()
+    for B in (1, 3, 65):
+        bidder, model = scenarios.make_batch("nuclear_24h", B, solver)
+        solver.solve(model)
+        assert (model.status == 0).all()
+    bidder, model = scenarios.make_batch("wind_battery_24h", 5, solver)
+    model.c[:] = model.base_c          # all prices zero: objective = fixed cost + curtailment terms only
+    model.c0 = np.full(5, model.base_c0) + model.c0_shift
+    solver.solve(model)
+    assert (model.status == 0).all()
+    rp, rd, rg = _kkt_certificate(model)
+    assert max(rp.max(), rd.max(), rg.max()) < 5e-9
+
+
+@gpu
+def test_iteration_limit_is_reported():
+    from dispatches_amd import scenarios
+    solver = _solver(max_iter=40)
+    bidder, model = scenarios.make_batch("wind_battery_24h", 4, solver)
+    res = solver.solve(model)
+    assert (model.status == 1).all() and (model.iterations == 40).all()
+    assert res.solver.termination_condition == "maxIterations"
