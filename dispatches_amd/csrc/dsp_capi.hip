@@ -23,6 +23,8 @@ static thread_local int g_last_hip_error = 0;
     }                                                  \
   } while (0)
 
+struct Geometry { int wpb = 1, blocks_per_cu = 1; size_t lds = 0; };
+
 struct dsp_handle {
   int device = 0;
   int n = 0, m = 0;
@@ -37,6 +39,8 @@ struct dsp_handle {
   int lds_limit = 160 * 1024;
   int num_cus = 256;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  bool geo_valid = false;
+  Geometry geo;
 };
 
 static int pick(const int *set, int count, int need) {
@@ -56,6 +60,12 @@ static int upload(dsp_handle *h, const std::vector<T> &v, const T **out) {
   return DSP_OK;
 }
 
+// pack a lane-major ELL (values + element indices) into the 16-byte device entries (byte offsets)
+static void pack_entries(const std::vector<double> &val, const std::vector<uint16_t> &idx, std::vector<Entry> &out) {
+  out.resize(val.size());
+  for (size_t i = 0; i < val.size(); ++i) { out[i].v = val[i]; out[i].off = (uint32_t)idx[i] * 8u; out[i].pad = 0; }
+}
+
 static int fill_long(LongList &L, const LaneELL &E) {
   if ((int)E.long_owner.size() > kMaxLong) return DSP_ERR_TOO_LARGE;
   L.count = (int)E.long_owner.size();
@@ -67,41 +77,62 @@ constexpr int kMaxWavesPerBlock = 8;   // kernels are compiled with __launch_bou
 
 // LDS bytes of a block with `wpb` waves
 static size_t lds_bytes(const DeviceProblem &P, int wpb) {
-  size_t dbl = (size_t)P.ellc_entries + P.ellr_entries + P.tailc_entries + P.tailr_entries + (size_t)wpb * (P.n_pad + P.m_pad);
-  size_t u16 = (size_t)P.ellc_entries + P.ellr_entries + P.tailc_entries + P.tailr_entries;
-  return ((dbl * 8 + u16 * 2 + 15) / 16) * 16;
+  size_t ent = (size_t)P.ellc_entries + P.ellr_entries + P.tailc_entries + P.tailr_entries;
+  return ent * sizeof(Entry) + (size_t)wpb * (P.n_pad + P.m_pad) * 8;
 }
 
-// choose waves per block: maximise resident waves per CU (<= 32), prefer fewer, larger blocks on ties
-static int choose_wpb(const dsp_handle *h, int requested, int B) {
-  if (requested > 0) return std::min(requested, kMaxWavesPerBlock);
-  int best = 1, best_waves = 0;
-  for (int wpb = 1; wpb <= kMaxWavesPerBlock; ++wpb) {
-    size_t l = lds_bytes(h->P, wpb);
-    if (l > (size_t)h->lds_limit) break;
-    int blocks = std::min<int>((int)(h->lds_limit / l), 32 / wpb);
-    int waves = blocks * wpb;
-    if (waves > best_waves) { best_waves = waves; best = wpb; }
+// Launch geometry of the solve kernel: waves (= scenarios in flight) per block and blocks per CU, from the runtime's
+// occupancy answer for the compiled kernel (VGPR- and LDS-limited).  Maximise resident waves per CU; on ties prefer
+// larger blocks (the shared matrix is staged once per block).  Cached per handle.
+static int solve_geometry(dsp_handle *h, int requested, int B, Geometry *g) {
+  if (h->geo_valid && requested <= 0) { *g = h->geo; }
+  else {
+    SolveArgs probe{};
+    probe.P = h->P;
+    int best_waves = -1;
+    Geometry best;
+    for (int wpb = kMaxWavesPerBlock; wpb >= 1; --wpb) {
+      if (requested > 0 && wpb != std::min(requested, kMaxWavesPerBlock)) continue;
+      size_t l = lds_bytes(h->P, wpb);
+      if (l > (size_t)h->lds_limit) continue;
+      int nb = 0;
+      hipError_t e = occupancy_solve(h->cpl, h->rpl, probe, 64 * wpb, l, &nb);
+      if (e != hipSuccess) { g_last_hip_error = (int)e; return DSP_ERR_HIP; }
+      if (nb * wpb > best_waves) { best_waves = nb * wpb; best.wpb = wpb; best.blocks_per_cu = nb; best.lds = l; }
+    }
+    if (best_waves <= 0) return DSP_ERR_TOO_LARGE;
+    *g = best;
+    if (requested <= 0) { h->geo = best; h->geo_valid = true; }
   }
-  // small batches: do not pack more waves into a block than needed to cover B across the CUs
-  int per_cu = (B + h->num_cus - 1) / h->num_cus;
-  while (best > 1 && best > per_cu) best--;
-  return std::max(best, 1);
+  // small batches: spread the scenarios over the CUs instead of packing blocks
+  if (requested <= 0) {
+    int per_cu = (B + h->num_cus - 1) / h->num_cus;
+    int wpb = g->wpb;
+    while (wpb > 1 && wpb > per_cu) wpb--;
+    if (wpb != g->wpb) { g->wpb = wpb; g->lds = lds_bytes(h->P, wpb); g->blocks_per_cu = std::max(1, per_cu / wpb); }
+  }
+  return DSP_OK;
 }
 
 extern "C" {
 
 void dsp_default_options(dsp_options *o) {
   if (!o) return;
+  std::memset(o, 0, sizeof(*o));
   o->eps_rel = 1e-9;
+  o->eps_obj = 1e-7;
   o->max_iter = 200000;
   o->check_every = 32;
   o->restart_sufficient = 0.2;
   o->restart_necessary = 0.8;
   o->restart_artificial = 0.36;
-  o->pid_kp = 0.7;
+  o->pid_kp = 0.5;
   o->max_dlog_weight = std::log(30.0);
   o->step_scale = 0.998;
+  o->jump_steady = 0.05;
+  o->jump_tol = 1e-3;
+  o->jump_min = 4.0;
+  o->ray_jumps = 1;
   o->ruiz_iters = 10;
   o->waves_per_block = 0;
 }
@@ -174,13 +205,15 @@ int dsp_create(const dsp_lp_desc *d, int device, const dsp_options *opt, dsp_han
   P.tailc_entries = (int)Ec.tail_val.size(); P.tailr_entries = (int)Er.tail_val.size();
   int rc;
   if ((rc = fill_long(P.long_c, Ec)) || (rc = fill_long(P.long_r, Er))) { delete h; return rc; }
+  std::vector<Entry> pk;
+#define UPE(val, idx, field) pack_entries(val, idx, pk); if ((rc = upload(h, pk, &P.field)) != DSP_OK) { dsp_destroy(h); return rc; }
 #define UP(vec, field) if ((rc = upload(h, vec, &P.field)) != DSP_OK) { dsp_destroy(h); return rc; }
-  UP(Ec.val, ellc_val) UP(Er.val, ellr_val) UP(Ec.tail_val, tailc_val) UP(Er.tail_val, tailr_val)
-  UP(Ecu.val, ellc_val_unscaled) UP(Eru.val, ellr_val_unscaled)
-  UP(Ecu.tail_val, tailc_val_unscaled) UP(Eru.tail_val, tailr_val_unscaled)
-  UP(Ec.idx, ellc_idx) UP(Er.idx, ellr_idx) UP(Ec.tail_idx, tailc_idx) UP(Er.tail_idx, tailr_idx)
+  UPE(Ec.val, Ec.idx, ellc) UPE(Er.val, Er.idx, ellr) UPE(Ec.tail_val, Ec.tail_idx, tailc) UPE(Er.tail_val, Er.tail_idx, tailr)
+  UPE(Ecu.val, Ecu.idx, ellc_unscaled) UPE(Eru.val, Eru.idx, ellr_unscaled)
+  UPE(Ecu.tail_val, Ecu.tail_idx, tailc_unscaled) UPE(Eru.tail_val, Eru.tail_idx, tailr_unscaled)
   UP(h->dc, col_scale) UP(h->dr, row_scale)
 #undef UP
+#undef UPE
   void *q = nullptr;
   if (hipMalloc(&q, sizeof(int)) != hipSuccess) { dsp_destroy(h); return DSP_ERR_HIP; }
   h->queue = (int *)q;
@@ -189,31 +222,28 @@ int dsp_create(const dsp_lp_desc *d, int device, const dsp_options *opt, dsp_han
   return DSP_OK;
 }
 
-int dsp_solve(dsp_handle *h, int32_t B, const double *c, int64_t c_stride, const double *var_lb, int64_t var_lb_stride,
-              const double *var_ub, int64_t var_ub_stride, const double *row_lb, int64_t row_lb_stride,
-              const double *row_ub, int64_t row_ub_stride, const double *x0, const double *y0,
-              const dsp_options *opt, double *x, double *y, double *obj, int32_t *status, int32_t *iters,
-              dsp_stats *stats, int sync_stats, void *hipStream) {
-  if (!h || B < 0 || !c || !x || !y || !obj || !status) return DSP_ERR_INVALID;
+int dsp_solve(dsp_handle *h, const dsp_batch *batch, const dsp_options *opt, dsp_stats *stats, int sync_stats,
+              void *hipStream) {
+  if (!h || !batch || batch->B < 0) return DSP_ERR_INVALID;
+  const int B = batch->B;
   if (B == 0) { if (stats) std::memset(stats, 0, sizeof(*stats)); return DSP_OK; }
+  if (!batch->c || !batch->x || !batch->y || !batch->obj || !batch->status) return DSP_ERR_INVALID;
   hipStream_t st = (hipStream_t)hipStream;
   HIP_TRY(hipSetDevice(h->device));
   SolveArgs a{};
-  a.P = h->P; a.B = B;
+  a.P = h->P; a.b = *batch;
   a.opt = opt ? *opt : h->opt;
-  if (a.opt.max_iter < 1 || a.opt.check_every < 1 || !(a.opt.eps_rel > 0) || !(a.opt.pid_kp >= 0) || !(a.opt.step_scale > 0))
+  if (a.opt.max_iter < 1 || a.opt.check_every < 1 || !(a.opt.eps_rel > 0) || !(a.opt.eps_obj >= 0) ||
+      !(a.opt.pid_kp >= 0) || !(a.opt.step_scale > 0))
     return DSP_ERR_INVALID;
   a.eta = a.opt.step_scale * h->eta_unit;
-  a.waves_per_block = choose_wpb(h, a.opt.waves_per_block, B);
-  size_t lds = lds_bytes(h->P, a.waves_per_block);
-  if (lds > (size_t)h->lds_limit) return DSP_ERR_TOO_LARGE;
+  Geometry geo;
+  int grc = solve_geometry(h, a.opt.waves_per_block, B, &geo);
+  if (grc != DSP_OK) return grc;
+  a.waves_per_block = geo.wpb;
+  const size_t lds = geo.lds;
   a.queue = h->queue;
-  a.c = c; a.var_lb = var_lb; a.var_ub = var_ub; a.row_lb = row_lb; a.row_ub = row_ub; a.x0 = x0; a.y0 = y0;
-  a.c_stride = c_stride; a.var_lb_stride = var_lb_stride; a.var_ub_stride = var_ub_stride;
-  a.row_lb_stride = row_lb_stride; a.row_ub_stride = row_ub_stride;
-  a.x = x; a.y = y; a.obj = obj; a.status = status; a.iters = iters;
-  int blocks_per_cu = std::max<int>(1, std::min<int>((int)(h->lds_limit / lds), 32 / a.waves_per_block));
-  int grid = std::min((B + a.waves_per_block - 1) / a.waves_per_block, h->num_cus * blocks_per_cu);
+  int grid = std::min((B + geo.wpb - 1) / geo.wpb, h->num_cus * geo.blocks_per_cu);
   HIP_TRY(hipMemsetAsync(h->queue, 0, sizeof(int), st));
   const bool timed = stats && sync_stats;
   if (timed) HIP_TRY(hipEventRecord(h->ev0, st));
@@ -227,11 +257,11 @@ int dsp_solve(dsp_handle *h, int32_t B, const double *c, int64_t c_stride, const
       HIP_TRY(hipStreamSynchronize(st));
       HIP_TRY(hipEventElapsedTime(&stats->kernel_ms, h->ev0, h->ev1));
       std::vector<int32_t> hs(B), hi(B);
-      HIP_TRY(hipMemcpy(hs.data(), status, B * sizeof(int32_t), hipMemcpyDeviceToHost));
-      if (iters) HIP_TRY(hipMemcpy(hi.data(), iters, B * sizeof(int32_t), hipMemcpyDeviceToHost));
+      HIP_TRY(hipMemcpy(hs.data(), batch->status, B * sizeof(int32_t), hipMemcpyDeviceToHost));
+      if (batch->iters) HIP_TRY(hipMemcpy(hi.data(), batch->iters, B * sizeof(int32_t), hipMemcpyDeviceToHost));
       for (int i = 0; i < B; ++i) {
         stats->n_optimal += hs[i] == DSP_STATUS_OPTIMAL;
-        if (iters) { stats->total_iterations += hi[i]; stats->max_iterations = std::max(stats->max_iterations, hi[i]); }
+        if (batch->iters) { stats->total_iterations += hi[i]; stats->max_iterations = std::max(stats->max_iterations, hi[i]); }
       }
     }
   }
@@ -244,8 +274,10 @@ int dsp_spmv_step(dsp_handle *h, int32_t B, const double *X, const double *Y, do
   HIP_TRY(hipSetDevice(h->device));
   SpmvArgs a{};
   a.P = h->P; a.B = B; a.X = X; a.Y = Y; a.AX = AX; a.ATY = ATY;
-  a.waves_per_block = choose_wpb(h, 0, B);
+  // streaming kernel: 8-wave blocks, as many as LDS admits per CU (its register footprint is small)
+  a.waves_per_block = kMaxWavesPerBlock;
   size_t lds = lds_bytes(h->P, a.waves_per_block);
+  while (lds > (size_t)h->lds_limit && a.waves_per_block > 1) lds = lds_bytes(h->P, --a.waves_per_block);
   if (lds > (size_t)h->lds_limit) return DSP_ERR_TOO_LARGE;
   int blocks_per_cu = std::max<int>(1, std::min<int>((int)(h->lds_limit / lds), 32 / a.waves_per_block));
   int grid = std::min((B + a.waves_per_block - 1) / a.waves_per_block, h->num_cus * blocks_per_cu);

@@ -10,6 +10,14 @@ namespace dsp {
 
 constexpr int kMaxLong = 32;   // long vectors (longer than the ELL width) per orientation
 
+// One matrix entry as the kernels read it from LDS with a single ds_read_b128:
+// value + BYTE offset of the multiplied vector element inside the wave's exchange buffer.
+struct __attribute__((aligned(16))) Entry {
+  double v;
+  uint32_t off;
+  uint32_t pad;
+};
+
 struct LongList {
   int count;
   int owner[kMaxLong];   // vector (column / row) index the partial sums belong to
@@ -18,29 +26,26 @@ struct LongList {
 };
 
 // Device-resident, scenario-independent data of one (flowsheet, horizon).
+// ELL layout: entry (e, slot q, lane) at ((e * S + q) * 64 + lane), S = CPL (A^T, columns) or RPL (A, rows):
+// for a fixed e the S slots of a lane are independent multiply-add chains.
 struct DeviceProblem {
   int n, m;
   int n_pad, m_pad;            // CPL*64, RPL*64
   int Wc, Wr;                  // ELL widths of A^T (columns) and A (rows)
   int ellc_entries, ellr_entries, tailc_entries, tailr_entries;
-  const double *ellc_val, *ellr_val, *tailc_val, *tailr_val;                       // scaled matrix
-  const double *ellc_val_unscaled, *ellr_val_unscaled, *tailc_val_unscaled, *tailr_val_unscaled;
-  const uint16_t *ellc_idx, *ellr_idx, *tailc_idx, *tailr_idx;
-  const double *col_scale, *row_scale;                                             // D_c [n], D_r [m]
+  const Entry *ellc, *ellr, *tailc, *tailr;                        // scaled matrix  D_r A D_c
+  const Entry *ellc_unscaled, *ellr_unscaled, *tailc_unscaled, *tailr_unscaled;
+  const double *col_scale, *row_scale;                             // D_c [n], D_r [m]
   LongList long_c, long_r;
 };
 
 struct SolveArgs {
   DeviceProblem P;
-  int B;
+  dsp_batch b;
   int waves_per_block;
   double eta;
   dsp_options opt;
   int *queue;                  // device work-queue head (zeroed before the launch)
-  const double *c, *var_lb, *var_ub, *row_lb, *row_ub, *x0, *y0;
-  long long c_stride, var_lb_stride, var_ub_stride, row_lb_stride, row_ub_stride;
-  double *x, *y, *obj;
-  int *status, *iters;
 };
 
 struct SpmvArgs {
@@ -52,6 +57,7 @@ struct SpmvArgs {
 };
 
 hipError_t launch_solve(int cpl, int rpl, const SolveArgs &a, dim3 grid, dim3 block, size_t lds, hipStream_t st);
+hipError_t occupancy_solve(int cpl, int rpl, const SolveArgs &a, int block_threads, size_t lds, int *blocks_per_cu);
 hipError_t launch_spmv(int cpl, int rpl, const SpmvArgs &a, dim3 grid, dim3 block, size_t lds, hipStream_t st);
 
 }  // namespace dsp

@@ -3,15 +3,22 @@
 // Hot path: one price scenario per 64-lane wave, several waves (scenarios) per workgroup.
 //   * lane l owns columns {l, l+64, ...} (CPL of them) and rows {l, l+64, ...} (RPL of them); every per-scenario
 //     vector (x, anchor, c, bounds, y, row bounds, A x) lives in that lane's registers for the whole solve;
-//   * the scaled constraint matrix, shared by all scenarios, is staged ONCE per workgroup into LDS in a
-//     lane-major ELL layout for A (row products) and A^T (column products): conflict-free ds_read_b64 streams,
-//     plus a per-wave LDS exchange buffer through which x-bar / y are gathered;
+//   * the scaled constraint matrix, shared by all scenarios, is staged ONCE per workgroup into LDS as 16-byte
+//     {value, byte offset} entries in a lane-major ELL layout for A (row products) and A^T (column products):
+//     one conflict-free ds_read_b128 per entry, then one ds_read_b64 gather from the wave's LDS exchange buffer
+//     through which x-bar / y are exchanged between lanes; for a fixed ELL position the CPL (RPL) slots of a lane
+//     are independent multiply-add chains, so the LDS latency of one chain hides behind the others;
 //   * vectors longer than the ELL width (e.g. the shared PEM-capacity column) are reduced cooperatively by the
 //     wave with cross-lane shuffles ("LDS-staged partials + wavefront reductions");
 //   * the iteration is the restarted, reflected Halpern PDHG (r2HPDHG): two SpMVs per iteration, NO reduction on
-//     the per-iteration path; restart / KKT tests every `check_every` iterations use 7 wave reductions;
+//     the per-iteration path; restart / KKT tests every `check_every` iterations use wave reductions;
+//   * "ray jumps": PDHG on an LP is piecewise affine; while the active set is not yet identified the iterates drift
+//     along a ray z + k v at constant speed for thousands of iterations.  When the check detects such a steady
+//     state (T(T z) - T z == T z - z), a ratio test over all clipping thresholds (one wave-min) gives the number of
+//     steps to the next breakpoint and the iterate jumps there in one go;
 //   * scenarios are pulled from a device-side work queue (one atomicAdd per scenario) so waves retire
 //     independently — iteration counts differ several-fold between price scenarios.
+// Control flow is wave-uniform throughout (one scenario per wave): no divergence.
 // No MFMA: the work is sparse BLAS-2 with ~3 nonzeros per row.  HBM is touched only to load a scenario's
 // (c, bounds) and to store (x, y, obj); the limiter is LDS issue + FP64 VALU.
 //
@@ -27,6 +34,17 @@
 
 namespace dsp {
 
+#ifdef DSP_NO_DRAIN
+#define DSP_DRAIN() do { } while (0)
+#else
+#define DSP_DRAIN() __builtin_amdgcn_s_waitcnt(0)
+#endif
+#ifdef DSP_DEBUG_TRACE
+#define DSP_TRACE(...) do { if (threadIdx.x == 0 && blockIdx.x == 0) printf(__VA_ARGS__); } while (0)
+#else
+#define DSP_TRACE(...) do { } while (0)
+#endif
+
 // ---- wave-level helpers ---------------------------------------------------------------------------------
 __device__ __forceinline__ void wave_lds_fence() {
   // Single-wave producer/consumer through LDS: the LDS unit executes one wave's DS ops in order, so only the
@@ -35,54 +53,84 @@ __device__ __forceinline__ void wave_lds_fence() {
   __builtin_amdgcn_wave_barrier();
 }
 
+// A value that is equal in all lanes, moved to scalar registers: tells the compiler that everything derived from it
+// (and every branch on it) is wave-uniform, so the solver's control flow compiles to scalar branches.
+__device__ __forceinline__ double uniform(double v) {
+  const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v));
+  const int hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+  return __hiloint2double(hi, lo);
+}
+
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-  return v;
+  return uniform(v);
 }
-
-// three / four sums at once (independent shuffle chains interleave)
-__device__ __forceinline__ void wave_sum3(double &a, double &b, double &c) {
+__device__ __forceinline__ double wave_min(double v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v = fmin(v, __shfl_xor(v, off, 64));
+  return uniform(v);
+}
+// N sums at once (independent shuffle chains interleave)
+template <int N>
+__device__ __forceinline__ void wave_sums(double (&a)[N]) {
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) {
-    double ta = __shfl_xor(a, off, 64), tb = __shfl_xor(b, off, 64), tc = __shfl_xor(c, off, 64);
-    a += ta; b += tb; c += tc;
-  }
-}
-__device__ __forceinline__ void wave_sum4(double &a, double &b, double &c, double &d) {
+    double t[N];
 #pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) {
-    double ta = __shfl_xor(a, off, 64), tb = __shfl_xor(b, off, 64), tc = __shfl_xor(c, off, 64),
-           td = __shfl_xor(d, off, 64);
-    a += ta; b += tb; c += tc; d += td;
+    for (int i = 0; i < N; ++i) t[i] = __shfl_xor(a[i], off, 64);
+#pragma unroll
+    for (int i = 0; i < N; ++i) a[i] += t[i];
   }
+#pragma unroll
+  for (int i = 0; i < N; ++i) a[i] = uniform(a[i]);
 }
 
 __device__ __forceinline__ double clampd(double v, double lo, double hi) { return fmin(fmax(v, lo), hi); }
 __device__ __forceinline__ double finite_or_zero(double v) { return (fabs(v) < INFINITY) ? v : 0.0; }
+__device__ __forceinline__ bool is_finite(double v) { return fabs(v) < INFINITY; }
+
+// steps until the clipped quantity g (moving by dg per step) changes its class among {< lo, [lo, hi], > hi}
+__device__ __forceinline__ double steps_to_break(double g, double dg, double lo, double hi) {
+  double a = INFINITY;
+  if (dg > 0.0) {
+    if (g < lo) a = (lo - g) / dg;
+    else if (g <= hi) a = (hi - g) / dg;
+  } else if (dg < 0.0) {
+    if (g > hi) a = (hi - g) / dg;
+    else if (g >= lo) a = (lo - g) / dg;
+  }
+  return (a == a) ? a : INFINITY;
+}
 
 // ---- lane-major ELL products --------------------------------------------------------------------------------
-// out[q] = sum_e val[(q*W+e)*64+lane] * vec[idx[...]]   for the S slots this lane owns, + long vectors.
-template <int S>
-__device__ __forceinline__ void ell_product(double (&out)[S], const double *__restrict__ ell_val,
-                                            const uint16_t *__restrict__ ell_idx, int W,
-                                            const double *vec /* per-wave LDS exchange buffer */, int lane,
-                                            const LongList &ll, const double *tail_val, const uint16_t *tail_idx) {
+// out[q] = sum_e ell[(e*S+q)*64+lane].v * vec[ell[...].off]   for the S slots this lane owns, + long vectors.
+template <int S, bool LONG>
+__device__ __forceinline__ void ell_product(double (&out)[S], const Entry *__restrict__ ell, int W,
+                                            const char *vec /* per-wave LDS exchange buffer */, int lane,
+                                            const LongList &ll, const Entry *__restrict__ tail) {
 #pragma unroll
-  for (int q = 0; q < S; ++q) {
-    double acc = 0.0;
-    const int base = q * W * 64 + lane;
-    for (int e = 0; e < W; ++e) {
-      const double a = ell_val[base + e * 64];
-      const int j = ell_idx[base + e * 64];
-      acc = fma(a, vec[j], acc);
-    }
-    out[q] = acc;
+  for (int q = 0; q < S; ++q) out[q] = 0.0;
+  const int4 *p = reinterpret_cast<const int4 *>(ell + lane);
+#pragma unroll 1
+  for (int e = 0; e < W; ++e, p += S * 64) {
+    int4 raw[S];
+#pragma unroll
+    for (int q = 0; q < S; ++q) raw[q] = p[q * 64];                               // ds_read_b128, conflict-free
+    double xv[S];
+#pragma unroll
+    for (int q = 0; q < S; ++q) xv[q] = *reinterpret_cast<const double *>(vec + (uint32_t)raw[q].z);   // gather
+#pragma unroll
+    for (int q = 0; q < S; ++q) out[q] = fma(__hiloint2double(raw[q].y, raw[q].x), xv[q], out[q]);
   }
+  if (!LONG) return;
   for (int l = 0; l < ll.count; ++l) {
     const int owner = ll.owner[l], start = ll.start[l], len = ll.len[l];
     double part = 0.0;
-    for (int t = lane; t < len; t += 64) part = fma(tail_val[start + t], vec[tail_idx[start + t]], part);
+    for (int t = lane; t < len; t += 64) {
+      const int4 raw = *reinterpret_cast<const int4 *>(tail + start + t);
+      part = fma(__hiloint2double(raw.y, raw.x), *reinterpret_cast<const double *>(vec + (uint32_t)raw.z), part);
+    }
     part = wave_sum(part);
 #pragma unroll
     for (int q = 0; q < S; ++q)
@@ -90,65 +138,77 @@ __device__ __forceinline__ void ell_product(double (&out)[S], const double *__re
   }
 }
 
+// stage the shared matrix of one workgroup into LDS (16-byte copies)
+__device__ __forceinline__ void stage_entries(Entry *dst, const Entry *__restrict__ src, int count) {
+  int4 *d = reinterpret_cast<int4 *>(dst);
+  const int4 *s = reinterpret_cast<const int4 *>(src);
+  for (int t = threadIdx.x; t < count; t += blockDim.x) d[t] = s[t];
+}
+
 // ---- the fused, LDS-resident PDLP solve ---------------------------------------------------------------------
-template <int CPL, int RPL>
-__global__ void __launch_bounds__(512) pdlp_solve_kernel(SolveArgs a) {
+#ifndef DSP_MIN_WAVES_SMALL
+#define DSP_MIN_WAVES_SMALL 4
+#endif
+template <int CPL, int RPL, bool LONG>
+__global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 2) pdlp_solve_kernel(SolveArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const DeviceProblem &P = a.P;
+  const dsp_batch &b = a.b;
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
 
   // ---- carve LDS: shared matrix region, then one exchange buffer pair per wave ----------------------------
-  double *ellc_val = reinterpret_cast<double *>(smem);                 // A^T (columns)  [CPL*Wc*64]
-  double *ellr_val = ellc_val + P.ellc_entries;                        // A   (rows)     [RPL*Wr*64]
-  double *tailc_val = ellr_val + P.ellr_entries;
-  double *tailr_val = tailc_val + P.tailc_entries;
-  double *wave_buf = tailr_val + P.tailr_entries;                      // [waves][n_pad + m_pad]
-  uint16_t *ellc_idx = reinterpret_cast<uint16_t *>(wave_buf + (size_t)a.waves_per_block * (P.n_pad + P.m_pad));
-  uint16_t *ellr_idx = ellc_idx + P.ellc_entries;
-  uint16_t *tailc_idx = ellr_idx + P.ellr_entries;
-  uint16_t *tailr_idx = tailc_idx + P.tailc_entries;
-
-  for (int t = threadIdx.x; t < P.ellc_entries; t += blockDim.x) { ellc_val[t] = P.ellc_val[t]; ellc_idx[t] = P.ellc_idx[t]; }
-  for (int t = threadIdx.x; t < P.ellr_entries; t += blockDim.x) { ellr_val[t] = P.ellr_val[t]; ellr_idx[t] = P.ellr_idx[t]; }
-  for (int t = threadIdx.x; t < P.tailc_entries; t += blockDim.x) { tailc_val[t] = P.tailc_val[t]; tailc_idx[t] = P.tailc_idx[t]; }
-  for (int t = threadIdx.x; t < P.tailr_entries; t += blockDim.x) { tailr_val[t] = P.tailr_val[t]; tailr_idx[t] = P.tailr_idx[t]; }
+  Entry *ellc = reinterpret_cast<Entry *>(smem);                       // A^T (columns)  [Wc*CPL*64]
+  Entry *ellr = ellc + P.ellc_entries;                                 // A   (rows)     [Wr*RPL*64]
+  Entry *tailc = ellr + P.ellr_entries;
+  Entry *tailr = tailc + P.tailc_entries;
+  char *wave_buf = reinterpret_cast<char *>(tailr + P.tailr_entries);  // [waves][(n_pad + m_pad) * 8]
+  stage_entries(ellc, P.ellc, P.ellc_entries);
+  stage_entries(ellr, P.ellr, P.ellr_entries);
+  stage_entries(tailc, P.tailc, P.tailc_entries);
+  stage_entries(tailr, P.tailr, P.tailr_entries);
   __syncthreads();
+  DSP_TRACE("[trace] staged: Wc=%d Wr=%d B=%d check=%d maxit=%d\n", P.Wc, P.Wr, b.B, a.opt.check_every, a.opt.max_iter);
 
-  double *xb = wave_buf + (size_t)wave * (P.n_pad + P.m_pad);          // gathered by row products
-  double *yb = xb + P.n_pad;                                           // gathered by column products
+  char *xb = wave_buf + (size_t)wave * (P.n_pad + P.m_pad) * 8;        // gathered by row products
+  char *yb = xb + (size_t)P.n_pad * 8;                                 // gathered by column products
+  double *xbl = reinterpret_cast<double *>(xb) + lane;                 // this lane's own slots: xbl[64*q]
+  double *ybl = reinterpret_cast<double *>(yb) + lane;
 
   const int n = P.n, m = P.m;
   const double eta = a.eta;
   const double eps = a.opt.eps_rel;
+  const double eps_obj = a.opt.eps_obj;
+  const int check_every = a.opt.check_every;
 
   for (;;) {
     // ---- pull the next scenario off the work queue ---------------------------------------------------------
     int s = 0;
     if (lane == 0) s = atomicAdd(a.queue, 1);
     s = __builtin_amdgcn_readfirstlane(s);
-    if (s >= a.B) break;
+    DSP_TRACE("[trace] scenario %d\n", s);
+    if (s >= b.B) break;
 
     // ---- load + scale this scenario's vectors (coalesced: lane-consecutive addresses) -----------------------
     double x[CPL], x0[CPL], c[CPL], lb[CPL], ub[CPL];
     double y[RPL], y0[RPL], rlo[RPL], rhi[RPL], ax[RPL], ax0[RPL];
-    double qn2 = 0.0, cn2 = 0.0, qs2 = 0.0, cs2 = 0.0;
+    double nrm[4] = {0.0, 0.0, 0.0, 0.0};                // |q|^2 unscaled, |c|^2 unscaled, |q|^2 scaled, |c|^2 scaled
 #pragma unroll
     for (int q = 0; q < CPL; ++q) {
       const int j = lane + 64 * q;
       const bool ok = j < n;
       const double d = ok ? P.col_scale[j] : 1.0;
-      const double cu = ok ? a.c[(size_t)s * a.c_stride + j] : 0.0;
-      const double lu = ok ? (a.var_lb ? a.var_lb[(size_t)s * a.var_lb_stride + j] : -INFINITY) : 0.0;
-      const double uu = ok ? (a.var_ub ? a.var_ub[(size_t)s * a.var_ub_stride + j] : INFINITY) : 0.0;
+      const double cu = ok ? b.c[(size_t)s * b.c_stride + j] : 0.0;
+      const double lu = ok ? (b.var_lb ? b.var_lb[(size_t)s * b.var_lb_stride + j] : -INFINITY) : 0.0;
+      const double uu = ok ? (b.var_ub ? b.var_ub[(size_t)s * b.var_ub_stride + j] : INFINITY) : 0.0;
       c[q] = cu * d;
       lb[q] = lu / d;
       ub[q] = uu / d;
-      cn2 += cu * cu;
-      cs2 += c[q] * c[q];
+      nrm[1] += cu * cu;
+      nrm[3] += c[q] * c[q];
       const double lf = finite_or_zero(lu), uf = finite_or_zero(uu);
-      qn2 += lf * lf + uf * uf;
-      double xs = (a.x0 && ok) ? a.x0[(size_t)s * n + j] / d : 0.0;
+      nrm[0] += lf * lf + uf * uf;
+      const double xs = (b.x0 && ok) ? b.x0[(size_t)s * n + j] / d : 0.0;
       x[q] = clampd(xs, lb[q], ub[q]);
       x0[q] = x[q];
     }
@@ -157,160 +217,245 @@ __global__ void __launch_bounds__(512) pdlp_solve_kernel(SolveArgs a) {
       const int i = lane + 64 * q;
       const bool ok = i < m;
       const double d = ok ? P.row_scale[i] : 1.0;
-      const double lo = (ok && a.row_lb) ? a.row_lb[(size_t)s * a.row_lb_stride + i] : -INFINITY;
-      const double hi = (ok && a.row_ub) ? a.row_ub[(size_t)s * a.row_ub_stride + i] : INFINITY;
+      const double lo = (ok && b.row_lb) ? b.row_lb[(size_t)s * b.row_lb_stride + i] : -INFINITY;
+      const double hi = (ok && b.row_ub) ? b.row_ub[(size_t)s * b.row_ub_stride + i] : INFINITY;
       rlo[q] = lo * d;
       rhi[q] = hi * d;
       const double big = fmax(fabs(finite_or_zero(lo)), fabs(finite_or_zero(hi)));
-      qn2 += big * big;
+      nrm[0] += big * big;
       const double bigs = fmax(fabs(finite_or_zero(rlo[q])), fabs(finite_or_zero(rhi[q])));
-      qs2 += bigs * bigs;
-      double ys = (a.y0 && ok) ? a.y0[(size_t)s * m + i] / d : 0.0;
+      nrm[2] += bigs * bigs;
+      double ys = (b.y0 && ok) ? b.y0[(size_t)s * m + i] / d : 0.0;
       // keep the warm start dual-feasible in sign
-      if (!(fabs(rlo[q]) < INFINITY)) ys = fmin(ys, 0.0);
-      if (!(fabs(rhi[q]) < INFINITY)) ys = fmax(ys, 0.0);
+      if (!is_finite(rlo[q])) ys = fmin(ys, 0.0);
+      if (!is_finite(rhi[q])) ys = fmax(ys, 0.0);
       y[q] = ys;
       y0[q] = ys;
     }
-    wave_sum4(qn2, cn2, qs2, cs2);
-    const double qn = sqrt(qn2), cn = sqrt(cn2);
-    const double qs = sqrt(qs2), cs = sqrt(cs2);
+    wave_sums<4>(nrm);
+    const double qn = sqrt(nrm[0]), cn = sqrt(nrm[1]);
+    const double qs = sqrt(nrm[2]), cs = sqrt(nrm[3]);
+    const double c0 = b.obj_offset ? b.obj_offset[(size_t)s * b.obj_offset_stride] : 0.0;
     double w = (cs > 1e-10 && qs > 1e-10) ? cs / qs : 1.0;       // primal weight
+    if (b.primal_weight) {
+      const double wi = b.primal_weight[s];
+      if (wi > 0.0 && is_finite(wi)) w = wi;
+    }
 
+    DSP_TRACE("[trace] loaded w=%g\n", w);
     // A x for the starting point
 #pragma unroll
-    for (int q = 0; q < CPL; ++q) xb[lane + 64 * q] = x[q];
+    for (int q = 0; q < CPL; ++q) xbl[64 * q] = x[q];
     wave_lds_fence();
-    ell_product<RPL>(ax, ellr_val, ellr_idx, P.Wr, xb, lane, P.long_r, tailr_val, tailr_idx);
+    ell_product<RPL, LONG>(ax, ellr, P.Wr, xb, lane, P.long_r, tailr);
 #pragma unroll
     for (int q = 0; q < RPL; ++q) ax0[q] = ax[q];
 
     int k = 0;                       // iterations since the last restart
     int it = 0;
+    int njump = 0;
     double r0 = INFINITY, rprev = INFINITY;
     int status = DSP_STATUS_ITERATION_LIMIT;
     double xp[CPL], yp[RPL], axb[RPL];
     double pobj = 0.0;
+#pragma unroll
+    for (int q = 0; q < CPL; ++q) xp[q] = x[q];
+#pragma unroll
+    for (int q = 0; q < RPL; ++q) { yp[q] = y[q]; axb[q] = ax[q]; }
 
-    for (it = 0; it < a.opt.max_iter; ++it) {
-      const double tau = eta / w, sig = eta * w;
-      // ---- column products: A^T y -------------------------------------------------------------------------
-#pragma unroll
-      for (int q = 0; q < RPL; ++q) yb[lane + 64 * q] = y[q];
-      wave_lds_fence();
-      double aty[CPL];
-      ell_product<CPL>(aty, ellc_val, ellc_idx, P.Wc, yb, lane, P.long_c, tailc_val, tailc_idx);
-      // ---- primal step, reflection point, row products: A (2 x+ - x) ---------------------------------------
-#pragma unroll
-      for (int q = 0; q < CPL; ++q) {
-        xp[q] = clampd(x[q] - tau * (c[q] - aty[q]), lb[q], ub[q]);
-        xb[lane + 64 * q] = 2.0 * xp[q] - x[q];
+// one PDHG application T(x, y) -> (xp, yp); leaves aty = A^T y and axb = A (2 xp - x) behind
+#define DSP_PDHG_STEP()                                                                                     \
+  {                                                                                                         \
+    _Pragma("unroll") for (int q = 0; q < RPL; ++q) ybl[64 * q] = y[q];                                     \
+    wave_lds_fence();                                                                                       \
+    ell_product<CPL, LONG>(aty, ellc, P.Wc, yb, lane, P.long_c, tailc);                                     \
+    _Pragma("unroll") for (int q = 0; q < CPL; ++q) {                                                       \
+      xp[q] = clampd(x[q] - tau * (c[q] - aty[q]), lb[q], ub[q]);                                           \
+      xbl[64 * q] = 2.0 * xp[q] - x[q];                                                                     \
+    }                                                                                                       \
+    wave_lds_fence();                                                                                       \
+    ell_product<RPL, LONG>(axb, ellr, P.Wr, xb, lane, P.long_r, tailr);                                     \
+    _Pragma("unroll") for (int q = 0; q < RPL; ++q) {                                                       \
+      const double wv = y[q] - sig * axb[q];                                                                \
+      yp[q] = wv + clampd(-wv, sig * rlo[q], sig * rhi[q]);                                                 \
+    }                                                                                                       \
+  }
+// reflected Halpern step toward the anchor (x0, y0); ax tracks A x through the same recursion
+#define DSP_HALPERN_STEP()                                                                                  \
+  {                                                                                                         \
+    const double lam = (double)(k + 1) / (double)(k + 2), oml = 1.0 - lam;                                  \
+    _Pragma("unroll") for (int q = 0; q < CPL; ++q) x[q] = lam * (2.0 * xp[q] - x[q]) + oml * x0[q];        \
+    _Pragma("unroll") for (int q = 0; q < RPL; ++q) {                                                       \
+      y[q] = lam * (2.0 * yp[q] - y[q]) + oml * y0[q];                                                      \
+      ax[q] = lam * axb[q] + oml * ax0[q];                                                                  \
+    }                                                                                                       \
+  }
+    double aty[CPL];
+    DSP_TRACE("[trace] enter loop\n");
+    for (it = 0;;) {
+      const double tau = eta / w, sig = eta * w;              // the primal weight changes only at checks
+      // ---- plain iterations up to the next check: two SpMVs + elementwise work, no reduction, no branch --------
+      const int plain = min(check_every - 1, a.opt.max_iter - it);
+      for (int u = 0; u < plain; ++u) {
+        DSP_PDHG_STEP()
+        ++k;
+        DSP_HALPERN_STEP()
       }
-      wave_lds_fence();
-      ell_product<RPL>(axb, ellr_val, ellr_idx, P.Wr, xb, lane, P.long_r, tailr_val, tailr_idx);
-      // ---- dual step ---------------------------------------------------------------------------------------
-#pragma unroll
-      for (int q = 0; q < RPL; ++q) {
-        const double wv = y[q] - sig * axb[q];
-        yp[q] = wv + clampd(-wv, sig * rlo[q], sig * rhi[q]);
-      }
+      it += plain;
+      DSP_TRACE("[trace] it=%d k=%d\n", it, k);
+      if (it >= a.opt.max_iter) break;
+      // ---- check iteration ----------------------------------------------------------------------------------
+      DSP_PDHG_STEP()
       ++k;
-      const bool check = ((it + 1) % a.opt.check_every) == 0;
-      const bool need_r0 = (k == 1);
-      bool restarted = false;
-      if (check || need_r0) {
-        // fixed-point residual in the PDHG metric: w|dx|^2 - 2 eta dy.A dx + |dy|^2 / w
-        double sxx = 0.0, syy = 0.0, sxy = 0.0;
+      bool moved = false;            // restarted or jumped: the Halpern step is skipped
+      {
+        // ---- KKT test at (x+, y+) in the ORIGINAL (unscaled) space + fixed-point residual --------------------
 #pragma unroll
-        for (int q = 0; q < CPL; ++q) { const double dx = xp[q] - x[q]; sxx = fma(dx, dx, sxx); }
+        for (int q = 0; q < RPL; ++q) ybl[64 * q] = yp[q];
+        wave_lds_fence();
+        double atyp[CPL];
+        ell_product<CPL, LONG>(atyp, ellc, P.Wc, yb, lane, P.long_c, tailc);
+        // red: 0 pres^2, 1 dres^2, 2 pobj, 3 dobj, 4 sum|y| viol, 5 sum|c x|, 6 |dx|^2, 7 |dy|^2, 8 dy.A dx
+        double red[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int q = 0; q < CPL; ++q) {
+          const double rc = c[q] - atyp[q];
+          const double lp = is_finite(lb[q]) ? fmax(rc, 0.0) : 0.0;
+          const double lm = is_finite(ub[q]) ? fmax(-rc, 0.0) : 0.0;
+          const int j = lane + 64 * q;
+          const double dr_ = (rc - lp + lm) / ((j < n) ? P.col_scale[j] : 1.0);
+          red[1] = fma(dr_, dr_, red[1]);
+          const double cx = c[q] * xp[q];
+          red[2] += cx;
+          red[5] += fabs(cx);
+          red[3] += lp * finite_or_zero(lb[q]) - lm * finite_or_zero(ub[q]);
+          const double dx = xp[q] - x[q];
+          red[6] = fma(dx, dx, red[6]);
+        }
 #pragma unroll
         for (int q = 0; q < RPL; ++q) {
+          const double axp = 0.5 * (axb[q] + ax[q]);
+          const double viol_s = fmax(rlo[q] - axp, 0.0) + fmax(axp - rhi[q], 0.0);
+          const int i = lane + 64 * q;
+          const double viol = viol_s / ((i < m) ? P.row_scale[i] : 1.0);
+          red[0] = fma(viol, viol, red[0]);
+          red[4] = fma(fabs(yp[q]), viol_s, red[4]);
+          red[3] += fmax(yp[q], 0.0) * finite_or_zero(rlo[q]) - fmax(-yp[q], 0.0) * finite_or_zero(rhi[q]);
           const double dy = yp[q] - y[q];
-          syy = fma(dy, dy, syy);
-          sxy = fma(dy, 0.5 * (axb[q] - ax[q]), sxy);
+          red[7] = fma(dy, dy, red[7]);
+          red[8] = fma(dy, 0.5 * (axb[q] - ax[q]), red[8]);
         }
-        wave_sum3(sxx, syy, sxy);
-        const double r = sqrt(fmax(w * sxx - 2.0 * eta * sxy + syy / w, 0.0));
-        if (!(r == r)) { status = DSP_STATUS_NUMERICAL; break; }
-        if (need_r0) { r0 = r; rprev = r; }
-        if (check) {
-          // ---- KKT test at (x+, y+) in the ORIGINAL (unscaled) space ----------------------------------------
+        wave_sums<9>(red);
+        const double po = red[2], dobj = red[3];
+        pobj = po;
+        const double r = sqrt(fmax(w * red[6] - 2.0 * eta * red[8] + red[7] / w, 0.0));
+        if (!(r == r) || !(po == po)) { status = DSP_STATUS_NUMERICAL; break; }
+        const double rp = sqrt(red[0]) / (1.0 + qn);
+        const double rd = sqrt(red[1]) / (1.0 + cn);
+        const double gap = fabs(po - dobj);
+        const double rg = gap / (1.0 + fabs(po) + fabs(dobj));
+        bool done = rp <= eps && rd <= eps && rg <= eps;
+        if (done && eps_obj > 0.0) {
+          const double lim = fmax(eps_obj * (1.0 + fabs(po + c0)), 1e-12 * red[5]);
+          done = gap <= lim && red[4] <= lim;
+        }
+        if (done) { status = DSP_STATUS_OPTIMAL; ++it; break; }
+        // ---- restart test (r0 = residual at the first check after a restart) ----------------------------------
+        const bool first = !(r0 < INFINITY);
+        const bool do_restart = !first && ((r <= a.opt.restart_sufficient * r0) ||
+                                           (r <= a.opt.restart_necessary * r0 && r > rprev) ||
+                                           ((double)k >= a.opt.restart_artificial * (double)(it + 1)));
+#ifdef DSP_NO_JUMP
+        const bool steady = false;
+#else
+        const bool steady = a.opt.ray_jumps && !do_restart && k >= 2 * check_every &&
+                            fabs(r - rprev) <= a.opt.jump_steady * r;
+#endif
+        if (first) r0 = r;
+        rprev = r;
+        if (do_restart) {
+          double dd[2] = {0.0, 0.0};
 #pragma unroll
-          for (int q = 0; q < RPL; ++q) yb[lane + 64 * q] = yp[q];
-          wave_lds_fence();
-          double atyp[CPL];
-          ell_product<CPL>(atyp, ellc_val, ellc_idx, P.Wc, yb, lane, P.long_c, tailc_val, tailc_idx);
-          double pres2 = 0.0, dres2 = 0.0, po = 0.0, dobj = 0.0;
+          for (int q = 0; q < CPL; ++q) { const double t = xp[q] - x0[q]; dd[0] = fma(t, t, dd[0]); }
 #pragma unroll
-          for (int q = 0; q < CPL; ++q) {
-            const int j = lane + 64 * q;
-            const double d = (j < n) ? P.col_scale[j] : 1.0;
-            const double rc = c[q] - atyp[q];
-            const double lp = (fabs(lb[q]) < INFINITY) ? fmax(rc, 0.0) : 0.0;
-            const double lm = (fabs(ub[q]) < INFINITY) ? fmax(-rc, 0.0) : 0.0;
-            const double dr_ = (rc - lp + lm) / d;
-            dres2 = fma(dr_, dr_, dres2);
-            po = fma(c[q], xp[q], po);
-            dobj += lp * finite_or_zero(lb[q]) - lm * finite_or_zero(ub[q]);
+          for (int q = 0; q < RPL; ++q) { const double t = yp[q] - y0[q]; dd[1] = fma(t, t, dd[1]); }
+          wave_sums<2>(dd);
+          const double ddx = sqrt(dd[0]), ddy = sqrt(dd[1]);
+          if (ddx > 1e-14 && ddy > 1e-14) {
+            const double e = log(w) + log(ddx) - log(ddy);
+            const double dl = clampd(-a.opt.pid_kp * e, -a.opt.max_dlog_weight, a.opt.max_dlog_weight);
+            w *= exp(dl);
           }
+#pragma unroll
+          for (int q = 0; q < CPL; ++q) { x[q] = xp[q]; x0[q] = xp[q]; }
 #pragma unroll
           for (int q = 0; q < RPL; ++q) {
-            const int i = lane + 64 * q;
-            const double d = (i < m) ? P.row_scale[i] : 1.0;
             const double axp = 0.5 * (axb[q] + ax[q]);
-            const double viol = (fmax(rlo[q] - axp, 0.0) + fmax(axp - rhi[q], 0.0)) / d;
-            pres2 = fma(viol, viol, pres2);
-            dobj += fmax(yp[q], 0.0) * finite_or_zero(rlo[q]) - fmax(-yp[q], 0.0) * finite_or_zero(rhi[q]);
+            y[q] = yp[q]; y0[q] = yp[q]; ax[q] = axp; ax0[q] = axp;
           }
-          wave_sum4(pres2, dres2, po, dobj);
-          pobj = po;
-          const double rp = sqrt(pres2) / (1.0 + qn);
-          const double rd = sqrt(dres2) / (1.0 + cn);
-          const double rg = fabs(po - dobj) / (1.0 + fabs(po) + fabs(dobj));
-          if (rp <= eps && rd <= eps && rg <= eps) { status = DSP_STATUS_OPTIMAL; ++it; break; }
-          // ---- restart test -----------------------------------------------------------------------------
-          const bool do_restart = (r <= a.opt.restart_sufficient * r0) ||
-                                  (r <= a.opt.restart_necessary * r0 && r > rprev) ||
-                                  ((double)k >= a.opt.restart_artificial * (double)(it + 1));
-          rprev = r;
-          if (do_restart) {
-            double ddx = 0.0, ddy = 0.0, dummy = 0.0;
+          k = 0; r0 = INFINITY; rprev = INFINITY;
+          moved = true;
+        } else if (steady) {
+          // ---- ray jump: second application of T from (x+, y+), translation test, ratio test ------------------
+          double x2[CPL], y2[RPL], axb1[RPL];
+          double tt[2] = {0.0, 0.0};       // |v2 - v1|^2_w, |v2|^2_w
+          double alpha = INFINITY;
 #pragma unroll
-            for (int q = 0; q < CPL; ++q) { const double t = xp[q] - x0[q]; ddx = fma(t, t, ddx); }
+          for (int q = 0; q < CPL; ++q) {
+            const double gx1 = xp[q] - tau * (c[q] - atyp[q]);
+            const double gx0 = x[q] - tau * (c[q] - aty[q]);
+            x2[q] = clampd(gx1, lb[q], ub[q]);
+            xbl[64 * q] = 2.0 * x2[q] - xp[q];
+            const double v1 = xp[q] - x[q], v2 = x2[q] - xp[q];
+            tt[0] = fma(w * (v2 - v1), v2 - v1, tt[0]);
+            tt[1] = fma(w * v2, v2, tt[1]);
+            alpha = fmin(alpha, steps_to_break(gx1, gx1 - gx0, lb[q], ub[q]));
+          }
+          wave_lds_fence();
+          ell_product<RPL, LONG>(axb1, ellr, P.Wr, xb, lane, P.long_r, tailr);
+          const double iw = 1.0 / w;
 #pragma unroll
-            for (int q = 0; q < RPL; ++q) { const double t = yp[q] - y0[q]; ddy = fma(t, t, ddy); }
-            wave_sum3(ddx, ddy, dummy);
-            ddx = sqrt(ddx); ddy = sqrt(ddy);
-            if (ddx > 1e-14 && ddy > 1e-14) {
-              const double e = log(w) + log(ddx) - log(ddy);
-              const double dl = clampd(-a.opt.pid_kp * e, -a.opt.max_dlog_weight, a.opt.max_dlog_weight);
-              w *= exp(dl);
+          for (int q = 0; q < RPL; ++q) {
+            const double gy1 = yp[q] - sig * axb1[q];
+            const double gy0 = y[q] - sig * axb[q];
+            y2[q] = gy1 + clampd(-gy1, sig * rlo[q], sig * rhi[q]);
+            const double v1 = yp[q] - y[q], v2 = y2[q] - yp[q];
+            tt[0] = fma(iw * (v2 - v1), v2 - v1, tt[0]);
+            tt[1] = fma(iw * v2, v2, tt[1]);
+            alpha = fmin(alpha, steps_to_break(-gy1, gy0 - gy1, sig * rlo[q], sig * rhi[q]));
+          }
+          wave_sums<2>(tt);
+          alpha = wave_min(alpha);
+          if (tt[1] > 0.0 && tt[0] <= a.opt.jump_tol * a.opt.jump_tol * tt[1] && alpha >= a.opt.jump_min &&
+              alpha < 1e200) {
+            const double al = floor(alpha) - 1.0;
+#pragma unroll
+            for (int q = 0; q < CPL; ++q) {
+              const double xn = clampd(x2[q] + al * (x2[q] - xp[q]), lb[q], ub[q]);
+              x[q] = xn; x0[q] = xn; xp[q] = xn;
+              xbl[64 * q] = xn;
             }
-#pragma unroll
-            for (int q = 0; q < CPL; ++q) { x[q] = xp[q]; x0[q] = xp[q]; }
+            wave_lds_fence();
+            ell_product<RPL, LONG>(ax, ellr, P.Wr, xb, lane, P.long_r, tailr);
 #pragma unroll
             for (int q = 0; q < RPL; ++q) {
-              const double axp = 0.5 * (axb[q] + ax[q]);
-              y[q] = yp[q]; y0[q] = yp[q]; ax[q] = axp; ax0[q] = axp;
+              const double yn = y2[q] + al * (y2[q] - yp[q]);
+              y[q] = yn; y0[q] = yn; yp[q] = yn;
+              ax0[q] = ax[q]; axb[q] = ax[q];
             }
             k = 0; r0 = INFINITY; rprev = INFINITY;
-            restarted = true;
+            ++njump;
+            moved = true;
           }
         }
       }
-      if (!restarted) {
-        // ---- reflected Halpern step toward the anchor ------------------------------------------------------
-        const double lam = (double)(k + 1) / (double)(k + 2), oml = 1.0 - lam;
-#pragma unroll
-        for (int q = 0; q < CPL; ++q) x[q] = lam * (2.0 * xp[q] - x[q]) + oml * x0[q];
-#pragma unroll
-        for (int q = 0; q < RPL; ++q) {
-          y[q] = lam * (2.0 * yp[q] - y[q]) + oml * y0[q];
-          ax[q] = lam * axb[q] + oml * ax0[q];
-        }
-      }
+      ++it;
+      if (!moved) DSP_HALPERN_STEP()
     }
+#undef DSP_PDHG_STEP
+#undef DSP_HALPERN_STEP
 
+    DSP_TRACE("[trace] store status=%d it=%d\n", status, it);
     // ---- store the scenario's result (unscaled) ----------------------------------------------------------
     if (status != DSP_STATUS_OPTIMAL) {
       double po = 0.0;
@@ -321,18 +466,26 @@ __global__ void __launch_bounds__(512) pdlp_solve_kernel(SolveArgs a) {
 #pragma unroll
     for (int q = 0; q < CPL; ++q) {
       const int j = lane + 64 * q;
-      if (j < n) a.x[(size_t)s * n + j] = xp[q] * P.col_scale[j];
+      if (j < n) b.x[(size_t)s * n + j] = xp[q] * P.col_scale[j];
     }
+    DSP_DRAIN();
+    DSP_TRACE("[trace] x stored %p\n", (void *)b.x);
 #pragma unroll
     for (int q = 0; q < RPL; ++q) {
       const int i = lane + 64 * q;
-      if (i < m) a.y[(size_t)s * m + i] = yp[q] * P.row_scale[i];
+      if (i < m) b.y[(size_t)s * m + i] = yp[q] * P.row_scale[i];
     }
+    DSP_DRAIN();
+    DSP_TRACE("[trace] y stored %p obj %p status %p iters %p jumps %p pw %p queue %p\n", (void *)b.y, (void *)b.obj, (void *)b.status, (void *)b.iters, (void *)b.jumps, (void *)b.primal_weight, (void *)a.queue);
     if (lane == 0) {
-      a.obj[s] = pobj;
-      a.status[s] = status;
-      if (a.iters) a.iters[s] = it;
+      b.obj[s] = pobj;
+      b.status[s] = status;
+      if (b.iters) b.iters[s] = it;
+      if (b.jumps) b.jumps[s] = njump;
+      if (b.primal_weight) b.primal_weight[s] = w;
     }
+    DSP_DRAIN();
+    DSP_TRACE("[trace] scalars stored\n");
   }
 }
 
@@ -340,39 +493,54 @@ __global__ void __launch_bounds__(512) pdlp_solve_kernel(SolveArgs a) {
 // One scenario per wave; the (unscaled) ELL matrix is staged into LDS once per workgroup; each wave streams its
 // x (coalesced) into its LDS exchange buffer, forms the row products from LDS and writes them coalesced.
 // Algorithmic HBM bytes per scenario: 2*8*(n+m)  (read x,y; write Ax, A^T y).
-template <int CPL, int RPL>
+template <int CPL, int RPL, bool LONG>
 __global__ void __launch_bounds__(512) spmv_step_kernel(SpmvArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const DeviceProblem &P = a.P;
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
-  double *ellc_val = reinterpret_cast<double *>(smem);
-  double *ellr_val = ellc_val + P.ellc_entries;
-  double *tailc_val = ellr_val + P.ellr_entries;
-  double *tailr_val = tailc_val + P.tailc_entries;
-  double *wave_buf = tailr_val + P.tailr_entries;
-  uint16_t *ellc_idx = reinterpret_cast<uint16_t *>(wave_buf + (size_t)a.waves_per_block * (P.n_pad + P.m_pad));
-  uint16_t *ellr_idx = ellc_idx + P.ellc_entries;
-  uint16_t *tailc_idx = ellr_idx + P.ellr_entries;
-  uint16_t *tailr_idx = tailc_idx + P.tailc_entries;
-  for (int t = threadIdx.x; t < P.ellc_entries; t += blockDim.x) { ellc_val[t] = P.ellc_val_unscaled[t]; ellc_idx[t] = P.ellc_idx[t]; }
-  for (int t = threadIdx.x; t < P.ellr_entries; t += blockDim.x) { ellr_val[t] = P.ellr_val_unscaled[t]; ellr_idx[t] = P.ellr_idx[t]; }
-  for (int t = threadIdx.x; t < P.tailc_entries; t += blockDim.x) { tailc_val[t] = P.tailc_val_unscaled[t]; tailc_idx[t] = P.tailc_idx[t]; }
-  for (int t = threadIdx.x; t < P.tailr_entries; t += blockDim.x) { tailr_val[t] = P.tailr_val_unscaled[t]; tailr_idx[t] = P.tailr_idx[t]; }
-  __syncthreads();
-  double *xb = wave_buf + (size_t)wave * (P.n_pad + P.m_pad);
-  double *yb = xb + P.n_pad;
+  Entry *ellc = reinterpret_cast<Entry *>(smem);
+  Entry *ellr = ellc + P.ellc_entries;
+  Entry *tailc = ellr + P.ellr_entries;
+  Entry *tailr = tailc + P.tailc_entries;
+  char *wave_buf = reinterpret_cast<char *>(tailr + P.tailr_entries);
+  stage_entries(ellc, P.ellc_unscaled, P.ellc_entries);
+  stage_entries(ellr, P.ellr_unscaled, P.ellr_entries);
+  stage_entries(tailc, P.tailc_unscaled, P.tailc_entries);
+  stage_entries(tailr, P.tailr_unscaled, P.tailr_entries);
   const int n = P.n, m = P.m;
   const int waves_total = gridDim.x * a.waves_per_block;
-  for (int s = blockIdx.x * a.waves_per_block + wave; s < a.B; s += waves_total) {
+  int s = blockIdx.x * a.waves_per_block + wave;
+  // first scenario's vectors are in flight while the matrix is staged
+  double xr[CPL], yr[RPL];
+  if (s < a.B) {
 #pragma unroll
-    for (int q = 0; q < CPL; ++q) { const int j = lane + 64 * q; xb[j] = (j < n) ? a.X[(size_t)s * n + j] : 0.0; }
+    for (int q = 0; q < CPL; ++q) { const int j = lane + 64 * q; xr[q] = (j < n) ? a.X[(size_t)s * n + j] : 0.0; }
 #pragma unroll
-    for (int q = 0; q < RPL; ++q) { const int i = lane + 64 * q; yb[i] = (i < m) ? a.Y[(size_t)s * m + i] : 0.0; }
+    for (int q = 0; q < RPL; ++q) { const int i = lane + 64 * q; yr[q] = (i < m) ? a.Y[(size_t)s * m + i] : 0.0; }
+  }
+  __syncthreads();
+  char *xb = wave_buf + (size_t)wave * (P.n_pad + P.m_pad) * 8;
+  char *yb = xb + (size_t)P.n_pad * 8;
+  double *xbl = reinterpret_cast<double *>(xb) + lane;
+  double *ybl = reinterpret_cast<double *>(yb) + lane;
+  for (; s < a.B; s += waves_total) {
+#pragma unroll
+    for (int q = 0; q < CPL; ++q) xbl[64 * q] = xr[q];
+#pragma unroll
+    for (int q = 0; q < RPL; ++q) ybl[64 * q] = yr[q];
     wave_lds_fence();
+    // prefetch the next scenario of this wave
+    const int sn = s + waves_total;
+    if (sn < a.B) {
+#pragma unroll
+      for (int q = 0; q < CPL; ++q) { const int j = lane + 64 * q; xr[q] = (j < n) ? a.X[(size_t)sn * n + j] : 0.0; }
+#pragma unroll
+      for (int q = 0; q < RPL; ++q) { const int i = lane + 64 * q; yr[q] = (i < m) ? a.Y[(size_t)sn * m + i] : 0.0; }
+    }
     double axv[RPL], atyv[CPL];
-    ell_product<RPL>(axv, ellr_val, ellr_idx, P.Wr, xb, lane, P.long_r, tailr_val, tailr_idx);
-    ell_product<CPL>(atyv, ellc_val, ellc_idx, P.Wc, yb, lane, P.long_c, tailc_val, tailc_idx);
+    ell_product<RPL, LONG>(axv, ellr, P.Wr, xb, lane, P.long_r, tailr);
+    ell_product<CPL, LONG>(atyv, ellc, P.Wc, yb, lane, P.long_c, tailc);
 #pragma unroll
     for (int q = 0; q < RPL; ++q) { const int i = lane + 64 * q; if (i < m) a.AX[(size_t)s * m + i] = axv[q]; }
 #pragma unroll
@@ -384,18 +552,24 @@ __global__ void __launch_bounds__(512) spmv_step_kernel(SpmvArgs a) {
 // ---- launch tables ------------------------------------------------------------------------------------------
 template <int CPL, int RPL>
 static hipError_t launch_solve_t(const SolveArgs &a, dim3 grid, dim3 block, size_t lds, hipStream_t st) {
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&pdlp_solve_kernel<CPL, RPL>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  const bool lng = a.P.long_c.count > 0 || a.P.long_r.count > 0;
+  const void *fn = lng ? reinterpret_cast<const void *>(&pdlp_solve_kernel<CPL, RPL, true>)
+                       : reinterpret_cast<const void *>(&pdlp_solve_kernel<CPL, RPL, false>);
+  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL((pdlp_solve_kernel<CPL, RPL>), grid, block, lds, st, a);
+  if (lng) hipLaunchKernelGGL((pdlp_solve_kernel<CPL, RPL, true>), grid, block, lds, st, a);
+  else hipLaunchKernelGGL((pdlp_solve_kernel<CPL, RPL, false>), grid, block, lds, st, a);
   return hipGetLastError();
 }
 template <int CPL, int RPL>
 static hipError_t launch_spmv_t(const SpmvArgs &a, dim3 grid, dim3 block, size_t lds, hipStream_t st) {
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&spmv_step_kernel<CPL, RPL>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  const bool lng = a.P.long_c.count > 0 || a.P.long_r.count > 0;
+  const void *fn = lng ? reinterpret_cast<const void *>(&spmv_step_kernel<CPL, RPL, true>)
+                       : reinterpret_cast<const void *>(&spmv_step_kernel<CPL, RPL, false>);
+  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL((spmv_step_kernel<CPL, RPL>), grid, block, lds, st, a);
+  if (lng) hipLaunchKernelGGL((spmv_step_kernel<CPL, RPL, true>), grid, block, lds, st, a);
+  else hipLaunchKernelGGL((spmv_step_kernel<CPL, RPL, false>), grid, block, lds, st, a);
   return hipGetLastError();
 }
 
@@ -426,6 +600,28 @@ static hipError_t launch_spmv_t(const SpmvArgs &a, dim3 grid, dim3 block, size_t
 
 hipError_t launch_solve(int cpl, int rpl, const SolveArgs &a, dim3 grid, dim3 block, size_t lds, hipStream_t st) {
   DSP_FOR_CPL(launch_solve_t)
+}
+
+// resident blocks per CU of the solve kernel for a block shape (register- and LDS-limited): the "launch" is dry
+template <int CPL, int RPL>
+static hipError_t occupancy_solve_t(const SolveArgs &a, dim3 grid, dim3 block, size_t lds, hipStream_t) {
+  const bool lng = a.P.long_c.count > 0 || a.P.long_r.count > 0;
+  const void *fn = lng ? reinterpret_cast<const void *>(&pdlp_solve_kernel<CPL, RPL, true>)
+                       : reinterpret_cast<const void *>(&pdlp_solve_kernel<CPL, RPL, false>);
+  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  int nb = 0;
+  e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, (int)block.x, lds);
+  *reinterpret_cast<int *>(a.queue) = nb;      // host pointer smuggled through the (unused) queue field
+  (void)grid;
+  return e;
+}
+hipError_t occupancy_solve(int cpl, int rpl, const SolveArgs &a0, int block_threads, size_t lds, int *blocks_per_cu) {
+  SolveArgs a = a0;
+  a.queue = blocks_per_cu;
+  dim3 grid(1), block(block_threads);
+  hipStream_t st = nullptr;
+  DSP_FOR_CPL(occupancy_solve_t)
 }
 hipError_t launch_spmv(int cpl, int rpl, const SpmvArgs &a, dim3 grid, dim3 block, size_t lds, hipStream_t st) {
   DSP_FOR_CPL(launch_spmv_t)

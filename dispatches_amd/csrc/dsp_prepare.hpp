@@ -94,12 +94,14 @@ inline double spectral_norm(const HostCSR &A, const HostCSR &AT, int iters = 300
 }
 
 // Lane-major ELL of a CSR whose "rows" are the vectors owned by lanes: vector v is owned by lane v % 64,
-// slot v / 64.  Entry (slot, e, lane) lives at ((slot*W + e)*64 + lane).  Vectors with more than W entries are
-// moved WHOLE to the long list (their ELL entries stay zero).
+// slot v / 64.  Entry (e, slot, lane) lives at ((e*slots + slot)*64 + lane): for a fixed e the `slots` entries of a
+// lane are independent multiply-add chains (instruction-level parallelism inside the wave).  Vectors with more than
+// W entries are moved WHOLE to the long list (their ELL entries stay zero).  idx = element index of the multiplied
+// vector; the C ABI turns it into a byte offset when it packs the device entries.
 struct LaneELL {
   int slots = 0, W = 0;
-  std::vector<double> val;       // [slots*W*64]
-  std::vector<uint16_t> idx;     // [slots*W*64] element index into the gathered vector
+  std::vector<double> val;       // [W*slots*64]
+  std::vector<uint16_t> idx;     // [W*slots*64]
   // long vectors
   std::vector<int32_t> long_owner;   // vector id
   std::vector<int32_t> long_start;   // offset into tail arrays (multiple of 64)
@@ -130,7 +132,7 @@ inline LaneELL build_lane_ell(const HostCSR &M, int slots) {
     int lane = v & 63, slot = v >> 6;
     if (len[v] <= E.W) {
       for (int e = 0; e < len[v]; ++e) {
-        size_t at = ((size_t)(slot * E.W + e)) * 64 + lane;
+        size_t at = ((size_t)(e * slots + slot)) * 64 + lane;
         E.val[at] = M.val[M.ptr[v] + e];
         E.idx[at] = (uint16_t)M.idx[M.ptr[v] + e];
       }

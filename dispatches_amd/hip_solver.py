@@ -21,10 +21,26 @@ _lib = None
 
 
 class DspOptions(C.Structure):
-    _fields_ = [("eps_rel", C.c_double), ("max_iter", C.c_int32), ("check_every", C.c_int32),
+    _fields_ = [("eps_rel", C.c_double), ("eps_obj", C.c_double), ("max_iter", C.c_int32), ("check_every", C.c_int32),
                 ("restart_sufficient", C.c_double), ("restart_necessary", C.c_double),
                 ("restart_artificial", C.c_double), ("pid_kp", C.c_double), ("max_dlog_weight", C.c_double),
-                ("step_scale", C.c_double), ("ruiz_iters", C.c_int32), ("waves_per_block", C.c_int32)]
+                ("step_scale", C.c_double), ("jump_steady", C.c_double), ("jump_tol", C.c_double),
+                ("jump_min", C.c_double), ("ray_jumps", C.c_int32), ("ruiz_iters", C.c_int32),
+                ("waves_per_block", C.c_int32), ("reserved", C.c_int32)]
+
+
+class DspBatch(C.Structure):
+    """dsp_batch of include/dsp_hip.h: device pointers + element strides of one call's B scenarios."""
+    _fields_ = [("B", C.c_int32), ("reserved", C.c_int32),
+                ("c", C.c_void_p), ("c_stride", C.c_int64),
+                ("var_lb", C.c_void_p), ("var_lb_stride", C.c_int64),
+                ("var_ub", C.c_void_p), ("var_ub_stride", C.c_int64),
+                ("row_lb", C.c_void_p), ("row_lb_stride", C.c_int64),
+                ("row_ub", C.c_void_p), ("row_ub_stride", C.c_int64),
+                ("obj_offset", C.c_void_p), ("obj_offset_stride", C.c_int64),
+                ("x0", C.c_void_p), ("y0", C.c_void_p), ("primal_weight", C.c_void_p),
+                ("x", C.c_void_p), ("y", C.c_void_p), ("obj", C.c_void_p),
+                ("status", C.c_void_p), ("iters", C.c_void_p), ("jumps", C.c_void_p)]
 
 
 class DspStats(C.Structure):
@@ -61,8 +77,7 @@ def load_library(path: Optional[str] = None):
     lib.dsp_default_options.restype = None
     lib.dsp_create.argtypes = [C.POINTER(DspLpDesc), C.c_int, C.POINTER(DspOptions), C.POINTER(vp)]
     lib.dsp_create.restype = C.c_int
-    lib.dsp_solve.argtypes = [vp, i32, dp, i64, dp, i64, dp, i64, dp, i64, dp, i64, dp, dp, C.POINTER(DspOptions),
-                              dp, dp, dp, dp, dp, C.POINTER(DspStats), C.c_int, vp]
+    lib.dsp_solve.argtypes = [vp, C.POINTER(DspBatch), C.POINTER(DspOptions), C.POINTER(DspStats), C.c_int, vp]
     lib.dsp_solve.restype = C.c_int
     lib.dsp_spmv_step.argtypes = [vp, i32, dp, dp, dp, dp, vp]
     lib.dsp_spmv_step.restype = C.c_int
@@ -157,8 +172,9 @@ class DeviceLP:
         return t.data_ptr(), width
 
     def solve(self, B, c, lb=None, ub=None, rlo=None, rhi=None, x0=None, y0=None, options=None, out=None,
-              sync_stats=True):
-        """All arguments are CUDA(HIP) float64 torch tensors; returns dict of output tensors (+ stats)."""
+              sync_stats=True, obj_offset=None, primal_weight=None):
+        """All arguments are CUDA(HIP) float64 torch tensors; returns dict of output tensors (+ stats).
+        obj_offset: [B] objective constants (scale of the eps_obj tests); primal_weight: [B] in/out."""
         import torch
 
         n, m = self.lp.n, self.lp.m
@@ -168,20 +184,32 @@ class DeviceLP:
                        y=torch.empty((B, max(m, 1)), dtype=torch.float64, device=dev),
                        obj=torch.empty(B, dtype=torch.float64, device=dev),
                        status=torch.empty(B, dtype=torch.int32, device=dev),
-                       iters=torch.empty(B, dtype=torch.int32, device=dev))
-        pc, sc = self._ptr_stride(c, n)
-        plb, slb = self._ptr_stride(lb, n)
-        pub, sub = self._ptr_stride(ub, n)
-        prl, srl = self._ptr_stride(rlo, m)
-        prh, srh = self._ptr_stride(rhi, m)
+                       iters=torch.empty(B, dtype=torch.int32, device=dev),
+                       jumps=torch.empty(B, dtype=torch.int32, device=dev))
+        bt = DspBatch()
+        bt.B = B
+        bt.c, bt.c_stride = self._ptr_stride(c, n)
+        bt.var_lb, bt.var_lb_stride = self._ptr_stride(lb, n)
+        bt.var_ub, bt.var_ub_stride = self._ptr_stride(ub, n)
+        bt.row_lb, bt.row_lb_stride = self._ptr_stride(rlo, m)
+        bt.row_ub, bt.row_ub_stride = self._ptr_stride(rhi, m)
+        if obj_offset is not None:
+            assert obj_offset.is_cuda and obj_offset.element_size() == 8 and obj_offset.numel() in (1, B)
+            bt.obj_offset, bt.obj_offset_stride = obj_offset.data_ptr(), (1 if obj_offset.numel() == B and B > 1 else 0)
+        bt.x0 = x0.data_ptr() if x0 is not None else None
+        bt.y0 = y0.data_ptr() if y0 is not None else None
+        if primal_weight is not None:
+            assert primal_weight.is_cuda and primal_weight.element_size() == 8 and primal_weight.numel() == B
+            bt.primal_weight = primal_weight.data_ptr()
+        bt.x, bt.y, bt.obj = out["x"].data_ptr(), out["y"].data_ptr(), out["obj"].data_ptr()
+        bt.status, bt.iters = out["status"].data_ptr(), out["iters"].data_ptr()
+        bt.jumps = out["jumps"].data_ptr() if "jumps" in out else None
         stats = DspStats()
         stream = torch.cuda.current_stream(dev).cuda_stream
-        rc = self.lib.dsp_solve(self.handle, B, pc, sc, plb, slb, pub, sub, prl, srl, prh, srh,
-                                x0.data_ptr() if x0 is not None else None, y0.data_ptr() if y0 is not None else None,
-                                C.byref(options) if options is not None else None,
-                                out["x"].data_ptr(), out["y"].data_ptr(), out["obj"].data_ptr(),
-                                out["status"].data_ptr(), out["iters"].data_ptr(), C.byref(stats),
-                                1 if sync_stats else 0, C.c_void_p(stream))
+        if os.environ.get('DSP_DEBUG'):
+            print('[py] ptrs', {f[0]: (hex(getattr(bt, f[0])) if isinstance(getattr(bt, f[0]), int) and f[0] not in ('B',) and not f[0].endswith('stride') else getattr(bt, f[0])) for f in bt._fields_}, flush=True)
+        rc = self.lib.dsp_solve(self.handle, C.byref(bt), C.byref(options) if options is not None else None,
+                                C.byref(stats), 1 if sync_stats else 0, C.c_void_p(stream))
         _check(self.lib, rc, "dsp_solve")
         self.last_stats = stats
         out["stats"] = stats
@@ -245,12 +273,14 @@ class HipPdlpSolver:
         if warm_start and model.x is not None and model.y is not None and model.x.shape == (B, model.lp.n):
             x0, y0 = up(model.x), up(model.y)
         out = dlp.solve(B, up(model.c), up(lb), up(ub), up(rlo) if model.lp.m else None,
-                        up(rhi) if model.lp.m else None, x0=x0, y0=y0, options=self.options)
+                        up(rhi) if model.lp.m else None, x0=x0, y0=y0, options=self.options,
+                        obj_offset=up(np.broadcast_to(np.asarray(model.c0, np.float64), (B,))))
         st = out["stats"]
         self.last_stats = st
         status = out["status"].cpu().numpy()
         model.store_solution(out["x"].cpu().numpy(), out["y"].cpu().numpy()[:, :model.lp.m],
                              out["obj"].cpu().numpy() + model.c0, status, out["iters"].cpu().numpy())
+        model.jumps = out["jumps"].cpu().numpy()
         if tee:
             print(f"[dsp_hip] B={B} n={model.lp.n} m={model.lp.m} nnz={model.lp.nnz} optimal={st.n_optimal}/{B} "
                   f"iters(sum/max)={st.total_iterations}/{st.max_iterations} kernel={st.kernel_ms:.3f} ms "

@@ -8,11 +8,11 @@
  *  dispatches/workflow/parametrized_bidder.py:73-119).  Where Pyomo writes an LP/NL file and spawns
  * cbc / ipopt, a binding of this library hands over the flattened standard form
  *
- *     min c.x   s.t.  row_lb <= A x <= row_ub,   var_lb <= x <= var_ub          (one scenario)
+ *     min c.x + c0   s.t.  row_lb <= A x <= row_ub,   var_lb <= x <= var_ub          (one scenario)
  *
  * once (dsp_create: the CSR of A shared by every scenario) and then, per call, B dense per-scenario vectors
  * (dsp_solve).  Plain C, opaque handle, caller-owned buffers, int return codes, stream-ordered.
- * All per-scenario pointers passed to dsp_solve / dsp_spmv_step are DEVICE pointers (e.g. torch.Tensor.data_ptr());
+ * All per-scenario pointers in dsp_batch / dsp_spmv_step are DEVICE pointers (e.g. torch.Tensor.data_ptr());
  * everything in dsp_lp_desc is a HOST pointer that is copied during dsp_create.
  */
 #ifndef DSP_HIP_H
@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define DSP_VERSION 1
+#define DSP_VERSION 2
 
 /* return codes (0 = ok, < 0 = API misuse / HIP error; text via dsp_strerror) */
 #define DSP_OK                 0
@@ -37,7 +37,7 @@ extern "C" {
 /* per-scenario termination status written to status[B] */
 #define DSP_STATUS_OPTIMAL            0
 #define DSP_STATUS_ITERATION_LIMIT    1
-#define DSP_STATUS_PRIMAL_INFEASIBLE  2   /* reserved: not detected by v1 (dispatch LPs carry slack columns) */
+#define DSP_STATUS_PRIMAL_INFEASIBLE  2   /* reserved: not detected (dispatch LPs carry slack columns)       */
 #define DSP_STATUS_DUAL_INFEASIBLE    3   /* reserved */
 #define DSP_STATUS_NUMERICAL          4   /* NaN / Inf met in the iteration                                  */
 
@@ -53,21 +53,53 @@ typedef struct dsp_lp_desc {
   const double  *A_val;      /* [nnz]  */
 } dsp_lp_desc;
 
-/* Solver options (restarted, reflected Halpern PDHG).  Zero-initialise then call
- * dsp_default_options() to get the defaults. */
+/* Solver options (restarted, reflected Halpern PDHG with ray jumps).  Fill with
+ * dsp_default_options() and override fields. */
 typedef struct dsp_options {
-  double  eps_rel;           /* relative KKT tolerance (primal, dual, gap)          default 1e-9  */
-  int32_t max_iter;          /* iteration limit per scenario                        default 200000 */
-  int32_t check_every;       /* restart / termination test period                   default 32    */
-  double  restart_sufficient;/* beta_1: restart when r <= beta_1 r0                 default 0.2   */
-  double  restart_necessary; /* beta_2: ... or r <= beta_2 r0 and r increased       default 0.8   */
-  double  restart_artificial;/* beta_3: ... or k >= beta_3 * total iterations       default 0.36  */
-  double  pid_kp;            /* proportional gain of the primal-weight controller   default 0.7   */
-  double  max_dlog_weight;   /* clamp on |delta log(primal weight)| per restart     default log(30) */
-  double  step_scale;        /* eta = step_scale / ||A_scaled||_2                   default 0.998 */
-  int32_t ruiz_iters;        /* Ruiz passes before Pock-Chambolle (create time)     default 10    */
-  int32_t waves_per_block;   /* scenarios per workgroup (1 wave each); 0 = auto                    */
+  double  eps_rel;           /* relative KKT tolerance (primal, dual, gap)            default 1e-9   */
+  double  eps_obj;           /* objective accuracy: |gap| and |y|.viol <= eps_obj (1 + |c.x + c0|);
+                                0 disables the two extra tests                        default 1e-7   */
+  int32_t max_iter;          /* iteration limit per scenario                          default 200000 */
+  int32_t check_every;       /* restart / termination test period                     default 32     */
+  double  restart_sufficient;/* beta_1: restart when r <= beta_1 r0                   default 0.2    */
+  double  restart_necessary; /* beta_2: ... or r <= beta_2 r0 and r increased         default 0.8    */
+  double  restart_artificial;/* beta_3: ... or k >= beta_3 * total iterations         default 0.36   */
+  double  pid_kp;            /* proportional gain of the primal-weight controller     default 0.5    */
+  double  max_dlog_weight;   /* clamp on |delta log(primal weight)| per restart       default log(30)*/
+  double  step_scale;        /* eta = step_scale / ||A_scaled||_2                     default 0.998  */
+  double  jump_steady;       /* ray jump: attempt when |r - r_prev| <= jump_steady r  default 0.05   */
+  double  jump_tol;          /* ... and ||T(T z)-2T z+z|| <= jump_tol ||T(T z)-T z||  default 1e-3   */
+  double  jump_min;          /* ... and the ray stays >= jump_min steps in its piece  default 4      */
+  int32_t ray_jumps;         /* 1 = enable ray jumps                                  default 1      */
+  int32_t ruiz_iters;        /* Ruiz passes before Pock-Chambolle (create time)       default 10     */
+  int32_t waves_per_block;   /* scenarios per workgroup (1 wave each); 0 = auto                      */
+  int32_t reserved;
 } dsp_options;
+
+/* The per-call data of B scenarios.  c is required; every other input may be NULL (= no bound: -inf / +inf,
+ * offset 0) and each has its own scenario stride in ELEMENTS: stride 0 broadcasts one template vector to all
+ * scenarios, stride n (or m, or 1 for obj_offset) is a dense array.  x0 / y0 (optional warm start) and x / y use
+ * dense strides n / m. */
+typedef struct dsp_batch {
+  int32_t B;
+  int32_t reserved;
+  const double *c;          int64_t c_stride;
+  const double *var_lb;     int64_t var_lb_stride;
+  const double *var_ub;     int64_t var_ub_stride;
+  const double *row_lb;     int64_t row_lb_stride;
+  const double *row_ub;     int64_t row_ub_stride;
+  const double *obj_offset; int64_t obj_offset_stride;  /* c0: only used to scale the eps_obj tests */
+  const double *x0;         /* [B][n] or NULL */
+  const double *y0;         /* [B][m] or NULL */
+  double  *primal_weight;   /* [B] in/out or NULL: > 0 on entry = initial primal weight of the scenario (rolling-
+                               horizon carry-over), anything else = automatic; holds the final weight on exit */
+  double  *x;               /* [B][n]  primal solution                                              */
+  double  *y;               /* [B][m]  row duals (sign: y >= 0 active lower side, y <= 0 upper)     */
+  double  *obj;             /* [B]     c.x at the returned x (the caller adds its own c0)           */
+  int32_t *status;          /* [B]     DSP_STATUS_*                                                 */
+  int32_t *iters;           /* [B] or NULL   iterations used                                        */
+  int32_t *jumps;           /* [B] or NULL   ray jumps taken                                        */
+} dsp_batch;
 
 /* Aggregate statistics of one dsp_solve call (filled after the call's stream work completes when
  * `sync_stats` is non-zero; otherwise only the launch geometry is filled). */
@@ -86,26 +118,15 @@ typedef struct dsp_stats {
 void dsp_default_options(dsp_options *opt);
 
 /* Build the shared, device-resident problem data for one (flowsheet, horizon): diagonal preconditioner
- * (Ruiz + Pock-Chambolle), scaled A in ELL + long-vector form for A and A^T, step size.  `opt` may be NULL. */
+ * (Ruiz + Pock-Chambolle), scaled A in lane-major ELL + long-vector form for A and A^T, step size.
+ * `opt` may be NULL. */
 int dsp_create(const dsp_lp_desc *desc, int device, const dsp_options *opt, dsp_handle **out);
 
-/* Solve B scenarios.  c is required; every other input may be NULL (= no bound: -inf / +inf) and each has its
- * own scenario stride in ELEMENTS: stride 0 broadcasts one template vector to all scenarios, stride n (or m)
- * is a dense [B][n] array.  x0 / y0 (optional warm start, may be NULL) and x / y use dense strides n / m.
- *   obj[B]    c.x at the returned x (the caller adds its own objective constant)
- *   status[B] DSP_STATUS_*        iters[B] iterations used (may be NULL)
- * hipStream: a hipStream_t (NULL = default stream).  The call enqueues work and returns; if `stats` is non-NULL
- * and sync_stats != 0 it synchronises the stream and fills the statistics. */
-int dsp_solve(dsp_handle *h, int32_t B,
-              const double *c, int64_t c_stride,
-              const double *var_lb, int64_t var_lb_stride,
-              const double *var_ub, int64_t var_ub_stride,
-              const double *row_lb, int64_t row_lb_stride,
-              const double *row_ub, int64_t row_ub_stride,
-              const double *x0, const double *y0,
-              const dsp_options *opt,
-              double *x, double *y, double *obj, int32_t *status, int32_t *iters,
-              dsp_stats *stats, int sync_stats, void *hipStream);
+/* Solve the B scenarios of `batch`.  hipStream: a hipStream_t (NULL = default stream).  The call enqueues
+ * work and returns; if `stats` is non-NULL and sync_stats != 0 it synchronises the stream and fills the
+ * statistics.  `opt` may be NULL (= the options given to dsp_create). */
+int dsp_solve(dsp_handle *h, const dsp_batch *batch, const dsp_options *opt, dsp_stats *stats, int sync_stats,
+              void *hipStream);
 
 /* The PDLP SpMV step in streaming form (vectors in HBM): AX[B][m] = A X[b],  ATY[B][n] = A^T Y[b] with the
  * UNSCALED A.  This is the kernel the HBM roofline of SURVEY.md 8(d) is quoted on

@@ -1,0 +1,170 @@
+"""Algorithm lab (development tool; NOT product, NOT oracle): batched numpy r2HPDHG with switchable primal-weight /
+restart rules, used to pick the rules the HIP kernel implements.  python tools/pdlp_lab.py <workload> <B> [k=v ...]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import numpy as np
+import scipy.sparse as sp
+import pdlp_proto as pp
+
+fin = lambda a: np.where(np.isfinite(a), a, 0.0)
+
+
+def solve(P, eps=1e-9, max_iter=60000, check=32, wrule="pid", kp=0.7, maxdl=np.log(30), r0_mode="k1",
+          beta=(0.2, 0.8, 0.36), eta_scale=0.998, n_ruiz=10, wclamp=None, bal_gain=0.25, bal_thresh=10.0,
+          c0_gap=True, verbose=False, colscale=None, stall=0, stall_frac=0.5, kp_decay=0.5, xinit=0, term=0, eps_obj=1e-7, jump=0, jtol=1e-2, jsteady=0.05, jmin=4.0, winit=0.0):
+    lp = P.lp
+    A0 = P.A
+    if colscale is not None:
+        A0 = sp.csr_matrix(A0 @ sp.diags(colscale))
+    As, dr, dc = pp.ruiz_pc_scaling(A0, n_ruiz=n_ruiz)
+    if colscale is not None:
+        dc = dc * colscale
+    AsT = sp.csr_matrix(As.T)
+    B, n, m = P.c.shape[0], lp.n, lp.m
+    c = P.c * dc; lb, ub = P.lb / dc, P.ub / dc; rlo, rhi = P.rlo * dr, P.rhi * dr
+    eta = eta_scale / pp.spectral_norm(As)
+    qs = np.sqrt(np.sum(np.maximum(np.abs(fin(rlo)), np.abs(fin(rhi))) ** 2, 1)); cs = np.linalg.norm(c, axis=1)
+    w = np.where((cs > 1e-10) & (qs > 1e-10), cs / np.maximum(qs, 1e-300), 1.0)
+    if winit:
+        w = np.full(B, winit)
+    w0 = w.copy()
+    x = np.clip(np.zeros((B, n)), lb, ub)
+    if xinit:
+        x = np.where((c < 0) & np.isfinite(ub), ub, x)
+    y = np.zeros((B, m)); x0, y0 = x.copy(), y.copy()
+    k = np.zeros(B); r0 = np.full(B, np.inf); rprev = np.full(B, np.inf)
+    done = np.zeros(B, bool); iters = np.full(B, max_iter); Xo = np.zeros((B, n)); Yo = np.zeros((B, m)); nrs = np.zeros(B, int)
+    c0 = P.c0 if c0_gap else 0.0
+    best = np.full(B, np.inf); wbest = w.copy(); itbest = np.zeros(B); kpv = np.full(B, kp); nrev = np.zeros(B, int)
+    max_iter = int(max_iter)
+    njump = np.zeros(B, int); jtot = np.zeros(B)
+    for it in range(max_iter):
+        tau = (eta / w)[:, None]; sig = (eta * w)[:, None]
+        xp = np.clip(x - tau * (c - y @ As), lb, ub)
+        Axb = (2 * xp - x) @ AsT
+        wv = y - sig * Axb
+        yp = wv + np.clip(-wv, sig * rlo, sig * rhi)
+        k += 1
+        chk = (it + 1) % check == 0
+        need = (k == 1) if r0_mode == "k1" else np.zeros(B, bool)
+        if chk or need.any():
+            dx, dy = xp - x, yp - y
+            r = np.sqrt(np.maximum(w * np.sum(dx * dx, 1) - 2 * eta * np.sum(dy * (dx @ AsT), 1) + np.sum(dy * dy, 1) / w, 0))
+            r0 = np.where(need, r, r0); rprev = np.where(need, r, rprev)
+        rs = np.zeros(B, bool); jumped = np.zeros(B, bool)
+        if chk:
+            rp, rd, rg, po, do = pp.kkt_unscaled(P, xp * dc, yp * dr)
+            if c0_gap:
+                rg = np.abs(po - do) / (1 + np.abs(po) + np.abs(do))      # po/do already include c0
+            else:
+                rg = np.abs(po - do) / (1 + np.abs(po - P.c0) + np.abs(do - P.c0))
+            if term:
+                Xu, Yu = xp * dc, yp * dr
+                AX = Xu @ P.A.T
+                viol = np.maximum(P.rlo - AX, 0) + np.maximum(AX - P.rhi, 0)
+                ierr = np.sum(np.abs(Yu) * viol, 1)
+                scale = np.sum(np.abs(P.c * Xu), 1)
+                gap = np.abs(po - do)
+                okg = gap <= np.maximum(eps_obj * (1 + np.abs(po)), 1e-12 * scale)
+                oki = ierr <= np.maximum(eps_obj * (1 + np.abs(po)), 1e-12 * scale)
+                rg = np.where(okg & oki, rg, np.maximum(rg, 2 * eps))
+            conv = (rp <= eps) & (rd <= eps) & (rg <= eps) & ~done
+            Xo[conv], Yo[conv] = (xp * dc)[conv], (yp * dr)[conv]; iters[conv] = it + 1; done |= conv
+            if done.all():
+                break
+            err = np.maximum(np.maximum(rp, rd), rg)
+            imp = err < 0.5 * best
+            best = np.where(imp, err, best); wbest = np.where(imp, w, wbest); itbest = np.where(imp, it + 1, itbest)
+            first = ~np.isfinite(r0)
+            r0 = np.where(first, r, r0)
+            rs = ~first & ((r <= beta[0] * r0) | ((r <= beta[1] * r0) & (r > rprev)) | (k >= beta[2] * (it + 1)))
+            steady = (np.abs(r - rprev) <= jsteady * r) & (k >= 2 * check) & ~done & ~rs if jump else np.zeros(B, bool)
+            rprev = r
+            if jump and steady.any():
+                gx0 = x - tau * (c - y @ As); gy0 = wv
+                gx1 = xp - tau * (c - yp @ As); x2 = np.clip(gx1, lb, ub)
+                gy1 = yp - sig * ((2 * x2 - xp) @ AsT); y2 = gy1 + np.clip(-gy1, sig * rlo, sig * rhi)
+                v1x, v1y, v2x, v2y = xp - x, yp - y, x2 - xp, y2 - yp
+                nv = lambda a, b: np.sqrt(w * np.sum(a * a, 1) + np.sum(b * b, 1) / w)
+                trans = steady & (nv(v2x - v1x, v2y - v1y) <= jtol * nv(v2x, v2y)) & (nv(v2x, v2y) > 0)
+                if trans.any():
+                    dgx = gx1 - gx0; dgy = -(gy1 - gy0); g = -gy1; lo_, hi_ = sig * rlo, sig * rhi
+                    big = 1e300
+                    def ratio(gv, dg, lo, hi):
+                        with np.errstate(divide='ignore', invalid='ignore'):
+                            a_up = np.where(dg > 0, np.where(gv < lo, (lo - gv) / dg, np.where(gv <= hi, (hi - gv) / dg, big)), big)
+                            a_dn = np.where(dg < 0, np.where(gv > hi, (hi - gv) / dg, np.where(gv >= lo, (lo - gv) / dg, big)), big)
+                        a = np.minimum(a_up, a_dn)
+                        return np.where(np.isfinite(a), a, big)
+                    ax_ = ratio(gx1, dgx, lb, ub).min(1); ay_ = ratio(g, dgy, lo_, hi_).min(1)
+                    alpha = np.minimum(ax_, ay_)
+                    dojump = trans & (alpha >= jmin) & (alpha < 1e200)
+                    if dojump.any():
+                        a = np.where(dojump, np.floor(alpha) - 1.0, 0.0)[:, None]
+                        xn = np.clip(x2 + a * v2x, lb, ub); yn = y2 + a * v2y
+                        m_ = dojump[:, None]
+                        x = np.where(m_, xn, x); y = np.where(m_, yn, y); x0 = np.where(m_, xn, x0); y0 = np.where(m_, yn, y0)
+                        xp = np.where(m_, xn, xp); yp = np.where(m_, yn, yp)
+                        k = np.where(dojump, 0, k); r0 = np.where(dojump, np.inf, r0); rprev = np.where(dojump, np.inf, rprev)
+                        njump += dojump; jtot += np.where(dojump, alpha, 0)
+                        jumped = dojump
+                        if verbose: print(it + 1, "jump", np.nonzero(dojump)[0], alpha[dojump])
+            if rs.any():
+                ddx = np.linalg.norm(xp - x0, axis=1); ddy = np.linalg.norm(yp - y0, axis=1)
+                ok = rs & (ddx > 1e-14) & (ddy > 1e-14)
+                e = np.where(ok, np.log(w) + np.log(np.maximum(ddx, 1e-300)) - np.log(np.maximum(ddy, 1e-300)), 0.0)
+                dl = np.clip(-kpv * e, -maxdl, maxdl)
+                if wrule == "balance":
+                    ratio = np.log(np.maximum(rp, 1e-300) / np.maximum(rd, 1e-300))
+                    dl = np.clip(bal_gain * ratio, -maxdl, maxdl)
+                elif wrule == "hybrid":
+                    ratio = np.maximum(rp, 1e-300) / np.maximum(rd, 1e-300)
+                    dl = np.where((ratio > bal_thresh) & (dl < 0), 0.0, dl)
+                    dl = np.where((ratio < 1 / bal_thresh) & (dl > 0), 0.0, dl)
+                elif wrule == "hybrid2":
+                    ratio = np.log(np.maximum(rp, 1e-300) / np.maximum(rd, 1e-300))
+                    bad = ((ratio > np.log(bal_thresh)) & (dl < 0)) | ((ratio < -np.log(bal_thresh)) & (dl > 0))
+                    dl = np.where(bad, np.clip(bal_gain * ratio, -maxdl, maxdl), dl)
+                logw = np.log(w) + np.where(rs, dl, 0.0)
+                if stall:
+                    st = rs & ((it + 1 - itbest) > stall + stall_frac * itbest)
+                    logw = np.where(st, np.log(wbest), logw); kpv = np.where(st, kpv * kp_decay, kpv); itbest = np.where(st, it + 1, itbest); nrev += st
+                if wclamp is not None:
+                    logw = np.clip(logw, np.log(w0) - np.log(wclamp), np.log(w0) + np.log(wclamp))
+                w = np.exp(logw)
+                m_ = rs[:, None]
+                x = np.where(m_, xp, x); y = np.where(m_, yp, y); x0 = np.where(m_, xp, x0); y0 = np.where(m_, yp, y0)
+                k = np.where(rs, 0, k); r0 = np.where(rs, np.inf, r0); rprev = np.where(rs, np.inf, rprev); nrs += rs
+        keep = ~(rs | jumped)
+        lam = ((k + 1) / (k + 2))[:, None]
+        x = np.where(keep[:, None], lam * (2 * xp - x) + (1 - lam) * x0, x)
+        y = np.where(keep[:, None], lam * (2 * yp - y) + (1 - lam) * y0, y)
+    Xo[~done], Yo[~done] = (xp * dc)[~done], (yp * dr)[~done]
+    solve.last_jumps = (njump, jtot); solve.last_w = w
+    return Xo, Yo, iters, nrs, done
+
+
+HARD = {"wind_battery_24h": [746, 1449, 2233, 2445, 2768], "wind_battery_48h": [527, 1216, 1847, 2636, 3147, 3562]}
+
+
+def subset(wl, nrand=int(os.environ.get("NRAND", 27)), seed=0, B=4096):
+    model, P = pp.build(wl, B)
+    rng = np.random.default_rng(seed)
+    ids = HARD.get(wl, []) + sorted(rng.choice(B, nrand, replace=False).tolist())
+    return ids, pp.Problem(P.lp, P.c[ids], P.lb[ids], P.ub[ids], P.rlo[ids], P.rhi[ids], P.c0[ids])
+
+
+if __name__ == "__main__":
+    wl = sys.argv[1]
+    ids, sub = subset(wl)
+    ref = np.array([pp.highs_obj(sub, i)[0] for i in range(len(ids))])
+    variants = [dict(a.split("=") for a in v.split(",") if a) for v in sys.argv[2:]] or [{}]
+    for kw in variants:
+        kw = {k: (v if k in ("wrule", "r0_mode") else float(v)) for k, v in kw.items()}
+        t = time.time()
+        X, Y, iters, nrs, done = solve(sub, **kw)
+        obj = np.sum(sub.c * X, 1) + sub.c0
+        err = np.abs(obj - ref) / np.maximum(1, np.abs(ref))
+        print(kw, f"done {done.sum()}/{len(ids)} mean {iters.mean():.0f} med {np.median(iters):.0f} max {iters.max()} "
+              f"hard {iters[:len(HARD.get(wl, []))]} jumps {solve.last_jumps[0].sum()} jsum {solve.last_jumps[1].sum():.0f} maxerr {err[done].max():.2e} t {time.time()-t:.1f}s", flush=True)
