@@ -129,6 +129,7 @@ void dsp_default_options(dsp_options *o) {
   o->pid_kp = 0.5;
   o->max_dlog_weight = std::log(30.0);
   o->step_scale = 0.998;
+  o->weight_guard = 4.0;
   o->jump_steady = 0.05;
   o->jump_tol = 1e-3;
   o->jump_min = 4.0;
@@ -191,7 +192,7 @@ int dsp_create(const dsp_lp_desc *d, int device, const dsp_options *opt, dsp_han
   A.idx.assign(d->A_colidx, d->A_colidx + d->nnz);
   A.val.assign(d->A_val, d->A_val + d->nnz);
   HostCSR Au = A;                                   // unscaled copy (streaming SpMV step)
-  equilibrate(A, h->opt.ruiz_iters, h->dr, h->dc);
+  equilibrate(A, h->opt.ruiz_iters, h->dr, h->dc, std::max(0, h->opt.geo_iters));
   HostCSR AT = transpose(A), ATu = transpose(Au);
   h->eta_unit = 1.0 / spectral_norm(A, AT, 500);
 

@@ -71,6 +71,11 @@ __device__ __forceinline__ double wave_min(double v) {
   for (int off = 32; off >= 1; off >>= 1) v = fmin(v, __shfl_xor(v, off, 64));
   return uniform(v);
 }
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
+  return uniform(v);
+}
 // N sums at once (independent shuffle chains interleave)
 template <int N>
 __device__ __forceinline__ void wave_sums(double (&a)[N]) {
@@ -193,6 +198,8 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
     double x[CPL], x0[CPL], c[CPL], lb[CPL], ub[CPL];
     double y[RPL], y0[RPL], rlo[RPL], rhi[RPL], ax[RPL], ax0[RPL];
     double nrm[4] = {0.0, 0.0, 0.0, 0.0};                // |q|^2 unscaled, |c|^2 unscaled, |q|^2 scaled, |c|^2 scaled
+    double cmax = 0.0, qmax = 0.0;                       // largest scaled |c_j| / finite scaled |row bound|
+    double bs2 = 0.0;                                    // sum of squared finite scaled column bounds
 #pragma unroll
     for (int q = 0; q < CPL; ++q) {
       const int j = lane + 64 * q;
@@ -206,6 +213,8 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
       ub[q] = uu / d;
       nrm[1] += cu * cu;
       nrm[3] += c[q] * c[q];
+      cmax = fmax(cmax, fabs(c[q]));
+      { const double lfs = finite_or_zero(lb[q]), ufs = finite_or_zero(ub[q]); bs2 += lfs * lfs + ufs * ufs; }
       const double lf = finite_or_zero(lu), uf = finite_or_zero(uu);
       nrm[0] += lf * lf + uf * uf;
       const double xs = (b.x0 && ok) ? b.x0[(size_t)s * n + j] / d : 0.0;
@@ -225,6 +234,7 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
       nrm[0] += big * big;
       const double bigs = fmax(fabs(finite_or_zero(rlo[q])), fabs(finite_or_zero(rhi[q])));
       nrm[2] += bigs * bigs;
+      qmax = fmax(qmax, bigs);
       double ys = (b.y0 && ok) ? b.y0[(size_t)s * m + i] / d : 0.0;
       // keep the warm start dual-feasible in sign
       if (!is_finite(rlo[q])) ys = fmin(ys, 0.0);
@@ -237,6 +247,16 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
     const double qs = sqrt(nrm[2]), cs = sqrt(nrm[3]);
     const double c0 = b.obj_offset ? b.obj_offset[(size_t)s * b.obj_offset_stride] : 0.0;
     double w = (cs > 1e-10 && qs > 1e-10) ? cs / qs : 1.0;       // primal weight
+    // Rounding guard: the primal step tau = eta / w amplifies the rounding error of (c - A^T y), about 1.1e-16 |c|_max,
+    // into x; once that noise reaches the primal tolerance the iteration stalls (seen when the dual has converged to
+    // machine precision and the movement-ratio controller keeps shrinking w).  Keep tau u |c|_max <= eps (1 + |q|) /
+    // guard (|q| = all finite row and column bounds), and symmetrically sigma u |q|_max <= eps (1 + |c|) / guard.
+    cmax = wave_max(cmax);
+    qmax = wave_max(qmax);
+    const double qall = sqrt(nrm[2] + wave_sum(bs2));       // row AND column bounds (the scale of the primal test)
+    const double w_lo = a.opt.weight_guard > 0.0 ? a.opt.weight_guard * eta * 1.1e-16 * cmax / (eps * (1.0 + qall)) : 0.0;
+    const double w_hi = (a.opt.weight_guard > 0.0 && qmax > 0.0)
+                            ? eps * (1.0 + cs) / (a.opt.weight_guard * eta * 1.1e-16 * qmax) : INFINITY;
     if (b.primal_weight) {
       const double wi = b.primal_weight[s];
       if (wi > 0.0 && is_finite(wi)) w = wi;
@@ -315,8 +335,9 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
         wave_lds_fence();
         double atyp[CPL];
         ell_product<CPL, LONG>(atyp, ellc, P.Wc, yb, lane, P.long_c, tailc);
-        // red: 0 pres^2, 1 dres^2, 2 pobj, 3 dobj, 4 sum|y| viol, 5 sum|c x|, 6 |dx|^2, 7 |dy|^2, 8 dy.A dx
-        double red[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        // red: 0 pres^2, 1 dres^2, 2 pobj, 3 dobj, 4 sum|y| viol, 5 sum|c x|, 6 |dx|^2, 7 |dy|^2, 8 dy.A dx,
+        //      9 sum|dual residual| |x|   (4 and 9 bound the objective error caused by the remaining infeasibility)
+        double red[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
         for (int q = 0; q < CPL; ++q) {
           const double rc = c[q] - atyp[q];
@@ -325,6 +346,7 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
           const int j = lane + 64 * q;
           const double dr_ = (rc - lp + lm) / ((j < n) ? P.col_scale[j] : 1.0);
           red[1] = fma(dr_, dr_, red[1]);
+          red[9] = fma(fabs(rc - lp + lm), fabs(xp[q]), red[9]);
           const double cx = c[q] * xp[q];
           red[2] += cx;
           red[5] += fabs(cx);
@@ -345,7 +367,7 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
           red[7] = fma(dy, dy, red[7]);
           red[8] = fma(dy, 0.5 * (axb[q] - ax[q]), red[8]);
         }
-        wave_sums<9>(red);
+        wave_sums<10>(red);
         const double po = red[2], dobj = red[3];
         pobj = po;
         const double r = sqrt(fmax(w * red[6] - 2.0 * eta * red[8] + red[7] / w, 0.0));
@@ -357,7 +379,7 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
         bool done = rp <= eps && rd <= eps && rg <= eps;
         if (done && eps_obj > 0.0) {
           const double lim = fmax(eps_obj * (1.0 + fabs(po + c0)), 1e-12 * red[5]);
-          done = gap <= lim && red[4] <= lim;
+          done = gap <= lim && red[4] <= lim && red[9] <= lim;
         }
         if (done) { status = DSP_STATUS_OPTIMAL; ++it; break; }
         // ---- restart test (r0 = residual at the first check after a restart) ----------------------------------
@@ -385,6 +407,7 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
             const double e = log(w) + log(ddx) - log(ddy);
             const double dl = clampd(-a.opt.pid_kp * e, -a.opt.max_dlog_weight, a.opt.max_dlog_weight);
             w *= exp(dl);
+            w = fmin(fmax(w, w_lo), fmax(w_hi, w_lo));
           }
 #pragma unroll
           for (int q = 0; q < CPL; ++q) { x[q] = xp[q]; x0[q] = xp[q]; }

@@ -41,7 +41,7 @@ inline HostCSR transpose(const HostCSR &A) {
 
 // Ruiz (inf-norm, `iters` passes) followed by Pock-Chambolle (alpha = 1).  A is scaled in place:
 // A <- diag(dr) A diag(dc).
-inline void equilibrate(HostCSR &A, int ruiz_iters, std::vector<double> &dr, std::vector<double> &dc) {
+inline void equilibrate(HostCSR &A, int ruiz_iters, std::vector<double> &dr, std::vector<double> &dc, int geo_iters = 0) {
   dr.assign(A.m, 1.0); dc.assign(A.n, 1.0);
   std::vector<double> rs(A.m), cs(A.n);
   auto apply = [&]() {
@@ -50,6 +50,27 @@ inline void equilibrate(HostCSR &A, int ruiz_iters, std::vector<double> &dr, std
     for (int i = 0; i < A.m; ++i) dr[i] *= rs[i];
     for (int j = 0; j < A.n; ++j) dc[j] *= cs[j];
   };
+  // optional geometric-mean passes: r_i = 1/sqrt(max_j|a_ij| min_j|a_ij|), then the same for columns
+  for (int it = 0; it < geo_iters; ++it) {
+    std::vector<double> mx(A.m, 0.0), mn(A.m, INFINITY);
+    for (int i = 0; i < A.m; ++i)
+      for (int p = A.ptr[i]; p < A.ptr[i + 1]; ++p) {
+        double a = std::fabs(A.val[p]);
+        if (a > 0) { mx[i] = std::max(mx[i], a); mn[i] = std::min(mn[i], a); }
+      }
+    for (int i = 0; i < A.m; ++i) rs[i] = mx[i] > 0 ? 1.0 / std::sqrt(mx[i] * mn[i]) : 1.0;
+    std::fill(cs.begin(), cs.end(), 1.0);
+    apply();
+    std::vector<double> cmx(A.n, 0.0), cmn(A.n, INFINITY);
+    for (int i = 0; i < A.m; ++i)
+      for (int p = A.ptr[i]; p < A.ptr[i + 1]; ++p) {
+        double a = std::fabs(A.val[p]);
+        if (a > 0) { cmx[A.idx[p]] = std::max(cmx[A.idx[p]], a); cmn[A.idx[p]] = std::min(cmn[A.idx[p]], a); }
+      }
+    for (int j = 0; j < A.n; ++j) cs[j] = cmx[j] > 0 ? 1.0 / std::sqrt(cmx[j] * cmn[j]) : 1.0;
+    std::fill(rs.begin(), rs.end(), 1.0);
+    apply();
+  }
   for (int it = 0; it < ruiz_iters; ++it) {
     std::fill(rs.begin(), rs.end(), 0.0); std::fill(cs.begin(), cs.end(), 0.0);
     for (int i = 0; i < A.m; ++i)

@@ -24,9 +24,9 @@ class DspOptions(C.Structure):
     _fields_ = [("eps_rel", C.c_double), ("eps_obj", C.c_double), ("max_iter", C.c_int32), ("check_every", C.c_int32),
                 ("restart_sufficient", C.c_double), ("restart_necessary", C.c_double),
                 ("restart_artificial", C.c_double), ("pid_kp", C.c_double), ("max_dlog_weight", C.c_double),
-                ("step_scale", C.c_double), ("jump_steady", C.c_double), ("jump_tol", C.c_double),
+                ("step_scale", C.c_double), ("weight_guard", C.c_double), ("jump_steady", C.c_double), ("jump_tol", C.c_double),
                 ("jump_min", C.c_double), ("ray_jumps", C.c_int32), ("ruiz_iters", C.c_int32),
-                ("waves_per_block", C.c_int32), ("reserved", C.c_int32)]
+                ("waves_per_block", C.c_int32), ("geo_iters", C.c_int32)]
 
 
 class DspBatch(C.Structure):
@@ -139,6 +139,7 @@ class DeviceLP:
         _check(self.lib, self.lib.dsp_create(C.byref(desc), device, C.byref(options) if options else None, C.byref(h)),
                "dsp_create")
         self.handle = h
+        self.options = options
         self.last_stats: Optional[DspStats] = None
 
     def close(self):
@@ -255,7 +256,10 @@ class HipPdlpSolver:
             self.options = default_options(**self._option_overrides)
         h = model.solve_handle
         if h is None or h.lp is not model.lp:
-            h = DeviceLP(model.lp, self.device, self.options)
+            # per-model-family preconditioner hints (e.g. geo_iters for tracking LPs), overridable by the user
+            hints = dict(getattr(model, "solver_hints", None) or {})
+            hints.update(self._option_overrides)
+            h = DeviceLP(model.lp, self.device, default_options(**hints))
             model.solve_handle = h
         return h
 
@@ -273,7 +277,7 @@ class HipPdlpSolver:
         if warm_start and model.x is not None and model.y is not None and model.x.shape == (B, model.lp.n):
             x0, y0 = up(model.x), up(model.y)
         out = dlp.solve(B, up(model.c), up(lb), up(ub), up(rlo) if model.lp.m else None,
-                        up(rhi) if model.lp.m else None, x0=x0, y0=y0, options=self.options,
+                        up(rhi) if model.lp.m else None, x0=x0, y0=y0, options=dlp.options,
                         obj_offset=up(np.broadcast_to(np.asarray(model.c0, np.float64), (B,))))
         st = out["stats"]
         self.last_stats = st

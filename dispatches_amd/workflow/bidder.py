@@ -131,6 +131,7 @@ class StochasticProgramBidder(AbstractBidder):
             model.day_ahead_power.append(pda)
             model.real_time_underbid_power.append(u)
         model.P_T_rows = None
+        model.solver_hints = dict(getattr(self.bidding_model_object, "solver_hints", None) or {})
         model.cost_weight = weight
         model._tot_cost_family = cost_name
         self._refresh_cost_objective(model)

@@ -57,8 +57,8 @@ typedef struct dsp_lp_desc {
  * dsp_default_options() and override fields. */
 typedef struct dsp_options {
   double  eps_rel;           /* relative KKT tolerance (primal, dual, gap)            default 1e-9   */
-  double  eps_obj;           /* objective accuracy: |gap| and |y|.viol <= eps_obj (1 + |c.x + c0|);
-                                0 disables the two extra tests                        default 1e-7   */
+  double  eps_obj;           /* objective accuracy: |gap|, sum|y||row violation| and sum|dual residual||x| are
+                                each <= eps_obj (1 + |c.x + c0|); 0 disables the tests     default 1e-7   */
   int32_t max_iter;          /* iteration limit per scenario                          default 200000 */
   int32_t check_every;       /* restart / termination test period                     default 32     */
   double  restart_sufficient;/* beta_1: restart when r <= beta_1 r0                   default 0.2    */
@@ -67,13 +67,17 @@ typedef struct dsp_options {
   double  pid_kp;            /* proportional gain of the primal-weight controller     default 0.5    */
   double  max_dlog_weight;   /* clamp on |delta log(primal weight)| per restart       default log(30)*/
   double  step_scale;        /* eta = step_scale / ||A_scaled||_2                     default 0.998  */
+  double  weight_guard;      /* keeps the primal weight where step x rounding noise stays below eps / guard:
+                                w >= guard eta 1.1e-16 |c|max / (eps (1+|q|)) (and the mirror bound); 0 = off  default 4 */
   double  jump_steady;       /* ray jump: attempt when |r - r_prev| <= jump_steady r  default 0.05   */
   double  jump_tol;          /* ... and ||T(T z)-2T z+z|| <= jump_tol ||T(T z)-T z||  default 1e-3   */
   double  jump_min;          /* ... and the ray stays >= jump_min steps in its piece  default 4      */
   int32_t ray_jumps;         /* 1 = enable ray jumps                                  default 1      */
   int32_t ruiz_iters;        /* Ruiz passes before Pock-Chambolle (create time)       default 10     */
   int32_t waves_per_block;   /* scenarios per workgroup (1 wave each); 0 = auto                      */
-  int32_t reserved;
+  int32_t geo_iters;         /* geometric-mean equilibration passes BEFORE Ruiz (create time): balances
+                                unit-mix rows such as P_T[MW] = 1e-3 (G + O)[kW]; helps the tracking LPs and the
+                                nuclear flowsheet, hurts wind+battery bidding           default 0      */
 } dsp_options;
 
 /* The per-call data of B scenarios.  c is required; every other input may be NULL (= no bound: -inf / +inf,

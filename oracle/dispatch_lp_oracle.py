@@ -301,10 +301,17 @@ class PreparedLP:
         self.b_ub = np.concatenate(rhs) if parts else None
         self.bounds = np.stack([lb, ub], axis=1)
 
-    def solve(self, c=None):
+    def solve(self, c=None, tight=False):
+        """HiGHS (dual simplex).  tight=True tightens HiGHS' feasibility tolerances from 1e-7 towards 1e-9 (falling
+        back one decade at a time if HiGHS cannot certify optimality there) so that the objective is good to
+        ~1e-9 relative; used when generating the parity fixtures."""
         c = self.c if c is None else c
-        res = linprog(c, A_ub=self.A_ub, b_ub=self.b_ub, A_eq=self.A_eq, b_eq=self.b_eq,
-                      bounds=self.bounds, method="highs")
+        for tol in ((1e-9, 1e-8, None) if tight else (None,)):
+            opts = dict(primal_feasibility_tolerance=tol, dual_feasibility_tolerance=tol) if tol else {}
+            res = linprog(c, A_ub=self.A_ub, b_ub=self.b_ub, A_eq=self.A_eq, b_eq=self.b_eq,
+                          bounds=self.bounds, method="highs-ds" if tol else "highs", options=opts)
+            if res.status == 0:
+                break
         if res.status != 0:
             raise RuntimeError(f"HiGHS did not solve: {res.message}")
         return res.x, float(res.fun + self.c0)

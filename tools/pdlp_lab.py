@@ -10,14 +10,35 @@ import pdlp_proto as pp
 fin = lambda a: np.where(np.isfinite(a), a, 0.0)
 
 
+def geo_scaling(A, iters=8):
+    """geometric-mean equilibration: r_i = 1/sqrt(max_j|a_ij| * min_j|a_ij|) over the nonzeros, same for columns"""
+    A = sp.csr_matrix(A, copy=True).astype(float)
+    m, n = A.shape
+    dr, dc = np.ones(m), np.ones(n)
+    for _ in range(iters):
+        coo = A.tocoo(); a = np.abs(coo.data)
+        rmax = np.zeros(m); rmin = np.full(m, np.inf); np.maximum.at(rmax, coo.row, a); np.minimum.at(rmin, coo.row, a)
+        r = np.where(rmax > 0, 1 / np.sqrt(rmax * np.where(np.isfinite(rmin), rmin, 1)), 1.0)
+        A = sp.diags(r) @ A; dr *= r
+        coo = A.tocoo(); a = np.abs(coo.data)
+        cmax = np.zeros(n); cmin = np.full(n, np.inf); np.maximum.at(cmax, coo.col, a); np.minimum.at(cmin, coo.col, a)
+        c = np.where(cmax > 0, 1 / np.sqrt(cmax * np.where(np.isfinite(cmin), cmin, 1)), 1.0)
+        A = A @ sp.diags(c); dc *= c
+    return sp.csr_matrix(A), dr, dc
+
+
 def solve(P, eps=1e-9, max_iter=60000, check=32, wrule="pid", kp=0.7, maxdl=np.log(30), r0_mode="k1",
           beta=(0.2, 0.8, 0.36), eta_scale=0.998, n_ruiz=10, wclamp=None, bal_gain=0.25, bal_thresh=10.0,
-          c0_gap=True, verbose=False, colscale=None, stall=0, stall_frac=0.5, kp_decay=0.5, xinit=0, term=0, eps_obj=1e-7, jump=0, jtol=1e-2, jsteady=0.05, jmin=4.0, winit=0.0):
+          c0_gap=True, verbose=False, colscale=None, stall=0, stall_frac=0.5, kp_decay=0.5, xinit=0, term=0, eps_obj=1e-7, jump=0, jtol=1e-2, jsteady=0.05, jmin=4.0, winit=0.0, geo=0, jumpw=0, wfloor=0.0):
     lp = P.lp
     A0 = P.A
     if colscale is not None:
         A0 = sp.csr_matrix(A0 @ sp.diags(colscale))
-    As, dr, dc = pp.ruiz_pc_scaling(A0, n_ruiz=n_ruiz)
+    if geo:
+        A0, gr, gc = geo_scaling(A0, int(geo))
+    As, dr, dc = pp.ruiz_pc_scaling(A0, n_ruiz=int(n_ruiz))
+    if geo:
+        dr, dc = dr * gr, dc * gc
     if colscale is not None:
         dc = dc * colscale
     AsT = sp.csr_matrix(As.T)
@@ -68,6 +89,10 @@ def solve(P, eps=1e-9, max_iter=60000, check=32, wrule="pid", kp=0.7, maxdl=np.l
                 gap = np.abs(po - do)
                 okg = gap <= np.maximum(eps_obj * (1 + np.abs(po)), 1e-12 * scale)
                 oki = ierr <= np.maximum(eps_obj * (1 + np.abs(po)), 1e-12 * scale)
+                rc_ = P.c - Yu @ P.A
+                lp_ = np.where(np.isfinite(P.lb), np.maximum(rc_, 0), 0.0); lm_ = np.where(np.isfinite(P.ub), np.maximum(-rc_, 0), 0.0)
+                derr = np.sum(np.abs(rc_ - lp_ + lm_) * np.abs(Xu), 1)
+                oki &= derr <= np.maximum(eps_obj * (1 + np.abs(po)), 1e-12 * scale)
                 rg = np.where(okg & oki, rg, np.maximum(rg, 2 * eps))
             conv = (rp <= eps) & (rd <= eps) & (rg <= eps) & ~done
             Xo[conv], Yo[conv] = (xp * dc)[conv], (yp * dr)[conv]; iters[conv] = it + 1; done |= conv
@@ -103,6 +128,11 @@ def solve(P, eps=1e-9, max_iter=60000, check=32, wrule="pid", kp=0.7, maxdl=np.l
                     if dojump.any():
                         a = np.where(dojump, np.floor(alpha) - 1.0, 0.0)[:, None]
                         xn = np.clip(x2 + a * v2x, lb, ub); yn = y2 + a * v2y
+                        if jumpw:
+                            ddx = np.linalg.norm(xn - x0, axis=1); ddy = np.linalg.norm(yn - y0, axis=1)
+                            okj = dojump & (ddx > 1e-14) & (ddy > 1e-14)
+                            ej = np.where(okj, np.log(w) + np.log(np.maximum(ddx, 1e-300)) - np.log(np.maximum(ddy, 1e-300)), 0.0)
+                            w = w * np.exp(np.clip(-kpv * ej, -maxdl, maxdl))
                         m_ = dojump[:, None]
                         x = np.where(m_, xn, x); y = np.where(m_, yn, y); x0 = np.where(m_, xn, x0); y0 = np.where(m_, yn, y0)
                         xp = np.where(m_, xn, xp); yp = np.where(m_, yn, yp)
@@ -127,12 +157,18 @@ def solve(P, eps=1e-9, max_iter=60000, check=32, wrule="pid", kp=0.7, maxdl=np.l
                     bad = ((ratio > np.log(bal_thresh)) & (dl < 0)) | ((ratio < -np.log(bal_thresh)) & (dl > 0))
                     dl = np.where(bad, np.clip(bal_gain * ratio, -maxdl, maxdl), dl)
                 logw = np.log(w) + np.where(rs, dl, 0.0)
+                if verbose: print(it + 1, 'restart', np.nonzero(rs)[0][:4], 'k', k[rs][:4], 'r', r[rs][:4], 'w', w[rs][:4], '->', np.exp(logw[rs][:4]), 'kkt', rp[rs][:4], rd[rs][:4], rg[rs][:4])
                 if stall:
                     st = rs & ((it + 1 - itbest) > stall + stall_frac * itbest)
                     logw = np.where(st, np.log(wbest), logw); kpv = np.where(st, kpv * kp_decay, kpv); itbest = np.where(st, it + 1, itbest); nrev += st
                 if wclamp is not None:
                     logw = np.clip(logw, np.log(w0) - np.log(wclamp), np.log(w0) + np.log(wclamp))
                 w = np.exp(logw)
+                if wfloor:
+                    cmax = np.max(np.abs(c), 1)
+                    qall = np.sqrt(qs ** 2 + np.sum(fin(lb) ** 2 + fin(ub) ** 2, 1))
+                    w = np.maximum(w, wfloor * eta * 1.1e-16 * cmax / (eps * (1 + qall)))
+                    w = np.minimum(w, 1.0 / (wfloor * eta * 1.1e-16 * np.max(np.abs(np.where(np.isfinite(rlo), rlo, 0)) + np.abs(np.where(np.isfinite(rhi), rhi, 0)), 1) / (eps * (1 + cs)) + 1e-300))
                 m_ = rs[:, None]
                 x = np.where(m_, xp, x); y = np.where(m_, yp, y); x0 = np.where(m_, xp, x0); y0 = np.where(m_, yp, y0)
                 k = np.where(rs, 0, k); r0 = np.where(rs, np.inf, r0); rprev = np.where(rs, np.inf, rprev); nrs += rs
