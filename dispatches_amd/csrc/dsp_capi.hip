@@ -41,6 +41,7 @@ struct dsp_handle {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   bool geo_valid = false;
   Geometry geo;
+  int matreg = 0;                 // register-resident-matrix kernel available for this shape
 };
 
 static int pick(const int *set, int count, int need) {
@@ -76,8 +77,9 @@ static int fill_long(LongList &L, const LaneELL &E) {
 constexpr int kMaxWavesPerBlock = 8;   // kernels are compiled with __launch_bounds__(512)
 
 // LDS bytes of a block with `wpb` waves
-static size_t lds_bytes(const DeviceProblem &P, int wpb) {
-  size_t ent = (size_t)P.ellc_entries + P.ellr_entries + P.tailc_entries + P.tailr_entries;
+static size_t lds_bytes(const DeviceProblem &P, int wpb, bool matreg = false) {
+  size_t ent = (size_t)P.tailc_entries + P.tailr_entries;
+  if (!matreg) ent += (size_t)P.ellc_entries + P.ellr_entries;
   return ent * sizeof(Entry) + (size_t)wpb * (P.n_pad + P.m_pad) * 8;
 }
 
@@ -89,11 +91,12 @@ static int solve_geometry(dsp_handle *h, int requested, int B, Geometry *g) {
   else {
     SolveArgs probe{};
     probe.P = h->P;
+    probe.matreg = h->matreg;
     int best_waves = -1;
     Geometry best;
     for (int wpb = kMaxWavesPerBlock; wpb >= 1; --wpb) {
       if (requested > 0 && wpb != std::min(requested, kMaxWavesPerBlock)) continue;
-      size_t l = lds_bytes(h->P, wpb);
+      size_t l = lds_bytes(h->P, wpb, h->matreg);
       if (l > (size_t)h->lds_limit) continue;
       int nb = 0;
       hipError_t e = occupancy_solve(h->cpl, h->rpl, probe, 64 * wpb, l, &nb);
@@ -109,7 +112,7 @@ static int solve_geometry(dsp_handle *h, int requested, int B, Geometry *g) {
     int per_cu = (B + h->num_cus - 1) / h->num_cus;
     int wpb = g->wpb;
     while (wpb > 1 && wpb > per_cu) wpb--;
-    if (wpb != g->wpb) { g->wpb = wpb; g->lds = lds_bytes(h->P, wpb); g->blocks_per_cu = std::max(1, per_cu / wpb); }
+    if (wpb != g->wpb) { g->wpb = wpb; g->lds = lds_bytes(h->P, wpb, h->matreg); g->blocks_per_cu = std::max(1, per_cu / wpb); }
   }
   return DSP_OK;
 }
@@ -206,6 +209,7 @@ int dsp_create(const dsp_lp_desc *d, int device, const dsp_options *opt, dsp_han
   P.tailc_entries = (int)Ec.tail_val.size(); P.tailr_entries = (int)Er.tail_val.size();
   int rc;
   if ((rc = fill_long(P.long_c, Ec)) || (rc = fill_long(P.long_r, Er))) { delete h; return rc; }
+  h->matreg = (!h->opt.no_matreg && matreg_available(cpl, rpl, P.Wc, P.Wr, P.long_c.count > 0 || P.long_r.count > 0)) ? 1 : 0;
   std::vector<Entry> pk;
 #define UPE(val, idx, field) pack_entries(val, idx, pk); if ((rc = upload(h, pk, &P.field)) != DSP_OK) { dsp_destroy(h); return rc; }
 #define UP(vec, field) if ((rc = upload(h, vec, &P.field)) != DSP_OK) { dsp_destroy(h); return rc; }
@@ -244,6 +248,7 @@ int dsp_solve(dsp_handle *h, const dsp_batch *batch, const dsp_options *opt, dsp
   a.waves_per_block = geo.wpb;
   const size_t lds = geo.lds;
   a.queue = h->queue;
+  a.matreg = h->matreg;
   int grid = std::min((B + geo.wpb - 1) / geo.wpb, h->num_cus * geo.blocks_per_cu);
   HIP_TRY(hipMemsetAsync(h->queue, 0, sizeof(int), st));
   const bool timed = stats && sync_stats;
@@ -253,7 +258,7 @@ int dsp_solve(dsp_handle *h, const dsp_batch *batch, const dsp_options *opt, dsp
   if (stats) {
     std::memset(stats, 0, sizeof(*stats));
     stats->grid_blocks = grid; stats->block_threads = 64 * a.waves_per_block; stats->lds_bytes = (int)lds;
-    stats->cols_per_lane = h->cpl; stats->rows_per_lane = h->rpl;
+    stats->cols_per_lane = h->cpl; stats->rows_per_lane = h->rpl; stats->matreg = h->matreg;
     if (sync_stats) {
       HIP_TRY(hipStreamSynchronize(st));
       HIP_TRY(hipEventElapsedTime(&stats->kernel_ms, h->ev0, h->ev1));

@@ -46,6 +46,7 @@ struct SolveArgs {
   double eta;
   dsp_options opt;
   int *queue;                  // device work-queue head (zeroed before the launch)
+  int matreg;                  // 1 = register-resident-matrix specialisation of the kernel
 };
 
 struct SpmvArgs {
@@ -57,6 +58,7 @@ struct SpmvArgs {
 };
 
 hipError_t launch_solve(int cpl, int rpl, const SolveArgs &a, dim3 grid, dim3 block, size_t lds, hipStream_t st);
+bool matreg_available(int cpl, int rpl, int wc, int wr, bool lng);
 hipError_t occupancy_solve(int cpl, int rpl, const SolveArgs &a, int block_threads, size_t lds, int *blocks_per_cu);
 hipError_t launch_spmv(int cpl, int rpl, const SpmvArgs &a, dim3 grid, dim3 block, size_t lds, hipStream_t st);
 

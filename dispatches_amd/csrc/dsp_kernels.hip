@@ -143,6 +143,55 @@ __device__ __forceinline__ void ell_product(double (&out)[S], const Entry *__res
   }
 }
 
+// Register-resident ELL (small LPs): the lane's W*S entries live in VGPRs for the whole kernel, so an SpMV is
+// W*S independent LDS gathers issued back to back (one LDS latency instead of W dependent round trips) + W*S FMAs.
+template <int S, int W>
+struct RegEll {
+  double v[W < 1 ? 1 : W][S];
+  uint32_t off[W < 1 ? 1 : W][S];
+  __device__ __forceinline__ void load(const Entry *__restrict__ g, int lane) {
+#pragma unroll
+    for (int e = 0; e < W; ++e)
+#pragma unroll
+      for (int q = 0; q < S; ++q) {
+        const int4 raw = *reinterpret_cast<const int4 *>(g + (e * S + q) * 64 + lane);     // coalesced global load
+        v[e][q] = __hiloint2double(raw.y, raw.x);
+        off[e][q] = (uint32_t)raw.z;
+      }
+  }
+  __device__ __forceinline__ void product(double (&out)[S], const char *vec) const {
+    double xv[W < 1 ? 1 : W][S];
+#pragma unroll
+    for (int e = 0; e < W; ++e)
+#pragma unroll
+      for (int q = 0; q < S; ++q) xv[e][q] = *reinterpret_cast<const double *>(vec + off[e][q]);
+#pragma unroll
+    for (int q = 0; q < S; ++q) out[q] = 0.0;
+#pragma unroll
+    for (int e = 0; e < W; ++e)
+#pragma unroll
+      for (int q = 0; q < S; ++q) out[q] = fma(v[e][q], xv[e][q], out[q]);
+  }
+};
+
+// long vectors only (their ELL entries are zero): cooperative wave reduction, tails in LDS
+template <int S>
+__device__ __forceinline__ void long_product(double (&out)[S], const char *vec, int lane, const LongList &ll,
+                                             const Entry *__restrict__ tail) {
+  for (int l = 0; l < ll.count; ++l) {
+    const int owner = ll.owner[l], start = ll.start[l], len = ll.len[l];
+    double part = 0.0;
+    for (int t = lane; t < len; t += 64) {
+      const int4 raw = *reinterpret_cast<const int4 *>(tail + start + t);
+      part = fma(__hiloint2double(raw.y, raw.x), *reinterpret_cast<const double *>(vec + (uint32_t)raw.z), part);
+    }
+    part = wave_sum(part);
+#pragma unroll
+    for (int q = 0; q < S; ++q)
+      if (owner == lane + 64 * q) out[q] += part;
+  }
+}
+
 // stage the shared matrix of one workgroup into LDS (16-byte copies)
 __device__ __forceinline__ void stage_entries(Entry *dst, const Entry *__restrict__ src, int count) {
   int4 *d = reinterpret_cast<int4 *>(dst);
@@ -152,10 +201,13 @@ __device__ __forceinline__ void stage_entries(Entry *dst, const Entry *__restric
 
 // ---- the fused, LDS-resident PDLP solve ---------------------------------------------------------------------
 #ifndef DSP_MIN_WAVES_SMALL
-#define DSP_MIN_WAVES_SMALL 4
+#define DSP_MIN_WAVES_SMALL 2
 #endif
-template <int CPL, int RPL, bool LONG>
+// WC / WR > 0: the ELL part of A^T / A is register-resident (RegEll) with these compile-time widths;
+// WC = WR = 0: generic path, matrix in LDS with run-time widths.
+template <int CPL, int RPL, bool LONG, int WC, int WR>
 __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 2) pdlp_solve_kernel(SolveArgs a) {
+  constexpr bool MATREG = WC > 0;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const DeviceProblem &P = a.P;
   const dsp_batch &b = a.b;
@@ -164,14 +216,22 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
 
   // ---- carve LDS: shared matrix region, then one exchange buffer pair per wave ----------------------------
   Entry *ellc = reinterpret_cast<Entry *>(smem);                       // A^T (columns)  [Wc*CPL*64]
-  Entry *ellr = ellc + P.ellc_entries;                                 // A   (rows)     [Wr*RPL*64]
-  Entry *tailc = ellr + P.ellr_entries;
+  Entry *ellr = ellc + (MATREG ? 0 : P.ellc_entries);                  // A   (rows)     [Wr*RPL*64]
+  Entry *tailc = ellr + (MATREG ? 0 : P.ellr_entries);
   Entry *tailr = tailc + P.tailc_entries;
   char *wave_buf = reinterpret_cast<char *>(tailr + P.tailr_entries);  // [waves][(n_pad + m_pad) * 8]
-  stage_entries(ellc, P.ellc, P.ellc_entries);
-  stage_entries(ellr, P.ellr, P.ellr_entries);
+  if (!MATREG) {
+    stage_entries(ellc, P.ellc, P.ellc_entries);
+    stage_entries(ellr, P.ellr, P.ellr_entries);
+  }
   stage_entries(tailc, P.tailc, P.tailc_entries);
   stage_entries(tailr, P.tailr, P.tailr_entries);
+  RegEll<CPL, WC> mreg_c;
+  RegEll<RPL, WR> mreg_r;
+  if (MATREG) {
+    mreg_c.load(P.ellc, lane);
+    mreg_r.load(P.ellr, lane);
+  }
   __syncthreads();
   DSP_TRACE("[trace] staged: Wc=%d Wr=%d B=%d check=%d maxit=%d\n", P.Wc, P.Wr, b.B, a.opt.check_every, a.opt.max_iter);
 
@@ -185,6 +245,22 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
   const double eps = a.opt.eps_rel;
   const double eps_obj = a.opt.eps_obj;
   const int check_every = a.opt.check_every;
+  auto col_product = [&](double (&out)[CPL]) __attribute__((always_inline)) {     // out = A^T (vector in yb)
+    if constexpr (MATREG) {
+      mreg_c.product(out, yb);
+      if (LONG) long_product<CPL>(out, yb, lane, P.long_c, tailc);
+    } else {
+      ell_product<CPL, LONG>(out, ellc, P.Wc, yb, lane, P.long_c, tailc);
+    }
+  };
+  auto row_product = [&](double (&out)[RPL]) __attribute__((always_inline)) {     // out = A (vector in xb)
+    if constexpr (MATREG) {
+      mreg_r.product(out, xb);
+      if (LONG) long_product<RPL>(out, xb, lane, P.long_r, tailr);
+    } else {
+      ell_product<RPL, LONG>(out, ellr, P.Wr, xb, lane, P.long_r, tailr);
+    }
+  };
 
   for (;;) {
     // ---- pull the next scenario off the work queue ---------------------------------------------------------
@@ -267,7 +343,7 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
 #pragma unroll
     for (int q = 0; q < CPL; ++q) xbl[64 * q] = x[q];
     wave_lds_fence();
-    ell_product<RPL, LONG>(ax, ellr, P.Wr, xb, lane, P.long_r, tailr);
+    row_product(ax);
 #pragma unroll
     for (int q = 0; q < RPL; ++q) ax0[q] = ax[q];
 
@@ -288,13 +364,13 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
   {                                                                                                         \
     _Pragma("unroll") for (int q = 0; q < RPL; ++q) ybl[64 * q] = y[q];                                     \
     wave_lds_fence();                                                                                       \
-    ell_product<CPL, LONG>(aty, ellc, P.Wc, yb, lane, P.long_c, tailc);                                     \
+    col_product(aty);                                     \
     _Pragma("unroll") for (int q = 0; q < CPL; ++q) {                                                       \
       xp[q] = clampd(x[q] - tau * (c[q] - aty[q]), lb[q], ub[q]);                                           \
       xbl[64 * q] = 2.0 * xp[q] - x[q];                                                                     \
     }                                                                                                       \
     wave_lds_fence();                                                                                       \
-    ell_product<RPL, LONG>(axb, ellr, P.Wr, xb, lane, P.long_r, tailr);                                     \
+    row_product(axb);                                     \
     _Pragma("unroll") for (int q = 0; q < RPL; ++q) {                                                       \
       const double wv = y[q] - sig * axb[q];                                                                \
       yp[q] = wv + clampd(-wv, sig * rlo[q], sig * rhi[q]);                                                 \
@@ -334,7 +410,7 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
         for (int q = 0; q < RPL; ++q) ybl[64 * q] = yp[q];
         wave_lds_fence();
         double atyp[CPL];
-        ell_product<CPL, LONG>(atyp, ellc, P.Wc, yb, lane, P.long_c, tailc);
+        col_product(atyp);
         // red: 0 pres^2, 1 dres^2, 2 pobj, 3 dobj, 4 sum|y| viol, 5 sum|c x|, 6 |dx|^2, 7 |dy|^2, 8 dy.A dx,
         //      9 sum|dual residual| |x|   (4 and 9 bound the objective error caused by the remaining infeasibility)
         double red[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -435,7 +511,7 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
             alpha = fmin(alpha, steps_to_break(gx1, gx1 - gx0, lb[q], ub[q]));
           }
           wave_lds_fence();
-          ell_product<RPL, LONG>(axb1, ellr, P.Wr, xb, lane, P.long_r, tailr);
+          row_product(axb1);
           const double iw = 1.0 / w;
 #pragma unroll
           for (int q = 0; q < RPL; ++q) {
@@ -459,7 +535,7 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
               xbl[64 * q] = xn;
             }
             wave_lds_fence();
-            ell_product<RPL, LONG>(ax, ellr, P.Wr, xb, lane, P.long_r, tailr);
+            row_product(ax);
 #pragma unroll
             for (int q = 0; q < RPL; ++q) {
               const double yn = y2[q] + al * (y2[q] - yp[q]);
@@ -573,16 +649,49 @@ __global__ void __launch_bounds__(512) spmv_step_kernel(SpmvArgs a) {
 }
 
 // ---- launch tables ------------------------------------------------------------------------------------------
+// Register-resident-matrix specialisations exist for the shapes of the reference's flowsheets at the benchmark
+// horizons (cols/lane, rows/lane, ELL width of A^T, ELL width of A, long vectors): everything else runs the generic
+// LDS-matrix kernel.  wind+battery 24 h, nuclear 24 h / 48 h, wind+PEM 48 h (shared capacity column = long vector).
+#define DSP_MATREG_SHAPES(X) X(4, 2, 3, 4, false) X(3, 2, 2, 4, false) X(5, 3, 2, 4, false) X(4, 3, 2, 3, true)
+
+bool matreg_available(int cpl, int rpl, int wc, int wr, bool lng) {
+#ifdef DSP_NO_MATREG
+  return false;
+#else
+#define DSP_X(C, R, WC_, WR_, L) if (cpl == C && rpl == R && wc == WC_ && wr == WR_ && lng == L) return true;
+  DSP_MATREG_SHAPES(DSP_X)
+#undef DSP_X
+  return false;
+#endif
+}
+
+static const void *matreg_fn(int cpl, int rpl, int wc, int wr, bool lng) {
+#ifndef DSP_NO_MATREG
+#define DSP_X(C, R, WC_, WR_, L)                                                            \
+  if (cpl == C && rpl == R && wc == WC_ && wr == WR_ && lng == L)                           \
+    return reinterpret_cast<const void *>(&pdlp_solve_kernel<C, R, L, WC_, WR_>);
+  DSP_MATREG_SHAPES(DSP_X)
+#undef DSP_X
+#endif
+  return nullptr;
+}
+
+template <int CPL, int RPL>
+static const void *generic_fn(bool lng) {
+  return lng ? reinterpret_cast<const void *>(&pdlp_solve_kernel<CPL, RPL, true, 0, 0>)
+             : reinterpret_cast<const void *>(&pdlp_solve_kernel<CPL, RPL, false, 0, 0>);
+}
+
 template <int CPL, int RPL>
 static hipError_t launch_solve_t(const SolveArgs &a, dim3 grid, dim3 block, size_t lds, hipStream_t st) {
   const bool lng = a.P.long_c.count > 0 || a.P.long_r.count > 0;
-  const void *fn = lng ? reinterpret_cast<const void *>(&pdlp_solve_kernel<CPL, RPL, true>)
-                       : reinterpret_cast<const void *>(&pdlp_solve_kernel<CPL, RPL, false>);
+  const void *fn = a.matreg ? matreg_fn(CPL, RPL, a.P.Wc, a.P.Wr, lng) : generic_fn<CPL, RPL>(lng);
+  if (!fn) return hipErrorInvalidValue;
   hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
-  if (lng) hipLaunchKernelGGL((pdlp_solve_kernel<CPL, RPL, true>), grid, block, lds, st, a);
-  else hipLaunchKernelGGL((pdlp_solve_kernel<CPL, RPL, false>), grid, block, lds, st, a);
-  return hipGetLastError();
+  SolveArgs args = a;
+  void *params[] = {&args};
+  return hipLaunchKernel(fn, grid, block, params, lds, st);
 }
 template <int CPL, int RPL>
 static hipError_t launch_spmv_t(const SpmvArgs &a, dim3 grid, dim3 block, size_t lds, hipStream_t st) {
@@ -629,8 +738,8 @@ hipError_t launch_solve(int cpl, int rpl, const SolveArgs &a, dim3 grid, dim3 bl
 template <int CPL, int RPL>
 static hipError_t occupancy_solve_t(const SolveArgs &a, dim3 grid, dim3 block, size_t lds, hipStream_t) {
   const bool lng = a.P.long_c.count > 0 || a.P.long_r.count > 0;
-  const void *fn = lng ? reinterpret_cast<const void *>(&pdlp_solve_kernel<CPL, RPL, true>)
-                       : reinterpret_cast<const void *>(&pdlp_solve_kernel<CPL, RPL, false>);
+  const void *fn = a.matreg ? matreg_fn(CPL, RPL, a.P.Wc, a.P.Wr, lng) : generic_fn<CPL, RPL>(lng);
+  if (!fn) return hipErrorInvalidValue;
   hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
   int nb = 0;

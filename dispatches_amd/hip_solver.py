@@ -26,7 +26,7 @@ class DspOptions(C.Structure):
                 ("restart_artificial", C.c_double), ("pid_kp", C.c_double), ("max_dlog_weight", C.c_double),
                 ("step_scale", C.c_double), ("weight_guard", C.c_double), ("jump_steady", C.c_double), ("jump_tol", C.c_double),
                 ("jump_min", C.c_double), ("ray_jumps", C.c_int32), ("ruiz_iters", C.c_int32),
-                ("waves_per_block", C.c_int32), ("geo_iters", C.c_int32)]
+                ("waves_per_block", C.c_int32), ("no_matreg", C.c_int32), ("geo_iters", C.c_int32)]
 
 
 class DspBatch(C.Structure):
@@ -46,7 +46,8 @@ class DspBatch(C.Structure):
 class DspStats(C.Structure):
     _fields_ = [("total_iterations", C.c_int64), ("max_iterations", C.c_int32), ("n_optimal", C.c_int32),
                 ("grid_blocks", C.c_int32), ("block_threads", C.c_int32), ("lds_bytes", C.c_int32),
-                ("cols_per_lane", C.c_int32), ("rows_per_lane", C.c_int32), ("kernel_ms", C.c_float)]
+                ("cols_per_lane", C.c_int32), ("rows_per_lane", C.c_int32), ("kernel_ms", C.c_float),
+                ("matreg", C.c_int32)]
 
 
 class DspLpDesc(C.Structure):
@@ -288,7 +289,7 @@ class HipPdlpSolver:
         if tee:
             print(f"[dsp_hip] B={B} n={model.lp.n} m={model.lp.m} nnz={model.lp.nnz} optimal={st.n_optimal}/{B} "
                   f"iters(sum/max)={st.total_iterations}/{st.max_iterations} kernel={st.kernel_ms:.3f} ms "
-                  f"grid={st.grid_blocks}x{st.block_threads} lds={st.lds_bytes}B")
+                  f"grid={st.grid_blocks}x{st.block_threads} lds={st.lds_bytes}B matreg={st.matreg}")
         all_ok = bool((status == 0).all())
         return SolveResults("ok" if all_ok else "warning", "optimal" if all_ok else "maxIterations",
                             iterations=int(st.total_iterations), kernel_ms=float(st.kernel_ms))

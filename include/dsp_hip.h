@@ -75,6 +75,7 @@ typedef struct dsp_options {
   int32_t ray_jumps;         /* 1 = enable ray jumps                                  default 1      */
   int32_t ruiz_iters;        /* Ruiz passes before Pock-Chambolle (create time)       default 10     */
   int32_t waves_per_block;   /* scenarios per workgroup (1 wave each); 0 = auto                      */
+  int32_t no_matreg;         /* 1 = never use the register-resident-matrix kernel (create time)  default 0 */
   int32_t geo_iters;         /* geometric-mean equilibration passes BEFORE Ruiz (create time): balances
                                 unit-mix rows such as P_T[MW] = 1e-3 (G + O)[kW]; helps the tracking LPs and the
                                 nuclear flowsheet, hurts wind+battery bidding           default 0      */
@@ -117,6 +118,7 @@ typedef struct dsp_stats {
   int32_t cols_per_lane;     /* CPL template parameter chosen                       */
   int32_t rows_per_lane;     /* RPL template parameter chosen                       */
   float   kernel_ms;         /* hipEvent time of the solve kernel on `stream` (sync_stats only) */
+  int32_t matreg;            /* 1 = the register-resident-matrix specialisation ran         */
 } dsp_stats;
 
 void dsp_default_options(dsp_options *opt);
