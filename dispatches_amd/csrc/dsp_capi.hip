@@ -35,7 +35,8 @@ struct dsp_handle {
   DeviceProblem P{};
   std::vector<void *> allocs;     // device allocations owned by the handle
   std::vector<double> dr, dc;
-  int *queue = nullptr;
+  int *queue = nullptr;           // ring of kQueueRing work-queue heads (64 B apart): launches on different streams
+  unsigned queue_next = 0;        // may be in flight together, each needs its own head
   int lds_limit = 160 * 1024;
   int num_cus = 256;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -74,6 +75,8 @@ static int fill_long(LongList &L, const LaneELL &E) {
   return DSP_OK;
 }
 
+constexpr int kQueueRing = 32;
+constexpr int kQueueStride = 16;       // ints (64 bytes) between ring slots
 constexpr int kMaxWavesPerBlock = 8;   // kernels are compiled with __launch_bounds__(512)
 
 // LDS bytes of a block with `wpb` waves
@@ -94,7 +97,11 @@ static int solve_geometry(dsp_handle *h, int requested, int B, Geometry *g) {
     probe.matreg = h->matreg;
     int best_waves = -1;
     Geometry best;
-    for (int wpb = kMaxWavesPerBlock; wpb >= 1; --wpb) {
+    // generic kernel: larger blocks win ties (the LDS matrix is staged once per block); register-resident matrix:
+    // one wave per block wins ties, so every wave's registers are released the moment ITS scenarios are done and a
+    // following launch (another stream) can back-fill the CU while this launch's stragglers finish
+    for (int step = 0; step < kMaxWavesPerBlock; ++step) {
+      const int wpb = h->matreg ? 1 + step : kMaxWavesPerBlock - step;
       if (requested > 0 && wpb != std::min(requested, kMaxWavesPerBlock)) continue;
       size_t l = lds_bytes(h->P, wpb, h->matreg);
       if (l > (size_t)h->lds_limit) continue;
@@ -125,16 +132,16 @@ void dsp_default_options(dsp_options *o) {
   o->eps_rel = 1e-9;
   o->eps_obj = 1e-7;
   o->max_iter = 200000;
-  o->check_every = 32;
+  o->check_every = 16;
   o->restart_sufficient = 0.2;
   o->restart_necessary = 0.8;
   o->restart_artificial = 0.36;
-  o->pid_kp = 0.5;
+  o->pid_kp = 0.7;
   o->max_dlog_weight = std::log(30.0);
   o->step_scale = 0.998;
   o->weight_guard = 4.0;
   o->jump_steady = 0.05;
-  o->jump_tol = 1e-3;
+  o->jump_tol = 3e-3;
   o->jump_min = 4.0;
   o->ray_jumps = 1;
   o->ruiz_iters = 10;
@@ -220,7 +227,7 @@ int dsp_create(const dsp_lp_desc *d, int device, const dsp_options *opt, dsp_han
 #undef UP
 #undef UPE
   void *q = nullptr;
-  if (hipMalloc(&q, sizeof(int)) != hipSuccess) { dsp_destroy(h); return DSP_ERR_HIP; }
+  if (hipMalloc(&q, sizeof(int) * kQueueRing * kQueueStride) != hipSuccess) { dsp_destroy(h); return DSP_ERR_HIP; }
   h->queue = (int *)q;
   if (hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess) { dsp_destroy(h); return DSP_ERR_HIP; }
   *out = h;
@@ -247,10 +254,10 @@ int dsp_solve(dsp_handle *h, const dsp_batch *batch, const dsp_options *opt, dsp
   if (grc != DSP_OK) return grc;
   a.waves_per_block = geo.wpb;
   const size_t lds = geo.lds;
-  a.queue = h->queue;
+  a.queue = h->queue + (size_t)(h->queue_next++ % kQueueRing) * kQueueStride;
   a.matreg = h->matreg;
   int grid = std::min((B + geo.wpb - 1) / geo.wpb, h->num_cus * geo.blocks_per_cu);
-  HIP_TRY(hipMemsetAsync(h->queue, 0, sizeof(int), st));
+  HIP_TRY(hipMemsetAsync(a.queue, 0, sizeof(int), st));
   const bool timed = stats && sync_stats;
   if (timed) HIP_TRY(hipEventRecord(h->ev0, st));
   HIP_TRY(launch_solve(h->cpl, h->rpl, a, dim3(grid), dim3(64 * a.waves_per_block), lds, st));

@@ -275,17 +275,22 @@ class HipPdlpSolver:
         lb, ub, rlo, rhi = model.scenario_bounds()
         up = lambda a: torch.as_tensor(np.ascontiguousarray(a, np.float64)).to(dev, non_blocking=False)
         x0 = y0 = None
+        pw = torch.zeros(B, dtype=torch.float64, device=dev)          # in: 0 = automatic; out: final primal weights
         if warm_start and model.x is not None and model.y is not None and model.x.shape == (B, model.lp.n):
             x0, y0 = up(model.x), up(model.y)
+            prev = getattr(model, "primal_weight", None)
+            if prev is not None and len(prev) == B:
+                pw = up(prev)
         out = dlp.solve(B, up(model.c), up(lb), up(ub), up(rlo) if model.lp.m else None,
                         up(rhi) if model.lp.m else None, x0=x0, y0=y0, options=dlp.options,
-                        obj_offset=up(np.broadcast_to(np.asarray(model.c0, np.float64), (B,))))
+                        obj_offset=up(np.broadcast_to(np.asarray(model.c0, np.float64), (B,))), primal_weight=pw)
         st = out["stats"]
         self.last_stats = st
         status = out["status"].cpu().numpy()
         model.store_solution(out["x"].cpu().numpy(), out["y"].cpu().numpy()[:, :model.lp.m],
                              out["obj"].cpu().numpy() + model.c0, status, out["iters"].cpu().numpy())
         model.jumps = out["jumps"].cpu().numpy()
+        model.primal_weight = pw.cpu().numpy()
         if tee:
             print(f"[dsp_hip] B={B} n={model.lp.n} m={model.lp.m} nnz={model.lp.nnz} optimal={st.n_optimal}/{B} "
                   f"iters(sum/max)={st.total_iterations}/{st.max_iterations} kernel={st.kernel_ms:.3f} ms "

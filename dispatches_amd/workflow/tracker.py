@@ -78,8 +78,10 @@ class Tracker:
             model.power_overdelivered.append(over)
             model.tracking_rows.append(row)
         # the dispatch rows P_T[MW] + under - over = D mix 1e-3 (kW -> MW) and 1.0 coefficients: ask the solver for
-        # geometric pre-equilibration (include/dsp_hip.h: geo_iters); model objects may override via `solver_hints`
-        model.solver_hints = {"geo_iters": 8, **(getattr(self.tracking_model_object, "solver_hints", None) or {})}
+        # geometric pre-equilibration (include/dsp_hip.h: geo_iters) and the conservative restart / ray-jump settings
+        # that these tiny, badly scaled LPs need; model objects may override via `solver_hints`
+        model.solver_hints = {"geo_iters": 8, "check_every": 32, "jump_tol": 1e-3, "pid_kp": 0.5,
+                              **(getattr(self.tracking_model_object, "solver_hints", None) or {})}
         self.model = model
         cost_name, weight = self.tracking_model_object.total_cost
         model._tot_cost_family, model.cost_weight = cost_name, weight

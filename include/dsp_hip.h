@@ -60,17 +60,17 @@ typedef struct dsp_options {
   double  eps_obj;           /* objective accuracy: |gap|, sum|y||row violation| and sum|dual residual||x| are
                                 each <= eps_obj (1 + |c.x + c0|); 0 disables the tests     default 1e-7   */
   int32_t max_iter;          /* iteration limit per scenario                          default 200000 */
-  int32_t check_every;       /* restart / termination test period                     default 32     */
+  int32_t check_every;       /* restart / termination test period                     default 16     */
   double  restart_sufficient;/* beta_1: restart when r <= beta_1 r0                   default 0.2    */
   double  restart_necessary; /* beta_2: ... or r <= beta_2 r0 and r increased         default 0.8    */
   double  restart_artificial;/* beta_3: ... or k >= beta_3 * total iterations         default 0.36   */
-  double  pid_kp;            /* proportional gain of the primal-weight controller     default 0.5    */
+  double  pid_kp;            /* proportional gain of the primal-weight controller     default 0.7    */
   double  max_dlog_weight;   /* clamp on |delta log(primal weight)| per restart       default log(30)*/
   double  step_scale;        /* eta = step_scale / ||A_scaled||_2                     default 0.998  */
   double  weight_guard;      /* keeps the primal weight where step x rounding noise stays below eps / guard:
                                 w >= guard eta 1.1e-16 |c|max / (eps (1+|q|)) (and the mirror bound); 0 = off  default 4 */
   double  jump_steady;       /* ray jump: attempt when |r - r_prev| <= jump_steady r  default 0.05   */
-  double  jump_tol;          /* ... and ||T(T z)-2T z+z|| <= jump_tol ||T(T z)-T z||  default 1e-3   */
+  double  jump_tol;          /* ... and ||T(T z)-2T z+z|| <= jump_tol ||T(T z)-T z||  default 3e-3   */
   double  jump_min;          /* ... and the ray stays >= jump_min steps in its piece  default 4      */
   int32_t ray_jumps;         /* 1 = enable ray jumps                                  default 1      */
   int32_t ruiz_iters;        /* Ruiz passes before Pock-Chambolle (create time)       default 10     */

@@ -29,7 +29,7 @@ def test_header_symbols_exported(lib):
 def test_default_options(lib):
     from dispatches_amd import hip_solver
     o = hip_solver.default_options()
-    assert o.eps_rel == 1e-9 and o.eps_obj == 1e-7 and o.check_every == 32 and o.max_iter == 200000
+    assert o.eps_rel == 1e-9 and o.eps_obj == 1e-7 and o.check_every == 16 and o.max_iter == 200000
     with pytest.raises(TypeError):
         hip_solver.default_options(not_an_option=1)
     assert lib.dsp_strerror(0) == b"ok" and b"invalid" in lib.dsp_strerror(-1)

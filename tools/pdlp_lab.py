@@ -29,7 +29,7 @@ def geo_scaling(A, iters=8):
 
 def solve(P, eps=1e-9, max_iter=60000, check=32, wrule="pid", kp=0.7, maxdl=np.log(30), r0_mode="k1",
           beta=(0.2, 0.8, 0.36), eta_scale=0.998, n_ruiz=10, wclamp=None, bal_gain=0.25, bal_thresh=10.0,
-          c0_gap=True, verbose=False, colscale=None, stall=0, stall_frac=0.5, kp_decay=0.5, xinit=0, term=0, eps_obj=1e-7, jump=0, jtol=1e-2, jsteady=0.05, jmin=4.0, winit=0.0, geo=0, jumpw=0, wfloor=0.0):
+          c0_gap=True, verbose=False, colscale=None, stall=0, stall_frac=0.5, kp_decay=0.5, xinit=0, term=0, eps_obj=1e-7, jump=0, jtol=1e-2, jsteady=0.05, jmin=4.0, winit=0.0, geo=0, jumpw=0, wfloor=0.0, jk=2.0, jacc=0.0, retry=0.0, retry_kps=(0.5, 0.35, 0.7, 0.25)):
     lp = P.lp
     A0 = P.A
     if colscale is not None:
@@ -60,6 +60,8 @@ def solve(P, eps=1e-9, max_iter=60000, check=32, wrule="pid", kp=0.7, maxdl=np.l
     best = np.full(B, np.inf); wbest = w.copy(); itbest = np.zeros(B); kpv = np.full(B, kp); nrev = np.zeros(B, int)
     max_iter = int(max_iter)
     njump = np.zeros(B, int); jtot = np.zeros(B)
+    attempt = np.zeros(B, int); t_attempt = np.zeros(B); budget = np.full(B, retry * (n + m) if retry else np.inf)
+    xstart0 = x.copy(); xstart1 = np.where((c < 0) & np.isfinite(ub), ub, x)
     for it in range(max_iter):
         tau = (eta / w)[:, None]; sig = (eta * w)[:, None]
         xp = np.clip(x - tau * (c - y @ As), lb, ub)
@@ -104,7 +106,7 @@ def solve(P, eps=1e-9, max_iter=60000, check=32, wrule="pid", kp=0.7, maxdl=np.l
             first = ~np.isfinite(r0)
             r0 = np.where(first, r, r0)
             rs = ~first & ((r <= beta[0] * r0) | ((r <= beta[1] * r0) & (r > rprev)) | (k >= beta[2] * (it + 1)))
-            steady = (np.abs(r - rprev) <= jsteady * r) & (k >= 2 * check) & ~done & ~rs if jump else np.zeros(B, bool)
+            steady = (np.abs(r - rprev) <= jsteady * r) & (k >= jk * check) & ~done & ~rs if jump else np.zeros(B, bool)
             rprev = r
             if jump and steady.any():
                 gx0 = x - tau * (c - y @ As); gy0 = wv
@@ -128,6 +130,13 @@ def solve(P, eps=1e-9, max_iter=60000, check=32, wrule="pid", kp=0.7, maxdl=np.l
                     if dojump.any():
                         a = np.where(dojump, np.floor(alpha) - 1.0, 0.0)[:, None]
                         xn = np.clip(x2 + a * v2x, lb, ub); yn = y2 + a * v2y
+                        if jacc:
+                            xl = np.clip(xn - tau * (c - yn @ As), lb, ub); gl = yn - sig * ((2 * xl - xn) @ AsT); yl = gl + np.clip(-gl, sig * rlo, sig * rhi)
+                            dxl, dyl = xl - xn, yl - yn
+                            rl = np.sqrt(np.maximum(w * np.sum(dxl * dxl, 1) - 2 * eta * np.sum(dyl * (dxl @ AsT), 1) + np.sum(dyl * dyl, 1) / w, 0))
+                            rej = dojump & ~(rl <= (1 + jacc) * r)
+                            solve.rejected = getattr(solve, 'rejected', 0) + rej.sum()
+                            dojump = dojump & ~rej
                         if jumpw:
                             ddx = np.linalg.norm(xn - x0, axis=1); ddy = np.linalg.norm(yn - y0, axis=1)
                             okj = dojump & (ddx > 1e-14) & (ddy > 1e-14)
@@ -172,12 +181,25 @@ def solve(P, eps=1e-9, max_iter=60000, check=32, wrule="pid", kp=0.7, maxdl=np.l
                 m_ = rs[:, None]
                 x = np.where(m_, xp, x); y = np.where(m_, yp, y); x0 = np.where(m_, xp, x0); y0 = np.where(m_, yp, y0)
                 k = np.where(rs, 0, k); r0 = np.where(rs, np.inf, r0); rprev = np.where(rs, np.inf, rprev); nrs += rs
+        if retry and chk:
+            rt = ~done & ((it + 1 - t_attempt) >= budget)
+            if rt.any():
+                attempt = attempt + rt
+                kpv = np.where(rt, np.array(retry_kps)[(attempt - 1) % len(retry_kps)], kpv)
+                xs = np.where((attempt % 2 == 1)[:, None], xstart1, xstart0)
+                m_ = rt[:, None]
+                x = np.where(m_, xs, x); y = np.where(m_, 0.0, y); x0 = np.where(m_, xs, x0); y0 = np.where(m_, 0.0, y0)
+                xp = np.where(m_, xs, xp); yp = np.where(m_, 0.0, yp)
+                w = np.where(rt, w0, w); k = np.where(rt, 0, k); r0 = np.where(rt, np.inf, r0); rprev = np.where(rt, np.inf, rprev)
+                t_attempt = np.where(rt, it + 1, t_attempt); budget = np.where(rt, budget * 2, budget)
+                jumped = jumped | rt
+                if verbose: print(it + 1, 'RETRY', np.nonzero(rt)[0], attempt[rt])
         keep = ~(rs | jumped)
         lam = ((k + 1) / (k + 2))[:, None]
         x = np.where(keep[:, None], lam * (2 * xp - x) + (1 - lam) * x0, x)
         y = np.where(keep[:, None], lam * (2 * yp - y) + (1 - lam) * y0, y)
     Xo[~done], Yo[~done] = (xp * dc)[~done], (yp * dr)[~done]
-    solve.last_jumps = (njump, jtot); solve.last_w = w
+    solve.last_jumps = (njump, jtot); solve.last_w = w; solve.last_attempts = attempt
     return Xo, Yo, iters, nrs, done
 
 
