@@ -21,6 +21,9 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# more hardware queues than the runtime's default 4, so that the launches of the pipelined steps (one HIP stream each)
+# really run concurrently; must be set before the HIP runtime initialises
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec (MI355X_MICROARCH.md); 6.29 TB/s measured copy ceiling
 
@@ -80,7 +83,7 @@ def main():
     ap.add_argument("--batch", type=int, default=4096, help="scenarios per GPU")
     ap.add_argument("--eps", type=float, default=1e-9)
     ap.add_argument("--cpu-sample", type=int, default=-1, help="scenarios for the CPU baseline (0 = skip)")
-    ap.add_argument("--streams", type=int, default=3, help="HIP streams the steps are pipelined over")
+    ap.add_argument("--streams", type=int, default=8, help="HIP streams the steps are pipelined over")
     ap.add_argument("--no-spmv", action="store_true", help="skip the streaming SpMV-step roofline measurement")
     args = ap.parse_args()
 

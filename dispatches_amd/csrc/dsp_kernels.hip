@@ -143,28 +143,42 @@ __device__ __forceinline__ void ell_product(double (&out)[S], const Entry *__res
   }
 }
 
+// 64-bit load from a 32-bit LDS byte address (device pass only; the host pass never executes it)
+__device__ __forceinline__ double lds_load_f64(uint32_t addr) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return *(const __attribute__((address_space(3))) double *)addr;
+#else
+  (void)addr;
+  return 0.0;
+#endif
+}
+
 // Register-resident ELL (small LPs): the lane's W*S entries live in VGPRs for the whole kernel, so an SpMV is
 // W*S independent LDS gathers issued back to back (one LDS latency instead of W dependent round trips) + W*S FMAs.
 template <int S, int W>
 struct RegEll {
   double v[W < 1 ? 1 : W][S];
   uint32_t off[W < 1 ? 1 : W][S];
-  __device__ __forceinline__ void load(const Entry *__restrict__ g, int lane) {
+  // `vec_lds` = LDS byte address of the exchange buffer this matrix gathers from: folded into the offsets once,
+  // so a gather needs no address arithmetic in the iteration
+  __device__ __forceinline__ void load(const Entry *__restrict__ g, int lane, uint32_t vec_lds) {
 #pragma unroll
     for (int e = 0; e < W; ++e)
 #pragma unroll
       for (int q = 0; q < S; ++q) {
         const int4 raw = *reinterpret_cast<const int4 *>(g + (e * S + q) * 64 + lane);     // coalesced global load
         v[e][q] = __hiloint2double(raw.y, raw.x);
-        off[e][q] = (uint32_t)raw.z;
+        off[e][q] = (uint32_t)raw.z + vec_lds;
+        asm volatile("" : "+v"(off[e][q]));      // keep the folded address in a VGPR (no re-add per iteration)
       }
   }
-  __device__ __forceinline__ void product(double (&out)[S], const char *vec) const {
+  __device__ __forceinline__ void product(double (&out)[S]) const {
     double xv[W < 1 ? 1 : W][S];
 #pragma unroll
     for (int e = 0; e < W; ++e)
 #pragma unroll
-      for (int q = 0; q < S; ++q) xv[e][q] = *reinterpret_cast<const double *>(vec + off[e][q]);
+      for (int q = 0; q < S; ++q)
+        xv[e][q] = lds_load_f64(off[e][q]);                                                 // ds_read_b64 gather
 #pragma unroll
     for (int q = 0; q < S; ++q) out[q] = 0.0;
 #pragma unroll
@@ -226,12 +240,6 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
   }
   stage_entries(tailc, P.tailc, P.tailc_entries);
   stage_entries(tailr, P.tailr, P.tailr_entries);
-  RegEll<CPL, WC> mreg_c;
-  RegEll<RPL, WR> mreg_r;
-  if (MATREG) {
-    mreg_c.load(P.ellc, lane);
-    mreg_r.load(P.ellr, lane);
-  }
   __syncthreads();
   DSP_TRACE("[trace] staged: Wc=%d Wr=%d B=%d check=%d maxit=%d\n", P.Wc, P.Wr, b.B, a.opt.check_every, a.opt.max_iter);
 
@@ -239,6 +247,13 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
   char *yb = xb + (size_t)P.n_pad * 8;                                 // gathered by column products
   double *xbl = reinterpret_cast<double *>(xb) + lane;                 // this lane's own slots: xbl[64*q]
   double *ybl = reinterpret_cast<double *>(yb) + lane;
+  RegEll<CPL, WC> mreg_c;
+  RegEll<RPL, WR> mreg_r;
+  if (MATREG) {
+    using lds_cptr = const __attribute__((address_space(3))) char *;
+    mreg_c.load(P.ellc, lane, (uint32_t)(uintptr_t)(lds_cptr)yb);      // A^T gathers y from yb
+    mreg_r.load(P.ellr, lane, (uint32_t)(uintptr_t)(lds_cptr)xb);      // A   gathers x from xb
+  }
 
   const int n = P.n, m = P.m;
   const double eta = a.eta;
@@ -247,7 +262,7 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
   const int check_every = a.opt.check_every;
   auto col_product = [&](double (&out)[CPL]) __attribute__((always_inline)) {     // out = A^T (vector in yb)
     if constexpr (MATREG) {
-      mreg_c.product(out, yb);
+      mreg_c.product(out);
       if (LONG) long_product<CPL>(out, yb, lane, P.long_c, tailc);
     } else {
       ell_product<CPL, LONG>(out, ellc, P.Wc, yb, lane, P.long_c, tailc);
@@ -255,7 +270,7 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
   };
   auto row_product = [&](double (&out)[RPL]) __attribute__((always_inline)) {     // out = A (vector in xb)
     if constexpr (MATREG) {
-      mreg_r.product(out, xb);
+      mreg_r.product(out);
       if (LONG) long_product<RPL>(out, xb, lane, P.long_r, tailr);
     } else {
       ell_product<RPL, LONG>(out, ellr, P.Wr, xb, lane, P.long_r, tailr);
@@ -379,7 +394,10 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
 // reflected Halpern step toward the anchor (x0, y0); ax tracks A x through the same recursion
 #define DSP_HALPERN_STEP()                                                                                  \
   {                                                                                                         \
-    const double lam = (double)(k + 1) / (double)(k + 2), oml = 1.0 - lam;                                  \
+    const double kk2 = (double)(k + 2);                                                                     \
+    double oml = __builtin_amdgcn_rcp(kk2);            /* v_rcp_f64 + one Newton step: 1/(k+2) to ~1 ulp */  \
+    oml = fma(fma(-kk2, oml, 1.0), oml, oml);                                                               \
+    const double lam = 1.0 - oml;                                                                           \
     _Pragma("unroll") for (int q = 0; q < CPL; ++q) x[q] = lam * (2.0 * xp[q] - x[q]) + oml * x0[q];        \
     _Pragma("unroll") for (int q = 0; q < RPL; ++q) {                                                       \
       y[q] = lam * (2.0 * yp[q] - y[q]) + oml * y0[q];                                                      \
