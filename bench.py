@@ -232,26 +232,32 @@ def main():
         }
         # ---- streaming SpMV step (vectors in HBM): the kernel SURVEY 8(d) quotes the HBM roofline on -------
         if not args.no_spmv:
-            X = torch.randn((B, lp.n), dtype=torch.float64, device=dev)
-            Y = torch.randn((B, lp.m), dtype=torch.float64, device=dev)
-            AX = torch.empty((B, lp.m), dtype=torch.float64, device=dev)
-            ATY = torch.empty((B, lp.n), dtype=torch.float64, device=dev)
-            for _ in range(5):
-                dlp.spmv_step(X, Y, AX, ATY)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            reps = 200
-            e0.record()
-            for _ in range(reps):
-                dlp.spmv_step(X, Y, AX, ATY)
-            e1.record()
-            torch.cuda.synchronize()
-            ms = e0.elapsed_time(e1) / reps
-            bsp = B * bytes_iter + bytes_shared
-            result["spmv_step"] = dict(bound="hbm", kernel="spmv_step_kernel", achieved=bsp / (ms * 1e-3) / 1e9,
-                                       peak=HBM_PEAK_GBS, unit="GB/s", frac=bsp / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                       traffic=None, kernel_ms=ms, algorithmic_bytes_per_launch=bsp,
-                                       note="timed with events on torch's current stream = the launch stream; "
-                                            "includes launch gaps of back-to-back launches")
+            def time_spmv(Bs, reps):
+                X = torch.randn((Bs, lp.n), dtype=torch.float64, device=dev)
+                Y = torch.randn((Bs, lp.m), dtype=torch.float64, device=dev)
+                AX = torch.empty((Bs, lp.m), dtype=torch.float64, device=dev)
+                ATY = torch.empty((Bs, lp.n), dtype=torch.float64, device=dev)
+                for _ in range(5):
+                    dlp.spmv_step(X, Y, AX, ATY)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(reps):
+                    dlp.spmv_step(X, Y, AX, ATY)
+                e1.record()
+                torch.cuda.synchronize()
+                ms = e0.elapsed_time(e1) / reps
+                bsp = Bs * bytes_iter + bytes_shared
+                return dict(bound="hbm", kernel="spmv_step_kernel", batch=Bs, achieved=bsp / (ms * 1e-3) / 1e9,
+                            peak=HBM_PEAK_GBS, unit="GB/s", frac=bsp / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                            traffic=None, kernel_ms=ms, algorithmic_bytes_per_launch=bsp)
+
+            result["spmv_step"] = time_spmv(B, 200)
+            result["spmv_step"]["note"] = ("one A x + one A^T y for every scenario of the batch with vectors streamed "
+                                           "from/to HBM; events on the launch stream, back-to-back launches (includes "
+                                           "launch gaps); at the metric batch the launch moves only ~20 MB and is "
+                                           "launch/latency bound")
+            # the same kernel on a batch large enough to be bandwidth bound (0.67 GB per launch, beyond L2 + MALL)
+            result["spmv_step_large_batch"] = time_spmv(32 * B, 20)
         # ---- CPU baseline on this box's host cores (bounded sample) ------------------------------------------
         if world == 1 and args.cpu_sample != 0 and args.workload.startswith("wind_battery"):
             procs = os.cpu_count() or 1

@@ -273,6 +273,34 @@ def test_full_size_batch_certificate_and_invariances():
 
 
 @gpu
+def test_rolling_update_and_real_time_bids_match_oracle(rts309):
+    """Rolling-horizon state update (reference wind_battery_double_loop.py:181-209) followed by a real-time bid
+    (pda fixed to the realised DA dispatch) on the GPU, against the oracle's RT LP.  The product keeps
+    the DA-revenue term of the DA objective, which is the constant sum_t DA_t * pda_t once pda is fixed; the oracle's
+    RT objective (pinned by golden G6) has no such term, so the two differ by exactly that constant."""
+    from dispatches_amd.flowsheets import MultiPeriodWindBattery
+    from dispatches_amd.workflow import Bidder, ThermalGeneratorModelData
+    from oracle import dispatch_lp_oracle as orc
+    from tests.test_workflow_cpu import _backcaster, thermal_params
+    mp = MultiPeriodWindBattery(model_data=ThermalGeneratorModelData(**thermal_params()),
+                                wind_capacity_factors=list(rts309["rt_cf"][:200]), wind_pmax_mw=200,
+                                battery_pmax_mw=25, battery_energy_capacity_mwh=100)
+    bidder = Bidder(bidding_model_object=mp, day_ahead_horizon=24, real_time_horizon=4, n_scenario=2,
+                    solver=_solver(), forecaster=_backcaster(rts309))
+    bidder.update_real_time_model(realized_soc=[1234.5678], realized_energy_throughput=[617.28391])
+    bids = bidder.compute_real_time_bids(date="2020-01-02", hour=1, realized_day_ahead_prices=[20.0] * 24,
+                                         realized_day_ahead_dispatches=[1.0] * 24)
+    assert sorted(bids) == [1, 2, 3, 4]
+    m = bidder.real_time_model
+    assert m.status.tolist() == [0, 0]
+    assert np.allclose(m.x[:, m.pda_cols], 1.0, atol=1e-9)
+    for k in range(2):
+        P, *_ = orc.wind_battery_rt(4, rts309["rt_cf"][1:5], m.rt_prices[k], [1.0] * 4, soc0=1234.57, e0=617.28)
+        ref = P.solve(tight=True)[1] - 20.0 * 1.0 * 4
+        assert abs(m.objective[k] - ref) <= 1e-6 * max(1.0, abs(ref)), (m.objective[k], ref)
+
+
+@gpu
 def test_edge_cases():
     """Ragged / degenerate inputs: B=1, B not a multiple of the block, zero prices, a free row, warm start."""
     from dispatches_amd import scenarios
