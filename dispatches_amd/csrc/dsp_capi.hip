@@ -36,7 +36,8 @@ struct dsp_handle {
   std::vector<void *> allocs;     // device allocations owned by the handle
   std::vector<double> dr, dc;
   int *queue = nullptr;           // ring of kQueueRing work-queue heads (64 B apart): launches on different streams
-  unsigned queue_next = 0;        // may be in flight together, each needs its own head
+  unsigned queue_next = 0;        // may be in flight together, each needs its own head.  Heads are zeroed once at
+  std::vector<unsigned> queue_base;  // create time and only count up; queue_base[slot] = value before the next launch
   int lds_limit = 160 * 1024;
   int num_cus = 256;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -75,7 +76,7 @@ static int fill_long(LongList &L, const LaneELL &E) {
   return DSP_OK;
 }
 
-constexpr int kQueueRing = 32;
+constexpr int kQueueRing = 256;
 constexpr int kQueueStride = 16;       // ints (64 bytes) between ring slots
 constexpr int kMaxWavesPerBlock = 8;   // kernels are compiled with __launch_bounds__(512)
 
@@ -229,6 +230,8 @@ int dsp_create(const dsp_lp_desc *d, int device, const dsp_options *opt, dsp_han
   void *q = nullptr;
   if (hipMalloc(&q, sizeof(int) * kQueueRing * kQueueStride) != hipSuccess) { dsp_destroy(h); return DSP_ERR_HIP; }
   h->queue = (int *)q;
+  if (hipMemset(q, 0, sizeof(int) * kQueueRing * kQueueStride) != hipSuccess) { dsp_destroy(h); return DSP_ERR_HIP; }
+  h->queue_base.assign(kQueueRing, 0u);
   if (hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess) { dsp_destroy(h); return DSP_ERR_HIP; }
   *out = h;
   return DSP_OK;
@@ -254,13 +257,15 @@ int dsp_solve(dsp_handle *h, const dsp_batch *batch, const dsp_options *opt, dsp
   if (grc != DSP_OK) return grc;
   a.waves_per_block = geo.wpb;
   const size_t lds = geo.lds;
-  a.queue = h->queue + (size_t)(h->queue_next++ % kQueueRing) * kQueueStride;
+  const unsigned slot = h->queue_next++ % kQueueRing;
+  a.queue = h->queue + (size_t)slot * kQueueStride;
+  a.queue_base = h->queue_base[slot];
   a.matreg = h->matreg;
   int grid = std::min((B + geo.wpb - 1) / geo.wpb, h->num_cus * geo.blocks_per_cu);
-  HIP_TRY(hipMemsetAsync(a.queue, 0, sizeof(int), st));
   const bool timed = stats && sync_stats;
   if (timed) HIP_TRY(hipEventRecord(h->ev0, st));
   HIP_TRY(launch_solve(h->cpl, h->rpl, a, dim3(grid), dim3(64 * a.waves_per_block), lds, st));
+  h->queue_base[slot] += (unsigned)B + (unsigned)grid * (unsigned)a.waves_per_block;   // B hits + one miss per wave
   if (timed) HIP_TRY(hipEventRecord(h->ev1, st));
   if (stats) {
     std::memset(stats, 0, sizeof(*stats));

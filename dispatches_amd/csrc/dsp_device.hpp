@@ -45,7 +45,8 @@ struct SolveArgs {
   int waves_per_block;
   double eta;
   dsp_options opt;
-  int *queue;                  // device work-queue head (zeroed before the launch)
+  int *queue;                  // device work-queue head: counts up for ever, this launch's scenarios are
+  unsigned queue_base;         //   head - queue_base (every wave overshoots exactly once when it finds the queue empty)
   int matreg;                  // 1 = register-resident-matrix specialisation of the kernel
 };
 

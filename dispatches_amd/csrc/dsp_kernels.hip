@@ -280,10 +280,10 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
   for (;;) {
     // ---- pull the next scenario off the work queue ---------------------------------------------------------
     int s = 0;
-    if (lane == 0) s = atomicAdd(a.queue, 1);
+    if (lane == 0) s = (int)((unsigned)atomicAdd(a.queue, 1) - a.queue_base);   // heads only ever count up: no reset
     s = __builtin_amdgcn_readfirstlane(s);
     DSP_TRACE("[trace] scenario %d\n", s);
-    if (s >= b.B) break;
+    if ((unsigned)s >= (unsigned)b.B) break;
 
     // ---- load + scale this scenario's vectors (coalesced: lane-consecutive addresses) -----------------------
     double x[CPL], x0[CPL], c[CPL], lb[CPL], ub[CPL];
