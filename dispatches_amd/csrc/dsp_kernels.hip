@@ -260,6 +260,7 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
   const double eps = a.opt.eps_rel;
   const double eps_obj = a.opt.eps_obj;
   const int check_every = a.opt.check_every;
+  const int kkt_every = a.opt.kkt_every > 0 ? a.opt.kkt_every : 1;
   auto col_product = [&](double (&out)[CPL]) __attribute__((always_inline)) {     // out = A^T (vector in yb)
     if constexpr (MATREG) {
       mreg_c.product(out);
@@ -365,6 +366,7 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
     int k = 0;                       // iterations since the last restart
     int it = 0;
     int njump = 0;
+    int ncheck = 0;
     double r0 = INFINITY, rprev = INFINITY;
     int status = DSP_STATUS_ITERATION_LIMIT;
     double xp[CPL], yp[RPL], axb[RPL];
@@ -423,59 +425,68 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
       ++k;
       bool moved = false;            // restarted or jumped: the Halpern step is skipped
       {
-        // ---- KKT test at (x+, y+) in the ORIGINAL (unscaled) space + fixed-point residual --------------------
+        // ---- every check: fixed-point residual in the PDHG metric (3 reductions) ------------------------------
+        double rr[3] = {0.0, 0.0, 0.0};                    // |dx|^2, |dy|^2, dy.A dx
 #pragma unroll
-        for (int q = 0; q < RPL; ++q) ybl[64 * q] = yp[q];
-        wave_lds_fence();
-        double atyp[CPL];
-        col_product(atyp);
-        // red: 0 pres^2, 1 dres^2, 2 pobj, 3 dobj, 4 sum|y| viol, 5 sum|c x|, 6 |dx|^2, 7 |dy|^2, 8 dy.A dx,
-        //      9 sum|dual residual| |x|   (4 and 9 bound the objective error caused by the remaining infeasibility)
-        double red[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-        for (int q = 0; q < CPL; ++q) {
-          const double rc = c[q] - atyp[q];
-          const double lp = is_finite(lb[q]) ? fmax(rc, 0.0) : 0.0;
-          const double lm = is_finite(ub[q]) ? fmax(-rc, 0.0) : 0.0;
-          const int j = lane + 64 * q;
-          const double dr_ = (rc - lp + lm) / ((j < n) ? P.col_scale[j] : 1.0);
-          red[1] = fma(dr_, dr_, red[1]);
-          red[9] = fma(fabs(rc - lp + lm), fabs(xp[q]), red[9]);
-          const double cx = c[q] * xp[q];
-          red[2] += cx;
-          red[5] += fabs(cx);
-          red[3] += lp * finite_or_zero(lb[q]) - lm * finite_or_zero(ub[q]);
-          const double dx = xp[q] - x[q];
-          red[6] = fma(dx, dx, red[6]);
-        }
+        for (int q = 0; q < CPL; ++q) { const double dx = xp[q] - x[q]; rr[0] = fma(dx, dx, rr[0]); }
 #pragma unroll
         for (int q = 0; q < RPL; ++q) {
-          const double axp = 0.5 * (axb[q] + ax[q]);
-          const double viol_s = fmax(rlo[q] - axp, 0.0) + fmax(axp - rhi[q], 0.0);
-          const int i = lane + 64 * q;
-          const double viol = viol_s / ((i < m) ? P.row_scale[i] : 1.0);
-          red[0] = fma(viol, viol, red[0]);
-          red[4] = fma(fabs(yp[q]), viol_s, red[4]);
-          red[3] += fmax(yp[q], 0.0) * finite_or_zero(rlo[q]) - fmax(-yp[q], 0.0) * finite_or_zero(rhi[q]);
           const double dy = yp[q] - y[q];
-          red[7] = fma(dy, dy, red[7]);
-          red[8] = fma(dy, 0.5 * (axb[q] - ax[q]), red[8]);
+          rr[1] = fma(dy, dy, rr[1]);
+          rr[2] = fma(dy, 0.5 * (axb[q] - ax[q]), rr[2]);
         }
-        wave_sums<10>(red);
-        const double po = red[2], dobj = red[3];
-        pobj = po;
-        const double r = sqrt(fmax(w * red[6] - 2.0 * eta * red[8] + red[7] / w, 0.0));
-        if (!(r == r) || !(po == po)) { status = DSP_STATUS_NUMERICAL; break; }
-        const double rp = sqrt(red[0]) / (1.0 + qn);
-        const double rd = sqrt(red[1]) / (1.0 + cn);
-        const double gap = fabs(po - dobj);
-        const double rg = gap / (1.0 + fabs(po) + fabs(dobj));
-        bool done = rp <= eps && rd <= eps && rg <= eps;
-        if (done && eps_obj > 0.0) {
-          const double lim = fmax(eps_obj * (1.0 + fabs(po + c0)), 1e-12 * red[5]);
-          done = gap <= lim && red[4] <= lim && red[9] <= lim;
+        wave_sums<3>(rr);
+        const double r = sqrt(fmax(w * rr[0] - 2.0 * eta * rr[2] + rr[1] / w, 0.0));
+        if (!(r == r)) { status = DSP_STATUS_NUMERICAL; break; }
+        // ---- every kkt_every-th check: KKT test at (x+, y+) in the ORIGINAL (unscaled) space ---------------------
+        if ((++ncheck % kkt_every) == 0) {
+#pragma unroll
+          for (int q = 0; q < RPL; ++q) ybl[64 * q] = yp[q];
+          wave_lds_fence();
+          double atyp[CPL];
+          col_product(atyp);
+          // red: 0 pres^2, 1 dres^2, 2 pobj, 3 dobj, 4 sum|y| viol, 5 sum|c x|, 6 sum|dual residual| |x|
+          //      (4 and 6 bound the objective error caused by the remaining infeasibility)
+          double red[7] = {0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+          for (int q = 0; q < CPL; ++q) {
+            const double rc = c[q] - atyp[q];
+            const double lp = is_finite(lb[q]) ? fmax(rc, 0.0) : 0.0;
+            const double lm = is_finite(ub[q]) ? fmax(-rc, 0.0) : 0.0;
+            const int j = lane + 64 * q;
+            const double dr_ = (rc - lp + lm) / ((j < n) ? P.col_scale[j] : 1.0);
+            red[1] = fma(dr_, dr_, red[1]);
+            red[6] = fma(fabs(rc - lp + lm), fabs(xp[q]), red[6]);
+            const double cx = c[q] * xp[q];
+            red[2] += cx;
+            red[5] += fabs(cx);
+            red[3] += lp * finite_or_zero(lb[q]) - lm * finite_or_zero(ub[q]);
+          }
+#pragma unroll
+          for (int q = 0; q < RPL; ++q) {
+            const double axp = 0.5 * (axb[q] + ax[q]);
+            const double viol_s = fmax(rlo[q] - axp, 0.0) + fmax(axp - rhi[q], 0.0);
+            const int i = lane + 64 * q;
+            const double viol = viol_s / ((i < m) ? P.row_scale[i] : 1.0);
+            red[0] = fma(viol, viol, red[0]);
+            red[4] = fma(fabs(yp[q]), viol_s, red[4]);
+            red[3] += fmax(yp[q], 0.0) * finite_or_zero(rlo[q]) - fmax(-yp[q], 0.0) * finite_or_zero(rhi[q]);
+          }
+          wave_sums<7>(red);
+          const double po = red[2], dobj = red[3];
+          pobj = po;
+          if (!(po == po)) { status = DSP_STATUS_NUMERICAL; break; }
+          const double rp = sqrt(red[0]) / (1.0 + qn);
+          const double rd = sqrt(red[1]) / (1.0 + cn);
+          const double gap = fabs(po - dobj);
+          const double rg = gap / (1.0 + fabs(po) + fabs(dobj));
+          bool done = rp <= eps && rd <= eps && rg <= eps;
+          if (done && eps_obj > 0.0) {
+            const double lim = fmax(eps_obj * (1.0 + fabs(po + c0)), 1e-12 * red[5]);
+            done = gap <= lim && red[4] <= lim && red[6] <= lim;
+          }
+          if (done) { status = DSP_STATUS_OPTIMAL; ++it; break; }
         }
-        if (done) { status = DSP_STATUS_OPTIMAL; ++it; break; }
         // ---- restart test (r0 = residual at the first check after a restart) ----------------------------------
         const bool first = !(r0 < INFINITY);
         const bool do_restart = !first && ((r <= a.opt.restart_sufficient * r0) ||
@@ -514,7 +525,11 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
           moved = true;
         } else if (steady) {
           // ---- ray jump: second application of T from (x+, y+), translation test, ratio test ------------------
-          double x2[CPL], y2[RPL], axb1[RPL];
+          double x2[CPL], y2[RPL], axb1[RPL], atyp[CPL];
+#pragma unroll
+          for (int q = 0; q < RPL; ++q) ybl[64 * q] = yp[q];
+          wave_lds_fence();
+          col_product(atyp);                 // A^T y+ for the second application of T
           double tt[2] = {0.0, 0.0};       // |v2 - v1|^2_w, |v2|^2_w
           double alpha = INFINITY;
 #pragma unroll
