@@ -69,6 +69,18 @@ static void pack_entries(const std::vector<double> &val, const std::vector<uint1
   for (size_t i = 0; i < val.size(); ++i) { out[i].v = val[i]; out[i].off = (uint32_t)idx[i] * 8u; out[i].pad = 0; }
 }
 
+static void pack_entries(const std::vector<double> &val, const std::vector<uint32_t> &off, std::vector<Entry> &out) {
+  out.resize(val.size());
+  for (size_t i = 0; i < val.size(); ++i) { out[i].v = val[i]; out[i].off = off[i]; out[i].pad = 0; }
+}
+
+static int fill_long(LongList &L, const SlotELL &E) {
+  if ((int)E.long_owner_pos.size() > kMaxLong) return DSP_ERR_TOO_LARGE;
+  L.count = (int)E.long_owner_pos.size();
+  for (int i = 0; i < L.count; ++i) { L.owner[i] = E.long_owner_pos[i]; L.start[i] = E.long_start[i]; L.len[i] = E.long_len[i]; }
+  return DSP_OK;
+}
+
 static int fill_long(LongList &L, const LaneELL &E) {
   if ((int)E.long_owner.size() > kMaxLong) return DSP_ERR_TOO_LARGE;
   L.count = (int)E.long_owner.size();
@@ -82,8 +94,8 @@ constexpr int kMaxWavesPerBlock = 8;   // kernels are compiled with __launch_bou
 
 // LDS bytes of a block with `wpb` waves
 static size_t lds_bytes(const DeviceProblem &P, int wpb, bool matreg = false) {
-  size_t ent = (size_t)P.tailc_entries + P.tailr_entries;
-  if (!matreg) ent += (size_t)P.ellc_entries + P.ellr_entries;
+  size_t ent = matreg ? (size_t)P.mr_tailc_entries + P.mr_tailr_entries
+                      : (size_t)P.tailc_entries + P.tailr_entries + P.ellc_entries + P.ellr_entries;
   return ent * sizeof(Entry) + (size_t)wpb * (P.n_pad + P.m_pad) * 8;
 }
 
@@ -218,7 +230,13 @@ int dsp_create(const dsp_lp_desc *d, int device, const dsp_options *opt, dsp_han
   P.tailc_entries = (int)Ec.tail_val.size(); P.tailr_entries = (int)Er.tail_val.size();
   int rc;
   if ((rc = fill_long(P.long_c, Ec)) || (rc = fill_long(P.long_r, Er))) { delete h; return rc; }
-  h->matreg = (!h->opt.no_matreg && matreg_available(cpl, rpl, P.Wc, P.Wr, P.long_c.count > 0 || P.long_r.count > 0)) ? 1 : 0;
+  // register-resident-matrix layout: ownership sorted by length, per-slot widths, position space
+  SortedLayout Lc = sorted_layout(AT, cpl, Ec.long_owner), Lr = sorted_layout(A, rpl, Er.long_owner);
+  SlotELL Sc = build_slot_ell(AT, Lc, Lr, Ec.long_owner), Sr = build_slot_ell(A, Lr, Lc, Er.long_owner);
+  P.mr_wc_pack = Sc.pack; P.mr_wr_pack = Sr.pack;
+  P.mr_tailc_entries = (int)Sc.tail_val.size(); P.mr_tailr_entries = (int)Sr.tail_val.size();
+  if ((rc = fill_long(P.mr_long_c, Sc)) || (rc = fill_long(P.mr_long_r, Sr))) { delete h; return rc; }
+  h->matreg = (!h->opt.no_matreg && matreg_available(cpl, rpl, Sc.pack, Sr.pack, P.long_c.count > 0 || P.long_r.count > 0)) ? 1 : 0;
   std::vector<Entry> pk;
 #define UPE(val, idx, field) pack_entries(val, idx, pk); if ((rc = upload(h, pk, &P.field)) != DSP_OK) { dsp_destroy(h); return rc; }
 #define UP(vec, field) if ((rc = upload(h, vec, &P.field)) != DSP_OK) { dsp_destroy(h); return rc; }
@@ -226,6 +244,8 @@ int dsp_create(const dsp_lp_desc *d, int device, const dsp_options *opt, dsp_han
   UPE(Ecu.val, Ecu.idx, ellc_unscaled) UPE(Eru.val, Eru.idx, ellr_unscaled)
   UPE(Ecu.tail_val, Ecu.tail_idx, tailc_unscaled) UPE(Eru.tail_val, Eru.tail_idx, tailr_unscaled)
   UP(h->dc, col_scale) UP(h->dr, row_scale)
+  UPE(Sc.val, Sc.off, mr_ellc) UPE(Sr.val, Sr.off, mr_ellr) UPE(Sc.tail_val, Sc.tail_off, mr_tailc) UPE(Sr.tail_val, Sr.tail_off, mr_tailr)
+  UP(Lc.at, mr_colat) UP(Lr.at, mr_rowat)
 #undef UP
 #undef UPE
   void *q = nullptr;

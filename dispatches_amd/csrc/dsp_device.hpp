@@ -37,6 +37,12 @@ struct DeviceProblem {
   const Entry *ellc_unscaled, *ellr_unscaled, *tailc_unscaled, *tailr_unscaled;
   const double *col_scale, *row_scale;                             // D_c [n], D_r [m]
   LongList long_c, long_r;
+  // register-resident-matrix layout (dsp_prepare.hpp: SortedLayout / SlotELL), everything in POSITION space
+  const Entry *mr_ellc, *mr_ellr, *mr_tailc, *mr_tailr;            // slot-major per-slot-width ELL of the scaled matrix
+  int mr_tailc_entries, mr_tailr_entries;
+  const int *mr_colat, *mr_rowat;                                  // [n_pad] / [m_pad] position -> column / row id, -1 = pad
+  unsigned mr_wc_pack, mr_wr_pack;                                 // per-slot widths, 4 bits each
+  LongList mr_long_c, mr_long_r;                                   // owner = POSITION
 };
 
 struct SolveArgs {
@@ -59,7 +65,7 @@ struct SpmvArgs {
 };
 
 hipError_t launch_solve(int cpl, int rpl, const SolveArgs &a, dim3 grid, dim3 block, size_t lds, hipStream_t st);
-bool matreg_available(int cpl, int rpl, int wc, int wr, bool lng);
+bool matreg_available(int cpl, int rpl, unsigned wc_pack, unsigned wr_pack, bool lng);
 hipError_t occupancy_solve(int cpl, int rpl, const SolveArgs &a, int block_threads, size_t lds, int *blocks_per_cu);
 hipError_t launch_spmv(int cpl, int rpl, const SpmvArgs &a, dim3 grid, dim3 block, size_t lds, hipStream_t st);
 

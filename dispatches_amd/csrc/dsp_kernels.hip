@@ -155,36 +155,36 @@ __device__ __forceinline__ double lds_load_f64(uint32_t addr) {
 
 // Register-resident ELL (small LPs): the lane's W*S entries live in VGPRs for the whole kernel, so an SpMV is
 // W*S independent LDS gathers issued back to back (one LDS latency instead of W dependent round trips) + W*S FMAs.
-template <int S, int W>
+template <int S, unsigned PACK>
 struct RegEll {
-  double v[W < 1 ? 1 : W][S];
-  uint32_t off[W < 1 ? 1 : W][S];
+  static constexpr int w(int q) { return q < 8 ? (int)((PACK >> (4 * q)) & 15u) : 0; }   // width of slot q (<= 8 slots)
+  static constexpr int base(int q) { int t = 0; for (int i = 0; i < q; ++i) t += w(i); return t; }
+  static constexpr int total() { return base(S); }
+  static constexpr int N = total() < 1 ? 1 : total();
+  double v[N];
+  uint32_t off[N];
   // `vec_lds` = LDS byte address of the exchange buffer this matrix gathers from: folded into the offsets once,
   // so a gather needs no address arithmetic in the iteration
   __device__ __forceinline__ void load(const Entry *__restrict__ g, int lane, uint32_t vec_lds) {
 #pragma unroll
-    for (int e = 0; e < W; ++e)
-#pragma unroll
-      for (int q = 0; q < S; ++q) {
-        const int4 raw = *reinterpret_cast<const int4 *>(g + (e * S + q) * 64 + lane);     // coalesced global load
-        v[e][q] = __hiloint2double(raw.y, raw.x);
-        off[e][q] = (uint32_t)raw.z + vec_lds;
-        asm volatile("" : "+v"(off[e][q]));      // keep the folded address in a VGPR (no re-add per iteration)
-      }
+    for (int t = 0; t < total(); ++t) {
+      const int4 raw = *reinterpret_cast<const int4 *>(g + t * 64 + lane);                   // coalesced global load
+      v[t] = __hiloint2double(raw.y, raw.x);
+      off[t] = (uint32_t)raw.z + vec_lds;
+      asm volatile("" : "+v"(off[t]));             // keep the folded address in a VGPR (no re-add per iteration)
+    }
   }
   __device__ __forceinline__ void product(double (&out)[S]) const {
-    double xv[W < 1 ? 1 : W][S];
+    double xv[N];
 #pragma unroll
-    for (int e = 0; e < W; ++e)
+    for (int t = 0; t < total(); ++t) xv[t] = lds_load_f64(off[t]);                          // ds_read_b64 gathers
 #pragma unroll
-      for (int q = 0; q < S; ++q)
-        xv[e][q] = lds_load_f64(off[e][q]);                                                 // ds_read_b64 gather
+    for (int q = 0; q < S; ++q) {
+      double acc = 0.0;
 #pragma unroll
-    for (int q = 0; q < S; ++q) out[q] = 0.0;
-#pragma unroll
-    for (int e = 0; e < W; ++e)
-#pragma unroll
-      for (int q = 0; q < S; ++q) out[q] = fma(v[e][q], xv[e][q], out[q]);
+      for (int e = 0; e < w(q); ++e) acc = fma(v[base(q) + e], xv[base(q) + e], acc);
+      out[q] = acc;
+    }
   }
 };
 
@@ -217,11 +217,12 @@ __device__ __forceinline__ void stage_entries(Entry *dst, const Entry *__restric
 #ifndef DSP_MIN_WAVES_SMALL
 #define DSP_MIN_WAVES_SMALL 2
 #endif
-// WC / WR > 0: the ELL part of A^T / A is register-resident (RegEll) with these compile-time widths;
-// WC = WR = 0: generic path, matrix in LDS with run-time widths.
-template <int CPL, int RPL, bool LONG, int WC, int WR>
+// WC / WR != 0: the ELL part of A^T / A is register-resident (RegEll); the template value packs the per-slot
+// widths, 4 bits each, and ownership follows the sorted layout (P.mr_colat / P.mr_rowat);
+// WC = WR = 0: generic path, matrix in LDS with run-time uniform widths, identity ownership.
+template <int CPL, int RPL, bool LONG, unsigned WC, unsigned WR>
 __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 2) pdlp_solve_kernel(SolveArgs a) {
-  constexpr bool MATREG = WC > 0;
+  constexpr bool MATREG = WC != 0;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const DeviceProblem &P = a.P;
   const dsp_batch &b = a.b;
@@ -232,14 +233,18 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
   Entry *ellc = reinterpret_cast<Entry *>(smem);                       // A^T (columns)  [Wc*CPL*64]
   Entry *ellr = ellc + (MATREG ? 0 : P.ellc_entries);                  // A   (rows)     [Wr*RPL*64]
   Entry *tailc = ellr + (MATREG ? 0 : P.ellr_entries);
-  Entry *tailr = tailc + P.tailc_entries;
-  char *wave_buf = reinterpret_cast<char *>(tailr + P.tailr_entries);  // [waves][(n_pad + m_pad) * 8]
+  const int n_tailc = MATREG ? P.mr_tailc_entries : P.tailc_entries;
+  const int n_tailr = MATREG ? P.mr_tailr_entries : P.tailr_entries;
+  Entry *tailr = tailc + n_tailc;
+  char *wave_buf = reinterpret_cast<char *>(tailr + n_tailr);          // [waves][(n_pad + m_pad) * 8]
   if (!MATREG) {
     stage_entries(ellc, P.ellc, P.ellc_entries);
     stage_entries(ellr, P.ellr, P.ellr_entries);
   }
-  stage_entries(tailc, P.tailc, P.tailc_entries);
-  stage_entries(tailr, P.tailr, P.tailr_entries);
+  stage_entries(tailc, MATREG ? P.mr_tailc : P.tailc, n_tailc);
+  stage_entries(tailr, MATREG ? P.mr_tailr : P.tailr, n_tailr);
+  const LongList &long_c = MATREG ? P.mr_long_c : P.long_c;
+  const LongList &long_r = MATREG ? P.mr_long_r : P.long_r;
   __syncthreads();
   DSP_TRACE("[trace] staged: Wc=%d Wr=%d B=%d check=%d maxit=%d\n", P.Wc, P.Wr, b.B, a.opt.check_every, a.opt.max_iter);
 
@@ -251,11 +256,20 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
   RegEll<RPL, WR> mreg_r;
   if (MATREG) {
     using lds_cptr = const __attribute__((address_space(3))) char *;
-    mreg_c.load(P.ellc, lane, (uint32_t)(uintptr_t)(lds_cptr)yb);      // A^T gathers y from yb
-    mreg_r.load(P.ellr, lane, (uint32_t)(uintptr_t)(lds_cptr)xb);      // A   gathers x from xb
+    mreg_c.load(P.mr_ellc, lane, (uint32_t)(uintptr_t)(lds_cptr)yb);   // A^T gathers y from yb
+    mreg_r.load(P.mr_ellr, lane, (uint32_t)(uintptr_t)(lds_cptr)xb);   // A   gathers x from xb
   }
 
   const int n = P.n, m = P.m;
+  // column / row owned by slot q of this lane (-1 = padding): sorted layout for the register-resident kernel
+  auto col_id = [&](int q) __attribute__((always_inline)) {
+    if constexpr (MATREG) return P.mr_colat[lane + 64 * q];
+    else { const int j = lane + 64 * q; return j < n ? j : -1; }
+  };
+  auto row_id = [&](int q) __attribute__((always_inline)) {
+    if constexpr (MATREG) return P.mr_rowat[lane + 64 * q];
+    else { const int i = lane + 64 * q; return i < m ? i : -1; }
+  };
   const double eta = a.eta;
   const double eps = a.opt.eps_rel;
   const double eps_obj = a.opt.eps_obj;
@@ -264,7 +278,7 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
   auto col_product = [&](double (&out)[CPL]) __attribute__((always_inline)) {     // out = A^T (vector in yb)
     if constexpr (MATREG) {
       mreg_c.product(out);
-      if (LONG) long_product<CPL>(out, yb, lane, P.long_c, tailc);
+      if (LONG) long_product<CPL>(out, yb, lane, long_c, tailc);
     } else {
       ell_product<CPL, LONG>(out, ellc, P.Wc, yb, lane, P.long_c, tailc);
     }
@@ -272,7 +286,7 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
   auto row_product = [&](double (&out)[RPL]) __attribute__((always_inline)) {     // out = A (vector in xb)
     if constexpr (MATREG) {
       mreg_r.product(out);
-      if (LONG) long_product<RPL>(out, xb, lane, P.long_r, tailr);
+      if (LONG) long_product<RPL>(out, xb, lane, long_r, tailr);
     } else {
       ell_product<RPL, LONG>(out, ellr, P.Wr, xb, lane, P.long_r, tailr);
     }
@@ -294,8 +308,8 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
     double bs2 = 0.0;                                    // sum of squared finite scaled column bounds
 #pragma unroll
     for (int q = 0; q < CPL; ++q) {
-      const int j = lane + 64 * q;
-      const bool ok = j < n;
+      const int j = col_id(q);
+      const bool ok = j >= 0;
       const double d = ok ? P.col_scale[j] : 1.0;
       const double cu = ok ? b.c[(size_t)s * b.c_stride + j] : 0.0;
       const double lu = ok ? (b.var_lb ? b.var_lb[(size_t)s * b.var_lb_stride + j] : -INFINITY) : 0.0;
@@ -315,8 +329,8 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
     }
 #pragma unroll
     for (int q = 0; q < RPL; ++q) {
-      const int i = lane + 64 * q;
-      const bool ok = i < m;
+      const int i = row_id(q);
+      const bool ok = i >= 0;
       const double d = ok ? P.row_scale[i] : 1.0;
       const double lo = (ok && b.row_lb) ? b.row_lb[(size_t)s * b.row_lb_stride + i] : -INFINITY;
       const double hi = (ok && b.row_ub) ? b.row_ub[(size_t)s * b.row_ub_stride + i] : INFINITY;
@@ -453,8 +467,8 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
             const double rc = c[q] - atyp[q];
             const double lp = is_finite(lb[q]) ? fmax(rc, 0.0) : 0.0;
             const double lm = is_finite(ub[q]) ? fmax(-rc, 0.0) : 0.0;
-            const int j = lane + 64 * q;
-            const double dr_ = (rc - lp + lm) / ((j < n) ? P.col_scale[j] : 1.0);
+            const int j = col_id(q);
+            const double dr_ = (rc - lp + lm) / ((j >= 0) ? P.col_scale[j] : 1.0);
             red[1] = fma(dr_, dr_, red[1]);
             red[6] = fma(fabs(rc - lp + lm), fabs(xp[q]), red[6]);
             const double cx = c[q] * xp[q];
@@ -466,8 +480,8 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
           for (int q = 0; q < RPL; ++q) {
             const double axp = 0.5 * (axb[q] + ax[q]);
             const double viol_s = fmax(rlo[q] - axp, 0.0) + fmax(axp - rhi[q], 0.0);
-            const int i = lane + 64 * q;
-            const double viol = viol_s / ((i < m) ? P.row_scale[i] : 1.0);
+            const int i = row_id(q);
+            const double viol = viol_s / ((i >= 0) ? P.row_scale[i] : 1.0);
             red[0] = fma(viol, viol, red[0]);
             red[4] = fma(fabs(yp[q]), viol_s, red[4]);
             red[3] += fmax(yp[q], 0.0) * finite_or_zero(rlo[q]) - fmax(-yp[q], 0.0) * finite_or_zero(rhi[q]);
@@ -597,15 +611,15 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
     }
 #pragma unroll
     for (int q = 0; q < CPL; ++q) {
-      const int j = lane + 64 * q;
-      if (j < n) b.x[(size_t)s * n + j] = xp[q] * P.col_scale[j];
+      const int j = col_id(q);
+      if (j >= 0) b.x[(size_t)s * n + j] = xp[q] * P.col_scale[j];
     }
     DSP_DRAIN();
     DSP_TRACE("[trace] x stored %p\n", (void *)b.x);
 #pragma unroll
     for (int q = 0; q < RPL; ++q) {
-      const int i = lane + 64 * q;
-      if (i < m) b.y[(size_t)s * m + i] = yp[q] * P.row_scale[i];
+      const int i = row_id(q);
+      if (i >= 0) b.y[(size_t)s * m + i] = yp[q] * P.row_scale[i];
     }
     DSP_DRAIN();
     DSP_TRACE("[trace] y stored %p obj %p status %p iters %p jumps %p pw %p queue %p\n", (void *)b.y, (void *)b.obj, (void *)b.status, (void *)b.iters, (void *)b.jumps, (void *)b.primal_weight, (void *)a.queue);
@@ -685,9 +699,14 @@ __global__ void __launch_bounds__(512) spmv_step_kernel(SpmvArgs a) {
 // Register-resident-matrix specialisations exist for the shapes of the reference's flowsheets at the benchmark
 // horizons (cols/lane, rows/lane, ELL width of A^T, ELL width of A, long vectors): everything else runs the generic
 // LDS-matrix kernel.  wind+battery 24 h, nuclear 24 h / 48 h, wind+PEM 48 h (shared capacity column = long vector).
-#define DSP_MATREG_SHAPES(X) X(4, 2, 3, 4, false) X(3, 2, 2, 4, false) X(5, 3, 2, 4, false) X(4, 3, 2, 3, true)
+// X(cols/lane, rows/lane, per-slot widths of A^T (4 bits each, slot 0 lowest), per-slot widths of A, long vectors)
+#define DSP_MATREG_SHAPES(X)                                                                                  \
+  X(4, 2, 0x1133u, 0x44u, false)      /* wind+battery 24 h */                                                 \
+  X(3, 2, 0x122u, 0x24u, false)       /* nuclear 24 h      */                                                 \
+  X(5, 3, 0x11222u, 0x234u, false)    /* nuclear 48 h      */                                                 \
+  X(4, 3, 0x1122u, 0x233u, true)      /* wind+PEM 48 h     */
 
-bool matreg_available(int cpl, int rpl, int wc, int wr, bool lng) {
+bool matreg_available(int cpl, int rpl, unsigned wc, unsigned wr, bool lng) {
 #ifdef DSP_NO_MATREG
   return false;
 #else
@@ -698,7 +717,7 @@ bool matreg_available(int cpl, int rpl, int wc, int wr, bool lng) {
 #endif
 }
 
-static const void *matreg_fn(int cpl, int rpl, int wc, int wr, bool lng) {
+static const void *matreg_fn(int cpl, int rpl, unsigned wc, unsigned wr, bool lng) {
 #ifndef DSP_NO_MATREG
 #define DSP_X(C, R, WC_, WR_, L)                                                            \
   if (cpl == C && rpl == R && wc == WC_ && wr == WR_ && lng == L)                           \
@@ -711,14 +730,14 @@ static const void *matreg_fn(int cpl, int rpl, int wc, int wr, bool lng) {
 
 template <int CPL, int RPL>
 static const void *generic_fn(bool lng) {
-  return lng ? reinterpret_cast<const void *>(&pdlp_solve_kernel<CPL, RPL, true, 0, 0>)
-             : reinterpret_cast<const void *>(&pdlp_solve_kernel<CPL, RPL, false, 0, 0>);
+  return lng ? reinterpret_cast<const void *>(&pdlp_solve_kernel<CPL, RPL, true, 0u, 0u>)
+             : reinterpret_cast<const void *>(&pdlp_solve_kernel<CPL, RPL, false, 0u, 0u>);
 }
 
 template <int CPL, int RPL>
 static hipError_t launch_solve_t(const SolveArgs &a, dim3 grid, dim3 block, size_t lds, hipStream_t st) {
   const bool lng = a.P.long_c.count > 0 || a.P.long_r.count > 0;
-  const void *fn = a.matreg ? matreg_fn(CPL, RPL, a.P.Wc, a.P.Wr, lng) : generic_fn<CPL, RPL>(lng);
+  const void *fn = a.matreg ? matreg_fn(CPL, RPL, a.P.mr_wc_pack, a.P.mr_wr_pack, lng) : generic_fn<CPL, RPL>(lng);
   if (!fn) return hipErrorInvalidValue;
   hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
@@ -771,7 +790,7 @@ hipError_t launch_solve(int cpl, int rpl, const SolveArgs &a, dim3 grid, dim3 bl
 template <int CPL, int RPL>
 static hipError_t occupancy_solve_t(const SolveArgs &a, dim3 grid, dim3 block, size_t lds, hipStream_t) {
   const bool lng = a.P.long_c.count > 0 || a.P.long_r.count > 0;
-  const void *fn = a.matreg ? matreg_fn(CPL, RPL, a.P.Wc, a.P.Wr, lng) : generic_fn<CPL, RPL>(lng);
+  const void *fn = a.matreg ? matreg_fn(CPL, RPL, a.P.mr_wc_pack, a.P.mr_wr_pack, lng) : generic_fn<CPL, RPL>(lng);
   if (!fn) return hipErrorInvalidValue;
   hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;

@@ -171,4 +171,86 @@ inline LaneELL build_lane_ell(const HostCSR &M, int slots) {
   return E;
 }
 
+// ---- register-resident-matrix layout: ownership sorted by vector length, per-slot ELL widths -------------------------
+// A lane-slot (q, lane) = POSITION p = q*64 + lane owns the vector at[p].  Vectors are placed by decreasing length
+// (long vectors last), so a slot's width is the longest vector IN THAT SLOT: wind+battery 24 h needs 3+3+1+1 = 8
+// column entries per lane instead of 4 x 3 = 12.  Everything the kernel exchanges through LDS lives in position space.
+struct SortedLayout {
+  int slots = 0;
+  std::vector<int32_t> at;     // [slots*64] position -> vector id, -1 = padding
+  std::vector<int32_t> pos;    // vector id -> position
+};
+
+inline SortedLayout sorted_layout(const HostCSR &M, int slots, const std::vector<int32_t> &long_ids) {
+  SortedLayout L;
+  L.slots = slots;
+  std::vector<char> is_long(M.m, 0);
+  for (int32_t v : long_ids) is_long[v] = 1;
+  std::vector<int32_t> order(M.m);
+  std::iota(order.begin(), order.end(), 0);
+  auto key = [&](int32_t v) { return is_long[v] ? -1 : (int)(M.ptr[v + 1] - M.ptr[v]); };
+  std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return key(a) > key(b); });
+  L.at.assign((size_t)slots * 64, -1);
+  L.pos.assign(M.m, -1);
+  for (int p = 0; p < M.m; ++p) { L.at[p] = order[p]; L.pos[order[p]] = p; }
+  return L;
+}
+
+struct SlotELL {
+  int slots = 0;
+  int width[16] = {0};
+  uint32_t pack = 0;             // 4 bits per slot
+  int total = 0;                 // sum of widths
+  std::vector<double> val;       // [(base(q)+e)*64 + lane]
+  std::vector<uint32_t> off;     // byte offset (position * 8) of the gathered element
+  std::vector<int32_t> long_owner_pos, long_start, long_len;
+  std::vector<double> tail_val;
+  std::vector<uint32_t> tail_off;
+};
+
+// M: CSR whose rows are the vectors owned through `own`; the gathered vector's elements sit at `other.pos`.
+inline SlotELL build_slot_ell(const HostCSR &M, const SortedLayout &own, const SortedLayout &other,
+                              const std::vector<int32_t> &long_ids) {
+  SlotELL E;
+  E.slots = own.slots;
+  std::vector<char> is_long(M.m, 0);
+  for (int32_t v : long_ids) is_long[v] = 1;
+  for (int q = 0; q < own.slots; ++q) {
+    int w = 0;
+    for (int l = 0; l < 64; ++l) {
+      int32_t v = own.at[q * 64 + l];
+      if (v >= 0 && !is_long[v]) w = std::max(w, (int)(M.ptr[v + 1] - M.ptr[v]));
+    }
+    E.width[q] = w;
+    E.pack |= (uint32_t)(w & 15) << (4 * q);
+    E.total += w;
+  }
+  E.val.assign((size_t)std::max(E.total, 1) * 64, 0.0);
+  E.off.assign((size_t)std::max(E.total, 1) * 64, 0u);
+  int base = 0;
+  for (int q = 0; q < own.slots; ++q) {
+    for (int l = 0; l < 64; ++l) {
+      int32_t v = own.at[q * 64 + l];
+      if (v < 0 || is_long[v]) continue;
+      for (int e = 0; e < M.ptr[v + 1] - M.ptr[v]; ++e) {
+        size_t at = (size_t)(base + e) * 64 + l;
+        E.val[at] = M.val[M.ptr[v] + e];
+        E.off[at] = (uint32_t)other.pos[M.idx[M.ptr[v] + e]] * 8u;
+      }
+    }
+    base += E.width[q];
+  }
+  for (int32_t v : long_ids) {
+    int len = M.ptr[v + 1] - M.ptr[v], padded = ((len + 63) / 64) * 64;
+    E.long_owner_pos.push_back(own.pos[v]);
+    E.long_start.push_back((int32_t)E.tail_val.size());
+    E.long_len.push_back(padded);
+    for (int e = 0; e < padded; ++e) {
+      E.tail_val.push_back(e < len ? M.val[M.ptr[v] + e] : 0.0);
+      E.tail_off.push_back(e < len ? (uint32_t)other.pos[M.idx[M.ptr[v] + e]] * 8u : 0u);
+    }
+  }
+  return E;
+}
+
 }  // namespace dsp
