@@ -93,10 +93,12 @@ constexpr int kQueueStride = 16;       // ints (64 bytes) between ring slots
 constexpr int kMaxWavesPerBlock = 8;   // kernels are compiled with __launch_bounds__(512)
 
 // LDS bytes of a block with `wpb` waves
-static size_t lds_bytes(const DeviceProblem &P, int wpb, bool matreg = false) {
+static size_t lds_bytes(const DeviceProblem &P, int wpb, int matreg = 0) {
   size_t ent = matreg ? (size_t)P.mr_tailc_entries + P.mr_tailr_entries
                       : (size_t)P.tailc_entries + P.tailr_entries + P.ellc_entries + P.ellr_entries;
-  return ent * sizeof(Entry) + (size_t)wpb * (P.n_pad + P.m_pad) * 8;
+  size_t per_wave = (size_t)(P.n_pad + P.m_pad) * 8;
+  if (matreg == 2) per_wave += (size_t)3 * P.n_pad * 8;          // (c, lb, ub) of the wave's scenario
+  return ent * sizeof(Entry) + (size_t)wpb * per_wave;
 }
 
 // Launch geometry of the solve kernel: waves (= scenarios in flight) per block and blocks per CU, from the runtime's
@@ -236,7 +238,7 @@ int dsp_create(const dsp_lp_desc *d, int device, const dsp_options *opt, dsp_han
   P.mr_wc_pack = Sc.pack; P.mr_wr_pack = Sr.pack;
   P.mr_tailc_entries = (int)Sc.tail_val.size(); P.mr_tailr_entries = (int)Sr.tail_val.size();
   if ((rc = fill_long(P.mr_long_c, Sc)) || (rc = fill_long(P.mr_long_r, Sr))) { delete h; return rc; }
-  h->matreg = (!h->opt.no_matreg && matreg_available(cpl, rpl, Sc.pack, Sr.pack, P.long_c.count > 0 || P.long_r.count > 0)) ? 1 : 0;
+  h->matreg = h->opt.no_matreg ? 0 : matreg_available(cpl, rpl, Sc.pack, Sr.pack, P.long_c.count > 0 || P.long_r.count > 0);
   std::vector<Entry> pk;
 #define UPE(val, idx, field) pack_entries(val, idx, pk); if ((rc = upload(h, pk, &P.field)) != DSP_OK) { dsp_destroy(h); return rc; }
 #define UP(vec, field) if ((rc = upload(h, vec, &P.field)) != DSP_OK) { dsp_destroy(h); return rc; }

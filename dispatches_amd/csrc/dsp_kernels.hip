@@ -220,7 +220,10 @@ __device__ __forceinline__ void stage_entries(Entry *dst, const Entry *__restric
 // WC / WR != 0: the ELL part of A^T / A is register-resident (RegEll); the template value packs the per-slot
 // widths, 4 bits each, and ownership follows the sorted layout (P.mr_colat / P.mr_rowat);
 // WC = WR = 0: generic path, matrix in LDS with run-time uniform widths, identity ownership.
-template <int CPL, int RPL, bool LONG, unsigned WC, unsigned WR>
+// CLDS: the scaled objective and column bounds (c, lb, ub) of the wave's scenario live in its LDS region instead of
+// registers and are re-read where they are used (3 conflict-free ds_read_b64 per owned column and iteration): trades
+// LDS issue slots for 6*CPL VGPRs so that the 48-h wind+battery LP fits the register-resident kernel.
+template <int CPL, int RPL, bool LONG, unsigned WC, unsigned WR, bool CLDS = false>
 __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 2) pdlp_solve_kernel(SolveArgs a) {
   constexpr bool MATREG = WC != 0;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -252,6 +255,10 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
   char *yb = xb + (size_t)P.n_pad * 8;                                 // gathered by column products
   double *xbl = reinterpret_cast<double *>(xb) + lane;                 // this lane's own slots: xbl[64*q]
   double *ybl = reinterpret_cast<double *>(yb) + lane;
+  // CLDS: [waves][3][n_pad] doubles behind all exchange buffers
+  double *clu = reinterpret_cast<double *>(wave_buf + (size_t)a.waves_per_block * (P.n_pad + P.m_pad) * 8) +
+                (size_t)wave * 3 * P.n_pad + lane;
+  const int clu_stride = P.n_pad;
   RegEll<CPL, WC> mreg_c;
   RegEll<RPL, WR> mreg_r;
   if (MATREG) {
@@ -326,6 +333,7 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
       const double xs = (b.x0 && ok) ? b.x0[(size_t)s * n + j] / d : 0.0;
       x[q] = clampd(xs, lb[q], ub[q]);
       x0[q] = x[q];
+      if constexpr (CLDS) { clu[64 * q] = c[q]; clu[clu_stride + 64 * q] = lb[q]; clu[2 * clu_stride + 64 * q] = ub[q]; }
     }
 #pragma unroll
     for (int q = 0; q < RPL; ++q) {
@@ -390,12 +398,20 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
 #pragma unroll
     for (int q = 0; q < RPL; ++q) { yp[q] = y[q]; axb[q] = ax[q]; }
 
+// CLDS: refresh the register copies of (c, lb, ub) from the wave's LDS region right before they are used
+#define DSP_CLU()                                                                                            \
+  if constexpr (CLDS) {                                                                                     \
+    _Pragma("unroll") for (int q = 0; q < CPL; ++q) {                                                       \
+      c[q] = clu[64 * q]; lb[q] = clu[clu_stride + 64 * q]; ub[q] = clu[2 * clu_stride + 64 * q];          \
+    }                                                                                                       \
+  }
 // one PDHG application T(x, y) -> (xp, yp); leaves aty = A^T y and axb = A (2 xp - x) behind
 #define DSP_PDHG_STEP()                                                                                     \
   {                                                                                                         \
     _Pragma("unroll") for (int q = 0; q < RPL; ++q) ybl[64 * q] = y[q];                                     \
     wave_lds_fence();                                                                                       \
     col_product(aty);                                     \
+    DSP_CLU()                                                                                               \
     _Pragma("unroll") for (int q = 0; q < CPL; ++q) {                                                       \
       xp[q] = clampd(x[q] - tau * (c[q] - aty[q]), lb[q], ub[q]);                                           \
       xbl[64 * q] = 2.0 * xp[q] - x[q];                                                                     \
@@ -604,6 +620,7 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
     DSP_TRACE("[trace] store status=%d it=%d\n", status, it);
     // ---- store the scenario's result (unscaled) ----------------------------------------------------------
     if (status != DSP_STATUS_OPTIMAL) {
+      DSP_CLU()
       double po = 0.0;
 #pragma unroll
       for (int q = 0; q < CPL; ++q) po = fma(c[q], xp[q], po);
@@ -630,6 +647,7 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
       if (b.jumps) b.jumps[s] = njump;
       if (b.primal_weight) b.primal_weight[s] = w;
     }
+#undef DSP_CLU
     DSP_DRAIN();
     DSP_TRACE("[trace] scalars stored\n");
   }
@@ -699,29 +717,32 @@ __global__ void __launch_bounds__(512) spmv_step_kernel(SpmvArgs a) {
 // Register-resident-matrix specialisations exist for the shapes of the reference's flowsheets at the benchmark
 // horizons (cols/lane, rows/lane, ELL width of A^T, ELL width of A, long vectors): everything else runs the generic
 // LDS-matrix kernel.  wind+battery 24 h, nuclear 24 h / 48 h, wind+PEM 48 h (shared capacity column = long vector).
-// X(cols/lane, rows/lane, per-slot widths of A^T (4 bits each, slot 0 lowest), per-slot widths of A, long vectors)
+// X(cols/lane, rows/lane, per-slot widths of A^T (4 bits each, slot 0 lowest), per-slot widths of A, long vectors,
+//   c/lb/ub in LDS)
 #define DSP_MATREG_SHAPES(X)                                                                                  \
-  X(4, 2, 0x1133u, 0x44u, false)      /* wind+battery 24 h */                                                 \
-  X(3, 2, 0x122u, 0x24u, false)       /* nuclear 24 h      */                                                 \
-  X(5, 3, 0x11222u, 0x234u, false)    /* nuclear 48 h      */                                                 \
-  X(4, 3, 0x1122u, 0x233u, true)      /* wind+PEM 48 h     */
+  X(4, 2, 0x1133u, 0x44u, false, false)         /* wind+battery 24 h */                                       \
+  X(3, 2, 0x122u, 0x24u, false, false)          /* nuclear 24 h      */                                       \
+  X(5, 3, 0x11222u, 0x234u, false, false)       /* nuclear 48 h      */                                       \
+  X(4, 3, 0x1122u, 0x233u, true, false)         /* wind+PEM 48 h     */                                       \
+  X(7, 4, 0x1112333u, 0x2444u, false, true)     /* wind+battery 48 h */
 
-bool matreg_available(int cpl, int rpl, unsigned wc, unsigned wr, bool lng) {
+// 0 = no specialisation, 1 = register-resident matrix, 2 = register-resident matrix + (c, lb, ub) in LDS
+int matreg_available(int cpl, int rpl, unsigned wc, unsigned wr, bool lng) {
 #ifdef DSP_NO_MATREG
-  return false;
+  return 0;
 #else
-#define DSP_X(C, R, WC_, WR_, L) if (cpl == C && rpl == R && wc == WC_ && wr == WR_ && lng == L) return true;
+#define DSP_X(C, R, WC_, WR_, L, CL) if (cpl == C && rpl == R && wc == WC_ && wr == WR_ && lng == L) return CL ? 2 : 1;
   DSP_MATREG_SHAPES(DSP_X)
 #undef DSP_X
-  return false;
+  return 0;
 #endif
 }
 
 static const void *matreg_fn(int cpl, int rpl, unsigned wc, unsigned wr, bool lng) {
 #ifndef DSP_NO_MATREG
-#define DSP_X(C, R, WC_, WR_, L)                                                            \
+#define DSP_X(C, R, WC_, WR_, L, CL)                                                        \
   if (cpl == C && rpl == R && wc == WC_ && wr == WR_ && lng == L)                           \
-    return reinterpret_cast<const void *>(&pdlp_solve_kernel<C, R, L, WC_, WR_>);
+    return reinterpret_cast<const void *>(&pdlp_solve_kernel<C, R, L, WC_, WR_, CL>);
   DSP_MATREG_SHAPES(DSP_X)
 #undef DSP_X
 #endif
