@@ -389,6 +389,7 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
     int it = 0;
     int njump = 0;
     int ncheck = 0;
+    bool lastjump = false;           // the last restart of the anchor was a ray jump
     double r0 = INFINITY, rprev = INFINITY;
     int status = DSP_STATUS_ITERATION_LIMIT;
     double xp[CPL], yp[RPL], axb[RPL];
@@ -525,8 +526,11 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
 #ifdef DSP_NO_JUMP
         const bool steady = false;
 #else
-        const bool steady = a.opt.ray_jumps && !do_restart && k >= 2 * check_every &&
-                            fabs(r - rprev) <= a.opt.jump_steady * r;
+        // steady residual over two checks, or (chaining, ray_jumps = 2) the previous event was a jump: a landing point
+        // usually lies on the next piece's ray already, so it is tested again at its first check
+        const bool steady = a.opt.ray_jumps && !do_restart &&
+                            ((k >= 2 * check_every && fabs(r - rprev) <= a.opt.jump_steady * r) ||
+                             (a.opt.ray_jumps > 1 && lastjump && k >= check_every));
 #endif
         if (first) r0 = r;
         rprev = r;
@@ -552,6 +556,7 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
             y[q] = yp[q]; y0[q] = yp[q]; ax[q] = axp; ax0[q] = axp;
           }
           k = 0; r0 = INFINITY; rprev = INFINITY;
+          lastjump = false;
           moved = true;
         } else if (steady) {
           // ---- ray jump: second application of T from (x+, y+), translation test, ratio test ------------------
@@ -607,6 +612,7 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
             }
             k = 0; r0 = INFINITY; rprev = INFINITY;
             ++njump;
+            lastjump = true;
             moved = true;
           }
         }

@@ -72,7 +72,8 @@ typedef struct dsp_options {
   double  jump_steady;       /* ray jump: attempt when |r - r_prev| <= jump_steady r  default 0.05   */
   double  jump_tol;          /* ... and ||T(T z)-2T z+z|| <= jump_tol ||T(T z)-T z||  default 3e-3   */
   double  jump_min;          /* ... and the ray stays >= jump_min steps in its piece  default 4      */
-  int32_t ray_jumps;         /* 1 = enable ray jumps                                  default 1      */
+  int32_t ray_jumps;         /* 0 = off, 1 = ray jumps, 2 = + chaining (a landing point is tested again at its
+                                first check; measured worse on full batches)           default 1      */
   int32_t ruiz_iters;        /* Ruiz passes before Pock-Chambolle (create time)       default 10     */
   int32_t waves_per_block;   /* scenarios per workgroup (1 wave each); 0 = auto                      */
   int32_t kkt_every;         /* the KKT / termination test (7 reductions + one SpMV) runs every kkt_every-th

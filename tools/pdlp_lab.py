@@ -29,7 +29,7 @@ def geo_scaling(A, iters=8):
 
 def solve(P, eps=1e-9, max_iter=60000, check=32, wrule="pid", kp=0.7, maxdl=np.log(30), r0_mode="k1",
           beta=(0.2, 0.8, 0.36), eta_scale=0.998, n_ruiz=10, wclamp=None, bal_gain=0.25, bal_thresh=10.0,
-          c0_gap=True, verbose=False, colscale=None, stall=0, stall_frac=0.5, kp_decay=0.5, xinit=0, term=0, eps_obj=1e-7, jump=0, jtol=1e-2, jsteady=0.05, jmin=4.0, winit=0.0, geo=0, jumpw=0, wfloor=0.0, jk=2.0, jacc=0.0, retry=0.0, retry_kps=(0.5, 0.35, 0.7, 0.25)):
+          c0_gap=True, verbose=False, colscale=None, stall=0, stall_frac=0.5, kp_decay=0.5, xinit=0, term=0, eps_obj=1e-7, jump=0, jtol=1e-2, jsteady=0.05, jmin=4.0, winit=0.0, geo=0, jumpw=0, wfloor=0.0, jk=2.0, jacc=0.0, jchain=0, retry=0.0, retry_kps=(0.5, 0.35, 0.7, 0.25)):
     lp = P.lp
     A0 = P.A
     if colscale is not None:
@@ -59,7 +59,7 @@ def solve(P, eps=1e-9, max_iter=60000, check=32, wrule="pid", kp=0.7, maxdl=np.l
     c0 = P.c0 if c0_gap else 0.0
     best = np.full(B, np.inf); wbest = w.copy(); itbest = np.zeros(B); kpv = np.full(B, kp); nrev = np.zeros(B, int)
     max_iter = int(max_iter)
-    njump = np.zeros(B, int); jtot = np.zeros(B)
+    njump = np.zeros(B, int); jtot = np.zeros(B); lastjump = np.zeros(B, bool)
     attempt = np.zeros(B, int); t_attempt = np.zeros(B); budget = np.full(B, retry * (n + m) if retry else np.inf)
     xstart0 = x.copy(); xstart1 = np.where((c < 0) & np.isfinite(ub), ub, x)
     for it in range(max_iter):
@@ -107,6 +107,8 @@ def solve(P, eps=1e-9, max_iter=60000, check=32, wrule="pid", kp=0.7, maxdl=np.l
             r0 = np.where(first, r, r0)
             rs = ~first & ((r <= beta[0] * r0) | ((r <= beta[1] * r0) & (r > rprev)) | (k >= beta[2] * (it + 1)))
             steady = (np.abs(r - rprev) <= jsteady * r) & (k >= jk * check) & ~done & ~rs if jump else np.zeros(B, bool)
+            if jump and jchain:
+                steady = steady | (lastjump & (k >= check) & ~done & ~rs)
             rprev = r
             if jump and steady.any():
                 gx0 = x - tau * (c - y @ As); gy0 = wv
@@ -148,6 +150,7 @@ def solve(P, eps=1e-9, max_iter=60000, check=32, wrule="pid", kp=0.7, maxdl=np.l
                         k = np.where(dojump, 0, k); r0 = np.where(dojump, np.inf, r0); rprev = np.where(dojump, np.inf, rprev)
                         njump += dojump; jtot += np.where(dojump, alpha, 0)
                         jumped = dojump
+                        lastjump = lastjump | dojump
                         if verbose: print(it + 1, "jump", np.nonzero(dojump)[0], alpha[dojump])
             if rs.any():
                 ddx = np.linalg.norm(xp - x0, axis=1); ddy = np.linalg.norm(yp - y0, axis=1)
@@ -181,6 +184,7 @@ def solve(P, eps=1e-9, max_iter=60000, check=32, wrule="pid", kp=0.7, maxdl=np.l
                 m_ = rs[:, None]
                 x = np.where(m_, xp, x); y = np.where(m_, yp, y); x0 = np.where(m_, xp, x0); y0 = np.where(m_, yp, y0)
                 k = np.where(rs, 0, k); r0 = np.where(rs, np.inf, r0); rprev = np.where(rs, np.inf, rprev); nrs += rs
+                lastjump = lastjump & ~rs
         if retry and chk:
             rt = ~done & ((it + 1 - t_attempt) >= budget)
             if rt.any():
