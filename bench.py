@@ -28,6 +28,27 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec (MI355X_MICROARCH.md); 6.29 TB/s measured copy ceiling
 
 
+def _profiled_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the newest committed rocprofv3 PMC summary (profiles/rNN*_pmc_summary.csv:
+    separate --pmc FETCH_SIZE / WRITE_SIZE passes of this same bench command; FETCH_SIZE doubled per the gfx950
+    correction of MI355X_MICROARCH.md, both counters are in KB).  None if no profile is committed."""
+    import csv
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.csv")))
+    if not files:
+        return None
+    fetch = write = None
+    for row in csv.DictReader(open(files[-1])):
+        if kernel in row["kernel"]:
+            if row["counter"] == "FETCH_SIZE":
+                fetch = float(row["mean_counter_value"] if "mean_counter_value" in row else row["mean_counter_value_KB"])
+            if row["counter"] == "WRITE_SIZE":
+                write = float(row["mean_counter_value"] if "mean_counter_value" in row else row["mean_counter_value_KB"])
+    if fetch is None or write is None:
+        return None
+    return (2.0 * fetch + write) * 1024.0
+
+
 def _oracle_worker(args):
     """CPU baseline leg: solve a chunk of scenarios with the HiGHS oracle (build once per scenario + solve)."""
     workload, T, ids = args
@@ -204,7 +225,7 @@ def main():
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9
         agg = alg_bytes * args.steps / elapsed / 1e9
         roofline = dict(bound="hbm", kernel="pdlp_solve_kernel", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
-                        frac=achieved / HBM_PEAK_GBS, traffic=None, kernel_ms=k_ms,
+                        frac=achieved / HBM_PEAK_GBS, traffic=_profiled_traffic("pdlp_solve_kernel"), kernel_ms=k_ms,
                         algorithmic_bytes_per_launch=alg_bytes, achieved_aggregate=agg,
                         frac_aggregate=agg / HBM_PEAK_GBS,
                         note="achieved = algorithmic bytes of one launch / mean HIP-event duration of a launch on its "
@@ -252,6 +273,7 @@ def main():
                             traffic=None, kernel_ms=ms, algorithmic_bytes_per_launch=bsp)
 
             result["spmv_step"] = time_spmv(B, 200)
+            result["spmv_step"]["traffic"] = _profiled_traffic("spmv_step_kernel")
             result["spmv_step"]["note"] = ("one A x + one A^T y for every scenario of the batch with vectors streamed "
                                            "from/to HBM; events on the launch stream, back-to-back launches (includes "
                                            "launch gaps); at the metric batch the launch moves only ~20 MB and is "

@@ -208,8 +208,6 @@ class DeviceLP:
         bt.jumps = out["jumps"].data_ptr() if "jumps" in out else None
         stats = DspStats()
         stream = torch.cuda.current_stream(dev).cuda_stream
-        if os.environ.get('DSP_DEBUG'):
-            print('[py] ptrs', {f[0]: (hex(getattr(bt, f[0])) if isinstance(getattr(bt, f[0]), int) and f[0] not in ('B',) and not f[0].endswith('stride') else getattr(bt, f[0])) for f in bt._fields_}, flush=True)
         rc = self.lib.dsp_solve(self.handle, C.byref(bt), C.byref(options) if options is not None else None,
                                 C.byref(stats), 1 if sync_stats else 0, C.c_void_p(stream))
         _check(self.lib, rc, "dsp_solve")
@@ -229,11 +227,34 @@ class DeviceLP:
         return AX, ATY
 
 
+def period_shift_maps(lp, shift: int):
+    """Index maps for a rolling-horizon warm start: column / row "name[t]" takes its start value from "name[t+shift]"
+    of the previous solve (the last `shift` periods keep their own old value).  Cached on the LP object."""
+    import re
+
+    cache = lp.__dict__.setdefault("_shift_maps", {})
+    if shift not in cache:
+        def build(names):
+            pat = re.compile(r"^(.*)\[(\d+)\]$")
+            where = {}
+            parsed = []
+            for k, nm in enumerate(names):
+                mt = pat.match(nm)
+                parsed.append((mt.group(1), int(mt.group(2))) if mt else None)
+                if mt:
+                    where[(mt.group(1), int(mt.group(2)))] = k
+            return np.array([where.get((p[0], p[1] + shift), k) if p else k for k, p in enumerate(parsed)], np.int64)
+        cache[shift] = (build(lp.col_names), build(lp.row_names))
+    return cache[shift]
+
+
 class HipPdlpSolver:
     """Solver object for Bidder / SelfScheduler / Tracker: `solver.solve(model, tee=False)`.
 
     Options (keyword arguments) are the fields of ``dsp_options`` (include/dsp_hip.h), e.g. ``eps_rel=1e-9``.
     """
+
+    supports_warm_start = True       # Bidder / Tracker pass warm_start / shift when the solver advertises this
 
     def __init__(self, device: int = 0, **options):
         self.device = device
@@ -264,7 +285,9 @@ class HipPdlpSolver:
             model.solve_handle = h
         return h
 
-    def solve(self, model, tee=False, warm_start=False):
+    def solve(self, model, tee=False, warm_start=False, shift=0):
+        """warm_start: start from the model's previous (x, y, primal weight); shift: the previous solve was `shift`
+        periods earlier in a rolling horizon, so period t starts from the old period t + shift."""
         import torch
 
         from .workflow.batch_model import SolveResults
@@ -277,7 +300,11 @@ class HipPdlpSolver:
         x0 = y0 = None
         pw = torch.zeros(B, dtype=torch.float64, device=dev)          # in: 0 = automatic; out: final primal weights
         if warm_start and model.x is not None and model.y is not None and model.x.shape == (B, model.lp.n):
-            x0, y0 = up(model.x), up(model.y)
+            xs, ys = model.x, model.y
+            if shift:
+                cmap, rmap = period_shift_maps(model.lp, int(shift))
+                xs, ys = xs[:, cmap], ys[:, rmap]
+            x0, y0 = up(xs), up(ys)
             prev = getattr(model, "primal_weight", None)
             if prev is not None and len(prev) == B:
                 pw = up(prev)

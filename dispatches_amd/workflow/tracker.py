@@ -32,11 +32,12 @@ class _PowerOutput:
 class Tracker:
     deviation_penalty = 10000.0
 
-    def __init__(self, tracking_model_object, tracking_horizon, n_tracking_hour, solver):
+    def __init__(self, tracking_model_object, tracking_horizon, n_tracking_hour, solver, warm_start=True):
         self.tracking_model_object = tracking_model_object
         self.tracking_horizon = tracking_horizon
         self.n_tracking_hour = n_tracking_hour
         self.solver = solver
+        self.warm_start = bool(warm_start)      # rolling-horizon warm start when the solver supports it (HIP solver)
         self._check_inputs()
         self.projection = None
         self.result_list = []
@@ -116,7 +117,11 @@ class Tracker:
         """Solve the tracking LP for the given dispatch [MW per hour], record, and roll the model forward by
         `n_tracking_hour` implemented steps."""
         self._pass_market_dispatch(market_dispatch)
-        self.solver.solve(self.model, tee=False)
+        if getattr(self.solver, "supports_warm_start", False) and self.warm_start and self.model.x is not None:
+            # rolling horizon: this hour's LP is the previous one shifted by the implemented steps
+            self.solver.solve(self.model, tee=False, warm_start=True, shift=self.n_tracking_hour)
+        else:
+            self.solver.solve(self.model, tee=False)
         self.record_results(date=date, hour=hour)
         profiles = self.tracking_model_object.get_implemented_profile(
             b=self.model.fs, last_implemented_time_step=self.n_tracking_hour - 1)
