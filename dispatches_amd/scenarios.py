@@ -107,14 +107,20 @@ def wind_pem_batch(B, T, solver, series="rts_gmlc_303.npz", stride=37, wind_mw=8
     return bidder, model
 
 
-def nuclear_batch(B, T, solver, seed=2020):
-    """LP #3 (nuclear + PEM + tank), BASELINE config 2: first B of the 3100 day-signals as DA prices,
-    RT = DA * (1 + 0.1 N(0,1)) clipped at 0."""
+def nuclear_prices(B, T, seed=2020):
+    """(DA, RT) price matrices [B, T] of the nuclear workloads: first B of the 3100 day-signals as DA prices,
+    RT = DA * (1 + 0.1 N(0,1)) clipped at 0 (one seeded draw for the whole batch)."""
     lmp = load_series("nuclear_lmp_signal.npz")["lmp"]
     rng = np.random.default_rng(seed)
     da = lmp[np.arange(B) % len(lmp)]
     da = np.tile(da, (1, (T + 23) // 24))[:, :T]
     rt = np.clip(da * (1 + 0.1 * rng.standard_normal(da.shape)), 0, None)
+    return da, rt
+
+
+def nuclear_batch(B, T, solver, seed=2020):
+    """LP #3 (nuclear + PEM + tank), BASELINE config 2."""
+    da, rt = nuclear_prices(B, T, seed)
 
     class _Fixed(AbstractPrescientPriceForecaster):
         def forecast_day_ahead_and_real_time_prices(self, date, hour, bus, horizon, n_samples):
