@@ -296,7 +296,7 @@ class HipPdlpSolver:
         dev = torch.device("cuda", self.device)
         B = model.n_scenario
         lb, ub, rlo, rhi = model.scenario_bounds()
-        up = lambda a: torch.as_tensor(np.ascontiguousarray(a, np.float64)).to(dev, non_blocking=False)
+        up = lambda a: torch.as_tensor(np.array(a, dtype=np.float64, order="C", copy=True)).to(dev, non_blocking=False)
         x0 = y0 = None
         pw = torch.zeros(B, dtype=torch.float64, device=dev)          # in: 0 = automatic; out: final primal weights
         if warm_start and model.x is not None and model.y is not None and model.x.shape == (B, model.lp.n):
