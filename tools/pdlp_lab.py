@@ -29,7 +29,7 @@ def geo_scaling(A, iters=8):
 
 def solve(P, eps=1e-9, max_iter=60000, check=32, wrule="pid", kp=0.7, maxdl=np.log(30), r0_mode="k1",
           beta=(0.2, 0.8, 0.36), eta_scale=0.998, n_ruiz=10, wclamp=None, bal_gain=0.25, bal_thresh=10.0,
-          c0_gap=True, verbose=False, colscale=None, stall=0, stall_frac=0.5, kp_decay=0.5, xinit=0, term=0, eps_obj=1e-7, jump=0, jtol=1e-2, jsteady=0.05, jmin=4.0, winit=0.0, geo=0, jumpw=0, wfloor=0.0, jk=2.0, jacc=0.0, jchain=0, retry=0.0, retry_kps=(0.5, 0.35, 0.7, 0.25)):
+          c0_gap=True, verbose=False, colscale=None, stall=0, stall_frac=0.5, kp_decay=0.5, xinit=0, term=0, eps_obj=1e-7, jump=0, jtol=1e-2, jsteady=0.05, jmin=4.0, winit=0.0, geo=0, jumpw=0, wfloor=0.0, jk=2.0, jacc=0.0, jchain=0, jland=-1.0, wfreeze=0, wfreeze_err=0.0, retry=0.0, retry_kps=(0.5, 0.35, 0.7, 0.25)):
     lp = P.lp
     A0 = P.A
     if colscale is not None:
@@ -59,7 +59,7 @@ def solve(P, eps=1e-9, max_iter=60000, check=32, wrule="pid", kp=0.7, maxdl=np.l
     c0 = P.c0 if c0_gap else 0.0
     best = np.full(B, np.inf); wbest = w.copy(); itbest = np.zeros(B); kpv = np.full(B, kp); nrev = np.zeros(B, int)
     max_iter = int(max_iter)
-    njump = np.zeros(B, int); jtot = np.zeros(B); lastjump = np.zeros(B, bool)
+    njump = np.zeros(B, int); jtot = np.zeros(B); lastjump = np.zeros(B, bool); wfrozen = np.zeros(B, bool)
     attempt = np.zeros(B, int); t_attempt = np.zeros(B); budget = np.full(B, retry * (n + m) if retry else np.inf)
     xstart0 = x.copy(); xstart1 = np.where((c < 0) & np.isfinite(ub), ub, x)
     for it in range(max_iter):
@@ -130,7 +130,7 @@ def solve(P, eps=1e-9, max_iter=60000, check=32, wrule="pid", kp=0.7, maxdl=np.l
                     alpha = np.minimum(ax_, ay_)
                     dojump = trans & (alpha >= jmin) & (alpha < 1e200)
                     if dojump.any():
-                        a = np.where(dojump, np.floor(alpha) - 1.0, 0.0)[:, None]
+                        a = np.where(dojump, np.maximum(np.floor(alpha) + jland, 0.0), 0.0)[:, None]
                         xn = np.clip(x2 + a * v2x, lb, ub); yn = y2 + a * v2y
                         if jacc:
                             xl = np.clip(xn - tau * (c - yn @ As), lb, ub); gl = yn - sig * ((2 * xl - xn) @ AsT); yl = gl + np.clip(-gl, sig * rlo, sig * rhi)
@@ -168,6 +168,12 @@ def solve(P, eps=1e-9, max_iter=60000, check=32, wrule="pid", kp=0.7, maxdl=np.l
                     ratio = np.log(np.maximum(rp, 1e-300) / np.maximum(rd, 1e-300))
                     bad = ((ratio > np.log(bal_thresh)) & (dl < 0)) | ((ratio < -np.log(bal_thresh)) & (dl > 0))
                     dl = np.where(bad, np.clip(bal_gain * ratio, -maxdl, maxdl), dl)
+                if wfreeze:
+                    dl = np.where(nrs >= wfreeze, 0.0, dl)
+                if wfreeze_err:
+                    frozen_ = np.maximum(np.maximum(rp, rd), rg) <= wfreeze_err
+                    wfrozen[:] = wfrozen | frozen_
+                    dl = np.where(wfrozen, 0.0, dl)
                 logw = np.log(w) + np.where(rs, dl, 0.0)
                 if verbose: print(it + 1, 'restart', np.nonzero(rs)[0][:4], 'k', k[rs][:4], 'r', r[rs][:4], 'w', w[rs][:4], '->', np.exp(logw[rs][:4]), 'kkt', rp[rs][:4], rd[rs][:4], rg[rs][:4])
                 if stall:
