@@ -173,8 +173,10 @@ class StochasticProgramBidder(AbstractBidder):
 
     def _pass_price_forecasts(self, model, da, rt):
         """Objective vectors for all scenarios at once:  c = base - RT (x) dP_T/dx - (DA-RT) on pda."""
-        c = np.tile(model.base_c, (self.n_scenario, 1))
-        c -= rt @ model.PT_matrix
+        c = np.empty((self.n_scenario, len(model.base_c)))
+        c[:] = model.base_c
+        rows, cols = np.nonzero(model.PT_matrix)                 # P_T[t] touches 1-2 columns per hour
+        np.subtract.at(c, (slice(None), cols), rt[:, rows] * model.PT_matrix[rows, cols])
         c[:, model.pda_cols] -= da - rt
         model.c = c
         model.c0 = model.base_c0 - rt @ model.PT_const
@@ -268,49 +270,57 @@ class Bidder(StochasticProgramBidder):
         is_thermal = md.generator_type == "thermal"
         power = model.expression_values(self.bidding_model_object.power_output) if market == "Real-time" \
             else model.x[:, model.pda_cols]
+        # all (scenario, hour) pairs rounded to 2 dp with Python's round() (exact decimal rounding, as the reference's
+        # bid assembly does), then grouped per hour with numpy: one pass over B*T numbers instead of B*T dict updates
+        T = len(model.HOUR)
+        B = model.n_scenario
+        p2 = np.array([round(v, 2) for v in np.asarray(power[:, :T], float).ravel().tolist()]).reshape(B, T)
+        c2 = np.array([round(v, 2) for v in np.asarray(energy_prices[:, :T], float).ravel().tolist()]).reshape(B, T)
+        default = [(round(p, 2), float(mc)) for p, mc in md.p_cost] \
+            if (is_thermal and getattr(md, "include_default_p_cost", False)) else []
+        pmin2 = round(md.p_min, 2)
         bids = {}
         for t_idx in model.HOUR:
             t = t_idx + hour
-            curve = {}
-            if is_thermal and getattr(md, "include_default_p_cost", False):
-                for p, mc in md.p_cost:
-                    curve[round(p, 2)] = float(mc)
-            for i in model.SCENARIOS:
-                p = round(float(power[i, t_idx]), 2)
-                price = round(float(energy_prices[i, t_idx]), 2)
-                if p < md.p_min:
-                    continue
-                curve[p] = max(curve.get(p, -np.inf), price)
-            if md.p_min not in curve:
-                curve[round(md.p_min, 2)] = min(curve.values()) if curve else 0.0
-            pairs = sorted(curve.items())
-            # non-decreasing marginal prices
-            run = -np.inf
-            mono = []
-            for p, mc in pairs:
-                run = max(run, mc)
-                mono.append((p, run))
-            p_cost = convert_marginal_costs_to_actual_costs(mono)
-            p_max = max(p for p, _ in p_cost)
+            keep = p2[:, t_idx] >= md.p_min
+            pw = np.concatenate([np.array([d[0] for d in default], float), p2[keep, t_idx]])
+            pr = np.concatenate([np.array([d[1] for d in default], float), c2[keep, t_idx]])
+            if len(pw):
+                up, inv = np.unique(pw, return_inverse=True)              # sorted distinct powers
+                mc = np.full(len(up), -np.inf)
+                np.maximum.at(mc, inv, pr)                                  # highest price offered at each power
+            else:
+                up, mc = np.zeros(0), np.zeros(0)
+            if not (len(up) and (up == md.p_min).any()):
+                # the reference adds the p_min point at the lowest marginal price seen (0 if there is none)
+                lowest = float(mc.min()) if len(mc) else 0.0
+                k = int(np.searchsorted(up, pmin2))
+                up = np.insert(up, k, pmin2)
+                mc = np.insert(mc, k, lowest)
+            mc = np.maximum.accumulate(mc)                                 # non-decreasing marginal prices
+            cost = np.empty(len(up))
+            cost[0] = up[0] * mc[0]
+            if len(up) > 1:
+                cost[1:] = cost[0] + np.cumsum(np.diff(up) * mc[1:])       # convert_marginal_costs_to_actual_costs
+            p_cost = list(zip(up.tolist(), cost.tolist()))
+            p_max = float(up[-1])
             bids[t] = {gen: {"p_cost": p_cost, "p_min": md.p_min, "p_max": p_max,
                              "startup_capacity": p_max, "shutdown_capacity": p_max}}
         return bids
 
     def _record_bids(self, bids, date, hour, **kwargs):
-        rows = []
-        for t in bids:
-            for gen in bids[t]:
-                row = {"Generator": gen, "Date": date, "Hour": t}
-                row.update(kwargs)
-                pairs = bids[t][gen]["p_cost"]
-                for idx, (p, c) in enumerate(pairs):
-                    row[f"Power {idx} [MW]"] = p
-                    row[f"Cost {idx} [$]"] = c
-                for idx in range(len(pairs), self.n_scenario):
-                    row[f"Power {idx} [MW]"] = None
-                    row[f"Cost {idx} [$]"] = None
-                rows.append(row)
-        self.bids_result_list.append(pd.DataFrame(rows))
+        """One row per (hour, generator) with `Power k [MW]` / `Cost k [$]` columns padded to n_scenario pairs (the
+        reference's layout); built as one array instead of row dictionaries."""
+        keys = [(t, gen) for t in bids for gen in bids[t]]
+        width = max([self.n_scenario] + [len(bids[t][gen]["p_cost"]) for t, gen in keys])
+        data = np.full((len(keys), 2 * width), np.nan)
+        for r, (t, gen) in enumerate(keys):
+            pairs = np.asarray(bids[t][gen]["p_cost"], float).reshape(-1, 2)
+            data[r, 0:2 * len(pairs):2] = pairs[:, 0]
+            data[r, 1:2 * len(pairs):2] = pairs[:, 1]
+        cols = [f"{kind} {k} [{unit}]" for k in range(width) for kind, unit in (("Power", "MW"), ("Cost", "$"))]
+        head = pd.DataFrame({"Generator": [g for _, g in keys], "Date": date, "Hour": [t for t, _ in keys], **kwargs})
+        self.bids_result_list.append(pd.concat([head, pd.DataFrame(data, columns=cols)], axis=1))
 
 
 class SelfScheduler(StochasticProgramBidder):
