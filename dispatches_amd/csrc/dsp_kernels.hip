@@ -313,6 +313,7 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
     double nrm[4] = {0.0, 0.0, 0.0, 0.0};                // |q|^2 unscaled, |c|^2 unscaled, |q|^2 scaled, |c|^2 scaled
     double cmax = 0.0, qmax = 0.0;                       // largest scaled |c_j| / finite scaled |row bound|
     double bs2 = 0.0;                                    // sum of squared finite scaled column bounds
+    double bad = 0.0;                                    // > 0: crossed bounds (lb > ub or row_lb > row_ub) or NaN input
 #pragma unroll
     for (int q = 0; q < CPL; ++q) {
       const int j = col_id(q);
@@ -325,6 +326,7 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
       lb[q] = lu / d;
       ub[q] = uu / d;
       nrm[1] += cu * cu;
+      if (!(lu <= uu) || !(cu == cu)) bad = 1.0;
       nrm[3] += c[q] * c[q];
       cmax = fmax(cmax, fabs(c[q]));
       { const double lfs = finite_or_zero(lb[q]), ufs = finite_or_zero(ub[q]); bs2 += lfs * lfs + ufs * ufs; }
@@ -344,6 +346,7 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
       const double hi = (ok && b.row_ub) ? b.row_ub[(size_t)s * b.row_ub_stride + i] : INFINITY;
       rlo[q] = lo * d;
       rhi[q] = hi * d;
+      if (!(lo <= hi)) bad = 1.0;
       const double big = fmax(fabs(finite_or_zero(lo)), fabs(finite_or_zero(hi)));
       nrm[0] += big * big;
       const double bigs = fmax(fabs(finite_or_zero(rlo[q])), fabs(finite_or_zero(rhi[q])));
@@ -357,6 +360,21 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
       y0[q] = ys;
     }
     wave_sums<4>(nrm);
+    if (wave_max(bad) > 0.0) {
+      // trivially infeasible / invalid scenario: report it and take the next one (nothing is iterated)
+#pragma unroll
+      for (int q = 0; q < CPL; ++q) { const int j = col_id(q); if (j >= 0) b.x[(size_t)s * n + j] = NAN; }
+#pragma unroll
+      for (int q = 0; q < RPL; ++q) { const int i = row_id(q); if (i >= 0) b.y[(size_t)s * m + i] = NAN; }
+      if (lane == 0) {
+        b.obj[s] = NAN;
+        b.status[s] = (nrm[0] == nrm[0] && nrm[1] == nrm[1]) ? DSP_STATUS_PRIMAL_INFEASIBLE : DSP_STATUS_NUMERICAL;
+        if (b.iters) b.iters[s] = 0;
+        if (b.jumps) b.jumps[s] = 0;
+      }
+      DSP_DRAIN();
+      continue;
+    }
     const double qn = sqrt(nrm[0]), cn = sqrt(nrm[1]);
     const double qs = sqrt(nrm[2]), cs = sqrt(nrm[3]);
     const double c0 = b.obj_offset ? b.obj_offset[(size_t)s * b.obj_offset_stride] : 0.0;

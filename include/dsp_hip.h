@@ -37,9 +37,10 @@ extern "C" {
 /* per-scenario termination status written to status[B] */
 #define DSP_STATUS_OPTIMAL            0
 #define DSP_STATUS_ITERATION_LIMIT    1
-#define DSP_STATUS_PRIMAL_INFEASIBLE  2   /* reserved: not detected (dispatch LPs carry slack columns)       */
+#define DSP_STATUS_PRIMAL_INFEASIBLE  2   /* crossed bounds (var_lb > var_ub or row_lb > row_ub) in the input; infeasibility
+                                             that needs a Farkas ray is NOT detected (dispatch LPs carry slack columns) */
 #define DSP_STATUS_DUAL_INFEASIBLE    3   /* reserved */
-#define DSP_STATUS_NUMERICAL          4   /* NaN / Inf met in the iteration                                  */
+#define DSP_STATUS_NUMERICAL          4   /* NaN in the input or NaN / Inf met in the iteration                */
 
 typedef struct dsp_handle dsp_handle;
 

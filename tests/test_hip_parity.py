@@ -319,6 +319,26 @@ def test_edge_cases():
 
 
 @gpu
+def test_invalid_scenarios_are_flagged_not_iterated():
+    """Crossed bounds -> status 2 (primal infeasible), NaN cost -> status 4; the other scenarios are unaffected."""
+    from dispatches_amd import scenarios
+    solver = _solver()
+    bidder, model = scenarios.make_batch("wind_battery_24h", 6, solver)
+    solver.solve(model)
+    ref = model.objective.copy()
+    model.ub = model.ub.copy()
+    model.ub[1, 3] = -5.0                       # below the column's lower bound 0
+    model.c = model.c.copy()
+    model.c[4, 7] = np.nan
+    model.x = model.y = None
+    solver.solve(model)
+    assert model.status.tolist() == [0, 2, 0, 0, 4, 0]
+    assert model.iterations[1] == 0 and model.iterations[4] == 0 and np.isnan(model.objective[[1, 4]]).all()
+    keep = [0, 2, 3, 5]
+    np.testing.assert_allclose(model.objective[keep], ref[keep], rtol=1e-9)
+
+
+@gpu
 def test_iteration_limit_is_reported():
     from dispatches_amd import scenarios
     solver = _solver(max_iter=40)
