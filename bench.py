@@ -192,6 +192,7 @@ def main():
     sum_iters_one = int(st.total_iterations)
     max_iters_one = int(st.max_iterations)
     geometry = [int(st.grid_blocks), int(st.block_threads), int(st.lds_bytes), int(st.matreg)]
+    lds_conflicts = [int(st.lds_conflicts_identity), int(st.lds_conflicts_chosen)]
 
     events = []
 
@@ -268,6 +269,8 @@ def main():
                        "mean_iterations": float(np.mean(sum_iters)) / B, "max_iterations": max_iters_one,
                        "optimal": int(n_opt.item()), "scenarios": B * world,
                        "grid": geometry[:2], "lds_bytes": geometry[2], "register_resident_matrix": bool(geometry[3]),
+                       "simulated_lds_gather_conflict_cycles_per_iteration": {"identity_layout": lds_conflicts[0],
+                                                                              "rotation_swizzle": lds_conflicts[1]},
                        "streams": depth, "single_batch_latency_ms": single_batch_ms,
                        "pipeline": f"steps issued round-robin on {depth} HIP streams (independent batches overlap; "
                                    "a lone batch takes single_batch_latency_ms, dominated by its slowest scenario)"},

@@ -44,6 +44,7 @@ struct dsp_handle {
   bool geo_valid = false;
   Geometry geo;
   int matreg = 0;                 // register-resident-matrix kernel available for this shape
+  int lds_conflicts[4] = {0, 0, 0, 0};   // simulated extra LDS cycles per iteration: y buffer identity/best, x identity/best
 };
 
 static int pick(const int *set, int count, int need) {
@@ -235,6 +236,12 @@ int dsp_create(const dsp_lp_desc *d, int device, const dsp_options *opt, dsp_han
   // register-resident-matrix layout: ownership sorted by length, per-slot widths, position space
   SortedLayout Lc = sorted_layout(AT, cpl, Ec.long_owner), Lr = sorted_layout(A, rpl, Er.long_owner);
   SlotELL Sc = build_slot_ell(AT, Lc, Lr, Ec.long_owner), Sr = build_slot_ell(A, Lr, Lc, Er.long_owner);
+  // bank-conflict-minimising rotation of each exchange buffer: the y buffer is gathered by the A^T entries (Sc), the
+  // x buffer by the A entries (Sr); padding entries of Sc / Sr keep offset 0
+  P.mr_rot_y = best_rotation(Sc, &h->lds_conflicts[0], &h->lds_conflicts[1]);
+  P.mr_rot_x = best_rotation(Sr, &h->lds_conflicts[2], &h->lds_conflicts[3]);
+  apply_rotation(Sc, P.mr_rot_y);
+  apply_rotation(Sr, P.mr_rot_x);
   P.mr_wc_pack = Sc.pack; P.mr_wr_pack = Sr.pack;
   P.mr_tailc_entries = (int)Sc.tail_val.size(); P.mr_tailr_entries = (int)Sr.tail_val.size();
   if ((rc = fill_long(P.mr_long_c, Sc)) || (rc = fill_long(P.mr_long_r, Sr))) { delete h; return rc; }
@@ -294,6 +301,8 @@ int dsp_solve(dsp_handle *h, const dsp_batch *batch, const dsp_options *opt, dsp
     std::memset(stats, 0, sizeof(*stats));
     stats->grid_blocks = grid; stats->block_threads = 64 * a.waves_per_block; stats->lds_bytes = (int)lds;
     stats->cols_per_lane = h->cpl; stats->rows_per_lane = h->rpl; stats->matreg = h->matreg;
+    stats->lds_conflicts_identity = h->lds_conflicts[0] + h->lds_conflicts[2];
+    stats->lds_conflicts_chosen = h->matreg ? h->lds_conflicts[1] + h->lds_conflicts[3] : stats->lds_conflicts_identity;
     if (sync_stats) {
       HIP_TRY(hipStreamSynchronize(st));
       HIP_TRY(hipEventElapsedTime(&stats->kernel_ms, h->ev0, h->ev1));

@@ -153,6 +153,21 @@ __device__ __forceinline__ double lds_load_f64(uint32_t addr) {
 #endif
 }
 
+__device__ __forceinline__ void lds_store_f64(uint32_t addr, double v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  *(__attribute__((address_space(3))) double *)addr = v;
+#else
+  (void)addr; (void)v;
+#endif
+}
+// LDS slot of exchange-buffer position p under the rotation swizzle r (dsp_prepare.hpp: rotation_slot): every
+// 32-slot block (one 256-byte bank row of 8-byte elements) is rotated by r * block, which breaks the stride-32
+// address patterns of the gathers; r is chosen per buffer at create time from the simulated bank conflicts.
+__device__ __forceinline__ uint32_t rotation_slot(uint32_t p, uint32_t r) {
+  const uint32_t blk = p >> 5;
+  return (blk << 5) | ((p + r * blk) & 31u);
+}
+
 // Register-resident ELL (small LPs): the lane's W*S entries live in VGPRs for the whole kernel, so an SpMV is
 // W*S independent LDS gathers issued back to back (one LDS latency instead of W dependent round trips) + W*S FMAs.
 template <int S, unsigned PACK>
@@ -253,8 +268,15 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
 
   char *xb = wave_buf + (size_t)wave * (P.n_pad + P.m_pad) * 8;        // gathered by row products
   char *yb = xb + (size_t)P.n_pad * 8;                                 // gathered by column products
-  double *xbl = reinterpret_cast<double *>(xb) + lane;                 // this lane's own slots: xbl[64*q]
-  double *ybl = reinterpret_cast<double *>(yb) + lane;
+  // LDS byte addresses of this lane's own elements in the exchange buffers (rotation-swizzled slots)
+  using lds_cptr = const __attribute__((address_space(3))) char *;
+  const uint32_t xb_lds = (uint32_t)(uintptr_t)(lds_cptr)xb, yb_lds = (uint32_t)(uintptr_t)(lds_cptr)yb;
+  const uint32_t rot_x = MATREG ? P.mr_rot_x : 0u, rot_y = MATREG ? P.mr_rot_y : 0u;
+  uint32_t xw[CPL], yw[RPL];
+#pragma unroll
+  for (int q = 0; q < CPL; ++q) xw[q] = xb_lds + 8u * rotation_slot((uint32_t)(lane + 64 * q), rot_x);
+#pragma unroll
+  for (int q = 0; q < RPL; ++q) yw[q] = yb_lds + 8u * rotation_slot((uint32_t)(lane + 64 * q), rot_y);
   // CLDS: [waves][3][n_pad] doubles behind all exchange buffers
   double *clu = reinterpret_cast<double *>(wave_buf + (size_t)a.waves_per_block * (P.n_pad + P.m_pad) * 8) +
                 (size_t)wave * 3 * P.n_pad + lane;
@@ -262,9 +284,8 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
   RegEll<CPL, WC> mreg_c;
   RegEll<RPL, WR> mreg_r;
   if (MATREG) {
-    using lds_cptr = const __attribute__((address_space(3))) char *;
-    mreg_c.load(P.mr_ellc, lane, (uint32_t)(uintptr_t)(lds_cptr)yb);   // A^T gathers y from yb
-    mreg_r.load(P.mr_ellr, lane, (uint32_t)(uintptr_t)(lds_cptr)xb);   // A   gathers x from xb
+    mreg_c.load(P.mr_ellc, lane, yb_lds);                               // A^T gathers y from yb
+    mreg_r.load(P.mr_ellr, lane, xb_lds);                               // A   gathers x from xb
   }
 
   const int n = P.n, m = P.m;
@@ -397,7 +418,7 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
     DSP_TRACE("[trace] loaded w=%g\n", w);
     // A x for the starting point
 #pragma unroll
-    for (int q = 0; q < CPL; ++q) xbl[64 * q] = x[q];
+    for (int q = 0; q < CPL; ++q) lds_store_f64(xw[q], x[q]);
     wave_lds_fence();
     row_product(ax);
 #pragma unroll
@@ -427,13 +448,13 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
 // one PDHG application T(x, y) -> (xp, yp); leaves aty = A^T y and axb = A (2 xp - x) behind
 #define DSP_PDHG_STEP()                                                                                     \
   {                                                                                                         \
-    _Pragma("unroll") for (int q = 0; q < RPL; ++q) ybl[64 * q] = y[q];                                     \
+    _Pragma("unroll") for (int q = 0; q < RPL; ++q) lds_store_f64(yw[q], y[q]);                                     \
     wave_lds_fence();                                                                                       \
     col_product(aty);                                     \
     DSP_CLU()                                                                                               \
     _Pragma("unroll") for (int q = 0; q < CPL; ++q) {                                                       \
       xp[q] = clampd(x[q] - tau * (c[q] - aty[q]), lb[q], ub[q]);                                           \
-      xbl[64 * q] = 2.0 * xp[q] - x[q];                                                                     \
+      lds_store_f64(xw[q], 2.0 * xp[q] - x[q]);                                                                     \
     }                                                                                                       \
     wave_lds_fence();                                                                                       \
     row_product(axb);                                     \
@@ -490,7 +511,7 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
         // ---- every kkt_every-th check: KKT test at (x+, y+) in the ORIGINAL (unscaled) space ---------------------
         if ((++ncheck % kkt_every) == 0) {
 #pragma unroll
-          for (int q = 0; q < RPL; ++q) ybl[64 * q] = yp[q];
+          for (int q = 0; q < RPL; ++q) lds_store_f64(yw[q], yp[q]);
           wave_lds_fence();
           double atyp[CPL];
           col_product(atyp);
@@ -580,7 +601,7 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
           // ---- ray jump: second application of T from (x+, y+), translation test, ratio test ------------------
           double x2[CPL], y2[RPL], axb1[RPL], atyp[CPL];
 #pragma unroll
-          for (int q = 0; q < RPL; ++q) ybl[64 * q] = yp[q];
+          for (int q = 0; q < RPL; ++q) lds_store_f64(yw[q], yp[q]);
           wave_lds_fence();
           col_product(atyp);                 // A^T y+ for the second application of T
           double tt[2] = {0.0, 0.0};       // |v2 - v1|^2_w, |v2|^2_w
@@ -590,7 +611,7 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
             const double gx1 = xp[q] - tau * (c[q] - atyp[q]);
             const double gx0 = x[q] - tau * (c[q] - aty[q]);
             x2[q] = clampd(gx1, lb[q], ub[q]);
-            xbl[64 * q] = 2.0 * x2[q] - xp[q];
+            lds_store_f64(xw[q], 2.0 * x2[q] - xp[q]);
             const double v1 = xp[q] - x[q], v2 = x2[q] - xp[q];
             tt[0] = fma(w * (v2 - v1), v2 - v1, tt[0]);
             tt[1] = fma(w * v2, v2, tt[1]);
@@ -618,7 +639,7 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
             for (int q = 0; q < CPL; ++q) {
               const double xn = clampd(x2[q] + al * (x2[q] - xp[q]), lb[q], ub[q]);
               x[q] = xn; x0[q] = xn; xp[q] = xn;
-              xbl[64 * q] = xn;
+              lds_store_f64(xw[q], xn);
             }
             wave_lds_fence();
             row_product(ax);

@@ -253,4 +253,51 @@ inline SlotELL build_slot_ell(const HostCSR &M, const SortedLayout &own, const S
   return E;
 }
 
+// ---- LDS bank conflicts of the gathers: rotation swizzle of the exchange buffers ---------------------------------
+// Slot of position p: every 32-slot block (one 256-byte LDS bank row of 8-byte elements) is rotated by r * block.
+inline uint32_t rotation_slot(uint32_t p, uint32_t r) {
+  const uint32_t blk = p >> 5;
+  return (blk << 5) | ((p + r * blk) & 31u);
+}
+
+// Extra LDS cycles of all gathers of E under rotation r: a ds_read_b64 is serviced in two 32-lane groups; within a
+// group, distinct addresses falling into the same (slot mod 32) bank pair cost one extra cycle each (equal addresses
+// broadcast).  E.off holds POSITION * 8 (un-swizzled).
+inline int gather_conflicts(const SlotELL &E, uint32_t r) {
+  int extra = 0;
+  for (int t = 0; t < E.total; ++t)
+    for (int g = 0; g < 2; ++g) {
+      int count[32] = {0};
+      std::vector<uint32_t> seen;
+      for (int l = 32 * g; l < 32 * g + 32; ++l) {
+        size_t at = (size_t)t * 64 + l;
+        uint32_t slot = rotation_slot(E.off[at] / 8u, r);      // padding entries read position 0
+        if (std::find(seen.begin(), seen.end(), slot) != seen.end()) continue;
+        seen.push_back(slot);
+        count[slot & 31u]++;
+      }
+      int worst = 1;
+      for (int b = 0; b < 32; ++b) worst = std::max(worst, count[b]);
+      extra += worst - 1;
+    }
+  return extra;
+}
+
+inline uint32_t best_rotation(const SlotELL &E, int *cost_identity = nullptr, int *cost_best = nullptr) {
+  uint32_t best = 0;
+  int bc = gather_conflicts(E, 0);
+  if (cost_identity) *cost_identity = bc;
+  for (uint32_t r = 1; r < 32; ++r) {
+    int c = gather_conflicts(E, r);
+    if (c < bc) { bc = c; best = r; }
+  }
+  if (cost_best) *cost_best = bc;
+  return best;
+}
+
+inline void apply_rotation(SlotELL &E, uint32_t r) {
+  for (auto &o : E.off) o = rotation_slot(o / 8u, r) * 8u;
+  for (auto &o : E.tail_off) o = rotation_slot(o / 8u, r) * 8u;
+}
+
 }  // namespace dsp

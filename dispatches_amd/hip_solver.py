@@ -47,7 +47,7 @@ class DspStats(C.Structure):
     _fields_ = [("total_iterations", C.c_int64), ("max_iterations", C.c_int32), ("n_optimal", C.c_int32),
                 ("grid_blocks", C.c_int32), ("block_threads", C.c_int32), ("lds_bytes", C.c_int32),
                 ("cols_per_lane", C.c_int32), ("rows_per_lane", C.c_int32), ("kernel_ms", C.c_float),
-                ("matreg", C.c_int32)]
+                ("matreg", C.c_int32), ("lds_conflicts_identity", C.c_int32), ("lds_conflicts_chosen", C.c_int32)]
 
 
 class DspLpDesc(C.Structure):
