@@ -9,7 +9,6 @@ library or GPU raises.
 from __future__ import annotations
 
 import ctypes as C
-import math
 import os
 from typing import Optional
 

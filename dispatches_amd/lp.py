@@ -12,7 +12,7 @@ Standard form:   min c.x + c0   s.t.  rlo <= A x <= rhi,   lb <=
 from __future__ import annotations
 
 from dataclasses import dataclass, field
-from typing import Dict, List, Optional, Sequence
+from typing import Dict, List, Optional
 
 import numpy as np
 

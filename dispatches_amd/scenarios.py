@@ -12,8 +12,7 @@ import os
 import numpy as np
 
 from .flowsheets import MultiPeriodNuclear, MultiPeriodWindBattery, MultiPeriodWindPEM
-from .flowsheets import parameters as prm
-from .workflow import Bidder, RenewableGeneratorModelData, ThermalGeneratorModelData
+from .workflow import Bidder, ThermalGeneratorModelData
 from .workflow.forecaster import AbstractPrescientPriceForecaster
 
 _DATA = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data")

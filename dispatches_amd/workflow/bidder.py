@@ -23,7 +23,7 @@ import pandas as pd
 
 from ..lp import LinearBlock, LinExpr
 from .batch_model import ScenarioBatchModel
-from .utils import convert_marginal_costs_to_actual_costs
+from .utils import convert_marginal_costs_to_actual_costs  # noqa: F401  (re-exported; the Bidder inlines its vectorised form)
 
 
 class AbstractBidder(ABC):

@@ -11,8 +11,6 @@ from __future__ import annotations
 
 from types import ModuleType
 
-import numpy as np
-
 from .utils import convert_marginal_costs_to_actual_costs
 
 
