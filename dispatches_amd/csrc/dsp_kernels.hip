@@ -53,43 +53,46 @@ __device__ __forceinline__ void wave_lds_fence() {
   __builtin_amdgcn_wave_barrier();
 }
 
-// A value that is equal in all lanes, moved to scalar registers: tells the compiler that everything derived from it
-// (and every branch on it) is wave-uniform, so the solver's control flow compiles to scalar branches.
-__device__ __forceinline__ double uniform(double v) {
-  const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v));
-  const int hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+// ---- wave64 reductions on the VALU (DPP), not through the LDS crossbar ---------------------------------------------
+// Four DPP steps make every lane of a 16-lane row hold its row's total (xor-1, xor-2 quad permutes, half-row mirror,
+// row mirror: the operation is commutative, so mirrored partners may be used); the four row totals are then read with
+// v_readlane into SGPRs.  ~100 cycles of dependent latency instead of six ds_bpermute round trips (~400), and the
+// result is wave-uniform by construction.
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, true);
   return __hiloint2double(hi, lo);
 }
+__device__ __forceinline__ double lane_f64(double v, int l) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+constexpr int kDppXor1 = 0xB1, kDppXor2 = 0x4E, kDppHalfMirror = 0x141, kDppMirror = 0x140;
 
-__device__ __forceinline__ double wave_sum(double v) {
+struct OpSum { __device__ __forceinline__ static double f(double a, double b) { return a + b; } };
+struct OpMax { __device__ __forceinline__ static double f(double a, double b) { return fmax(a, b); } };
+struct OpMin { __device__ __forceinline__ static double f(double a, double b) { return fmin(a, b); } };
+
+template <class Op, int N>
+__device__ __forceinline__ void wave_reduce(double (&a)[N]) {
 #pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-  return uniform(v);
-}
-__device__ __forceinline__ double wave_min(double v) {
+  for (int i = 0; i < N; ++i) a[i] = Op::f(a[i], dpp_f64<kDppXor1>(a[i]));
 #pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) v = fmin(v, __shfl_xor(v, off, 64));
-  return uniform(v);
-}
-__device__ __forceinline__ double wave_max(double v) {
+  for (int i = 0; i < N; ++i) a[i] = Op::f(a[i], dpp_f64<kDppXor2>(a[i]));
 #pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
-  return uniform(v);
+  for (int i = 0; i < N; ++i) a[i] = Op::f(a[i], dpp_f64<kDppHalfMirror>(a[i]));
+#pragma unroll
+  for (int i = 0; i < N; ++i) a[i] = Op::f(a[i], dpp_f64<kDppMirror>(a[i]));
+#pragma unroll
+  for (int i = 0; i < N; ++i)
+    a[i] = Op::f(Op::f(lane_f64(a[i], 0), lane_f64(a[i], 16)), Op::f(lane_f64(a[i], 32), lane_f64(a[i], 48)));
 }
-// N sums at once (independent shuffle chains interleave)
+__device__ __forceinline__ double wave_sum(double v) { double a[1] = {v}; wave_reduce<OpSum, 1>(a); return a[0]; }
+__device__ __forceinline__ double wave_min(double v) { double a[1] = {v}; wave_reduce<OpMin, 1>(a); return a[0]; }
+__device__ __forceinline__ double wave_max(double v) { double a[1] = {v}; wave_reduce<OpMax, 1>(a); return a[0]; }
+// N sums at once (independent chains interleave)
 template <int N>
-__device__ __forceinline__ void wave_sums(double (&a)[N]) {
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) {
-    double t[N];
-#pragma unroll
-    for (int i = 0; i < N; ++i) t[i] = __shfl_xor(a[i], off, 64);
-#pragma unroll
-    for (int i = 0; i < N; ++i) a[i] += t[i];
-  }
-#pragma unroll
-  for (int i = 0; i < N; ++i) a[i] = uniform(a[i]);
-}
+__device__ __forceinline__ void wave_sums(double (&a)[N]) { wave_reduce<OpSum, N>(a); }
 
 __device__ __forceinline__ double clampd(double v, double lo, double hi) { return fmin(fmax(v, lo), hi); }
 __device__ __forceinline__ double finite_or_zero(double v) { return (fabs(v) < INFINITY) ? v : 0.0; }
