@@ -122,7 +122,8 @@ def main():
     ap.add_argument("--batch", type=int, default=4096, help="scenarios per GPU")
     ap.add_argument("--eps", type=float, default=1e-9)
     ap.add_argument("--cpu-sample", type=int, default=-1, help="scenarios for the CPU baseline (0 = skip)")
-    ap.add_argument("--streams", type=int, default=8, help="HIP streams the steps are pipelined over")
+    ap.add_argument("--streams", type=int, default=0,
+                    help="HIP streams the steps are pipelined over (0 = choose among 6/8/12/16 during the warm-up)")
     ap.add_argument("--no-spmv", action="store_true", help="skip the streaming SpMV-step roofline measurement")
     args = ap.parse_args()
 
@@ -178,11 +179,16 @@ def main():
     # Pipeline: consecutive steps (independent batches) are issued round-robin on `--streams` HIP streams, each with
     # its own output buffers, so that one batch's straggler scenarios do not idle the GPU: iteration counts differ
     # ~10x between price scenarios and a single launch ends with a long, nearly empty tail.
-    depth = max(1, args.streams)
-    streams = [torch.cuda.Stream(device=dev) for _ in range(depth)]
-    outs = [new_out() for _ in range(depth)]
-    gathered = [torch.empty(B * world, dtype=torch.float64, device=dev) if world > 1 else None for _ in range(depth)]
+    # --streams 0 (default): the depth is picked during the untimed warm-up from a short trial of each candidate (how
+    # many kernels really run concurrently differs between boxes); rank 0's choice is broadcast so all ranks agree.
+    candidates = [args.streams] if args.streams > 0 else [6, 8, 12, 16]
+    max_depth = max(candidates)
+    streams = [torch.cuda.Stream(device=dev) for _ in range(max_depth)]
+    outs = [new_out() for _ in range(max_depth)]
+    gathered = [torch.empty(B * world, dtype=torch.float64, device=dev) if world > 1 else None
+                for _ in range(max_depth)]
     out = outs[0]
+    depth = candidates[0]
 
     # single-batch latency (one synchronous solve; also the untimed warm-up of the library / geometry cache)
     dlp.solve(B, c_d, lb_d, ub_d, rlo_d, rhi_d, options=opts, out=out, sync_stats=True, obj_offset=c0_d)
@@ -210,8 +216,22 @@ def main():
             events.append((e0, e1))
 
     torch.cuda.synchronize()
-    for i in range(args.warmup):
-        step(i, False)
+    trials = {}
+    if len(candidates) > 1:
+        for cand in candidates:                       # untimed (warm-up phase): 2 * cand steps at each depth
+            depth = cand
+            torch.cuda.synchronize()
+            t_try = time.perf_counter()
+            for i in range(2 * cand):
+                step(i, False)
+            torch.cuda.synchronize()
+            trials[cand] = (time.perf_counter() - t_try) / (2 * cand)
+        best = torch.tensor([min(trials, key=trials.get)], device=dev)
+        if world > 1:
+            dist.broadcast(best, src=0)
+        depth = int(best.item())
+    for i in range(max(args.warmup, depth)):      # every stream launches at least once before the timed region
+        step(i, False)                            # (a stream's first launch creates its hardware queue: milliseconds)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -271,7 +291,8 @@ def main():
                        "grid": geometry[:2], "lds_bytes": geometry[2], "register_resident_matrix": bool(geometry[3]),
                        "simulated_lds_gather_conflict_cycles_per_iteration": {"identity_layout": lds_conflicts[0],
                                                                               "rotation_swizzle": lds_conflicts[1]},
-                       "streams": depth, "single_batch_latency_ms": single_batch_ms,
+                       "streams": depth, "stream_trials_ms_per_step": {str(k): 1e3 * v for k, v in trials.items()},
+                       "single_batch_latency_ms": single_batch_ms,
                        "pipeline": f"steps issued round-robin on {depth} HIP streams (independent batches overlap; "
                                    "a lone batch takes single_batch_latency_ms, dominated by its slowest scenario)"},
             "roofline": roofline,
