@@ -1,0 +1,82 @@
+"""Host-side flatten-once layer (dispatches_amd/lp.py): the flattened StandardFormLP equals the block's algebra, the
+light presolve only removes rows that can never bind, and mutable bounds stay live after flatten()."""
+import numpy as np
+import pytest
+from scipy.optimize import linprog
+
+from dispatches_amd.lp import LinearBlock, LinExpr
+
+
+def _solve(lp, lb, ub, rlo, rhi):
+    A = lp.csr().toarray()
+    eq = np.isfinite(rlo) & (rlo == rhi)
+    up = np.isfinite(rhi) & ~eq
+    dn = np.isfinite(rlo) & ~eq
+    Aub = np.vstack([A[up], -A[dn]]) if (up.any() or dn.any()) else None
+    bub = np.concatenate([rhi[up], -rlo[dn]]) if Aub is not None else None
+    r = linprog(lp.c, A_ub=Aub, b_ub=bub, A_eq=A[eq] if eq.any() else None, b_eq=rhi[eq] if eq.any() else None,
+                bounds=np.stack([lb, ub], 1), method="highs")
+    assert r.status == 0, r.message
+    return r.fun + lp.c0, r.x
+
+
+def _random_block(rng, n=9, m=7):
+    b = LinearBlock("t")
+    xs = [b.var(f"x[{j}]", lb=0.0, ub=float(rng.integers(5, 50)), mutable=(j % 3 == 0), hull=(0.0, 100.0) if j % 3 == 0 else None)
+          for j in range(n)]
+    rows = []
+    for i in range(m):
+        cols = rng.choice(n, size=3, replace=False)
+        body = LinExpr()
+        for j in cols:
+            body = body + xs[j] * float(rng.integers(1, 5))
+        body = body + float(rng.integers(0, 3))                       # constants move to the bounds
+        if i % 3 == 0:
+            rows.append(b.equality(f"e[{i}]", body, rhs=float(rng.integers(10, 40))))
+        elif i % 3 == 1:
+            rows.append(b.constraint(f"le[{i}]", body, hi=float(rng.integers(60, 120))))
+        else:
+            rows.append(b.constraint(f"never[{i}]", body, hi=1e8))   # can never bind: presolve must drop it
+    obj = LinExpr()
+    for j in range(n):
+        obj = obj + xs[j] * float(rng.normal())
+    return b, xs, obj + 3.5
+
+
+@pytest.mark.parametrize("seed", range(5))
+def test_flatten_matches_algebra_and_presolve_is_safe(seed):
+    rng = np.random.default_rng(seed)
+    b, xs, obj = _random_block(rng)
+    full = b.flatten(obj, presolve=False)
+    b2, xs2, obj2 = _random_block(np.random.default_rng(seed))
+    red = b2.flatten(obj2, presolve=True)
+    assert red.m < full.m and all("never" not in r for r in red.row_names)
+    assert full.c0 == pytest.approx(3.5) and red.n == full.n
+    # the row bodies: A x + moved constants reproduce the original expressions
+    x = rng.random(full.n) * 10
+    A = full.csr().toarray()
+    for i, expr in enumerate(b.row_expr):
+        assert A[i] @ x == pytest.approx(sum(v * x[j] for j, v in expr.items()))
+    try:
+        f_full, _ = _solve(full, *b.current_bounds())
+    except AssertionError:
+        pytest.skip("random instance infeasible")
+    f_red, _ = _solve(red, *b2.current_bounds())
+    assert f_red == pytest.approx(f_full, rel=1e-9, abs=1e-9)
+
+
+def test_mutable_bounds_stay_live_and_immutable_ones_are_protected():
+    b = LinearBlock("t")
+    x = b.var("x[0]", 0.0, 10.0, mutable=True, hull=(0.0, 20.0))
+    y = b.var("y[0]", 0.0, 5.0)
+    r = b.constraint("cap[0]", x + y, hi=12.0, mutable=True)
+    lp = b.flatten(x * -1.0 + y * -2.0)
+    f0, _ = _solve(lp, *b.current_bounds())
+    x.setub(20.0)                                    # inside the declared hull: allowed after flatten()
+    b.set_row_bounds(r, -np.inf, 18.0)
+    f1, sol = _solve(lp, *b.current_bounds())
+    assert f1 < f0 and sol[0] + sol[1] <= 18.0 + 1e-9
+    with pytest.raises(ValueError):
+        y.setub(7.0)                                 # immutable column
+    with pytest.raises(ValueError):
+        x.setub(25.0)                                # leaves the hull
