@@ -95,6 +95,18 @@ template <int N>
 __device__ __forceinline__ void wave_sums(double (&a)[N]) { wave_reduce<OpSum, N>(a); }
 
 __device__ __forceinline__ double clampd(double v, double lo, double hi) { return fmin(fmax(v, lo), hi); }
+// clampd for the hot loop: the bare v_max_f64 / v_min_f64 pair.  fmax / fmin on loop-carried operands make the
+// compiler quiet them first (v_max_f64 x, x, x: a 4-cycle FP64 slot each); the operands here are never signalling NaNs.
+__device__ __forceinline__ double clampd_bare(double v, double lo, double hi) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  double t, r;
+  asm("v_max_f64 %0, %1, %2" : "=v"(t) : "v"(v), "v"(lo));
+  asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(t), "v"(hi));
+  return r;
+#else
+  return clampd(v, lo, hi);
+#endif
+}
 __device__ __forceinline__ double finite_or_zero(double v) { return (fabs(v) < INFINITY) ? v : 0.0; }
 __device__ __forceinline__ bool is_finite(double v) { return fabs(v) < INFINITY; }
 
@@ -323,6 +335,10 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
     }
   };
 
+#ifdef DSP_CLOCKS   /* development: shader clock vs constant 100 MHz clock, cycles per wave-iteration */
+  const long long clk0 = clock64(), wall0 = wall_clock64();
+  long long iters_done = 0;
+#endif
   for (;;) {
     // ---- pull the next scenario off the work queue ---------------------------------------------------------
     int s = 0;
@@ -430,7 +446,8 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
     int k = 0;                       // iterations since the last restart
     int it = 0;
     int njump = 0;
-    int ncheck = 0;
+    int ncheck = 0, last_kkt = 0;
+    double r_gate = 0.0;             // the next gated KKT test runs once r <= r_gate
     bool lastjump = false;           // the last restart of the anchor was a ray jump
     double r0 = INFINITY, rprev = INFINITY;
     int status = DSP_STATUS_ITERATION_LIMIT;
@@ -463,7 +480,7 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
     row_product(axb);                                     \
     _Pragma("unroll") for (int q = 0; q < RPL; ++q) {                                                       \
       const double wv = y[q] - sig * axb[q];                                                                \
-      yp[q] = wv + clampd(-wv, sig * rlo[q], sig * rhi[q]);                                                 \
+      yp[q] = wv - clampd_bare(wv, ylo[q], yhi[q]);                                                         \
     }                                                                                                       \
   }
 // reflected Halpern step toward the anchor (x0, y0); ax tracks A x through the same recursion
@@ -483,6 +500,9 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
     DSP_TRACE("[trace] enter loop\n");
     for (it = 0;;) {
       const double tau = eta / w, sig = eta * w;              // the primal weight changes only at checks
+      double ylo[RPL], yhi[RPL];                              // y+ = v - clamp(v, -sig rhi, -sig rlo),  v = y - sig A(2x+ - x)
+#pragma unroll
+      for (int q = 0; q < RPL; ++q) { ylo[q] = -(sig * rhi[q]); yhi[q] = -(sig * rlo[q]); }
       // ---- plain iterations up to the next check: two SpMVs + elementwise work, no reduction, no branch --------
       const int plain = min(check_every - 1, a.opt.max_iter - it);
       for (int u = 0; u < plain; ++u) {
@@ -511,8 +531,13 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
         wave_sums<3>(rr);
         const double r = sqrt(fmax(w * rr[0] - 2.0 * eta * rr[2] + rr[1] / w, 0.0));
         if (!(r == r)) { status = DSP_STATUS_NUMERICAL; break; }
-        // ---- every kkt_every-th check: KKT test at (x+, y+) in the ORIGINAL (unscaled) space ---------------------
-        if ((++ncheck % kkt_every) == 0) {
+        // ---- KKT test at (x+, y+) in the ORIGINAL (unscaled) space: 7 reductions + one SpMV, so it is scheduled from
+        // r, which the restart test has anyway (see dsp_options::kkt_gate); kkt_gate = 0: every kkt_every-th check
+        ++ncheck;
+        const bool kkt_now = a.opt.kkt_gate > 0.0
+                                 ? (ncheck - last_kkt >= (last_kkt ? kkt_every : min(4, kkt_every)) || r <= r_gate)
+                                 : (ncheck % kkt_every) == 0;
+        if (kkt_now) {
 #pragma unroll
           for (int q = 0; q < RPL; ++q) lds_store_f64(yw[q], yp[q]);
           wave_lds_fence();
@@ -559,6 +584,13 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
             done = gap <= lim && red[4] <= lim && red[6] <= lim;
           }
           if (done) { status = DSP_STATUS_OPTIMAL; ++it; break; }
+          double rho = fmax(fmax(rp, rd), rg) / eps;             // how far the worst criterion is from its limit
+          if (eps_obj > 0.0) {
+            const double lim = fmax(eps_obj * (1.0 + fabs(po + c0)), 1e-12 * red[5]);
+            rho = fmax(rho, fmax(fmax(gap, red[4]), red[6]) / lim);
+          }
+          r_gate = r * fmin(1.0, a.opt.kkt_gate / rho);
+          last_kkt = ncheck;
         }
         // ---- restart test (r0 = residual at the first check after a restart) ----------------------------------
         const bool first = !(r0 < INFINITY);
@@ -692,6 +724,9 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
       b.obj[s] = pobj;
       b.status[s] = status;
       if (b.iters) b.iters[s] = it;
+#ifdef DSP_CLOCKS
+      iters_done += it;
+#endif
       if (b.jumps) b.jumps[s] = njump;
       if (b.primal_weight) b.primal_weight[s] = w;
     }
@@ -699,6 +734,13 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
     DSP_DRAIN();
     DSP_TRACE("[trace] scalars stored\n");
   }
+#ifdef DSP_CLOCKS
+  if (lane == 0 && (blockIdx.x % 509) == 0 && iters_done > 0) {
+    const long long dc = clock64() - clk0, dw = wall_clock64() - wall0;
+    printf("[clocks] block %d: %.2f ms, shader clock %.0f MHz, %lld iterations, %.0f shader cycles / iteration\n",
+           (int)blockIdx.x, dw * 1e-5, 100.0 * (double)dc / (double)dw, iters_done, (double)dc / (double)iters_done);
+  }
+#endif
 }
 
 // ---- streaming SpMV step: AX = A X, ATY = A^T Y with vectors in HBM --------------------------------------

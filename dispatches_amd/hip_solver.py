@@ -25,7 +25,8 @@ class DspOptions(C.Structure):
                 ("restart_artificial", C.c_double), ("pid_kp", C.c_double), ("max_dlog_weight", C.c_double),
                 ("step_scale", C.c_double), ("weight_guard", C.c_double), ("jump_steady", C.c_double), ("jump_tol", C.c_double),
                 ("jump_min", C.c_double), ("ray_jumps", C.c_int32), ("ruiz_iters", C.c_int32),
-                ("waves_per_block", C.c_int32), ("kkt_every", C.c_int32), ("no_matreg", C.c_int32), ("geo_iters", C.c_int32)]
+                ("waves_per_block", C.c_int32), ("kkt_every", C.c_int32), ("no_matreg", C.c_int32), ("geo_iters", C.c_int32),
+                ("kkt_gate", C.c_double)]
 
 
 class DspBatch(C.Structure):
@@ -109,7 +110,12 @@ def default_options(**overrides) -> DspOptions:
     lib = load_library()
     o = DspOptions()
     lib.dsp_default_options(C.byref(o))
-    for k, v in overrides.items():
+    # tuning knob: DSP_OPTIONS="check_every=32,kkt_every=2" overrides the library defaults (explicit arguments win)
+    env = {}
+    for item in filter(None, os.environ.get("DSP_OPTIONS", "").split(",")):
+        k, _, v = item.partition("=")
+        env[k.strip()] = type(getattr(o, k.strip(), 0.0))(float(v))
+    for k, v in {**env, **overrides}.items():
         if not hasattr(o, k):
             raise TypeError(f"unknown solver option {k!r}")
         setattr(o, k, v)

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define DSP_VERSION 2
+#define DSP_VERSION 3
 
 /* return codes (0 = ok, < 0 = API misuse / HIP error; text via dsp_strerror) */
 #define DSP_OK                 0
@@ -77,12 +77,17 @@ typedef struct dsp_options {
                                 first check; measured worse on full batches)           default 1      */
   int32_t ruiz_iters;        /* Ruiz passes before Pock-Chambolle (create time)       default 10     */
   int32_t waves_per_block;   /* scenarios per workgroup (1 wave each); 0 = auto                      */
-  int32_t kkt_every;         /* the KKT / termination test (7 reductions + one SpMV) runs every kkt_every-th
-                                check                                                     default 4      */
+  int32_t kkt_every;         /* the KKT / termination test (7 reductions + one SpMV) runs at least every
+                                kkt_every-th check (kkt_gate = 0: exactly every kkt_every-th)   default 32     */
   int32_t no_matreg;         /* 1 = never use the register-resident-matrix kernel (create time)  default 0 */
   int32_t geo_iters;         /* geometric-mean equilibration passes BEFORE Ruiz (create time): balances
                                 unit-mix rows such as P_T[MW] = 1e-3 (G + O)[kW]; helps the tracking LPs and the
                                 nuclear flowsheet, hurts wind+battery bidding           default 0      */
+  double  kkt_gate;          /* > 0: the KKT test is scheduled from the (free) fixed-point residual r of the restart
+                                test: a test that fails by the factor rho = worst criterion / its limit arms the next
+                                one for r <= r_now min(1, kkt_gate / rho); the first test runs at the 4th check and
+                                kkt_every bounds the gap.  Only moves WHEN termination is detected, never the iterates.
+                                0 = fixed cadence                                         default 16     */
 } dsp_options;
 
 /* The per-call data of B scenarios.  c is required; every other input may be NULL (= no bound: -inf / +inf,

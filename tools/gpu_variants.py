@@ -21,7 +21,7 @@ for path in sorted(glob.glob(os.path.join(os.path.dirname(hip_solver.__file__), 
         it = model.iterations
         msg = (f"{os.path.basename(path)} {wl}: kernel {st.kernel_ms:.3f} ms  {B / st.kernel_ms * 1e3:.0f} scen/s  optimal {st.n_optimal}/{B} "
                f"iters mean {it.mean():.0f} med {np.median(it):.0f} p99 {np.percentile(it, 99):.0f} max {it.max()} jumps {model.jumps.sum()} "
-               f"grid {st.grid_blocks}x{st.block_threads} lds {st.lds_bytes}")
+               f"grid {st.grid_blocks}x{st.block_threads} lds {st.lds_bytes}  {it.sum() / st.kernel_ms / 1e3:.0f} M iter/s")
         if ref is not None and wl + "_obj" in ref and B == len(ref[wl + "_obj"]):
             ok = ref[wl + "_status"] == 0
             err = np.abs(model.objective - ref[wl + "_obj"]) / np.maximum(1, np.abs(ref[wl + "_obj"]))

@@ -96,7 +96,14 @@ def solve(P, eps=1e-9, max_iter=60000, check=32, wrule="pid", kp=0.7, maxdl=np.l
                 derr = np.sum(np.abs(rc_ - lp_ + lm_) * np.abs(Xu), 1)
                 oki &= derr <= np.maximum(eps_obj * (1 + np.abs(po)), 1e-12 * scale)
                 rg = np.where(okg & oki, rg, np.maximum(rg, 2 * eps))
+                lim_ = np.maximum(eps_obj * (1 + np.abs(po)), 1e-12 * scale)
+                solve.rho_obj = np.maximum(np.maximum(gap, ierr), derr) / lim_
             conv = (rp <= eps) & (rd <= eps) & (rg <= eps) & ~done
+            if getattr(solve, "trace", None) is not None:      # (iteration, r, rho = worst criterion / its limit, done)
+                rho = np.maximum(np.maximum(rp, rd), rg) / eps
+                if term:
+                    rho = np.maximum(rho, solve.rho_obj)
+                solve.trace.append((it + 1, r.copy(), rho, done.copy()))
             Xo[conv], Yo[conv] = (xp * dc)[conv], (yp * dr)[conv]; iters[conv] = it + 1; done |= conv
             if done.all():
                 break
