@@ -434,6 +434,7 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
       if (wi > 0.0 && is_finite(wi)) w = wi;
     }
 
+    const double w_init = w;
     DSP_TRACE("[trace] loaded w=%g\n", w);
     // A x for the starting point
 #pragma unroll
@@ -594,9 +595,13 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
         }
         // ---- restart test (r0 = residual at the first check after a restart) ----------------------------------
         const bool first = !(r0 < INFINITY);
-        const bool do_restart = !first && ((r <= a.opt.restart_sufficient * r0) ||
-                                           (r <= a.opt.restart_necessary * r0 && r > rprev) ||
-                                           ((double)k >= a.opt.restart_artificial * (double)(it + 1)));
+        const bool decayed = (r <= a.opt.restart_sufficient * r0) || (r <= a.opt.restart_necessary * r0 && r > rprev);
+        const bool artificial = (double)k >= a.opt.restart_artificial * (double)(it + 1);
+        const bool do_restart = !first && (decayed || artificial);
+        // no decay for >= stall_rescue iterations with the weight within 30x of its rounding guard: the iteration sits on
+        // the rounding floor under a runaway primal weight (dsp_options::stall_rescue)
+        const bool stalled = do_restart && !decayed && a.opt.stall_rescue > 0 && k >= a.opt.stall_rescue &&
+                             (w < 30.0 * w_lo || 30.0 * w > w_hi);
 #ifdef DSP_NO_JUMP
         const bool steady = false;
 #else
@@ -616,12 +621,14 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
           for (int q = 0; q < RPL; ++q) { const double t = yp[q] - y0[q]; dd[1] = fma(t, t, dd[1]); }
           wave_sums<2>(dd);
           const double ddx = sqrt(dd[0]), ddy = sqrt(dd[1]);
-          if (ddx > 1e-14 && ddy > 1e-14) {
+          if (stalled) {
+            w = sqrt(w * w_init);
+          } else if (ddx > 1e-14 && ddy > 1e-14) {
             const double e = log(w) + log(ddx) - log(ddy);
             const double dl = clampd(-a.opt.pid_kp * e, -a.opt.max_dlog_weight, a.opt.max_dlog_weight);
             w *= exp(dl);
-            w = fmin(fmax(w, w_lo), fmax(w_hi, w_lo));
           }
+          w = fmin(fmax(w, w_lo), fmax(w_hi, w_lo));
 #pragma unroll
           for (int q = 0; q < CPL; ++q) { x[q] = xp[q]; x0[q] = xp[q]; }
 #pragma unroll

@@ -88,6 +88,16 @@ typedef struct dsp_options {
                                 one for r <= r_now min(1, kkt_gate / rho); the first test runs at the 4th check and
                                 kkt_every bounds the gap.  Only moves WHEN termination is detected, never the iterates.
                                 0 = fixed cadence                                         default 16     */
+  int32_t stall_rescue;      /* > 0: a restart forced by the artificial criterion alone after >= stall_rescue
+                                iterations without the residual decaying, with the primal weight within 30x of its
+                                rounding guard (weight_guard), means the iteration sits on its rounding floor under
+                                a weight the movement-ratio controller has driven away (seen: gap stuck at 1e-7
+                                relative, primal and dual residuals at 1e-12): the weight is pulled back to the
+                                geometric mean of its value and the initial weight.  A last resort: scenarios that
+                                converge with a weight at the guard do so within a few thousand iterations and are
+                                slowed down badly by an earlier rescue (measured with 1000).  0 = off
+                                                                                          default 30000  */
+  int32_t reserved;
 } dsp_options;
 
 /* The per-call data of B scenarios.  c is required; every other input may be NULL (= no bound: -inf / +inf,

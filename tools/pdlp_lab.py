@@ -29,7 +29,7 @@ def geo_scaling(A, iters=8):
 
 def solve(P, eps=1e-9, max_iter=60000, check=32, wrule="pid", kp=0.7, maxdl=np.log(30), r0_mode="k1",
           beta=(0.2, 0.8, 0.36), eta_scale=0.998, n_ruiz=10, wclamp=None, bal_gain=0.25, bal_thresh=10.0,
-          c0_gap=True, verbose=False, colscale=None, stall=0, stall_frac=0.5, kp_decay=0.5, xinit=0, term=0, eps_obj=1e-7, jump=0, jtol=1e-2, jsteady=0.05, jmin=4.0, winit=0.0, geo=0, jumpw=0, wfloor=0.0, jk=2.0, jacc=0.0, jchain=0, jland=-1.0, wfreeze=0, wfreeze_err=0.0, retry=0.0, retry_kps=(0.5, 0.35, 0.7, 0.25)):
+          c0_gap=True, verbose=False, colscale=None, stall=0, stall_frac=0.5, kp_decay=0.5, xinit=0, term=0, eps_obj=1e-7, jump=0, jtol=1e-2, jsteady=0.05, jmin=4.0, winit=0.0, geo=0, jumpw=0, wfloor=0.0, jk=2.0, jacc=0.0, jchain=0, jland=-1.0, wfreeze=0, wfreeze_err=0.0, retry=0.0, retry_kps=(0.5, 0.35, 0.7, 0.25), rescue_k=0, rescue_mode=0, rescue_zone=0.0):
     lp = P.lp
     A0 = P.A
     if colscale is not None:
@@ -113,6 +113,7 @@ def solve(P, eps=1e-9, max_iter=60000, check=32, wrule="pid", kp=0.7, maxdl=np.l
             first = ~np.isfinite(r0)
             r0 = np.where(first, r, r0)
             rs = ~first & ((r <= beta[0] * r0) | ((r <= beta[1] * r0) & (r > rprev)) | (k >= beta[2] * (it + 1)))
+            stalled = ~first & ~((r <= beta[0] * r0) | ((r <= beta[1] * r0) & (r > rprev))) & (k >= beta[2] * (it + 1)) & (k >= rescue_k) if rescue_k else np.zeros(B, bool)
             steady = (np.abs(r - rprev) <= jsteady * r) & (k >= jk * check) & ~done & ~rs if jump else np.zeros(B, bool)
             if jump and jchain:
                 steady = steady | (lastjump & (k >= check) & ~done & ~rs)
@@ -182,6 +183,17 @@ def solve(P, eps=1e-9, max_iter=60000, check=32, wrule="pid", kp=0.7, maxdl=np.l
                     wfrozen[:] = wfrozen | frozen_
                     dl = np.where(wfrozen, 0.0, dl)
                 logw = np.log(w) + np.where(rs, dl, 0.0)
+                if rescue_k and rescue_zone:
+                    cmax_ = np.max(np.abs(c), 1); qall_ = np.sqrt(qs ** 2 + np.sum(fin(lb) ** 2 + fin(ub) ** 2, 1))
+                    wlo_ = wfloor * eta * 1.1e-16 * cmax_ / (eps * (1 + qall_))
+                    if verbose and stalled.any(): print(it + 1, "stalled", w[stalled], "w_lo", wlo_[stalled])
+                    stalled = stalled & (w < rescue_zone * wlo_)
+                if rescue_k and stalled.any():
+                    # stalled at the noise floor: pull the weight back toward its initial value
+                    tgt = 0.5 * (np.log(w) + np.log(w0)) if rescue_mode == 0 else np.log(w) + np.sign(np.log(w0) - np.log(w)) * np.log(30.0)
+                    logw = np.where(stalled, tgt, logw)
+                    solve.rescues = getattr(solve, "rescues", 0) + int(stalled.sum())
+                    if verbose: print(it + 1, "RESCUE", np.nonzero(stalled)[0], w[stalled], "->", np.exp(logw[stalled]))
                 if verbose: print(it + 1, 'restart', np.nonzero(rs)[0][:4], 'k', k[rs][:4], 'r', r[rs][:4], 'w', w[rs][:4], '->', np.exp(logw[rs][:4]), 'kkt', rp[rs][:4], rd[rs][:4], rg[rs][:4])
                 if stall:
                     st = rs & ((it + 1 - itbest) > stall + stall_frac * itbest)
