@@ -125,6 +125,9 @@ def main():
     ap.add_argument("--streams", type=int, default=0,
                     help="HIP streams the steps are pipelined over (0 = choose among 6/8/12/16 during the warm-up)")
     ap.add_argument("--no-spmv", action="store_true", help="skip the streaming SpMV-step roofline measurement")
+    ap.add_argument("--spmv-large-mult", type=int, default=32,
+                    help="also time spmv_step on a batch this many times larger (0 = skip; the PMC passes skip it so "
+                         "that the per-dispatch counter means belong to one batch size)")
     args = ap.parse_args()
 
     import torch
@@ -325,7 +328,8 @@ def main():
                                            "launch gaps); at the metric batch the launch moves only ~20 MB and is "
                                            "launch/latency bound")
             # the same kernel on a batch large enough to be bandwidth bound (0.67 GB per launch, beyond L2 + MALL)
-            result["spmv_step_large_batch"] = time_spmv(32 * B, 20)
+            if args.spmv_large_mult > 0:
+                result["spmv_step_large_batch"] = time_spmv(args.spmv_large_mult * B, 20)
         # ---- CPU baseline on this box's host cores (bounded sample) ------------------------------------------
         if world == 1 and args.cpu_sample != 0:
             procs = os.cpu_count() or 1

@@ -498,12 +498,18 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
     }                                                                                                       \
   }
     double aty[CPL];
+    // step sizes and the clamp window of the dual update (y+ = v - clamp(v, -sig rhi, -sig rlo), v = y - sig A(2x+ - x)):
+    // functions of the primal weight, refreshed only where it changes (one FP64 division)
+    double tau, sig, ylo[RPL], yhi[RPL];
+#define DSP_SET_STEPS()                                                                                     \
+  {                                                                                                         \
+    tau = eta / w;                                                                                          \
+    sig = eta * w;                                                                                          \
+    _Pragma("unroll") for (int q = 0; q < RPL; ++q) { ylo[q] = -(sig * rhi[q]); yhi[q] = -(sig * rlo[q]); } \
+  }
+    DSP_SET_STEPS()
     DSP_TRACE("[trace] enter loop\n");
     for (it = 0;;) {
-      const double tau = eta / w, sig = eta * w;              // the primal weight changes only at checks
-      double ylo[RPL], yhi[RPL];                              // y+ = v - clamp(v, -sig rhi, -sig rlo),  v = y - sig A(2x+ - x)
-#pragma unroll
-      for (int q = 0; q < RPL; ++q) { ylo[q] = -(sig * rhi[q]); yhi[q] = -(sig * rlo[q]); }
       // ---- plain iterations up to the next check: two SpMVs + elementwise work, no reduction, no branch --------
       const int plain = min(check_every - 1, a.opt.max_iter - it);
       for (int u = 0; u < plain; ++u) {
@@ -629,6 +635,7 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
             w *= exp(dl);
           }
           w = fmin(fmax(w, w_lo), fmax(w_hi, w_lo));
+          DSP_SET_STEPS()
 #pragma unroll
           for (int q = 0; q < CPL; ++q) { x[q] = xp[q]; x0[q] = xp[q]; }
 #pragma unroll
@@ -647,35 +654,43 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
           wave_lds_fence();
           col_product(atyp);                 // A^T y+ for the second application of T
           double tt[2] = {0.0, 0.0};       // |v2 - v1|^2_w, |v2|^2_w
-          double alpha = INFINITY;
+          double gx1[CPL], dgx[CPL], gy1[RPL], dgy[RPL];
 #pragma unroll
           for (int q = 0; q < CPL; ++q) {
-            const double gx1 = xp[q] - tau * (c[q] - atyp[q]);
-            const double gx0 = x[q] - tau * (c[q] - aty[q]);
-            x2[q] = clampd(gx1, lb[q], ub[q]);
+            gx1[q] = xp[q] - tau * (c[q] - atyp[q]);
+            dgx[q] = gx1[q] - (x[q] - tau * (c[q] - aty[q]));
+            x2[q] = clampd(gx1[q], lb[q], ub[q]);
             lds_store_f64(xw[q], 2.0 * x2[q] - xp[q]);
             const double v1 = xp[q] - x[q], v2 = x2[q] - xp[q];
             tt[0] = fma(w * (v2 - v1), v2 - v1, tt[0]);
             tt[1] = fma(w * v2, v2, tt[1]);
-            alpha = fmin(alpha, steps_to_break(gx1, gx1 - gx0, lb[q], ub[q]));
           }
           wave_lds_fence();
           row_product(axb1);
           const double iw = 1.0 / w;
 #pragma unroll
           for (int q = 0; q < RPL; ++q) {
-            const double gy1 = yp[q] - sig * axb1[q];
-            const double gy0 = y[q] - sig * axb[q];
-            y2[q] = gy1 + clampd(-gy1, sig * rlo[q], sig * rhi[q]);
+            gy1[q] = yp[q] - sig * axb1[q];
+            dgy[q] = (y[q] - sig * axb[q]) - gy1[q];
+            y2[q] = gy1[q] + clampd(-gy1[q], sig * rlo[q], sig * rhi[q]);
             const double v1 = yp[q] - y[q], v2 = y2[q] - yp[q];
             tt[0] = fma(iw * (v2 - v1), v2 - v1, tt[0]);
             tt[1] = fma(iw * v2, v2, tt[1]);
-            alpha = fmin(alpha, steps_to_break(-gy1, gy0 - gy1, sig * rlo[q], sig * rhi[q]));
           }
           wave_sums<2>(tt);
-          alpha = wave_min(alpha);
-          if (tt[1] > 0.0 && tt[0] <= a.opt.jump_tol * a.opt.jump_tol * tt[1] && alpha >= a.opt.jump_min &&
-              alpha < 1e200) {
+          // the ratio test (one FP64 division per owned element + a wave-min) only for rays that pass the translation
+          // test: about one attempt in ten
+          double alpha = 0.0;
+          if (tt[1] > 0.0 && tt[0] <= a.opt.jump_tol * a.opt.jump_tol * tt[1]) {
+            alpha = INFINITY;
+#pragma unroll
+            for (int q = 0; q < CPL; ++q) alpha = fmin(alpha, steps_to_break(gx1[q], dgx[q], lb[q], ub[q]));
+#pragma unroll
+            for (int q = 0; q < RPL; ++q)
+              alpha = fmin(alpha, steps_to_break(-gy1[q], dgy[q], sig * rlo[q], sig * rhi[q]));
+            alpha = wave_min(alpha);
+          }
+          if (alpha >= a.opt.jump_min && alpha < 1e200) {
             const double al = floor(alpha) - 1.0;
 #pragma unroll
             for (int q = 0; q < CPL; ++q) {
@@ -702,6 +717,7 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
       if (!moved) DSP_HALPERN_STEP()
     }
 #undef DSP_PDHG_STEP
+#undef DSP_SET_STEPS
 #undef DSP_HALPERN_STEP
 
     DSP_TRACE("[trace] store status=%d it=%d\n", status, it);

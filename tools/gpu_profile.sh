@@ -1,0 +1,35 @@
+#!/bin/bash
+# Round profile recipe (run on the GPU box through gpurun):  bash tools/gpu_profile.sh r01k
+#   1. bench.py (full default run)                          -> gpurun_out/<tag>_bench.json
+#   2. rocprofv3 --kernel-trace --stats of the same command -> gpurun_out/<tag>_kernel_stats.csv
+#   3. rocprofv3 --pmc passes (own runs, no trace domains)  -> gpurun_out/<tag>_pmc_summary.csv (mean per dispatch)
+tag=${1:-prof}
+repo="$(cd "$(dirname "$0")/.." && pwd)"
+out="$repo/gpurun_out"; mkdir -p "$out"
+cd /tmp && export TMPDIR=/tmp
+bench="python $repo/bench.py"
+$bench > "$out/${tag}_bench.json" 2> "$out/${tag}_bench.err"
+tail -c 600 "$out/${tag}_bench.json"; echo
+rm -rf /tmp/prof_trace; timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_trace -- $bench --cpu-sample 0 > /dev/null 2>&1
+f=$(find /tmp/prof_trace -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp "$f" "$out/${tag}_kernel_stats.csv" && head -4 "$f" | cut -c1-200
+i=0
+for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY" \
+           "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY" "SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_WAVES"; do
+  i=$((i+1)); rm -rf /tmp/prof_pmc$i
+  extra="--no-spmv"; [ $i -le 2 ] && extra="--spmv-large-mult 0"
+  timeout 300 rocprofv3 --pmc $set --output-format csv -d /tmp/prof_pmc$i -- $bench --cpu-sample 0 --steps 8 --warmup 1 --streams 8 $extra > /dev/null 2>&1
+done
+python - "$out/${tag}_pmc_summary.csv" <<'PY'
+import csv, glob, sys, collections
+acc = collections.OrderedDict()
+for f in sorted(glob.glob("/tmp/prof_pmc*/**/*counter_collection.csv", recursive=True)):
+    for row in csv.DictReader(open(f)):
+        k = (row["Counter_Name"], row["Kernel_Name"])
+        a = acc.setdefault(k, [0, 0.0]); a[0] += 1; a[1] += float(row["Counter_Value"])
+with open(sys.argv[1], "w") as o:
+    w = csv.writer(o); w.writerow(["counter", "kernel", "dispatches", "mean_counter_value"])
+    for (c, k), (n, s) in acc.items():
+        if "dsp::" in k:
+            w.writerow([c, k, n, round(s / n, 1)])
+print(open(sys.argv[1]).read())
+PY
