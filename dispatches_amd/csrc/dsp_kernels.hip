@@ -487,14 +487,16 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
 // reflected Halpern step toward the anchor (x0, y0); ax tracks A x through the same recursion
 #define DSP_HALPERN_STEP()                                                                                  \
   {                                                                                                         \
-    const double kk2 = (double)(k + 2);                                                                     \
-    double oml = __builtin_amdgcn_rcp(kk2);            /* v_rcp_f64 + one Newton step: 1/(k+2) to ~1 ulp */  \
-    oml = fma(fma(-kk2, oml, 1.0), oml, oml);                                                               \
-    const double lam = 1.0 - oml;                                                                           \
-    _Pragma("unroll") for (int q = 0; q < CPL; ++q) x[q] = lam * (2.0 * xp[q] - x[q]) + oml * x0[q];        \
+    /* anchor weight 1/(k+2): the bare v_rcp_f64 (no Newton step); Halpern needs the weight, not its last bits */ \
+    const double oml = __builtin_amdgcn_rcp((double)(k + 2));                                               \
+    _Pragma("unroll") for (int q = 0; q < CPL; ++q) {                                                       \
+      const double t = 2.0 * xp[q] - x[q];                                                                  \
+      x[q] = fma(oml, x0[q] - t, t);                                                                        \
+    }                                                                                                       \
     _Pragma("unroll") for (int q = 0; q < RPL; ++q) {                                                       \
-      y[q] = lam * (2.0 * yp[q] - y[q]) + oml * y0[q];                                                      \
-      ax[q] = lam * axb[q] + oml * ax0[q];                                                                  \
+      const double t = 2.0 * yp[q] - y[q];                                                                  \
+      y[q] = fma(oml, y0[q] - t, t);                                                                        \
+      ax[q] = fma(oml, ax0[q] - axb[q], axb[q]);                                                            \
     }                                                                                                       \
   }
     double aty[CPL];
@@ -626,11 +628,10 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
 #pragma unroll
           for (int q = 0; q < RPL; ++q) { const double t = yp[q] - y0[q]; dd[1] = fma(t, t, dd[1]); }
           wave_sums<2>(dd);
-          const double ddx = sqrt(dd[0]), ddy = sqrt(dd[1]);
           if (stalled) {
             w = sqrt(w * w_init);
-          } else if (ddx > 1e-14 && ddy > 1e-14) {
-            const double e = log(w) + log(ddx) - log(ddy);
+          } else if (dd[0] > 1e-28 && dd[1] > 1e-28) {
+            const double e = log(w) + 0.5 * log(dd[0] / dd[1]);          // log(w |dx| / |dy|)
             const double dl = clampd(-a.opt.pid_kp * e, -a.opt.max_dlog_weight, a.opt.max_dlog_weight);
             w *= exp(dl);
           }
