@@ -195,22 +195,24 @@ struct RegEll {
   uint32_t off[N];
   // `vec_lds` = LDS byte address of the exchange buffer this matrix gathers from: folded into the offsets once,
   // so a gather needs no address arithmetic in the iteration
-  __device__ __forceinline__ void load(const Entry *__restrict__ g, int lane, uint32_t vec_lds) {
+  // The values are stored pre-multiplied by `scale` (the solve kernel folds its step size into the matrix).
+  __device__ __forceinline__ void load(const Entry *__restrict__ g, int lane, uint32_t vec_lds, double scale) {
 #pragma unroll
     for (int t = 0; t < total(); ++t) {
       const int4 raw = *reinterpret_cast<const int4 *>(g + t * 64 + lane);                   // coalesced global load
-      v[t] = __hiloint2double(raw.y, raw.x);
+      v[t] = scale * __hiloint2double(raw.y, raw.x);
       off[t] = (uint32_t)raw.z + vec_lds;
       asm volatile("" : "+v"(off[t]));             // keep the folded address in a VGPR (no re-add per iteration)
     }
   }
-  __device__ __forceinline__ void product(double (&out)[S]) const {
+  // out = init + (scaled matrix) * (vector in LDS); out and init may be the same array
+  __device__ __forceinline__ void product(double (&out)[S], const double (&init)[S]) const {
     double xv[N];
 #pragma unroll
     for (int t = 0; t < total(); ++t) xv[t] = lds_load_f64(off[t]);                          // ds_read_b64 gathers
 #pragma unroll
     for (int q = 0; q < S; ++q) {
-      double acc = 0.0;
+      double acc = init[q];
 #pragma unroll
       for (int e = 0; e < w(q); ++e) acc = fma(v[base(q) + e], xv[base(q) + e], acc);
       out[q] = acc;
@@ -221,7 +223,7 @@ struct RegEll {
 // long vectors only (their ELL entries are zero): cooperative wave reduction, tails in LDS
 template <int S>
 __device__ __forceinline__ void long_product(double (&out)[S], const char *vec, int lane, const LongList &ll,
-                                             const Entry *__restrict__ tail) {
+                                             const Entry *__restrict__ tail, double scale) {
   for (int l = 0; l < ll.count; ++l) {
     const int owner = ll.owner[l], start = ll.start[l], len = ll.len[l];
     double part = 0.0;
@@ -232,7 +234,7 @@ __device__ __forceinline__ void long_product(double (&out)[S], const char *vec, 
     part = wave_sum(part);
 #pragma unroll
     for (int q = 0; q < S; ++q)
-      if (owner == lane + 64 * q) out[q] += part;
+      if (owner == lane + 64 * q) out[q] = fma(scale, part, out[q]);
   }
 }
 
@@ -289,19 +291,21 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
   const uint32_t rot_x = MATREG ? P.mr_rot_x : 0u, rot_y = MATREG ? P.mr_rot_y : 0u;
   uint32_t xw[CPL], yw[RPL];
 #pragma unroll
-  for (int q = 0; q < CPL; ++q) xw[q] = xb_lds + 8u * rotation_slot((uint32_t)(lane + 64 * q), rot_x);
+  for (int q = 0; q < CPL; ++q) {
+    xw[q] = xb_lds + 8u * rotation_slot((uint32_t)(lane + 64 * q), rot_x);
+    asm volatile("" : "+v"(xw[q]));                // opaque: keeps the address in a VGPR instead of re-adding it per store
+  }
 #pragma unroll
-  for (int q = 0; q < RPL; ++q) yw[q] = yb_lds + 8u * rotation_slot((uint32_t)(lane + 64 * q), rot_y);
+  for (int q = 0; q < RPL; ++q) {
+    yw[q] = yb_lds + 8u * rotation_slot((uint32_t)(lane + 64 * q), rot_y);
+    asm volatile("" : "+v"(yw[q]));
+  }
   // CLDS: [waves][3][n_pad] doubles behind all exchange buffers
   double *clu = reinterpret_cast<double *>(wave_buf + (size_t)a.waves_per_block * (P.n_pad + P.m_pad) * 8) +
                 (size_t)wave * 3 * P.n_pad + lane;
   const int clu_stride = P.n_pad;
-  RegEll<CPL, WC> mreg_c;
-  RegEll<RPL, WR> mreg_r;
-  if (MATREG) {
-    mreg_c.load(P.mr_ellc, lane, yb_lds);                               // A^T gathers y from yb
-    mreg_r.load(P.mr_ellr, lane, xb_lds);                               // A   gathers x from xb
-  }
+  RegEll<CPL, WC> mreg_c;                                                // tau A^T, gathers y from yb   } loaded per
+  RegEll<RPL, WR> mreg_r;                                                // -sig A, gathers x from xb    } scenario / weight
 
   const int n = P.n, m = P.m;
   // column / row owned by slot q of this lane (-1 = padding): sorted layout for the register-resident kernel
@@ -318,22 +322,32 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
   const double eps_obj = a.opt.eps_obj;
   const int check_every = a.opt.check_every;
   const int kkt_every = a.opt.kkt_every > 0 ? a.opt.kkt_every : 1;
-  auto col_product = [&](double (&out)[CPL]) __attribute__((always_inline)) {     // out = A^T (vector in yb)
+  // The step sizes are folded into the products: out = init + tau A^T (vector in yb) and out = init - sig A (vector in
+  // xb).  Register-resident matrices hold tau A^T / -sig A themselves, so a PDHG half-step is the FMA chain alone;
+  // the LDS matrix is shared by the block's waves (each with its own weight) and is scaled on the way out.
+  auto col_step = [&](double (&out)[CPL], const double (&init)[CPL], double tau_) __attribute__((always_inline)) {
     if constexpr (MATREG) {
-      mreg_c.product(out);
-      if (LONG) long_product<CPL>(out, yb, lane, long_c, tailc);
+      mreg_c.product(out, init);
+      if (LONG) long_product<CPL>(out, yb, lane, long_c, tailc, tau_);
     } else {
-      ell_product<CPL, LONG>(out, ellc, P.Wc, yb, lane, P.long_c, tailc);
+      double pr[CPL];
+      ell_product<CPL, LONG>(pr, ellc, P.Wc, yb, lane, P.long_c, tailc);
+#pragma unroll
+      for (int q = 0; q < CPL; ++q) out[q] = fma(tau_, pr[q], init[q]);
     }
   };
-  auto row_product = [&](double (&out)[RPL]) __attribute__((always_inline)) {     // out = A (vector in xb)
+  auto row_step = [&](double (&out)[RPL], const double (&init)[RPL], double nsig_) __attribute__((always_inline)) {
     if constexpr (MATREG) {
-      mreg_r.product(out);
-      if (LONG) long_product<RPL>(out, xb, lane, long_r, tailr);
+      mreg_r.product(out, init);
+      if (LONG) long_product<RPL>(out, xb, lane, long_r, tailr, nsig_);
     } else {
-      ell_product<RPL, LONG>(out, ellr, P.Wr, xb, lane, P.long_r, tailr);
+      double pr[RPL];
+      ell_product<RPL, LONG>(pr, ellr, P.Wr, xb, lane, P.long_r, tailr);
+#pragma unroll
+      for (int q = 0; q < RPL; ++q) out[q] = fma(nsig_, pr[q], init[q]);
     }
   };
+  const double zero_c[CPL] = {}, zero_r[RPL] = {};
 
 #ifdef DSP_CLOCKS   /* development: shader clock vs constant 100 MHz clock, cycles per wave-iteration */
   const long long clk0 = clock64(), wall0 = wall_clock64();
@@ -349,7 +363,7 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
 
     // ---- load + scale this scenario's vectors (coalesced: lane-consecutive addresses) -----------------------
     double x[CPL], x0[CPL], c[CPL], lb[CPL], ub[CPL];
-    double y[RPL], y0[RPL], rlo[RPL], rhi[RPL], ax[RPL], ax0[RPL];
+    double y[RPL], y0[RPL], rlo[RPL], rhi[RPL];
     double nrm[4] = {0.0, 0.0, 0.0, 0.0};                // |q|^2 unscaled, |c|^2 unscaled, |q|^2 scaled, |c|^2 scaled
     double cmax = 0.0, qmax = 0.0;                       // largest scaled |c_j| / finite scaled |row bound|
     double bs2 = 0.0;                                    // sum of squared finite scaled column bounds
@@ -436,14 +450,6 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
 
     const double w_init = w;
     DSP_TRACE("[trace] loaded w=%g\n", w);
-    // A x for the starting point
-#pragma unroll
-    for (int q = 0; q < CPL; ++q) lds_store_f64(xw[q], x[q]);
-    wave_lds_fence();
-    row_product(ax);
-#pragma unroll
-    for (int q = 0; q < RPL; ++q) ax0[q] = ax[q];
-
     int k = 0;                       // iterations since the last restart
     int it = 0;
     int njump = 0;
@@ -452,12 +458,13 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
     bool lastjump = false;           // the last restart of the anchor was a ray jump
     double r0 = INFINITY, rprev = INFINITY;
     int status = DSP_STATUS_ITERATION_LIMIT;
-    double xp[CPL], yp[RPL], axb[RPL];
+    double xp[CPL], yp[RPL];
+    double gx[CPL], gy[RPL];         // the last step before its projections: x - tau (c - A^T y),  y - sig A (2 x+ - x)
     double pobj = 0.0;
 #pragma unroll
     for (int q = 0; q < CPL; ++q) xp[q] = x[q];
 #pragma unroll
-    for (int q = 0; q < RPL; ++q) { yp[q] = y[q]; axb[q] = ax[q]; }
+    for (int q = 0; q < RPL; ++q) yp[q] = y[q];
 
 // CLDS: refresh the register copies of (c, lb, ub) from the wave's LDS region right before they are used
 #define DSP_CLU()                                                                                            \
@@ -466,25 +473,23 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
       c[q] = clu[64 * q]; lb[q] = clu[clu_stride + 64 * q]; ub[q] = clu[2 * clu_stride + 64 * q];          \
     }                                                                                                       \
   }
-// one PDHG application T(x, y) -> (xp, yp); leaves aty = A^T y and axb = A (2 xp - x) behind
+// one PDHG application T(x, y) -> (xp, yp); leaves the unprojected points gx, gy behind (the ray jump uses them)
 #define DSP_PDHG_STEP()                                                                                     \
   {                                                                                                         \
-    _Pragma("unroll") for (int q = 0; q < RPL; ++q) lds_store_f64(yw[q], y[q]);                                     \
+    _Pragma("unroll") for (int q = 0; q < RPL; ++q) lds_store_f64(yw[q], y[q]);                             \
     wave_lds_fence();                                                                                       \
-    col_product(aty);                                     \
     DSP_CLU()                                                                                               \
+    _Pragma("unroll") for (int q = 0; q < CPL; ++q) gx[q] = fma(-tau, c[q], x[q]);                          \
+    col_step(gx, gx, tau);                                                                                  \
     _Pragma("unroll") for (int q = 0; q < CPL; ++q) {                                                       \
-      xp[q] = clampd(x[q] - tau * (c[q] - aty[q]), lb[q], ub[q]);                                           \
-      lds_store_f64(xw[q], 2.0 * xp[q] - x[q]);                                                                     \
+      xp[q] = clampd(gx[q], lb[q], ub[q]);                                                                  \
+      lds_store_f64(xw[q], 2.0 * xp[q] - x[q]);                                                             \
     }                                                                                                       \
     wave_lds_fence();                                                                                       \
-    row_product(axb);                                     \
-    _Pragma("unroll") for (int q = 0; q < RPL; ++q) {                                                       \
-      const double wv = y[q] - sig * axb[q];                                                                \
-      yp[q] = wv - clampd_bare(wv, ylo[q], yhi[q]);                                                         \
-    }                                                                                                       \
+    row_step(gy, y, -sig);                                                                                  \
+    _Pragma("unroll") for (int q = 0; q < RPL; ++q) yp[q] = gy[q] - clampd_bare(gy[q], ylo[q], yhi[q]);     \
   }
-// reflected Halpern step toward the anchor (x0, y0); ax tracks A x through the same recursion
+// reflected Halpern step toward the anchor (x0, y0)
 #define DSP_HALPERN_STEP()                                                                                  \
   {                                                                                                         \
     /* anchor weight 1/(k+2): the bare v_rcp_f64 (no Newton step); Halpern needs the weight, not its last bits */ \
@@ -496,18 +501,21 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
     _Pragma("unroll") for (int q = 0; q < RPL; ++q) {                                                       \
       const double t = 2.0 * yp[q] - y[q];                                                                  \
       y[q] = fma(oml, y0[q] - t, t);                                                                        \
-      ax[q] = fma(oml, ax0[q] - axb[q], axb[q]);                                                            \
     }                                                                                                       \
   }
-    double aty[CPL];
-    // step sizes and the clamp window of the dual update (y+ = v - clamp(v, -sig rhi, -sig rlo), v = y - sig A(2x+ - x)):
-    // functions of the primal weight, refreshed only where it changes (one FP64 division)
+    // step sizes, the clamp window of the dual update (y+ = v - clamp(v, -sig rhi, -sig rlo), v = y - sig A(2x+ - x))
+    // and the step-scaled register matrices: functions of the primal weight, refreshed only where it changes (one FP64
+    // division; the matrices are re-read from L2, 16 bytes per entry and lane, so they stay exact)
     double tau, sig, ylo[RPL], yhi[RPL];
 #define DSP_SET_STEPS()                                                                                     \
   {                                                                                                         \
     tau = eta / w;                                                                                          \
     sig = eta * w;                                                                                          \
     _Pragma("unroll") for (int q = 0; q < RPL; ++q) { ylo[q] = -(sig * rhi[q]); yhi[q] = -(sig * rlo[q]); } \
+    if constexpr (MATREG) {                                                                                 \
+      mreg_c.load(P.mr_ellc, lane, yb_lds, tau);                                                            \
+      mreg_r.load(P.mr_ellr, lane, xb_lds, -sig);                                                           \
+    }                                                                                                       \
   }
     DSP_SET_STEPS()
     DSP_TRACE("[trace] enter loop\n");
@@ -527,18 +535,26 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
       ++k;
       bool moved = false;            // restarted or jumped: the Halpern step is skipped
       {
-        // ---- every check: fixed-point residual in the PDHG metric (3 reductions) ------------------------------
-        double rr[3] = {0.0, 0.0, 0.0};                    // |dx|^2, |dy|^2, dy.A dx
+        // ---- every check: fixed-point residual in the PDHG metric (one SpMV, 3 reductions) ----------------------
+        double rr[3] = {0.0, 0.0, 0.0};                    // |dx|^2, |dy|^2, dy.(-sig A dx)
 #pragma unroll
-        for (int q = 0; q < CPL; ++q) { const double dx = xp[q] - x[q]; rr[0] = fma(dx, dx, rr[0]); }
+        for (int q = 0; q < CPL; ++q) {
+          const double dx = xp[q] - x[q];
+          rr[0] = fma(dx, dx, rr[0]);
+          lds_store_f64(xw[q], dx);
+        }
+        wave_lds_fence();
+        double adx[RPL];
+        row_step(adx, zero_r, -sig);                       // -sig A (x+ - x)
 #pragma unroll
         for (int q = 0; q < RPL; ++q) {
           const double dy = yp[q] - y[q];
           rr[1] = fma(dy, dy, rr[1]);
-          rr[2] = fma(dy, 0.5 * (axb[q] - ax[q]), rr[2]);
+          rr[2] = fma(dy, adx[q], rr[2]);
         }
         wave_sums<3>(rr);
-        const double r = sqrt(fmax(w * rr[0] - 2.0 * eta * rr[2] + rr[1] / w, 0.0));
+        // |dz|^2_M = w |dx|^2 - 2 eta dy.A dx + |dy|^2 / w,  and  -2 eta dy.A dx = 2 rr[2] / w  (sig = eta w)
+        const double r = sqrt(fmax(w * rr[0] + (2.0 * rr[2] + rr[1]) / w, 0.0));
         if (!(r == r)) { status = DSP_STATUS_NUMERICAL; break; }
         // ---- KKT test at (x+, y+) in the ORIGINAL (unscaled) space: 7 reductions + one SpMV, so it is scheduled from
         // r, which the restart test has anyway (see dsp_options::kkt_gate); kkt_gate = 0: every kkt_every-th check
@@ -550,14 +566,19 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
 #pragma unroll
           for (int q = 0; q < RPL; ++q) lds_store_f64(yw[q], yp[q]);
           wave_lds_fence();
-          double atyp[CPL];
-          col_product(atyp);
+          double atyp[CPL], axp[RPL];
+          col_step(atyp, zero_c, tau);                       // tau A^T y+
+#pragma unroll
+          for (int q = 0; q < CPL; ++q) lds_store_f64(xw[q], xp[q]);
+          wave_lds_fence();
+          row_step(axp, zero_r, -sig);                       // -sig A x+
+          const double itau = w / eta, nisig = -1.0 / sig;
           // red: 0 pres^2, 1 dres^2, 2 pobj, 3 dobj, 4 sum|y| viol, 5 sum|c x|, 6 sum|dual residual| |x|
           //      (4 and 6 bound the objective error caused by the remaining infeasibility)
           double red[7] = {0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
           for (int q = 0; q < CPL; ++q) {
-            const double rc = c[q] - atyp[q];
+            const double rc = c[q] - itau * atyp[q];
             const double lp = is_finite(lb[q]) ? fmax(rc, 0.0) : 0.0;
             const double lm = is_finite(ub[q]) ? fmax(-rc, 0.0) : 0.0;
             const int j = col_id(q);
@@ -571,8 +592,8 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
           }
 #pragma unroll
           for (int q = 0; q < RPL; ++q) {
-            const double axp = 0.5 * (axb[q] + ax[q]);
-            const double viol_s = fmax(rlo[q] - axp, 0.0) + fmax(axp - rhi[q], 0.0);
+            const double ax_ = nisig * axp[q];
+            const double viol_s = fmax(rlo[q] - ax_, 0.0) + fmax(ax_ - rhi[q], 0.0);
             const int i = row_id(q);
             const double viol = viol_s / ((i >= 0) ? P.row_scale[i] : 1.0);
             red[0] = fma(viol, viol, red[0]);
@@ -628,6 +649,7 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
 #pragma unroll
           for (int q = 0; q < RPL; ++q) { const double t = yp[q] - y0[q]; dd[1] = fma(t, t, dd[1]); }
           wave_sums<2>(dd);
+          const double w_was = w;
           if (stalled) {
             w = sqrt(w * w_init);
           } else if (dd[0] > 1e-28 && dd[1] > 1e-28) {
@@ -636,30 +658,28 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
             w *= exp(dl);
           }
           w = fmin(fmax(w, w_lo), fmax(w_hi, w_lo));
-          DSP_SET_STEPS()
+          if (w != w_was) DSP_SET_STEPS()
 #pragma unroll
           for (int q = 0; q < CPL; ++q) { x[q] = xp[q]; x0[q] = xp[q]; }
 #pragma unroll
-          for (int q = 0; q < RPL; ++q) {
-            const double axp = 0.5 * (axb[q] + ax[q]);
-            y[q] = yp[q]; y0[q] = yp[q]; ax[q] = axp; ax0[q] = axp;
-          }
+          for (int q = 0; q < RPL; ++q) { y[q] = yp[q]; y0[q] = yp[q]; }
           k = 0; r0 = INFINITY; rprev = INFINITY;
           lastjump = false;
           moved = true;
         } else if (steady) {
           // ---- ray jump: second application of T from (x+, y+), translation test, ratio test ------------------
-          double x2[CPL], y2[RPL], axb1[RPL], atyp[CPL];
+          double x2[CPL], y2[RPL];
 #pragma unroll
           for (int q = 0; q < RPL; ++q) lds_store_f64(yw[q], yp[q]);
           wave_lds_fence();
-          col_product(atyp);                 // A^T y+ for the second application of T
           double tt[2] = {0.0, 0.0};       // |v2 - v1|^2_w, |v2|^2_w
           double gx1[CPL], dgx[CPL], gy1[RPL], dgy[RPL];
 #pragma unroll
+          for (int q = 0; q < CPL; ++q) gx1[q] = fma(-tau, c[q], xp[q]);
+          col_step(gx1, gx1, tau);           // x+ - tau (c - A^T y+)
+#pragma unroll
           for (int q = 0; q < CPL; ++q) {
-            gx1[q] = xp[q] - tau * (c[q] - atyp[q]);
-            dgx[q] = gx1[q] - (x[q] - tau * (c[q] - aty[q]));
+            dgx[q] = gx1[q] - gx[q];
             x2[q] = clampd(gx1[q], lb[q], ub[q]);
             lds_store_f64(xw[q], 2.0 * x2[q] - xp[q]);
             const double v1 = xp[q] - x[q], v2 = x2[q] - xp[q];
@@ -667,13 +687,12 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
             tt[1] = fma(w * v2, v2, tt[1]);
           }
           wave_lds_fence();
-          row_product(axb1);
+          row_step(gy1, yp, -sig);           // y+ - sig A (2 x2 - x+)
           const double iw = 1.0 / w;
 #pragma unroll
           for (int q = 0; q < RPL; ++q) {
-            gy1[q] = yp[q] - sig * axb1[q];
-            dgy[q] = (y[q] - sig * axb[q]) - gy1[q];
-            y2[q] = gy1[q] + clampd(-gy1[q], sig * rlo[q], sig * rhi[q]);
+            dgy[q] = gy[q] - gy1[q];
+            y2[q] = gy1[q] - clampd(gy1[q], ylo[q], yhi[q]);
             const double v1 = yp[q] - y[q], v2 = y2[q] - yp[q];
             tt[0] = fma(iw * (v2 - v1), v2 - v1, tt[0]);
             tt[1] = fma(iw * v2, v2, tt[1]);
@@ -697,15 +716,11 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
             for (int q = 0; q < CPL; ++q) {
               const double xn = clampd(x2[q] + al * (x2[q] - xp[q]), lb[q], ub[q]);
               x[q] = xn; x0[q] = xn; xp[q] = xn;
-              lds_store_f64(xw[q], xn);
             }
-            wave_lds_fence();
-            row_product(ax);
 #pragma unroll
             for (int q = 0; q < RPL; ++q) {
               const double yn = y2[q] + al * (y2[q] - yp[q]);
               y[q] = yn; y0[q] = yn; yp[q] = yn;
-              ax0[q] = ax[q]; axb[q] = ax[q];
             }
             k = 0; r0 = INFINITY; rprev = INFINITY;
             ++njump;
