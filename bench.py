@@ -123,7 +123,7 @@ def main():
     ap.add_argument("--eps", type=float, default=1e-9)
     ap.add_argument("--cpu-sample", type=int, default=-1, help="scenarios for the CPU baseline (0 = skip)")
     ap.add_argument("--streams", type=int, default=0,
-                    help="HIP streams the steps are pipelined over (0 = choose among 6/8/12/16 during the warm-up)")
+                    help="HIP streams the steps are pipelined over (0 = choose among 8/12/16/24 during the warm-up)")
     ap.add_argument("--no-spmv", action="store_true", help="skip the streaming SpMV-step roofline measurement")
     ap.add_argument("--spmv-large-mult", type=int, default=32,
                     help="also time spmv_step on a batch this many times larger (0 = skip; the PMC passes skip it so "
@@ -184,7 +184,7 @@ def main():
     # ~10x between price scenarios and a single launch ends with a long, nearly empty tail.
     # --streams 0 (default): the depth is picked during the untimed warm-up from a short trial of each candidate (how
     # many kernels really run concurrently differs between boxes); rank 0's choice is broadcast so all ranks agree.
-    candidates = [args.streams] if args.streams > 0 else [6, 8, 12, 16]
+    candidates = [args.streams] if args.streams > 0 else [8, 12, 16, 24]
     max_depth = max(candidates)
     streams = [torch.cuda.Stream(device=dev) for _ in range(max_depth)]
     outs = [new_out() for _ in range(max_depth)]

@@ -151,7 +151,7 @@ void dsp_default_options(dsp_options *o) {
   o->check_every = 16;
   o->kkt_every = 32;
   o->kkt_gate = 16.0;
-  o->stall_rescue = 30000;
+  o->stall_rescue = 4000;
   o->reserved = 0;
   o->restart_sufficient = 0.2;
   o->restart_necessary = 0.8;

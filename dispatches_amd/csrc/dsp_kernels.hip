@@ -322,6 +322,13 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
   const double eps_obj = a.opt.eps_obj;
   const int check_every = a.opt.check_every;
   const int kkt_every = a.opt.kkt_every > 0 ? a.opt.kkt_every : 1;
+  // the restart / steady tests on SQUARED residuals: r <= beta r0  <=>  r^2 <= beta^2 r0^2,
+  // |r - rprev| <= s r  <=>  (1 - s)^2 r^2 <= rprev^2 <= (1 + s)^2 r^2
+  const double beta_s2 = a.opt.restart_sufficient * a.opt.restart_sufficient;
+  const double beta_n2 = a.opt.restart_necessary * a.opt.restart_necessary;
+  const double steady_lo2 = (1.0 - a.opt.jump_steady) * (1.0 - a.opt.jump_steady);
+  const double steady_hi2 = (1.0 + a.opt.jump_steady) * (1.0 + a.opt.jump_steady);
+  const double ieta = 1.0 / a.eta;
   // The step sizes are folded into the products: out = init + tau A^T (vector in yb) and out = init - sig A (vector in
   // xb).  Register-resident matrices hold tau A^T / -sig A themselves, so a PDHG half-step is the FMA chain alone;
   // the LDS matrix is shared by the block's waves (each with its own weight) and is scaled on the way out.
@@ -454,9 +461,9 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
     int it = 0;
     int njump = 0;
     int ncheck = 0, last_kkt = 0;
-    double r_gate = 0.0;             // the next gated KKT test runs once r <= r_gate
+    double gate2 = 0.0;              // the next gated KKT test runs once r^2 <= gate2
     bool lastjump = false;           // the last restart of the anchor was a ray jump
-    double r0 = INFINITY, rprev = INFINITY;
+    double r0 = INFINITY, rprev = INFINITY;      // SQUARED residuals (no square root on the check path)
     int status = DSP_STATUS_ITERATION_LIMIT;
     double xp[CPL], yp[RPL];
     double gx[CPL], gy[RPL];         // the last step before its projections: x - tau (c - A^T y),  y - sig A (2 x+ - x)
@@ -506,10 +513,11 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
     // step sizes, the clamp window of the dual update (y+ = v - clamp(v, -sig rhi, -sig rlo), v = y - sig A(2x+ - x))
     // and the step-scaled register matrices: functions of the primal weight, refreshed only where it changes (one FP64
     // division; the matrices are re-read from L2, 16 bytes per entry and lane, so they stay exact)
-    double tau, sig, ylo[RPL], yhi[RPL];
+    double tau, sig, iw, ylo[RPL], yhi[RPL];
 #define DSP_SET_STEPS()                                                                                     \
   {                                                                                                         \
-    tau = eta / w;                                                                                          \
+    iw = 1.0 / w;                                                                                           \
+    tau = eta * iw;                                                                                         \
     sig = eta * w;                                                                                          \
     _Pragma("unroll") for (int q = 0; q < RPL; ++q) { ylo[q] = -(sig * rhi[q]); yhi[q] = -(sig * rlo[q]); } \
     if constexpr (MATREG) {                                                                                 \
@@ -554,13 +562,14 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
         }
         wave_sums<3>(rr);
         // |dz|^2_M = w |dx|^2 - 2 eta dy.A dx + |dy|^2 / w,  and  -2 eta dy.A dx = 2 rr[2] / w  (sig = eta w)
-        const double r = sqrt(fmax(w * rr[0] + (2.0 * rr[2] + rr[1]) / w, 0.0));
+        // (r is kept squared: every test below compares ratios)
+        const double r = fmax(w * rr[0] + (2.0 * rr[2] + rr[1]) * iw, 0.0);
         if (!(r == r)) { status = DSP_STATUS_NUMERICAL; break; }
         // ---- KKT test at (x+, y+) in the ORIGINAL (unscaled) space: 7 reductions + one SpMV, so it is scheduled from
         // r, which the restart test has anyway (see dsp_options::kkt_gate); kkt_gate = 0: every kkt_every-th check
         ++ncheck;
         const bool kkt_now = a.opt.kkt_gate > 0.0
-                                 ? (ncheck - last_kkt >= (last_kkt ? kkt_every : min(4, kkt_every)) || r <= r_gate)
+                                 ? (ncheck - last_kkt >= (last_kkt ? kkt_every : min(4, kkt_every)) || r <= gate2)
                                  : (ncheck % kkt_every) == 0;
         if (kkt_now) {
 #pragma unroll
@@ -572,7 +581,7 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
           for (int q = 0; q < CPL; ++q) lds_store_f64(xw[q], xp[q]);
           wave_lds_fence();
           row_step(axp, zero_r, -sig);                       // -sig A x+
-          const double itau = w / eta, nisig = -1.0 / sig;
+          const double itau = w * ieta, nisig = -(iw * ieta);
           // red: 0 pres^2, 1 dres^2, 2 pobj, 3 dobj, 4 sum|y| viol, 5 sum|c x|, 6 sum|dual residual| |x|
           //      (4 and 6 bound the objective error caused by the remaining infeasibility)
           double red[7] = {0, 0, 0, 0, 0, 0, 0};
@@ -619,12 +628,13 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
             const double lim = fmax(eps_obj * (1.0 + fabs(po + c0)), 1e-12 * red[5]);
             rho = fmax(rho, fmax(fmax(gap, red[4]), red[6]) / lim);
           }
-          r_gate = r * fmin(1.0, a.opt.kkt_gate / rho);
+          const double gf = fmin(1.0, a.opt.kkt_gate / rho);
+          gate2 = r * gf * gf;
           last_kkt = ncheck;
         }
         // ---- restart test (r0 = residual at the first check after a restart) ----------------------------------
         const bool first = !(r0 < INFINITY);
-        const bool decayed = (r <= a.opt.restart_sufficient * r0) || (r <= a.opt.restart_necessary * r0 && r > rprev);
+        const bool decayed = (r <= beta_s2 * r0) || (r <= beta_n2 * r0 && r > rprev);
         const bool artificial = (double)k >= a.opt.restart_artificial * (double)(it + 1);
         const bool do_restart = !first && (decayed || artificial);
         // no decay for >= stall_rescue iterations with the weight within 30x of its rounding guard: the iteration sits on
@@ -637,7 +647,7 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
         // steady residual over two checks, or (chaining, ray_jumps = 2) the previous event was a jump: a landing point
         // usually lies on the next piece's ray already, so it is tested again at its first check
         const bool steady = a.opt.ray_jumps && !do_restart &&
-                            ((k >= 2 * check_every && fabs(r - rprev) <= a.opt.jump_steady * r) ||
+                            ((k >= 2 * check_every && rprev >= steady_lo2 * r && rprev <= steady_hi2 * r) ||
                              (a.opt.ray_jumps > 1 && lastjump && k >= check_every));
 #endif
         if (first) r0 = r;
@@ -653,9 +663,11 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
           if (stalled) {
             w = sqrt(w * w_init);
           } else if (dd[0] > 1e-28 && dd[1] > 1e-28) {
-            const double e = log(w) + 0.5 * log(dd[0] / dd[1]);          // log(w |dx| / |dy|)
-            const double dl = clampd(-a.opt.pid_kp * e, -a.opt.max_dlog_weight, a.opt.max_dlog_weight);
-            w *= exp(dl);
+            // log(w |dx| / |dy|) and the exponential in single precision (hardware v_log_f32 / v_exp_f32): the weight
+            // is a heuristic parameter, 1e-7 relative noise on it is irrelevant and FP64 log + exp cost ~150 instructions
+            const float e = __logf((float)w) + 0.5f * (__logf((float)dd[0]) - __logf((float)dd[1]));
+            const float dl = fminf(fmaxf(-(float)a.opt.pid_kp * e, -(float)a.opt.max_dlog_weight), (float)a.opt.max_dlog_weight);
+            w *= (double)__expf(dl);
           }
           w = fmin(fmax(w, w_lo), fmax(w_hi, w_lo));
           if (w != w_was) DSP_SET_STEPS()
@@ -688,7 +700,6 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
           }
           wave_lds_fence();
           row_step(gy1, yp, -sig);           // y+ - sig A (2 x2 - x+)
-          const double iw = 1.0 / w;
 #pragma unroll
           for (int q = 0; q < RPL; ++q) {
             dgy[q] = gy[q] - gy1[q];

@@ -112,8 +112,8 @@ def solve(P, eps=1e-9, max_iter=60000, check=32, wrule="pid", kp=0.7, maxdl=np.l
             best = np.where(imp, err, best); wbest = np.where(imp, w, wbest); itbest = np.where(imp, it + 1, itbest)
             first = ~np.isfinite(r0)
             r0 = np.where(first, r, r0)
-            rs = ~first & ((r <= beta[0] * r0) | ((r <= beta[1] * r0) & (r > rprev)) | (k >= beta[2] * (it + 1)))
-            stalled = ~first & ~((r <= beta[0] * r0) | ((r <= beta[1] * r0) & (r > rprev))) & (k >= beta[2] * (it + 1)) & (k >= rescue_k) if rescue_k else np.zeros(B, bool)
+            rs = ~first & ((r <= beta[0] * r0) | ((r <= beta[1] * r0) & (r > rprev)) | (k >= beta[2] * (it + 1 - t_attempt)))
+            stalled = ~first & ~((r <= beta[0] * r0) | ((r <= beta[1] * r0) & (r > rprev))) & (k >= beta[2] * (it + 1 - t_attempt)) & (k >= rescue_k) if rescue_k else np.zeros(B, bool)
             steady = (np.abs(r - rprev) <= jsteady * r) & (k >= jk * check) & ~done & ~rs if jump else np.zeros(B, bool)
             if jump and jchain:
                 steady = steady | (lastjump & (k >= check) & ~done & ~rs)
