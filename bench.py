@@ -293,7 +293,7 @@ def main():
                        "optimal": int(n_opt.item()), "scenarios": B * world,
                        "grid": geometry[:2], "lds_bytes": geometry[2], "register_resident_matrix": bool(geometry[3]),
                        "simulated_lds_gather_conflict_cycles_per_iteration": {"identity_layout": lds_conflicts[0],
-                                                                              "rotation_swizzle": lds_conflicts[1]},
+                                                                              "slot_permutation": lds_conflicts[1]},
                        "streams": depth, "stream_trials_ms_per_step": {str(k): 1e3 * v for k, v in trials.items()},
                        "single_batch_latency_ms": single_batch_ms,
                        "pipeline": f"steps issued round-robin on {depth} HIP streams (independent batches overlap; "

@@ -239,12 +239,13 @@ int dsp_create(const dsp_lp_desc *d, int device, const dsp_options *opt, dsp_han
   // register-resident-matrix layout: ownership sorted by length, per-slot widths, position space
   SortedLayout Lc = sorted_layout(AT, cpl, Ec.long_owner), Lr = sorted_layout(A, rpl, Er.long_owner);
   SlotELL Sc = build_slot_ell(AT, Lc, Lr, Ec.long_owner), Sr = build_slot_ell(A, Lr, Lc, Er.long_owner);
-  // bank-conflict-minimising rotation of each exchange buffer: the y buffer is gathered by the A^T entries (Sc), the
-  // x buffer by the A entries (Sr); padding entries of Sc / Sr keep offset 0
-  P.mr_rot_y = best_rotation(Sc, &h->lds_conflicts[0], &h->lds_conflicts[1]);
-  P.mr_rot_x = best_rotation(Sr, &h->lds_conflicts[2], &h->lds_conflicts[3]);
-  apply_rotation(Sc, P.mr_rot_y);
-  apply_rotation(Sr, P.mr_rot_x);
+  // bank-conflict-minimising slot permutation of each exchange buffer: the y buffer is gathered by the A^T entries
+  // (Sc), the x buffer by the A entries (Sr)
+  SlotMap My = optimise_slots(Sc, P.m_pad), Mx = optimise_slots(Sr, P.n_pad);
+  h->lds_conflicts[0] = My.cost_identity; h->lds_conflicts[1] = My.cost_final;
+  h->lds_conflicts[2] = Mx.cost_identity; h->lds_conflicts[3] = Mx.cost_final;
+  apply_slots(Sc, My.slot);
+  apply_slots(Sr, Mx.slot);
   P.mr_wc_pack = Sc.pack; P.mr_wr_pack = Sr.pack;
   P.mr_tailc_entries = (int)Sc.tail_val.size(); P.mr_tailr_entries = (int)Sr.tail_val.size();
   if ((rc = fill_long(P.mr_long_c, Sc)) || (rc = fill_long(P.mr_long_r, Sr))) { delete h; return rc; }
@@ -257,7 +258,7 @@ int dsp_create(const dsp_lp_desc *d, int device, const dsp_options *opt, dsp_han
   UPE(Ecu.tail_val, Ecu.tail_idx, tailc_unscaled) UPE(Eru.tail_val, Eru.tail_idx, tailr_unscaled)
   UP(h->dc, col_scale) UP(h->dr, row_scale)
   UPE(Sc.val, Sc.off, mr_ellc) UPE(Sr.val, Sr.off, mr_ellr) UPE(Sc.tail_val, Sc.tail_off, mr_tailc) UPE(Sr.tail_val, Sr.tail_off, mr_tailr)
-  UP(Lc.at, mr_colat) UP(Lr.at, mr_rowat)
+  UP(Lc.at, mr_colat) UP(Lr.at, mr_rowat) UP(Mx.slot, mr_slot_x) UP(My.slot, mr_slot_y)
 #undef UP
 #undef UPE
   void *q = nullptr;

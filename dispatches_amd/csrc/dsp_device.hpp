@@ -42,7 +42,7 @@ struct DeviceProblem {
   int mr_tailc_entries, mr_tailr_entries;
   const int *mr_colat, *mr_rowat;                                  // [n_pad] / [m_pad] position -> column / row id, -1 = pad
   unsigned mr_wc_pack, mr_wr_pack;                                 // per-slot widths, 4 bits each
-  unsigned mr_rot_x, mr_rot_y;                                     // rotation swizzle of the x / y exchange buffers
+  const int32_t *mr_slot_x, *mr_slot_y;                            // [n_pad] / [m_pad] LDS slot of each exchange-buffer position
   LongList mr_long_c, mr_long_r;                                   // owner = POSITION
 };
 

@@ -175,14 +175,6 @@ __device__ __forceinline__ void lds_store_f64(uint32_t addr, double v) {
   (void)addr; (void)v;
 #endif
 }
-// LDS slot of exchange-buffer position p under the rotation swizzle r (dsp_prepare.hpp: rotation_slot): every
-// 32-slot block (one 256-byte bank row of 8-byte elements) is rotated by r * block, which breaks the stride-32
-// address patterns of the gathers; r is chosen per buffer at create time from the simulated bank conflicts.
-__device__ __forceinline__ uint32_t rotation_slot(uint32_t p, uint32_t r) {
-  const uint32_t blk = p >> 5;
-  return (blk << 5) | ((p + r * blk) & 31u);
-}
-
 // Register-resident ELL (small LPs): the lane's W*S entries live in VGPRs for the whole kernel, so an SpMV is
 // W*S independent LDS gathers issued back to back (one LDS latency instead of W dependent round trips) + W*S FMAs.
 template <int S, unsigned PACK>
@@ -285,19 +277,18 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
 
   char *xb = wave_buf + (size_t)wave * (P.n_pad + P.m_pad) * 8;        // gathered by row products
   char *yb = xb + (size_t)P.n_pad * 8;                                 // gathered by column products
-  // LDS byte addresses of this lane's own elements in the exchange buffers (rotation-swizzled slots)
+  // LDS byte addresses of this lane's own elements in the exchange buffers (permuted slots: dsp_prepare.hpp, optimise_slots)
   using lds_cptr = const __attribute__((address_space(3))) char *;
   const uint32_t xb_lds = (uint32_t)(uintptr_t)(lds_cptr)xb, yb_lds = (uint32_t)(uintptr_t)(lds_cptr)yb;
-  const uint32_t rot_x = MATREG ? P.mr_rot_x : 0u, rot_y = MATREG ? P.mr_rot_y : 0u;
   uint32_t xw[CPL], yw[RPL];
 #pragma unroll
   for (int q = 0; q < CPL; ++q) {
-    xw[q] = xb_lds + 8u * rotation_slot((uint32_t)(lane + 64 * q), rot_x);
+    xw[q] = xb_lds + 8u * (uint32_t)(MATREG ? P.mr_slot_x[lane + 64 * q] : lane + 64 * q);
     asm volatile("" : "+v"(xw[q]));                // opaque: keeps the address in a VGPR instead of re-adding it per store
   }
 #pragma unroll
   for (int q = 0; q < RPL; ++q) {
-    yw[q] = yb_lds + 8u * rotation_slot((uint32_t)(lane + 64 * q), rot_y);
+    yw[q] = yb_lds + 8u * (uint32_t)(MATREG ? P.mr_slot_y[lane + 64 * q] : lane + 64 * q);
     asm volatile("" : "+v"(yw[q]));
   }
   // CLDS: [waves][3][n_pad] doubles behind all exchange buffers

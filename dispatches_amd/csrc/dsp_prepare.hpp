@@ -253,28 +253,37 @@ inline SlotELL build_slot_ell(const HostCSR &M, const SortedLayout &own, const S
   return E;
 }
 
-// ---- LDS bank conflicts of the gathers: rotation swizzle of the exchange buffers ---------------------------------
-// Slot of position p: every 32-slot block (one 256-byte LDS bank row of 8-byte elements) is rotated by r * block.
+// ---- LDS bank conflicts of the gathers: slot permutation of the exchange buffers -----------------------------------
+// Position p of an exchange buffer (the element owned by lane p % 64, slot p / 64) is stored at LDS slot slot[p].
+// Slots are permuted only WITHIN each 32-slot block (one 256-byte LDS bank row of 8-byte elements), so the owner
+// stores (16 consecutive lanes per LDS cycle) stay conflict-free whatever the permutation; the gathers see bank
+// slot[p] % 32.  Start: every block rotated by r * block (best of 32 rotations); then a deterministic local search
+// swaps two slots of a block whenever that does not increase the simulated gather conflicts.
 inline uint32_t rotation_slot(uint32_t p, uint32_t r) {
   const uint32_t blk = p >> 5;
   return (blk << 5) | ((p + r * blk) & 31u);
 }
 
-// Extra LDS cycles of all gathers of E under rotation r: a ds_read_b64 is serviced in two 32-lane groups; within a
-// group, distinct addresses falling into the same (slot mod 32) bank pair cost one extra cycle each (equal addresses
-// broadcast).  E.off holds POSITION * 8 (un-swizzled).
-inline int gather_conflicts(const SlotELL &E, uint32_t r) {
+// Extra LDS cycles of all gathers of E: a ds_read_b64 is serviced in two 32-lane groups; within a group, distinct
+// addresses falling into the same (slot mod 32) bank pair cost one extra cycle each (equal addresses broadcast).
+// E.off holds POSITION * 8 (un-swizzled).  Padding entries (value 0) are skipped: apply_slots points them at an
+// address their group reads anyway.
+inline int gather_conflicts(const SlotELL &E, const std::vector<int32_t> &slot) {
   int extra = 0;
   for (int t = 0; t < E.total; ++t)
     for (int g = 0; g < 2; ++g) {
       int count[32] = {0};
-      std::vector<uint32_t> seen;
+      int32_t seen[32];
+      int ns = 0;
       for (int l = 32 * g; l < 32 * g + 32; ++l) {
         size_t at = (size_t)t * 64 + l;
-        uint32_t slot = rotation_slot(E.off[at] / 8u, r);      // padding entries read position 0
-        if (std::find(seen.begin(), seen.end(), slot) != seen.end()) continue;
-        seen.push_back(slot);
-        count[slot & 31u]++;
+        if (E.val[at] == 0.0) continue;
+        int32_t sl = slot[E.off[at] / 8u];
+        bool dup = false;
+        for (int k = 0; k < ns; ++k) dup |= seen[k] == sl;
+        if (dup) continue;
+        seen[ns++] = sl;
+        count[sl & 31]++;
       }
       int worst = 1;
       for (int b = 0; b < 32; ++b) worst = std::max(worst, count[b]);
@@ -283,21 +292,55 @@ inline int gather_conflicts(const SlotELL &E, uint32_t r) {
   return extra;
 }
 
-inline uint32_t best_rotation(const SlotELL &E, int *cost_identity = nullptr, int *cost_best = nullptr) {
-  uint32_t best = 0;
-  int bc = gather_conflicts(E, 0);
-  if (cost_identity) *cost_identity = bc;
+struct SlotMap {
+  std::vector<int32_t> slot;      // [npad] position -> LDS slot
+  int cost_identity = 0, cost_rotation = 0, cost_final = 0;
+};
+
+inline SlotMap optimise_slots(const SlotELL &E, int npad, int sweeps = 40000) {
+  SlotMap M;
+  M.slot.resize((size_t)npad);
+  for (int p = 0; p < npad; ++p) M.slot[p] = p;
+  M.cost_identity = gather_conflicts(E, M.slot);
+  std::vector<int32_t> trial((size_t)npad);
+  int best = M.cost_identity;
   for (uint32_t r = 1; r < 32; ++r) {
-    int c = gather_conflicts(E, r);
-    if (c < bc) { bc = c; best = r; }
+    for (int p = 0; p < npad; ++p) trial[p] = (int32_t)rotation_slot((uint32_t)p, r);
+    int c = gather_conflicts(E, trial);
+    if (c < best) { best = c; M.slot = trial; }
   }
-  if (cost_best) *cost_best = bc;
-  return best;
+  M.cost_rotation = best;
+  uint64_t rng = 0x9E3779B97F4A7C15ull;                       // fixed seed: the layout is a function of the matrix only
+  auto next = [&rng]() { rng = rng * 6364136223846793005ull + 1442695040888963407ull; return (uint32_t)(rng >> 33); };
+  const int blocks = npad / 32;
+  for (int it = 0; it < sweeps && best > 0; ++it) {
+    const int b = (int)(next() % (uint32_t)blocks), i = (int)(next() & 31u), j = (int)(next() & 31u);
+    if (i == j) continue;
+    std::swap(M.slot[b * 32 + i], M.slot[b * 32 + j]);
+    int c = gather_conflicts(E, M.slot);
+    if (c <= best) best = c;
+    else std::swap(M.slot[b * 32 + i], M.slot[b * 32 + j]);
+  }
+  M.cost_final = best;
+  return M;
 }
 
-inline void apply_rotation(SlotELL &E, uint32_t r) {
-  for (auto &o : E.off) o = rotation_slot(o / 8u, r) * 8u;
-  for (auto &o : E.tail_off) o = rotation_slot(o / 8u, r) * 8u;
+// rewrite the gather offsets of E (position * 8 -> slot * 8); padding entries read an address of their own 32-lane
+// group (a broadcast), or slot 0 if the group has no real entry
+inline void apply_slots(SlotELL &E, const std::vector<int32_t> &slot) {
+  for (int t = 0; t < E.total; ++t)
+    for (int g = 0; g < 2; ++g) {
+      uint32_t any = 0;
+      for (int l = 32 * g; l < 32 * g + 32; ++l) {
+        size_t at = (size_t)t * 64 + l;
+        if (E.val[at] != 0.0) { E.off[at] = (uint32_t)slot[E.off[at] / 8u] * 8u; any = E.off[at]; }
+      }
+      for (int l = 32 * g; l < 32 * g + 32; ++l) {
+        size_t at = (size_t)t * 64 + l;
+        if (E.val[at] == 0.0) E.off[at] = any;
+      }
+    }
+  for (size_t k = 0; k < E.tail_off.size(); ++k) E.tail_off[k] = (uint32_t)slot[E.tail_off[k] / 8u] * 8u;
 }
 
 }  // namespace dsp
