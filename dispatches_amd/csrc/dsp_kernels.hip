@@ -534,12 +534,15 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
       ++k;
       bool moved = false;            // restarted or jumped: the Halpern step is skipped
       {
-        // ---- every check: fixed-point residual in the PDHG metric (one SpMV, 3 reductions) ----------------------
-        double rr[3] = {0.0, 0.0, 0.0};                    // |dx|^2, |dy|^2, dy.(-sig A dx)
+        // ---- every check: fixed-point residual in the PDHG metric (one SpMV, ONE reduction) ---------------------
+        // |dz|^2_M = w |dx|^2 - 2 eta dy.A dx + |dy|^2 / w with -2 eta dy.A dx = 2 dy.(-sig A dx) / w  (sig = eta w):
+        // a linear combination with wave-uniform weights, so the lanes combine their three partial sums first.
+        // r is kept squared: every test below compares ratios.
+        double px = 0.0, py = 0.0;
 #pragma unroll
         for (int q = 0; q < CPL; ++q) {
           const double dx = xp[q] - x[q];
-          rr[0] = fma(dx, dx, rr[0]);
+          px = fma(dx, dx, px);
           lds_store_f64(xw[q], dx);
         }
         wave_lds_fence();
@@ -548,13 +551,9 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
 #pragma unroll
         for (int q = 0; q < RPL; ++q) {
           const double dy = yp[q] - y[q];
-          rr[1] = fma(dy, dy, rr[1]);
-          rr[2] = fma(dy, adx[q], rr[2]);
+          py = fma(dy, fma(2.0, adx[q], dy), py);
         }
-        wave_sums<3>(rr);
-        // |dz|^2_M = w |dx|^2 - 2 eta dy.A dx + |dy|^2 / w,  and  -2 eta dy.A dx = 2 rr[2] / w  (sig = eta w)
-        // (r is kept squared: every test below compares ratios)
-        const double r = fmax(w * rr[0] + (2.0 * rr[2] + rr[1]) * iw, 0.0);
+        const double r = fmax(wave_sum(fma(w, px, iw * py)), 0.0);
         if (!(r == r)) { status = DSP_STATUS_NUMERICAL; break; }
         // ---- KKT test at (x+, y+) in the ORIGINAL (unscaled) space: 7 reductions + one SpMV, so it is scheduled from
         // r, which the restart test has anyway (see dsp_options::kkt_gate); kkt_gate = 0: every kkt_every-th check
