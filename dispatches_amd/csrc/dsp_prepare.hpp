@@ -255,10 +255,14 @@ inline SlotELL build_slot_ell(const HostCSR &M, const SortedLayout &own, const S
 
 // ---- LDS bank conflicts of the gathers: slot permutation of the exchange buffers -----------------------------------
 // Position p of an exchange buffer (the element owned by lane p % 64, slot p / 64) is stored at LDS slot slot[p].
-// Slots are permuted only WITHIN each 32-slot block (one 256-byte LDS bank row of 8-byte elements), so the owner
-// stores (16 consecutive lanes per LDS cycle) stay conflict-free whatever the permutation; the gathers see bank
-// slot[p] % 32.  Start: every block rotated by r * block (best of 32 rotations); then a deterministic local search
-// swaps two slots of a block whenever that does not increase the simulated gather conflicts.
+// Slots are permuted only WITHIN each 32-slot block (one 256-byte LDS bank row of 8-byte elements) and so that the 16
+// consecutive owner lanes a ds_write_b64 services per LDS cycle keep 16 slots that are distinct mod 16 (32 four-byte
+// banks = 16 eight-byte pairs on the store side): the owner stores stay conflict-free whatever the permutation (an
+// unrestricted within-block search lowered the simulated gather conflicts further but doubled the MEASURED
+// SQ_LDS_BANK_CONFLICT through 2-way store conflicts).  The gathers see bank pair slot[p] % 32 (64 banks on the
+// ds_read_b64 side).  Start: every block rotated by r * block (best of 32 rotations); then a deterministic local
+// search applies store-safe swaps (two positions of one 16-lane group, or two slots congruent mod 16) whenever that
+// does not increase the simulated gather conflicts.
 inline uint32_t rotation_slot(uint32_t p, uint32_t r) {
   const uint32_t blk = p >> 5;
   return (blk << 5) | ((p + r * blk) & 31u);
@@ -316,6 +320,8 @@ inline SlotMap optimise_slots(const SlotELL &E, int npad, int sweeps = 40000) {
   for (int it = 0; it < sweeps && best > 0; ++it) {
     const int b = (int)(next() % (uint32_t)blocks), i = (int)(next() & 31u), j = (int)(next() & 31u);
     if (i == j) continue;
+    // store-safe moves only: same 16-lane group, or slots congruent mod 16
+    if ((i >> 4) != (j >> 4) && ((M.slot[b * 32 + i] ^ M.slot[b * 32 + j]) & 15) != 0) continue;
     std::swap(M.slot[b * 32 + i], M.slot[b * 32 + j]);
     int c = gather_conflicts(E, M.slot);
     if (c <= best) best = c;
