@@ -98,7 +98,6 @@ static size_t lds_bytes(const DeviceProblem &P, int wpb, int matreg = 0) {
   size_t ent = matreg ? (size_t)P.mr_tailc_entries + P.mr_tailr_entries
                       : (size_t)P.tailc_entries + P.tailr_entries + P.ellc_entries + P.ellr_entries;
   size_t per_wave = (size_t)(P.n_pad + P.m_pad) * 8;
-  if (matreg == 2) per_wave += (size_t)3 * P.n_pad * 8;          // (c, lb, ub) of the wave's scenario
   return ent * sizeof(Entry) + (size_t)wpb * per_wave;
 }
 

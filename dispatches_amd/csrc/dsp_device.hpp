@@ -66,7 +66,7 @@ struct SpmvArgs {
 };
 
 hipError_t launch_solve(int cpl, int rpl, const SolveArgs &a, dim3 grid, dim3 block, size_t lds, hipStream_t st);
-int matreg_available(int cpl, int rpl, unsigned wc_pack, unsigned wr_pack, bool lng);   // 0 / 1 / 2 (+ c,lb,ub in LDS)
+int matreg_available(int cpl, int rpl, unsigned wc_pack, unsigned wr_pack, bool lng);   // 0 / 1
 hipError_t occupancy_solve(int cpl, int rpl, const SolveArgs &a, int block_threads, size_t lds, int *blocks_per_cu);
 hipError_t launch_spmv(int cpl, int rpl, const SpmvArgs &a, dim3 grid, dim3 block, size_t lds, hipStream_t st);
 

@@ -244,10 +244,7 @@ __device__ __forceinline__ void stage_entries(Entry *dst, const Entry *__restric
 // WC / WR != 0: the ELL part of A^T / A is register-resident (RegEll); the template value packs the per-slot
 // widths, 4 bits each, and ownership follows the sorted layout (P.mr_colat / P.mr_rowat);
 // WC = WR = 0: generic path, matrix in LDS with run-time uniform widths, identity ownership.
-// CLDS: the scaled objective and column bounds (c, lb, ub) of the wave's scenario live in its LDS region instead of
-// registers and are re-read where they are used (3 conflict-free ds_read_b64 per owned column and iteration): trades
-// LDS issue slots for 6*CPL VGPRs so that the 48-h wind+battery LP fits the register-resident kernel.
-template <int CPL, int RPL, bool LONG, unsigned WC, unsigned WR, bool CLDS = false>
+template <int CPL, int RPL, bool LONG, unsigned WC, unsigned WR>
 __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 2) pdlp_solve_kernel(SolveArgs a) {
   constexpr bool MATREG = WC != 0;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -291,10 +288,6 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
     yw[q] = yb_lds + 8u * (uint32_t)(MATREG ? P.mr_slot_y[lane + 64 * q] : lane + 64 * q);
     asm volatile("" : "+v"(yw[q]));
   }
-  // CLDS: [waves][3][n_pad] doubles behind all exchange buffers
-  double *clu = reinterpret_cast<double *>(wave_buf + (size_t)a.waves_per_block * (P.n_pad + P.m_pad) * 8) +
-                (size_t)wave * 3 * P.n_pad + lane;
-  const int clu_stride = P.n_pad;
   RegEll<CPL, WC> mreg_c;                                                // tau A^T, gathers y from yb   } loaded per
   RegEll<RPL, WR> mreg_r;                                                // -sig A, gathers x from xb    } scenario / weight
 
@@ -387,7 +380,6 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
       const double xs = (b.x0 && ok) ? b.x0[(size_t)s * n + j] / d : 0.0;
       x[q] = clampd(xs, lb[q], ub[q]);
       x0[q] = x[q];
-      if constexpr (CLDS) { clu[64 * q] = c[q]; clu[clu_stride + 64 * q] = lb[q]; clu[2 * clu_stride + 64 * q] = ub[q]; }
     }
 #pragma unroll
     for (int q = 0; q < RPL; ++q) {
@@ -464,19 +456,11 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
 #pragma unroll
     for (int q = 0; q < RPL; ++q) yp[q] = y[q];
 
-// CLDS: refresh the register copies of (c, lb, ub) from the wave's LDS region right before they are used
-#define DSP_CLU()                                                                                            \
-  if constexpr (CLDS) {                                                                                     \
-    _Pragma("unroll") for (int q = 0; q < CPL; ++q) {                                                       \
-      c[q] = clu[64 * q]; lb[q] = clu[clu_stride + 64 * q]; ub[q] = clu[2 * clu_stride + 64 * q];          \
-    }                                                                                                       \
-  }
 // one PDHG application T(x, y) -> (xp, yp); leaves the unprojected points gx, gy behind (the ray jump uses them)
 #define DSP_PDHG_STEP()                                                                                     \
   {                                                                                                         \
     _Pragma("unroll") for (int q = 0; q < RPL; ++q) lds_store_f64(yw[q], y[q]);                             \
     wave_lds_fence();                                                                                       \
-    DSP_CLU()                                                                                               \
     _Pragma("unroll") for (int q = 0; q < CPL; ++q) gx[q] = fma(-tau, c[q], x[q]);                          \
     col_step(gx, gx, tau);                                                                                  \
     _Pragma("unroll") for (int q = 0; q < CPL; ++q) {                                                       \
@@ -740,7 +724,6 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
     DSP_TRACE("[trace] store status=%d it=%d\n", status, it);
     // ---- store the scenario's result (unscaled) ----------------------------------------------------------
     if (status != DSP_STATUS_OPTIMAL) {
-      DSP_CLU()
       double po = 0.0;
 #pragma unroll
       for (int q = 0; q < CPL; ++q) po = fma(c[q], xp[q], po);
@@ -770,7 +753,6 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
       if (b.jumps) b.jumps[s] = njump;
       if (b.primal_weight) b.primal_weight[s] = w;
     }
-#undef DSP_CLU
     DSP_DRAIN();
     DSP_TRACE("[trace] scalars stored\n");
   }
@@ -850,18 +832,18 @@ __global__ void __launch_bounds__(512) spmv_step_kernel(SpmvArgs a) {
 // X(cols/lane, rows/lane, per-slot widths of A^T (4 bits each, slot 0 lowest), per-slot widths of A, long vectors,
 //   c/lb/ub in LDS)
 #define DSP_MATREG_SHAPES(X)                                                                                  \
-  X(4, 2, 0x1133u, 0x44u, false, false)         /* wind+battery 24 h */                                       \
-  X(3, 2, 0x122u, 0x24u, false, false)          /* nuclear 24 h      */                                       \
-  X(5, 3, 0x11222u, 0x234u, false, false)       /* nuclear 48 h      */                                       \
-  X(4, 3, 0x1122u, 0x233u, true, false)         /* wind+PEM 48 h     */                                       \
-  X(7, 4, 0x1112333u, 0x2444u, false, true)     /* wind+battery 48 h */
+  X(4, 2, 0x1133u, 0x44u, false)         /* wind+battery 24 h */                                              \
+  X(3, 2, 0x122u, 0x24u, false)          /* nuclear 24 h      */                                              \
+  X(5, 3, 0x11222u, 0x234u, false)       /* nuclear 48 h      */                                              \
+  X(4, 3, 0x1122u, 0x233u, true)         /* wind+PEM 48 h     */                                              \
+  X(7, 4, 0x1112333u, 0x2444u, false)    /* wind+battery 48 h */
 
-// 0 = no specialisation, 1 = register-resident matrix, 2 = register-resident matrix + (c, lb, ub) in LDS
+// 0 = no specialisation, 1 = register-resident matrix
 int matreg_available(int cpl, int rpl, unsigned wc, unsigned wr, bool lng) {
 #ifdef DSP_NO_MATREG
   return 0;
 #else
-#define DSP_X(C, R, WC_, WR_, L, CL) if (cpl == C && rpl == R && wc == WC_ && wr == WR_ && lng == L) return CL ? 2 : 1;
+#define DSP_X(C, R, WC_, WR_, L) if (cpl == C && rpl == R && wc == WC_ && wr == WR_ && lng == L) return 1;
   DSP_MATREG_SHAPES(DSP_X)
 #undef DSP_X
   return 0;
@@ -870,9 +852,9 @@ int matreg_available(int cpl, int rpl, unsigned wc, unsigned wr, bool lng) {
 
 static const void *matreg_fn(int cpl, int rpl, unsigned wc, unsigned wr, bool lng) {
 #ifndef DSP_NO_MATREG
-#define DSP_X(C, R, WC_, WR_, L, CL)                                                        \
+#define DSP_X(C, R, WC_, WR_, L)                                                            \
   if (cpl == C && rpl == R && wc == WC_ && wr == WR_ && lng == L)                           \
-    return reinterpret_cast<const void *>(&pdlp_solve_kernel<C, R, L, WC_, WR_, CL>);
+    return reinterpret_cast<const void *>(&pdlp_solve_kernel<C, R, L, WC_, WR_>);
   DSP_MATREG_SHAPES(DSP_X)
 #undef DSP_X
 #endif

@@ -138,7 +138,7 @@ typedef struct dsp_stats {
   int32_t cols_per_lane;     /* CPL template parameter chosen                       */
   int32_t rows_per_lane;     /* RPL template parameter chosen                       */
   float   kernel_ms;         /* hipEvent time of the solve kernel on `stream` (sync_stats only) */
-  int32_t matreg;            /* 1 / 2 = the register-resident-matrix specialisation ran      */
+  int32_t matreg;            /* 1 = the register-resident-matrix specialisation ran          */
   int32_t lds_conflicts_identity; /* simulated extra LDS cycles per iteration of the gathers, identity layout */
   int32_t lds_conflicts_chosen;   /* ... with the rotation swizzle chosen at create time          */
 } dsp_stats;
