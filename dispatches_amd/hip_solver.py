@@ -60,6 +60,9 @@ EXPORTED_SYMBOLS = ("dsp_default_options", "dsp_create", "dsp_solve", "dsp_spmv_
                     "dsp_get_scaling", "dsp_destroy", "dsp_strerror", "dsp_last_hip_error", "dsp_version")
 
 
+ABI_VERSION = 3          # DSP_VERSION of the include/dsp_hip.h these structures mirror
+
+
 def load_library(path: Optional[str] = None):
     """Load libdsp_hip.so (after torch, so both share one HIP runtime).  Raises if it has not been built."""
     global _lib
@@ -92,6 +95,10 @@ def load_library(path: Optional[str] = None):
     lib.dsp_strerror.restype = C.c_char_p
     lib.dsp_last_hip_error.restype = C.c_int
     lib.dsp_version.restype = C.c_int
+    if lib.dsp_version() != ABI_VERSION:
+        # the ctypes structures below mirror ONE header version; a stale library would read them with another layout
+        raise RuntimeError(f"{path} has ABI version {lib.dsp_version()}, this binding mirrors include/dsp_hip.h version "
+                           f"{ABI_VERSION}: rebuild (python -c 'import __graft_entry__ as g; g.build(force=True)')")
     if path == _LIB_PATH:
         _lib = lib
     return lib

@@ -26,10 +26,25 @@ def test_header_symbols_exported(lib):
         assert hasattr(lib, name), f"{name} declared in include/dsp_hip.h but not exported"
 
 
+def test_binding_mirrors_the_header(lib):
+    """The ctypes structures are a field-for-field copy of the header's: same ABI version, same field names and order
+    (a mismatch would make the library read the caller's structures with another layout)."""
+    from dispatches_amd import hip_solver
+    hdr = open(os.path.join(ROOT, "include", "dsp_hip.h")).read()
+    assert int(re.search(r"#define DSP_VERSION (\d+)", hdr).group(1)) == hip_solver.ABI_VERSION == lib.dsp_version()
+    for struct, cls in (("dsp_options", hip_solver.DspOptions), ("dsp_stats", hip_solver.DspStats),
+                        ("dsp_lp_desc", hip_solver.DspLpDesc), ("dsp_batch", hip_solver.DspBatch)):
+        body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (struct, struct), hdr, re.S).group(1)
+        body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+        fields = re.findall(r"\b\*?\s*\*?([A-Za-z_][A-Za-z0-9_]*)\s*;", body)
+        assert fields == [f[0] for f in cls._fields_], (struct, fields, [f[0] for f in cls._fields_])
+
+
 def test_default_options(lib):
     from dispatches_amd import hip_solver
     o = hip_solver.default_options()
     assert o.eps_rel == 1e-9 and o.eps_obj == 1e-7 and o.check_every == 16 and o.max_iter == 200000
+    assert o.kkt_every == 32 and o.kkt_gate == 16.0 and o.stall_rescue == 4000
     with pytest.raises(TypeError):
         hip_solver.default_options(not_an_option=1)
     assert lib.dsp_strerror(0) == b"ok" and b"invalid" in lib.dsp_strerror(-1)
