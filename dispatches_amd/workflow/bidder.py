@@ -260,6 +260,23 @@ class StochasticProgramBidder(AbstractBidder):
         self._generator = name
 
 
+def round_decimal(a, ndigits):
+    """Python's round(x, ndigits) - correctly rounded decimal, ties to even - for a whole array.
+
+    numpy's round is rint(x * 10**n) / 10**n: the scaling can push a value across a tie (round(1.115, 2) is 1.11, the
+    scaled rint gives 1.12).  Away from ties both agree bit for bit (k / 10**n is the correctly rounded quotient, i.e.
+    the double nearest to the decimal), so only the values whose scaled fraction lies within 1e-6 of one half are sent
+    through round() itself."""
+    a = np.asarray(a, float)
+    scale = 10.0 ** ndigits
+    y = a * scale
+    out = np.rint(y) / scale
+    near_tie = np.abs(y - np.floor(y) - 0.5) < 1e-6
+    if near_tie.any():
+        out[near_tie] = [round(v, ndigits) for v in a[near_tie].tolist()]
+    return out
+
+
 class Bidder(StochasticProgramBidder):
     """Bid-curve bidder: per hour the (power, price) pairs of all scenarios, rounded to 2 dp, sorted and
     integrated to a cost curve (pinned by SURVEY.md A.7 G2)."""
@@ -270,12 +287,12 @@ class Bidder(StochasticProgramBidder):
         is_thermal = md.generator_type == "thermal"
         power = model.expression_values(self.bidding_model_object.power_output) if market == "Real-time" \
             else model.x[:, model.pda_cols]
-        # all (scenario, hour) pairs rounded to 2 dp with Python's round() (exact decimal rounding, as the reference's
-        # bid assembly does), then grouped per hour with numpy: one pass over B*T numbers instead of B*T dict updates
+        # all (scenario, hour) pairs rounded to 2 dp exactly as Python's round() does (the reference's bid assembly calls it
+        # per pair), then grouped per hour with numpy: one pass over B*T numbers instead of B*T dict updates
         T = len(model.HOUR)
         B = model.n_scenario
-        p2 = np.array([round(v, 2) for v in np.asarray(power[:, :T], float).ravel().tolist()]).reshape(B, T)
-        c2 = np.array([round(v, 2) for v in np.asarray(energy_prices[:, :T], float).ravel().tolist()]).reshape(B, T)
+        p2 = round_decimal(np.asarray(power[:, :T], float), 2).reshape(B, T)
+        c2 = round_decimal(np.asarray(energy_prices[:, :T], float), 2).reshape(B, T)
         default = [(round(p, 2), float(mc)) for p, mc in md.p_cost] \
             if (is_thermal and getattr(md, "include_default_p_cost", False)) else []
         pmin2 = round(md.p_min, 2)

@@ -164,3 +164,16 @@ def test_rolling_update_and_rt_bids(rts309):
     m = bidder.real_time_model
     assert np.allclose(m.x[:, m.pda_cols], 1.0)
     assert m.status.tolist() == [0, 0]
+
+
+def test_round_decimal_is_pythons_round():
+    """Bid assembly rounds every (power, price) pair to 2 dp like the reference's per-pair round(); the vectorised
+    replacement must agree bit for bit, including the ties numpy's scaled rint gets wrong (round(1.115, 2) == 1.11)."""
+    from dispatches_amd.workflow.bidder import round_decimal
+    rng = np.random.default_rng(7)
+    a = np.concatenate([rng.uniform(-500, 500, 200000), np.round(rng.uniform(0, 100, 50000), 3),
+                        [1.115, 2.675, 0.145, 1.005, 0.125, 0.375, -0.125, 2.5e-3, 0.0, 25.0]])
+    for nd in (2, 4):
+        ref = np.array([round(v, nd) for v in a.tolist()])
+        assert (round_decimal(a, nd) == ref).all()
+    assert (np.round(a, 2) != np.array([round(v, 2) for v in a.tolist()])).any()      # the reason this helper exists
