@@ -301,7 +301,7 @@ struct SlotMap {
   int cost_identity = 0, cost_rotation = 0, cost_final = 0;
 };
 
-inline SlotMap optimise_slots(const SlotELL &E, int npad, int sweeps = 40000) {
+inline SlotMap optimise_slots(const SlotELL &E, int npad, int sweeps = 4000) {
   SlotMap M;
   M.slot.resize((size_t)npad);
   for (int p = 0; p < npad; ++p) M.slot[p] = p;
