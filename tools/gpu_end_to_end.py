@@ -10,6 +10,8 @@ for wl, T in (("wind_battery", 24), ("wind_battery", 48)):
     t = time.perf_counter()
     bidder, model = getattr(scenarios, wl + "_batch")(B, T, solver)
     t_build = time.perf_counter() - t
+    t = time.perf_counter(); solver._device_lp(model); t_create = time.perf_counter() - t
+    print(f"{wl} {T} h: DeviceLP (dsp_create: scaling, layouts, uploads; first call also loads the code object) {t_create*1e3:.0f} ms", flush=True)
     inner = []
     orig = solver.solve
     def timed(*a, **k):
