@@ -73,12 +73,38 @@ def test_preparation_of_the_dispatch_lps(harness, workload, tmp_path):
     assert res["search_ms"] < 2000
 
 
-def test_metric_lp_uses_the_registered_shape(harness, tmp_path):
-    """The 24 h wind+battery LP must keep hitting the register-resident specialisation compiled for it
+def _registered_lps():
+    """(name, lp) of every LP the reference workflows solve at the benchmark horizons: day-ahead bidding models of the
+    BASELINE workloads, their real-time bidding models, the 4 h tracking model."""
+    from dispatches_amd import scenarios
+    from dispatches_amd.workflow import Tracker
+    out = []
+    rt_done = set()
+    for wl, (fn, kw) in scenarios.WORKLOADS.items():
+        bidder, model = fn(B=2, solver=_NoSolver(), **kw)
+        out.append((wl, model.lp))
+        fam = wl.rsplit("_", 1)[0]
+        if fam not in rt_done:
+            rt_done.add(fam)
+            out.append((fam + " real-time", bidder.real_time_model.lp))
+    bidder, _ = scenarios.wind_battery_batch(2, 24, _NoSolver())
+    tr = Tracker(tracking_model_object=bidder.bidding_model_object, tracking_horizon=4, n_tracking_hour=1, solver=_NoSolver())
+    out.append(("wind_battery tracker", tr.model.lp))
+    return out
+
+
+def test_reference_lps_hit_a_register_resident_specialisation(harness, tmp_path):
+    """Every LP of the reference workflows must keep hitting a register-resident specialisation compiled for it
     (csrc/dsp_kernels.hip: DSP_MATREG_SHAPES); a change of the flattening that alters the per-slot widths would silently
-    fall back to the slower LDS-matrix kernel."""
-    lp = _lp("wind_battery_24h")
-    _, res, _, _ = _run(harness, lp, tmp_path)
-    assert (res["pack_c"], res["pack_r"], res["long_c"], res["long_r"]) == (0x1133, 0x44, 0, 0)
+    fall back to the 3-4x slower LDS-matrix kernel."""
+    import re
     src = open(os.path.join(ROOT, "dispatches_amd", "csrc", "dsp_kernels.hip")).read()
-    assert "X(4, 2, 0x1133u, 0x44u, false)" in src
+    table = src[src.index("#define DSP_MATREG_SHAPES"):]
+    table = table[:table.index("\n\n")]
+    shapes = {(int(a), int(b), int(c, 16), int(d, 16), e == "true")
+              for a, b, c, d, e in re.findall(r"X\((\d+), (\d+), (0x[0-9a-f]+)u, (0x[0-9a-f]+)u, (true|false)\)", table)}
+    assert len(shapes) >= 8
+    for name, lp in _registered_lps():
+        _, res, _, _ = _run(harness, lp, tmp_path)
+        key = ((lp.n + 63) // 64, (lp.m + 63) // 64, res["pack_c"], res["pack_r"], res["long_c"] + res["long_r"] > 0)
+        assert key in shapes, (name, key[:2], hex(key[2]), hex(key[3]), key[4])
