@@ -1,26 +1,28 @@
 // dsp_kernels.hip — hand-written gfx950 (CDNA4, wave64) kernels of the batched dispatch-LP solver.
 //
-// Hot path: one price scenario per 64-lane wave, several waves (scenarios) per workgroup.
-//   * lane l owns columns {l, l+64, ...} (CPL of them) and rows {l, l+64, ...} (RPL of them); every per-scenario
-//     vector (x, anchor, c, bounds, y, row bounds, A x) lives in that lane's registers for the whole solve;
-//   * the scaled constraint matrix, shared by all scenarios, is staged ONCE per workgroup into LDS as 16-byte
-//     {value, byte offset} entries in a lane-major ELL layout for A (row products) and A^T (column products):
-//     one conflict-free ds_read_b128 per entry, then one ds_read_b64 gather from the wave's LDS exchange buffer
-//     through which x-bar / y are exchanged between lanes; for a fixed ELL position the CPL (RPL) slots of a lane
-//     are independent multiply-add chains, so the LDS latency of one chain hides behind the others;
-//   * vectors longer than the ELL width (e.g. the shared PEM-capacity column) are reduced cooperatively by the
-//     wave with cross-lane shuffles ("LDS-staged partials + wavefront reductions");
-//   * the iteration is the restarted, reflected Halpern PDHG (r2HPDHG): two SpMVs per iteration, NO reduction on
-//     the per-iteration path; restart / KKT tests every `check_every` iterations use wave reductions;
+// Hot path: one price scenario per 64-lane wave (pdlp_solve_kernel).
+//   * lane l owns CPL columns and RPL rows; every per-scenario vector (x, anchor, c, bounds, y, anchor, row bounds)
+//     lives in that lane's registers for the whole solve; lanes exchange x-bar / y through a per-wave LDS buffer (one
+//     ds_write_b64 per owned element, one ds_read_b64 gather per matrix entry, slots permuted against bank conflicts);
+//   * the scaled constraint matrix, shared by all scenarios, is held in one of two forms:
+//       - register-resident (RegEll; every LP of the reference workflows): each lane keeps the entries of the vectors
+//         it owns in VGPRs, pre-multiplied by the step sizes (tau A^T and -sig A), so a PDHG half-step is a chain of
+//         FMAs that starts from x - tau c / y; ownership is sorted by vector length and the ELL width is per slot;
+//       - LDS-resident (any other LP that fits): staged once per workgroup as 16-byte {value, byte offset} entries in a
+//         lane-major ELL layout, one conflict-free ds_read_b128 per entry;
+//   * vectors longer than the ELL width (e.g. the shared PEM-capacity column) are reduced cooperatively by the wave;
+//   * the iteration is the restarted, reflected Halpern PDHG (r2HPDHG): two SpMVs per iteration, NO reduction on the
+//     per-iteration path; every `check_every` iterations one extra SpMV + one wave reduction give the fixed-point
+//     residual for the restart test; the KKT / termination test is scheduled from that residual (dsp_options::kkt_gate);
 //   * "ray jumps": PDHG on an LP is piecewise affine; while the active set is not yet identified the iterates drift
 //     along a ray z + k v at constant speed for thousands of iterations.  When the check detects such a steady
 //     state (T(T z) - T z == T z - z), a ratio test over all clipping thresholds (one wave-min) gives the number of
 //     steps to the next breakpoint and the iterate jumps there in one go;
 //   * scenarios are pulled from a device-side work queue (one atomicAdd per scenario) so waves retire
-//     independently — iteration counts differ several-fold between price scenarios.
-// Control flow is wave-uniform throughout (one scenario per wave): no divergence.
+//     independently — iteration counts differ 20-fold between price scenarios.
+// Control flow is wave-uniform throughout (one scenario per wave): no divergence.  Wave reductions run on the VALU (DPP).
 // No MFMA: the work is sparse BLAS-2 with ~3 nonzeros per row.  HBM is touched only to load a scenario's
-// (c, bounds) and to store (x, y, obj); the limiter is LDS issue + FP64 VALU.
+// (c, bounds) and to store (x, y, obj); FP64 VALU issue and the LDS pipe limit it about equally.
 //
 // The streaming SpMV step kernel at the bottom keeps X/Y in HBM and is the kernel whose HBM roofline
 // SURVEY.md 8(d) defines.
