@@ -101,9 +101,8 @@ class MultiPeriodNuclear:
             "Final holdup [kg]": np.round(col("tank_holdup") * prm.mw_h2, 2),
             "Hydrogen Market [kg/hr]": np.round(col("outlet_to_pipeline") * prm.mw_h2 * 3600, 2),
             "Total Cost [$]": np.round([blk.value(blk.tot_cost[t]) for t in range(T)], 2),
+            **kwargs,                     # e.g. Scenario=, Market= (appended as the last columns, as the reference does)
         })
-        for key in kwargs:
-            df[key] = kwargs[key]
         self.result_list.append(df)
 
     def write_results(self, path):

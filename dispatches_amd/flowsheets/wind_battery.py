@@ -134,9 +134,8 @@ class MultiPeriodWindBattery:
             "Wind Power to Battery [MW]": np.round(col("elec_in") * 1e-3, 2),
             "State of Charge [MWh]": np.round(col("state_of_charge") * 1e-3, 2),
             "Total Cost [$]": np.round([b.value(b.tot_cost[t]) for t in range(T)], 2),
+            **kwargs,                     # e.g. Scenario=, Market= (appended as the last columns, as the reference does)
         })
-        for key in kwargs:
-            df[key] = kwargs[key]
         self.result_list.append(df)
 
     def write_results(self, path):

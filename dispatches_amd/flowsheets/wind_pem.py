@@ -109,9 +109,8 @@ class MultiPeriodWindPEM:
             "Wind Curtailment [MW]": round(b.value(b.wind_waste[0]), 2),
             "Hydrogen Sales [kg]": np.round(self._h2_kg_per_hr(col("pem_elec")), 2),
             "Total Cost [$]": np.round([b.value(b.tot_cost[t]) for t in range(T)], 2),
+            **kwargs,                     # e.g. Scenario=, Market= (appended as the last columns, as the reference does)
         })
-        for key in kwargs:
-            df[key] = kwargs[key]
         self.result_list.append(df)
 
     def write_results(self, path):
