@@ -541,7 +541,7 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
         }
         const double r = fmax(wave_sum(fma(w, px, iw * py)), 0.0);
         if (!(r == r)) { status = DSP_STATUS_NUMERICAL; break; }
-        // ---- KKT test at (x+, y+) in the ORIGINAL (unscaled) space: 7 reductions + one SpMV, so it is scheduled from
+        // ---- KKT test at (x+, y+) in the ORIGINAL (unscaled) space: 7 reductions + two SpMVs, so it is scheduled from
         // r, which the restart test has anyway (see dsp_options::kkt_gate); kkt_gate = 0: every kkt_every-th check
         ++ncheck;
         const bool kkt_now = a.opt.kkt_gate > 0.0

@@ -61,7 +61,7 @@ typedef struct dsp_options {
   double  eps_obj;           /* objective accuracy: |gap|, sum|y||row violation| and sum|dual residual||x| are
                                 each <= eps_obj (1 + |c.x + c0|); 0 disables the tests     default 1e-7   */
   int32_t max_iter;          /* iteration limit per scenario                          default 200000 */
-  int32_t check_every;       /* restart / ray-jump test period (3 reductions)         default 16     */
+  int32_t check_every;       /* restart / ray-jump test period (1 SpMV + 1 reduction) default 16     */
   double  restart_sufficient;/* beta_1: restart when r <= beta_1 r0                   default 0.2    */
   double  restart_necessary; /* beta_2: ... or r <= beta_2 r0 and r increased         default 0.8    */
   double  restart_artificial;/* beta_3: ... or k >= beta_3 * total iterations         default 0.36   */
@@ -77,7 +77,7 @@ typedef struct dsp_options {
                                 first check; measured worse on full batches)           default 1      */
   int32_t ruiz_iters;        /* Ruiz passes before Pock-Chambolle (create time)       default 10     */
   int32_t waves_per_block;   /* scenarios per workgroup (1 wave each); 0 = auto                      */
-  int32_t kkt_every;         /* the KKT / termination test (7 reductions + one SpMV) runs at least every
+  int32_t kkt_every;         /* the KKT / termination test (7 reductions + two SpMVs) runs at least every
                                 kkt_every-th check (kkt_gate = 0: exactly every kkt_every-th)   default 32     */
   int32_t no_matreg;         /* 1 = never use the register-resident-matrix kernel (create time)  default 0 */
   int32_t geo_iters;         /* geometric-mean equilibration passes BEFORE Ruiz (create time): balances
@@ -140,7 +140,7 @@ typedef struct dsp_stats {
   float   kernel_ms;         /* hipEvent time of the solve kernel on `stream` (sync_stats only) */
   int32_t matreg;            /* 1 = the register-resident-matrix specialisation ran          */
   int32_t lds_conflicts_identity; /* simulated extra LDS cycles per iteration of the gathers, identity layout */
-  int32_t lds_conflicts_chosen;   /* ... with the rotation swizzle chosen at create time          */
+  int32_t lds_conflicts_chosen;   /* ... with the slot permutation chosen at create time          */
 } dsp_stats;
 
 void dsp_default_options(dsp_options *opt);
