@@ -447,6 +447,8 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
     int njump = 0;
     int ncheck = 0, last_kkt = 0;
     double gate2 = 0.0;              // the next gated KKT test runs once r^2 <= gate2
+    int stalls = 0;                  // restarts forced after >= stall_rescue iterations without decay
+    bool waive_obj = false;          // stalled twice: terminate on the eps_rel tests alone
     bool lastjump = false;           // the last restart of the anchor was a ray jump
     double r0 = INFINITY, rprev = INFINITY;      // SQUARED residuals (no square root on the check path)
     int status = DSP_STATUS_ITERATION_LIMIT;
@@ -594,7 +596,7 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
           const double gap = fabs(po - dobj);
           const double rg = gap / (1.0 + fabs(po) + fabs(dobj));
           bool done = rp <= eps && rd <= eps && rg <= eps;
-          if (done && eps_obj > 0.0) {
+          if (done && eps_obj > 0.0 && !waive_obj) {
             const double lim = fmax(eps_obj * (1.0 + fabs(po + c0)), 1e-12 * red[5]);
             done = gap <= lim && red[4] <= lim && red[6] <= lim;
           }
@@ -613,10 +615,12 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
         const bool decayed = (r <= beta_s2 * r0) || (r <= beta_n2 * r0 && r > rprev);
         const bool artificial = (double)k >= a.opt.restart_artificial * (double)(it + 1);
         const bool do_restart = !first && (decayed || artificial);
-        // no decay for >= stall_rescue iterations with the weight within 30x of its rounding guard: the iteration sits on
-        // the rounding floor under a runaway primal weight (dsp_options::stall_rescue)
-        const bool stalled = do_restart && !decayed && a.opt.stall_rescue > 0 && k >= a.opt.stall_rescue &&
-                             (w < 30.0 * w_lo || 30.0 * w > w_hi);
+        // no decay for >= stall_rescue iterations: the iteration sits on its rounding floor (dsp_options::stall_rescue).
+        // First time, with the weight within 30x of its rounding guard: the controller has driven the weight away, reset
+        // it.  From the second time on: nothing more to gain, the eps_obj tests are waived (the eps_rel tests stay).
+        const bool floor_hit = do_restart && !decayed && a.opt.stall_rescue > 0 && k >= a.opt.stall_rescue;
+        const bool stalled = floor_hit && stalls == 0 && (w < 30.0 * w_lo || 30.0 * w > w_hi);
+        if (floor_hit && ++stalls >= 2) { waive_obj = true; gate2 = INFINITY; }
 #ifdef DSP_NO_JUMP
         const bool steady = false;
 #else

@@ -89,15 +89,18 @@ typedef struct dsp_options {
                                 kkt_every bounds the gap.  Only moves WHEN termination is detected, never the iterates.
                                 0 = fixed cadence                                         default 16     */
   int32_t stall_rescue;      /* > 0: a restart forced by the artificial criterion alone after >= stall_rescue
-                                iterations without the residual decaying, with the primal weight within 30x of its
-                                rounding guard (weight_guard), means the iteration sits on its rounding floor under
-                                a weight the movement-ratio controller has driven away (seen: gap stuck at 1e-7
-                                relative, primal and dual residuals at 1e-12): the weight is pulled back to the
-                                geometric mean of its value and the initial weight.  The threshold matters:
+                                iterations without the residual decaying means the iteration sits on its rounding
+                                floor.  The first time, if the primal weight is within 30x of its rounding guard
+                                (weight_guard), the movement-ratio controller has driven it away (seen: gap stuck
+                                at 1e-7 relative, residuals at 1e-12) and the weight is pulled back to the
+                                geometric mean of its value and the initial weight.  From the second time on the
+                                eps_obj tests are waived and the scenario terminates on the eps_rel tests alone:
+                                an objective that is the difference of terms 1e5 times larger (near-zero-price
+                                days) cannot be resolved to eps_obj in double precision.  The threshold matters:
                                 scenarios that converge with a weight at the guard do so within ~10 k iterations
                                 and a rescue after 1000 slowed ~70 of the 4096 48-h scenarios 10-25x; 4000 (first
-                                possible trigger at iteration 11 k) touches none of them and frees the trapped
-                                ones at ~14 k iterations.  0 = off                     default 4000   */
+                                possible trigger at iteration 11 k) touches none of them.  0 = off
+                                                                                          default 4000   */
   int32_t reserved;
 } dsp_options;
 
