@@ -152,6 +152,7 @@ void dsp_default_options(dsp_options *o) {
   o->kkt_gate = 16.0;
   o->stall_rescue = 4000;
   o->reserved = 0;
+  o->jump_rel = 3.0;
   o->restart_sufficient = 0.2;
   o->restart_necessary = 0.8;
   o->restart_artificial = 0.36;
@@ -281,7 +282,7 @@ int dsp_solve(dsp_handle *h, const dsp_batch *batch, const dsp_options *opt, dsp
   SolveArgs a{};
   a.P = h->P; a.b = *batch;
   a.opt = opt ? *opt : h->opt;
-  if (a.opt.max_iter < 1 || a.opt.check_every < 1 || a.opt.kkt_every < 0 || !(a.opt.kkt_gate >= 0) || a.opt.stall_rescue < 0 || !(a.opt.eps_rel > 0) || !(a.opt.eps_obj >= 0) ||
+  if (a.opt.max_iter < 1 || a.opt.check_every < 1 || a.opt.kkt_every < 0 || !(a.opt.kkt_gate >= 0) || a.opt.stall_rescue < 0 || !(a.opt.jump_rel >= 0) || !(a.opt.eps_rel > 0) || !(a.opt.eps_obj >= 0) ||
       !(a.opt.pid_kp >= 0) || !(a.opt.step_scale > 0))
     return DSP_ERR_INVALID;
   a.eta = a.opt.step_scale * h->eta_unit;

@@ -447,6 +447,7 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
     int njump = 0;
     int ncheck = 0, last_kkt = 0;
     double gate2 = 0.0;              // the next gated KKT test runs once r^2 <= gate2
+    int jump_not_before = 0;         // no ray-jump test while k (iterations since the anchor reset) is below this
     int stalls = 0;                  // restarts forced after >= stall_rescue iterations without decay
     bool waive_obj = false;          // stalled twice: terminate on the eps_rel tests alone
     bool lastjump = false;           // the last restart of the anchor was a ray jump
@@ -626,7 +627,7 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
 #else
         // steady residual over two checks, or (chaining, ray_jumps = 2) the previous event was a jump: a landing point
         // usually lies on the next piece's ray already, so it is tested again at its first check
-        const bool steady = a.opt.ray_jumps && !do_restart &&
+        const bool steady = a.opt.ray_jumps && !do_restart && k >= jump_not_before &&
                             ((k >= 2 * check_every && rprev >= steady_lo2 * r && rprev <= steady_hi2 * r) ||
                              (a.opt.ray_jumps > 1 && lastjump && k >= check_every));
 #endif
@@ -655,7 +656,7 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
           for (int q = 0; q < CPL; ++q) { x[q] = xp[q]; x0[q] = xp[q]; }
 #pragma unroll
           for (int q = 0; q < RPL; ++q) { y[q] = yp[q]; y0[q] = yp[q]; }
-          k = 0; r0 = INFINITY; rprev = INFINITY;
+          k = 0; r0 = INFINITY; rprev = INFINITY; jump_not_before = 0;
           lastjump = false;
           moved = true;
         } else if (steady) {
@@ -701,7 +702,10 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
               alpha = fmin(alpha, steps_to_break(-gy1[q], dgy[q], sig * rlo[q], sig * rhi[q]));
             alpha = wave_min(alpha);
           }
-          if (alpha >= a.opt.jump_min && alpha < 1e200) {
+          // a ray that is too short to be worth an anchor reset reaches its breakpoint by itself in alpha steps: no
+          // point in testing again before that
+          if (alpha >= a.opt.jump_min && alpha < a.opt.jump_rel * (double)k) jump_not_before = k + (int)fmin(alpha, 1e6);
+          if (alpha >= a.opt.jump_min && alpha >= a.opt.jump_rel * (double)k && alpha < 1e200) {
             const double al = floor(alpha) - 1.0;
 #pragma unroll
             for (int q = 0; q < CPL; ++q) {
@@ -713,7 +717,7 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
               const double yn = y2[q] + al * (y2[q] - yp[q]);
               y[q] = yn; y0[q] = yn; yp[q] = yn;
             }
-            k = 0; r0 = INFINITY; rprev = INFINITY;
+            k = 0; r0 = INFINITY; rprev = INFINITY; jump_not_before = 0;
             ++njump;
             lastjump = true;
             moved = true;

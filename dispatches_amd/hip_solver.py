@@ -26,7 +26,8 @@ class DspOptions(C.Structure):
                 ("step_scale", C.c_double), ("weight_guard", C.c_double), ("jump_steady", C.c_double), ("jump_tol", C.c_double),
                 ("jump_min", C.c_double), ("ray_jumps", C.c_int32), ("ruiz_iters", C.c_int32),
                 ("waves_per_block", C.c_int32), ("kkt_every", C.c_int32), ("no_matreg", C.c_int32), ("geo_iters", C.c_int32),
-                ("kkt_gate", C.c_double), ("stall_rescue", C.c_int32), ("reserved", C.c_int32)]
+                ("kkt_gate", C.c_double), ("stall_rescue", C.c_int32), ("reserved", C.c_int32),
+                ("jump_rel", C.c_double)]
 
 
 class DspBatch(C.Structure):

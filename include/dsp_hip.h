@@ -102,6 +102,11 @@ typedef struct dsp_options {
                                 possible trigger at iteration 11 k) touches none of them.  0 = off
                                                                                           default 4000   */
   int32_t reserved;
+  double  jump_rel;          /* ray jump: ... and the ray stays >= jump_rel * (iterations since the anchor was
+                                last reset) steps in its piece.  A jump resets the Halpern anchor; when the pieces
+                                are short the solver otherwise jumps at every opportunity (one jump per ~40
+                                iterations, thousands per scenario) and never gets the averaged iteration going:
+                                such scenarios were the 10-60x stragglers of every batch        default 3    */
 } dsp_options;
 
 /* The per-call data of B scenarios.  c is required; every other input may be NULL (= no bound: -inf / +inf,

@@ -44,7 +44,7 @@ def test_default_options(lib):
     from dispatches_amd import hip_solver
     o = hip_solver.default_options()
     assert o.eps_rel == 1e-9 and o.eps_obj == 1e-7 and o.check_every == 16 and o.max_iter == 200000
-    assert o.kkt_every == 32 and o.kkt_gate == 16.0 and o.stall_rescue == 4000
+    assert o.kkt_every == 32 and o.kkt_gate == 16.0 and o.stall_rescue == 4000 and o.jump_rel == 3.0
     with pytest.raises(TypeError):
         hip_solver.default_options(not_an_option=1)
     assert lib.dsp_strerror(0) == b"ok" and b"invalid" in lib.dsp_strerror(-1)

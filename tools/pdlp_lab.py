@@ -29,7 +29,7 @@ def geo_scaling(A, iters=8):
 
 def solve(P, eps=1e-9, max_iter=60000, check=32, wrule="pid", kp=0.7, maxdl=np.log(30), r0_mode="k1",
           beta=(0.2, 0.8, 0.36), eta_scale=0.998, n_ruiz=10, wclamp=None, bal_gain=0.25, bal_thresh=10.0,
-          c0_gap=True, verbose=False, colscale=None, stall=0, stall_frac=0.5, kp_decay=0.5, xinit=0, term=0, eps_obj=1e-7, jump=0, jtol=1e-2, jsteady=0.05, jmin=4.0, winit=0.0, geo=0, jumpw=0, wfloor=0.0, jk=2.0, jacc=0.0, jchain=0, jland=-1.0, wfreeze=0, wfreeze_err=0.0, retry=0.0, retry_kps=(0.5, 0.35, 0.7, 0.25), rescue_k=0, rescue_mode=0, rescue_zone=0.0):
+          c0_gap=True, verbose=False, colscale=None, stall=0, stall_frac=0.5, kp_decay=0.5, xinit=0, term=0, eps_obj=1e-7, jump=0, jtol=1e-2, jsteady=0.05, jmin=4.0, winit=0.0, geo=0, jumpw=0, wfloor=0.0, jk=2.0, jacc=0.0, jchain=0, jland=-1.0, wfreeze=0, wfreeze_err=0.0, retry=0.0, retry_kps=(0.5, 0.35, 0.7, 0.25), rescue_k=0, rescue_mode=0, rescue_zone=0.0, jrel=0.0):
     lp = P.lp
     A0 = P.A
     if colscale is not None:
@@ -136,7 +136,7 @@ def solve(P, eps=1e-9, max_iter=60000, check=32, wrule="pid", kp=0.7, maxdl=np.l
                         return np.where(np.isfinite(a), a, big)
                     ax_ = ratio(gx1, dgx, lb, ub).min(1); ay_ = ratio(g, dgy, lo_, hi_).min(1)
                     alpha = np.minimum(ax_, ay_)
-                    dojump = trans & (alpha >= jmin) & (alpha < 1e200)
+                    dojump = trans & (alpha >= jmin) & (alpha >= jrel * k) & (alpha < 1e200)
                     if dojump.any():
                         a = np.where(dojump, np.maximum(np.floor(alpha) + jland, 0.0), 0.0)[:, None]
                         xn = np.clip(x2 + a * v2x, lb, ub); yn = y2 + a * v2y
