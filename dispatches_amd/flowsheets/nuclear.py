@@ -91,7 +91,9 @@ class MultiPeriodNuclear:
         T = len(per)
         x = blk.solution
         col = lambda key: np.array([x[p[key].index] for p in per])
-        df = pd.DataFrame({
+        # kept as a plain dict; the frames are built once in write_results (one pandas constructor per recorded
+        # scenario and call was most of the host time of an hourly real-time bid)
+        rec = {
             "Date": date,
             "Hour": hour,
             "Horizon [hr]": np.arange(T, dtype=int),
@@ -102,11 +104,11 @@ class MultiPeriodNuclear:
             "Hydrogen Market [kg/hr]": np.round(col("outlet_to_pipeline") * prm.mw_h2 * 3600, 2),
             "Total Cost [$]": np.round([blk.value(blk.tot_cost[t]) for t in range(T)], 2),
             **kwargs,                     # e.g. Scenario=, Market= (appended as the last columns, as the reference does)
-        })
-        self.result_list.append(df)
+        }
+        self.result_list.append(rec)
 
     def write_results(self, path):
-        pd.concat(self.result_list).to_csv(path, index=False)
+        pd.concat([pd.DataFrame(r) for r in self.result_list]).to_csv(path, index=False)
 
     @property
     def power_output(self):

@@ -121,7 +121,9 @@ class MultiPeriodWindBattery:
         col = lambda key: np.array([x[p[key].index] for p in per])
         # the reference reports wind_waste[0] in every row (:312); kept for CSV compatibility
         waste0 = b.value(b.wind_waste[0])
-        df = pd.DataFrame({
+        # kept as a plain dict; the frames are built once in write_results (one pandas constructor per recorded
+        # scenario and call was most of the host time of an hourly real-time bid)
+        rec = {
             "Generator": self.model_data.gen_name,
             "Date": date,
             "Hour": hour,
@@ -135,11 +137,11 @@ class MultiPeriodWindBattery:
             "State of Charge [MWh]": np.round(col("state_of_charge") * 1e-3, 2),
             "Total Cost [$]": np.round([b.value(b.tot_cost[t]) for t in range(T)], 2),
             **kwargs,                     # e.g. Scenario=, Market= (appended as the last columns, as the reference does)
-        })
-        self.result_list.append(df)
+        }
+        self.result_list.append(rec)
 
     def write_results(self, path):
-        pd.concat(self.result_list).to_csv(path, index=False)
+        pd.concat([pd.DataFrame(r) for r in self.result_list]).to_csv(path, index=False)
 
     @property
     def power_output(self):

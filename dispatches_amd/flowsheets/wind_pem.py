@@ -97,7 +97,9 @@ class MultiPeriodWindPEM:
         T = len(per)
         x = b.solution
         col = lambda key: np.array([x[p[key].index] for p in per])
-        df = pd.DataFrame({
+        # kept as a plain dict; the frames are built once in write_results (one pandas constructor per recorded
+        # scenario and call was most of the host time of an hourly real-time bid)
+        rec = {
             "Generator": self.model_data.gen_name,
             "Date": date,
             "Hour": hour,
@@ -110,11 +112,11 @@ class MultiPeriodWindPEM:
             "Hydrogen Sales [kg]": np.round(self._h2_kg_per_hr(col("pem_elec")), 2),
             "Total Cost [$]": np.round([b.value(b.tot_cost[t]) for t in range(T)], 2),
             **kwargs,                     # e.g. Scenario=, Market= (appended as the last columns, as the reference does)
-        })
-        self.result_list.append(df)
+        }
+        self.result_list.append(rec)
 
     def write_results(self, path):
-        pd.concat(self.result_list).to_csv(path, index=False)
+        pd.concat([pd.DataFrame(r) for r in self.result_list]).to_csv(path, index=False)
 
     @property
     def power_output(self):

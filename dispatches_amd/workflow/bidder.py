@@ -248,7 +248,8 @@ class StochasticProgramBidder(AbstractBidder):
     def write_results(self, path):
         print("")
         print("Saving bidding results to disk...")
-        pd.concat(self.bids_result_list).to_csv(os.path.join(path, "bidder_detail.csv"), index=False)
+        frames = [f() if callable(f) else f for f in self.bids_result_list]
+        pd.concat(frames).to_csv(os.path.join(path, "bidder_detail.csv"), index=False)
         self.bidding_model_object.write_results(path=os.path.join(path, "bidding_model_detail.csv"))
 
     @property
@@ -335,9 +336,11 @@ class Bidder(StochasticProgramBidder):
             pairs = np.asarray(bids[t][gen]["p_cost"], float).reshape(-1, 2)
             data[r, 0:2 * len(pairs):2] = pairs[:, 0]
             data[r, 1:2 * len(pairs):2] = pairs[:, 1]
-        cols = [f"{kind} {k} [{unit}]" for k in range(width) for kind, unit in (("Power", "MW"), ("Cost", "$"))]
-        head = pd.DataFrame({"Generator": [g for _, g in keys], "Date": date, "Hour": [t for t, _ in keys], **kwargs})
-        self.bids_result_list.append(pd.concat([head, pd.DataFrame(data, columns=cols)], axis=1))
+        def frame():                       # built once, in write_results
+            cols = [f"{kind} {k} [{unit}]" for k in range(width) for kind, unit in (("Power", "MW"), ("Cost", "$"))]
+            head = pd.DataFrame({"Generator": [g for _, g in keys], "Date": date, "Hour": [t for t, _ in keys], **kwargs})
+            return pd.concat([head, pd.DataFrame(data, columns=cols)], axis=1)
+        self.bids_result_list.append(frame)
 
 
 class SelfScheduler(StochasticProgramBidder):
@@ -381,4 +384,4 @@ class SelfScheduler(StochasticProgramBidder):
                 row["Bid Power [MW]"] = bids[t][gen].get("p_max")
                 row["Bid Min Power [MW]"] = bids[t][gen].get("p_min")
                 rows.append(row)
-        self.bids_result_list.append(pd.DataFrame(rows))
+        self.bids_result_list.append(lambda rows=rows: pd.DataFrame(rows))      # built once, in write_results

@@ -160,10 +160,11 @@ class Tracker:
                 "Power Underdelivered [MW]": round(self.model.power_underdelivered[t].value, 2),
                 "Power Overdelivered [MW]": round(self.model.power_overdelivered[t].value, 2),
             })
-        self.result_list.append(pd.DataFrame(rows))
+        self.result_list.append(rows)              # row dicts; the frame is built once in write_results
 
     def write_results(self, path):
         print("")
         print("Saving tracking results to disk...")
-        pd.concat(self.result_list).to_csv(os.path.join(path, "tracker_detail.csv"), index=False)
+        pd.DataFrame([row for rows in self.result_list for row in rows]).to_csv(
+            os.path.join(path, "tracker_detail.csv"), index=False)
         self.tracking_model_object.write_results(path=os.path.join(path, "tracking_model_detail.csv"))
