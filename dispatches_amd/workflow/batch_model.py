@@ -94,13 +94,16 @@ class ScenarioBatchModel:
         self.block.solution = self.x[0]
 
     def expression_values(self, family: str) -> np.ndarray:
-        """[B, T] values of an expression family (e.g. 'P_T') for every scenario at once."""
+        """[B, T] values of an expression family (e.g. 'P_T') for every scenario at once.  The expressions have two or
+        three terms each, so this is a gather over the few columns involved, not a dense [B, n] x [n, T] product."""
         fam = self.block.expressions[family]
         T = len(fam)
-        M = np.zeros((T, self.lp.n))
+        K = max(1, max(len(fam[t].coef) for t in range(T)))
+        cols = np.zeros((T, K), dtype=np.intp)
+        vals = np.zeros((T, K))
         k = np.zeros(T)
         for t in range(T):
-            for j, v in fam[t].coef.items():
-                M[t, j] = v
+            for e, (j, v) in enumerate(fam[t].coef.items()):
+                cols[t, e], vals[t, e] = j, v
             k[t] = fam[t].const
-        return self.x @ M.T + k
+        return (self.x[:, cols] * vals).sum(axis=2) + k
