@@ -849,7 +849,12 @@ __global__ void __launch_bounds__(512) spmv_step_kernel(SpmvArgs a) {
   X(7, 4, 0x1112333u, 0x2444u, false)    /* wind+battery 48 h */                                              \
   X(1, 1, 0x3u, 0x4u, false)             /* wind+battery real-time bids and tracking, 4 h */                  \
   X(1, 1, 0x4u, 0x3u, false)             /* wind+PEM real-time bids, 4 h */                                   \
-  X(2, 1, 0x12u, 0x4u, false)            /* nuclear real-time bids, 12 h */
+  X(2, 1, 0x12u, 0x4u, false)            /* nuclear real-time bids, 12 h */                                  \
+  X(2, 1, 0x13u, 0x4u, false)            /* wind+battery 12 h */                                              \
+  X(5, 3, 0x11333u, 0x344u, false)       /* wind+battery 36 h */                                              \
+  X(2, 2, 0x12u, 0x23u, true)            /* wind+PEM 24 h     */                                              \
+  X(3, 2, 0x122u, 0x33u, true)           /* wind+PEM 36 h     */                                              \
+  X(4, 2, 0x1122u, 0x34u, false)         /* nuclear 36 h      */
 
 // 0 = no specialisation, 1 = register-resident matrix
 int matreg_available(int cpl, int rpl, unsigned wc, unsigned wr, bool lng) {
