@@ -221,6 +221,10 @@ def main():
     torch.cuda.synchronize()
     trials = {}
     if len(candidates) > 1:
+        depth = max_depth                             # one launch per stream first: a stream's first launch creates its
+        for i in range(max_depth):                    # hardware queue (milliseconds) and would bias the trials below
+            step(i, False)
+        torch.cuda.synchronize()
         for cand in candidates:                       # untimed (warm-up phase): 2 * cand steps at each depth
             depth = cand
             torch.cuda.synchronize()
