@@ -232,6 +232,12 @@ def solve(P, eps=1e-9, max_iter=60000, check=32, wrule="pid", kp=0.7, maxdl=np.l
     return Xo, Yo, iters, nrs, done
 
 
+# The settings that mirror the kernel's defaults (include/dsp_hip.h): python tools/pdlp_lab.py wind_battery_24h gpu
+# Not mirrored here: the residual-gated KKT schedule (moves only the stopping time), the stall logic of
+# dsp_options::stall_rescue (use rescue_k / rescue_zone for its first stage) and the re-test delay after a too-short ray.
+GPU_DEFAULTS = dict(check=16, jump=1, jtol=3e-3, jsteady=0.05, jmin=4.0, jrel=3.0, term=1, eps_obj=1e-7, wfloor=4, kp=0.7)
+
+
 HARD = {"wind_battery_24h": [746, 1449, 2233, 2445, 2768], "wind_battery_48h": [527, 1216, 1847, 2636, 3147, 3562]}
 
 
@@ -246,7 +252,8 @@ if __name__ == "__main__":
     wl = sys.argv[1]
     ids, sub = subset(wl)
     ref = np.array([pp.highs_obj(sub, i)[0] for i in range(len(ids))])
-    variants = [dict(a.split("=") for a in v.split(",") if a) for v in sys.argv[2:]] or [{}]
+    variants = [dict(a.split("=") for a in v.split(",") if a and a != "gpu") if v != "gpu" else dict(GPU_DEFAULTS)
+                for v in sys.argv[2:]] or [{}]
     for kw in variants:
         kw = {k: (v if k in ("wrule", "r0_mode") else float(v)) for k, v in kw.items()}
         t = time.time()
