@@ -271,20 +271,23 @@ class LinearBlock:
         return LinExpr._as(expr).value(self.solution)
 
     # -- flattening ----------------------------------------------------------------------------------------
-    def _propagate_bounds(self):
-        """Implied column bounds from rows (bound propagation), trusting only immutable bounds / declared hulls."""
+    def _propagate_bounds(self, active):
+        """Implied column bounds from the rows flagged in `active` (bound propagation), starting from immutable bounds /
+        declared hulls only.  Mutable columns are never tightened."""
         lb = np.array([h[0] for h in self.col_hull])
         ub = np.array([h[1] for h in self.col_hull])
+        rows = [(list(self.row_expr[i].items()), self.row_lo[i], self.row_hi[i])
+                for i in range(len(self.row_expr)) if active[i] and not self.row_mutable[i]]
         for _ in range(3):
-            for r, lo, hi in zip(self.row_expr, self.row_lo, self.row_hi):
-                items = list(r.items())
+            for items, lo, hi in rows:
                 mins = [(a * lb[j] if a > 0 else a * ub[j]) for j, a in items]
                 maxs = [(a * ub[j] if a > 0 else a * lb[j]) for j, a in items]
+                smin, smax = sum(mins), sum(maxs)
                 for k, (j, a) in enumerate(items):
                     if self.col_mutable[j]:
                         continue
                     if np.isfinite(hi):
-                        rest = sum(mins[:k]) + sum(mins[k + 1:])
+                        rest = smin - mins[k] if np.isfinite(mins[k]) else sum(mins[:k]) + sum(mins[k + 1:])
                         if np.isfinite(rest):
                             b = (hi - rest) / a
                             if a > 0:
@@ -292,7 +295,7 @@ class LinearBlock:
                             else:
                                 lb[j] = max(lb[j], b)
                     if np.isfinite(lo):
-                        rest = sum(maxs[:k]) + sum(maxs[k + 1:])
+                        rest = smax - maxs[k] if np.isfinite(maxs[k]) else sum(maxs[:k]) + sum(maxs[k + 1:])
                         if np.isfinite(rest):
                             b = (lo - rest) / a
                             if a > 0:
@@ -301,19 +304,36 @@ class LinearBlock:
                                 ub[j] = min(ub[j], b)
         return lb, ub
 
+    def _row_range(self, i, lb, ub):
+        r = self.row_expr[i]
+        amin = sum((a * lb[j] if a > 0 else a * ub[j]) for j, a in r.items())
+        amax = sum((a * ub[j] if a > 0 else a * lb[j]) for j, a in r.items())
+        return amin, amax
+
+    def _never_binds(self, i, lb, ub):
+        lo, hi = self.row_lo[i], self.row_hi[i]
+        if self.row_mutable[i] or lo == hi:
+            return False
+        amin, amax = self._row_range(i, lb, ub)
+        tol = 1e-9 * max(1.0, abs(lo) if np.isfinite(lo) else 0.0, abs(hi) if np.isfinite(hi) else 0.0)
+        return amin >= lo - tol and amax <= hi + tol
+
     def flatten(self, objective: Optional[LinExpr] = None, presolve: bool = True) -> StandardFormLP:
+        """Presolve drops a row only when the column bounds implied by the declared hulls and by the OTHER rows that
+        stay in the LP prove it can never bind.  (A row must not certify its own redundancy: bounds propagated from row
+        R are never written into the LP's column bounds, so testing R against them would drop e.g. the singleton row
+        x <= 5 and leave x unbounded.)  Candidates are found with one propagation over all rows and then confirmed
+        one at a time against the rows still kept, so two rows can never vouch for each other either."""
         n, m_all = len(self.col_names), len(self.row_names)
         keep = np.ones(m_all, bool)
         if presolve and m_all:
-            lb, ub = self._propagate_bounds()
-            for i, (r, lo, hi) in enumerate(zip(self.row_expr, self.row_lo, self.row_hi)):
-                amin = sum((a * lb[j] if a > 0 else a * ub[j]) for j, a in r.items())
-                amax = sum((a * ub[j] if a > 0 else a * lb[j]) for j, a in r.items())
-                tol = 1e-9 * max(1.0, abs(lo) if np.isfinite(lo) else 0.0, abs(hi) if np.isfinite(hi) else 0.0)
-                if self.row_mutable[i]:
-                    continue
-                if amin >= lo - tol and amax <= hi + tol and not (lo == hi):
-                    keep[i] = False
+            lb, ub = self._propagate_bounds(keep)
+            candidates = [i for i in range(m_all) if self._never_binds(i, lb, ub)]
+            for i in candidates:
+                keep[i] = False
+                lb, ub = self._propagate_bounds(keep)
+                if not self._never_binds(i, lb, ub):
+                    keep[i] = True
         self._kept_rows = np.nonzero(keep)[0]
         indptr, indices, data = [0], [], []
         for i in self._kept_rows:

@@ -99,8 +99,12 @@ class AbstractBidder(ABC):
 
 class StochasticProgramBidder(AbstractBidder):
     def __init__(self, bidding_model_object, day_ahead_horizon, real_time_horizon, n_scenario, solver, forecaster,
-                 real_time_underbid_penalty=10000):
+                 real_time_underbid_penalty=10000, strict=False):
         self.bidding_model_object = bidding_model_object
+        # strict: raise if ANY scenario fails to reach optimality; otherwise failed scenarios are left out of the bids
+        # (and listed in `failed_scenarios`), and only a solve without a single optimal scenario raises
+        self.strict = bool(strict)
+        self.failed_scenarios = {}
         self.day_ahead_horizon = day_ahead_horizon
         self.real_time_horizon = real_time_horizon
         self.n_scenario = n_scenario
@@ -195,7 +199,9 @@ class StochasticProgramBidder(AbstractBidder):
             if v.lb != 0.0 or np.isfinite(v.ub):
                 model.block.set_bounds(v, 0.0, np.inf)
         self._pass_price_forecasts(model, da, rt)
+        self._check_scenario_coupling(da, rt)
         self.solver.solve(model, tee=False)
+        self._check_solution(model, "Day-ahead", date, hour)
         bids = self._assemble_bids(model, da, hour, market="Day-ahead")
         self.record_bids(bids, model=model, date=date, hour=hour, market="Day-ahead")
         return bids
@@ -220,10 +226,33 @@ class StochasticProgramBidder(AbstractBidder):
             else:
                 model.block.set_bounds(v, 0.0, np.inf)
         self._pass_price_forecasts(model, da, rt)
+        self._check_scenario_coupling(da, rt)
         self.solver.solve(model, tee=False)
+        self._check_solution(model, "Real-time", date, hour)
         bids = self._assemble_bids(model, rt, hour, market="Real-time")
         self.record_bids(bids, model=model, date=date, hour=hour, market="Real-time")
         return bids
+
+    # -- solution checks -----------------------------------------------------------------------------------
+    def _check_scenario_coupling(self, da, rt):
+        """Hook for bidders whose upstream formulation couples the scenarios (see SelfScheduler)."""
+
+    def _check_solution(self, model, market, date, hour):
+        """Never turn an unconverged / invalid scenario into a bid: the solver reports ITERATION_LIMIT, and NaN x for the
+        invalid-input statuses (include/dsp_hip.h).  `model.ok` is the mask the bid assembly uses."""
+        status = np.asarray(model.status)
+        ok = status == 0
+        model.ok = ok
+        if ok.all():
+            return
+        bad = np.nonzero(~ok)[0]
+        self.failed_scenarios[(str(date), hour, market)] = {int(i): int(status[i]) for i in bad}
+        msg = (f"{market} bidding problem of {self.generator} ({date}, hour {hour}): {len(bad)} of {len(status)} scenarios "
+               f"did not reach optimality (scenario: status) {dict(list(self.failed_scenarios[(str(date), hour, market)].items())[:8])}")
+        if self.strict or not ok.any():
+            raise RuntimeError(msg)
+        import warnings
+        warnings.warn(msg + "; they are left out of the bids", RuntimeWarning, stacklevel=3)
 
     # -- rolling-horizon state -----------------------------------------------------------------------------
     def _update_model(self, model, **kwargs):
@@ -292,6 +321,11 @@ class Bidder(StochasticProgramBidder):
         # per pair), then grouped per hour with numpy: one pass over B*T numbers instead of B*T dict updates
         T = len(model.HOUR)
         B = model.n_scenario
+        ok = getattr(model, "ok", None)
+        if ok is not None and not ok.all():                # scenarios that failed to solve offer nothing
+            power = np.asarray(power, float)[ok]
+            energy_prices = np.asarray(energy_prices, float)[ok]
+            B = int(ok.sum())
         p2 = round_decimal(np.asarray(power[:, :T], float), 2).reshape(B, T)
         c2 = round_decimal(np.asarray(energy_prices[:, :T], float), 2).reshape(B, T)
         default = [(round(p, 2), float(mc)) for p, mc in md.p_cost] \
@@ -347,10 +381,21 @@ class SelfScheduler(StochasticProgramBidder):
     """Self-schedule bidder: p_max[t] = round(scheduled power, 4) (pinned by SURVEY.md A.7 G1)."""
 
     def __init__(self, bidding_model_object, day_ahead_horizon, real_time_horizon, n_scenario, solver, forecaster,
-                 real_time_underbid_penalty=10000, fixed_to_schedule=False):
+                 real_time_underbid_penalty=10000, fixed_to_schedule=False, strict=True):
         self.fixed_to_schedule = fixed_to_schedule
         super().__init__(bidding_model_object, day_ahead_horizon, real_time_horizon, n_scenario, solver, forecaster,
-                         real_time_underbid_penalty)
+                         real_time_underbid_penalty, strict=strict)
+
+    def _check_scenario_coupling(self, da, rt):
+        """Upstream couples the scenarios of a self-schedule by non-anticipativity rows (one day-ahead schedule for all
+        price scenarios).  With identical scenarios (a one-day Backcaster history: every reference golden and notebook
+        log) those rows are vacuous and scenario 0's LP IS the stochastic program; with different scenarios the
+        independent LPs solved here are not, so refuse instead of silently returning scenario 0's schedule."""
+        if self.n_scenario > 1 and not (np.all(da == da[0]) and np.all(rt == rt[0])):
+            raise NotImplementedError(
+                "SelfScheduler with n_scenario > 1 and DIFFERENT price scenarios needs the upstream non-anticipativity "
+                "coupling (day_ahead_power equal across scenarios), which the batched independent-scenario solve does "
+                "not impose; use n_scenario=1, identical scenarios, or the Bidder (independent bid curves)")
 
     def _assemble_bids(self, model, energy_prices, hour, market):
         md = self.bidding_model_object.model_data

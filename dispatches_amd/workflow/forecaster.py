@@ -35,6 +35,9 @@ class Backcaster(AbstractPrescientPriceForecaster):
         self.max_historical_days = int(max_historical_days)
         self._historical_da_prices = self._validate(historical_da_prices)
         self._historical_rt_prices = self._validate(historical_rt_prices)
+        # RT LMPs of the day in progress, per bus: they join the history only as a WHOLE day (the forecast indexes the
+        # history as 24 * day + hour, so a partial day would shift every stored day by the hours appended so far)
+        self._current_day_rt_prices = {bus: [] for bus in self._historical_rt_prices}
 
     def _validate(self, prices):
         if not isinstance(prices, dict):
@@ -84,10 +87,16 @@ class Backcaster(AbstractPrescientPriceForecaster):
         store[bus] = (store[bus] + [float(v) for v in values])[-24 * self.max_historical_days:]
 
     def fetch_hourly_stats_from_prescient(self, prescient_hourly_stats):
-        """Append the hour's RT LMPs (Prescient hourly stats expose `observed_bus_LMPs`)."""
+        """Collect the hour's RT LMPs (Prescient hourly stats expose `observed_bus_LMPs`) in the current-day buffer; the
+        buffer is rolled into the history (dropping the oldest stored day at the cap) once it holds 24 values, as the
+        upstream Backcaster does."""
         for bus in self._historical_rt_prices:
             lmp = prescient_hourly_stats.observed_bus_LMPs[bus]
-            self._append(self._historical_rt_prices, bus, [lmp])
+            day = self._current_day_rt_prices.setdefault(bus, [])
+            day.append(float(lmp))
+            if len(day) >= 24:
+                self._append(self._historical_rt_prices, bus, day[:24])
+                self._current_day_rt_prices[bus] = day[24:]
 
     def fetch_day_ahead_stats_from_prescient(self, uc_date, uc_hour, day_ahead_result):
         """Append the cleared day's 24 DA LMPs (Prescient RUC market exposes `day_ahead_prices[(bus, t)]`)."""

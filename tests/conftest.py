@@ -14,6 +14,19 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` on the GPU box)")
 
 
+def pytest_runtest_setup(item):
+    """`gpu` tests on a box without any AMD GPU device node (a CPU CI box): skip.  On a GPU box (/dev/kfd present, or
+    DSP_REQUIRE_GPU=1) a GPU that torch cannot see is a FAILURE, never a silent skip: the product has no CPU path."""
+    if item.get_closest_marker("gpu") is None:
+        return
+    import torch
+    if torch.cuda.is_available():
+        return
+    if os.path.exists("/dev/kfd") or os.environ.get("DSP_REQUIRE_GPU") == "1":
+        pytest.fail("GPU test selected on a GPU box but no GPU is visible to torch")
+    pytest.skip("needs an MI355X (no /dev/kfd on this box)")
+
+
 @pytest.fixture(scope="session", autouse=True)
 def _built_library():
     """libdsp_hip.so is git-ignored: (re)build it in-tree when it is missing or older than its sources, so that both

@@ -15,18 +15,45 @@ from dispatches_amd.workflow import (Backcaster, Bidder, DoubleLoopCoordinator, 
 from tests.test_workflow_cpu import generator_params, thermal_params
 
 
+# The registration methods of prescient.plugins.plugin_registration.PluginRegistrationContext (gridx-prescient 2.2:
+# every `register_*_callback` the plugin API offers; SURVEY.md App. B, reference coordinator.py:29-40 uses three of
+# them by name).  Anything else is a misspelt hook and must fail here as it would inside Prescient.
+PRESCIENT_CALLBACK_HOOKS = (
+    "options_preview", "initialization", "finalization",
+    "after_get_initial_actuals_model_for_sced", "after_get_initial_actuals_model_for_simulation_actuals",
+    "after_get_initial_forecast_model_for_ruc", "after_get_initial_forecast_model_for_simulation_actuals",
+    "after_ruc_generation", "after_ruc_activation", "before_ruc_solve", "before_operations_solve",
+    "after_operations", "update_operations_stats",
+)
+
+
 class _StubContext:
-    """Collects whatever the coordinator registers, like prescient.plugins.PluginRegistrationContext."""
+    """Collects what the coordinator registers, like prescient.plugins.PluginRegistrationContext: ONLY the hook names
+    Prescient really has exist as methods; an unknown `register_*_callback` raises AttributeError."""
 
     def __init__(self):
         self.callbacks = {}
 
     def __getattr__(self, name):
         if name.startswith("register_") and name.endswith("_callback"):
-            def reg(fn, _name=name[len("register_"):-len("_callback")]):
-                self.callbacks.setdefault(_name, []).append(fn)
-            return reg
-        raise AttributeError(name)
+            hook = name[len("register_"):-len("_callback")]
+            if hook in PRESCIENT_CALLBACK_HOOKS:
+                def reg(fn, _name=hook):
+                    if not callable(fn):
+                        raise TypeError(f"{name} needs a callable")
+                    self.callbacks.setdefault(_name, []).append(fn)
+                return reg
+        raise AttributeError(f"PluginRegistrationContext has no attribute {name!r}")
+
+
+def test_stub_context_rejects_unknown_hooks():
+    ctx = _StubContext()
+    with pytest.raises(AttributeError):
+        ctx.register_before_ruc_solv_callback(lambda: None)
+    with pytest.raises(AttributeError):
+        ctx.register_after_sced_callback(lambda: None)
+    ctx.register_before_ruc_solve_callback(lambda: None)
+    assert list(ctx.callbacks) == ["before_ruc_solve"]
 
 
 def _instance(gen):
@@ -51,8 +78,10 @@ def _run_double_loop(solver_factory, tmp_path, rts309, thermal=True):
     plugin.register_plugins(ctx, options=None, plugin_config=SimpleNamespace(bidding_generator=md.gen_name))
     for name in ("initialization", "before_ruc_solve", "before_operations_solve", "after_operations",
                  "update_operations_stats", "after_ruc_activation", "after_ruc_generation", "finalization",
-                 "after_get_initial_actuals_model_for_sced", "after_get_initial_forecast_model_for_ruc"):
+                 "after_get_initial_actuals_model_for_sced", "after_get_initial_forecast_model_for_ruc",
+                 "after_get_initial_actuals_model_for_simulation_actuals"):
         assert name in ctx.callbacks, name
+    assert set(ctx.callbacks) <= set(PRESCIENT_CALLBACK_HOOKS)
 
     gen = md.gen_name
     options = SimpleNamespace(output_directory=str(tmp_path))

@@ -113,3 +113,34 @@ def test_period_shift_maps_for_rolling_warm_start():
                     assert mp[k] == k
             assert moved > 0
     assert period_shift_maps(lp, 1) is period_shift_maps(lp, 1)            # cached on the LP
+
+
+def test_presolve_never_lets_a_row_certify_itself():
+    """Round-1 advisor repros: bounds propagated from a row are not written into the LP, so that row (or a row that
+    depends on it) must survive presolve."""
+    import numpy as np
+    from dispatches_amd.lp import LinearBlock
+    # 1: singleton row x <= 5 is the only upper bound of x
+    b = LinearBlock()
+    x = b.var("x", 0.0, np.inf)
+    b.constraint("cap", x, -np.inf, 5.0)
+    lp = b.flatten(x * -1.0)
+    assert lp.m == 1 and lp.rhi[0] == 5.0
+    # 2: x + y <= 10 with y fixed at 3
+    b = LinearBlock()
+    x, y = b.var("x", 0.0, np.inf), b.var("y", 3.0, 3.0)
+    b.constraint("sum", x + y, -np.inf, 10.0)
+    assert b.flatten(x * -1.0).m == 1
+    # 3: x - y <= 0 together with y <= 5: neither row may vouch for the other
+    b = LinearBlock()
+    x, y = b.var("x", 0.0, np.inf), b.var("y", 0.0, np.inf)
+    b.constraint("link", x - y, -np.inf, 0.0)
+    b.constraint("cap", y, -np.inf, 5.0)
+    assert b.flatten(x * -1.0).m == 2
+    # a row that other rows + hulls really make redundant is still dropped (the 1e8 battery ramp rows)
+    b = LinearBlock()
+    s0, s1 = b.var("s0", 0.0, 100.0), b.var("s1", 0.0, np.inf)
+    b.constraint("cap", s1, -np.inf, 100.0)
+    b.constraint("ramp", s1 - s0, -1e8, 1e8)
+    lp = b.flatten(s1 * 1.0)
+    assert lp.row_names == ["cap"]

@@ -177,3 +177,83 @@ def test_round_decimal_is_pythons_round():
         ref = np.array([round(v, nd) for v in a.tolist()])
         assert (round_decimal(a, nd) == ref).all()
     assert (np.round(a, 2) != np.array([round(v, 2) for v in a.tolist()])).any()      # the reason this helper exists
+
+
+def test_backcaster_keeps_day_alignment_when_hourly_prices_arrive_at_the_cap():
+    """Round-1 advisor repro: with the history at its cap, hourly RT appends must not shift the stored days.  Prices
+    encode the hour of day, so any drift shows up directly."""
+    from types import SimpleNamespace
+    days = 3
+    hist = [float(h) for _ in range(days) for h in range(24)]
+    bc = Backcaster({"b": list(hist)}, {"b": list(hist)}, max_historical_days=days)
+    for h in range(5):                      # five hours of the next day arrive
+        bc.fetch_hourly_stats_from_prescient(SimpleNamespace(observed_bus_LMPs={"b": 100.0 + h}))
+        got = bc.forecast_real_time_prices("2020-01-02", 5, "b", 4, 2)
+        assert got[0] == [5.0, 6.0, 7.0, 8.0] and got[1] == [5.0, 6.0, 7.0, 8.0]
+    assert len(bc.historical_rt_prices["b"]) == 24 * days
+    for h in range(5, 24):                  # the day completes: it becomes the most recent stored day
+        bc.fetch_hourly_stats_from_prescient(SimpleNamespace(observed_bus_LMPs={"b": 100.0 + h}))
+    assert len(bc.historical_rt_prices["b"]) == 24 * days
+    got = bc.forecast_real_time_prices("2020-01-03", 5, "b", 4, 2)
+    assert got[0] == [105.0, 106.0, 107.0, 108.0] and got[1] == [5.0, 6.0, 7.0, 8.0]
+
+
+class _FailingSolver(HighsTestSolver):
+    """HiGHS stand-in that reports chosen scenarios as unconverged (status 1) with NaN solutions."""
+
+    def __init__(self, bad):
+        self.bad = list(bad)
+
+    def solve(self, model, tee=False):
+        res = super().solve(model, tee)
+        st = np.zeros(model.n_scenario, np.int32)
+        st[self.bad] = 1
+        x = model.x.copy()
+        x[self.bad] = np.nan
+        model.store_solution(x, model.y, model.objective, st)
+        return res
+
+
+def _thermal_bidder(rts309, solver, n_scenario, cls=Bidder, history_days=1, **kw):
+    h = 24 * history_days      # a one-day Backcaster history yields identical scenarios (as in the reference notebooks)
+    fc = Backcaster({bus_name: rts309["da_lmp"][:h].tolist()}, {bus_name: rts309["rt_lmp"][:h].tolist()})
+    mp = MultiPeriodWindBattery(model_data=ThermalGeneratorModelData(**thermal_params()),
+                                wind_capacity_factors=rts309["rt_cf"], wind_pmax_mw=200,
+                                battery_pmax_mw=25, battery_energy_capacity_mwh=100)
+    return cls(bidding_model_object=mp, day_ahead_horizon=24, real_time_horizon=4, n_scenario=n_scenario,
+               solver=solver, forecaster=fc, **kw)
+
+
+def test_unconverged_scenarios_never_become_bids(rts309):
+    """Round-1 advisor finding: solver status was ignored.  A failed scenario is left out of the bid curves (warning),
+    strict=True raises, a batch without a single optimal scenario raises, and the Tracker always raises."""
+    good = _thermal_bidder(rts309, HighsTestSolver(), 2).compute_day_ahead_bids(date="2020-01-02")
+    bidder = _thermal_bidder(rts309, _FailingSolver([1]), 2)
+    with pytest.warns(RuntimeWarning, match="did not reach optimality"):
+        bids = bidder.compute_day_ahead_bids(date="2020-01-02")
+    assert bidder.failed_scenarios[("2020-01-02", 0, "Day-ahead")] == {1: 1}
+    for t in bids:            # the two backcast scenarios are identical, so dropping one changes nothing - and no NaN
+        assert bids[t]["309_WIND_1"]["p_cost"] == good[t]["309_WIND_1"]["p_cost"]
+        assert np.isfinite(np.asarray(bids[t]["309_WIND_1"]["p_cost"])).all()
+    with pytest.raises(RuntimeError, match="did not reach optimality"):
+        _thermal_bidder(rts309, _FailingSolver([1]), 2, strict=True).compute_day_ahead_bids(date="2020-01-02")
+    with pytest.raises(RuntimeError, match="did not reach optimality"):
+        _thermal_bidder(rts309, _FailingSolver([0, 1]), 2).compute_day_ahead_bids(date="2020-01-02")
+    mp = MultiPeriodWindBattery(model_data=RenewableGeneratorModelData(**generator_params),
+                                wind_capacity_factors=rts309["rt_cf"], wind_pmax_mw=pmax,
+                                battery_pmax_mw=25, battery_energy_capacity_mwh=100)
+    tracker = Tracker(tracking_model_object=mp, tracking_horizon=4, n_tracking_hour=1, solver=_FailingSolver([0]))
+    with pytest.raises(RuntimeError, match="did not reach optimality"):
+        tracker.track_market_dispatch(market_dispatch=[0, 1.5, 15, 24.5], date="2020-01-02", hour="00:00")
+
+
+def test_self_scheduler_refuses_uncoupled_different_scenarios(rts309):
+    """Upstream couples a self-schedule's scenarios (non-anticipativity).  Identical scenarios (every reference golden)
+    are fine; different ones must not silently return scenario 0's schedule."""
+    ident = _thermal_bidder(rts309, HighsTestSolver(), 3, cls=SelfScheduler)
+    bids = ident.compute_day_ahead_bids(date="2020-01-02")          # one stored day -> 3 identical scenarios
+    assert len(bids) == 24
+    diff = _thermal_bidder(rts309, HighsTestSolver(), 2, cls=SelfScheduler, history_days=2)
+    # horizon 24 from a 2-day history: scenario 0 = day 2, scenario 1 = day 1 -> different prices
+    with pytest.raises(NotImplementedError, match="non-anticipativity"):
+        diff.compute_day_ahead_bids(date="2020-01-02")
