@@ -28,25 +28,33 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec (MI355X_MICROARCH.md); 6.29 TB/s measured copy ceiling
 
 
-def _profiled_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the newest committed rocprofv3 PMC summary (profiles/rNN*_pmc_summary.csv:
-    separate --pmc FETCH_SIZE / WRITE_SIZE passes of this same bench command; FETCH_SIZE doubled per the gfx950
-    correction of MI355X_MICROARCH.md, both counters are in KB).  None if no profile is committed."""
+SIMDS = 256 * 4           # MI355X: 256 CUs x 4 SIMDs
+PEAK_CLOCK_HZ = 2.4e9     # max shader clock (MI355X_MICROARCH.md)
+FP64_VECTOR_PEAK_TFLOPS = 78.6   # 1/2 of the 157.3 TF FP32 vector peak
+
+
+def _profiled_counters(kernel):
+    """Mean per-launch PMC counters of `kernel` from the newest committed rocprofv3 summary (profiles/rNN*_pmc_summary.csv:
+    separate --pmc passes of this same bench command, tools/gpu_profile.sh).  {} if no profile is committed."""
     import csv
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.csv")))
     if not files:
-        return None
-    fetch = write = None
+        return {}, None
+    out = {}
     for row in csv.DictReader(open(files[-1])):
         if kernel in row["kernel"]:
-            if row["counter"] == "FETCH_SIZE":
-                fetch = float(row["mean_counter_value"] if "mean_counter_value" in row else row["mean_counter_value_KB"])
-            if row["counter"] == "WRITE_SIZE":
-                write = float(row["mean_counter_value"] if "mean_counter_value" in row else row["mean_counter_value_KB"])
-    if fetch is None or write is None:
+            out[row["counter"]] = float(row["mean_counter_value"])
+    return out, os.path.basename(files[-1])
+
+
+def _profiled_traffic(kernel):
+    """HBM bytes per launch of `kernel` from that summary: FETCH_SIZE doubled per the gfx950 correction of
+    MI355X_MICROARCH.md (both counters are in KB).  None if no profile is committed."""
+    c, _ = _profiled_counters(kernel)
+    if "FETCH_SIZE" not in c or "WRITE_SIZE" not in c:
         return None
-    return (2.0 * fetch + write) * 1024.0
+    return (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0
 
 
 _NUCLEAR_PRICES = {}
@@ -124,6 +132,10 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=-1, help="scenarios for the CPU baseline (0 = skip)")
     ap.add_argument("--streams", type=int, default=0,
                     help="HIP streams the steps are pipelined over (0 = choose among 8/12/16/24 during the warm-up)")
+    ap.add_argument("--total", type=int, default=0,
+                    help="STRONG scaling: this many scenarios in total, sharded over the ranks through "
+                         "dispatches_amd.distributed.solve_sharded_device (e.g. --total 8192 --workload wind_battery_48h = "
+                         "BASELINE config 4: 1024 per GPU on 8 GPUs); 0 = weak scaling with --batch scenarios per GPU")
     ap.add_argument("--no-spmv", action="store_true", help="skip the streaming SpMV-step roofline measurement")
     ap.add_argument("--spmv-large-mult", type=int, default=32,
                     help="also time spmv_step on a batch this many times larger (0 = skip; the PMC passes skip it so "
@@ -153,13 +165,23 @@ def main():
     from dispatches_amd import scenarios
     from dispatches_amd.hip_solver import DeviceLP, HipPdlpSolver, default_options
 
-    B = args.batch
+    from dispatches_amd.distributed import shard_bounds
     solver = HipPdlpSolver(device=local_rank, eps_rel=args.eps)
-    # rank r owns scenarios [r*B, (r+1)*B): build the full id range lazily through the stride-based windows
     fn, kw = scenarios.WORKLOADS[args.workload]
-    bidder, model = fn(B=B * world, solver=solver, **kw)
+    if args.total > 0:
+        # strong scaling: the SAME total batch at every N, rank r owns the contiguous shard shard_bounds(total, N, r)
+        n_total = args.total
+        lo_s, hi_s = shard_bounds(n_total, world, rank)
+    else:
+        # weak scaling: rank r owns scenarios [r*B, (r+1)*B) of a batch that grows with N
+        n_total = args.batch * world
+        lo_s, hi_s = rank * args.batch, (rank + 1) * args.batch
+    B = hi_s - lo_s
+    B_max = max(shard_bounds(n_total, world, r)[1] - shard_bounds(n_total, world, r)[0] for r in range(world)) \
+        if args.total > 0 else B
+    bidder, model = fn(B=n_total, solver=solver, **kw)
     scenarios.load_prices(bidder, model)
-    sl = slice(rank * B, (rank + 1) * B)
+    sl = slice(lo_s, hi_s)
     lp = model.lp
     lb, ub, rlo, rhi = model.scenario_bounds()
     up = lambda a: torch.as_tensor(np.ascontiguousarray(a, np.float64)).to(dev)
@@ -188,8 +210,11 @@ def main():
     max_depth = max(candidates)
     streams = [torch.cuda.Stream(device=dev) for _ in range(max_depth)]
     outs = [new_out() for _ in range(max_depth)]
-    gathered = [torch.empty(B * world, dtype=torch.float64, device=dev) if world > 1 else None
-                for _ in range(max_depth)]
+    # the ONE collective of a step: all-gather of the converged objectives and statuses straight from the solver's
+    # device outputs (dispatches_amd.distributed.gather_device_results: RCCL over xGMI, no host hop); ragged shards
+    # are padded to the largest shard
+    from dispatches_amd.distributed import gather_device_results, make_gather_buffers
+    gathered = [make_gather_buffers(world, B_max, dev, width=2) if world > 1 else None for _ in range(max_depth)]
     out = outs[0]
     depth = candidates[0]
 
@@ -214,7 +239,7 @@ def main():
             dlp.solve(B, c_d, lb_d, ub_d, rlo_d, rhi_d, options=opts, out=outs[k], sync_stats=False, obj_offset=c0_d)
             e1.record()
             if world > 1:
-                dist.all_gather_into_tensor(gathered[k], outs[k]["obj"])
+                gather_device_results(outs[k], gathered[k], B_max)
         if record:
             events.append((e0, e1))
 
@@ -261,40 +286,72 @@ def main():
         dist.all_reduce(n_opt)
 
     if rank == 0:
-        total = B * world * args.steps
+        total = n_total * args.steps
         value = total / elapsed
-        # ---- roofline of the dominant kernel (the fused solve): algorithmic bytes of SURVEY.md 8(d) ---------
+        # ---- roofline of the dominant kernel (the fused solve) ---------------------------------------------------
+        # The fused kernel keeps x / y / A in registers and LDS, so HBM is NOT what bounds it (SURVEY.md 8(d) asks for
+        # "effective bandwidth + the true limiter" in that case).  The limiters are FP64 VALU issue and the LDS pipe:
+        #   VALU: SQ_INSTS_VALU wave-instructions per launch x 4 clk (an FP64 wave64 op occupies its SIMD for 4 cycles)
+        #         / (1024 SIMDs x step time x clock)
+        #   LDS : SQ_LDS_IDX_ACTIVE (LDS-array cycles per launch, summed over CUs) / (256 CUs x step time x clock)
+        # Instruction / cycle counts per launch are deterministic for a given build + batch and come from the newest
+        # committed rocprofv3 PMC summary of this same command (tools/gpu_profile.sh); the step time is measured live
+        # here (whole timed region / steps, launches of different streams overlap, so this is the sustained rate).
+        # Fractions are quoted at the 2.4 GHz peak clock, i.e. they are LOWER bounds of the busy fraction at the
+        # clock the kernel really sustains.
         w = 8
-        bytes_iter = 2 * w * (lp.n + lp.m)                                   # per scenario-iteration
+        bytes_iter = 2 * w * (lp.n + lp.m)                                   # SURVEY 8(d): per scenario-iteration
         bytes_shared = 2 * (lp.nnz * (w + 4) + 4 * (lp.m + 1))
+        step_s = elapsed / args.steps
         k_ms = float(np.mean(kernel_ms))
         alg_bytes = float(np.mean(sum_iters)) * bytes_iter + bytes_shared + B * w * (3 * lp.n + 2 * lp.m + 1)
-        achieved = alg_bytes / (k_ms * 1e-3) / 1e9
-        agg = alg_bytes * args.steps / elapsed / 1e9
-        roofline = dict(bound="hbm", kernel="pdlp_solve_kernel", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
-                        frac=achieved / HBM_PEAK_GBS, traffic=_profiled_traffic("pdlp_solve_kernel"), kernel_ms=k_ms,
-                        algorithmic_bytes_per_launch=alg_bytes, achieved_aggregate=agg,
-                        frac_aggregate=agg / HBM_PEAK_GBS,
-                        note="achieved = algorithmic bytes of one launch / mean HIP-event duration of a launch on its "
-                             "stream (launches of different streams overlap, so this is per-launch latency based); "
-                             "achieved_aggregate = bytes of all timed launches / wall time.  "
-                             "fused LDS-resident solve: x/y/A never leave the CU between iterations, so the "
-                             "algorithmic SpMV bytes are served from LDS/registers and this is an EFFECTIVE "
-                             "bandwidth (true limiter: LDS issue + FP64 VALU); the HBM-streaming form of the same "
-                             "step is reported under spmv_step")
+        # true per-launch I/O of the fused kernel: inputs that vary per scenario + outputs (x, y, obj, status, iters, jumps)
+        true_io = (sum(t.numel() for t in (c_d, lb_d, ub_d, rlo_d, rhi_d) if t.dim() == 2) * w
+                   + B * w * (lp.n + lp.m + 1) + B * 12)
+        pmc, pmc_file = _profiled_counters("pdlp_solve_kernel")
+        traffic = _profiled_traffic("pdlp_solve_kernel")
+        valu_frac = lds_frac = valu_rate = None
+        if "SQ_INSTS_VALU" in pmc:
+            valu_rate = pmc["SQ_INSTS_VALU"] / step_s                         # wave-instructions / s, sustained
+            valu_frac = pmc["SQ_INSTS_VALU"] * 4.0 / (SIMDS * step_s * PEAK_CLOCK_HZ)
+        if "SQ_LDS_IDX_ACTIVE" in pmc:
+            lds_frac = pmc["SQ_LDS_IDX_ACTIVE"] / (256 * step_s * PEAK_CLOCK_HZ)
+        flops = 4.0 * lp.nnz * float(np.mean(sum_iters)) / step_s / 1e12      # SURVEY 8(d) flop unit: 4 nnz per scenario-iteration
+        roofline = dict(
+            bound="valu+lds", kernel="pdlp_solve_kernel",
+            achieved=(valu_rate / 1e9) if valu_rate else None, peak=SIMDS * PEAK_CLOCK_HZ / 4.0 / 1e9,
+            unit="G FP64-wave-instr/s", frac=valu_frac, frac_lds=lds_frac,
+            traffic=traffic, true_io_bytes_per_launch=true_io,
+            traffic_over_true_io=(traffic / true_io) if traffic else None,
+            counters_from=pmc_file, step_ms=1e3 * step_s, kernel_latency_ms=k_ms,
+            spmv_flops=dict(achieved=flops, peak=FP64_VECTOR_PEAK_TFLOPS, unit="TFLOP/s", frac=flops / FP64_VECTOR_PEAK_TFLOPS,
+                            note="4 nnz flop per scenario-iteration (SURVEY 8(d)); the SpMV FMAs are 16 of the ~52 FP64 "
+                                 "ops of an iteration, the rest is the PDHG update / Halpern step on the same registers"),
+            effective_hbm=dict(achieved=alg_bytes / step_s / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
+                               frac=alg_bytes / step_s / 1e9 / HBM_PEAK_GBS, algorithmic_bytes_per_launch=alg_bytes,
+                               note="SURVEY 8(d) algorithmic SpMV bytes / sustained step time: an EFFECTIVE bandwidth (may "
+                                    "exceed the HBM peak) - these bytes are served from VGPRs / LDS and never reach HBM; the "
+                                    "HBM-streaming form of the same step is reported under spmv_step"),
+            note="fused register/LDS-resident solve: limiter = FP64 VALU issue + LDS pipe (frac / frac_lds, from the "
+                 "committed SQ counters of this command and the step time measured here, at the 2.4 GHz peak clock); "
+                 "traffic = FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE per launch from the same profile; kernel_latency_ms "
+                 "= mean HIP-event duration of one launch on its stream (launches overlap, so it exceeds step_ms)")
         result = {
             "metric": "LP scenarios solved/sec, RTS-GMLC 24h multi-period dispatch, batch=4096" if (
                 args.workload == "wind_battery_24h" and B == 4096) else
                 f"LP scenarios solved/sec, {args.workload}, batch={B}",
             "value": value, "unit": "scenarios/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+            "scaling": "strong" if args.total > 0 else "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"{args.workload}: {B} scenarios/GPU x {len(model.HOUR)} h day-ahead bidding LP "
+            "world_size": world, "collective_backend": (f"nccl(RCCL) {'.'.join(map(str, torch.cuda.nccl.version()))}"
+                                                        if world > 1 else None),
+            "config": {"workload": f"{args.workload}: {B_max} scenarios/GPU x {len(model.HOUR)} h day-ahead bidding LP "
                                    f"(n={lp.n}, m={lp.m}, nnz={lp.nnz}), synthetic scenarios from the in-tree RTS-GMLC / nuclear "
                                    f"LMP series (dispatches_amd/scenarios.py)",
-                       "batch_per_gpu": B, "eps_rel": args.eps, "parallelism": f"scenario-sharded x{world}",
+                       "batch_per_gpu": B_max, "eps_rel": args.eps, "parallelism": f"scenario-sharded x{world}",
                        "mean_iterations": float(np.mean(sum_iters)) / B, "max_iterations": max_iters_one,
-                       "optimal": int(n_opt.item()), "scenarios": B * world,
+                       "optimal": int(n_opt.item()), "scenarios": n_total,
                        "grid": geometry[:2], "lds_bytes": geometry[2], "register_resident_matrix": bool(geometry[3]),
                        "simulated_lds_gather_conflict_cycles_per_iteration": {"identity_layout": lds_conflicts[0],
                                                                               "slot_permutation": lds_conflicts[1]},
@@ -306,7 +363,7 @@ def main():
         }
         # ---- streaming SpMV step (vectors in HBM): the kernel SURVEY 8(d) quotes the HBM roofline on -------
         if not args.no_spmv:
-            def time_spmv(Bs, reps):
+            def time_spmv(dlp, lp, Bs, reps):
                 X = torch.randn((Bs, lp.n), dtype=torch.float64, device=dev)
                 Y = torch.randn((Bs, lp.m), dtype=torch.float64, device=dev)
                 AX = torch.empty((Bs, lp.m), dtype=torch.float64, device=dev)
@@ -320,20 +377,27 @@ def main():
                 e1.record()
                 torch.cuda.synchronize()
                 ms = e0.elapsed_time(e1) / reps
-                bsp = Bs * bytes_iter + bytes_shared
+                bsp = Bs * 2 * w * (lp.n + lp.m) + 2 * (lp.nnz * (w + 4) + 4 * (lp.m + 1))
                 return dict(bound="hbm", kernel="spmv_step_kernel", batch=Bs, achieved=bsp / (ms * 1e-3) / 1e9,
                             peak=HBM_PEAK_GBS, unit="GB/s", frac=bsp / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                             traffic=None, kernel_ms=ms, algorithmic_bytes_per_launch=bsp)
 
-            result["spmv_step"] = time_spmv(B, 200)
-            result["spmv_step"]["traffic"] = _profiled_traffic("spmv_step_kernel")
+            result["spmv_step"] = time_spmv(dlp, lp, B, 200)
+            result["spmv_step"]["traffic"] = _profiled_traffic("spmv_stream_kernel") or _profiled_traffic("spmv_step_kernel")
             result["spmv_step"]["note"] = ("one A x + one A^T y for every scenario of the batch with vectors streamed "
-                                           "from/to HBM; events on the launch stream, back-to-back launches (includes "
-                                           "launch gaps); at the metric batch the launch moves only ~20 MB and is "
-                                           "launch/latency bound")
+                                           "from/to HBM (register-resident matrix, one scenario per wave, everything in "
+                                           "flight at once); events on the launch stream, back-to-back launches; a "
+                                           "20-40 MB launch is bound by one memory round trip + the launch ramp")
             # the same kernel on a batch large enough to be bandwidth bound (0.67 GB per launch, beyond L2 + MALL)
             if args.spmv_large_mult > 0:
-                result["spmv_step_large_batch"] = time_spmv(args.spmv_large_mult * B, 20)
+                result["spmv_step_large_batch"] = time_spmv(dlp, lp, args.spmv_large_mult * B, 20)
+            # BASELINE.md section 3 quotes the contract figure at T = 48, B = 4096 (40.9 MB, <= 10.2 us <=> >= 50 %)
+            if args.workload == "wind_battery_24h":
+                _, m48 = scenarios.WORKLOADS["wind_battery_48h"][0](B=2, solver=solver, T=48)
+                d48 = DeviceLP(m48.lp, local_rank, opts)
+                result["spmv_step_T48_B4096"] = time_spmv(d48, m48.lp, 4096, 200)
+                result["spmv_step_T48_B4096"]["note"] = "BASELINE.md section 3 configuration: wind+battery 48 h, 4096 scenarios"
+                d48.close()
         # ---- CPU baseline on this box's host cores (bounded sample) ------------------------------------------
         if world == 1 and args.cpu_sample != 0:
             procs = os.cpu_count() or 1

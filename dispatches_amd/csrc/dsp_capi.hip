@@ -239,6 +239,8 @@ int dsp_create(const dsp_lp_desc *d, int device, const dsp_options *opt, dsp_han
   // register-resident-matrix layout: ownership sorted by length, per-slot widths, position space
   SortedLayout Lc = sorted_layout(AT, cpl, Ec.long_owner), Lr = sorted_layout(A, rpl, Er.long_owner);
   SlotELL Sc = build_slot_ell(AT, Lc, Lr, Ec.long_owner), Sr = build_slot_ell(A, Lr, Lc, Er.long_owner);
+  // the unscaled matrix in the same position-space layout (same sparsity): streaming SpMV step
+  SlotELL Scu = build_slot_ell(ATu, Lc, Lr, Ec.long_owner), Sru = build_slot_ell(Au, Lr, Lc, Er.long_owner);
   // bank-conflict-minimising slot permutation of each exchange buffer: the y buffer is gathered by the A^T entries
   // (Sc), the x buffer by the A entries (Sr)
   SlotMap My = optimise_slots(Sc, P.m_pad), Mx = optimise_slots(Sr, P.n_pad);
@@ -246,6 +248,12 @@ int dsp_create(const dsp_lp_desc *d, int device, const dsp_options *opt, dsp_han
   h->lds_conflicts[2] = Mx.cost_identity; h->lds_conflicts[3] = Mx.cost_final;
   apply_slots(Sc, My.slot);
   apply_slots(Sr, Mx.slot);
+  apply_slots(Scu, My.slot);
+  apply_slots(Sru, Mx.slot);
+  // LDS byte offset of every natural element: column j sits at position Lc.pos[j], whose exchange slot is Mx.slot[...]
+  std::vector<int32_t> nat_x((size_t)P.n_pad, 0), nat_y((size_t)P.m_pad, 0);
+  for (int j = 0; j < d->n; ++j) nat_x[j] = 8 * Mx.slot[Lc.pos[j]];
+  for (int i = 0; i < d->m; ++i) nat_y[i] = 8 * My.slot[Lr.pos[i]];
   P.mr_wc_pack = Sc.pack; P.mr_wr_pack = Sr.pack;
   P.mr_tailc_entries = (int)Sc.tail_val.size(); P.mr_tailr_entries = (int)Sr.tail_val.size();
   if ((rc = fill_long(P.mr_long_c, Sc)) || (rc = fill_long(P.mr_long_r, Sr))) { delete h; return rc; }
@@ -259,6 +267,9 @@ int dsp_create(const dsp_lp_desc *d, int device, const dsp_options *opt, dsp_han
   UP(h->dc, col_scale) UP(h->dr, row_scale)
   UPE(Sc.val, Sc.off, mr_ellc) UPE(Sr.val, Sr.off, mr_ellr) UPE(Sc.tail_val, Sc.tail_off, mr_tailc) UPE(Sr.tail_val, Sr.tail_off, mr_tailr)
   UP(Lc.at, mr_colat) UP(Lr.at, mr_rowat) UP(Mx.slot, mr_slot_x) UP(My.slot, mr_slot_y)
+  UPE(Scu.val, Scu.off, mr_ellc_unscaled) UPE(Sru.val, Sru.off, mr_ellr_unscaled)
+  UPE(Scu.tail_val, Scu.tail_off, mr_tailc_unscaled) UPE(Sru.tail_val, Sru.tail_off, mr_tailr_unscaled)
+  UP(nat_x, mr_nat_slot_x) UP(nat_y, mr_nat_slot_y)
 #undef UP
 #undef UPE
   void *q = nullptr;
@@ -328,7 +339,19 @@ int dsp_spmv_step(dsp_handle *h, int32_t B, const double *X, const double *Y, do
   HIP_TRY(hipSetDevice(h->device));
   SpmvArgs a{};
   a.P = h->P; a.B = B; a.X = X; a.Y = Y; a.AX = AX; a.ATY = ATY;
-  // streaming kernel: 8-wave blocks, as many as LDS admits per CU (its register footprint is small)
+  if (h->matreg) {
+    // register-resident-matrix form: one scenario per wave, 4-wave blocks, the whole batch resident at once when it
+    // fits (32 waves per CU); LDS = the waves' exchange buffers (+ long-vector tails)
+    a.waves_per_block = 4;
+    const size_t lds = ((size_t)h->P.mr_tailc_entries + h->P.mr_tailr_entries) * sizeof(Entry) +
+                       (size_t)a.waves_per_block * (h->P.n_pad + h->P.m_pad) * 8;
+    if (lds > (size_t)h->lds_limit) return DSP_ERR_TOO_LARGE;
+    const int per_cu = std::max<int>(1, std::min<int>((int)(h->lds_limit / lds), 32 / a.waves_per_block));
+    const int grid = std::min((B + a.waves_per_block - 1) / a.waves_per_block, h->num_cus * per_cu);
+    HIP_TRY(launch_spmv_stream(h->cpl, h->rpl, a, dim3(grid), dim3(64 * a.waves_per_block), lds, (hipStream_t)hipStream));
+    return DSP_OK;
+  }
+  // generic form (matrix staged in LDS per block): 8-wave blocks, as many as LDS admits per CU
   a.waves_per_block = kMaxWavesPerBlock;
   size_t lds = lds_bytes(h->P, a.waves_per_block);
   while (lds > (size_t)h->lds_limit && a.waves_per_block > 1) lds = lds_bytes(h->P, --a.waves_per_block);

@@ -44,6 +44,9 @@ struct DeviceProblem {
   unsigned mr_wc_pack, mr_wr_pack;                                 // per-slot widths, 4 bits each
   const int32_t *mr_slot_x, *mr_slot_y;                            // [n_pad] / [m_pad] LDS slot of each exchange-buffer position
   LongList mr_long_c, mr_long_r;                                   // owner = POSITION
+  // unscaled copies in the same layout + the LDS byte offset of every NATURAL element (streaming SpMV step)
+  const Entry *mr_ellc_unscaled, *mr_ellr_unscaled, *mr_tailc_unscaled, *mr_tailr_unscaled;
+  const int32_t *mr_nat_slot_x, *mr_nat_slot_y;                    // [n_pad] / [m_pad]  8 * slot(position(column j / row i))
 };
 
 struct SolveArgs {
@@ -69,5 +72,6 @@ hipError_t launch_solve(int cpl, int rpl, const SolveArgs &a, dim3 grid, dim3 bl
 int matreg_available(int cpl, int rpl, unsigned wc_pack, unsigned wr_pack, bool lng);   // 0 / 1
 hipError_t occupancy_solve(int cpl, int rpl, const SolveArgs &a, int block_threads, size_t lds, int *blocks_per_cu);
 hipError_t launch_spmv(int cpl, int rpl, const SpmvArgs &a, dim3 grid, dim3 block, size_t lds, hipStream_t st);
+hipError_t launch_spmv_stream(int cpl, int rpl, const SpmvArgs &a, dim3 grid, dim3 block, size_t lds, hipStream_t st);
 
 }  // namespace dsp

@@ -46,13 +46,44 @@ class _ShardView:
         self.iterations = None if iterations is None else np.asarray(iterations)
 
 
+def make_gather_buffers(world: int, per_rank: int, device, width: int = 2):
+    """Send / receive buffers of the per-solve collective: `width` float64 columns per scenario (objective, status
+    [, iterations, x, y]), shards padded to `per_rank` rows (the largest shard) with NaN."""
+    import torch
+    return dict(local=torch.full((per_rank, width), float("nan"), dtype=torch.float64, device=device),
+                all=torch.empty((world * per_rank, width), dtype=torch.float64, device=device))
+
+
+def gather_device_results(out, buffers, per_rank=None, group=None, columns=("obj", "status")):
+    """The ONE collective of a sharded solve, straight from the solver's DEVICE outputs: the columns of `out` (device
+    tensors of this rank's shard: `obj` [b], `status` [b], `iters` [b], `x` [b, n], `y` [b, m]) are packed on the device
+    into buffers["local"] and all-gathered into buffers["all"] (RCCL over xGMI under backend "nccl"; no host hop).
+    Stream-ordered on the current stream.  Returns buffers["all"] viewed as [world, per_rank, width]."""
+    import torch.distributed as dist
+    local, everything = buffers["local"], buffers["all"]
+    per = local.shape[0]
+    col = 0
+    for key in columns:
+        t = out[key]
+        b = t.shape[0]
+        w = 1 if t.dim() == 1 else t.shape[1]
+        local[:b, col:col + w] = t.reshape(b, w)            # dtype conversion (int32 status -> float64) happens here
+        col += w
+    dist.all_gather_into_tensor(everything, local, group=group)
+    return everything.view(-1, per, local.shape[1])
+
+
 def solve_sharded(model, solver, group=None, gather_solution: bool = False):
     """Solve `model`'s scenarios sharded over the ranks of `group` and all-gather the results.
 
     Every rank must call this with an identical `model` (same LP, same per-scenario data).  After the call
     ``model.objective`` / ``model.status`` / ``model.iterations`` hold ALL scenarios on every rank;
     ``model.x`` / ``model.y`` hold all scenarios if `gather_solution`, otherwise only the local shard is valid
-    (rows outside the shard are NaN).  Returns (lo, hi), the shard this rank solved."""
+    (rows outside the shard are NaN).  Returns (lo, hi), the shard this rank solved.
+
+    Under RCCL (backend "nccl") the collective reads the solver's device outputs directly
+    (`solver.last_device_out`, set by HipPdlpSolver.solve) and the gathered batch is copied to the host once; under
+    gloo (CPU tests) the same packing runs on host tensors."""
     import torch
     import torch.distributed as dist
 
@@ -67,22 +98,38 @@ def solve_sharded(model, solver, group=None, gather_solution: bool = False):
     n, m = model.lp.n, model.lp.m
     per = max(shard_bounds(B, world, r)[1] - shard_bounds(B, world, r)[0] for r in range(world))
     width = 3 + ((n + m) if gather_solution else 0)          # objective, status, iterations [, x, y]
-    dev = torch.device("cuda", torch.cuda.current_device()) if (dist.is_initialized() and
-                                                                 dist.get_backend(group) == "nccl") else "cpu"
-    local = torch.full((per, width), float("nan"), dtype=torch.float64, device=dev)
-    if hi > lo:
-        cols = [view.objective, view.status.astype(np.float64),
-                (view.iterations if view.iterations is not None else np.zeros(hi - lo)).astype(np.float64)]
-        packed = np.stack(cols, 1)
-        if gather_solution:
-            packed = np.concatenate([packed, view.x, view.y.reshape(hi - lo, m)], 1)
-        local[:hi - lo] = torch.as_tensor(packed, dtype=torch.float64).to(dev)
-    if world > 1:
-        everything = torch.empty((world * per, width), dtype=torch.float64, device=dev)
-        dist.all_gather_into_tensor(everything, local, group=group)       # the ONE collective of the solve
-        everything = everything.cpu().numpy().reshape(world, per, width)
+    on_gpu = dist.is_initialized() and dist.get_backend(group) == "nccl"
+    dev = torch.device("cuda", torch.cuda.current_device()) if on_gpu else torch.device("cpu")
+    columns = ("obj", "status", "iters") + (("x", "y") if gather_solution else ())
+    dev_out = getattr(solver, "last_device_out", None) if on_gpu else None
+    if hi > lo and dev_out is not None and dev_out["obj"].shape[0] == hi - lo:
+        # device path: objective is c.x on the device, the model's constant is added after the gather
+        out = dict(dev_out)
+        out["y"] = out["y"][:, :m]
+        c0_local = torch.as_tensor(np.ascontiguousarray(view.c0, np.float64)).to(dev)
+        out["obj"] = out["obj"] + c0_local
+    elif hi > lo:
+        it = view.iterations if view.iterations is not None else np.zeros(hi - lo)
+        host = dict(obj=view.objective, status=view.status, iters=it, x=view.x, y=np.reshape(view.y, (hi - lo, m)))
+        out = {k: torch.as_tensor(np.ascontiguousarray(host[k], np.float64)).to(dev) for k in columns}
     else:
-        everything = local.cpu().numpy()[None]
+        out = None
+    buffers = make_gather_buffers(world, per, dev, width)
+    if world > 1:
+        if out is None:                                     # empty shard: still takes part in the collective
+            dist.all_gather_into_tensor(buffers["all"], buffers["local"], group=group)
+            everything = buffers["all"].view(world, per, width)
+        else:
+            everything = gather_device_results(out, buffers, per, group, columns)   # the ONE collective of the solve
+        everything = everything.cpu().numpy()
+    else:
+        col = 0
+        for key in columns:
+            t = out[key]
+            w = 1 if t.dim() == 1 else t.shape[1]
+            buffers["local"][:hi - lo, col:col + w] = t.reshape(hi - lo, w)
+            col += w
+        everything = buffers["local"].cpu().numpy()[None]
     obj = np.empty(B)
     status = np.empty(B, np.int32)
     iters = np.empty(B, np.int64)
@@ -95,6 +142,6 @@ def solve_sharded(model, solver, group=None, gather_solution: bool = False):
         if gather_solution:
             x[a:b], y[a:b] = blk[:, 3:3 + n], blk[:, 3 + n:3 + n + m]
     if not gather_solution and hi > lo:
-        x[lo:hi], y[lo:hi] = view.x, view.y.reshape(hi - lo, m)
+        x[lo:hi], y[lo:hi] = view.x, np.reshape(view.y, (hi - lo, m))
     model.store_solution(x, y, obj, status, iters)
     return lo, hi

@@ -338,6 +338,9 @@ class HipPdlpSolver:
                         obj_offset=up("c0", np.broadcast_to(np.asarray(model.c0, np.float64), (B,))), primal_weight=pw)
         st = out["stats"]
         self.last_stats = st
+        # device outputs of this solve (x, y, obj = c.x without the model constant, status, iters): a sharded solve
+        # all-gathers these directly over RCCL (dispatches_amd.distributed.solve_sharded)
+        self.last_device_out = out
         # downloads into fresh pinned host tensors (torch caches freed pinned blocks, so this is cheap after the first
         # call); the numpy views handed to the model keep their tensors alive
         def down(t):

@@ -167,3 +167,104 @@ def make_batch(name, B, solver):
     bidder, model = fn(B=B, solver=solver, **kw)
     load_prices(bidder, model)
     return bidder, model
+
+
+# ---- the HOURLY LPs of the double loop at batch scale (real-time bids and tracking) ----------------
+# One simulated day is 1 day-ahead solve + 24 x (real-time bid + tracking) solves per scenario: 24 of the 25 solves are
+# these small LPs.  Each scenario carries its own rolling-horizon state (initial SOC / throughput / tank holdup, fixed
+# through column bounds exactly as `update_model` does), capacity-factor window and realised dispatch.
+class _MatrixForecaster(AbstractPrescientPriceForecaster):
+    def __init__(self, da, rt):
+        self.da, self.rt = np.asarray(da, float), np.asarray(rt, float)
+
+    def forecast_day_ahead_and_real_time_prices(self, date, hour, bus, horizon, n_samples):
+        return self.da[:n_samples, :horizon], self.rt[:n_samples, :horizon]
+
+    def fetch_hourly_stats_from_prescient(self, s):
+        pass
+
+    def fetch_day_ahead_stats_from_prescient(self, *a):
+        pass
+
+
+def _per_scenario_bounds(model):
+    B = model.n_scenario
+    lb, ub, _, _ = model.block.current_bounds()
+    return np.tile(lb, (B, 1)), np.tile(ub, (B, 1))
+
+
+def _nuclear_model_data():
+    return ThermalGeneratorModelData(
+        gen_name="121_NUCLEAR_1", bus="Attlee", p_min=400, p_max=500, min_down_time=48, min_up_time=24,
+        ramp_up_60min=100, ramp_down_60min=100, shutdown_capacity=500, startup_capacity=500, initial_status=-1,
+        initial_p_output=0, production_cost_bid_pairs=[(400, 15), (450, 17.5), (500, 20)],
+        startup_cost_pairs=[(48, 7355.42)], fixed_commitment=1)
+
+
+def _hourly_model_object(case, T, cf_template):
+    if case.startswith("wind_battery"):
+        return MultiPeriodWindBattery(_thermal_data("309_WIND_1", "Carter", 200.0, 25.0),
+                                      wind_capacity_factors=list(cf_template), wind_pmax_mw=200.0,
+                                      battery_pmax_mw=25.0, battery_energy_capacity_mwh=100.0)
+    if case.startswith("wind_pem"):
+        return MultiPeriodWindPEM(_thermal_data("309_WIND_1", "Carter", 200.0, 25.0),
+                                  wind_capacity_factors=list(cf_template), wind_pmax_mw=200.0, pem_pmax_mw=25.0)
+    return MultiPeriodNuclear(_nuclear_model_data())
+
+
+def _apply_hourly_state(case, model, inp, lb, ub):
+    """Per-scenario rolling-horizon state and wind availability as column bounds (what `update_model` writes)."""
+    blk = model.block
+    if case.startswith("wind"):
+        fam = blk.windBattery if case.startswith("wind_battery") else blk.windPEM
+        wind_cols = np.array([p["wind"].index for p in fam["periods"]])
+        ub[:, wind_cols] = fam["wind_kw"] * inp["cf"]
+        if case.startswith("wind_battery"):
+            for key, col in (("soc0", fam["soc_init"].index), ("e0", fam["thr_init"].index)):
+                lb[:, col] = ub[:, col] = inp[key]
+        cf_t = np.array([p["wind"].ub for p in fam["periods"]]) / fam["wind_kw"]
+        per_kw = 1.0 if case.startswith("wind_pem") else 1e-3 * 1e3          # curtailment weight per kW (SURVEY A.1/A.2)
+        return per_kw * fam["wind_kw"] * (inp["cf"].sum(1) - cf_t.sum())      # objective-constant shift per scenario
+    col = blk.nuclear["holdup_init"].index
+    lb[:, col] = ub[:, col] = inp["holdup0"]
+    return np.zeros(model.n_scenario)
+
+
+def hourly_bid_batch(case, inp, solver):
+    """Real-time bidding LPs (`case` = wind_battery_rt4 / wind_pem_rt4 / nuclear_rt12) for B scenarios: day_ahead_power
+    fixed to each scenario's realised dispatch.  Returns (bidder, model); model.objective follows the product's
+    convention (it keeps the constant DA revenue sum_t DA_t * dispatch_t, the oracle's RT objective does not)."""
+    B, T = inp["rt"].shape
+    mo = _hourly_model_object(case, T, inp["cf"][0] if "cf" in inp else None)
+    bidder = Bidder(mo, day_ahead_horizon=T, real_time_horizon=T, n_scenario=B, solver=solver,
+                    forecaster=_MatrixForecaster(inp["da"], inp["rt"]))
+    model = bidder.real_time_model
+    lb, ub = _per_scenario_bounds(model)
+    model.c0_shift = _apply_hourly_state(case, model, inp, lb, ub)
+    lb[:, model.pda_cols] = ub[:, model.pda_cols] = inp["dispatch"]
+    model.lb, model.ub = lb, ub
+    bidder._pass_price_forecasts(model, np.asarray(inp["da"], float), np.asarray(inp["rt"], float))
+    return bidder, model
+
+
+def hourly_tracking_batch(case, inp, solver):
+    """Tracking LPs (`case` = wind_battery_track4 / wind_pem_track4 / nuclear_track4) for B scenarios, each with its own
+    dispatch signal and state.  Returns (tracker, model)."""
+    from .workflow import Tracker
+    B, T = inp["dispatch"].shape
+    mo = _hourly_model_object(case, T, inp["cf"][0] if "cf" in inp else None)
+    tracker = Tracker(tracking_model_object=mo, tracking_horizon=T, n_tracking_hour=1, solver=solver)
+    model = tracker.model
+    tracker._pass_market_dispatch([0.0] * T)                    # rows become equalities; the values are per scenario
+    model.n_scenario, model.SCENARIOS = B, range(B)
+    lb, ub = _per_scenario_bounds(model)
+    shift = _apply_hourly_state(case, model, inp, lb, ub)
+    model.lb, model.ub = lb, ub
+    _, _, rlo, rhi = model.block.current_bounds()
+    rlo, rhi = np.tile(rlo, (B, 1)), np.tile(rhi, (B, 1))
+    rows = np.array([model.block.kept_row_index(r) for r in model.tracking_rows])
+    rlo[:, rows] = rhi[:, rows] = inp["dispatch"] - model.PT_const[None, :]
+    model.rlo, model.rhi = rlo, rhi
+    model.c = np.tile(model.c[0], (B, 1))
+    model.c0 = np.full(B, float(model.c0[0])) + shift
+    return tracker, model

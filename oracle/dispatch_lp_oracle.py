@@ -350,6 +350,13 @@ def wind_pem_da(T, cf, da, rt, wind_kw=200e3, **kw):
     return PreparedLP(lp), fs, pda, u
 
 
+def wind_pem_rt(T, cf, rt, realized_da, wind_kw=200e3, **kw):
+    lp = _LP()
+    fs = wind_pem_rows(lp, T, cf, wind_kw, **kw)
+    u = add_rt_bidding(lp, fs, rt, realized_da)
+    return PreparedLP(lp), fs, u
+
+
 def wind_pem_track(T, cf, dispatch, wind_kw=200e3, **kw):
     lp = _LP()
     fs = wind_pem_rows(lp, T, cf, wind_kw, **kw)
@@ -362,6 +369,13 @@ def nuclear_da(T, da, rt, holdup0=0.0, **kw):
     fs = nuclear_rows(lp, T, holdup0, **kw)
     pda, u = add_da_bidding(lp, fs, da, rt)
     return PreparedLP(lp), fs, pda, u
+
+
+def nuclear_rt(T, rt, realized_da, holdup0=0.0, **kw):
+    lp = _LP()
+    fs = nuclear_rows(lp, T, holdup0, **kw)
+    u = add_rt_bidding(lp, fs, rt, realized_da)
+    return PreparedLP(lp), fs, u
 
 
 def nuclear_track(T, dispatch, holdup0=0.0, **kw):

@@ -98,6 +98,9 @@ def solve(P, eps=1e-9, max_iter=60000, check=32, wrule="pid", kp=0.7, maxdl=np.l
                 rg = np.where(okg & oki, rg, np.maximum(rg, 2 * eps))
                 lim_ = np.maximum(eps_obj * (1 + np.abs(po)), 1e-12 * scale)
                 solve.rho_obj = np.maximum(np.maximum(gap, ierr), derr) / lim_
+            if getattr(solve, "hook", None) is not None:       # development hook (tools/polish_lab.py)
+                solve.hook(it + 1, dict(xp=xp, yp=yp, gx=x - tau * (c - y @ As), gy=wv, lb=lb, ub=ub, rlo=rlo, rhi=rhi,
+                                        sig=sig, tau=tau, As=As, c=c, done=done, dc=dc, dr=dr, w=w))
             conv = (rp <= eps) & (rd <= eps) & (rg <= eps) & ~done
             if getattr(solve, "trace", None) is not None:      # (iteration, r, rho = worst criterion / its limit, done)
                 rho = np.maximum(np.maximum(rp, rd), rg) / eps
