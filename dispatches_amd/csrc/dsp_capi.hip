@@ -3,6 +3,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -44,6 +45,10 @@ struct dsp_handle {
   bool geo_valid = false;
   Geometry geo;
   int matreg = 0;                 // register-resident-matrix kernel available for this shape
+  int simplex = 0;                // tiny LP: the in-wave dense simplex runs first (dsp_simplex.hip)
+  const double *A_dense = nullptr;   // [m][n] scaled matrix, row-major (simplex only)
+  int sx_row_stride = 0;
+  size_t sx_lds = 0;
   int lds_conflicts[4] = {0, 0, 0, 0};   // simulated extra LDS cycles per iteration: y buffer identity/best, x identity/best
 };
 
@@ -151,7 +156,7 @@ void dsp_default_options(dsp_options *o) {
   o->kkt_every = 32;
   o->kkt_gate = 16.0;
   o->stall_rescue = 4000;
-  o->reserved = 0;
+  o->no_simplex = 0;
   o->jump_rel = 3.0;
   o->restart_sufficient = 0.2;
   o->restart_necessary = 0.8;
@@ -272,6 +277,17 @@ int dsp_create(const dsp_lp_desc *d, int device, const dsp_options *opt, dsp_han
   UP(nat_x, mr_nat_slot_x) UP(nat_y, mr_nat_slot_y)
 #undef UP
 #undef UPE
+  // tiny LPs: dense scaled matrix for the in-wave simplex
+  if (!h->opt.no_simplex && d->n + d->m <= 128 && d->m <= 64 && d->m >= 1) {
+    h->sx_lds = simplex_lds_bytes(d->n, d->m, &h->sx_row_stride);
+    if (h->sx_lds <= (size_t)h->lds_limit) {
+      std::vector<double> dense((size_t)d->m * d->n, 0.0);
+      for (int i = 0; i < A.m; ++i)
+        for (int p = A.ptr[i]; p < A.ptr[i + 1]; ++p) dense[(size_t)i * d->n + A.idx[p]] = A.val[p];
+      if ((rc = upload(h, dense, &h->A_dense)) != DSP_OK) { dsp_destroy(h); return rc; }
+      h->simplex = 1;
+    }
+  }
   void *q = nullptr;
   if (hipMalloc(&q, sizeof(int) * kQueueRing * kQueueStride) != hipSuccess) { dsp_destroy(h); return DSP_ERR_HIP; }
   h->queue = (int *)q;
@@ -309,13 +325,24 @@ int dsp_solve(dsp_handle *h, const dsp_batch *batch, const dsp_options *opt, dsp
   int grid = std::min((B + geo.wpb - 1) / geo.wpb, h->num_cus * geo.blocks_per_cu);
   const bool timed = stats && sync_stats;
   if (timed) HIP_TRY(hipEventRecord(h->ev0, st));
+  if (h->simplex) {
+    // simplex pass: certified vertices get their final status; DSP_STATUS_UNSOLVED marks what the PDLP kernel still has to do
+    SimplexArgs sa{};
+    sa.n = h->n; sa.m = h->m; sa.row_stride = h->sx_row_stride; sa.max_pivots = 20 * (h->n + h->m);
+    sa.A_dense = h->A_dense; sa.col_scale = h->P.col_scale; sa.row_scale = h->P.row_scale; sa.b = *batch;
+    sa.tol_p = 1e-10; sa.tol_d = 1e-12; sa.tol_piv = 1e-9;
+    const int per_cu = std::max<int>(1, std::min<int>(32, (int)((size_t)h->lds_limit / h->sx_lds)));
+    const int sgrid = std::min(B, h->num_cus * per_cu);
+    HIP_TRY(launch_simplex(sa, sgrid, h->sx_lds, st));
+    a.skip_solved = 1;
+  }
   HIP_TRY(launch_solve(h->cpl, h->rpl, a, dim3(grid), dim3(64 * a.waves_per_block), lds, st));
   h->queue_base[slot] += (unsigned)B + (unsigned)grid * (unsigned)a.waves_per_block;   // B hits + one miss per wave
   if (timed) HIP_TRY(hipEventRecord(h->ev1, st));
   if (stats) {
     std::memset(stats, 0, sizeof(*stats));
     stats->grid_blocks = grid; stats->block_threads = 64 * a.waves_per_block; stats->lds_bytes = (int)lds;
-    stats->cols_per_lane = h->cpl; stats->rows_per_lane = h->rpl; stats->matreg = h->matreg;
+    stats->cols_per_lane = h->cpl; stats->rows_per_lane = h->rpl; stats->matreg = h->matreg; stats->simplex = h->simplex;
     stats->lds_conflicts_identity = h->lds_conflicts[0] + h->lds_conflicts[2];
     stats->lds_conflicts_chosen = h->matreg ? h->lds_conflicts[1] + h->lds_conflicts[3] : stats->lds_conflicts_identity;
     if (sync_stats) {
@@ -339,14 +366,18 @@ int dsp_spmv_step(dsp_handle *h, int32_t B, const double *X, const double *Y, do
   HIP_TRY(hipSetDevice(h->device));
   SpmvArgs a{};
   a.P = h->P; a.B = B; a.X = X; a.Y = Y; a.AX = AX; a.ATY = ATY;
-  if (h->matreg) {
+  // development knobs: DSP_SPMV_LDS=1 forces the LDS-staged form, DSP_SPMV_WAVES_PER_CU caps the resident waves per CU
+  // of the register-resident form (fewer waves = more scenarios per wave = fewer matrix loads, less in flight)
+  static const bool force_lds = getenv("DSP_SPMV_LDS") && atoi(getenv("DSP_SPMV_LDS")) != 0;
+  static const int waves_cap = getenv("DSP_SPMV_WAVES_PER_CU") ? atoi(getenv("DSP_SPMV_WAVES_PER_CU")) : 32;
+  if (h->matreg && !force_lds) {
     // register-resident-matrix form: one scenario per wave, 4-wave blocks, the whole batch resident at once when it
     // fits (32 waves per CU); LDS = the waves' exchange buffers (+ long-vector tails)
     a.waves_per_block = 4;
     const size_t lds = ((size_t)h->P.mr_tailc_entries + h->P.mr_tailr_entries) * sizeof(Entry) +
                        (size_t)a.waves_per_block * (h->P.n_pad + h->P.m_pad) * 8;
     if (lds > (size_t)h->lds_limit) return DSP_ERR_TOO_LARGE;
-    const int per_cu = std::max<int>(1, std::min<int>((int)(h->lds_limit / lds), 32 / a.waves_per_block));
+    const int per_cu = std::max<int>(1, std::min<int>((int)(h->lds_limit / lds), std::max(1, waves_cap / a.waves_per_block)));
     const int grid = std::min((B + a.waves_per_block - 1) / a.waves_per_block, h->num_cus * per_cu);
     HIP_TRY(launch_spmv_stream(h->cpl, h->rpl, a, dim3(grid), dim3(64 * a.waves_per_block), lds, (hipStream_t)hipStream));
     return DSP_OK;

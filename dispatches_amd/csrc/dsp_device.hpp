@@ -49,15 +49,30 @@ struct DeviceProblem {
   const int32_t *mr_nat_slot_x, *mr_nat_slot_y;                    // [n_pad] / [m_pad]  8 * slot(position(column j / row i))
 };
 
+// internal status written by the simplex kernel for scenarios it leaves to the PDLP kernel (never reaches the caller)
+#define DSP_STATUS_UNSOLVED 99
+
 struct SolveArgs {
   DeviceProblem P;
   dsp_batch b;
+  int skip_solved;             // 1 = only scenarios whose status is DSP_STATUS_UNSOLVED are solved (after the simplex pass)
   int waves_per_block;
   double eta;
   dsp_options opt;
   int *queue;                  // device work-queue head: counts up for ever, this launch's scenarios are
   unsigned queue_base;         //   head - queue_base (every wave overshoots exactly once when it finds the queue empty)
   int matreg;                  // 1 = register-resident-matrix specialisation of the kernel
+};
+
+// in-wave dense simplex for tiny LPs (dsp_simplex.hip)
+struct SimplexArgs {
+  int n, m;
+  int row_stride;              // doubles per tableau row in LDS (odd)
+  int max_pivots;
+  const double *A_dense;       // [m][n] scaled matrix D_r A D_c, row-major
+  const double *col_scale, *row_scale;
+  dsp_batch b;
+  double tol_p, tol_d, tol_piv;
 };
 
 struct SpmvArgs {
@@ -71,6 +86,8 @@ struct SpmvArgs {
 hipError_t launch_solve(int cpl, int rpl, const SolveArgs &a, dim3 grid, dim3 block, size_t lds, hipStream_t st);
 int matreg_available(int cpl, int rpl, unsigned wc_pack, unsigned wr_pack, bool lng);   // 0 / 1
 hipError_t occupancy_solve(int cpl, int rpl, const SolveArgs &a, int block_threads, size_t lds, int *blocks_per_cu);
+size_t simplex_lds_bytes(int n, int m, int *row_stride);
+hipError_t launch_simplex(const SimplexArgs &a, int grid, size_t lds, hipStream_t st);
 hipError_t launch_spmv(int cpl, int rpl, const SpmvArgs &a, dim3 grid, dim3 block, size_t lds, hipStream_t st);
 hipError_t launch_spmv_stream(int cpl, int rpl, const SpmvArgs &a, dim3 grid, dim3 block, size_t lds, hipStream_t st);
 

@@ -1,0 +1,359 @@
+// dsp_simplex.hip — in-wave dense simplex for the TINY LPs of the double loop (gfx950, wave64).
+//
+// 24 of the 25 solves of a simulated day are hourly LPs with 20-110 columns + rows (4-h real-time bids, 12-h nuclear
+// real-time bids, 4-h tracking: SURVEY.md 3.3).  A first-order method needs thousands of iterations on them (1e4
+// penalty columns against 1e-2 costs) and fails outright when the dispatch signal cannot be met; a vertex method needs
+// ~(n + m) / 2 pivots and returns the exact vertex - the same kind of answer the reference's CBC / Xpress return.
+//
+// One LP per wave.  Bounded-variable primal simplex on the dense tableau (executable specification:
+// tools/simplex_proto.py, which this file follows step by step):
+//     min c.x  s.t.  rlo <= A x <= rhi,  lb <= x <= ub                 (scaled by the handle's D_r, D_c)
+//     z = (x, s),  s = A x in [rlo, rhi];   start: all slacks basic, structurals at their finite bound nearest 0
+//     phase 1: minimise the sum of bound violations of the basic variables; an infeasible basic blocks when it
+//              reaches the bound it violates
+//     phase 2: Dantzig pricing on reduced costs RECOMPUTED from the tableau every pivot (no drift), two-pass ratio test
+//              (minimum ratio, then the largest pivot among the ties), bound flips
+// Layout: the tableau T [m][N] (N = n + m <= 128) lives in the wave's LDS with an odd row stride, so that both access
+// patterns are bank-conflict free: lane j sweeping its column(s) j, j + 64 (pricing, pivot update) and lane i reading
+// its row's entry of the entering column (ratio test).  Lane i < m also owns row i's basic variable (value, bounds,
+// index), lane j owns column j's status.  All control flow is wave-uniform; reductions run on the VALU (DPP).
+// A solved LP is certified against the ORIGINAL rows before it is reported optimal; anything else (pivot limit,
+// failed certificate) is left to the PDLP kernel that runs afterwards on the scenarios still marked unsolved.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdint>
+
+#include "dsp_device.hpp"
+#include "dsp_wave.hpp"
+
+namespace dsp {
+
+namespace {
+
+constexpr double kBig = 1e300;
+
+__device__ __forceinline__ double lds_d(const double *base, int idx) { return base[idx]; }
+
+// lowest set lane of a wave-uniform 64-bit ballot
+__device__ __forceinline__ int first_lane(unsigned long long mask) { return __ffsll((long long)mask) - 1; }
+
+template <int CQ>
+__global__ void __launch_bounds__(64) simplex_kernel(SimplexArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const dsp_batch &b = a.b;
+  const int lane = threadIdx.x;
+  const int n = a.n, m = a.m, N = n + m;
+  const int RS = a.row_stride;                       // odd number of doubles per tableau row
+  double *T = reinterpret_cast<double *>(smem);      // [m][RS]
+  double *alpha_s = T + (size_t)m * RS;              // [64]  entering column
+  double *cB_s = alpha_s + 64;                       // [64]  cost of each row's basic variable (current phase)
+  double *xval = cB_s + 64;                          // [128] value of every variable (final assembly / start)
+  double *scal = xval + 128;                         // [8]   broadcast scalars
+  int *iscal = reinterpret_cast<int *>(scal + 8);    // [8]
+
+  for (int s = blockIdx.x; s < b.B; s += gridDim.x) {
+    // ---- this scenario's data: columns j = lane + 64 q (structural j < n, slack n <= j < N) ---------------------
+    double lo[CQ], hi[CQ], cost[CQ], val[CQ];
+    bool basic[CQ], upper[CQ], fixedv[CQ], live[CQ];
+    double cabs = 0.0;
+    bool bad = false;
+#pragma unroll
+    for (int q = 0; q < CQ; ++q) {
+      const int j = lane + 64 * q;
+      live[q] = j < N;
+      lo[q] = 0.0; hi[q] = 0.0; cost[q] = 0.0;
+      if (j < n) {
+        const double d = a.col_scale[j];
+        const double cu = b.c[(size_t)s * b.c_stride + j];
+        const double lu = b.var_lb ? b.var_lb[(size_t)s * b.var_lb_stride + j] : -INFINITY;
+        const double uu = b.var_ub ? b.var_ub[(size_t)s * b.var_ub_stride + j] : INFINITY;
+        cost[q] = cu * d; lo[q] = lu / d; hi[q] = uu / d;
+        if (!(lu <= uu) || !(cu == cu)) bad = true;
+      } else if (j < N) {
+        const int i = j - n;
+        const double d = a.row_scale[i];
+        const double l = b.row_lb ? b.row_lb[(size_t)s * b.row_lb_stride + i] : -INFINITY;
+        const double u = b.row_ub ? b.row_ub[(size_t)s * b.row_ub_stride + i] : INFINITY;
+        lo[q] = l * d; hi[q] = u * d;
+        if (!(l <= u)) bad = true;
+      }
+      cabs = fmax(cabs, fabs(cost[q]));
+      fixedv[q] = lo[q] == hi[q];
+      basic[q] = live[q] && j >= n;
+      // nonbasic start: the finite bound nearest to zero (free columns start at 0)
+      const bool lo_f = is_finite(lo[q]), hi_f = is_finite(hi[q]);
+      double v = 0.0;
+      if (lo_f && (!hi_f || fabs(lo[q]) <= fabs(hi[q]))) v = lo[q];
+      else if (hi_f) v = hi[q];
+      val[q] = v;
+      upper[q] = hi_f && v == hi[q] && !(v == lo[q]);
+    }
+    if (__ballot(bad) != 0ull) {
+      // crossed bounds / NaN input: flagged exactly as the PDLP kernel does, nothing is iterated
+#pragma unroll
+      for (int q = 0; q < CQ; ++q) { const int j = lane + 64 * q; if (j < n) b.x[(size_t)s * n + j] = NAN; }
+      if (lane < m) b.y[(size_t)s * m + lane] = NAN;
+      bool nanc = false;
+#pragma unroll
+      for (int q = 0; q < CQ; ++q) nanc |= !(cost[q] == cost[q]);
+      const bool any_nan = __ballot(nanc) != 0ull;
+      if (lane == 0) {
+        b.obj[s] = NAN;
+        b.status[s] = any_nan ? DSP_STATUS_NUMERICAL : DSP_STATUS_PRIMAL_INFEASIBLE;
+        if (b.iters) b.iters[s] = 0;
+        if (b.jumps) b.jumps[s] = 0;
+      }
+      continue;
+    }
+    const double ctol = a.tol_d * (1.0 + wave_max(cabs));
+    // ---- tableau: row i = s_i - sum_j a_ij x_j = 0, basis = slacks ----------------------------------------------
+    for (int i = 0; i < m; ++i) {
+#pragma unroll
+      for (int q = 0; q < CQ; ++q) {
+        const int j = lane + 64 * q;
+        if (j < N) T[i * RS + j] = (j < n) ? -a.A_dense[(size_t)i * n + j] : ((j - n == i) ? 1.0 : 0.0);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < CQ; ++q) { const int j = lane + 64 * q; if (j < N) xval[j] = val[q]; }
+    wave_lds_fence();
+    // row lanes: basic variable of row i (slack n + i), its value s_i = sum_j a_ij x_j and bounds
+    int bvar = (lane < m) ? n + lane : -1;
+    double beta = 0.0, blo = -INFINITY, bhi = INFINITY;
+    if (lane < m) {
+      for (int j = 0; j < n; ++j) beta = fma(-T[lane * RS + j], xval[j], beta);
+      const double d = a.row_scale[lane];
+      const double l = b.row_lb ? b.row_lb[(size_t)s * b.row_lb_stride + lane] : -INFINITY;
+      const double u = b.row_ub ? b.row_ub[(size_t)s * b.row_ub_stride + lane] : INFINITY;
+      blo = l * d; bhi = u * d;
+    }
+    int status = -1, pivots = 0;
+    bool phase1 = false;
+
+    for (int it = 0;; ++it) {
+      // ---- phase and basic costs --------------------------------------------------------------------------------
+      const double ptol = a.tol_p * (1.0 + fmax(fabs(finite_or_zero(blo)), fabs(finite_or_zero(bhi))));
+      const bool below = lane < m && beta < blo - ptol;
+      const bool above = lane < m && beta > bhi + ptol;
+      phase1 = __ballot(below || above) != 0ull;
+      if (lane < m) {
+        double cb;
+        if (phase1) cb = below ? -1.0 : (above ? 1.0 : 0.0);
+        else cb = 0.0;                                  // filled below from the owning column lane (phase 2)
+        cB_s[lane] = cb;
+      }
+      wave_lds_fence();
+      if (!phase1) {
+        // phase 2: cost of a basic variable lives with its column owner: scatter it to the row that holds it
+#pragma unroll
+        for (int q = 0; q < CQ; ++q) { const int j = lane + 64 * q; if (j < N) xval[j] = cost[q]; }
+        wave_lds_fence();
+        if (lane < m) cB_s[lane] = xval[bvar];
+        wave_lds_fence();
+      }
+      // ---- pricing: d_j = c_j - sum_i cB_i T[i][j] ---------------------------------------------------------------
+      double dj[CQ];
+#pragma unroll
+      for (int q = 0; q < CQ; ++q) dj[q] = phase1 ? 0.0 : cost[q];
+      for (int i = 0; i < m; ++i) {
+        const double cb = cB_s[i];
+#pragma unroll
+        for (int q = 0; q < CQ; ++q) { const int j = lane + 64 * q; if (j < N) dj[q] = fma(-cb, T[i * RS + j], dj[q]); }
+      }
+      const double dtol = phase1 ? 1e-9 : ctol;
+      double score[CQ];
+      double best = -1.0;
+#pragma unroll
+      for (int q = 0; q < CQ; ++q) {
+        const bool free_col = !is_finite(lo[q]) && !is_finite(hi[q]);
+        const bool elig = live[q] && !basic[q] && !fixedv[q] &&
+                          (free_col ? fabs(dj[q]) > dtol : ((!upper[q] && dj[q] < -dtol) || (upper[q] && dj[q] > dtol)));
+        score[q] = elig ? fabs(dj[q]) : -1.0;
+        best = fmax(best, score[q]);
+      }
+      best = wave_max(best);
+      if (best < 0.0) { status = phase1 ? DSP_STATUS_PRIMAL_INFEASIBLE : DSP_STATUS_OPTIMAL; break; }
+      if (it >= a.max_pivots) { status = -1; break; }
+      // entering column: the smallest index among the maxima (as numpy's argmax in the prototype)
+      int jin = -1;
+#pragma unroll
+      for (int q = 0; q < CQ; ++q) {
+        if (jin < 0) {
+          const unsigned long long mk = __ballot(score[q] == best);
+          if (mk) jin = first_lane(mk) + 64 * q;
+        }
+      }
+      const int jl = jin & 63, jq = jin >> 6;
+      // its owner broadcasts direction, bounds and value
+#pragma unroll
+      for (int q = 0; q < CQ; ++q) {
+        if (q == jq && lane == jl) {
+          const bool free_col = !is_finite(lo[q]) && !is_finite(hi[q]);
+          const bool down = free_col ? (dj[q] > 0.0) : upper[q];
+          scal[0] = down ? -1.0 : 1.0;
+          scal[1] = lo[q]; scal[2] = hi[q]; scal[3] = val[q];
+        }
+      }
+      wave_lds_fence();
+      const double sgn = scal[0], jlo = scal[1], jhi = scal[2], jval = scal[3];
+      // ---- ratio test on the row lanes ----------------------------------------------------------------------------
+      const double al = (lane < m) ? T[lane * RS + jin] : 0.0;
+      if (lane < m) alpha_s[lane] = al;
+      const double amax = wave_max(fabs(al));
+      const double ptv = a.tol_piv * fmax(1.0, amax);
+      const double delta = -sgn * al;
+      const bool dec = delta < -ptv, inc = delta > ptv;
+      const bool feas = !below && !above;
+      double ti = kBig;
+      if (lane < m) {
+        if (feas && dec && is_finite(blo)) ti = (beta - blo) / -delta;
+        if (feas && inc && is_finite(bhi)) ti = (bhi - beta) / delta;
+        if (below && inc) ti = (blo - beta) / delta;
+        if (above && dec) ti = (beta - bhi) / -delta;
+        ti = fmax(ti, 0.0);
+      }
+      double tflip = jhi - jlo;
+      if (!is_finite(tflip)) tflip = kBig;
+      const double trow = wave_min(ti);
+      const double tmin = fmin(trow, tflip);
+      if (tmin >= kBig) { status = phase1 ? DSP_STATUS_PRIMAL_INFEASIBLE : DSP_STATUS_DUAL_INFEASIBLE; break; }
+      const bool flip = tflip <= trow;
+      // second pass: the largest pivot among the rows within a hair of the minimum
+      const bool tie = lane < m && ti <= tmin * (1.0 + 1e-9) + 1e-12;
+      const double pv = wave_max(tie ? fabs(al) : -1.0);
+      const int r = first_lane(__ballot(tie && fabs(al) == pv));
+      // ---- move ---------------------------------------------------------------------------------------------------
+      if (lane < m) beta = fma(delta, tmin, beta);
+      const double newval = fma(sgn, tmin, jval);
+      if (flip) {
+#pragma unroll
+        for (int q = 0; q < CQ; ++q)
+          if (q == jq && lane == jl) { val[q] = newval; upper[q] = !upper[q]; }
+        continue;
+      }
+      // leaving variable: the basic of row r, to the bound it reached
+      if (lane == r) {
+        const bool hi_f = is_finite(bhi), lo_f = is_finite(blo);
+        bool to_up = fabs(beta - bhi) < fabs(beta - blo);
+        if (hi_f && !lo_f) to_up = true;
+        if (!hi_f) to_up = false;
+        iscal[0] = bvar;
+        iscal[1] = to_up ? 1 : 0;
+        scal[4] = to_up ? bhi : blo;
+        bvar = jin; beta = newval; blo = jlo; bhi = jhi;
+      }
+      wave_lds_fence();
+      const int jout = iscal[0];
+      const bool out_up = iscal[1] != 0;
+      const double out_val = scal[4];
+#pragma unroll
+      for (int q = 0; q < CQ; ++q) {
+        const int j = lane + 64 * q;
+        if (j == jout) { basic[q] = false; val[q] = out_val; upper[q] = out_up; }
+        if (j == jin) basic[q] = true;
+      }
+      // ---- tableau update: row r /= alpha_r, rows i != r -= alpha_i * row r -------------------------------------
+      const double inv = 1.0 / alpha_s[r];
+      double prow[CQ];
+#pragma unroll
+      for (int q = 0; q < CQ; ++q) { const int j = lane + 64 * q; prow[q] = (j < N) ? T[r * RS + j] * inv : 0.0; }
+      for (int i = 0; i < m; ++i) {
+        const double ai = alpha_s[i];
+#pragma unroll
+        for (int q = 0; q < CQ; ++q) {
+          const int j = lane + 64 * q;
+          if (j < N) T[i * RS + j] = (i == r) ? prow[q] : fma(-ai, prow[q], T[i * RS + j]);
+        }
+      }
+      wave_lds_fence();
+      ++pivots;
+    }
+
+    // ---- assemble the vertex, certify it against the original rows, store ----------------------------------------
+#pragma unroll
+    for (int q = 0; q < CQ; ++q) { const int j = lane + 64 * q; if (j < N) xval[j] = val[q]; }
+    wave_lds_fence();
+    if (lane < m) xval[bvar] = beta;
+    wave_lds_fence();
+    double xs[CQ];
+    double po = 0.0;
+    bool okv = true;
+#pragma unroll
+    for (int q = 0; q < CQ; ++q) {
+      const int j = lane + 64 * q;
+      xs[q] = (j < N) ? xval[j] : 0.0;
+      if (j < N) {
+        const double tol = 1e-9 * (1.0 + fabs(xs[q]));
+        if (xs[q] < lo[q] - tol || xs[q] > hi[q] + tol || !(xs[q] == xs[q])) okv = false;
+      }
+      if (j < n) po = fma(cost[q], xs[q], po);
+    }
+    po = wave_sum(po);
+    if (lane < m) {
+      // row residual with the ORIGINAL scaled matrix: sum_j a_ij x_j - s_i
+      double res = -xval[n + lane], mag = fabs(xval[n + lane]);
+      for (int j = 0; j < n; ++j) {
+        const double t = a.A_dense[(size_t)lane * n + j] * xval[j];
+        res += t; mag += fabs(t);
+      }
+      if (!(fabs(res) <= 1e-9 * (1.0 + mag))) okv = false;
+    }
+    const bool certified = __ballot(!okv) == 0ull;
+    if (status == DSP_STATUS_OPTIMAL && !certified) status = -1;
+    if (status == -1) {
+      if (lane == 0) b.status[s] = DSP_STATUS_UNSOLVED;      // the PDLP kernel takes it from here
+      continue;
+    }
+    // duals: y_i = reduced cost of slack i with the phase-2 costs (recomputed so that a phase-1 stop reports something sane)
+#pragma unroll
+    for (int q = 0; q < CQ; ++q) { const int j = lane + 64 * q; if (j < N) xval[j] = cost[q]; }
+    wave_lds_fence();
+    if (lane < m) cB_s[lane] = xval[bvar];
+    wave_lds_fence();
+    double dsl[CQ];
+#pragma unroll
+    for (int q = 0; q < CQ; ++q) dsl[q] = cost[q];
+    for (int i = 0; i < m; ++i) {
+      const double cb = cB_s[i];
+#pragma unroll
+      for (int q = 0; q < CQ; ++q) { const int j = lane + 64 * q; if (j < N) dsl[q] = fma(-cb, T[i * RS + j], dsl[q]); }
+    }
+#pragma unroll
+    for (int q = 0; q < CQ; ++q) {
+      const int j = lane + 64 * q;
+      if (j < n) b.x[(size_t)s * n + j] = xs[q] * a.col_scale[j];
+      else if (j < N) b.y[(size_t)s * m + (j - n)] = dsl[q] * a.row_scale[j - n];
+    }
+    if (lane == 0) {
+      b.obj[s] = po;
+      b.status[s] = status;
+      if (b.iters) b.iters[s] = pivots;
+      if (b.jumps) b.jumps[s] = 0;
+    }
+    wave_lds_fence();
+  }
+}
+
+}  // namespace
+
+size_t simplex_lds_bytes(int n, int m, int *row_stride) {
+  const int N = n + m;
+  int rs = ((N + 63) / 64) * 64 + 1;                 // odd number of doubles: conflict-free column AND row sweeps
+  if (row_stride) *row_stride = rs;
+  return ((size_t)m * rs + 64 + 64 + 128 + 8 + 8) * sizeof(double);
+}
+
+hipError_t launch_simplex(const SimplexArgs &a, int grid, size_t lds, hipStream_t st) {
+  const int cq = (a.n + a.m + 63) / 64;
+  const void *fn = cq <= 1 ? reinterpret_cast<const void *>(&simplex_kernel<1>)
+                           : reinterpret_cast<const void *>(&simplex_kernel<2>);
+  if (cq > 2) return hipErrorInvalidValue;
+  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  SimplexArgs args = a;
+  void *params[] = {&args};
+  return hipLaunchKernel(fn, dim3(grid), dim3(64), params, lds, st);
+}
+
+}  // namespace dsp

@@ -26,7 +26,7 @@ class DspOptions(C.Structure):
                 ("step_scale", C.c_double), ("weight_guard", C.c_double), ("jump_steady", C.c_double), ("jump_tol", C.c_double),
                 ("jump_min", C.c_double), ("ray_jumps", C.c_int32), ("ruiz_iters", C.c_int32),
                 ("waves_per_block", C.c_int32), ("kkt_every", C.c_int32), ("no_matreg", C.c_int32), ("geo_iters", C.c_int32),
-                ("kkt_gate", C.c_double), ("stall_rescue", C.c_int32), ("reserved", C.c_int32),
+                ("kkt_gate", C.c_double), ("stall_rescue", C.c_int32), ("no_simplex", C.c_int32),
                 ("jump_rel", C.c_double)]
 
 
@@ -48,7 +48,8 @@ class DspStats(C.Structure):
     _fields_ = [("total_iterations", C.c_int64), ("max_iterations", C.c_int32), ("n_optimal", C.c_int32),
                 ("grid_blocks", C.c_int32), ("block_threads", C.c_int32), ("lds_bytes", C.c_int32),
                 ("cols_per_lane", C.c_int32), ("rows_per_lane", C.c_int32), ("kernel_ms", C.c_float),
-                ("matreg", C.c_int32), ("lds_conflicts_identity", C.c_int32), ("lds_conflicts_chosen", C.c_int32)]
+                ("matreg", C.c_int32), ("lds_conflicts_identity", C.c_int32), ("lds_conflicts_chosen", C.c_int32),
+                ("simplex", C.c_int32), ("reserved", C.c_int32)]
 
 
 class DspLpDesc(C.Structure):
@@ -61,7 +62,7 @@ EXPORTED_SYMBOLS = ("dsp_default_options", "dsp_create", "dsp_solve", "dsp_spmv_
                     "dsp_get_scaling", "dsp_destroy", "dsp_strerror", "dsp_last_hip_error", "dsp_version")
 
 
-ABI_VERSION = 3          # DSP_VERSION of the include/dsp_hip.h these structures mirror
+ABI_VERSION = 4          # DSP_VERSION of the include/dsp_hip.h these structures mirror
 
 
 def load_library(path: Optional[str] = None):
@@ -359,7 +360,7 @@ class HipPdlpSolver:
         if tee:
             print(f"[dsp_hip] B={B} n={model.lp.n} m={model.lp.m} nnz={model.lp.nnz} optimal={st.n_optimal}/{B} "
                   f"iters(sum/max)={st.total_iterations}/{st.max_iterations} kernel={st.kernel_ms:.3f} ms "
-                  f"grid={st.grid_blocks}x{st.block_threads} lds={st.lds_bytes}B matreg={st.matreg}")
+                  f"grid={st.grid_blocks}x{st.block_threads} lds={st.lds_bytes}B matreg={st.matreg} simplex={st.simplex}")
         all_ok = bool((status == 0).all())
         return SolveResults("ok" if all_ok else "warning", "optimal" if all_ok else "maxIterations",
                             iterations=int(st.total_iterations), kernel_ms=float(st.kernel_ms))

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define DSP_VERSION 3
+#define DSP_VERSION 4
 
 /* return codes (0 = ok, < 0 = API misuse / HIP error; text via dsp_strerror) */
 #define DSP_OK                 0
@@ -41,6 +41,7 @@ extern "C" {
                                              that needs a Farkas ray is NOT detected (dispatch LPs carry slack columns) */
 #define DSP_STATUS_DUAL_INFEASIBLE    3   /* reserved */
 #define DSP_STATUS_NUMERICAL          4   /* NaN in the input or NaN / Inf met in the iteration                */
+/* DSP_STATUS_DUAL_INFEASIBLE is reported by the simplex path only (an unbounded ray of a tiny LP). */
 
 typedef struct dsp_handle dsp_handle;
 
@@ -101,7 +102,12 @@ typedef struct dsp_options {
                                 and a rescue after 1000 slowed ~70 of the 4096 48-h scenarios 10-25x; 4000 (first
                                 possible trigger at iteration 11 k) touches none of them.  0 = off
                                                                                           default 4000   */
-  int32_t reserved;
+  int32_t no_simplex;        /* 1 = never use the in-wave dense simplex (create time).  LPs with n + m <= 128 and m <= 64
+                                (the hourly real-time-bid and tracking LPs: 24 of the 25 solves of a simulated day) are
+                                solved by a bounded-variable primal simplex on the dense tableau, one LP per wave,
+                                ~(n + m) / 2 pivots instead of thousands of first-order iterations, and the vertex is
+                                certified against the original rows; whatever it does not certify falls through to the
+                                PDLP kernel in the same call                                  default 0      */
   double  jump_rel;          /* ray jump: ... and the ray stays >= jump_rel * (iterations since the anchor was
                                 last reset) steps in its piece.  A jump resets the Halpern anchor; when the pieces
                                 are short the solver otherwise jumps at every opportunity (one jump per ~40
@@ -149,6 +155,9 @@ typedef struct dsp_stats {
   int32_t matreg;            /* 1 = the register-resident-matrix specialisation ran          */
   int32_t lds_conflicts_identity; /* simulated extra LDS cycles per iteration of the gathers, identity layout */
   int32_t lds_conflicts_chosen;   /* ... with the slot permutation chosen at create time          */
+  int32_t simplex;                /* 1 = the in-wave simplex pass ran first (iters[] then counts pivots for the
+                                     scenarios it solved)                                           */
+  int32_t reserved;
 } dsp_stats;
 
 void dsp_default_options(dsp_options *opt);
