@@ -3,6 +3,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
 #include <new>
@@ -10,6 +11,7 @@
 
 #include "dsp_device.hpp"
 #include "dsp_prepare.hpp"
+#include "dsp_stream.hpp"
 
 using namespace dsp;
 
@@ -36,9 +38,10 @@ struct dsp_handle {
   DeviceProblem P{};
   std::vector<void *> allocs;     // device allocations owned by the handle
   std::vector<double> dr, dc;
-  int *queue = nullptr;           // ring of kQueueRing work-queue heads (64 B apart): launches on different streams
-  unsigned queue_next = 0;        // may be in flight together, each needs its own head.  Heads are zeroed once at
-  std::vector<unsigned> queue_base;  // create time and only count up; queue_base[slot] = value before the next launch
+  int *queue = nullptr;           // ring of kQueueRing work-queue slots (64 B apart): launches on different streams may
+  std::atomic<unsigned> queue_next{0};  // be in flight together, each needs its own.  Slot = {queue head, count of
+                                  // scenarios the simplex pass left unsolved}; both are zeroed on the launch's stream
+                                  // right before it (one 8-byte memset), so no host-side bookkeeping of the heads exists
   int lds_limit = 160 * 1024;
   int num_cus = 256;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -49,6 +52,8 @@ struct dsp_handle {
   const double *A_dense = nullptr;   // [m][n] scaled matrix, row-major (simplex only)
   int sx_row_stride = 0;
   size_t sx_lds = 0;
+  int streaming = 0;              // LP too large for the fused kernels: HBM-resident PDLP (dsp_stream.hip)
+  StreamSolver stream;
   int lds_conflicts[4] = {0, 0, 0, 0};   // simulated extra LDS cycles per iteration: y buffer identity/best, x identity/best
 };
 
@@ -180,7 +185,7 @@ const char *dsp_strerror(int code) {
   switch (code) {
     case DSP_OK: return "ok";
     case DSP_ERR_INVALID: return "invalid argument";
-    case DSP_ERR_TOO_LARGE: return "LP too large for the LDS-resident solver (n <= 640, m <= 384 and the matrix must fit LDS)";
+    case DSP_ERR_TOO_LARGE: return "LP too large (more than 4096 vectors longer than the ELL width, or dsp_spmv_step on a streaming handle)";
     case DSP_ERR_HIP: return "HIP runtime error (see dsp_last_hip_error)";
     case DSP_ERR_NO_DEVICE: return "no HIP device";
     case DSP_ERR_ALLOC: return "allocation failed";
@@ -202,9 +207,10 @@ int dsp_create(const dsp_lp_desc *d, int device, const dsp_options *opt, dsp_han
   }
   static const int kCpl[] = {1, 2, 3, 4, 5, 7, 10};
   static const int kRpl[] = {1, 2, 3, 4, 6};
-  const int cpl = pick(kCpl, 7, (d->n + 63) / 64);
-  const int rpl = pick(kRpl, 5, std::max(1, (d->m + 63) / 64));
-  if (cpl < 0 || rpl < 0 || d->n > 65535 || d->m > 65535) return DSP_ERR_TOO_LARGE;
+  int cpl = pick(kCpl, 7, (d->n + 63) / 64);
+  int rpl = pick(kRpl, 5, std::max(1, (d->m + 63) / 64));
+  const bool streaming = cpl < 0 || rpl < 0 || d->n > 65535 || d->m > 65535;
+  if (streaming && d->m < 1) return DSP_ERR_INVALID;
 
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return DSP_ERR_NO_DEVICE;
@@ -230,6 +236,18 @@ int dsp_create(const dsp_lp_desc *d, int device, const dsp_options *opt, dsp_han
   equilibrate(A, h->opt.ruiz_iters, h->dr, h->dc, std::max(0, h->opt.geo_iters));
   HostCSR AT = transpose(A), ATu = transpose(Au);
   h->eta_unit = 1.0 / spectral_norm(A, AT, 500);
+  if (streaming) {
+    // LP beyond the register/LDS-resident kernels (n > 640 or m > 384): HBM-resident PDLP
+    int rc2;
+    h->streaming = 1; h->cpl = h->rpl = 0;
+    if ((rc2 = upload(h, h->dc, &h->P.col_scale)) != DSP_OK || (rc2 = upload(h, h->dr, &h->P.row_scale)) != DSP_OK) { dsp_destroy(h); return rc2; }
+    h->P.n = d->n; h->P.m = d->m;
+    hipError_t se = stream_create(A, AT, h->P.col_scale, h->P.row_scale, &h->stream);
+    if (se != hipSuccess) { g_last_hip_error = (int)se; dsp_destroy(h); return se == hipErrorInvalidValue ? DSP_ERR_TOO_LARGE : DSP_ERR_HIP; }
+    if (hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess) { dsp_destroy(h); return DSP_ERR_HIP; }
+    *out = h;
+    return DSP_OK;
+  }
 
   LaneELL Er = build_lane_ell(A, rpl), Ec = build_lane_ell(AT, cpl);
   // unscaled values in the SAME layout (same sparsity => same W / long split)
@@ -292,7 +310,6 @@ int dsp_create(const dsp_lp_desc *d, int device, const dsp_options *opt, dsp_han
   if (hipMalloc(&q, sizeof(int) * kQueueRing * kQueueStride) != hipSuccess) { dsp_destroy(h); return DSP_ERR_HIP; }
   h->queue = (int *)q;
   if (hipMemset(q, 0, sizeof(int) * kQueueRing * kQueueStride) != hipSuccess) { dsp_destroy(h); return DSP_ERR_HIP; }
-  h->queue_base.assign(kQueueRing, 0u);
   if (hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess) { dsp_destroy(h); return DSP_ERR_HIP; }
   *out = h;
   return DSP_OK;
@@ -313,14 +330,41 @@ int dsp_solve(dsp_handle *h, const dsp_batch *batch, const dsp_options *opt, dsp
       !(a.opt.pid_kp >= 0) || !(a.opt.step_scale > 0))
     return DSP_ERR_INVALID;
   a.eta = a.opt.step_scale * h->eta_unit;
+  if (h->streaming) {
+    const bool timed_s = stats && sync_stats;
+    if (timed_s) HIP_TRY(hipEventRecord(h->ev0, st));
+    int periods = 0;
+    HIP_TRY(stream_solve(&h->stream, *batch, a.opt, a.eta, st, &periods));
+    if (timed_s) HIP_TRY(hipEventRecord(h->ev1, st));
+    if (stats) {
+      std::memset(stats, 0, sizeof(*stats));
+      stats->streaming = 1;
+      stats->grid_blocks = (std::max(h->n, h->m) + 255) / 256; stats->block_threads = 256;
+      stats->stream_bytes_per_iteration = (int64_t)stream_bytes_per_iteration(&h->stream);
+      if (sync_stats) {
+        HIP_TRY(hipStreamSynchronize(st));
+        HIP_TRY(hipEventElapsedTime(&stats->kernel_ms, h->ev0, h->ev1));
+        std::vector<int32_t> hs(B), hi(B);
+        HIP_TRY(hipMemcpy(hs.data(), batch->status, B * sizeof(int32_t), hipMemcpyDeviceToHost));
+        if (batch->iters) HIP_TRY(hipMemcpy(hi.data(), batch->iters, B * sizeof(int32_t), hipMemcpyDeviceToHost));
+        for (int i = 0; i < B; ++i) {
+          stats->n_optimal += hs[i] == DSP_STATUS_OPTIMAL;
+          if (batch->iters) { stats->total_iterations += hi[i]; stats->max_iterations = std::max(stats->max_iterations, hi[i]); }
+        }
+      }
+    }
+    return DSP_OK;
+  }
   Geometry geo;
   int grc = solve_geometry(h, a.opt.waves_per_block, B, &geo);
   if (grc != DSP_OK) return grc;
   a.waves_per_block = geo.wpb;
   const size_t lds = geo.lds;
-  const unsigned slot = h->queue_next++ % kQueueRing;
+  const unsigned slot = h->queue_next.fetch_add(1u) % kQueueRing;
   a.queue = h->queue + (size_t)slot * kQueueStride;
-  a.queue_base = h->queue_base[slot];
+  a.queue_base = 0u;
+  a.unsolved = a.queue + 1;
+  HIP_TRY(hipMemsetAsync(a.queue, 0, 2 * sizeof(int), st));
   a.matreg = h->matreg;
   int grid = std::min((B + geo.wpb - 1) / geo.wpb, h->num_cus * geo.blocks_per_cu);
   const bool timed = stats && sync_stats;
@@ -331,13 +375,13 @@ int dsp_solve(dsp_handle *h, const dsp_batch *batch, const dsp_options *opt, dsp
     sa.n = h->n; sa.m = h->m; sa.row_stride = h->sx_row_stride; sa.max_pivots = 20 * (h->n + h->m);
     sa.A_dense = h->A_dense; sa.col_scale = h->P.col_scale; sa.row_scale = h->P.row_scale; sa.b = *batch;
     sa.tol_p = 1e-10; sa.tol_d = 1e-12; sa.tol_piv = 1e-9;
+    sa.unsolved = a.queue + 1;
     const int per_cu = std::max<int>(1, std::min<int>(32, (int)((size_t)h->lds_limit / h->sx_lds)));
     const int sgrid = std::min(B, h->num_cus * per_cu);
     HIP_TRY(launch_simplex(sa, sgrid, h->sx_lds, st));
     a.skip_solved = 1;
   }
   HIP_TRY(launch_solve(h->cpl, h->rpl, a, dim3(grid), dim3(64 * a.waves_per_block), lds, st));
-  h->queue_base[slot] += (unsigned)B + (unsigned)grid * (unsigned)a.waves_per_block;   // B hits + one miss per wave
   if (timed) HIP_TRY(hipEventRecord(h->ev1, st));
   if (stats) {
     std::memset(stats, 0, sizeof(*stats));
@@ -363,16 +407,20 @@ int dsp_solve(dsp_handle *h, const dsp_batch *batch, const dsp_options *opt, dsp
 int dsp_spmv_step(dsp_handle *h, int32_t B, const double *X, const double *Y, double *AX, double *ATY, void *hipStream) {
   if (!h || B < 0 || !X || !Y || !AX || !ATY) return DSP_ERR_INVALID;
   if (B == 0) return DSP_OK;
+  if (h->streaming) return DSP_ERR_TOO_LARGE;        // the streaming solver has its own fused sweeps
   HIP_TRY(hipSetDevice(h->device));
   SpmvArgs a{};
   a.P = h->P; a.B = B; a.X = X; a.Y = Y; a.AX = AX; a.ATY = ATY;
-  // development knobs: DSP_SPMV_LDS=1 forces the LDS-staged form, DSP_SPMV_WAVES_PER_CU caps the resident waves per CU
-  // of the register-resident form (fewer waves = more scenarios per wave = fewer matrix loads, less in flight)
-  static const bool force_lds = getenv("DSP_SPMV_LDS") && atoi(getenv("DSP_SPMV_LDS")) != 0;
+  // Two forms of the streaming step exist.  Default: the matrix is staged once per 8-wave block in LDS (shared by its
+  // waves).  DSP_SPMV_REG=1 selects the register-resident-matrix form (one scenario per wave, no block barrier, every
+  // load in flight at once), measured SLOWER at every batch size on MI355X (r02e: 7.1-7.6 vs 6.7 us at 4096 x 24 h,
+  // 14.8-16.0 vs 11.3 us at 4096 x 48 h): each wave pulls its own 16-28 matrix entries through the vector memory path,
+  // 7x the bytes of the vectors it streams.  DSP_SPMV_WAVES_PER_CU caps its resident waves, DSP_SPMV_WPB the block
+  // size of the default form.
+  static const bool use_reg = getenv("DSP_SPMV_REG") && atoi(getenv("DSP_SPMV_REG")) != 0;
   static const int waves_cap = getenv("DSP_SPMV_WAVES_PER_CU") ? atoi(getenv("DSP_SPMV_WAVES_PER_CU")) : 32;
-  if (h->matreg && !force_lds) {
-    // register-resident-matrix form: one scenario per wave, 4-wave blocks, the whole batch resident at once when it
-    // fits (32 waves per CU); LDS = the waves' exchange buffers (+ long-vector tails)
+  static const int wpb_env = getenv("DSP_SPMV_WPB") ? atoi(getenv("DSP_SPMV_WPB")) : 0;
+  if (h->matreg && use_reg) {
     a.waves_per_block = 4;
     const size_t lds = ((size_t)h->P.mr_tailc_entries + h->P.mr_tailr_entries) * sizeof(Entry) +
                        (size_t)a.waves_per_block * (h->P.n_pad + h->P.m_pad) * 8;
@@ -383,7 +431,7 @@ int dsp_spmv_step(dsp_handle *h, int32_t B, const double *X, const double *Y, do
     return DSP_OK;
   }
   // generic form (matrix staged in LDS per block): 8-wave blocks, as many as LDS admits per CU
-  a.waves_per_block = kMaxWavesPerBlock;
+  a.waves_per_block = wpb_env > 0 ? std::min(wpb_env, kMaxWavesPerBlock) : kMaxWavesPerBlock;
   size_t lds = lds_bytes(h->P, a.waves_per_block);
   while (lds > (size_t)h->lds_limit && a.waves_per_block > 1) lds = lds_bytes(h->P, --a.waves_per_block);
   if (lds > (size_t)h->lds_limit) return DSP_ERR_TOO_LARGE;
@@ -413,6 +461,7 @@ int dsp_destroy(dsp_handle *h) {
   if (!h) return DSP_OK;
   (void)hipSetDevice(h->device);
   for (void *p : h->allocs) (void)hipFree(p);
+  stream_destroy(&h->stream);
   if (h->queue) (void)hipFree(h->queue);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);

@@ -59,8 +59,9 @@ struct SolveArgs {
   int waves_per_block;
   double eta;
   dsp_options opt;
-  int *queue;                  // device work-queue head: counts up for ever, this launch's scenarios are
-  unsigned queue_base;         //   head - queue_base (every wave overshoots exactly once when it finds the queue empty)
+  int *queue;                  // device work-queue head of this launch (zeroed on the stream right before it)
+  unsigned queue_base;         //   scenario = ticket - queue_base (0 since the heads are reset per launch)
+  const int *unsolved;         // skip_solved: number of scenarios the simplex pass left unsolved (0 = nothing to do)
   int matreg;                  // 1 = register-resident-matrix specialisation of the kernel
 };
 
@@ -73,6 +74,7 @@ struct SimplexArgs {
   const double *col_scale, *row_scale;
   dsp_batch b;
   double tol_p, tol_d, tol_piv;
+  int *unsolved;               // incremented for every scenario left to the PDLP kernel
 };
 
 struct SpmvArgs {

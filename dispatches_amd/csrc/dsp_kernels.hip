@@ -37,11 +37,8 @@
 
 namespace dsp {
 
-#ifdef DSP_NO_DRAIN
-#define DSP_DRAIN() do { } while (0)
-#else
-#define DSP_DRAIN() __builtin_amdgcn_s_waitcnt(0)
-#endif
+// DSP_LEGACY_PULL (development): the round-1 form of the work-queue pull, kept to reproduce the hang it caused - see
+// the comment at the pull.
 #ifdef DSP_DEBUG_TRACE
 #define DSP_TRACE(...) do { if (threadIdx.x == 0 && blockIdx.x == 0) printf(__VA_ARGS__); } while (0)
 #else
@@ -169,6 +166,8 @@ template <int CPL, int RPL, bool LONG, unsigned WC, unsigned WR>
 __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 2) pdlp_solve_kernel(SolveArgs a) {
   constexpr bool MATREG = WC != 0;
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  // after a simplex pass that certified every scenario there is nothing to do (one scalar load per wave)
+  if (a.skip_solved && __builtin_amdgcn_readfirstlane(*a.unsolved) == 0) return;
   const DeviceProblem &P = a.P;
   const dsp_batch &b = a.b;
   const int lane = threadIdx.x & 63;
@@ -267,9 +266,26 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
 #endif
   for (;;) {
     // ---- pull the next scenario off the work queue ---------------------------------------------------------
+    // EVERY lane takes part in the atomic (lane 0 adds 1, the others 0; the compiler's atomic optimiser turns that into
+    // one global atomic per wave) and the ticket is read from lane 0 explicitly.  Round 1 wrote
+    //     if (lane == 0) s = atomicAdd(queue, 1);  s = readfirstlane(s);
+    // and needed an s_waitcnt 0 after the result stores at the bottom of the loop "against a hang".  Root cause (round 2,
+    // tools/gpu_drain_modes.sh: a compiler-only barrier `asm volatile("" ::: "memory")` in place of that s_waitcnt cures it
+    // just as well, so no memory ordering is involved): the loop body ends with `if (lane == 0) { stores }` and began with
+    // `if (lane == 0) { atomic }`; with nothing side-effecting in between, the compiler threads the divergent
+    // `lane == 0` branch across the back-edge, the wave re-enters the pull with a partial EXEC mask, v_readfirstlane
+    // returns the value of a lane that did not run the atomic (s = 0), and every wave re-solves scenario 0 for ever -
+    // "hung at the end of the first scenario of every wave".  A pull without a divergent branch and without
+    // readfirstlane has nothing to thread and does not depend on EXEC.
+#ifdef DSP_LEGACY_PULL
     int s = 0;
-    if (lane == 0) s = (int)((unsigned)atomicAdd(a.queue, 1) - a.queue_base);   // heads only ever count up: no reset
+    if (lane == 0) s = (int)((unsigned)atomicAdd(a.queue, 1) - a.queue_base);   
     s = __builtin_amdgcn_readfirstlane(s);
+#else
+    __builtin_amdgcn_wave_barrier();
+    const int ticket = (int)((unsigned)atomicAdd(a.queue, lane == 0 ? 1 : 0) - a.queue_base);
+    const int s = __builtin_amdgcn_readlane(ticket, 0);
+#endif
     DSP_TRACE("[trace] scenario %d\n", s);
     if ((unsigned)s >= (unsigned)b.B) break;
     if (a.skip_solved && __builtin_amdgcn_readfirstlane(b.status[s]) != DSP_STATUS_UNSOLVED) continue;
@@ -338,7 +354,6 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
         if (b.iters) b.iters[s] = 0;
         if (b.jumps) b.jumps[s] = 0;
       }
-      DSP_DRAIN();
       continue;
     }
     const double qn = sqrt(nrm[0]), cn = sqrt(nrm[1]);
@@ -664,14 +679,12 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
       const int j = col_id(q);
       if (j >= 0) b.x[(size_t)s * n + j] = xp[q] * P.col_scale[j];
     }
-    DSP_DRAIN();
     DSP_TRACE("[trace] x stored %p\n", (void *)b.x);
 #pragma unroll
     for (int q = 0; q < RPL; ++q) {
       const int i = row_id(q);
       if (i >= 0) b.y[(size_t)s * m + i] = yp[q] * P.row_scale[i];
     }
-    DSP_DRAIN();
     DSP_TRACE("[trace] y stored %p obj %p status %p iters %p jumps %p pw %p queue %p\n", (void *)b.y, (void *)b.obj, (void *)b.status, (void *)b.iters, (void *)b.jumps, (void *)b.primal_weight, (void *)a.queue);
     if (lane == 0) {
       b.obj[s] = pobj;
@@ -683,7 +696,6 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
       if (b.jumps) b.jumps[s] = njump;
       if (b.primal_weight) b.primal_weight[s] = w;
     }
-    DSP_DRAIN();
     DSP_TRACE("[trace] scalars stored\n");
   }
 #ifdef DSP_CLOCKS

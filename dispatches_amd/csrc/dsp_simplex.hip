@@ -156,7 +156,8 @@ __global__ void __launch_bounds__(64) simplex_kernel(SimplexArgs a) {
       double dj[CQ];
 #pragma unroll
       for (int q = 0; q < CQ; ++q) dj[q] = phase1 ? 0.0 : cost[q];
-      for (int i = 0; i < m; ++i) {
+#pragma unroll 4
+      for (int i = 0; i < m; ++i) {               // loads only: unrolled so that four rows' LDS reads are in flight together
         const double cb = cB_s[i];
 #pragma unroll
         for (int q = 0; q < CQ; ++q) { const int j = lane + 64 * q; if (j < N) dj[q] = fma(-cb, T[i * RS + j], dj[q]); }
@@ -258,12 +259,27 @@ __global__ void __launch_bounds__(64) simplex_kernel(SimplexArgs a) {
       double prow[CQ];
 #pragma unroll
       for (int q = 0; q < CQ; ++q) { const int j = lane + 64 * q; prow[q] = (j < N) ? T[r * RS + j] * inv : 0.0; }
-      for (int i = 0; i < m; ++i) {
-        const double ai = alpha_s[i];
+      // four rows per step: all their LDS reads are issued before the first dependent store (the compiler cannot
+      // prove that the rows do not alias and would otherwise serialise load -> fma -> store per row)
+      for (int i0 = 0; i0 < m; i0 += 4) {
+        double ai[4], tv[4][CQ];
 #pragma unroll
-        for (int q = 0; q < CQ; ++q) {
-          const int j = lane + 64 * q;
-          if (j < N) T[i * RS + j] = (i == r) ? prow[q] : fma(-ai, prow[q], T[i * RS + j]);
+        for (int u = 0; u < 4; ++u) {
+          const int i = min(i0 + u, m - 1);
+          ai[u] = alpha_s[i];
+#pragma unroll
+          for (int q = 0; q < CQ; ++q) { const int j = lane + 64 * q; tv[u][q] = (j < N) ? T[i * RS + j] : 0.0; }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int i = i0 + u;
+          if (i < m) {
+#pragma unroll
+            for (int q = 0; q < CQ; ++q) {
+              const int j = lane + 64 * q;
+              if (j < N) T[i * RS + j] = (i == r) ? prow[q] : fma(-ai[u], prow[q], tv[u][q]);
+            }
+          }
         }
       }
       wave_lds_fence();
@@ -302,7 +318,7 @@ __global__ void __launch_bounds__(64) simplex_kernel(SimplexArgs a) {
     const bool certified = __ballot(!okv) == 0ull;
     if (status == DSP_STATUS_OPTIMAL && !certified) status = -1;
     if (status == -1) {
-      if (lane == 0) b.status[s] = DSP_STATUS_UNSOLVED;      // the PDLP kernel takes it from here
+      if (lane == 0) { b.status[s] = DSP_STATUS_UNSOLVED; atomicAdd(a.unsolved, 1); }   // the PDLP kernel takes it from here
       continue;
     }
     // duals: y_i = reduced cost of slack i with the phase-2 costs (recomputed so that a phase-1 stop reports something sane)
@@ -314,6 +330,7 @@ __global__ void __launch_bounds__(64) simplex_kernel(SimplexArgs a) {
     double dsl[CQ];
 #pragma unroll
     for (int q = 0; q < CQ; ++q) dsl[q] = cost[q];
+#pragma unroll 4
     for (int i = 0; i < m; ++i) {
       const double cb = cB_s[i];
 #pragma unroll

@@ -1,0 +1,683 @@
+// dsp_stream.hip — HBM-resident ("streaming") batched PDLP for LPs too large for the register/LDS-resident kernels
+// (gfx950).  Workload: the long-horizon price-taker design LPs of the reference (SURVEY.md 8(f)-4:
+// wind_battery_LMP.py:172-269, 8736 hourly periods -> n, m ~ 5e4) solved for a family of B scenarios that share the
+// constraint matrix and differ in (c, bounds) - e.g. capital-cost x price sweeps, the 60-point (h2_price x
+// pem_capacity) enumeration of price_taker_analysis.py:353-419.
+//
+// Here one scenario's state (x, anchor, y, anchor, c, bounds: ~12 vectors of n or m doubles, MBs) cannot live on a
+// CU, so - unlike the fused kernels - the PDHG iteration really streams from HBM, and the 8 TB/s roofline is what
+// bounds it.  Same algorithm as dsp_kernels.hip (restarted, reflected Halpern PDHG on the Ruiz + Pock-Chambolle scaled
+// problem, PDLP restart criteria, proportional primal-weight controller with rounding guard, relative KKT termination in
+// the original space + the eps_obj objective-error bounds); no ray jumps / stall rescue on this path.
+//
+// Structure: an iteration is two grid-wide dependent steps (A^T y for the primal step, A (2x+ - x) for the dual step),
+// i.e. two kernel launches (a kernel boundary costs ~1.5 us on MI355X, an in-kernel grid barrier ~4 us, so launches
+// it is).  The Halpern averaging is fused into the dual-step launch (rows do the dual step, columns the averaging of
+// x), so a plain iteration moves, per scenario, 11 n + 7 m doubles:
+//     k_primal        reads x, c, lb, ub (+ gathers y)          writes x+, xbar = 2x+ - x
+//     k_dual_halpern  reads y, y0, rlo, rhi (+ gathers xbar)    writes y+, y ;   reads x, x+, x0, writes x
+// Every `check_every` iterations the dual step is replaced by a check sequence (k_check_rows, k_kkt_cols, k_control,
+// k_apply) that produces the fixed-point residual, the KKT quantities and the restart / termination decision of every
+// scenario ON THE DEVICE; per-scenario control state lives in HBM, so the host only enqueues launches and polls a
+// "scenarios finished" counter every few check periods.  Reductions are two-stage and ordered (block partials in a
+// fixed layout, summed by one block per scenario), so a solve is bit-reproducible.
+//
+// Matrix layout: ELL, entry-major ([W][nvec]: thread v reads entry e at e * nvec + v, coalesced) for A (rows) and A^T
+// (columns); the matrix is read once per thread and reused across the SG scenarios a thread processes.  Vectors longer
+// than the ELL width (design columns that touch every period) are "long": CSR segments reduced by one block each.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+#include "dsp_device.hpp"
+#include "dsp_stream.hpp"
+
+namespace dsp {
+
+namespace {
+
+constexpr int kTB = 256;                // threads per block
+constexpr int kNQ = 16;                 // partial-sum slots per (scenario, block)
+
+__device__ __forceinline__ double fin0(double v) { return (fabs(v) < INFINITY) ? v : 0.0; }
+__device__ __forceinline__ bool finite_d(double v) { return fabs(v) < INFINITY; }
+__device__ __forceinline__ double clampd2(double v, double lo, double hi) { return fmin(fmax(v, lo), hi); }
+
+// block-wide ordered sum of NQ quantities -> partial[(b * nblk + blk) * kNQ + q]   (wave shuffles, then LDS across waves)
+template <int NQ>
+__device__ __forceinline__ void block_partials(double (&v)[NQ], double *partial_out) {
+  __shared__ double red[kTB / 64][kNQ];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    double t = v[q];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off, 64);
+    if (lane == 0) red[wave][q] = t;
+  }
+  __syncthreads();
+  if (threadIdx.x < NQ) {
+    double t = 0.0;
+#pragma unroll
+    for (int w = 0; w < kTB / 64; ++w) t += red[w][threadIdx.x];
+    partial_out[threadIdx.x] = t;
+  }
+  __syncthreads();
+}
+
+// sum_e val[e][v] * vec[idx[e][v]]  for one vector v of an entry-major ELL
+__device__ __forceinline__ double ell_dot(const StreamMatrix &M, int v, const double *__restrict__ vec) {
+  double s = 0.0;
+  for (int e = 0; e < M.W; ++e) s = fma(M.val[(size_t)e * M.nvec + v], vec[M.idx[(size_t)e * M.nvec + v]], s);
+  return s;
+}
+
+// one block reduces one long vector (CSR segment) against `vec`
+__device__ __forceinline__ double long_dot(const StreamMatrix &M, int l, const double *__restrict__ vec) {
+  __shared__ double red[kTB / 64];
+  double s = 0.0;
+  for (int p = M.long_ptr[l] + threadIdx.x; p < M.long_ptr[l + 1]; p += kTB) s = fma(M.long_val[p], vec[M.long_idx[p]], s);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  double t = 0.0;
+#pragma unroll
+  for (int w = 0; w < kTB / 64; ++w) t += red[w];
+  __syncthreads();
+  return t;                                     // every thread holds the total
+}
+
+// ---- init: scale the scenario's data, starting point, norms -----------------------------------------------------------
+// partial slots: 0 |q|^2 unscaled (row + col bounds), 1 |c|^2 unscaled, 2 |q_rows|^2 scaled, 3 |c|^2 scaled,
+//                4 sum of squared finite scaled column bounds; max slots (combined with fmax): 5 cmax, 6 qmax, 7 bad
+__global__ void k_init(StreamArgs a) {
+  const StreamProblem &P = a.P;
+  const dsp_batch &b = a.b;
+  const int t = blockIdx.x * kTB + threadIdx.x;
+  const int s = blockIdx.y;
+  const size_t on = (size_t)s * P.n, om = (size_t)s * P.m;
+  double v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (t < P.n) {
+    const double d = P.col_scale[t];
+    const double cu = b.c[(size_t)s * b.c_stride + t];
+    const double lu = b.var_lb ? b.var_lb[(size_t)s * b.var_lb_stride + t] : -INFINITY;
+    const double uu = b.var_ub ? b.var_ub[(size_t)s * b.var_ub_stride + t] : INFINITY;
+    const double cs = cu * d, ls = lu / d, us = uu / d;
+    a.W.c[on + t] = cs; a.W.lb[on + t] = ls; a.W.ub[on + t] = us;
+    const double x0 = clampd2((b.x0 ? b.x0[on + t] / d : 0.0), ls, us);
+    a.W.x[on + t] = x0; a.W.x0[on + t] = x0; a.W.xp[on + t] = x0; a.W.xbar[on + t] = x0;
+    v[0] += fin0(lu) * fin0(lu) + fin0(uu) * fin0(uu);
+    v[1] += cu * cu;
+    v[3] += cs * cs;
+    v[4] += fin0(ls) * fin0(ls) + fin0(us) * fin0(us);
+    v[5] = fabs(cs);
+    if (!(lu <= uu) || !(cu == cu)) v[7] = 1.0;
+  }
+  if (t < P.m) {
+    const double d = P.row_scale[t];
+    const double lo = b.row_lb ? b.row_lb[(size_t)s * b.row_lb_stride + t] : -INFINITY;
+    const double hi = b.row_ub ? b.row_ub[(size_t)s * b.row_ub_stride + t] : INFINITY;
+    const double ls = lo * d, hs = hi * d;
+    a.W.rlo[om + t] = ls; a.W.rhi[om + t] = hs;
+    double ys = b.y0 ? b.y0[om + t] / d : 0.0;
+    if (!finite_d(ls)) ys = fmin(ys, 0.0);
+    if (!finite_d(hs)) ys = fmax(ys, 0.0);
+    a.W.y[om + t] = ys; a.W.y0[om + t] = ys; a.W.yp[om + t] = ys;
+    const double big = fmax(fabs(fin0(lo)), fabs(fin0(hi))), bigs = fmax(fabs(fin0(ls)), fabs(fin0(hs)));
+    v[0] += big * big;
+    v[2] += bigs * bigs;
+    v[6] = bigs;
+    if (!(lo <= hi)) v[7] = 1.0;
+  }
+  // sums in slots 0-4, maxima in 5-7: reduce the maxima separately
+  __shared__ double mx[kTB / 64][3];
+  double m5 = v[5], m6 = v[6], m7 = v[7];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    m5 = fmax(m5, __shfl_down(m5, off, 64)); m6 = fmax(m6, __shfl_down(m6, off, 64)); m7 = fmax(m7, __shfl_down(m7, off, 64));
+  }
+  if ((threadIdx.x & 63) == 0) { mx[threadIdx.x >> 6][0] = m5; mx[threadIdx.x >> 6][1] = m6; mx[threadIdx.x >> 6][2] = m7; }
+  double sums[5] = {v[0], v[1], v[2], v[3], v[4]};
+  double *out = a.W.partial + ((size_t)s * a.nblk + blockIdx.x) * kNQ;
+  block_partials<5>(sums, out);
+  if (threadIdx.x == 0) {
+    double q5 = 0, q6 = 0, q7 = 0;
+    for (int w = 0; w < kTB / 64; ++w) { q5 = fmax(q5, mx[w][0]); q6 = fmax(q6, mx[w][1]); q7 = fmax(q7, mx[w][2]); }
+    out[5] = q5; out[6] = q6; out[7] = q7;
+  }
+}
+
+// one block per scenario: finish the init reductions, set up the control block
+__global__ void k_init_control(StreamArgs a) {
+  const int s = blockIdx.x;
+  __shared__ double acc[8];
+  if (threadIdx.x < 8) {
+    double t = 0.0;
+    for (int blk = 0; blk < a.nblk; ++blk) {
+      const double p = a.W.partial[((size_t)s * a.nblk + blk) * kNQ + threadIdx.x];
+      t = threadIdx.x < 5 ? t + p : fmax(t, p);
+    }
+    acc[threadIdx.x] = t;
+  }
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  StreamCtrl &c = a.W.ctrl[s];
+  const dsp_options &o = a.opt;
+  c = StreamCtrl{};
+  c.qn = sqrt(acc[0]); c.cn = sqrt(acc[1]);
+  const double qs = sqrt(acc[2]), cs = sqrt(acc[3]);
+  const double qall = sqrt(acc[2] + acc[4]);
+  c.c0 = a.b.obj_offset ? a.b.obj_offset[(size_t)s * a.b.obj_offset_stride] : 0.0;
+  double w = (cs > 1e-10 && qs > 1e-10) ? cs / qs : 1.0;
+  c.w_lo = o.weight_guard > 0.0 ? o.weight_guard * a.eta * 1.1e-16 * acc[5] / (o.eps_rel * (1.0 + qall)) : 0.0;
+  c.w_hi = (o.weight_guard > 0.0 && acc[6] > 0.0) ? o.eps_rel * (1.0 + cs) / (o.weight_guard * a.eta * 1.1e-16 * acc[6]) : INFINITY;
+  if (a.b.primal_weight) { const double wi = a.b.primal_weight[s]; if (wi > 0.0 && finite_d(wi)) w = wi; }
+  c.w = w; c.tau = a.eta / w; c.sig = a.eta * w;
+  c.r0 = INFINITY; c.rprev = INFINITY;
+  c.k = 0; c.it = 0; c.status = DSP_STATUS_ITERATION_LIMIT; c.done = 0; c.mode = 0;
+  if (acc[7] > 0.0) {                       // crossed bounds / NaN input: flagged, never iterated
+    c.done = 1;
+    c.status = (acc[0] == acc[0] && acc[1] == acc[1]) ? DSP_STATUS_PRIMAL_INFEASIBLE : DSP_STATUS_NUMERICAL;
+    c.pobj = NAN;
+    atomicAdd(a.W.ndone, 1);
+  }
+}
+
+// ---- primal step -----------------------------------------------------------------------------------------------------
+// grid: (column blocks + one block per long column, scenario groups)
+template <int SG>
+__global__ void k_primal(StreamArgs a) {
+  const StreamProblem &P = a.P;
+  const int b0 = blockIdx.y * SG;
+  if ((int)blockIdx.x >= a.nblk_n) {
+    // long column: A^T y by one block
+    const int l = blockIdx.x - a.nblk_n;
+    const int j = P.C.long_id[l];
+    for (int u = 0; u < SG; ++u) {
+      const int s = b0 + u;
+      if (s >= a.b.B) break;
+      const StreamCtrl &c = a.W.ctrl[s];
+      if (c.done) continue;
+      const double aty = long_dot(P.C, l, a.W.y + (size_t)s * P.m);
+      if (threadIdx.x == 0) {
+        const size_t at = (size_t)s * P.n + j;
+        const double x = a.W.x[at];
+        const double gx = fma(-c.tau, a.W.c[at] - aty, x);
+        const double xp = clampd2(gx, a.W.lb[at], a.W.ub[at]);
+        a.W.xp[at] = xp; a.W.xbar[at] = 2.0 * xp - x;
+      }
+    }
+    return;
+  }
+  const int j = blockIdx.x * kTB + threadIdx.x;
+  if (j >= P.n || P.C.is_long[j]) return;
+  double val[kStreamMaxW];
+  int idx[kStreamMaxW];
+  for (int e = 0; e < P.C.W; ++e) { val[e] = P.C.val[(size_t)e * P.n + j]; idx[e] = P.C.idx[(size_t)e * P.n + j]; }
+#pragma unroll
+  for (int u = 0; u < SG; ++u) {
+    const int s = b0 + u;
+    if (s >= a.b.B) break;
+    const StreamCtrl &c = a.W.ctrl[s];
+    if (c.done) continue;
+    const double *__restrict__ y = a.W.y + (size_t)s * P.m;
+    double aty = 0.0;
+    for (int e = 0; e < P.C.W; ++e) aty = fma(val[e], y[idx[e]], aty);
+    const size_t at = (size_t)s * P.n + j;
+    const double x = a.W.x[at];
+    const double gx = fma(-c.tau, a.W.c[at] - aty, x);
+    const double xp = clampd2(gx, a.W.lb[at], a.W.ub[at]);
+    a.W.xp[at] = xp; a.W.xbar[at] = 2.0 * xp - x;
+  }
+}
+
+// ---- dual step + Halpern averaging (plain iterations) -----------------------------------------------------------------
+// thread t: row t (dual step, y averaging) and column t (x averaging); kofs = iterations since the last check
+template <int SG>
+__global__ void k_dual_halpern(StreamArgs a, int kofs) {
+  const StreamProblem &P = a.P;
+  const int b0 = blockIdx.y * SG;
+  if ((int)blockIdx.x >= a.nblk) {
+    const int l = blockIdx.x - a.nblk;          // long row
+    const int i = P.R.long_id[l];
+    for (int u = 0; u < SG; ++u) {
+      const int s = b0 + u;
+      if (s >= a.b.B) break;
+      const StreamCtrl &c = a.W.ctrl[s];
+      if (c.done) continue;
+      const double ax = long_dot(P.R, l, a.W.xbar + (size_t)s * P.n);
+      if (threadIdx.x == 0) {
+        const size_t at = (size_t)s * P.m + i;
+        const double y = a.W.y[at];
+        const double gy = fma(-c.sig, ax, y);
+        const double yp = gy - clampd2(gy, -c.sig * a.W.rhi[at], -c.sig * a.W.rlo[at]);
+        const double oml = 1.0 / (double)(c.k + kofs + 3);   // k counts this iteration: anchor weight 1 / (k + 2)
+        const double tt = 2.0 * yp - y;
+        a.W.yp[at] = yp; a.W.y[at] = fma(oml, a.W.y0[at] - tt, tt);
+      }
+    }
+    return;
+  }
+  const int t = blockIdx.x * kTB + threadIdx.x;
+  const bool row = t < P.m && !P.R.is_long[t < P.m ? t : 0];
+  double val[kStreamMaxW];
+  int idx[kStreamMaxW];
+  if (row) for (int e = 0; e < P.R.W; ++e) { val[e] = P.R.val[(size_t)e * P.m + t]; idx[e] = P.R.idx[(size_t)e * P.m + t]; }
+#pragma unroll
+  for (int u = 0; u < SG; ++u) {
+    const int s = b0 + u;
+    if (s >= a.b.B) break;
+    const StreamCtrl &c = a.W.ctrl[s];
+    if (c.done) continue;
+    const double oml = 1.0 / (double)(c.k + kofs + 3);   // k counts this iteration: anchor weight 1 / (k + 2)
+    if (row) {
+      const double *__restrict__ xb = a.W.xbar + (size_t)s * P.n;
+      double ax = 0.0;
+      for (int e = 0; e < P.R.W; ++e) ax = fma(val[e], xb[idx[e]], ax);
+      const size_t at = (size_t)s * P.m + t;
+      const double y = a.W.y[at];
+      const double gy = fma(-c.sig, ax, y);
+      const double yp = gy - clampd2(gy, -c.sig * a.W.rhi[at], -c.sig * a.W.rlo[at]);
+      const double tt = 2.0 * yp - y;
+      a.W.yp[at] = yp; a.W.y[at] = fma(oml, a.W.y0[at] - tt, tt);
+    }
+    if (t < P.n) {
+      const size_t at = (size_t)s * P.n + t;
+      const double x = a.W.x[at];
+      const double tt = 2.0 * a.W.xp[at] - x;
+      a.W.x[at] = fma(oml, a.W.x0[at] - tt, tt);
+    }
+  }
+}
+
+// ---- check iteration, rows: dual step WITHOUT averaging + residual and KKT row quantities -------------------------------
+// partial slots (per scenario, block): 0 px = |dx|^2, 1 py = sum dy (2 (-sig A dx) + dy), 2 pres^2, 3 sum |y+| viol,
+// 4 dual objective (row part), 5 |y+ - y0|^2, 6 |x+ - x0|^2
+template <int SG>
+__global__ void k_check_rows(StreamArgs a) {
+  const StreamProblem &P = a.P;
+  const int b0 = blockIdx.y * SG;
+  const int t = blockIdx.x * kTB + threadIdx.x;
+  const bool is_long_block = (int)blockIdx.x >= a.nblk;
+  const bool row = !is_long_block && t < P.m && !P.R.is_long[t < P.m ? t : 0];
+  double val[kStreamMaxW];
+  int idx[kStreamMaxW];
+  if (row) for (int e = 0; e < P.R.W; ++e) { val[e] = P.R.val[(size_t)e * P.m + t]; idx[e] = P.R.idx[(size_t)e * P.m + t]; }
+  for (int u = 0; u < SG; ++u) {
+    const int s = b0 + u;
+    if (s >= a.b.B) break;
+    const StreamCtrl &c = a.W.ctrl[s];
+    double v[7] = {0, 0, 0, 0, 0, 0, 0};
+    if (!c.done) {
+      const double *__restrict__ xb = a.W.xbar + (size_t)s * P.n;
+      const double *__restrict__ xpv = a.W.xp + (size_t)s * P.n;
+      int i = -1;
+      double axb = 0.0, axp = 0.0;
+      if (is_long_block) {
+        const int l = blockIdx.x - a.nblk;
+        const double t1 = long_dot(P.R, l, xb), t2 = long_dot(P.R, l, xpv);
+        if (threadIdx.x == 0) { i = P.R.long_id[l]; axb = t1; axp = t2; }
+      } else if (row) {
+        i = t;
+        for (int e = 0; e < P.R.W; ++e) { axb = fma(val[e], xb[idx[e]], axb); axp = fma(val[e], xpv[idx[e]], axp); }
+      }
+      if (i >= 0) {
+        const size_t at = (size_t)s * P.m + i;
+        const double y = a.W.y[at], rlo = a.W.rlo[at], rhi = a.W.rhi[at];
+        const double gy = fma(-c.sig, axb, y);
+        const double yp = gy - clampd2(gy, -c.sig * rhi, -c.sig * rlo);
+        a.W.yp[at] = yp;
+        const double dy = yp - y;
+        const double nsadx = -c.sig * (axb - axp);                 // -sig A (x+ - x)   (xbar - x+ = x+ - x)
+        v[1] = dy * fma(2.0, nsadx, dy);
+        const double viol_s = fmax(rlo - axp, 0.0) + fmax(axp - rhi, 0.0);
+        const double viol = viol_s / P.row_scale[i];
+        v[2] = viol * viol;
+        v[3] = fabs(yp) * viol_s;
+        v[4] = fmax(yp, 0.0) * fin0(rlo) - fmax(-yp, 0.0) * fin0(rhi);
+        const double d0 = yp - a.W.y0[at];
+        v[5] = d0 * d0;
+      }
+      if (!is_long_block && t < P.n) {
+        const size_t at = (size_t)s * P.n + t;
+        const double xp = a.W.xp[at];
+        const double dx = xp - a.W.x[at], d0 = xp - a.W.x0[at];
+        v[0] = dx * dx;
+        v[6] = d0 * d0;
+      }
+    }
+    block_partials<7>(v, a.W.partial + ((size_t)s * a.nblk_tot + blockIdx.x) * kNQ);
+  }
+}
+
+// ---- check iteration, columns: reduced costs at y+ -----------------------------------------------------------------------
+// partial slots: 8 dres^2, 9 pobj = c.x+, 10 dual objective (column part), 11 sum |c x|, 12 sum |dual residual| |x|
+template <int SG>
+__global__ void k_kkt_cols(StreamArgs a) {
+  const StreamProblem &P = a.P;
+  const int b0 = blockIdx.y * SG;
+  const int t = blockIdx.x * kTB + threadIdx.x;
+  const bool is_long_block = (int)blockIdx.x >= a.nblk_n;
+  const bool col = !is_long_block && t < P.n && !P.C.is_long[t < P.n ? t : 0];
+  double val[kStreamMaxW];
+  int idx[kStreamMaxW];
+  if (col) for (int e = 0; e < P.C.W; ++e) { val[e] = P.C.val[(size_t)e * P.n + t]; idx[e] = P.C.idx[(size_t)e * P.n + t]; }
+  for (int u = 0; u < SG; ++u) {
+    const int s = b0 + u;
+    if (s >= a.b.B) break;
+    const StreamCtrl &c = a.W.ctrl[s];
+    double v[5] = {0, 0, 0, 0, 0};
+    if (!c.done) {
+      const double *__restrict__ ypv = a.W.yp + (size_t)s * P.m;
+      int j = -1;
+      double aty = 0.0;
+      if (is_long_block) {
+        const int l = blockIdx.x - a.nblk_n;
+        const double t1 = long_dot(P.C, l, ypv);
+        if (threadIdx.x == 0) { j = P.C.long_id[l]; aty = t1; }
+      } else if (col) {
+        j = t;
+        for (int e = 0; e < P.C.W; ++e) aty = fma(val[e], ypv[idx[e]], aty);
+      }
+      if (j >= 0) {
+        const size_t at = (size_t)s * P.n + j;
+        const double cj = a.W.c[at], lb = a.W.lb[at], ub = a.W.ub[at], xp = a.W.xp[at];
+        const double rc = cj - aty;
+        const double lp = finite_d(lb) ? fmax(rc, 0.0) : 0.0;
+        const double lm = finite_d(ub) ? fmax(-rc, 0.0) : 0.0;
+        const double dr = (rc - lp + lm) / P.col_scale[j];
+        v[0] = dr * dr;
+        v[1] = cj * xp;
+        v[2] = lp * fin0(lb) - lm * fin0(ub);
+        v[3] = fabs(cj * xp);
+        v[4] = fabs(rc - lp + lm) * fabs(xp);
+      }
+    }
+    block_partials<5>(v, a.W.partial + ((size_t)s * a.nblk_tot + blockIdx.x) * kNQ + 8);
+  }
+}
+
+// ---- control: one block per scenario sums the partials in a fixed order and decides ------------------------------------------
+__global__ void k_control(StreamArgs a, int iters_this_period) {
+  const int s = blockIdx.x;
+  StreamCtrl &c = a.W.ctrl[s];
+  if (c.done) return;
+  __shared__ double acc[kNQ];
+  if (threadIdx.x < kNQ) {
+    double t = 0.0;
+    for (int blk = 0; blk < a.nblk_tot; ++blk) t += a.W.partial[((size_t)s * a.nblk_tot + blk) * kNQ + threadIdx.x];
+    acc[threadIdx.x] = t;
+  }
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  const dsp_options &o = a.opt;
+  c.it += iters_this_period;
+  c.k += iters_this_period;
+  const double w = c.w, iw = 1.0 / w;
+  const double r = fmax(w * acc[0] + iw * acc[1], 0.0);        // squared fixed-point residual in the PDHG metric
+  int mode = 0;
+  if (!(r == r)) { c.status = DSP_STATUS_NUMERICAL; c.done = 1; }
+  else {
+    const double po = acc[9], dobj = acc[4] + acc[10];
+    c.pobj = po;
+    const double rp = sqrt(acc[2]) / (1.0 + c.qn), rd = sqrt(acc[8]) / (1.0 + c.cn);
+    const double gap = fabs(po - dobj);
+    const double rg = gap / (1.0 + fabs(po) + fabs(dobj));
+    bool fin = rp <= o.eps_rel && rd <= o.eps_rel && rg <= o.eps_rel;
+    if (fin && o.eps_obj > 0.0) {
+      const double lim = fmax(o.eps_obj * (1.0 + fabs(po + c.c0)), 1e-12 * acc[11]);
+      fin = gap <= lim && acc[3] <= lim && acc[12] <= lim;
+    }
+    c.last_rp = rp; c.last_rd = rd; c.last_rg = rg;
+    if (fin) { c.status = DSP_STATUS_OPTIMAL; c.done = 1; }
+    else if (c.it >= o.max_iter) { c.status = DSP_STATUS_ITERATION_LIMIT; c.done = 1; }
+    else {
+      const double bs2 = o.restart_sufficient * o.restart_sufficient, bn2 = o.restart_necessary * o.restart_necessary;
+      const bool first = !(c.r0 < INFINITY);
+      const bool decayed = (r <= bs2 * c.r0) || (r <= bn2 * c.r0 && r > c.rprev);
+      const bool artificial = (double)c.k >= o.restart_artificial * (double)c.it;
+      if (first) c.r0 = r;
+      c.rprev = r;
+      if (!first && (decayed || artificial)) {
+        double wn = w;
+        if (acc[6] > 1e-28 && acc[5] > 1e-28) {
+          const double e = log(w) + 0.5 * (log(acc[6]) - log(acc[5]));
+          const double dl = fmin(fmax(-o.pid_kp * e, -o.max_dlog_weight), o.max_dlog_weight);
+          wn = w * exp(dl);
+        }
+        wn = fmin(fmax(wn, c.w_lo), fmax(c.w_hi, c.w_lo));
+        c.w = wn; c.tau = a.eta / wn; c.sig = a.eta * wn;
+        c.k = 0; c.r0 = INFINITY; c.rprev = INFINITY;
+        c.nrestart += 1;
+        mode = 1;
+      }
+    }
+  }
+  c.mode = mode;
+  if (c.done) atomicAdd(a.W.ndone, 1);
+}
+
+// ---- apply: Halpern step or restart after a check ---------------------------------------------------------------------------
+template <int SG>
+__global__ void k_apply(StreamArgs a) {
+  const StreamProblem &P = a.P;
+  const int b0 = blockIdx.y * SG;
+  const int t = blockIdx.x * kTB + threadIdx.x;
+#pragma unroll
+  for (int u = 0; u < SG; ++u) {
+    const int s = b0 + u;
+    if (s >= a.b.B) break;
+    const StreamCtrl &c = a.W.ctrl[s];
+    if (c.done) continue;
+    const double oml = 1.0 / (double)(c.k + 2);
+    if (t < P.n) {
+      const size_t at = (size_t)s * P.n + t;
+      const double xp = a.W.xp[at];
+      if (c.mode == 1) { a.W.x[at] = xp; a.W.x0[at] = xp; }
+      else { const double x = a.W.x[at]; const double tt = 2.0 * xp - x; a.W.x[at] = fma(oml, a.W.x0[at] - tt, tt); }
+    }
+    if (t < P.m) {
+      const size_t at = (size_t)s * P.m + t;
+      const double yp = a.W.yp[at];
+      if (c.mode == 1) { a.W.y[at] = yp; a.W.y0[at] = yp; }
+      else { const double y = a.W.y[at]; const double tt = 2.0 * yp - y; a.W.y[at] = fma(oml, a.W.y0[at] - tt, tt); }
+    }
+  }
+}
+
+// ---- results -------------------------------------------------------------------------------------------------------------------
+__global__ void k_finalize(StreamArgs a) {
+  const StreamProblem &P = a.P;
+  const dsp_batch &b = a.b;
+  const int t = blockIdx.x * kTB + threadIdx.x;
+  const int s = blockIdx.y;
+  const StreamCtrl &c = a.W.ctrl[s];
+  const bool invalid = c.status == DSP_STATUS_PRIMAL_INFEASIBLE || c.status == DSP_STATUS_NUMERICAL;
+  if (t < P.n) b.x[(size_t)s * P.n + t] = invalid && c.it == 0 ? NAN : a.W.xp[(size_t)s * P.n + t] * P.col_scale[t];
+  if (t < P.m) b.y[(size_t)s * P.m + t] = invalid && c.it == 0 ? NAN : a.W.yp[(size_t)s * P.m + t] * P.row_scale[t];
+  if (t == 0) {
+    b.obj[s] = c.pobj;
+    b.status[s] = c.status;
+    if (b.iters) b.iters[s] = c.it;
+    if (b.jumps) b.jumps[s] = 0;
+    if (b.primal_weight) b.primal_weight[s] = c.w;
+  }
+}
+
+template <class T>
+hipError_t up(std::vector<void *> &allocs, const std::vector<T> &v, const T **out) {
+  void *d = nullptr;
+  hipError_t e = hipMalloc(&d, std::max<size_t>(v.size(), 1) * sizeof(T));
+  if (e != hipSuccess) return e;
+  allocs.push_back(d);
+  if (!v.empty()) { e = hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice); if (e != hipSuccess) return e; }
+  *out = reinterpret_cast<const T *>(d);
+  return hipSuccess;
+}
+
+// entry-major ELL + long list of a host CSR (vectors = rows of M)
+hipError_t build_matrix(const HostCSR &M, std::vector<void *> &allocs, StreamMatrix *out, int *width) {
+  const int nv = M.m;
+  // ELL width: the smallest W <= kStreamMaxW that leaves at most kStreamMaxLong long vectors
+  std::vector<int> len(nv);
+  for (int v = 0; v < nv; ++v) len[v] = M.ptr[v + 1] - M.ptr[v];
+  int W = 1;
+  for (W = 1; W <= kStreamMaxW; ++W) {
+    int nl = 0;
+    for (int v = 0; v < nv; ++v) nl += len[v] > W;
+    if (nl == 0) break;
+    if (W == kStreamMaxW) break;
+  }
+  W = std::min(W, kStreamMaxW);
+  std::vector<double> val((size_t)W * nv, 0.0);
+  std::vector<int32_t> idx((size_t)W * nv, 0);
+  std::vector<uint8_t> is_long(std::max(nv, 1), 0);
+  std::vector<int32_t> lid, lptr{0}, lidx;
+  std::vector<double> lval;
+  for (int v = 0; v < nv; ++v) {
+    if (len[v] <= W) {
+      for (int e = 0; e < len[v]; ++e) { val[(size_t)e * nv + v] = M.val[M.ptr[v] + e]; idx[(size_t)e * nv + v] = M.idx[M.ptr[v] + e]; }
+    } else {
+      is_long[v] = 1;
+      lid.push_back(v);
+      for (int p = M.ptr[v]; p < M.ptr[v + 1]; ++p) { lidx.push_back(M.idx[p]); lval.push_back(M.val[p]); }
+      lptr.push_back((int32_t)lidx.size());
+    }
+  }
+  if ((int)lid.size() > kStreamMaxLong) return hipErrorInvalidValue;
+  out->nvec = nv; out->W = W; out->nlong = (int)lid.size();
+  hipError_t e;
+  if ((e = up(allocs, val, &out->val)) != hipSuccess) return e;
+  if ((e = up(allocs, idx, &out->idx)) != hipSuccess) return e;
+  if ((e = up(allocs, is_long, &out->is_long)) != hipSuccess) return e;
+  if ((e = up(allocs, lid, &out->long_id)) != hipSuccess) return e;
+  if ((e = up(allocs, lptr, &out->long_ptr)) != hipSuccess) return e;
+  if ((e = up(allocs, lidx, &out->long_idx)) != hipSuccess) return e;
+  if ((e = up(allocs, lval, &out->long_val)) != hipSuccess) return e;
+  *width = W;
+  return hipSuccess;
+}
+
+}  // namespace
+
+// ---- host side ---------------------------------------------------------------------------------------------------------------
+hipError_t stream_create(const HostCSR &A_scaled, const HostCSR &AT_scaled, const double *col_scale_dev,
+                         const double *row_scale_dev, StreamSolver *S) {
+  S->P.n = A_scaled.n; S->P.m = A_scaled.m;
+  S->P.col_scale = col_scale_dev; S->P.row_scale = row_scale_dev;
+  int wr = 0, wc = 0;
+  hipError_t e;
+  if ((e = build_matrix(A_scaled, S->allocs, &S->P.R, &wr)) != hipSuccess) return e;
+  if ((e = build_matrix(AT_scaled, S->allocs, &S->P.C, &wc)) != hipSuccess) return e;
+  return hipSuccess;
+}
+
+void stream_destroy(StreamSolver *S) {
+  for (void *p : S->allocs) (void)hipFree(p);
+  for (void *p : S->work_allocs) (void)hipFree(p);
+  S->allocs.clear(); S->work_allocs.clear();
+  if (S->ndone_host) { (void)hipHostFree(S->ndone_host); S->ndone_host = nullptr; }
+}
+
+static hipError_t ensure_workspace(StreamSolver *S, int B) {
+  if (B <= S->work_B) return hipSuccess;
+  for (void *p : S->work_allocs) (void)hipFree(p);
+  S->work_allocs.clear();
+  S->work_B = 0;
+  const size_t n = S->P.n, m = S->P.m;
+  const int nblk = (int)((std::max(n, m) + kTB - 1) / kTB);
+  const int nblk_tot = nblk + std::max(S->P.R.nlong, S->P.C.nlong);
+  auto alloc = [&](size_t bytes, void **out) {
+    hipError_t e = hipMalloc(out, std::max<size_t>(bytes, 8));
+    if (e == hipSuccess) S->work_allocs.push_back(*out);
+    return e;
+  };
+  StreamWork &W = S->W;
+  hipError_t e;
+  double **colv[] = {&W.x, &W.x0, &W.xp, &W.xbar, &W.c, &W.lb, &W.ub};
+  double **rowv[] = {&W.y, &W.y0, &W.yp, &W.rlo, &W.rhi};
+  for (double **p : colv) if ((e = alloc((size_t)B * n * sizeof(double), (void **)p)) != hipSuccess) return e;
+  for (double **p : rowv) if ((e = alloc((size_t)B * m * sizeof(double), (void **)p)) != hipSuccess) return e;
+  if ((e = alloc((size_t)B * sizeof(StreamCtrl), (void **)&W.ctrl)) != hipSuccess) return e;
+  if ((e = alloc((size_t)B * nblk_tot * kNQ * sizeof(double), (void **)&W.partial)) != hipSuccess) return e;
+  if ((e = hipMemset(W.partial, 0, (size_t)B * nblk_tot * kNQ * sizeof(double))) != hipSuccess) return e;
+  if ((e = alloc(sizeof(int), (void **)&W.ndone)) != hipSuccess) return e;
+  if (!S->ndone_host && (e = hipHostMalloc((void **)&S->ndone_host, sizeof(int))) != hipSuccess) return e;
+  S->work_B = B;
+  return hipSuccess;
+}
+
+size_t stream_bytes_per_iteration(const StreamSolver *S) {
+  // per scenario and plain iteration (see the file header): 11 n + 7 m doubles
+  return (size_t)8 * (11 * (size_t)S->P.n + 7 * (size_t)S->P.m);
+}
+
+template <int SG>
+static hipError_t run(StreamSolver *S, StreamArgs &a, hipStream_t st, int *periods_run) {
+  const StreamProblem &P = a.P;
+  const int B = a.b.B;
+  const int groups = (B + SG - 1) / SG;
+  const dim3 blk(kTB);
+  const dim3 g_primal(a.nblk_n + P.C.nlong, groups), g_dual(a.nblk + P.R.nlong, groups), g_cols(a.nblk_n + P.C.nlong, groups);
+  const dim3 g_elem(a.nblk, groups);
+  const int C = std::max(1, a.opt.check_every);
+  const int max_periods = (a.opt.max_iter + C - 1) / C;
+  const int poll = 4;                                        // check periods between two looks at the finished counter
+  int period = 0;
+  hipError_t e = hipSuccess;
+  for (; period < max_periods; ++period) {
+    for (int u = 0; u < C - 1; ++u) {
+      hipLaunchKernelGGL((k_primal<SG>), g_primal, blk, 0, st, a);
+      hipLaunchKernelGGL((k_dual_halpern<SG>), g_dual, blk, 0, st, a, u);
+    }
+    hipLaunchKernelGGL((k_primal<SG>), g_primal, blk, 0, st, a);
+    hipLaunchKernelGGL((k_check_rows<SG>), g_dual, blk, 0, st, a);
+    hipLaunchKernelGGL((k_kkt_cols<SG>), g_cols, blk, 0, st, a);
+    hipLaunchKernelGGL(k_control, dim3(B), dim3(64), 0, st, a, C);
+    hipLaunchKernelGGL((k_apply<SG>), g_elem, blk, 0, st, a);
+    if ((period + 1) % poll == 0 || period + 1 == max_periods) {
+      if ((e = hipMemcpyAsync(S->ndone_host, a.W.ndone, sizeof(int), hipMemcpyDeviceToHost, st)) != hipSuccess) return e;
+      if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;
+      if (*S->ndone_host >= B) { ++period; break; }
+    }
+  }
+  *periods_run = period;
+  return hipGetLastError();
+}
+
+hipError_t stream_solve(StreamSolver *S, const dsp_batch &batch, const dsp_options &opt, double eta, hipStream_t st,
+                        int *periods_run) {
+  const int B = batch.B;
+  hipError_t e = ensure_workspace(S, B);
+  if (e != hipSuccess) return e;
+  StreamArgs a{};
+  a.P = S->P; a.W = S->W; a.b = batch; a.opt = opt; a.eta = eta;
+  a.nblk_n = (S->P.n + kTB - 1) / kTB;
+  a.nblk = (std::max(S->P.n, S->P.m) + kTB - 1) / kTB;
+  a.nblk_tot = a.nblk + std::max(S->P.R.nlong, S->P.C.nlong);
+  if ((e = hipMemsetAsync(a.W.ndone, 0, sizeof(int), st)) != hipSuccess) return e;
+  if ((e = hipMemsetAsync(a.W.partial, 0, (size_t)B * a.nblk_tot * kNQ * sizeof(double), st)) != hipSuccess) return e;
+  hipLaunchKernelGGL(k_init, dim3(a.nblk, B), dim3(kTB), 0, st, a);
+  hipLaunchKernelGGL(k_init_control, dim3(B), dim3(64), 0, st, a);
+  // k_init wrote its partials with stride nblk; the check kernels use nblk_tot: clear again before the first check
+  if ((e = hipMemsetAsync(a.W.partial, 0, (size_t)B * a.nblk_tot * kNQ * sizeof(double), st)) != hipSuccess) return e;
+  // scenarios per thread: enough (element blocks x scenario groups) to fill the chip, matrix reuse otherwise
+  const long blocks1 = a.nblk;
+  int sg = 4;
+  if (blocks1 * ((B + 3) / 4) < 1024) sg = 2;
+  if (blocks1 * ((B + 1) / 2) < 1024) sg = 1;
+  a.nblk_tot = a.nblk + std::max(S->P.R.nlong, S->P.C.nlong);
+  if (sg == 4) e = run<4>(S, a, st, periods_run);
+  else if (sg == 2) e = run<2>(S, a, st, periods_run);
+  else e = run<1>(S, a, st, periods_run);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(k_finalize, dim3(a.nblk, B), dim3(kTB), 0, st, a);
+  return hipGetLastError();
+}
+
+}  // namespace dsp

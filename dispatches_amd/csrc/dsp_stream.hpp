@@ -1,0 +1,77 @@
+// dsp_stream.hpp — data structures of the HBM-resident ("streaming") batched PDLP (dsp_stream.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <vector>
+
+#include "../../include/dsp_hip.h"
+#include "dsp_prepare.hpp"
+
+namespace dsp {
+
+constexpr int kStreamMaxW = 8;         // ELL width cap: longer vectors go to the long list
+constexpr int kStreamMaxLong = 4096;   // long vectors per orientation
+
+// one orientation of the scaled matrix: entry-major ELL ([W][nvec]) + CSR segments of the long vectors
+struct StreamMatrix {
+  int nvec, W, nlong;
+  const double *val;          // [W][nvec]
+  const int32_t *idx;         // [W][nvec]
+  const uint8_t *is_long;     // [nvec]
+  const int32_t *long_id;     // [nlong]   vector id
+  const int32_t *long_ptr;    // [nlong+1]
+  const int32_t *long_idx;
+  const double *long_val;
+};
+
+struct StreamProblem {
+  int n, m;
+  StreamMatrix R, C;          // A (rows) and A^T (columns)
+  const double *col_scale, *row_scale;
+};
+
+// per-scenario control block (device memory; written by k_init_control / k_control only)
+struct StreamCtrl {
+  double w, tau, sig, w_lo, w_hi;
+  double r0, rprev;
+  double qn, cn, c0, pobj;
+  double last_rp, last_rd, last_rg;
+  int k, it, status, done, mode, nrestart;
+};
+
+struct StreamWork {
+  double *x, *x0, *xp, *xbar, *c, *lb, *ub;     // [B][n]  scaled space
+  double *y, *y0, *yp, *rlo, *rhi;              // [B][m]
+  StreamCtrl *ctrl;                             // [B]
+  double *partial;                              // [B][nblk_tot][16] ordered block partial sums
+  int *ndone;                                   // scenarios finished
+};
+
+struct StreamArgs {
+  StreamProblem P;
+  StreamWork W;
+  dsp_batch b;
+  dsp_options opt;
+  double eta;
+  int nblk_n;      // blocks over the columns
+  int nblk;        // blocks over max(n, m) elements
+  int nblk_tot;    // + blocks of the long vectors (partial-sum stride)
+};
+
+struct StreamSolver {
+  StreamProblem P{};
+  StreamWork W{};
+  int work_B = 0;
+  std::vector<void *> allocs, work_allocs;
+  int *ndone_host = nullptr;
+};
+
+hipError_t stream_create(const HostCSR &A_scaled, const HostCSR &AT_scaled, const double *col_scale_dev,
+                         const double *row_scale_dev, StreamSolver *S);
+void stream_destroy(StreamSolver *S);
+hipError_t stream_solve(StreamSolver *S, const dsp_batch &batch, const dsp_options &opt, double eta, hipStream_t st,
+                        int *periods_run);
+size_t stream_bytes_per_iteration(const StreamSolver *S);
+
+}  // namespace dsp

@@ -15,7 +15,8 @@ from typing import Optional
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "libdsp_hip.so")
+# DSP_LIB selects another build of the library in the package directory (development: e.g. a -DDSP_NO_DRAIN build)
+_LIB_PATH = os.path.join(_HERE, os.environ.get("DSP_LIB", "libdsp_hip.so"))
 _lib = None
 
 
@@ -49,7 +50,7 @@ class DspStats(C.Structure):
                 ("grid_blocks", C.c_int32), ("block_threads", C.c_int32), ("lds_bytes", C.c_int32),
                 ("cols_per_lane", C.c_int32), ("rows_per_lane", C.c_int32), ("kernel_ms", C.c_float),
                 ("matreg", C.c_int32), ("lds_conflicts_identity", C.c_int32), ("lds_conflicts_chosen", C.c_int32),
-                ("simplex", C.c_int32), ("reserved", C.c_int32)]
+                ("simplex", C.c_int32), ("streaming", C.c_int32), ("stream_bytes_per_iteration", C.c_int64)]
 
 
 class DspLpDesc(C.Structure):
@@ -360,7 +361,7 @@ class HipPdlpSolver:
         if tee:
             print(f"[dsp_hip] B={B} n={model.lp.n} m={model.lp.m} nnz={model.lp.nnz} optimal={st.n_optimal}/{B} "
                   f"iters(sum/max)={st.total_iterations}/{st.max_iterations} kernel={st.kernel_ms:.3f} ms "
-                  f"grid={st.grid_blocks}x{st.block_threads} lds={st.lds_bytes}B matreg={st.matreg} simplex={st.simplex}")
+                  f"grid={st.grid_blocks}x{st.block_threads} lds={st.lds_bytes}B matreg={st.matreg} simplex={st.simplex} streaming={st.streaming}")
         all_ok = bool((status == 0).all())
         return SolveResults("ok" if all_ok else "warning", "optimal" if all_ok else "maxIterations",
                             iterations=int(st.total_iterations), kernel_ms=float(st.kernel_ms))

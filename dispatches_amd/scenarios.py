@@ -268,3 +268,33 @@ def hourly_tracking_batch(case, inp, solver):
     model.c = np.tile(model.c[0], (B, 1))
     model.c0 = np.full(B, float(model.c0[0])) + shift
     return tracker, model
+
+
+# ---- long-horizon price-taker design LPs: a scenario family sharing one constraint matrix ---------------
+PRICE_TAKER_FAMILY = [(bf, lm) for lm in (1.0, 1.5, 2.0, 3.0) for bf in (1.0, 0.5, 0.25, 0.1)]   # (battery capital-cost factor, LMP multiplier)
+
+
+def price_taker_inputs(T, series="rts_gmlc_303.npz", price_cap=200.0):
+    """Capacity factors and day-ahead LMPs of the first T hours of the bus-303 series (LMPs capped at 200 $/MWh as the
+    reference's test fixture does, tests/test_RE_flowsheet.py:24-26)."""
+    s = load_series(series)
+    idx = np.arange(T) % len(s["da_lmp"])
+    return s["rt_cf"][idx], np.minimum(s["da_lmp"][idx], price_cap)
+
+
+def price_taker_batch(T, B, solver, wind_mw=847.0):
+    """Wind + battery price-taker design LP over T hourly periods (reference wind_battery_optimize) for the first B members
+    of PRICE_TAKER_FAMILY: scenarios differ in the objective only.  n = 6 T + 3, m = 6 T + 2: beyond the fused kernels for
+    T >= 107, i.e. solved by the HBM-resident streaming PDLP.  Returns (handles, model)."""
+    from .flowsheets.price_taker import wind_battery_price_taker
+    from .workflow.batch_model import ScenarioBatchModel
+    cf, lmp = price_taker_inputs(T)
+    block, objective, handles = wind_battery_price_taker(T, cf, lmp, wind_mw=wind_mw)
+    model = ScenarioBatchModel(block, B, T, indexed=True)
+    model.finalize(objective)
+    fam = [PRICE_TAKER_FAMILY[i % len(PRICE_TAKER_FAMILY)] for i in range(B)]
+    model.c = np.stack([handles["objective_vector"](model.lp.n, lmp_multiplier=lm, batt_cap_factor=bf) for bf, lm in fam])
+    model.c0 = np.full(B, model.lp.c0)
+    model.family = fam
+    model.solver = solver
+    return handles, model

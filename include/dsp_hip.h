@@ -29,7 +29,7 @@ extern "C" {
 /* return codes (0 = ok, < 0 = API misuse / HIP error; text via dsp_strerror) */
 #define DSP_OK                 0
 #define DSP_ERR_INVALID       -1   /* bad argument (NULL, negative size, unsorted CSR, ...)            */
-#define DSP_ERR_TOO_LARGE     -2   /* one scenario does not fit the LDS-resident kernel               */
+#define DSP_ERR_TOO_LARGE     -2   /* LP beyond what the layouts support (see dsp_strerror)            */
 #define DSP_ERR_HIP           -3   /* a HIP runtime call failed (dsp_last_hip_error())                */
 #define DSP_ERR_NO_DEVICE     -4   /* no gfx950 device visible                                        */
 #define DSP_ERR_ALLOC         -5
@@ -157,7 +157,10 @@ typedef struct dsp_stats {
   int32_t lds_conflicts_chosen;   /* ... with the slot permutation chosen at create time          */
   int32_t simplex;                /* 1 = the in-wave simplex pass ran first (iters[] then counts pivots for the
                                      scenarios it solved)                                           */
-  int32_t reserved;
+  int32_t streaming;              /* 1 = LP beyond the register/LDS-resident kernels (n > 640 or m > 384): the HBM-resident
+                                     PDLP ran (state streamed from HBM every iteration: dsp_stream.hip)    */
+  int64_t stream_bytes_per_iteration;  /* streaming path: algorithmic HBM bytes per scenario and plain iteration
+                                          (11 n + 7 m doubles)                                          */
 } dsp_stats;
 
 void dsp_default_options(dsp_options *opt);

@@ -409,3 +409,64 @@ def marginal_to_actual_costs(pairs):
         out.append((p, cost))
         prev = p
     return out
+
+
+# ---- LP #4: long-horizon wind + battery price-taker design problem ------------------------------------------------
+# wind_battery_LMP.py:172-269 (`wind_battery_optimize`), default input parameters (design_opt = True, extant_wind = True,
+# load_parameters.py:124-138).  UN-reduced: every block keeps its own nameplate_power / nameplate_energy / wind
+# system_capacity columns and the link rows between consecutive blocks, as the Pyomo MultiPeriodModel builds them.
+BATT_OP_COST = 31.39              # $/kW-yr  wind_battery_cost_parameter.json battery.fixed_om.moderate.2023[1]  (load_parameters.py:40)
+BATT_CAP_COST_KW = 236.365        # $/kW     battery.batt_cap_cost_param.moderate.2023[0]                          (:41)
+BATT_CAP_COST_KWH = 254.835       # $/kWh    battery.batt_cap_cost_param.moderate.2023[1]                          (:42)
+PRESENT_VALUE_FACTOR = ((1 + 0.08) ** 30 - 1) / (0.08 * (1 + 0.08) ** 30)                                        # (:119-121)
+BATTERY_DURATION = 4.0                                                                                              # (:36)
+
+
+def wind_battery_price_taker(T, cf, lmp, wind_kw=847e3, wind_kw_ub=10000e3, batt_cap_factor=1.0):
+    """Returns (PreparedLP of  min -NPV * 1e-5, info) ; lmp in $/MWh (scaled by 1e-3 as wind_battery_LMP.py:249)."""
+    lp = _LP()
+    Cw = lp.var("wind_system_capacity", 0.0, wind_kw_ub)                      # :203
+    Pb = lp.var("battery_system_capacity", 0.0, np.inf)                       # :204
+    elec = []
+    prev = None
+    for t in range(T):
+        cap = lp.var(f"cap{t}", wind_kw, wind_kw)                             # extant wind: block capacity stays fixed (:208-209)
+        W = lp.var(f"W{t}")
+        G = lp.var(f"G{t}")
+        I = lp.var(f"I{t}")
+        O = lp.var(f"O{t}")
+        S = lp.var(f"S{t}")
+        E = lp.var(f"E{t}")
+        P = lp.var(f"P{t}", 0.0, 1e8)                                         # battery.py nameplate_power bounds
+        En = lp.var(f"En{t}", 0.0, 1e9)                                       # battery.py nameplate_energy bounds
+        lp.row({W: 1, cap: -cf[t]}, -np.inf, 0.0)                             # wind_power.py:120-122
+        lp.row({W: 1, G: -1, I: -1}, 0.0, 0.0)                                # elec_splitter.py:115-117
+        if prev is None:                                                      # initial SOC / throughput fixed to 0 (:199-200)
+            lp.row({S: 1, I: -ETA_C, O: 1 / ETA_D}, 0.0, 0.0)
+            lp.row({E: 1, I: -0.5, O: -0.5}, 0.0, 0.0)
+        else:
+            lp.row({S: 1, prev["S"]: -1, I: -ETA_C, O: 1 / ETA_D}, 0.0, 0.0)  # battery.py:145-149 + link :33
+            lp.row({E: 1, prev["E"]: -1, I: -0.5, O: -0.5}, 0.0, 0.0)         # battery.py:151-153 + link :34
+            lp.row({P: 1, prev["P"]: -1}, 0.0, 0.0)                           # link :35
+            lp.row({S: 1, prev["S"]: -1}, -BATTERY_RAMP_RATE, BATTERY_RAMP_RATE)   # :139-142
+        lp.row({S: 1, E: DEGRADATION, En: -1}, -np.inf, 0.0)                  # battery.py:155-157
+        lp.row({I: 1, P: -1}, -np.inf, 0.0)                                   # battery.py:159-161
+        lp.row({O: 1, P: -1}, -np.inf, 0.0)                                   # battery.py:163-165
+        lp.row({P: BATTERY_DURATION, En: -1}, 0.0, 0.0)                       # RE_flowsheet.py:155-156
+        lp.row({cap: 1, Cw: -1}, -np.inf, 0.0)                                # :212
+        lp.row({P: 1, Pb: -1}, -np.inf, 0.0)                                  # :213
+        elec.append((G, O))
+        prev = dict(S=S, E=E, P=P)
+    lp.row({prev["S"]: 1}, 0.0, 0.0)                                          # periodic pair: S_{T-1} = initial SOC = 0 (:40-51)
+    n_weeks = T / (7 * 24)
+    k = 52 / n_weeks
+    # NPV = -(batt_cap_cost_kw + batt_cap_cost_kwh * duration) Pb + PA * annual_revenue  (wind_cap_cost = 0: extant wind)
+    npv = {}
+    for t, (G, O) in enumerate(elec):
+        for j in (G, O):
+            npv[j] = npv.get(j, 0.0) + PRESENT_VALUE_FACTOR * k * lmp[t] * 1e-3
+    npv[Cw] = -PRESENT_VALUE_FACTOR * k * T * WIND_OP_COST / 8760
+    npv[Pb] = (-PRESENT_VALUE_FACTOR * k * T * BATT_OP_COST / 8760
+               - batt_cap_factor * (BATT_CAP_COST_KW + BATT_CAP_COST_KWH * BATTERY_DURATION))   # scenario family: scaled battery capital cost
+    lp.add_cost((npv, 0.0), -1e-5)
+    return PreparedLP(lp), dict(Cw=Cw, Pb=Pb, npv=(npv, 0.0), elec=elec, annual_scale=k)

@@ -409,3 +409,25 @@ def test_other_price_series_and_near_zero_objectives():
         ref = P.solve(tight=True)[1]
         scale = float(np.abs(model.c[k] * model.x[k]).sum())
         assert abs(model.objective[k] - ref) <= 1e-6 * max(1.0, abs(ref)) + 2e-10 * scale, (k, model.objective[k], ref, scale)
+
+
+@gpu
+@pytest.mark.parametrize("no_matreg,waves_per_block", [(1, 8), (0, 1)])
+def test_work_queue_turnover_stress(no_matreg, waves_per_block):
+    """65 536 tiny LPs through the PDLP kernels' device work queue (generic kernel with 8 waves per block, and the
+    register-resident kernel): every wave retires ~30 scenarios back to back.  This is the regime in which the round-1
+    form of the queue pull (`if (lane == 0) atomicAdd` + readfirstlane) hung every wave at the end of its first scenario
+    unless an s_waitcnt sat after the result stores (root cause: csrc/dsp_kernels.hip, comment at the pull; reproduced with
+    -DDSP_LEGACY_PULL by tools/gpu_round2_e.sh).  The test hangs / times out if the pull regresses."""
+    import os
+    from dispatches_amd import scenarios
+    fx = np.load(os.path.join(os.path.dirname(__file__), "golden", "oracle_hourly.npz"))
+    case, B = "wind_pem_track4", 65536
+    inp = {k.split("/", 1)[1]: np.tile(fx[k], (B // 4096,) + (1,) * (fx[k].ndim - 1)) for k in fx.files if k.startswith(case + "/")}
+    solver = _solver(no_simplex=1, no_matreg=no_matreg, waves_per_block=waves_per_block)
+    _, model = scenarios.hourly_tracking_batch(case, inp, solver)
+    solver.solve(model)
+    assert solver.last_stats.simplex == 0 and solver.last_stats.matreg == (0 if no_matreg else 1)
+    assert (model.status == 0).all(), np.bincount(model.status)
+    err = np.abs(model.objective - inp["obj"]) / np.maximum(1.0, np.abs(inp["obj"]))
+    assert err.max() < 1e-6

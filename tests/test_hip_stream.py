@@ -1,0 +1,61 @@
+"""GPU tests of the HBM-resident (streaming) PDLP: the long-horizon price-taker design LPs of the reference
+(wind_battery_LMP.py:172-269) at a one-week horizon (n = 1011, m = 1010: beyond the register/LDS-resident kernels)
+against the independent oracle (un-reduced LP + HiGHS, tests/golden/oracle_price_taker.npz)."""
+import os
+
+import numpy as np
+import pytest
+
+gpu = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@gpu
+def test_price_taker_family_matches_oracle_and_is_reproducible():
+    from dispatches_amd import scenarios
+    from dispatches_amd.hip_solver import HipPdlpSolver
+    from tests.test_hip_parity import _kkt_certificate
+    fx = np.load(os.path.join(GOLD, "oracle_price_taker.npz"))
+    T, B = 168, 8
+    solver = HipPdlpSolver(device=0, check_every=64)
+    handles, model = scenarios.price_taker_batch(T, B, solver)
+    assert model.lp.n == 6 * T + 3 and model.lp.m == 6 * T + 2
+    solver.solve(model, tee=True)
+    assert solver.last_stats.streaming == 1
+    assert solver.last_stats.stream_bytes_per_iteration == 8 * (11 * model.lp.n + 7 * model.lp.m)
+    assert (model.status == 0).all(), (np.bincount(model.status), model.iterations)
+    ref = fx["T168/obj"][:B]
+    err = np.abs(model.objective - ref) / np.maximum(1.0, np.abs(ref))
+    assert err.max() < 1e-6, (err, model.iterations)
+    rp, rd, rg = _kkt_certificate(model)
+    assert max(rp.max(), rd.max(), rg.max()) < 5e-9
+    # the design decision itself: optimal battery size [MW] (unique whenever a battery is built)
+    batt = model.x[:, handles["battery_system_capacity"].index] * 1e-3
+    np.testing.assert_allclose(batt, fx["T168/batt_mw"][:B], rtol=1e-3, atol=0.5)
+    # ordered two-stage reductions: a second solve reproduces the first bit for bit
+    obj1, it1 = model.objective.copy(), model.iterations.copy()
+    solver.solve(model)
+    assert np.array_equal(model.objective, obj1) and np.array_equal(model.iterations, it1)
+
+
+@gpu
+def test_streaming_edge_cases():
+    """B = 1, an invalid scenario (crossed bounds), the iteration limit."""
+    from dispatches_amd import scenarios
+    from dispatches_amd.hip_solver import HipPdlpSolver
+    fx = np.load(os.path.join(GOLD, "oracle_price_taker.npz"))
+    solver = HipPdlpSolver(device=0, check_every=64)
+    handles, model = scenarios.price_taker_batch(168, 1, solver)
+    solver.solve(model)
+    assert model.status.tolist() == [0]
+    assert abs(model.objective[0] - fx["T168/obj"][0]) <= 1e-6 * abs(fx["T168/obj"][0])
+    handles, model = scenarios.price_taker_batch(168, 3, solver)
+    lb, ub, _, _ = model.block.current_bounds()
+    model.ub = np.tile(ub, (3, 1))
+    model.ub[1, 5] = -1.0                                   # below the column's lower bound
+    solver.solve(model)
+    assert model.status.tolist() == [0, 2, 0] and np.isnan(model.objective[1])
+    limited = HipPdlpSolver(device=0, check_every=64, max_iter=128)
+    handles, model = scenarios.price_taker_batch(168, 2, limited)
+    limited.solve(model)
+    assert model.status.tolist() == [1, 1] and (model.iterations == 128).all()
