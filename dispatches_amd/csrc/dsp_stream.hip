@@ -42,6 +42,7 @@ namespace {
 
 constexpr int kTB = 256;                // threads per block
 constexpr int kNQ = 16;                 // partial-sum slots per (scenario, block)
+constexpr int kLongChunk = 2048;        // entries of a long vector per block in the plain-iteration kernels
 
 __device__ __forceinline__ double fin0(double v) { return (fabs(v) < INFINITY) ? v : 0.0; }
 __device__ __forceinline__ bool finite_d(double v) { return fabs(v) < INFINITY; }
@@ -76,11 +77,14 @@ __device__ __forceinline__ double ell_dot(const StreamMatrix &M, int v, const do
   return s;
 }
 
-// one block reduces one long vector (CSR segment) against `vec`
-__device__ __forceinline__ double long_dot(const StreamMatrix &M, int l, const double *__restrict__ vec) {
+// one block reduces one CHUNK (kLongChunk entries) of a long vector (CSR segment) against `vec`; the chunk partials are
+// summed in chunk order by the *_long_finish kernels (a design column that touches every period has 3 T entries: one
+// block per vector was the critical path of the whole iteration)
+__device__ __forceinline__ double long_dot(const StreamMatrix &M, int chunk, const double *__restrict__ vec) {
   __shared__ double red[kTB / 64];
   double s = 0.0;
-  for (int p = M.long_ptr[l] + threadIdx.x; p < M.long_ptr[l + 1]; p += kTB) s = fma(M.long_val[p], vec[M.long_idx[p]], s);
+  const int p0 = M.chunk_begin[chunk], p1 = M.chunk_end[chunk];
+  for (int p = p0 + threadIdx.x; p < p1; p += kTB) s = fma(M.long_val[p], vec[M.long_idx[p]], s);
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
@@ -90,6 +94,13 @@ __device__ __forceinline__ double long_dot(const StreamMatrix &M, int l, const d
   for (int w = 0; w < kTB / 64; ++w) t += red[w];
   __syncthreads();
   return t;                                     // every thread holds the total
+}
+
+// whole long vector by one block, chunk after chunk (check kernels only: once per check period)
+__device__ __forceinline__ double long_dot_all(const StreamMatrix &M, int l, const double *__restrict__ vec) {
+  double t = 0.0;
+  for (int ch = M.long_chunk_ptr[l]; ch < M.long_chunk_ptr[l + 1]; ++ch) t += long_dot(M, ch, vec);
+  return t;
 }
 
 // ---- init: scale the scenario's data, starting point, norms -----------------------------------------------------------
@@ -195,22 +206,14 @@ __global__ void k_primal(StreamArgs a) {
   const StreamProblem &P = a.P;
   const int b0 = blockIdx.y * SG;
   if ((int)blockIdx.x >= a.nblk_n) {
-    // long column: A^T y by one block
-    const int l = blockIdx.x - a.nblk_n;
-    const int j = P.C.long_id[l];
+    // chunk of a long column: partial A^T y, finished by k_primal_long_finish
+    const int ch = blockIdx.x - a.nblk_n;
     for (int u = 0; u < SG; ++u) {
       const int s = b0 + u;
       if (s >= a.b.B) break;
-      const StreamCtrl &c = a.W.ctrl[s];
-      if (c.done) continue;
-      const double aty = long_dot(P.C, l, a.W.y + (size_t)s * P.m);
-      if (threadIdx.x == 0) {
-        const size_t at = (size_t)s * P.n + j;
-        const double x = a.W.x[at];
-        const double gx = fma(-c.tau, a.W.c[at] - aty, x);
-        const double xp = clampd2(gx, a.W.lb[at], a.W.ub[at]);
-        a.W.xp[at] = xp; a.W.xbar[at] = 2.0 * xp - x;
-      }
+      if (a.W.ctrl[s].done) continue;
+      const double part = long_dot(P.C, ch, a.W.y + (size_t)s * P.m);
+      if (threadIdx.x == 0) a.W.long_partial[(size_t)s * a.nchunk_max + ch] = part;
     }
     return;
   }
@@ -236,6 +239,24 @@ __global__ void k_primal(StreamArgs a) {
   }
 }
 
+// one thread per (long column, scenario): ordered sum of its chunk partials, then the primal update of that column
+__global__ void k_primal_long_finish(StreamArgs a) {
+  const StreamProblem &P = a.P;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= P.C.nlong * a.b.B) return;
+  const int l = t % P.C.nlong, s = t / P.C.nlong;
+  const StreamCtrl &c = a.W.ctrl[s];
+  if (c.done) return;
+  double aty = 0.0;
+  for (int ch = P.C.long_chunk_ptr[l]; ch < P.C.long_chunk_ptr[l + 1]; ++ch) aty += a.W.long_partial[(size_t)s * a.nchunk_max + ch];
+  const int j = P.C.long_id[l];
+  const size_t at = (size_t)s * P.n + j;
+  const double x = a.W.x[at];
+  const double gx = fma(-c.tau, a.W.c[at] - aty, x);
+  const double xp = clampd2(gx, a.W.lb[at], a.W.ub[at]);
+  a.W.xp[at] = xp; a.W.xbar[at] = 2.0 * xp - x;
+}
+
 // ---- dual step + Halpern averaging (plain iterations) -----------------------------------------------------------------
 // thread t: row t (dual step, y averaging) and column t (x averaging); kofs = iterations since the last check
 template <int SG>
@@ -243,23 +264,13 @@ __global__ void k_dual_halpern(StreamArgs a, int kofs) {
   const StreamProblem &P = a.P;
   const int b0 = blockIdx.y * SG;
   if ((int)blockIdx.x >= a.nblk) {
-    const int l = blockIdx.x - a.nblk;          // long row
-    const int i = P.R.long_id[l];
+    const int ch = blockIdx.x - a.nblk;         // chunk of a long row: partial A xbar, finished by k_dual_long_finish
     for (int u = 0; u < SG; ++u) {
       const int s = b0 + u;
       if (s >= a.b.B) break;
-      const StreamCtrl &c = a.W.ctrl[s];
-      if (c.done) continue;
-      const double ax = long_dot(P.R, l, a.W.xbar + (size_t)s * P.n);
-      if (threadIdx.x == 0) {
-        const size_t at = (size_t)s * P.m + i;
-        const double y = a.W.y[at];
-        const double gy = fma(-c.sig, ax, y);
-        const double yp = gy - clampd2(gy, -c.sig * a.W.rhi[at], -c.sig * a.W.rlo[at]);
-        const double oml = 1.0 / (double)(c.k + kofs + 3);   // k counts this iteration: anchor weight 1 / (k + 2)
-        const double tt = 2.0 * yp - y;
-        a.W.yp[at] = yp; a.W.y[at] = fma(oml, a.W.y0[at] - tt, tt);
-      }
+      if (a.W.ctrl[s].done) continue;
+      const double part = long_dot(P.R, ch, a.W.xbar + (size_t)s * P.n);
+      if (threadIdx.x == 0) a.W.long_partial[(size_t)s * a.nchunk_max + ch] = part;
     }
     return;
   }
@@ -295,6 +306,24 @@ __global__ void k_dual_halpern(StreamArgs a, int kofs) {
   }
 }
 
+__global__ void k_dual_long_finish(StreamArgs a, int kofs) {
+  const StreamProblem &P = a.P;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= P.R.nlong * a.b.B) return;
+  const int l = t % P.R.nlong, s = t / P.R.nlong;
+  const StreamCtrl &c = a.W.ctrl[s];
+  if (c.done) return;
+  double ax = 0.0;
+  for (int ch = P.R.long_chunk_ptr[l]; ch < P.R.long_chunk_ptr[l + 1]; ++ch) ax += a.W.long_partial[(size_t)s * a.nchunk_max + ch];
+  const size_t at = (size_t)s * P.m + P.R.long_id[l];
+  const double y = a.W.y[at];
+  const double gy = fma(-c.sig, ax, y);
+  const double yp = gy - clampd2(gy, -c.sig * a.W.rhi[at], -c.sig * a.W.rlo[at]);
+  const double oml = 1.0 / (double)(c.k + kofs + 3);
+  const double tt = 2.0 * yp - y;
+  a.W.yp[at] = yp; a.W.y[at] = fma(oml, a.W.y0[at] - tt, tt);
+}
+
 // ---- check iteration, rows: dual step WITHOUT averaging + residual and KKT row quantities -------------------------------
 // partial slots (per scenario, block): 0 px = |dx|^2, 1 py = sum dy (2 (-sig A dx) + dy), 2 pres^2, 3 sum |y+| viol,
 // 4 dual objective (row part), 5 |y+ - y0|^2, 6 |x+ - x0|^2
@@ -320,7 +349,7 @@ __global__ void k_check_rows(StreamArgs a) {
       double axb = 0.0, axp = 0.0;
       if (is_long_block) {
         const int l = blockIdx.x - a.nblk;
-        const double t1 = long_dot(P.R, l, xb), t2 = long_dot(P.R, l, xpv);
+        const double t1 = long_dot_all(P.R, l, xb), t2 = long_dot_all(P.R, l, xpv);
         if (threadIdx.x == 0) { i = P.R.long_id[l]; axb = t1; axp = t2; }
       } else if (row) {
         i = t;
@@ -378,7 +407,7 @@ __global__ void k_kkt_cols(StreamArgs a) {
       double aty = 0.0;
       if (is_long_block) {
         const int l = blockIdx.x - a.nblk_n;
-        const double t1 = long_dot(P.C, l, ypv);
+        const double t1 = long_dot_all(P.C, l, ypv);
         if (threadIdx.x == 0) { j = P.C.long_id[l]; aty = t1; }
       } else if (col) {
         j = t;
@@ -550,7 +579,13 @@ hipError_t build_matrix(const HostCSR &M, std::vector<void *> &allocs, StreamMat
     }
   }
   if ((int)lid.size() > kStreamMaxLong) return hipErrorInvalidValue;
-  out->nvec = nv; out->W = W; out->nlong = (int)lid.size();
+  // chunks of at most kLongChunk entries: one block each in the plain-iteration kernels
+  std::vector<int32_t> cbeg, cend, cptr{0};
+  for (size_t l = 0; l < lid.size(); ++l) {
+    for (int p = lptr[l]; p < lptr[l + 1]; p += kLongChunk) { cbeg.push_back(p); cend.push_back(std::min(p + kLongChunk, lptr[l + 1])); }
+    cptr.push_back((int32_t)cbeg.size());
+  }
+  out->nvec = nv; out->W = W; out->nlong = (int)lid.size(); out->nchunk = (int)cbeg.size();
   hipError_t e;
   if ((e = up(allocs, val, &out->val)) != hipSuccess) return e;
   if ((e = up(allocs, idx, &out->idx)) != hipSuccess) return e;
@@ -559,6 +594,9 @@ hipError_t build_matrix(const HostCSR &M, std::vector<void *> &allocs, StreamMat
   if ((e = up(allocs, lptr, &out->long_ptr)) != hipSuccess) return e;
   if ((e = up(allocs, lidx, &out->long_idx)) != hipSuccess) return e;
   if ((e = up(allocs, lval, &out->long_val)) != hipSuccess) return e;
+  if ((e = up(allocs, cbeg, &out->chunk_begin)) != hipSuccess) return e;
+  if ((e = up(allocs, cend, &out->chunk_end)) != hipSuccess) return e;
+  if ((e = up(allocs, cptr, &out->long_chunk_ptr)) != hipSuccess) return e;
   *width = W;
   return hipSuccess;
 }
@@ -606,6 +644,7 @@ static hipError_t ensure_workspace(StreamSolver *S, int B) {
   if ((e = alloc((size_t)B * sizeof(StreamCtrl), (void **)&W.ctrl)) != hipSuccess) return e;
   if ((e = alloc((size_t)B * nblk_tot * kNQ * sizeof(double), (void **)&W.partial)) != hipSuccess) return e;
   if ((e = hipMemset(W.partial, 0, (size_t)B * nblk_tot * kNQ * sizeof(double))) != hipSuccess) return e;
+  if ((e = alloc((size_t)B * std::max(1, std::max(S->P.R.nchunk, S->P.C.nchunk)) * sizeof(double), (void **)&W.long_partial)) != hipSuccess) return e;
   if ((e = alloc(sizeof(int), (void **)&W.ndone)) != hipSuccess) return e;
   if (!S->ndone_host && (e = hipHostMalloc((void **)&S->ndone_host, sizeof(int))) != hipSuccess) return e;
   S->work_B = B;
@@ -623,8 +662,14 @@ static hipError_t run(StreamSolver *S, StreamArgs &a, hipStream_t st, int *perio
   const int B = a.b.B;
   const int groups = (B + SG - 1) / SG;
   const dim3 blk(kTB);
-  const dim3 g_primal(a.nblk_n + P.C.nlong, groups), g_dual(a.nblk + P.R.nlong, groups), g_cols(a.nblk_n + P.C.nlong, groups);
+  const dim3 g_primal(a.nblk_n + P.C.nchunk, groups), g_dual(a.nblk + P.R.nchunk, groups);
+  const dim3 g_rows_chk(a.nblk + P.R.nlong, groups), g_cols(a.nblk_n + P.C.nlong, groups);
   const dim3 g_elem(a.nblk, groups);
+  const int fin_c = (P.C.nlong * B + 63) / 64, fin_r = (P.R.nlong * B + 63) / 64;
+  auto primal = [&]() {
+    hipLaunchKernelGGL((k_primal<SG>), g_primal, blk, 0, st, a);
+    if (P.C.nlong) hipLaunchKernelGGL(k_primal_long_finish, dim3(fin_c), dim3(64), 0, st, a);
+  };
   const int C = std::max(1, a.opt.check_every);
   const int max_periods = (a.opt.max_iter + C - 1) / C;
   const int poll = 4;                                        // check periods between two looks at the finished counter
@@ -632,11 +677,12 @@ static hipError_t run(StreamSolver *S, StreamArgs &a, hipStream_t st, int *perio
   hipError_t e = hipSuccess;
   for (; period < max_periods; ++period) {
     for (int u = 0; u < C - 1; ++u) {
-      hipLaunchKernelGGL((k_primal<SG>), g_primal, blk, 0, st, a);
+      primal();
       hipLaunchKernelGGL((k_dual_halpern<SG>), g_dual, blk, 0, st, a, u);
+      if (P.R.nlong) hipLaunchKernelGGL(k_dual_long_finish, dim3(fin_r), dim3(64), 0, st, a, u);
     }
-    hipLaunchKernelGGL((k_primal<SG>), g_primal, blk, 0, st, a);
-    hipLaunchKernelGGL((k_check_rows<SG>), g_dual, blk, 0, st, a);
+    primal();
+    hipLaunchKernelGGL((k_check_rows<SG>), g_rows_chk, blk, 0, st, a);
     hipLaunchKernelGGL((k_kkt_cols<SG>), g_cols, blk, 0, st, a);
     hipLaunchKernelGGL(k_control, dim3(B), dim3(64), 0, st, a, C);
     hipLaunchKernelGGL((k_apply<SG>), g_elem, blk, 0, st, a);
@@ -660,6 +706,7 @@ hipError_t stream_solve(StreamSolver *S, const dsp_batch &batch, const dsp_optio
   a.nblk_n = (S->P.n + kTB - 1) / kTB;
   a.nblk = (std::max(S->P.n, S->P.m) + kTB - 1) / kTB;
   a.nblk_tot = a.nblk + std::max(S->P.R.nlong, S->P.C.nlong);
+  a.nchunk_max = std::max(1, std::max(S->P.R.nchunk, S->P.C.nchunk));
   if ((e = hipMemsetAsync(a.W.ndone, 0, sizeof(int), st)) != hipSuccess) return e;
   if ((e = hipMemsetAsync(a.W.partial, 0, (size_t)B * a.nblk_tot * kNQ * sizeof(double), st)) != hipSuccess) return e;
   hipLaunchKernelGGL(k_init, dim3(a.nblk, B), dim3(kTB), 0, st, a);

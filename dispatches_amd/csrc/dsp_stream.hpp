@@ -23,6 +23,9 @@ struct StreamMatrix {
   const int32_t *long_ptr;    // [nlong+1]
   const int32_t *long_idx;
   const double *long_val;
+  int nchunk;                 // chunks of <= 2048 entries over all long vectors
+  const int32_t *chunk_begin, *chunk_end;   // [nchunk]   entry range of each chunk
+  const int32_t *long_chunk_ptr;            // [nlong+1]  chunks of each long vector
 };
 
 struct StreamProblem {
@@ -45,6 +48,7 @@ struct StreamWork {
   double *y, *y0, *yp, *rlo, *rhi;              // [B][m]
   StreamCtrl *ctrl;                             // [B]
   double *partial;                              // [B][nblk_tot][16] ordered block partial sums
+  double *long_partial;                         // [B][nchunk_max] chunk partials of the long vectors
   int *ndone;                                   // scenarios finished
 };
 
@@ -57,6 +61,7 @@ struct StreamArgs {
   int nblk_n;      // blocks over the columns
   int nblk;        // blocks over max(n, m) elements
   int nblk_tot;    // + blocks of the long vectors (partial-sum stride)
+  int nchunk_max;  // stride of long_partial
 };
 
 struct StreamSolver {

@@ -307,6 +307,10 @@ class HipPdlpSolver:
 
         from .workflow.batch_model import SolveResults
 
+        if getattr(model.lp, "qdiag", None) is not None and np.any(model.lp.qdiag):
+            # the flattener can express lifted diagonal quadratic terms (LinearBlock.quadratic, Bidder(ramp_cost=...)),
+            # the kernels do not take Q yet: never drop it silently
+            raise NotImplementedError("quadratic objective terms (ramp_cost) are not supported by the HIP kernels yet")
         dlp = self._device_lp(model)
         dev = torch.device("cuda", self.device)
         B = model.n_scenario

@@ -149,6 +149,7 @@ class StandardFormLP:
     rhi: np.ndarray         # [m]  (+inf allowed)
     col_names: List[str] = field(default_factory=list)
     row_names: List[str] = field(default_factory=list)
+    qdiag: Optional[np.ndarray] = None     # [n] diagonal of Q for  min c.x + 1/2 sum_j qdiag_j x_j^2  (None = LP)
 
     @property
     def nnz(self) -> int:
@@ -162,7 +163,8 @@ class StandardFormLP:
     def objective(self, x: np.ndarray, c: Optional[np.ndarray] = None, c0: Optional[float] = None):
         c = self.c if c is None else c
         c0 = self.c0 if c0 is None else c0
-        return float(c @ x + c0)
+        quad = 0.0 if self.qdiag is None else 0.5 * float(self.qdiag @ (x * x))
+        return float(c @ x + c0) + quad
 
     def max_violation(self, x, lb=None, ub=None, rlo=None, rhi=None):
         lb = self.lb if lb is None else lb
@@ -198,6 +200,7 @@ class LinearBlock:
         self.row_hi: List[float] = []
         self.row_mutable: List[bool] = []
         self.expressions: Dict[str, Dict[int, LinExpr]] = {}
+        self.col_quad: Dict[int, float] = {}        # column -> weight w of an objective term (w / 2) x^2
         self.solution: Optional[np.ndarray] = None
         self._constructed = False
         self._kept_rows: Optional[np.ndarray] = None
@@ -235,6 +238,18 @@ class LinearBlock:
 
     def equality(self, name, body, rhs=0.0):
         return self.constraint(name, body, rhs, rhs)
+
+    def quadratic(self, name: str, expr, weight: float) -> Var:
+        """Objective term (weight / 2) * expr^2, LIFTED so that Q stays diagonal: a free column r with the row
+        r - expr = 0 and the term (weight / 2) r^2.  A diagonal Q keeps the proximal step of the first-order solver in
+        closed form (x+ = clip((x - tau (c - A^T y)) / (1 + tau q))); the solver's ABI accepts Q in CSR but only diagonal
+        ones (include/dsp_hip.h)."""
+        if weight < 0:
+            raise ValueError("quadratic terms must be convex (weight >= 0)")
+        r = self.var(name, -INF, INF)
+        self.constraint(name + ".def", LinExpr._as(r) - LinExpr._as(expr), 0.0, 0.0, mutable=True)   # never presolved away
+        self.col_quad[r.index] = float(weight)
+        return r
 
     def set_row_bounds(self, row: int, lo: float, hi: float):
         if self._kept_rows is not None and not self.row_mutable[row]:
@@ -349,6 +364,8 @@ class LinearBlock:
             data=np.asarray(data, np.float64), c=obj.dense(n), c0=obj.const,
             lb=lbv, ub=ubv, rlo=rlo, rhi=rhi,
             col_names=list(self.col_names), row_names=[self.row_names[i] for i in self._kept_rows],
+            qdiag=(None if not self.col_quad else
+                   np.array([self.col_quad.get(j, 0.0) for j in range(n)], np.float64)),
         )
 
     def current_bounds(self):

@@ -71,7 +71,7 @@ def _apply_cf_windows(model, wind_cols, wind_kw, cf_windows, cf_template, waste_
 
 
 def wind_battery_batch(B, T, solver, series="rts_gmlc_309.npz", stride=17, wind_mw=200.0, batt_mw=25.0,
-                       price_cap=500.0):
+                       price_cap=500.0, ramp_cost=0.0):
     """LP #1 (wind + battery) day-ahead bidding, B scenarios x T hours (BASELINE metric workload: T=24, B=4096;
     config 4 shape: T=48, bus 309, start hours (17 k) mod (N - T))."""
     s = load_series(series)
@@ -81,7 +81,8 @@ def wind_battery_batch(B, T, solver, series="rts_gmlc_309.npz", stride=17, wind_
     mp = MultiPeriodWindBattery(_thermal_data("309_WIND_1", "Carter", wind_mw, batt_mw),
                                 wind_capacity_factors=list(s["rt_cf"]), wind_pmax_mw=wind_mw,
                                 battery_pmax_mw=batt_mw, battery_energy_capacity_mwh=4 * batt_mw)
-    bidder = Bidder(mp, day_ahead_horizon=T, real_time_horizon=4, n_scenario=B, solver=solver, forecaster=fc)
+    bidder = Bidder(mp, day_ahead_horizon=T, real_time_horizon=4, n_scenario=B, solver=solver, forecaster=fc,
+                    ramp_cost=ramp_cost)
     model = bidder.day_ahead_model
     cfw = fc.windows(s["rt_cf"], 0, T, B)
     wind_cols = np.array([p["wind"].index for p in model.block.windBattery["periods"]])
@@ -160,10 +161,13 @@ WORKLOADS = {
     "nuclear_24h": (nuclear_batch, dict(T=24)),                  # config 2
     "nuclear_48h": (nuclear_batch, dict(T=48)),
 }
+# BASELINE config 5: the metric LP with a quadratic ramp cost rho/2 sum (P_T[t] - P_T[t-1])^2 (convex QP, diagonal Q after lifting)
+QP_WORKLOADS = {f"wind_battery_24h_qp{tag}": (wind_battery_batch, dict(T=24, ramp_cost=rho))
+                for tag, rho in (("001", 0.01), ("01", 0.1), ("1", 1.0))}
 
 
 def make_batch(name, B, solver):
-    fn, kw = WORKLOADS[name]
+    fn, kw = (WORKLOADS.get(name) or QP_WORKLOADS[name])
     bidder, model = fn(B=B, solver=solver, **kw)
     load_prices(bidder, model)
     return bidder, model

@@ -99,8 +99,12 @@ class AbstractBidder(ABC):
 
 class StochasticProgramBidder(AbstractBidder):
     def __init__(self, bidding_model_object, day_ahead_horizon, real_time_horizon, n_scenario, solver, forecaster,
-                 real_time_underbid_penalty=10000, strict=False):
+                 real_time_underbid_penalty=10000, strict=False, ramp_cost=0.0):
         self.bidding_model_object = bidding_model_object
+        # ramp_cost rho [$/MW^2] > 0 adds (rho / 2) sum_t (P_T[t] - P_T[t-1])^2 to every scenario's cost (BASELINE config 5:
+        # "stochastic bidder with quadratic ramp cost"; OUR extension - the reference has no such term): the problems
+        # become convex QPs with a diagonal Q after lifting (LinearBlock.quadratic)
+        self.ramp_cost = float(ramp_cost)
         # strict: raise if ANY scenario fails to reach optimality; otherwise failed scenarios are left out of the bids
         # (and listed in `failed_scenarios`), and only a solve without a single optimal scenario raises
         self.strict = bool(strict)
@@ -134,6 +138,9 @@ class StochasticProgramBidder(AbstractBidder):
             block.constraint(f"real_time_underbid[{t}]", pda - P_T[t] - u, -np.inf, 0.0)
             model.day_ahead_power.append(pda)
             model.real_time_underbid_power.append(u)
+        if self.ramp_cost > 0.0:
+            for t in range(1, horizon):
+                block.quadratic(f"power_ramp[{t}]", P_T[t] - P_T[t - 1], self.ramp_cost)
         model.P_T_rows = None
         model.solver_hints = dict(getattr(self.bidding_model_object, "solver_hints", None) or {})
         model.cost_weight = weight

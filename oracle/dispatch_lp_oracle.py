@@ -470,3 +470,28 @@ def wind_battery_price_taker(T, cf, lmp, wind_kw=847e3, wind_kw_ub=10000e3, batt
                - batt_cap_factor * (BATT_CAP_COST_KW + BATT_CAP_COST_KWH * BATTERY_DURATION))   # scenario family: scaled battery capital cost
     lp.add_cost((npv, 0.0), -1e-5)
     return PreparedLP(lp), dict(Cw=Cw, Pb=Pb, npv=(npv, 0.0), elec=elec, annual_scale=k)
+
+
+# ---- QP variant: quadratic ramp cost on the delivered power (BASELINE config 5; OUR extension, no reference formulation) ---
+def ramp_hessian(lp, fs, rho):
+    """Hessian of (rho / 2) sum_t (P_T[t] - P_T[t-1])^2 in the ORIGINAL variables (P_T[t] is a linear expression of two
+    or three columns, so Q = rho E^T D^T D E is not diagonal): a formulation independent of the product's lifted one."""
+    n = len(lp.names)
+    T = len(fs["P_T"])
+    E = sp.lil_matrix((T, n))
+    for t, (d, _k) in enumerate(fs["P_T"]):
+        for j, v in d.items():
+            E[t, j] = v
+    D = sp.diags([-np.ones(T - 1), np.ones(T - 1)], [0, 1], shape=(T - 1, T))
+    M = (D @ E.tocsr())
+    return (rho * (M.T @ M)).tocsc()
+
+
+def wind_battery_da_qp(T, cf, da, rt, rho, **kw):
+    """LP #1 + A.4 day-ahead bidding with the ramp cost:  min (LP objective) + (rho / 2) sum_t (P_T[t] - P_T[t-1])^2."""
+    lp = _LP()
+    fs = wind_battery_rows(lp, T, cf, kw.pop("wind_kw", 200e3), kw.pop("batt_kw", 25e3), kw.pop("batt_kwh", 100e3), **kw)
+    pda, u = add_da_bidding(lp, fs, da, rt)
+    P = PreparedLP(lp)
+    const = sum(k for _d, k in fs["P_T"])            # P_T constants cancel in the differences (all zero here anyway)
+    return P, ramp_hessian(lp, fs, rho), fs, pda
