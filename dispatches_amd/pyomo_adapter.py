@@ -1,0 +1,179 @@
+"""Live-Pyomo flattener: turn a POPULATED Pyomo block (what the reference's model objects build in
+``populate_model``: wind_battery_double_loop.py:136-179, nuclear_flowsheet_multiperiod_class.py:158-212, and what the
+upstream Bidder / Tracker wrap around it) into the ``StandardFormLP`` + per-solve vectors the HIP solver takes - so that
+ANY linear DISPATCHES flowsheet can use the backend without being restated on a ``LinearBlock``.
+
+Pyomo is NOT installed in the build container, so this module never imports it at module level and is written against
+the small part of Pyomo's public API it needs (duck-typed, exercised in tests/test_pyomo_adapter.py with stand-in objects
+that mimic that API; it has NOT been run against a real Pyomo model):
+
+    block.component_data_objects(ctype, active=True, descend_into=True)     Var / Constraint / Objective data objects
+    var.lb, var.ub, var.fixed, var.value, var.name
+    con.body, con.lower, con.upper, con.name          (lower / upper may be None; equality: lower == upper)
+    obj.expr, obj.sense                               (sense: +1 minimise, -1 maximise)
+    generate_standard_repn(expr, compute_values=True) -> .linear_vars, .linear_coefs, .constant, .is_linear()
+
+What it does (the reference's solvers do the same inside their LP writers + presolve):
+  * fixed variables (``var.fixed``) are folded into row constants / the objective constant; they get no column;
+  * a row whose body is a constant after that is checked for consistency and dropped;
+  * ``refresh()`` re-reads everything that mutable Params / ``fix()`` calls can change between solves (objective
+    coefficients, variable bounds, row bounds and the constants that fixed variables contribute) and verifies that the
+    constraint MATRIX did not change - the flatten-once contract of the batched solver.  A changed matrix (e.g. a
+    mutable Param that multiplies a variable inside a constraint) raises, so nothing is silently solved with stale data.
+"""
+from __future__ import annotations
+
+from typing import Callable, Dict, List, Optional
+
+import numpy as np
+
+from .lp import StandardFormLP
+
+INF = float("inf")
+
+
+def _pyomo():
+    """Import the pieces of Pyomo this adapter uses (only when no stand-ins are injected)."""
+    from pyomo.core.base.constraint import Constraint
+    from pyomo.core.base.objective import Objective
+    from pyomo.core.base.var import Var
+    from pyomo.repn import generate_standard_repn
+    return Var, Constraint, Objective, generate_standard_repn
+
+
+class PyomoLP:
+    """StandardFormLP view of a populated Pyomo block, refreshable after Param / bound / fix changes."""
+
+    def __init__(self, block, objective=None, ctypes=None, generate_standard_repn: Optional[Callable] = None):
+        if ctypes is None or generate_standard_repn is None:
+            Var, Constraint, Objective, gsr = _pyomo()
+            ctypes = ctypes or (Var, Constraint, Objective)
+            generate_standard_repn = generate_standard_repn or gsr
+        self._Var, self._Constraint, self._Objective = ctypes
+        self._repn = generate_standard_repn
+        self.block = block
+        self._objective = objective
+        self.lp: Optional[StandardFormLP] = None
+        self._cols: Dict[int, int] = {}          # id(var data) -> column
+        self._vars: List = []
+        self._rows: List = []                    # constraint data objects kept as rows
+        self._pattern = None
+        self.flatten()
+
+    # ---- walking ------------------------------------------------------------------------------------------------------
+    def _active_objective(self):
+        if self._objective is not None:
+            return self._objective
+        objs = list(self.block.component_data_objects(self._Objective, active=True, descend_into=True))
+        if len(objs) != 1:
+            raise ValueError(f"expected exactly one active objective on the block, found {len(objs)}")
+        return objs[0]
+
+    def _linear(self, expr, what):
+        r = self._repn(expr, compute_values=True)
+        if not r.is_linear():
+            raise ValueError(f"{what} is not linear: the HIP backend solves LPs only")
+        return r
+
+    def _row_data(self, con):
+        """(dict column -> coefficient, constant incl. fixed variables, lower, upper) of one constraint."""
+        r = self._linear(con.body, f"constraint {con.name}")
+        coefs: Dict[int, float] = {}
+        const = float(r.constant)
+        for v, a in zip(r.linear_vars, r.linear_coefs):
+            a = float(a)
+            if v.fixed:
+                const += a * float(v.value)
+            else:
+                j = self._cols.get(id(v))
+                if j is None:
+                    raise ValueError(f"variable {v.name} of constraint {con.name} is not a variable of the flattened block")
+                coefs[j] = coefs.get(j, 0.0) + a
+        lo = -INF if con.lower is None else float(con.lower)
+        hi = INF if con.upper is None else float(con.upper)
+        return coefs, const, lo, hi
+
+    # ---- flatten once ---------------------------------------------------------------------------------------------------
+    def flatten(self) -> StandardFormLP:
+        self._vars = [v for v in self.block.component_data_objects(self._Var, active=True, descend_into=True) if not v.fixed]
+        self._cols = {id(v): j for j, v in enumerate(self._vars)}
+        n = len(self._vars)
+        indptr, indices, data, rlo, rhi, names = [0], [], [], [], [], []
+        self._rows = []
+        for con in self.block.component_data_objects(self._Constraint, active=True, descend_into=True):
+            coefs, const, lo, hi = self._row_data(con)
+            coefs = {j: a for j, a in coefs.items() if a != 0.0}
+            if not coefs:
+                tol = 1e-8 * max(1.0, abs(const))
+                if const < lo - tol or const > hi + tol:
+                    raise ValueError(f"constraint {con.name} is infeasible once the fixed variables are substituted")
+                continue
+            for j in sorted(coefs):
+                indices.append(j)
+                data.append(coefs[j])
+            indptr.append(len(indices))
+            rlo.append(lo - const if np.isfinite(lo) else -INF)
+            rhi.append(hi - const if np.isfinite(hi) else INF)
+            names.append(con.name)
+            self._rows.append(con)
+        c, c0 = self._objective_vector(n)
+        lb, ub = self._bounds()
+        self._pattern = (np.asarray(indptr, np.int32), np.asarray(indices, np.int32), np.asarray(data, np.float64))
+        self.lp = StandardFormLP(n=n, m=len(self._rows), indptr=self._pattern[0], indices=self._pattern[1],
+                                 data=self._pattern[2], c=c, c0=c0, lb=lb, ub=ub,
+                                 rlo=np.asarray(rlo, np.float64), rhi=np.asarray(rhi, np.float64),
+                                 col_names=[v.name for v in self._vars], row_names=names)
+        return self.lp
+
+    def _objective_vector(self, n):
+        obj = self._active_objective()
+        r = self._linear(obj.expr, "objective")
+        sign = -1.0 if getattr(obj, "sense", 1) in (-1, "maximize") else 1.0        # the solver minimises
+        c = np.zeros(n)
+        c0 = float(r.constant)
+        for v, a in zip(r.linear_vars, r.linear_coefs):
+            if v.fixed:
+                c0 += float(a) * float(v.value)
+            else:
+                c[self._cols[id(v)]] += float(a)
+        self.objective_sign = sign
+        return sign * c, sign * c0
+
+    def _bounds(self):
+        lb = np.array([-INF if v.lb is None else float(v.lb) for v in self._vars], np.float64)
+        ub = np.array([INF if v.ub is None else float(v.ub) for v in self._vars], np.float64)
+        return lb, ub
+
+    # ---- refresh between solves ---------------------------------------------------------------------------------------
+    def refresh(self):
+        """Re-read (c, c0, lb, ub, rlo, rhi) after mutable Params / bounds / values of FIXED variables changed.  The set of
+        fixed variables and the matrix must be what flatten() saw."""
+        now_free = [v for v in self.block.component_data_objects(self._Var, active=True, descend_into=True) if not v.fixed]
+        if len(now_free) != len(self._vars) or any(a is not b for a, b in zip(now_free, self._vars)):
+            raise ValueError("the set of fixed variables changed since flatten(): flatten again (new constraint matrix)")
+        lp = self.lp
+        indptr, indices, data = self._pattern
+        rlo, rhi = np.empty(lp.m), np.empty(lp.m)
+        for i, con in enumerate(self._rows):
+            coefs, const, lo, hi = self._row_data(con)
+            cols = sorted(j for j, a in coefs.items() if a != 0.0)
+            a, b = indptr[i], indptr[i + 1]
+            if len(cols) != b - a or any(cj != ij for cj, ij in zip(cols, indices[a:b])) or \
+                    any(abs(coefs[cj] - dv) > 1e-12 * max(1.0, abs(dv)) for cj, dv in zip(cols, data[a:b])):
+                raise ValueError(f"constraint {con.name} changed its coefficients since flatten(): a mutable Param multiplies a "
+                                 "variable there; the batched solver shares ONE matrix across solves - flatten again")
+            rlo[i] = lo - const if np.isfinite(lo) else -INF
+            rhi[i] = hi - const if np.isfinite(hi) else INF
+        lp.c, lp.c0 = self._objective_vector(lp.n)
+        lp.lb, lp.ub = self._bounds()
+        lp.rlo, lp.rhi = rlo, rhi
+        return lp
+
+    # ---- solution back into the Pyomo variables ---------------------------------------------------------------------------
+    def load_solution(self, x):
+        for v, xv in zip(self._vars, np.asarray(x, float)):
+            v.value = float(xv)
+
+    def objective_value(self, x):
+        """Objective in the model's own sense (a maximisation problem reports the maximum)."""
+        return self.objective_sign * (float(self.lp.c @ np.asarray(x, float)) + self.lp.c0)

@@ -1,0 +1,207 @@
+"""Device-resident batched double loop: the rolling-horizon solves of B independent wind + battery plants (BASELINE config 4:
+"RTS-GMLC full-year double loop, 8192 scenarios sharded across 8 x MI355X").
+
+What the reference does for ONE plant through Prescient's callbacks (run_double_loop_battery.py:222-305 ->
+DoubleLoopCoordinator.bid_into_DAM / bid_into_RTM / track_sced_signal):
+
+    every day   : day-ahead bids            Bidder.compute_day_ahead_bids          (48-h LP)
+    every hour  : real-time bids            Bidder.compute_real_time_bids          (4-h LP, day_ahead_power fixed to the
+                                                                                    cleared DA dispatch where it is known)
+                  tracking of the dispatch  Tracker.track_market_dispatch          (4-h LP)
+                  state hand-off            get_implemented_profile -> update_model on tracker and bidder
+                                            (initial SOC / energy throughput re-fixed to the realised values ROUNDED to
+                                            2 dp, clock advanced one hour, capacity-factor window shifted;
+                                            wind_battery_double_loop.py:181-274)
+
+is done here for B plants at once with every per-plant vector resident in HBM: price / capacity-factor windows are
+gathered on the device, the objective vectors and the mutable bounds of the three LPs are rewritten by device index
+operations, the solves go straight through the C ABI on device pointers (day-ahead: PDLP kernel; the hourly LPs: the
+in-wave simplex), and the realised state (SOC, throughput) never leaves the device between hours - the rolling
+hand-off of SURVEY.md 8(f)-3.  No Prescient: the market is a stub that clears every offer at its maximum (day-ahead
+dispatch = day-ahead offer, real-time dispatch = real-time offer), as in tests/test_double_loop_stub.py.  Day-ahead bids
+for day d are computed at hour 0 of day d from the realised state (the reference computes them during day d - 1 from a
+projected state; without a unit-commitment run in between the two coincide in the stub market).
+
+Scenario k is the plant seen through the price / capacity-factor year that starts at hour (stride * k) mod N of the
+RTS-GMLC series (the BASELINE config-4 windows of SURVEY.md 8(d)).  Shards are contiguous scenario ranges: one rank
+per GPU runs its shard with no communication and the per-scenario annual results are all-gathered once at the end
+(dispatches_amd.distributed.gather_device_results).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import scenarios
+from .hip_solver import DeviceLP, default_options
+
+
+class _NoSolver:
+    def solve(self, *a, **k):
+        raise RuntimeError("template model: never solved on the host")
+
+
+class _DeviceModel:
+    """One of the three LPs on the device: handle + per-scenario tensors + the index sets the rolling updates touch."""
+
+    def __init__(self, model, B, dev, device_index, hints=None):
+        import torch
+        self.lp = model.lp
+        self.T = len(model.HOUR)
+        t = lambda a, dt=torch.float64: torch.as_tensor(np.ascontiguousarray(a), dtype=dt, device=dev)
+        lb, ub, rlo, rhi = model.block.current_bounds()
+        self.c = t(model.base_c if hasattr(model, "base_c") else model.c[0]).repeat(B, 1)
+        self.base_c = self.c[0].clone()
+        self.lb, self.ub = t(lb).repeat(B, 1), t(ub).repeat(B, 1)
+        self.rlo, self.rhi = t(rlo).repeat(B, 1), t(rhi).repeat(B, 1)
+        fam = model.block.windBattery
+        per = fam["periods"]
+        idx = lambda cols: torch.as_tensor(np.asarray(cols, np.int64), device=dev)
+        self.wind_cols = idx([p["wind"].index for p in per])
+        self.soc_init, self.thr_init = fam["soc_init"].index, fam["thr_init"].index
+        self.soc0, self.thr0 = per[0]["state_of_charge"].index, per[0]["energy_throughput"].index
+        self.wind_kw = float(fam["wind_kw"])
+        # P_T[t] = 1e-3 (grid_elec[t] + elec_out[t]): the two columns of every hour
+        self.pt_cols = idx([[p["grid_elec"].index, p["elec_out"].index] for p in per])       # [T, 2]
+        self.opts = default_options(**(hints or {}))
+        self.dlp = DeviceLP(self.lp, device_index, self.opts)
+        self.out = None
+
+    def power_output(self, x):
+        return 1e-3 * x[:, self.pt_cols].sum(dim=2)                                            # [B, T] MW
+
+    def solve(self, B):
+        self.out = self.dlp.solve(B, self.c, self.lb, self.ub, self.rlo if self.lp.m else None,
+                                  self.rhi if self.lp.m else None, options=self.opts, out=self.out, sync_stats=False)
+        return self.out
+
+
+class BatchedWindBatteryDoubleLoop:
+    def __init__(self, n_scenarios, device=0, first_scenario=0, series="rts_gmlc_309.npz", stride=17,
+                 day_ahead_horizon=48, real_time_horizon=4, tracking_horizon=4, wind_mw=200.0, batt_mw=25.0,
+                 price_cap=500.0):
+        import torch
+        from .workflow import Tracker
+        self.B = B = int(n_scenarios)
+        self.dev = dev = torch.device("cuda", device)
+        s = scenarios.load_series(series)
+        self.N = N = len(s["rt_lmp"])
+        t = lambda a: torch.as_tensor(np.ascontiguousarray(a, np.float64), device=dev)
+        self.da_series = t(np.clip(s["da_lmp"], 0.0, price_cap))
+        self.rt_series = t(np.clip(s["rt_lmp"], 0.0, price_cap))
+        self.cf_series = t(s["rt_cf"])
+        ids = first_scenario + np.arange(B)
+        self.start = torch.as_tensor((stride * ids) % N, dtype=torch.int64, device=dev)
+        self.T_da, self.T_rt, self.T_tr = day_ahead_horizon, real_time_horizon, tracking_horizon
+        # ---- the three LPs, built ONCE through the product's own model objects (B = 1 templates) --------------------
+        bidder, da_model = scenarios.wind_battery_batch(1, day_ahead_horizon, _NoSolver(), series=series, stride=stride,
+                                                        wind_mw=wind_mw, batt_mw=batt_mw, price_cap=price_cap)
+        rt_model = bidder.real_time_model
+        if real_time_horizon != 4:
+            raise NotImplementedError("real_time_horizon is 4 in every reference driver")
+        tracker = Tracker(tracking_model_object=bidder.bidding_model_object.__class__(
+            model_data=bidder.bidding_model_object.model_data, wind_capacity_factors=list(s["rt_cf"][:tracking_horizon]),
+            wind_pmax_mw=wind_mw, battery_pmax_mw=batt_mw, battery_energy_capacity_mwh=4 * batt_mw),
+            tracking_horizon=tracking_horizon, n_tracking_hour=1, solver=_NoSolver())
+        tracker._pass_market_dispatch([0.0] * tracking_horizon)           # dispatch rows become equalities
+        tr_model = tracker.model
+        self.penalty = float(bidder.real_time_underbid_penalty)
+        self.da = _DeviceModel(da_model, B, dev, device, hints=getattr(da_model, "solver_hints", None))
+        self.rt = _DeviceModel(rt_model, B, dev, device, hints=getattr(rt_model, "solver_hints", None))
+        self.tr = _DeviceModel(tr_model, B, dev, device, hints=getattr(tr_model, "solver_hints", None))
+        idx = lambda cols: torch.as_tensor(np.asarray(cols, np.int64), device=dev)
+        self.da.pda_cols, self.rt.pda_cols = idx(da_model.pda_cols), idx(rt_model.pda_cols)
+        self.tr.track_rows = idx([tr_model.block.kept_row_index(r) for r in tr_model.tracking_rows])
+        self.tr.c[:] = t(tr_model.c[0])
+        # ---- realised state + annual accumulators (device) -----------------------------------------------------------
+        z = lambda: torch.zeros(B, dtype=torch.float64, device=dev)
+        self.soc, self.thr = z(), z()
+        self.revenue, self.energy_mwh, self.da_energy_mwh = z(), z(), z()
+        self.bad = torch.zeros((), dtype=torch.bool, device=dev)          # any non-optimal status so far
+        self.hour = 0
+        self.solves = 0
+
+    # -- windows -----------------------------------------------------------------------------------------------------------
+    def _window(self, series, hour, T):
+        import torch
+        idx = (self.start[:, None] + hour + torch.arange(T, device=self.dev)[None, :]) % self.N
+        return series[idx]                                                                     # [B, T]
+
+    def _set_prices(self, m, da, rt):
+        """c = base - RT x dP_T/dx - (DA - RT) on day_ahead_power   (Bidder._pass_price_forecasts, on the device)"""
+        m.c[:] = m.base_c
+        m.c[:, m.pt_cols[:, 0]] -= 1e-3 * rt
+        m.c[:, m.pt_cols[:, 1]] -= 1e-3 * rt
+        m.c[:, m.pda_cols] -= da - rt
+
+    def _set_state(self, m, hour):
+        """What update_model writes: initial SOC / throughput fixed to the realised values, wind availability of the window"""
+        m.lb[:, m.soc_init] = self.soc
+        m.ub[:, m.soc_init] = self.soc
+        m.lb[:, m.thr_init] = self.thr
+        m.ub[:, m.thr_init] = self.thr
+        m.ub[:, m.wind_cols] = m.wind_kw * self._window(self.cf_series, hour, m.T)
+
+    def _check(self, out):
+        self.bad = self.bad | (out["status"] != 0).any()
+        self.solves += self.B
+
+    # -- one simulated day -------------------------------------------------------------------------------------------------
+    def day_ahead(self):
+        """Day-ahead bids of every plant for the day that starts at self.hour: returns the offers [B, 24] (= cleared dispatch)."""
+        m, h0 = self.da, self.hour
+        da, rt = self._window(self.da_series, h0, m.T), self._window(self.rt_series, h0, m.T)
+        self._set_prices(m, da, rt)
+        self._set_state(m, h0)
+        m.lb[:, m.pda_cols] = 0.0
+        m.ub[:, m.pda_cols] = float("inf")
+        out = m.solve(self.B)
+        self._check(out)
+        self.da_offer = out["x"][:, m.pda_cols][:, :24].clone()
+        self.da_prices = da[:, :24].clone()
+        self.day_start = h0
+        self.da_energy_mwh += self.da_offer.sum(1)
+        return self.da_offer
+
+    def hour_step(self):
+        """Real-time bid, stub clearing, tracking and state hand-off of ONE hour for every plant (all on the device)."""
+        import torch
+        h, k = self.hour, self.hour - self.day_start                   # k = hour of the day
+        m = self.rt
+        rt = self._window(self.rt_series, h, m.T)
+        da = self._window(self.da_series, h, m.T).clone()
+        known = min(m.T, 24 - k)                                         # hours of the horizon inside the cleared day
+        da[:, :known] = self.da_prices[:, k:k + known]
+        self._set_prices(m, da, rt)
+        self._set_state(m, h)
+        m.lb[:, m.pda_cols] = 0.0
+        m.ub[:, m.pda_cols] = float("inf")
+        m.lb[:, m.pda_cols[:known]] = self.da_offer[:, k:k + known]
+        m.ub[:, m.pda_cols[:known]] = self.da_offer[:, k:k + known]
+        out = m.solve(self.B)
+        self._check(out)
+        offer = m.power_output(out["x"])                                 # real-time offer = SCED dispatch in the stub market
+        # tracking
+        tr = self.tr
+        self._set_state(tr, h)
+        tr.rlo[:, tr.track_rows] = offer[:, :tr.T]
+        tr.rhi[:, tr.track_rows] = offer[:, :tr.T]
+        out = tr.solve(self.B)
+        self._check(out)
+        x = out["x"]
+        delivered = tr.power_output(x)[:, 0]
+        # implemented profile -> next hour's initial state, rounded to 2 dp as update_model does
+        self.soc = torch.round(x[:, tr.soc0] * 100.0) / 100.0
+        self.thr = torch.round(x[:, tr.thr0] * 100.0) / 100.0
+        self.revenue += delivered * rt[:, 0] + self.da_offer[:, k] * (self.da_prices[:, k] - rt[:, 0])
+        self.energy_mwh += delivered
+        self.hour += 1
+        return delivered
+
+    def run_day(self):
+        self.day_ahead()
+        for _ in range(24):
+            self.hour_step()
+
+    def results(self):
+        """Per-scenario totals so far (device tensors) + whether every solve was optimal (one device->host sync)."""
+        return dict(obj=self.revenue, energy_mwh=self.energy_mwh, soc=self.soc, throughput=self.thr), not bool(self.bad.item())
