@@ -98,9 +98,16 @@ class AbstractBidder(ABC):
 
 
 class StochasticProgramBidder(AbstractBidder):
+    default_scenario_coupling = "independent"
+
     def __init__(self, bidding_model_object, day_ahead_horizon, real_time_horizon, n_scenario, solver, forecaster,
-                 real_time_underbid_penalty=10000, strict=False, ramp_cost=0.0):
+                 real_time_underbid_penalty=10000, strict=False, ramp_cost=0.0, scenario_coupling=None):
         self.bidding_model_object = bidding_model_object
+        # scenario_coupling: None = the class default (SelfScheduler: "non_anticipative" as upstream; Bidder:
+        # "independent" - the batched independent-scenario solve this package is built around; "monotone" gives the
+        # upstream Bidder's bid-curve monotonicity rows).  Coupled problems are ONE LP (workflow/coupling.py).
+        self.scenario_coupling = scenario_coupling or self.default_scenario_coupling
+        self._coupled = {}
         # ramp_cost rho [$/MW^2] > 0 adds (rho / 2) sum_t (P_T[t] - P_T[t-1])^2 to every scenario's cost (BASELINE config 5:
         # "stochastic bidder with quadratic ramp cost"; OUR extension - the reference has no such term): the problems
         # become convex QPs with a diagonal Q after lifting (LinearBlock.quadratic)
@@ -206,8 +213,7 @@ class StochasticProgramBidder(AbstractBidder):
             if v.lb != 0.0 or np.isfinite(v.ub):
                 model.block.set_bounds(v, 0.0, np.inf)
         self._pass_price_forecasts(model, da, rt)
-        self._check_scenario_coupling(da, rt)
-        self.solver.solve(model, tee=False)
+        self._solve(model, da, rt, energy_prices=da)
         self._check_solution(model, "Day-ahead", date, hour)
         bids = self._assemble_bids(model, da, hour, market="Day-ahead")
         self.record_bids(bids, model=model, date=date, hour=hour, market="Day-ahead")
@@ -233,16 +239,30 @@ class StochasticProgramBidder(AbstractBidder):
             else:
                 model.block.set_bounds(v, 0.0, np.inf)
         self._pass_price_forecasts(model, da, rt)
-        self._check_scenario_coupling(da, rt)
-        self.solver.solve(model, tee=False)
+        self._solve(model, da, rt, energy_prices=rt)
         self._check_solution(model, "Real-time", date, hour)
         bids = self._assemble_bids(model, rt, hour, market="Real-time")
         self.record_bids(bids, model=model, date=date, hour=hour, market="Real-time")
         return bids
 
-    # -- solution checks -----------------------------------------------------------------------------------
-    def _check_scenario_coupling(self, da, rt):
-        """Hook for bidders whose upstream formulation couples the scenarios (see SelfScheduler)."""
+    # -- solve: independent scenarios (one batch) or the coupled LP ---------------------------------------------
+    def _solve(self, model, da, rt, energy_prices):
+        identical = self.n_scenario == 1 or (np.all(da == da[0]) and np.all(rt == rt[0]) and self._bounds_identical(model))
+        if self.scenario_coupling == "independent" or identical:
+            # identical scenarios make every coupling row vacuous: scenario 0's LP IS the stochastic program
+            self.solver.solve(model, tee=False)
+            model.coupled_objective = None
+            return
+        from .coupling import CoupledScenarioModel
+        big = self._coupled.get(id(model))
+        if big is None:
+            big = self._coupled[id(model)] = CoupledScenarioModel(model, self.scenario_coupling)
+        big.load(energy_prices)
+        self.solver.solve(big, tee=False)
+
+    @staticmethod
+    def _bounds_identical(model):
+        return all(a is None or np.ndim(a) == 1 or np.all(a == a[0]) for a in (model.lb, model.ub, model.rlo, model.rhi))
 
     def _check_solution(self, model, market, date, hour):
         """Never turn an unconverged / invalid scenario into a bid: the solver reports ITERATION_LIMIT, and NaN x for the
@@ -385,24 +405,16 @@ class Bidder(StochasticProgramBidder):
 
 
 class SelfScheduler(StochasticProgramBidder):
-    """Self-schedule bidder: p_max[t] = round(scheduled power, 4) (pinned by SURVEY.md A.7 G1)."""
+    """Self-schedule bidder: p_max[t] = round(scheduled power, 4) (pinned by SURVEY.md A.7 G1).  With n_scenario > 1 and
+    different scenarios the upstream non-anticipativity rows (one day-ahead schedule for all price scenarios) are
+    imposed: the scenarios are solved as ONE coupled LP (workflow/coupling.py), so scenario 0's schedule is THE schedule."""
+    default_scenario_coupling = "non_anticipative"
 
     def __init__(self, bidding_model_object, day_ahead_horizon, real_time_horizon, n_scenario, solver, forecaster,
                  real_time_underbid_penalty=10000, fixed_to_schedule=False, strict=True):
         self.fixed_to_schedule = fixed_to_schedule
         super().__init__(bidding_model_object, day_ahead_horizon, real_time_horizon, n_scenario, solver, forecaster,
                          real_time_underbid_penalty, strict=strict)
-
-    def _check_scenario_coupling(self, da, rt):
-        """Upstream couples the scenarios of a self-schedule by non-anticipativity rows (one day-ahead schedule for all
-        price scenarios).  With identical scenarios (a one-day Backcaster history: every reference golden and notebook
-        log) those rows are vacuous and scenario 0's LP IS the stochastic program; with different scenarios the
-        independent LPs solved here are not, so refuse instead of silently returning scenario 0's schedule."""
-        if self.n_scenario > 1 and not (np.all(da == da[0]) and np.all(rt == rt[0])):
-            raise NotImplementedError(
-                "SelfScheduler with n_scenario > 1 and DIFFERENT price scenarios needs the upstream non-anticipativity "
-                "coupling (day_ahead_power equal across scenarios), which the batched independent-scenario solve does "
-                "not impose; use n_scenario=1, identical scenarios, or the Bidder (independent bid curves)")
 
     def _assemble_bids(self, model, energy_prices, hour, market):
         md = self.bidding_model_object.model_data

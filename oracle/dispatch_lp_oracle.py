@@ -495,3 +495,33 @@ def wind_battery_da_qp(T, cf, da, rt, rho, **kw):
     P = PreparedLP(lp)
     const = sum(k for _d, k in fs["P_T"])            # P_T constants cancel in the differences (all zero here anyway)
     return P, ramp_hessian(lp, fs, rho), fs, pda
+
+
+# ---- coupled day-ahead problem of the stochastic bidders for n_scenario > 1 with DIFFERENT scenarios -----------------------
+def wind_battery_da_coupled(T, cf, da, rt, mode, **kw):
+    """S = len(da) copies of LP #1 + A.4 in ONE LP, objective = sum of the scenario objectives, plus the upstream coupling
+    rows (UNPINNED by any reference vector - every golden has identical scenarios):
+        mode "non_anticipative" (SelfScheduler): pda[s, t] = pda[0, t]
+        mode "monotone"         (Bidder):        (pda[k, t] - pda[j, t]) (DA[k, t] - DA[j, t]) >= 0   for all pairs j < k
+    `cf` is shared (one plant), `da` / `rt` are [S][T].  Returns (PreparedLP, [pda columns per scenario])."""
+    lp = _LP()
+    S = len(da)
+    pdas = []
+    for s in range(S):
+        fs = wind_battery_rows(lp, T, cf, kw.get("wind_kw", 200e3), kw.get("batt_kw", 25e3), kw.get("batt_kwh", 100e3))
+        pda, _u = add_da_bidding(lp, fs, da[s], rt[s])
+        pdas.append(pda)
+    if mode == "non_anticipative":
+        for s in range(1, S):
+            for t in range(T):
+                lp.row({pdas[s][t]: 1.0, pdas[0][t]: -1.0}, 0.0, 0.0)
+    elif mode == "monotone":
+        for j in range(S):
+            for k in range(j + 1, S):
+                for t in range(T):
+                    d = da[k][t] - da[j][t]
+                    if d != 0.0:
+                        lp.row({pdas[k][t]: np.sign(d), pdas[j][t]: -np.sign(d)}, 0.0, np.inf)
+    else:
+        raise ValueError(mode)
+    return PreparedLP(lp), pdas

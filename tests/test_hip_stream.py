@@ -59,3 +59,32 @@ def test_streaming_edge_cases():
     handles, model = scenarios.price_taker_batch(168, 2, limited)
     limited.solve(model)
     assert model.status.tolist() == [1, 1] and (model.iterations == 128).all()
+
+
+@gpu
+@pytest.mark.parametrize("mode", ["non_anticipative", "monotone"])
+def test_coupled_stochastic_bidders_on_the_gpu(rts309, mode):
+    """n_scenario = 3 with different scenarios: the coupled day-ahead LP (582 columns, 408 / 432 rows: beyond the fused
+    kernels, so the streaming path solves it) against the oracle's independent coupled formulation."""
+    from dispatches_amd.hip_solver import HipPdlpSolver
+    from dispatches_amd.workflow import Bidder, SelfScheduler
+    from oracle import dispatch_lp_oracle as orc
+    from tests.test_workflow_cpu import _thermal_bidder
+    T, S = 24, 3
+    cls, kw = (SelfScheduler, {}) if mode == "non_anticipative" else (Bidder, dict(scenario_coupling="monotone"))
+    solver = HipPdlpSolver(device=0, check_every=64)
+    bidder = _thermal_bidder(rts309, solver, S, cls=cls, history_days=3, **kw)
+    bidder.compute_day_ahead_bids(date="2020-01-02")
+    model = bidder.day_ahead_model
+    assert solver.last_stats.streaming == 1 and (model.status == 0).all()
+    P, _ = orc.wind_battery_da_coupled(T, rts309["rt_cf"][:T], model.da_prices, model.rt_prices, mode)
+    ref = P.solve(tight=True)[1]
+    assert model.coupled_objective == pytest.approx(ref, rel=1e-6)
+    pda = model.x[:, model.pda_cols]
+    if mode == "non_anticipative":
+        assert np.allclose(pda, pda[0], atol=1e-4)
+    else:
+        da = model.da_prices
+        for j in range(S):
+            for k in range(j + 1, S):
+                assert np.all((pda[k] - pda[j]) * (da[k] - da[j]) >= -1e-3)

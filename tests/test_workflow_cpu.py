@@ -247,13 +247,41 @@ def test_unconverged_scenarios_never_become_bids(rts309):
         tracker.track_market_dispatch(market_dispatch=[0, 1.5, 15, 24.5], date="2020-01-02", hour="00:00")
 
 
-def test_self_scheduler_refuses_uncoupled_different_scenarios(rts309):
-    """Upstream couples a self-schedule's scenarios (non-anticipativity).  Identical scenarios (every reference golden)
-    are fine; different ones must not silently return scenario 0's schedule."""
+def test_self_scheduler_identical_scenarios_need_no_coupling(rts309):
+    """One stored day -> 3 identical scenarios (every reference golden): the coupling rows are vacuous and the batch solve
+    of the scenarios IS the stochastic program."""
     ident = _thermal_bidder(rts309, HighsTestSolver(), 3, cls=SelfScheduler)
-    bids = ident.compute_day_ahead_bids(date="2020-01-02")          # one stored day -> 3 identical scenarios
-    assert len(bids) == 24
-    diff = _thermal_bidder(rts309, HighsTestSolver(), 2, cls=SelfScheduler, history_days=2)
-    # horizon 24 from a 2-day history: scenario 0 = day 2, scenario 1 = day 1 -> different prices
-    with pytest.raises(NotImplementedError, match="non-anticipativity"):
-        diff.compute_day_ahead_bids(date="2020-01-02")
+    bids = ident.compute_day_ahead_bids(date="2020-01-02")
+    assert len(bids) == 24 and ident.day_ahead_model.coupled_objective is None
+
+
+@pytest.mark.parametrize("cls,mode", [(SelfScheduler, "non_anticipative"), (Bidder, "monotone")])
+def test_coupled_scenarios_match_the_oracle(rts309, cls, mode):
+    """n_scenario = 3 with DIFFERENT price scenarios (a 3-day Backcaster history): the upstream coupling rows make the
+    stochastic program ONE LP.  Checked against the oracle's independent coupled formulation (unpinned by reference
+    vectors: SURVEY 8(c)); the self-schedule is the same in every scenario, the bid curves are monotone."""
+    from oracle import dispatch_lp_oracle as orc
+    T, S = 24, 3
+    kw = dict(scenario_coupling=mode) if cls is Bidder else {}
+    bidder = _thermal_bidder(rts309, HighsTestSolver(), S, cls=cls, history_days=3, **kw)
+    assert bidder.scenario_coupling == mode
+    bids = bidder.compute_day_ahead_bids(date="2020-01-02")
+    model = bidder.day_ahead_model
+    da, rt = model.da_prices, model.rt_prices
+    assert not np.all(da == da[0])
+    P, pdas = orc.wind_battery_da_coupled(T, rts309["rt_cf"][:T], da, rt, mode)
+    ref = P.solve(tight=True)[1]
+    assert model.coupled_objective == pytest.approx(ref, rel=1e-7)
+    assert float(np.sum(model.objective)) == pytest.approx(ref, rel=1e-7)
+    pda = model.x[:, model.pda_cols]
+    if mode == "non_anticipative":
+        assert np.allclose(pda, pda[0], atol=1e-6)
+        assert [bids[t]["309_WIND_1"]["p_max"] for t in range(T)] == pytest.approx(np.round(pda[0], 4).tolist(), abs=1e-4)
+    else:
+        for j in range(S):
+            for k in range(j + 1, S):
+                assert np.all((pda[k] - pda[j]) * (da[k] - da[j]) >= -1e-6)
+    # the independent solve of the same scenarios is a relaxation: its optimum cannot be worse
+    indep = _thermal_bidder(rts309, HighsTestSolver(), S, cls=Bidder, history_days=3)
+    indep.compute_day_ahead_bids(date="2020-01-02")
+    assert float(np.sum(indep.day_ahead_model.objective)) <= ref + 1e-6 * abs(ref)
