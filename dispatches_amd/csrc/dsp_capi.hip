@@ -376,6 +376,8 @@ int dsp_solve(dsp_handle *h, const dsp_batch *batch, const dsp_options *opt, dsp
     sa.A_dense = h->A_dense; sa.col_scale = h->P.col_scale; sa.row_scale = h->P.row_scale; sa.b = *batch;
     sa.tol_p = 1e-10; sa.tol_d = 1e-12; sa.tol_piv = 1e-9;
     sa.unsolved = a.queue + 1;
+    static const int sx_debug = getenv("DSP_SX_DEBUG") ? atoi(getenv("DSP_SX_DEBUG")) : 0;
+    sa.debug_keep = sx_debug;
     const int per_cu = std::max<int>(1, std::min<int>(32, (int)((size_t)h->lds_limit / h->sx_lds)));
     const int sgrid = std::min(B, h->num_cus * per_cu);
     HIP_TRY(launch_simplex(sa, sgrid, h->sx_lds, st));

@@ -75,6 +75,7 @@ struct SimplexArgs {
   dsp_batch b;
   double tol_p, tol_d, tol_piv;
   int *unsolved;               // incremented for every scenario left to the PDLP kernel
+  int debug_keep;              // development (DSP_SX_DEBUG=1): status 51 / 52 instead of the hand-over
 };
 
 struct SpmvArgs {

@@ -294,31 +294,51 @@ __global__ void __launch_bounds__(64) simplex_kernel(SimplexArgs a) {
     wave_lds_fence();
     double xs[CQ];
     double po = 0.0;
-    bool okv = true;
+    bool okv = true, okb = true;
 #pragma unroll
     for (int q = 0; q < CQ; ++q) {
       const int j = lane + 64 * q;
       xs[q] = (j < N) ? xval[j] : 0.0;
       if (j < N) {
-        const double tol = 1e-9 * (1.0 + fabs(xs[q]));
-        if (xs[q] < lo[q] - tol || xs[q] > hi[q] + tol || !(xs[q] == xs[q])) okv = false;
+        // same scale as the simplex' own feasibility tolerance (tol_p (1 + the variable's larger finite bound)), 10x looser
+        const double tol = 1e-9 * (1.0 + fmax(fabs(xs[q]), fmax(fabs(finite_or_zero(lo[q])), fabs(finite_or_zero(hi[q])))));
+        if (xs[q] < lo[q] - tol || xs[q] > hi[q] + tol || !(xs[q] == xs[q])) { okv = false; okb = false; }
       }
       if (j < n) po = fma(cost[q], xs[q], po);
     }
     po = wave_sum(po);
-    if (lane < m) {
-      // row residual with the ORIGINAL scaled matrix: sum_j a_ij x_j - s_i
-      double res = -xval[n + lane], mag = fabs(xval[n + lane]);
-      for (int j = 0; j < n; ++j) {
-        const double t = a.A_dense[(size_t)lane * n + j] * xval[j];
-        res += t; mag += fabs(t);
+    {
+      // row residuals with the ORIGINAL scaled matrix, sum_j a_ij x_j - s_i, against the scale of the whole vertex: the
+      // basic values carry an ABSOLUTE drift of ~1e-11 x the largest number in the tableau (1e5 kWh states), which lands
+      // on rows whose own terms may all be ~0 (seen: 4.9e-6 on such a row, 5e-11 of the state-of-charge scale).  The
+      // certificate is there to catch a broken tableau, not rounding.
+      double res = 0.0, mag = 0.0;
+      if (lane < m) {
+        res = -xval[n + lane]; mag = fabs(xval[n + lane]);
+        for (int j = 0; j < n; ++j) {
+          const double t = a.A_dense[(size_t)lane * n + j] * xval[j];
+          res += t; mag += fabs(t);
+        }
       }
-      if (!(fabs(res) <= 1e-9 * (1.0 + mag))) okv = false;
+      const double gmag = wave_max(mag);
+      if (lane < m && !(fabs(res) <= 1e-9 * (1.0 + gmag))) okv = false;
     }
     const bool certified = __ballot(!okv) == 0ull;
-    if (status == DSP_STATUS_OPTIMAL && !certified) status = -1;
+    const unsigned long long bad_bounds = __ballot(!okb), bad_any = __ballot(!okv);
+    int reason = status == -1 ? 1 : 0;                       // 1 = pivot limit
+    if (status == DSP_STATUS_OPTIMAL && !certified) { status = -1; reason = 2; }   // 2 = vertex failed its certificate
     if (status == -1) {
-      if (lane == 0) { b.status[s] = DSP_STATUS_UNSOLVED; atomicAdd(a.unsolved, 1); }   // the PDLP kernel takes it from here
+      if (lane == 0) {
+        if (a.debug_keep) {                                  // development: report why instead of handing over to PDLP
+          b.status[s] = 50 + reason;
+          if (b.iters) b.iters[s] = pivots;
+          if (b.jumps) b.jumps[s] = bad_bounds ? 1000 + first_lane(bad_bounds) : (bad_any ? 2000 + first_lane(bad_any) : 0);
+          b.obj[s] = po;
+        } else {
+          b.status[s] = DSP_STATUS_UNSOLVED;                 // the PDLP kernel takes it from here
+          atomicAdd(a.unsolved, 1);
+        }
+      }
       continue;
     }
     // duals: y_i = reduced cost of slack i with the phase-2 costs (recomputed so that a phase-1 stop reports something sane)

@@ -115,3 +115,27 @@ def test_tracking_lps_full_batch(case):
     _check_objective(model.objective, inp["obj"], case)
     _check_range(model.expression_values("P_T"), inp["P_T_lo"], inp["P_T_width"], f"{case} P_T",
                  tracker.tracking_model_object.model_data.p_max)
+
+
+@gpu
+def test_simplex_certificate_regression():
+    """Three 4-h real-time LPs met in the rolling double loop (day_ahead_power fixed to un-rounded offers, SOC ~45 MWh):
+    the in-wave simplex found the right vertex (objective = HiGHS to 14 digits) but an over-strict certificate (row
+    residuals measured against the row's own terms instead of the scale of the vertex) handed them to the PDLP kernel,
+    which ran into its iteration limit.  Inputs + HiGHS objectives: tests/golden/simplex_regression.npz."""
+    import torch
+    from dispatches_amd import scenarios
+    from dispatches_amd.hip_solver import DeviceLP, default_options
+    d = np.load(os.path.join(GOLD, "simplex_regression.npz"))
+
+    class _NoSolver:
+        def solve(self, *a, **k):
+            raise RuntimeError
+    bidder, _ = scenarios.wind_battery_batch(1, 48, _NoSolver())
+    lp = bidder.real_time_model.lp
+    dlp = DeviceLP(lp, 0, default_options(max_iter=64))          # the PDLP fallback could not rescue them within 64 iterations
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float64, device="cuda")
+    out = dlp.solve(3, t(d["c"]), t(d["lb"]), t(d["ub"]), t(d["rlo"]), t(d["rhi"]))
+    assert out["stats"].simplex == 1
+    assert out["status"].cpu().numpy().tolist() == [0, 0, 0]
+    np.testing.assert_allclose(out["obj"].cpu().numpy(), d["obj_highs"], rtol=1e-10)
