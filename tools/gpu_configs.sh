@@ -10,6 +10,7 @@ run --workload wind_pem_48h
 run --workload wind_battery_48h --batch 1024
 run --workload wind_battery_48h
 run --workload nuclear_48h
+timeout 300 python bench.py --workload double_loop --total 1024 --steps 5 --warmup 1 2>/dev/null | tail -1 > "$repo/gpurun_out/${tag}_double_loop.json"; cut -c1-400 "$repo/gpurun_out/${tag}_double_loop.json"
 python - "$out" <<'PY'
 import json, sys
 for l in open(sys.argv[1]):
