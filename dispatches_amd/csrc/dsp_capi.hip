@@ -262,8 +262,21 @@ int dsp_create(const dsp_lp_desc *d, int device, const dsp_options *opt, dsp_han
   // register-resident-matrix layout: ownership sorted by length, per-slot widths, position space
   SortedLayout Lc = sorted_layout(AT, cpl, Ec.long_owner), Lr = sorted_layout(A, rpl, Er.long_owner);
   SlotELL Sc = build_slot_ell(AT, Lc, Lr, Ec.long_owner), Sr = build_slot_ell(A, Lr, Lc, Er.long_owner);
+  const bool has_long = P.long_c.count > 0 || P.long_r.count > 0;
+  int pad_w = 0;
+  if (!h->opt.no_matreg && !matreg_available(cpl, rpl, Sc.pack, Sr.pack, has_long)) {
+    // no tight specialisation for this shape: the PADDED one (every slot kPadWidth wide) if the LP fits it
+    int wmax = 0;
+    for (int q = 0; q < Sc.slots; ++q) wmax = std::max(wmax, Sc.width[q]);
+    for (int q = 0; q < Sr.slots; ++q) wmax = std::max(wmax, Sr.width[q]);
+    if (!has_long && wmax <= kPadWidth && matreg_available(cpl, rpl, uniform_pack(cpl, kPadWidth), uniform_pack(rpl, kPadWidth), false)) {
+      pad_w = kPadWidth;
+      Sc = build_slot_ell(AT, Lc, Lr, Ec.long_owner, pad_w);
+      Sr = build_slot_ell(A, Lr, Lc, Er.long_owner, pad_w);
+    }
+  }
   // the unscaled matrix in the same position-space layout (same sparsity): streaming SpMV step
-  SlotELL Scu = build_slot_ell(ATu, Lc, Lr, Ec.long_owner), Sru = build_slot_ell(Au, Lr, Lc, Er.long_owner);
+  SlotELL Scu = build_slot_ell(ATu, Lc, Lr, Ec.long_owner, pad_w), Sru = build_slot_ell(Au, Lr, Lc, Er.long_owner, pad_w);
   // bank-conflict-minimising slot permutation of each exchange buffer: the y buffer is gathered by the A^T entries
   // (Sc), the x buffer by the A entries (Sr)
   SlotMap My = optimise_slots(Sc, P.m_pad), Mx = optimise_slots(Sr, P.n_pad);

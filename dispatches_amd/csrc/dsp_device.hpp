@@ -86,6 +86,10 @@ struct SpmvArgs {
   double *AX, *ATY;
 };
 
+// padded register-resident specialisations: every slot kPadWidth entries wide (LP shapes without a tight specialisation)
+constexpr int kPadWidth = 4;
+inline unsigned uniform_pack(int slots, int w) { unsigned p = 0; for (int q = 0; q < slots; ++q) p |= (unsigned)w << (4 * q); return p; }
+
 hipError_t launch_solve(int cpl, int rpl, const SolveArgs &a, dim3 grid, dim3 block, size_t lds, hipStream_t st);
 int matreg_available(int cpl, int rpl, unsigned wc_pack, unsigned wr_pack, bool lng);   // 0 / 1
 hipError_t occupancy_solve(int cpl, int rpl, const SolveArgs &a, int block_threads, size_t lds, int *blocks_per_cu);

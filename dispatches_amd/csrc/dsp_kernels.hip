@@ -865,7 +865,18 @@ __global__ void __launch_bounds__(256) spmv_stream_kernel(SpmvArgs a) {
   X(5, 3, 0x11333u, 0x344u, false)       /* wind+battery 36 h */                                              \
   X(2, 2, 0x12u, 0x23u, true)            /* wind+PEM 24 h     */                                              \
   X(3, 2, 0x122u, 0x33u, true)           /* wind+PEM 36 h     */                                              \
-  X(4, 2, 0x1122u, 0x34u, false)         /* nuclear 36 h      */
+  X(4, 2, 0x1122u, 0x34u, false)         /* nuclear 36 h      */                                              \
+  /* PADDED specialisations (every slot 4 entries wide, zero-filled): any LP without long vectors whose columns and  \
+     rows have <= 4 entries gets a register-resident matrix even when no tight shape was compiled for it (other       \
+     horizons, perturbed flowsheets): ~1.3-1.5x the gathers and FMAs of a tight shape, still well ahead of the       \
+     LDS-matrix kernel */                                                                                             \
+  X(1, 1, 0x4u, 0x4u, false)                                                                                          \
+  X(2, 1, 0x44u, 0x4u, false)                                                                                         \
+  X(2, 2, 0x44u, 0x44u, false)                                                                                        \
+  X(3, 2, 0x444u, 0x44u, false)                                                                                       \
+  X(4, 2, 0x4444u, 0x44u, false)                                                                                      \
+  X(4, 3, 0x4444u, 0x444u, false)                                                                                     \
+  X(5, 3, 0x44444u, 0x444u, false)
 
 // 0 = no specialisation, 1 = register-resident matrix
 int matreg_available(int cpl, int rpl, unsigned wc, unsigned wr, bool lng) {

@@ -209,8 +209,10 @@ struct SlotELL {
 };
 
 // M: CSR whose rows are the vectors owned through `own`; the gathered vector's elements sit at `other.pos`.
+// force_width > 0: every slot gets that width (zero-padded entries) - the layout of the PADDED register-resident
+// specialisations that serve LP shapes without a tight one; requires every non-long vector to have <= force_width entries
 inline SlotELL build_slot_ell(const HostCSR &M, const SortedLayout &own, const SortedLayout &other,
-                              const std::vector<int32_t> &long_ids) {
+                              const std::vector<int32_t> &long_ids, int force_width = 0) {
   SlotELL E;
   E.slots = own.slots;
   std::vector<char> is_long(M.m, 0);
@@ -221,6 +223,7 @@ inline SlotELL build_slot_ell(const HostCSR &M, const SortedLayout &own, const S
       int32_t v = own.at[q * 64 + l];
       if (v >= 0 && !is_long[v]) w = std::max(w, (int)(M.ptr[v + 1] - M.ptr[v]));
     }
+    if (force_width > 0) w = force_width;
     E.width[q] = w;
     E.pack |= (uint32_t)(w & 15) << (4 * q);
     E.total += w;

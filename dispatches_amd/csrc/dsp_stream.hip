@@ -13,9 +13,10 @@
 // Structure: an iteration is two grid-wide dependent steps (A^T y for the primal step, A (2x+ - x) for the dual step),
 // i.e. two kernel launches (a kernel boundary costs ~1.5 us on MI355X, an in-kernel grid barrier ~4 us, so launches
 // it is).  The Halpern averaging is fused into the dual-step launch (rows do the dual step, columns the averaging of
-// x), so a plain iteration moves, per scenario, 11 n + 7 m doubles:
-//     k_primal        reads x, c, lb, ub (+ gathers y)          writes x+, xbar = 2x+ - x
-//     k_dual_halpern  reads y, y0, rlo, rhi (+ gathers xbar)    writes y+, y ;   reads x, x+, x0, writes x
+// x: the reflected point 2x+ - x IS xbar, so x_new = x0/(k+2) + (1 - 1/(k+2)) xbar needs neither x nor x+), and x+ / y+
+// themselves are only materialised at check iterations.  A plain iteration moves, per scenario, 8 n + 6 m doubles:
+//     k_primal        reads x, c, lb, ub (+ gathers y)                  writes xbar = 2x+ - x
+//     k_dual_halpern  reads y, y0, rlo, rhi (+ gathers xbar)            writes y ;   reads xbar, x0, writes x
 // Every `check_every` iterations the dual step is replaced by a check sequence (k_check_rows, k_kkt_cols, k_control,
 // k_apply) that produces the fixed-point residual, the KKT quantities and the restart / termination decision of every
 // scenario ON THE DEVICE; per-scenario control state lives in HBM, so the host only enqueues launches and polls a
@@ -30,6 +31,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -201,7 +203,7 @@ __global__ void k_init_control(StreamArgs a) {
 
 // ---- primal step -----------------------------------------------------------------------------------------------------
 // grid: (column blocks + one block per long column, scenario groups)
-template <int SG>
+template <int SG, bool WRITE_XP>
 __global__ void k_primal(StreamArgs a) {
   const StreamProblem &P = a.P;
   const int b0 = blockIdx.y * SG;
@@ -235,12 +237,13 @@ __global__ void k_primal(StreamArgs a) {
     const double x = a.W.x[at];
     const double gx = fma(-c.tau, a.W.c[at] - aty, x);
     const double xp = clampd2(gx, a.W.lb[at], a.W.ub[at]);
-    a.W.xp[at] = xp; a.W.xbar[at] = 2.0 * xp - x;
+    if (WRITE_XP) a.W.xp[at] = xp;
+    a.W.xbar[at] = 2.0 * xp - x;
   }
 }
 
 // one thread per (long column, scenario): ordered sum of its chunk partials, then the primal update of that column
-__global__ void k_primal_long_finish(StreamArgs a) {
+__global__ void k_primal_long_finish(StreamArgs a, int write_xp) {
   const StreamProblem &P = a.P;
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= P.C.nlong * a.b.B) return;
@@ -254,7 +257,8 @@ __global__ void k_primal_long_finish(StreamArgs a) {
   const double x = a.W.x[at];
   const double gx = fma(-c.tau, a.W.c[at] - aty, x);
   const double xp = clampd2(gx, a.W.lb[at], a.W.ub[at]);
-  a.W.xp[at] = xp; a.W.xbar[at] = 2.0 * xp - x;
+  if (write_xp) a.W.xp[at] = xp;
+  a.W.xbar[at] = 2.0 * xp - x;
 }
 
 // ---- dual step + Halpern averaging (plain iterations) -----------------------------------------------------------------
@@ -295,12 +299,11 @@ __global__ void k_dual_halpern(StreamArgs a, int kofs) {
       const double gy = fma(-c.sig, ax, y);
       const double yp = gy - clampd2(gy, -c.sig * a.W.rhi[at], -c.sig * a.W.rlo[at]);
       const double tt = 2.0 * yp - y;
-      a.W.yp[at] = yp; a.W.y[at] = fma(oml, a.W.y0[at] - tt, tt);
+      a.W.y[at] = fma(oml, a.W.y0[at] - tt, tt);
     }
     if (t < P.n) {
       const size_t at = (size_t)s * P.n + t;
-      const double x = a.W.x[at];
-      const double tt = 2.0 * a.W.xp[at] - x;
+      const double tt = a.W.xbar[at];                      // 2 x+ - x
       a.W.x[at] = fma(oml, a.W.x0[at] - tt, tt);
     }
   }
@@ -321,7 +324,7 @@ __global__ void k_dual_long_finish(StreamArgs a, int kofs) {
   const double yp = gy - clampd2(gy, -c.sig * a.W.rhi[at], -c.sig * a.W.rlo[at]);
   const double oml = 1.0 / (double)(c.k + kofs + 3);
   const double tt = 2.0 * yp - y;
-  a.W.yp[at] = yp; a.W.y[at] = fma(oml, a.W.y0[at] - tt, tt);
+  a.W.y[at] = fma(oml, a.W.y0[at] - tt, tt);
 }
 
 // ---- check iteration, rows: dual step WITHOUT averaging + residual and KKT row quantities -------------------------------
@@ -652,8 +655,8 @@ static hipError_t ensure_workspace(StreamSolver *S, int B) {
 }
 
 size_t stream_bytes_per_iteration(const StreamSolver *S) {
-  // per scenario and plain iteration (see the file header): 11 n + 7 m doubles
-  return (size_t)8 * (11 * (size_t)S->P.n + 7 * (size_t)S->P.m);
+  // per scenario and plain iteration (see the file header): 8 n + 6 m doubles
+  return (size_t)8 * (8 * (size_t)S->P.n + 6 * (size_t)S->P.m);
 }
 
 template <int SG>
@@ -666,9 +669,10 @@ static hipError_t run(StreamSolver *S, StreamArgs &a, hipStream_t st, int *perio
   const dim3 g_rows_chk(a.nblk + P.R.nlong, groups), g_cols(a.nblk_n + P.C.nlong, groups);
   const dim3 g_elem(a.nblk, groups);
   const int fin_c = (P.C.nlong * B + 63) / 64, fin_r = (P.R.nlong * B + 63) / 64;
-  auto primal = [&]() {
-    hipLaunchKernelGGL((k_primal<SG>), g_primal, blk, 0, st, a);
-    if (P.C.nlong) hipLaunchKernelGGL(k_primal_long_finish, dim3(fin_c), dim3(64), 0, st, a);
+  auto primal = [&](bool write_xp) {
+    if (write_xp) hipLaunchKernelGGL((k_primal<SG, true>), g_primal, blk, 0, st, a);
+    else hipLaunchKernelGGL((k_primal<SG, false>), g_primal, blk, 0, st, a);
+    if (P.C.nlong) hipLaunchKernelGGL(k_primal_long_finish, dim3(fin_c), dim3(64), 0, st, a, write_xp ? 1 : 0);
   };
   const int C = std::max(1, a.opt.check_every);
   const int max_periods = (a.opt.max_iter + C - 1) / C;
@@ -677,11 +681,11 @@ static hipError_t run(StreamSolver *S, StreamArgs &a, hipStream_t st, int *perio
   hipError_t e = hipSuccess;
   for (; period < max_periods; ++period) {
     for (int u = 0; u < C - 1; ++u) {
-      primal();
+      primal(false);
       hipLaunchKernelGGL((k_dual_halpern<SG>), g_dual, blk, 0, st, a, u);
       if (P.R.nlong) hipLaunchKernelGGL(k_dual_long_finish, dim3(fin_r), dim3(64), 0, st, a, u);
     }
-    primal();
+    primal(true);
     hipLaunchKernelGGL((k_check_rows<SG>), g_rows_chk, blk, 0, st, a);
     hipLaunchKernelGGL((k_kkt_cols<SG>), g_cols, blk, 0, st, a);
     hipLaunchKernelGGL(k_control, dim3(B), dim3(64), 0, st, a, C);
@@ -719,7 +723,10 @@ hipError_t stream_solve(StreamSolver *S, const dsp_batch &batch, const dsp_optio
   if (blocks1 * ((B + 3) / 4) < 1024) sg = 2;
   if (blocks1 * ((B + 1) / 2) < 1024) sg = 1;
   a.nblk_tot = a.nblk + std::max(S->P.R.nlong, S->P.C.nlong);
-  if (sg == 4) e = run<4>(S, a, st, periods_run);
+  static const int sg_env = getenv("DSP_STREAM_SG") ? atoi(getenv("DSP_STREAM_SG")) : 0;     // development override
+  if (sg_env == 1 || sg_env == 2 || sg_env == 4 || sg_env == 8) sg = sg_env;
+  if (sg == 8) e = run<8>(S, a, st, periods_run);
+  else if (sg == 4) e = run<4>(S, a, st, periods_run);
   else if (sg == 2) e = run<2>(S, a, st, periods_run);
   else e = run<1>(S, a, st, periods_run);
   if (e != hipSuccess) return e;

@@ -160,7 +160,7 @@ typedef struct dsp_stats {
   int32_t streaming;              /* 1 = LP beyond the register/LDS-resident kernels (n > 640 or m > 384): the HBM-resident
                                      PDLP ran (state streamed from HBM every iteration: dsp_stream.hip)    */
   int64_t stream_bytes_per_iteration;  /* streaming path: algorithmic HBM bytes per scenario and plain iteration
-                                          (11 n + 7 m doubles)                                          */
+                                          (8 n + 6 m doubles)                                          */
 } dsp_stats;
 
 void dsp_default_options(dsp_options *opt);

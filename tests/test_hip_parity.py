@@ -431,3 +431,27 @@ def test_work_queue_turnover_stress(no_matreg, waves_per_block):
     assert (model.status == 0).all(), np.bincount(model.status)
     err = np.abs(model.objective - inp["obj"]) / np.maximum(1.0, np.abs(inp["obj"]))
     assert err.max() < 1e-6
+
+
+@gpu
+@pytest.mark.parametrize("T", [20, 30])
+def test_untabulated_horizons_get_a_padded_register_resident_kernel(T):
+    """Horizons without a tight register-resident specialisation (the table in csrc/dsp_kernels.hip covers the reference's
+    12 / 24 / 36 / 48 h) must not silently drop to the 3-4x slower LDS-matrix kernel: the PADDED specialisation (every
+    slot 4 entries wide) takes any LP without long vectors whose rows and columns have <= 4 entries."""
+    from dispatches_amd import scenarios
+    from oracle import dispatch_lp_oracle as orc
+    solver = _solver()
+    B = 64
+    bidder, model = scenarios.wind_battery_batch(B, T, solver)
+    scenarios.load_prices(bidder, model)
+    solver.solve(model)
+    assert solver.last_stats.matreg == 1
+    assert (model.status == 0).all(), np.bincount(model.status)
+    s = scenarios.load_series("rts_gmlc_309.npz")
+    N = len(s["rt_lmp"])
+    for k in range(0, B, 8):
+        h0 = (17 * k) % (N - T)
+        P, *_ = orc.wind_battery_da(T, s["rt_cf"][h0:h0 + T], np.clip(s["da_lmp"][h0:h0 + T], 0, 500), np.clip(s["rt_lmp"][h0:h0 + T], 0, 500))
+        ref = P.solve(tight=True)[1]
+        assert abs(model.objective[k] - ref) <= 1e-6 * max(1.0, abs(ref)), (k, model.objective[k], ref)

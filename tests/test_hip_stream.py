@@ -22,7 +22,7 @@ def test_price_taker_family_matches_oracle_and_is_reproducible():
     assert model.lp.n == 6 * T + 3 and model.lp.m == 6 * T + 2
     solver.solve(model, tee=True)
     assert solver.last_stats.streaming == 1
-    assert solver.last_stats.stream_bytes_per_iteration == 8 * (11 * model.lp.n + 7 * model.lp.m)
+    assert solver.last_stats.stream_bytes_per_iteration == 8 * (8 * model.lp.n + 6 * model.lp.m)
     assert (model.status == 0).all(), (np.bincount(model.status), model.iterations)
     ref = fx["T168/obj"][:B]
     err = np.abs(model.objective - ref) / np.maximum(1.0, np.abs(ref))
