@@ -434,20 +434,9 @@ __global__ void k_kkt_cols(StreamArgs a) {
   }
 }
 
-// ---- control: one block per scenario sums the partials in a fixed order and decides ------------------------------------------
-__global__ void k_control(StreamArgs a, int iters_this_period) {
-  const int s = blockIdx.x;
-  StreamCtrl &c = a.W.ctrl[s];
-  if (c.done) return;
-  __shared__ double acc[kNQ];
-  if (threadIdx.x < kNQ) {
-    double t = 0.0;
-    for (int blk = 0; blk < a.nblk_tot; ++blk) t += a.W.partial[((size_t)s * a.nblk_tot + blk) * kNQ + threadIdx.x];
-    acc[threadIdx.x] = t;
-  }
-  __syncthreads();
-  if (threadIdx.x != 0) return;
-  const dsp_options &o = a.opt;
+// ---- control: the restart / termination decision of one scenario from its check sums (slot layout: k_check_rows / k_kkt_cols)
+// returns the mode for the apply step (0 = Halpern step, 1 = restart at (x+, y+)); sets c.done / c.status on termination
+__device__ int control_decide(const double *acc, StreamCtrl &c, const dsp_options &o, double eta, int iters_this_period) {
   c.it += iters_this_period;
   c.k += iters_this_period;
   const double w = c.w, iw = 1.0 / w;
@@ -483,7 +472,7 @@ __global__ void k_control(StreamArgs a, int iters_this_period) {
           wn = w * exp(dl);
         }
         wn = fmin(fmax(wn, c.w_lo), fmax(c.w_hi, c.w_lo));
-        c.w = wn; c.tau = a.eta / wn; c.sig = a.eta * wn;
+        c.w = wn; c.tau = eta / wn; c.sig = eta * wn;
         c.k = 0; c.r0 = INFINITY; c.rprev = INFINITY;
         c.nrestart += 1;
         mode = 1;
@@ -491,6 +480,23 @@ __global__ void k_control(StreamArgs a, int iters_this_period) {
     }
   }
   c.mode = mode;
+  return mode;
+}
+
+// one block per scenario sums the check partials in a fixed order and decides
+__global__ void k_control(StreamArgs a, int iters_this_period) {
+  const int s = blockIdx.x;
+  StreamCtrl &c = a.W.ctrl[s];
+  if (c.done) return;
+  __shared__ double acc[kNQ];
+  if (threadIdx.x < kNQ) {
+    double t = 0.0;
+    for (int blk = 0; blk < a.nblk_tot; ++blk) t += a.W.partial[((size_t)s * a.nblk_tot + blk) * kNQ + threadIdx.x];
+    acc[threadIdx.x] = t;
+  }
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  control_decide(acc, c, a.opt, a.eta, iters_this_period);
   if (c.done) atomicAdd(a.W.ndone, 1);
 }
 
@@ -520,6 +526,183 @@ __global__ void k_apply(StreamArgs a) {
       else { const double y = a.W.y[at]; const double tt = 2.0 * yp - y; a.W.y[at] = fma(oml, a.W.y0[at] - tt, tt); }
     }
   }
+}
+
+// ---- block-resident solve for MID-SIZE LPs: one workgroup per scenario, the whole state in LDS --------------------------------
+// LPs just beyond the fused kernels (coupled stochastic bidders: 582 x 408; a one-week price-taker design LP: 1011 x 1010)
+// are far too small for the launch-per-half-step form above (12-16 us per iteration, all launch latency).  When
+// 8 (7 n + 6 m) bytes fit the CU's LDS, ONE launch runs the whole solve: workgroup s owns scenario s, every per-element
+// vector (x, anchor, c, bounds, x+, xbar; y, anchor, row bounds, y+) lives in LDS, the matrix is read from L2 each half
+// step (shared by all scenarios, coalesced), a half step ends in one __syncthreads, the check reductions are block
+// reductions, and thread 0 takes the same restart / termination decision (control_decide).  Same iterates as the
+// launch-per-step form up to the summation order of the check sums.
+__device__ __forceinline__ void block_sum(double *v, int nq, double *red /* [kTB/64 .. waves][kNQ] */, double *acc) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  for (int q = 0; q < nq; ++q) {
+    double t = v[q];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off, 64);
+    if (lane == 0) red[wave * kNQ + q] = t;
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < nq) {
+    double t = 0.0;
+    for (int w = 0; w < nw; ++w) t += red[w * kNQ + threadIdx.x];
+    acc[threadIdx.x] = t;
+  }
+  __syncthreads();
+}
+
+// sum over a long vector's entries against an LDS-resident vector, by the whole block; every thread gets the total
+__device__ __forceinline__ double block_long_dot(const StreamMatrix &M, int l, const double *vec, double *red, double *acc) {
+  double part[1] = {0.0};
+  for (int p = M.long_ptr[l] + threadIdx.x; p < M.long_ptr[l + 1]; p += blockDim.x) part[0] = fma(M.long_val[p], vec[M.long_idx[p]], part[0]);
+  block_sum(part, 1, red, acc);
+  const double t = acc[0];
+  __syncthreads();
+  return t;
+}
+
+__global__ void __launch_bounds__(1024) k_block_solve(StreamArgs a) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const StreamProblem &P = a.P;
+  const int s = blockIdx.x, n = P.n, m = P.m, NT = blockDim.x, t0 = threadIdx.x;
+  double *x = lds, *x0 = x + n, *cc = x0 + n, *lb = cc + n, *ub = lb + n, *xp = ub + n, *xb = xp + n;
+  double *y = xb + n, *y0 = y + m, *rlo = y0 + m, *rhi = rlo + m, *yp = rhi + m, *axp = yp + m;
+  double *red = axp + m, *acc = red + (1024 / 64) * kNQ;
+  __shared__ StreamCtrl c;
+  __shared__ int mode_s;
+  if (t0 == 0) c = a.W.ctrl[s];
+  for (int j = t0; j < n; j += NT) {
+    const size_t at = (size_t)s * n + j;
+    x[j] = a.W.x[at]; x0[j] = a.W.x0[at]; cc[j] = a.W.c[at]; lb[j] = a.W.lb[at]; ub[j] = a.W.ub[at]; xp[j] = x[j]; xb[j] = x[j];
+  }
+  for (int i = t0; i < m; i += NT) {
+    const size_t at = (size_t)s * m + i;
+    y[i] = a.W.y[at]; y0[i] = a.W.y0[at]; rlo[i] = a.W.rlo[at]; rhi[i] = a.W.rhi[at]; yp[i] = y[i];
+  }
+  __syncthreads();
+  const int C = a.opt.check_every > 0 ? a.opt.check_every : 64;
+  while (!c.done) {
+    for (int u = 0; u < C; ++u) {
+      const bool check = u == C - 1;
+      const double tau = c.tau, sig = c.sig;
+      // ---- primal step ------------------------------------------------------------------------------------------
+      for (int j = t0; j < n; j += NT) {
+        if (P.C.is_long[j]) continue;
+        double aty = 0.0;
+        for (int e = 0; e < P.C.W; ++e) aty = fma(P.C.val[(size_t)e * n + j], y[P.C.idx[(size_t)e * n + j]], aty);
+        const double gx = fma(-tau, cc[j] - aty, x[j]);
+        const double v = clampd2(gx, lb[j], ub[j]);
+        xp[j] = v; xb[j] = 2.0 * v - x[j];
+      }
+      for (int l = 0; l < P.C.nlong; ++l) {
+        const double aty = block_long_dot(P.C, l, y, red, acc);
+        if (t0 == 0) {
+          const int j = P.C.long_id[l];
+          const double gx = fma(-tau, cc[j] - aty, x[j]);
+          const double v = clampd2(gx, lb[j], ub[j]);
+          xp[j] = v; xb[j] = 2.0 * v - x[j];
+        }
+      }
+      __syncthreads();
+      // ---- dual step (+ Halpern averaging on plain iterations) ----------------------------------------------------
+      const double oml = 1.0 / (double)(c.k + u + 3);
+      for (int i = t0; i < m; i += NT) {
+        if (P.R.is_long[i]) continue;
+        double ax = 0.0, ax2 = 0.0;
+        for (int e = 0; e < P.R.W; ++e) {
+          const double v = P.R.val[(size_t)e * m + i];
+          const int id = P.R.idx[(size_t)e * m + i];
+          ax = fma(v, xb[id], ax);
+          if (check) ax2 = fma(v, xp[id], ax2);
+        }
+        const double gy = fma(-sig, ax, y[i]);
+        const double v = gy - clampd2(gy, -sig * rhi[i], -sig * rlo[i]);
+        yp[i] = v;
+        if (check) axp[i] = ax2;                   // A x+  (A xbar - A x+ = A (x+ - x))
+        else { const double tt = 2.0 * v - y[i]; y[i] = fma(oml, y0[i] - tt, tt); }
+      }
+      for (int l = 0; l < P.R.nlong; ++l) {
+        const double ax = block_long_dot(P.R, l, xb, red, acc);
+        const double ax2 = check ? block_long_dot(P.R, l, xp, red, acc) : 0.0;
+        if (t0 == 0) {
+          const int i = P.R.long_id[l];
+          const double gy = fma(-sig, ax, y[i]);
+          const double v = gy - clampd2(gy, -sig * rhi[i], -sig * rlo[i]);
+          yp[i] = v;
+          if (check) axp[i] = ax2;
+          else { const double tt = 2.0 * v - y[i]; y[i] = fma(oml, y0[i] - tt, tt); }
+        }
+      }
+      if (!check) {
+        for (int j = t0; j < n; j += NT) { const double tt = xb[j]; x[j] = fma(oml, x0[j] - tt, tt); }
+        __syncthreads();
+        continue;
+      }
+      __syncthreads();
+      // ---- check: residual + KKT sums (slot layout of k_check_rows / k_kkt_cols), decision, apply ------------------
+      double v[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+      for (int i = t0; i < m; i += NT) {
+        double axb = 0.0;                          // A xbar again (not kept by the dual step): A xbar - A x+ = A (x+ - x)
+        for (int e = 0; e < P.R.W; ++e) axb = fma(P.R.val[(size_t)e * m + i], xb[P.R.idx[(size_t)e * m + i]], axb);
+        const double dy = yp[i] - y[i];
+        const double nsadx = -sig * (axb - axp[i]);
+        v[1] += dy * fma(2.0, nsadx, dy);
+        const double viol_s = fmax(rlo[i] - axp[i], 0.0) + fmax(axp[i] - rhi[i], 0.0);
+        const double viol = viol_s / P.row_scale[i];
+        v[2] += viol * viol;
+        v[3] += fabs(yp[i]) * viol_s;
+        v[4] += fmax(yp[i], 0.0) * fin0(rlo[i]) - fmax(-yp[i], 0.0) * fin0(rhi[i]);
+        const double d0 = yp[i] - y0[i];
+        v[5] += d0 * d0;
+      }
+      for (int j = t0; j < n; j += NT) {
+        const double dx = xp[j] - x[j], d0 = xp[j] - x0[j];
+        v[0] += dx * dx;
+        v[6] += d0 * d0;
+        if (P.C.is_long[j]) continue;
+        double aty = 0.0;
+        for (int e = 0; e < P.C.W; ++e) aty = fma(P.C.val[(size_t)e * n + j], yp[P.C.idx[(size_t)e * n + j]], aty);
+        const double rc = cc[j] - aty;
+        const double lp = finite_d(lb[j]) ? fmax(rc, 0.0) : 0.0, lm = finite_d(ub[j]) ? fmax(-rc, 0.0) : 0.0;
+        const double dr = (rc - lp + lm) / P.col_scale[j];
+        v[8] += dr * dr;
+        v[9] += cc[j] * xp[j];
+        v[10] += lp * fin0(lb[j]) - lm * fin0(ub[j]);
+        v[11] += fabs(cc[j] * xp[j]);
+        v[12] += fabs(rc - lp + lm) * fabs(xp[j]);
+      }
+      for (int l = 0; l < P.C.nlong; ++l) {
+        const double aty = block_long_dot(P.C, l, yp, red, acc);
+        if (t0 == 0) {
+          const int j = P.C.long_id[l];
+          const double rc = cc[j] - aty;
+          const double lp = finite_d(lb[j]) ? fmax(rc, 0.0) : 0.0, lm = finite_d(ub[j]) ? fmax(-rc, 0.0) : 0.0;
+          const double dr = (rc - lp + lm) / P.col_scale[j];
+          v[8] += dr * dr; v[9] += cc[j] * xp[j]; v[10] += lp * fin0(lb[j]) - lm * fin0(ub[j]);
+          v[11] += fabs(cc[j] * xp[j]); v[12] += fabs(rc - lp + lm) * fabs(xp[j]);
+        }
+      }
+      block_sum(v, 13, red, acc);
+      if (t0 == 0) mode_s = control_decide(acc, c, a.opt, a.eta, C);
+      __syncthreads();
+      if (c.done) break;
+      const double om2 = 1.0 / (double)(c.k + 2);
+      if (mode_s == 1) {
+        for (int j = t0; j < n; j += NT) { x[j] = xp[j]; x0[j] = xp[j]; }
+        for (int i = t0; i < m; i += NT) { y[i] = yp[i]; y0[i] = yp[i]; }
+      } else {
+        for (int j = t0; j < n; j += NT) { const double tt = 2.0 * xp[j] - x[j]; x[j] = fma(om2, x0[j] - tt, tt); }
+        for (int i = t0; i < m; i += NT) { const double tt = 2.0 * yp[i] - y[i]; y[i] = fma(om2, y0[i] - tt, tt); }
+      }
+      __syncthreads();
+    }
+  }
+  // ---- results back to the workspace (k_finalize unscales them) -------------------------------------------------------
+  for (int j = t0; j < n; j += NT) a.W.xp[(size_t)s * n + j] = xp[j];
+  for (int i = t0; i < m; i += NT) a.W.yp[(size_t)s * m + i] = yp[i];
+  if (t0 == 0) a.W.ctrl[s] = c;
 }
 
 // ---- results -------------------------------------------------------------------------------------------------------------------
@@ -717,6 +900,21 @@ hipError_t stream_solve(StreamSolver *S, const dsp_batch &batch, const dsp_optio
   hipLaunchKernelGGL(k_init_control, dim3(B), dim3(64), 0, st, a);
   // k_init wrote its partials with stride nblk; the check kernels use nblk_tot: clear again before the first check
   if ((e = hipMemsetAsync(a.W.partial, 0, (size_t)B * a.nblk_tot * kNQ * sizeof(double), st)) != hipSuccess) return e;
+  // mid-size LPs: the whole solve in ONE launch, one workgroup per scenario with its state in LDS
+  {
+    const size_t lds = ((size_t)7 * S->P.n + 7 * S->P.m + (1024 / 64) * kNQ + kNQ) * sizeof(double);
+    static const int no_block = getenv("DSP_STREAM_NO_BLOCK") ? atoi(getenv("DSP_STREAM_NO_BLOCK")) : 0;
+    const bool long_rows_ok = S->P.R.nlong == 0;      // long ROWS are not handled by the check of the block form
+    if (!no_block && long_rows_ok && lds <= S->lds_limit) {
+      const int nt = std::max(S->P.n, S->P.m) > 2048 ? 1024 : (std::max(S->P.n, S->P.m) > 512 ? 512 : 256);
+      hipError_t be = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_block_solve), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (be != hipSuccess) return be;
+      hipLaunchKernelGGL(k_block_solve, dim3(B), dim3(nt), lds, st, a);
+      hipLaunchKernelGGL(k_finalize, dim3(a.nblk, B), dim3(kTB), 0, st, a);
+      *periods_run = -1;
+      return hipGetLastError();
+    }
+  }
   // scenarios per thread: enough (element blocks x scenario groups) to fill the chip, matrix reuse otherwise
   const long blocks1 = a.nblk;
   int sg = 4;

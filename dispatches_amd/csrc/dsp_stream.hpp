@@ -70,6 +70,7 @@ struct StreamSolver {
   int work_B = 0;
   std::vector<void *> allocs, work_allocs;
   int *ndone_host = nullptr;
+  size_t lds_limit = 160 * 1024 - 2048;   // dynamic LDS available to the block-resident form (static __shared__ on top)
 };
 
 hipError_t stream_create(const HostCSR &A_scaled, const HostCSR &AT_scaled, const double *col_scale_dev,
