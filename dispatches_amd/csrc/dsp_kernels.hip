@@ -270,7 +270,7 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
     // one global atomic per wave) and the ticket is read from lane 0 explicitly.  Round 1 wrote
     //     if (lane == 0) s = atomicAdd(queue, 1);  s = readfirstlane(s);
     // and needed an s_waitcnt 0 after the result stores at the bottom of the loop "against a hang".  Root cause (round 2,
-    // tools/gpu_drain_modes.sh: a compiler-only barrier `asm volatile("" ::: "memory")` in place of that s_waitcnt cures it
+    // profiles/r02d_drain_modes.log (seven builds bisecting the drains): a compiler-only barrier `asm volatile("" ::: "memory")` in place of that s_waitcnt cures it
     // just as well, so no memory ordering is involved): the loop body ends with `if (lane == 0) { stores }` and began with
     // `if (lane == 0) { atomic }`; with nothing side-effecting in between, the compiler threads the divergent
     // `lane == 0` branch across the back-edge, the wave re-enters the pull with a partial EXEC mask, v_readfirstlane

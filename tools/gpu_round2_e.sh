@@ -1,4 +1,8 @@
 #!/bin/bash
+# Round-2 measurement recipe (profiles/r02e_*.log): branch-free queue pull under stress, reproduction of the round-1 hang
+# with the legacy pull (build that library first:  hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -DDSP_LEGACY_PULL
+#   -o dispatches_amd/libdsp_legacy_pull.so dispatches_amd/csrc/dsp_{kernels,simplex,stream,capi}.hip ), streaming PDLP,
+# hourly LPs on the simplex, SpMV-step variants.
 cd "$(dirname "$0")/.."
 o=gpurun_out/r02e.log; : > $o
 run() { echo "== $*" >> $o; timeout ${TMO:-120} "$@" >> $o 2>&1; echo "rc=$?" >> $o; }
