@@ -43,7 +43,7 @@ class _NoSolver:
 class _DeviceModel:
     """One of the three LPs on the device: handle + per-scenario tensors + the index sets the rolling updates touch."""
 
-    def __init__(self, model, B, dev, device_index, hints=None):
+    def __init__(self, model, B, dev, device_index, hints=None, lp_backend=None):
         import torch
         self.lp = model.lp
         self.T = len(model.HOUR)
@@ -62,8 +62,12 @@ class _DeviceModel:
         self.wind_kw = float(fam["wind_kw"])
         # P_T[t] = 1e-3 (grid_elec[t] + elec_out[t]): the two columns of every hour
         self.pt_cols = idx([[p["grid_elec"].index, p["elec_out"].index] for p in per])       # [T, 2]
-        self.opts = default_options(**(hints or {}))
-        self.dlp = DeviceLP(self.lp, device_index, self.opts)
+        if lp_backend is None:
+            self.opts = default_options(**(hints or {}))
+            self.dlp = DeviceLP(self.lp, device_index, self.opts)
+        else:                                   # tests: a stand-in with DeviceLP.solve's signature (CPU tensors + HiGHS)
+            self.opts = None
+            self.dlp = lp_backend(self.lp)
         self.out = None
 
     def power_output(self, x):
@@ -79,11 +83,14 @@ class _DeviceModel:
 class BatchedWindBatteryDoubleLoop:
     def __init__(self, n_scenarios, device=0, first_scenario=0, series="rts_gmlc_309.npz", stride=17,
                  day_ahead_horizon=48, real_time_horizon=4, tracking_horizon=4, wind_mw=200.0, batt_mw=25.0,
-                 price_cap=500.0, warm_start=False):
+                 price_cap=500.0, warm_start=False, lp_backend=None):
+        """lp_backend: None = the HIP solver on GPU `device`; tests pass a factory lp -> object with DeviceLP.solve's
+        signature working on CPU tensors (tests/_highs_solver.py::HighsTensorLP), which runs the SAME window / objective /
+        state-hand-off logic without a GPU."""
         import torch
         from .workflow import Tracker
         self.B = B = int(n_scenarios)
-        self.dev = dev = torch.device("cuda", device)
+        self.dev = dev = torch.device("cuda", device) if lp_backend is None else torch.device("cpu")
         s = scenarios.load_series(series)
         self.N = N = len(s["rt_lmp"])
         t = lambda a: torch.as_tensor(np.ascontiguousarray(a, np.float64), device=dev)
@@ -106,9 +113,9 @@ class BatchedWindBatteryDoubleLoop:
         tracker._pass_market_dispatch([0.0] * tracking_horizon)           # dispatch rows become equalities
         tr_model = tracker.model
         self.penalty = float(bidder.real_time_underbid_penalty)
-        self.da = _DeviceModel(da_model, B, dev, device, hints=getattr(da_model, "solver_hints", None))
-        self.rt = _DeviceModel(rt_model, B, dev, device, hints=getattr(rt_model, "solver_hints", None))
-        self.tr = _DeviceModel(tr_model, B, dev, device, hints=getattr(tr_model, "solver_hints", None))
+        self.da = _DeviceModel(da_model, B, dev, device, hints=getattr(da_model, "solver_hints", None), lp_backend=lp_backend)
+        self.rt = _DeviceModel(rt_model, B, dev, device, hints=getattr(rt_model, "solver_hints", None), lp_backend=lp_backend)
+        self.tr = _DeviceModel(tr_model, B, dev, device, hints=getattr(tr_model, "solver_hints", None), lp_backend=lp_backend)
         idx = lambda cols: torch.as_tensor(np.asarray(cols, np.int64), device=dev)
         self.da.pda_cols, self.rt.pda_cols = idx(da_model.pda_cols), idx(rt_model.pda_cols)
         # OPTIONAL rolling warm start of the day-ahead LP: day d + 1's 48-h problem is day d's shifted by 24 h, so period t

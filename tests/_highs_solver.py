@@ -34,3 +34,28 @@ class HighsTestSolver:
             obj[i] = res.fun + model.c0[i]
         model.store_solution(X, Y, obj, np.zeros(B, np.int32))
         return SolveResults("ok", "optimal")
+
+
+class HighsTensorLP:
+    """TEST-ONLY stand-in for dispatches_amd.hip_solver.DeviceLP: same `solve` signature, CPU torch tensors in and out,
+    HiGHS per scenario.  Lets the device-resident batched double loop (dispatches_amd/rolling.py) run its window / objective /
+    state-hand-off logic in the CPU test tier."""
+
+    def __init__(self, lp):
+        self.lp = lp
+
+    def solve(self, B, c, lb=None, ub=None, rlo=None, rhi=None, x0=None, y0=None, options=None, out=None, sync_stats=True,
+              obj_offset=None, primal_weight=None):
+        import torch
+        from oracle.highs_direct import HighsModel
+        lp = self.lp
+        A = lp.csr()
+        pick = lambda t, i: (t[i] if t.dim() == 2 else t).numpy()
+        X, Y = np.zeros((B, lp.n)), np.zeros((B, lp.m))
+        obj, st = np.zeros(B), np.zeros(B, np.int32)
+        for i in range(B):
+            M = HighsModel(pick(c, i), A, pick(rlo, i), pick(rhi, i), pick(lb, i), pick(ub, i))
+            x, f, y = M.solve()
+            X[i], Y[i], obj[i] = x, y, f
+        return dict(x=torch.as_tensor(X), y=torch.as_tensor(Y), obj=torch.as_tensor(obj), status=torch.as_tensor(st),
+                    iters=torch.zeros(B, dtype=torch.int32), jumps=torch.zeros(B, dtype=torch.int32))

@@ -1,0 +1,117 @@
+"""CPU tier of the device-resident batched double loop (dispatches_amd/rolling.py, BASELINE config 4): the same window
+gathers, objective / bound rewrites and state hand-off on CPU tensors with a HiGHS stand-in for the device solver,
+against the host-object path (Bidder / Tracker, one scenario each) - and the shard / all-gather logic of
+`bench.py --workload double_loop` under gloo with world size 2."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _host_reference(k, stride, offers, da_prices, hours):
+    """First hours of day 0 of plant k through the product's Bidder / Tracker objects (reference call order)."""
+    from dispatches_amd import scenarios
+    from dispatches_amd.flowsheets import MultiPeriodWindBattery
+    from dispatches_amd.workflow import Bidder, Tracker
+    from tests._highs_solver import HighsTestSolver
+    s = scenarios.load_series("rts_gmlc_309.npz")
+    N = len(s["rt_lmp"])
+    start = (stride * k) % N
+    cf = np.roll(s["rt_cf"], -start)
+    fc = scenarios.WindowForecaster(s["da_lmp"], s["rt_lmp"], [start], clip=(0.0, 500.0))
+    mk = lambda: MultiPeriodWindBattery(scenarios._thermal_data("309_WIND_1", "Carter", 200.0, 25.0), wind_capacity_factors=list(cf),
+                                        wind_pmax_mw=200.0, battery_pmax_mw=25.0, battery_energy_capacity_mwh=100.0)
+    bidder = Bidder(mk(), day_ahead_horizon=48, real_time_horizon=4, n_scenario=1, solver=HighsTestSolver(), forecaster=fc)
+    tracker = Tracker(tracking_model_object=mk(), tracking_horizon=4, n_tracking_hour=1, solver=HighsTestSolver())
+    out = []
+    for h in range(hours):
+        bidder.compute_real_time_bids("2020-01-02", h, list(da_prices), list(offers))
+        dispatch = [float(v) for v in bidder.real_time_model.expression_values("P_T")[0]]
+        prof = tracker.track_market_dispatch(market_dispatch=dispatch, date="2020-01-02", hour=h)
+        delivered = tracker.get_last_delivered_power()
+        tracker.update_model(**prof)
+        bidder.update_real_time_model(**prof)
+        out.append((delivered, round(prof["realized_soc"][-1], 2), round(prof["realized_energy_throughput"][-1], 2)))
+    return out
+
+
+def test_batched_double_loop_logic_on_cpu():
+    from dispatches_amd.rolling import BatchedWindBatteryDoubleLoop
+    from tests._highs_solver import HighsTensorLP
+    B, hours, stride = 2, 3, 17
+    loop = BatchedWindBatteryDoubleLoop(B, stride=stride, lp_backend=HighsTensorLP)
+    offers = loop.day_ahead().numpy()
+    da_prices = loop.da_prices.numpy()
+    assert offers.shape == (B, 24) and (offers >= -1e-9).all() and (offers <= 225 + 1e-6).all()
+    got = []
+    for _ in range(hours):
+        d = loop.hour_step().numpy()
+        got.append((d.copy(), loop.soc.numpy().copy(), loop.thr.numpy().copy()))
+    res, ok = loop.results()
+    assert ok and loop.hour == hours and loop.solves == B * (1 + 2 * hours)
+    for k in range(B):
+        ref = _host_reference(k, stride, offers[k], da_prices[k], hours)
+        for h in range(hours):
+            # both paths solve the same LPs with the same simplex code: the vertices agree
+            assert got[h][0][k] == pytest.approx(ref[h][0], abs=1e-6 * 225), (k, h)
+            assert got[h][1][k] == pytest.approx(ref[h][1], abs=0.011), (k, h)
+            assert got[h][2][k] == pytest.approx(ref[h][2], abs=0.011), (k, h)
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, total, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch
+    import torch.distributed as dist
+    from dispatches_amd.distributed import gather_device_results, make_gather_buffers, shard_bounds
+    from dispatches_amd.rolling import BatchedWindBatteryDoubleLoop
+    from tests._highs_solver import HighsTensorLP
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        lo, hi = shard_bounds(total, world, rank)
+        per = max(shard_bounds(total, world, r)[1] - shard_bounds(total, world, r)[0] for r in range(world))
+        loop = BatchedWindBatteryDoubleLoop(hi - lo, first_scenario=lo, lp_backend=HighsTensorLP)
+        loop.day_ahead()
+        loop.hour_step()
+        buffers = make_gather_buffers(world, per, torch.device("cpu"), width=2)
+        everything = gather_device_results(dict(obj=loop.revenue, status=torch.zeros(hi - lo, dtype=torch.float64)), buffers, per)
+        q.put((rank, lo, hi, everything.numpy().copy(), loop.revenue.numpy().copy()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_double_loop_shards_world2_gloo():
+    """3 plants over 2 ranks (ragged 2 + 1): every rank ends with every plant's revenue, equal to the single-process run."""
+    import torch.multiprocessing as mp
+    from dispatches_amd.rolling import BatchedWindBatteryDoubleLoop
+    from tests._highs_solver import HighsTensorLP
+    total, world = 3, 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, total, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    single = BatchedWindBatteryDoubleLoop(total, lp_backend=HighsTensorLP)
+    single.day_ahead()
+    single.hour_step()
+    ref = single.revenue.numpy()
+    for rank, lo, hi, everything, mine in got:
+        np.testing.assert_allclose(mine, ref[lo:hi], rtol=1e-9, atol=1e-6)
+        flat = np.concatenate([everything[r, :b - a, 0] for r, (a, b) in
+                               enumerate([(0, 2), (2, 3)])])
+        np.testing.assert_allclose(flat, ref, rtol=1e-9, atol=1e-6)
