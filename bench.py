@@ -230,6 +230,130 @@ def bench_price_taker(args, rank, local_rank, world, dev):
         dist.destroy_process_group()
 
 
+def _qp_oracle_worker(args):
+    """CPU baseline leg of qp_sweep: certified brackets of a chunk of scenarios (oracle/qp_cutting_plane.py)."""
+    rho, ids = args
+    sys.path.insert(0, ROOT)
+    from oracle import qp_cutting_plane as qp
+    from tools.make_qp_fixtures import qp_scenario
+    out = []
+    for k in ids:
+        cf, da, rt = qp_scenario(k)
+        out.append(qp.wind_battery_da_qp(24, cf, da, rt, rho)[0]["upper"])
+    return out
+
+
+def bench_qp_sweep(args, rank, local_rank, world, dev):
+    """BASELINE config 5: the stochastic bidder's day-ahead problems with a quadratic ramp cost (convex QP: soft rows with
+    a dual compliance) on --batch scenarios per GPU, float64 vs float32 iterates over the tolerance ladder 1e-3 ... 1e-9.
+    value = QP scenarios solved / s at the CONTRACT setting (float64, eps_rel = 1e-9, eps_obj = 1e-7: parity with the
+    oracle's certified brackets to 1e-6), steps pipelined over 8 HIP streams like the metric workload.  `sweep` lists, per
+    precision and eps_rel (eps_obj tests off: the sweep is about eps_rel alone), one lone batch: kernel time, scenarios
+    that terminated, iterations, and the error of the objective of the RETURNED point against the oracle bracket."""
+    import torch
+    import torch.distributed as dist
+    from dispatches_amd import scenarios
+    from dispatches_amd.hip_solver import DeviceLP, HipPdlpSolver, default_options
+    wl = args.qp_workload
+    B = args.batch
+    fx = np.load(os.path.join(ROOT, "tests", "golden", "oracle_qp.npz"))
+    solver = HipPdlpSolver(device=local_rank)
+    fn, kw = scenarios.QP_WORKLOADS[wl]
+    bidder, model = fn(B=B * world, solver=solver, **kw)
+    scenarios.load_prices(bidder, model)
+    sl = slice(rank * B, (rank + 1) * B)
+    lp = model.lp
+    lb, ub, rlo, rhi = model.scenario_bounds()
+    up = lambda a: torch.as_tensor(np.ascontiguousarray(a, np.float64)).to(dev)
+    c_d, lb_d, ub_d, rlo_d, rhi_d = up(model.c[sl]), up(lb), up(ub), up(rlo), up(rhi)
+    kap_d, c0_d = up(lp.row_compliance), up(np.ascontiguousarray(model.c0[sl]))
+    dlp = DeviceLP(lp, local_rank, default_options())
+    have = min(B * world, len(fx[f"{wl}/upper"]))
+    ref_up, ref_lo = fx[f"{wl}/upper"], fx[f"{wl}/lower"]
+
+    def errors(out):
+        ids = np.arange(rank * B, (rank + 1) * B)
+        ok = ids < have
+        obj = (out["obj"].cpu().numpy() + model.c0[sl])[ok]
+        u, l = ref_up[ids[ok]], ref_lo[ids[ok]]
+        return np.maximum(np.maximum(l - obj, obj - u), 0.0) / np.maximum(1.0, np.abs(u))
+
+    def lone(opts):
+        out = dlp.solve(B, c_d, lb_d, ub_d, rlo_d, rhi_d, options=opts, sync_stats=True, obj_offset=c0_d, row_compliance=kap_d)
+        st = out["stats"]
+        e = errors(out)
+        stat = out["status"].cpu().numpy()
+        return dict(kernel_ms=float(st.kernel_ms), terminated=int(st.n_optimal), mean_iterations=float(st.total_iterations) / B,
+                    max_iterations=int(st.max_iterations), obj_err_median=float(np.median(e)), obj_err_p99=float(np.quantile(e, 0.99)),
+                    obj_err_max=float(e.max()), obj_err_median_of_terminated=(float(np.median(e[stat[:len(e)] == 0])) if (stat[:len(e)] == 0).any() else None),
+                    scenarios_per_s_lone_batch=B / (1e-3 * float(st.kernel_ms)))
+    sweep = []
+    if rank == 0:
+        for prec in (0, 1):
+            for eps in (1e-3, 1e-4, 1e-5, 1e-6, 1e-7, 1e-8, 1e-9):
+                o = default_options(precision=prec, eps_rel=eps, eps_obj=0.0, max_iter=args.sweep_max_iter)
+                lone(o)
+                sweep.append(dict(precision="f32" if prec else "f64", eps_rel=eps, **lone(o)))
+    # ---- the contract setting, pipelined ---------------------------------------------------------------------------
+    opts = default_options(eps_rel=args.eps)
+    depth = args.streams if args.streams > 0 else 8
+    streams = [torch.cuda.Stream(device=dev) for _ in range(depth)]
+    outs = [None] * depth
+    first = lone(opts)
+    first = lone(opts)
+
+    def step(i):
+        k = i % depth
+        with torch.cuda.stream(streams[k]):
+            outs[k] = dlp.solve(B, c_d, lb_d, ub_d, rlo_d, rhi_d, options=opts, out=outs[k], sync_stats=False, obj_offset=c0_d,
+                                row_compliance=kap_d)
+    for i in range(max(args.warmup, depth)):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    if rank == 0:
+        e = errors(outs[0])
+        cpu = None
+        if args.cpu_sample != 0:
+            import multiprocessing as mp
+            procs = os.cpu_count() or 1
+            sample = min(B, 4096)
+            rho = kw["ramp_cost"]
+            chunks = [(rho, c.tolist()) for c in np.array_split(np.arange(sample), procs * 4) if len(c)]
+            with mp.get_context("spawn").Pool(procs) as pool:
+                pool.map(_qp_oracle_worker, [(rho, [0])] * procs)
+                tc = time.perf_counter()
+                pool.map(_qp_oracle_worker, chunks)
+                wall = time.perf_counter() - tc
+            cpu = dict(value=sample / wall, unit="scenarios/s", cores=procs, kind="port",
+                       sample=f"the first {sample} scenarios of the same batch, Kelley cutting planes on HiGHS LPs to a certified 1e-9 "
+                              f"bracket (oracle/qp_cutting_plane.py; no QP solver in the image reaches the bar), {procs} processes, wall {wall:.2f} s")
+        print(json.dumps({
+            "metric": f"QP scenarios solved/sec, RTS-GMLC 24h day-ahead bidding + quadratic ramp cost (config 5), batch={B}",
+            "value": world * B * args.steps / elapsed, "unit": "scenarios/s", "n_gpus": world, "steps": args.steps, "warmup": max(args.warmup, depth),
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic", "world_size": world,
+            "config": {"workload": f"{wl}: {B} scenarios/GPU x 24 h day-ahead bidding QP (n={lp.n}, m={lp.m}, nnz={lp.nnz}, "
+                                   f"{int(np.count_nonzero(lp.row_compliance))} soft rows, rho={kw['ramp_cost']})",
+                       "eps_rel": args.eps, "streams": depth, "lone_batch": first, "optimal": first["terminated"],
+                       "max_rel_obj_err_vs_oracle_bracket": float(e.max()), "scenarios_beyond_1e-6": int((e >= 1e-6).sum())},
+            "sweep": sweep, "cpu_baseline": cpu}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -246,6 +370,8 @@ def main():
                     help="STRONG scaling: this many scenarios in total, sharded over the ranks through "
                          "dispatches_amd.distributed.solve_sharded_device (e.g. --total 8192 --workload wind_battery_48h = "
                          "BASELINE config 4: 1024 per GPU on 8 GPUs); 0 = weak scaling with --batch scenarios per GPU")
+    ap.add_argument("--qp-workload", default="wind_battery_24h_qp01", help="--workload qp_sweep: which of scenarios.QP_WORKLOADS")
+    ap.add_argument("--sweep-max-iter", type=int, default=40000, help="--workload qp_sweep: iteration cap of the sweep entries")
     ap.add_argument("--no-spmv", action="store_true", help="skip the streaming SpMV-step roofline measurement")
     ap.add_argument("--spmv-large-mult", type=int, default=32,
                     help="also time spmv_step on a batch this many times larger (0 = skip; the PMC passes skip it so "
@@ -280,6 +406,8 @@ def main():
         return bench_double_loop(args, rank, local_rank, world, dev)
     if args.workload == "price_taker":
         return bench_price_taker(args, rank, local_rank, world, dev)
+    if args.workload == "qp_sweep":
+        return bench_qp_sweep(args, rank, local_rank, world, dev)
     solver = HipPdlpSolver(device=local_rank, eps_rel=args.eps)
     fn, kw = scenarios.WORKLOADS[args.workload]
     if args.total > 0:

@@ -45,9 +45,10 @@ struct dsp_handle {
   int lds_limit = 160 * 1024;
   int num_cus = 256;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  bool geo_valid = false;
-  Geometry geo;
+  bool geo_valid[2] = {false, false};   // [0] LP kernels, [1] QP instantiations (soft rows)
+  Geometry geo[2];
   int matreg = 0;                 // register-resident-matrix kernel available for this shape
+  int matreg_qp = 0;              // ... and its QP instantiation
   int simplex = 0;                // tiny LP: the in-wave dense simplex runs first (dsp_simplex.hip)
   const double *A_dense = nullptr;   // [m][n] scaled matrix, row-major (simplex only)
   int sx_row_stride = 0;
@@ -114,21 +115,23 @@ static size_t lds_bytes(const DeviceProblem &P, int wpb, int matreg = 0) {
 // Launch geometry of the solve kernel: waves (= scenarios in flight) per block and blocks per CU, from the runtime's
 // occupancy answer for the compiled kernel (VGPR- and LDS-limited).  Maximise resident waves per CU; on ties prefer
 // larger blocks (the shared matrix is staged once per block).  Cached per handle.
-static int solve_geometry(dsp_handle *h, int requested, int B, Geometry *g) {
-  if (h->geo_valid && requested <= 0) { *g = h->geo; }
+static int solve_geometry(dsp_handle *h, int requested, int B, Geometry *g, int qp) {
+  const int matreg = qp ? h->matreg_qp : h->matreg;
+  if (h->geo_valid[qp] && requested <= 0) { *g = h->geo[qp]; }
   else {
     SolveArgs probe{};
     probe.P = h->P;
-    probe.matreg = h->matreg;
+    probe.matreg = matreg;
+    probe.qp = qp;
     int best_waves = -1;
     Geometry best;
     // generic kernel: larger blocks win ties (the LDS matrix is staged once per block); register-resident matrix:
     // one wave per block wins ties, so every wave's registers are released the moment ITS scenarios are done and a
     // following launch (another stream) can back-fill the CU while this launch's stragglers finish
     for (int step = 0; step < kMaxWavesPerBlock; ++step) {
-      const int wpb = h->matreg ? 1 + step : kMaxWavesPerBlock - step;
+      const int wpb = matreg ? 1 + step : kMaxWavesPerBlock - step;
       if (requested > 0 && wpb != std::min(requested, kMaxWavesPerBlock)) continue;
-      size_t l = lds_bytes(h->P, wpb, h->matreg);
+      size_t l = lds_bytes(h->P, wpb, matreg);
       if (l > (size_t)h->lds_limit) continue;
       int nb = 0;
       hipError_t e = occupancy_solve(h->cpl, h->rpl, probe, 64 * wpb, l, &nb);
@@ -137,14 +140,14 @@ static int solve_geometry(dsp_handle *h, int requested, int B, Geometry *g) {
     }
     if (best_waves <= 0) return DSP_ERR_TOO_LARGE;
     *g = best;
-    if (requested <= 0) { h->geo = best; h->geo_valid = true; }
+    if (requested <= 0) { h->geo[qp] = best; h->geo_valid[qp] = true; }
   }
   // small batches: spread the scenarios over the CUs instead of packing blocks
   if (requested <= 0) {
     int per_cu = (B + h->num_cus - 1) / h->num_cus;
     int wpb = g->wpb;
     while (wpb > 1 && wpb > per_cu) wpb--;
-    if (wpb != g->wpb) { g->wpb = wpb; g->lds = lds_bytes(h->P, wpb, h->matreg); g->blocks_per_cu = std::max(1, per_cu / wpb); }
+    if (wpb != g->wpb) { g->wpb = wpb; g->lds = lds_bytes(h->P, wpb, matreg); g->blocks_per_cu = std::max(1, per_cu / wpb); }
   }
   return DSP_OK;
 }
@@ -176,6 +179,7 @@ void dsp_default_options(dsp_options *o) {
   o->ray_jumps = 1;
   o->ruiz_iters = 10;
   o->waves_per_block = 0;
+  o->precision = 0;
 }
 
 int dsp_version(void) { return DSP_VERSION; }
@@ -264,7 +268,8 @@ int dsp_create(const dsp_lp_desc *d, int device, const dsp_options *opt, dsp_han
   SlotELL Sc = build_slot_ell(AT, Lc, Lr, Ec.long_owner), Sr = build_slot_ell(A, Lr, Lc, Er.long_owner);
   const bool has_long = P.long_c.count > 0 || P.long_r.count > 0;
   int pad_w = 0;
-  if (!h->opt.no_matreg && !matreg_available(cpl, rpl, Sc.pack, Sr.pack, has_long)) {
+  if (!h->opt.no_matreg && !matreg_available(cpl, rpl, Sc.pack, Sr.pack, has_long) &&
+      !matreg_available(cpl, rpl, Sc.pack, Sr.pack, has_long, true)) {
     // no tight specialisation for this shape: the PADDED one (every slot kPadWidth wide) if the LP fits it
     int wmax = 0;
     for (int q = 0; q < Sc.slots; ++q) wmax = std::max(wmax, Sc.width[q]);
@@ -294,6 +299,7 @@ int dsp_create(const dsp_lp_desc *d, int device, const dsp_options *opt, dsp_han
   P.mr_tailc_entries = (int)Sc.tail_val.size(); P.mr_tailr_entries = (int)Sr.tail_val.size();
   if ((rc = fill_long(P.mr_long_c, Sc)) || (rc = fill_long(P.mr_long_r, Sr))) { delete h; return rc; }
   h->matreg = h->opt.no_matreg ? 0 : matreg_available(cpl, rpl, Sc.pack, Sr.pack, P.long_c.count > 0 || P.long_r.count > 0);
+  h->matreg_qp = h->opt.no_matreg ? 0 : matreg_available(cpl, rpl, Sc.pack, Sr.pack, P.long_c.count > 0 || P.long_r.count > 0, true);
   std::vector<Entry> pk;
 #define UPE(val, idx, field) pack_entries(val, idx, pk); if ((rc = upload(h, pk, &P.field)) != DSP_OK) { dsp_destroy(h); return rc; }
 #define UP(vec, field) if ((rc = upload(h, vec, &P.field)) != DSP_OK) { dsp_destroy(h); return rc; }
@@ -343,6 +349,11 @@ int dsp_solve(dsp_handle *h, const dsp_batch *batch, const dsp_options *opt, dsp
       !(a.opt.pid_kp >= 0) || !(a.opt.step_scale > 0))
     return DSP_ERR_INVALID;
   a.eta = a.opt.step_scale * h->eta_unit;
+  const int qp = batch->row_compliance != nullptr;
+  if (a.opt.precision != 0 && a.opt.precision != 1) return DSP_ERR_INVALID;
+  // soft rows / float32 iterates exist in the fused kernels only (not in the HBM-resident streaming form, not for LPs with
+  // vectors longer than the ELL width)
+  if ((qp || a.opt.precision) && (h->streaming || h->P.long_c.count > 0 || h->P.long_r.count > 0)) return DSP_ERR_INVALID;
   if (h->streaming) {
     const bool timed_s = stats && sync_stats;
     if (timed_s) HIP_TRY(hipEventRecord(h->ev0, st));
@@ -368,8 +379,38 @@ int dsp_solve(dsp_handle *h, const dsp_batch *batch, const dsp_options *opt, dsp
     }
     return DSP_OK;
   }
+  if (a.opt.precision == 1) {
+    // float32 iterates (tolerance sweep of BASELINE config 5): its own kernel, one scenario per wave, LDS-resident matrix
+    const unsigned slot32 = h->queue_next.fetch_add(1u) % kQueueRing;
+    a.queue = h->queue + (size_t)slot32 * kQueueStride;
+    a.qp = qp;
+    HIP_TRY(hipMemsetAsync(a.queue, 0, 2 * sizeof(int), st));
+    const bool timed32 = stats && sync_stats;
+    if (timed32) HIP_TRY(hipEventRecord(h->ev0, st));
+    int grid32 = 0, threads32 = 0;
+    size_t lds32 = 0;
+    HIP_TRY(launch_solve_f32(h->cpl, h->rpl, a, h->num_cus, (size_t)h->lds_limit, st, &grid32, &threads32, &lds32));
+    if (timed32) HIP_TRY(hipEventRecord(h->ev1, st));
+    if (stats) {
+      std::memset(stats, 0, sizeof(*stats));
+      stats->grid_blocks = grid32; stats->block_threads = threads32; stats->lds_bytes = (int)lds32;
+      stats->cols_per_lane = h->cpl; stats->rows_per_lane = h->rpl; stats->quadratic = qp; stats->precision = 1;
+      if (sync_stats) {
+        HIP_TRY(hipStreamSynchronize(st));
+        HIP_TRY(hipEventElapsedTime(&stats->kernel_ms, h->ev0, h->ev1));
+        std::vector<int32_t> hs(B), hi(B);
+        HIP_TRY(hipMemcpy(hs.data(), batch->status, B * sizeof(int32_t), hipMemcpyDeviceToHost));
+        if (batch->iters) HIP_TRY(hipMemcpy(hi.data(), batch->iters, B * sizeof(int32_t), hipMemcpyDeviceToHost));
+        for (int i = 0; i < B; ++i) {
+          stats->n_optimal += hs[i] == DSP_STATUS_OPTIMAL;
+          if (batch->iters) { stats->total_iterations += hi[i]; stats->max_iterations = std::max(stats->max_iterations, hi[i]); }
+        }
+      }
+    }
+    return DSP_OK;
+  }
   Geometry geo;
-  int grc = solve_geometry(h, a.opt.waves_per_block, B, &geo);
+  int grc = solve_geometry(h, a.opt.waves_per_block, B, &geo, qp);
   if (grc != DSP_OK) return grc;
   a.waves_per_block = geo.wpb;
   const size_t lds = geo.lds;
@@ -378,11 +419,12 @@ int dsp_solve(dsp_handle *h, const dsp_batch *batch, const dsp_options *opt, dsp
   a.queue_base = 0u;
   a.unsolved = a.queue + 1;
   HIP_TRY(hipMemsetAsync(a.queue, 0, 2 * sizeof(int), st));
-  a.matreg = h->matreg;
+  a.matreg = qp ? h->matreg_qp : h->matreg;
+  a.qp = qp;
   int grid = std::min((B + geo.wpb - 1) / geo.wpb, h->num_cus * geo.blocks_per_cu);
   const bool timed = stats && sync_stats;
   if (timed) HIP_TRY(hipEventRecord(h->ev0, st));
-  if (h->simplex) {
+  if (h->simplex && !qp) {
     // simplex pass: certified vertices get their final status; DSP_STATUS_UNSOLVED marks what the PDLP kernel still has to do
     SimplexArgs sa{};
     sa.n = h->n; sa.m = h->m; sa.row_stride = h->sx_row_stride; sa.max_pivots = 20 * (h->n + h->m);
@@ -401,9 +443,10 @@ int dsp_solve(dsp_handle *h, const dsp_batch *batch, const dsp_options *opt, dsp
   if (stats) {
     std::memset(stats, 0, sizeof(*stats));
     stats->grid_blocks = grid; stats->block_threads = 64 * a.waves_per_block; stats->lds_bytes = (int)lds;
-    stats->cols_per_lane = h->cpl; stats->rows_per_lane = h->rpl; stats->matreg = h->matreg; stats->simplex = h->simplex;
+    stats->cols_per_lane = h->cpl; stats->rows_per_lane = h->rpl; stats->matreg = a.matreg; stats->simplex = h->simplex && !qp;
+    stats->quadratic = qp;
     stats->lds_conflicts_identity = h->lds_conflicts[0] + h->lds_conflicts[2];
-    stats->lds_conflicts_chosen = h->matreg ? h->lds_conflicts[1] + h->lds_conflicts[3] : stats->lds_conflicts_identity;
+    stats->lds_conflicts_chosen = a.matreg ? h->lds_conflicts[1] + h->lds_conflicts[3] : stats->lds_conflicts_identity;
     if (sync_stats) {
       HIP_TRY(hipStreamSynchronize(st));
       HIP_TRY(hipEventElapsedTime(&stats->kernel_ms, h->ev0, h->ev1));

@@ -63,6 +63,7 @@ struct SolveArgs {
   unsigned queue_base;         //   scenario = ticket - queue_base (0 since the heads are reset per launch)
   const int *unsolved;         // skip_solved: number of scenarios the simplex pass left unsolved (0 = nothing to do)
   int matreg;                  // 1 = register-resident-matrix specialisation of the kernel
+  int qp;                      // 1 = soft rows present (b.row_compliance): QP instantiation
 };
 
 // in-wave dense simplex for tiny LPs (dsp_simplex.hip)
@@ -91,10 +92,13 @@ constexpr int kPadWidth = 4;
 inline unsigned uniform_pack(int slots, int w) { unsigned p = 0; for (int q = 0; q < slots; ++q) p |= (unsigned)w << (4 * q); return p; }
 
 hipError_t launch_solve(int cpl, int rpl, const SolveArgs &a, dim3 grid, dim3 block, size_t lds, hipStream_t st);
-int matreg_available(int cpl, int rpl, unsigned wc_pack, unsigned wr_pack, bool lng);   // 0 / 1
+int matreg_available(int cpl, int rpl, unsigned wc_pack, unsigned wr_pack, bool lng, bool qp = false);   // 0 / 1
 hipError_t occupancy_solve(int cpl, int rpl, const SolveArgs &a, int block_threads, size_t lds, int *blocks_per_cu);
 size_t simplex_lds_bytes(int n, int m, int *row_stride);
 hipError_t launch_simplex(const SimplexArgs &a, int grid, size_t lds, hipStream_t st);
+// float32-iterate solve (dsp_qp.hip); returns the launch geometry it chose
+hipError_t launch_solve_f32(int cpl, int rpl, const SolveArgs &a, int num_cus, size_t lds_limit, hipStream_t st, int *grid,
+                            int *threads, size_t *lds);
 hipError_t launch_spmv(int cpl, int rpl, const SpmvArgs &a, dim3 grid, dim3 block, size_t lds, hipStream_t st);
 hipError_t launch_spmv_stream(int cpl, int rpl, const SpmvArgs &a, dim3 grid, dim3 block, size_t lds, hipStream_t st);
 

@@ -162,7 +162,10 @@ __device__ __forceinline__ void stage_entries(Entry *dst, const Entry *__restric
 // WC / WR != 0: the ELL part of A^T / A is register-resident (RegEll); the template value packs the per-slot
 // widths, 4 bits each, and ownership follows the sorted layout (P.mr_colat / P.mr_rowat);
 // WC = WR = 0: generic path, matrix in LDS with run-time uniform widths, identity ownership.
-template <int CPL, int RPL, bool LONG, unsigned WC, unsigned WR>
+// QP: rows with a compliance (dsp_batch::row_compliance) are soft - the dual step of every row is followed by the
+// proximal shrink 1 / (1 + sig kappa_i) (= 1 for hard rows), the KKT test counts no violation for soft rows and adds the
+// quadratic terms to both objectives.  A separate instantiation: the LP kernels pay nothing for it.
+template <int CPL, int RPL, bool LONG, unsigned WC, unsigned WR, bool QP = false>
 __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 2) pdlp_solve_kernel(SolveArgs a) {
   constexpr bool MATREG = WC != 0;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -293,6 +296,7 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
     // ---- load + scale this scenario's vectors (coalesced: lane-consecutive addresses) -----------------------
     double x[CPL], x0[CPL], c[CPL], lb[CPL], ub[CPL];
     double y[RPL], y0[RPL], rlo[RPL], rhi[RPL];
+    double kap[QP ? RPL : 1], srow[QP ? RPL : 1];        // QP: scaled compliance kappa d_r^2 and 1 / (1 + sig kappa)
     double nrm[4] = {0.0, 0.0, 0.0, 0.0};                // |q|^2 unscaled, |c|^2 unscaled, |q|^2 scaled, |c|^2 scaled
     double cmax = 0.0, qmax = 0.0;                       // largest scaled |c_j| / finite scaled |row bound|
     double bs2 = 0.0;                                    // sum of squared finite scaled column bounds
@@ -329,6 +333,12 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
       rlo[q] = lo * d;
       rhi[q] = hi * d;
       if (!(lo <= hi)) bad = 1.0;
+      if constexpr (QP) {
+        const double kp_ = ok ? a.b.row_compliance[(size_t)s * a.b.row_compliance_stride + i] : 0.0;
+        kap[q] = kp_ * d * d;
+        // a soft row is the term (a.x - b)^2 / (2 kappa): it needs ONE finite target b = row_lb = row_ub
+        if (!(kp_ >= 0.0) || (kp_ > 0.0 && !(lo == hi && is_finite(lo)))) bad = 1.0;
+      }
       const double big = fmax(fabs(finite_or_zero(lo)), fabs(finite_or_zero(hi)));
       nrm[0] += big * big;
       const double bigs = fmax(fabs(finite_or_zero(rlo[q])), fabs(finite_or_zero(rhi[q])));
@@ -353,6 +363,7 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
         b.status[s] = (nrm[0] == nrm[0] && nrm[1] == nrm[1]) ? DSP_STATUS_PRIMAL_INFEASIBLE : DSP_STATUS_NUMERICAL;
         if (b.iters) b.iters[s] = 0;
         if (b.jumps) b.jumps[s] = 0;
+        if (b.flags) b.flags[s] = 0;
       }
       continue;
     }
@@ -409,7 +420,10 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
     }                                                                                                       \
     wave_lds_fence();                                                                                       \
     row_step(gy, y, -sig);                                                                                  \
-    _Pragma("unroll") for (int q = 0; q < RPL; ++q) yp[q] = gy[q] - clampd_bare(gy[q], ylo[q], yhi[q]);     \
+    _Pragma("unroll") for (int q = 0; q < RPL; ++q) {                                                       \
+      yp[q] = gy[q] - clampd_bare(gy[q], ylo[q], yhi[q]);                                                   \
+      if constexpr (QP) yp[q] *= srow[q];                                                                   \
+    }                                                                                                       \
   }
 // reflected Halpern step toward the anchor (x0, y0)
 #define DSP_HALPERN_STEP()                                                                                  \
@@ -435,6 +449,7 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
     tau = eta * iw;                                                                                         \
     sig = eta * w;                                                                                          \
     _Pragma("unroll") for (int q = 0; q < RPL; ++q) { ylo[q] = -(sig * rhi[q]); yhi[q] = -(sig * rlo[q]); } \
+    if constexpr (QP) { _Pragma("unroll") for (int q = 0; q < RPL; ++q) srow[q] = 1.0 / fma(sig, kap[q], 1.0); } \
     if constexpr (MATREG) {                                                                                 \
       mreg_c.load(P.mr_ellc, lane, yb_lds, tau);                                                            \
       mreg_r.load(P.mr_ellr, lane, xb_lds, -sig);                                                           \
@@ -516,7 +531,16 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
 #pragma unroll
           for (int q = 0; q < RPL; ++q) {
             const double ax_ = nisig * axp[q];
-            const double viol_s = fmax(rlo[q] - ax_, 0.0) + fmax(ax_ - rhi[q], 0.0);
+            double viol_s = fmax(rlo[q] - ax_, 0.0) + fmax(ax_ - rhi[q], 0.0);
+            if constexpr (QP) {
+              if (kap[q] > 0.0) {
+                // soft row: no violation; (a.x - b)^2 / (2 kappa) joins the primal objective, -kappa y^2 / 2 the dual one
+                const double dev = ax_ - rlo[q];
+                red[2] = fma(0.5 * dev, dev / kap[q], red[2]);
+                red[3] = fma(-0.5 * kap[q] * yp[q], yp[q], red[3]);
+                viol_s = 0.0;
+              }
+            }
             const int i = row_id(q);
             const double viol = viol_s / ((i >= 0) ? P.row_scale[i] : 1.0);
             red[0] = fma(viol, viol, red[0]);
@@ -620,6 +644,7 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
           for (int q = 0; q < RPL; ++q) {
             dgy[q] = gy[q] - gy1[q];
             y2[q] = gy1[q] - clampd(gy1[q], ylo[q], yhi[q]);
+            if constexpr (QP) y2[q] *= srow[q];
             const double v1 = yp[q] - y[q], v2 = y2[q] - yp[q];
             tt[0] = fma(iw * (v2 - v1), v2 - v1, tt[0]);
             tt[1] = fma(iw * v2, v2, tt[1]);
@@ -672,6 +697,16 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
       double po = 0.0;
 #pragma unroll
       for (int q = 0; q < CPL; ++q) po = fma(c[q], xp[q], po);
+      if constexpr (QP) {
+#pragma unroll
+        for (int q = 0; q < CPL; ++q) lds_store_f64(xw[q], xp[q]);
+        wave_lds_fence();
+        double axq[RPL];
+        row_step(axq, zero_r, -sig);                         // -sig A x+
+#pragma unroll
+        for (int q = 0; q < RPL; ++q)
+          if (kap[q] > 0.0) { const double dev = -(iw * ieta) * axq[q] - rlo[q]; po = fma(0.5 * dev, dev / kap[q], po); }
+      }
       pobj = wave_sum(po);
     }
 #pragma unroll
@@ -694,6 +729,7 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
       iters_done += it;
 #endif
       if (b.jumps) b.jumps[s] = njump;
+      if (b.flags) b.flags[s] = (waive_obj && status == DSP_STATUS_OPTIMAL ? DSP_FLAG_OBJ_WAIVED : 0) | (stalls > 0 ? DSP_FLAG_STALL_RESCUE : 0);
       if (b.primal_weight) b.primal_weight[s] = w;
     }
     DSP_TRACE("[trace] scalars stored\n");
@@ -878,31 +914,48 @@ __global__ void __launch_bounds__(256) spmv_stream_kernel(SpmvArgs a) {
   X(4, 3, 0x4444u, 0x444u, false)                                                                                     \
   X(5, 3, 0x44444u, 0x444u, false)
 
+// QP instantiations (soft rows, dsp_batch::row_compliance) of the register-resident kernel: the ramp-cost variant of the
+// metric LP (BASELINE config 5) + the padded shapes.  Every other QP without long vectors runs the generic QP kernel.
+#define DSP_MATREG_QP_SHAPES(X)                                                                               \
+  X(4, 3, 0x1135u, 0x244u, false)        /* wind+battery 24 h + quadratic ramp cost (23 soft rows) */          \
+  X(2, 2, 0x44u, 0x44u, false)                                                                                \
+  X(3, 2, 0x444u, 0x44u, false)                                                                               \
+  X(4, 2, 0x4444u, 0x44u, false)                                                                              \
+  X(4, 3, 0x4444u, 0x444u, false)                                                                             \
+  X(5, 3, 0x44444u, 0x444u, false)
+
 // 0 = no specialisation, 1 = register-resident matrix
-int matreg_available(int cpl, int rpl, unsigned wc, unsigned wr, bool lng) {
+int matreg_available(int cpl, int rpl, unsigned wc, unsigned wr, bool lng, bool qp) {
 #ifdef DSP_NO_MATREG
   return 0;
 #else
 #define DSP_X(C, R, WC_, WR_, L) if (cpl == C && rpl == R && wc == WC_ && wr == WR_ && lng == L) return 1;
-  DSP_MATREG_SHAPES(DSP_X)
+  if (qp) { DSP_MATREG_QP_SHAPES(DSP_X) }
+  else { DSP_MATREG_SHAPES(DSP_X) }
 #undef DSP_X
   return 0;
 #endif
 }
 
-static const void *matreg_fn(int cpl, int rpl, unsigned wc, unsigned wr, bool lng) {
+static const void *matreg_fn(int cpl, int rpl, unsigned wc, unsigned wr, bool lng, bool qp) {
 #ifndef DSP_NO_MATREG
 #define DSP_X(C, R, WC_, WR_, L)                                                            \
   if (cpl == C && rpl == R && wc == WC_ && wr == WR_ && lng == L)                           \
     return reinterpret_cast<const void *>(&pdlp_solve_kernel<C, R, L, WC_, WR_>);
-  DSP_MATREG_SHAPES(DSP_X)
+  if (!qp) { DSP_MATREG_SHAPES(DSP_X) }
+#undef DSP_X
+#define DSP_X(C, R, WC_, WR_, L)                                                            \
+  if (cpl == C && rpl == R && wc == WC_ && wr == WR_ && lng == L)                           \
+    return reinterpret_cast<const void *>(&pdlp_solve_kernel<C, R, L, WC_, WR_, true>);
+  if (qp) { DSP_MATREG_QP_SHAPES(DSP_X) }
 #undef DSP_X
 #endif
   return nullptr;
 }
 
 template <int CPL, int RPL>
-static const void *generic_fn(bool lng) {
+static const void *generic_fn(bool lng, bool qp) {
+  if (qp) return lng ? nullptr : reinterpret_cast<const void *>(&pdlp_solve_kernel<CPL, RPL, false, 0u, 0u, true>);
   return lng ? reinterpret_cast<const void *>(&pdlp_solve_kernel<CPL, RPL, true, 0u, 0u>)
              : reinterpret_cast<const void *>(&pdlp_solve_kernel<CPL, RPL, false, 0u, 0u>);
 }
@@ -910,7 +963,7 @@ static const void *generic_fn(bool lng) {
 template <int CPL, int RPL>
 static hipError_t launch_solve_t(const SolveArgs &a, dim3 grid, dim3 block, size_t lds, hipStream_t st) {
   const bool lng = a.P.long_c.count > 0 || a.P.long_r.count > 0;
-  const void *fn = a.matreg ? matreg_fn(CPL, RPL, a.P.mr_wc_pack, a.P.mr_wr_pack, lng) : generic_fn<CPL, RPL>(lng);
+  const void *fn = a.matreg ? matreg_fn(CPL, RPL, a.P.mr_wc_pack, a.P.mr_wr_pack, lng, a.qp != 0) : generic_fn<CPL, RPL>(lng, a.qp != 0);
   if (!fn) return hipErrorInvalidValue;
   hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
@@ -963,7 +1016,7 @@ hipError_t launch_solve(int cpl, int rpl, const SolveArgs &a, dim3 grid, dim3 bl
 template <int CPL, int RPL>
 static hipError_t occupancy_solve_t(const SolveArgs &a, dim3 grid, dim3 block, size_t lds, hipStream_t) {
   const bool lng = a.P.long_c.count > 0 || a.P.long_r.count > 0;
-  const void *fn = a.matreg ? matreg_fn(CPL, RPL, a.P.mr_wc_pack, a.P.mr_wr_pack, lng) : generic_fn<CPL, RPL>(lng);
+  const void *fn = a.matreg ? matreg_fn(CPL, RPL, a.P.mr_wc_pack, a.P.mr_wr_pack, lng, a.qp != 0) : generic_fn<CPL, RPL>(lng, a.qp != 0);
   if (!fn) return hipErrorInvalidValue;
   hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;

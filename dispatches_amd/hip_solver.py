@@ -28,7 +28,7 @@ class DspOptions(C.Structure):
                 ("jump_min", C.c_double), ("ray_jumps", C.c_int32), ("ruiz_iters", C.c_int32),
                 ("waves_per_block", C.c_int32), ("kkt_every", C.c_int32), ("no_matreg", C.c_int32), ("geo_iters", C.c_int32),
                 ("kkt_gate", C.c_double), ("stall_rescue", C.c_int32), ("no_simplex", C.c_int32),
-                ("jump_rel", C.c_double)]
+                ("jump_rel", C.c_double), ("precision", C.c_int32), ("reserved0", C.c_int32)]
 
 
 class DspBatch(C.Structure):
@@ -40,9 +40,10 @@ class DspBatch(C.Structure):
                 ("row_lb", C.c_void_p), ("row_lb_stride", C.c_int64),
                 ("row_ub", C.c_void_p), ("row_ub_stride", C.c_int64),
                 ("obj_offset", C.c_void_p), ("obj_offset_stride", C.c_int64),
+                ("row_compliance", C.c_void_p), ("row_compliance_stride", C.c_int64),
                 ("x0", C.c_void_p), ("y0", C.c_void_p), ("primal_weight", C.c_void_p),
                 ("x", C.c_void_p), ("y", C.c_void_p), ("obj", C.c_void_p),
-                ("status", C.c_void_p), ("iters", C.c_void_p), ("jumps", C.c_void_p)]
+                ("status", C.c_void_p), ("iters", C.c_void_p), ("jumps", C.c_void_p), ("flags", C.c_void_p)]
 
 
 class DspStats(C.Structure):
@@ -50,7 +51,8 @@ class DspStats(C.Structure):
                 ("grid_blocks", C.c_int32), ("block_threads", C.c_int32), ("lds_bytes", C.c_int32),
                 ("cols_per_lane", C.c_int32), ("rows_per_lane", C.c_int32), ("kernel_ms", C.c_float),
                 ("matreg", C.c_int32), ("lds_conflicts_identity", C.c_int32), ("lds_conflicts_chosen", C.c_int32),
-                ("simplex", C.c_int32), ("streaming", C.c_int32), ("stream_bytes_per_iteration", C.c_int64)]
+                ("simplex", C.c_int32), ("streaming", C.c_int32), ("stream_bytes_per_iteration", C.c_int64),
+                ("quadratic", C.c_int32), ("precision", C.c_int32)]
 
 
 class DspLpDesc(C.Structure):
@@ -63,7 +65,7 @@ EXPORTED_SYMBOLS = ("dsp_default_options", "dsp_create", "dsp_solve", "dsp_spmv_
                     "dsp_get_scaling", "dsp_destroy", "dsp_strerror", "dsp_last_hip_error", "dsp_version")
 
 
-ABI_VERSION = 4          # DSP_VERSION of the include/dsp_hip.h these structures mirror
+ABI_VERSION = 5          # DSP_VERSION of the include/dsp_hip.h these structures mirror
 
 
 def load_library(path: Optional[str] = None):
@@ -189,9 +191,10 @@ class DeviceLP:
         return t.data_ptr(), width
 
     def solve(self, B, c, lb=None, ub=None, rlo=None, rhi=None, x0=None, y0=None, options=None, out=None,
-              sync_stats=True, obj_offset=None, primal_weight=None):
+              sync_stats=True, obj_offset=None, primal_weight=None, row_compliance=None):
         """All arguments are CUDA(HIP) float64 torch tensors; returns dict of output tensors (+ stats).
-        obj_offset: [B] objective constants (scale of the eps_obj tests); primal_weight: [B] in/out."""
+        obj_offset: [B] objective constants (scale of the eps_obj tests); primal_weight: [B] in/out;
+        row_compliance: [m] or [B, m] compliances of the soft rows (convex QP, dsp_batch::row_compliance)."""
         import torch
 
         n, m = self.lp.n, self.lp.m
@@ -202,7 +205,8 @@ class DeviceLP:
                        obj=torch.empty(B, dtype=torch.float64, device=dev),
                        status=torch.empty(B, dtype=torch.int32, device=dev),
                        iters=torch.empty(B, dtype=torch.int32, device=dev),
-                       jumps=torch.empty(B, dtype=torch.int32, device=dev))
+                       jumps=torch.empty(B, dtype=torch.int32, device=dev),
+                       flags=torch.zeros(B, dtype=torch.int32, device=dev))
         bt = DspBatch()
         bt.B = B
         bt.c, bt.c_stride = self._ptr_stride(c, n)
@@ -213,6 +217,8 @@ class DeviceLP:
         if obj_offset is not None:
             assert obj_offset.is_cuda and obj_offset.element_size() == 8 and obj_offset.numel() in (1, B)
             bt.obj_offset, bt.obj_offset_stride = obj_offset.data_ptr(), (1 if obj_offset.numel() == B and B > 1 else 0)
+        if row_compliance is not None:
+            bt.row_compliance, bt.row_compliance_stride = self._ptr_stride(row_compliance, m)
         bt.x0 = x0.data_ptr() if x0 is not None else None
         bt.y0 = y0.data_ptr() if y0 is not None else None
         if primal_weight is not None:
@@ -221,6 +227,7 @@ class DeviceLP:
         bt.x, bt.y, bt.obj = out["x"].data_ptr(), out["y"].data_ptr(), out["obj"].data_ptr()
         bt.status, bt.iters = out["status"].data_ptr(), out["iters"].data_ptr()
         bt.jumps = out["jumps"].data_ptr() if "jumps" in out else None
+        bt.flags = out["flags"].data_ptr() if "flags" in out else None
         stats = DspStats()
         stream = torch.cuda.current_stream(dev).cuda_stream
         rc = self.lib.dsp_solve(self.handle, C.byref(bt), C.byref(options) if options is not None else None,
@@ -307,14 +314,12 @@ class HipPdlpSolver:
 
         from .workflow.batch_model import SolveResults
 
-        if getattr(model.lp, "qdiag", None) is not None and np.any(model.lp.qdiag):
-            # the flattener can express lifted diagonal quadratic terms (LinearBlock.quadratic, Bidder(ramp_cost=...)),
-            # the kernels do not take Q yet: never drop it silently
-            raise NotImplementedError("quadratic objective terms (ramp_cost) are not supported by the HIP kernels yet")
         dlp = self._device_lp(model)
         dev = torch.device("cuda", self.device)
         B = model.n_scenario
         lb, ub, rlo, rhi = model.scenario_bounds()
+        # convex QP: quadratic objective terms arrive as soft rows (LinearBlock.quadratic -> StandardFormLP.row_compliance)
+        kappa = getattr(model.lp, "row_compliance", None)
         # uploads go through per-handle pinned staging buffers (a pageable 6 MB numpy array takes ~4 ms to reach the
         # device, a pinned one ~0.3 ms; the previous solve has synchronised, so the buffers are free to overwrite)
         stage = dlp.__dict__.setdefault("_staging", {})
@@ -341,7 +346,8 @@ class HipPdlpSolver:
                 pw = up("primal_weight", prev)
         out = dlp.solve(B, up("c", model.c), up("lb", lb), up("ub", ub), up("rlo", rlo) if model.lp.m else None,
                         up("rhi", rhi) if model.lp.m else None, x0=x0, y0=y0, options=dlp.options,
-                        obj_offset=up("c0", np.broadcast_to(np.asarray(model.c0, np.float64), (B,))), primal_weight=pw)
+                        obj_offset=up("c0", np.broadcast_to(np.asarray(model.c0, np.float64), (B,))), primal_weight=pw,
+                        row_compliance=(up("kappa", kappa) if kappa is not None and np.any(kappa) else None))
         st = out["stats"]
         self.last_stats = st
         # device outputs of this solve (x, y, obj = c.x without the model constant, status, iters): a sharded solve
@@ -354,13 +360,14 @@ class HipPdlpSolver:
             h.copy_(t, non_blocking=True)
             return h
 
-        host = {k: down(out[k]) for k in ("x", "y", "obj", "status", "iters", "jumps")}
+        host = {k: down(out[k]) for k in ("x", "y", "obj", "status", "iters", "jumps", "flags")}
         host["pw"] = down(pw)
         torch.cuda.current_stream(dev).synchronize()
         status = host["status"].numpy()
         model.store_solution(host["x"].numpy(), host["y"].numpy()[:, :model.lp.m],
                              host["obj"].numpy() + model.c0, status, host["iters"].numpy())
         model.jumps = host["jumps"].numpy()
+        model.flags = host["flags"].numpy()      # DSP_FLAG_* bits (1 = optimal on the eps_rel tests only, objective accuracy waived)
         model.primal_weight = host["pw"].numpy()
         if tee:
             print(f"[dsp_hip] B={B} n={model.lp.n} m={model.lp.m} nnz={model.lp.nnz} optimal={st.n_optimal}/{B} "

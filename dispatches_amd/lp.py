@@ -149,7 +149,10 @@ class StandardFormLP:
     rhi: np.ndarray         # [m]  (+inf allowed)
     col_names: List[str] = field(default_factory=list)
     row_names: List[str] = field(default_factory=list)
-    qdiag: Optional[np.ndarray] = None     # [n] diagonal of Q for  min c.x + 1/2 sum_j qdiag_j x_j^2  (None = LP)
+    # [m] compliance kappa_i >= 0 of every row (None = LP).  A row with kappa_i > 0 is SOFT: not a constraint but the
+    # objective term (a_i.x - b_i)^2 / (2 kappa_i), b_i = its (equal) row bounds - the factored form Q = sum_i a_i a_i^T /
+    # kappa_i of a convex quadratic objective, which first-order solvers take in the DUAL (LinearBlock.quadratic)
+    row_compliance: Optional[np.ndarray] = None
 
     @property
     def nnz(self) -> int:
@@ -163,8 +166,15 @@ class StandardFormLP:
     def objective(self, x: np.ndarray, c: Optional[np.ndarray] = None, c0: Optional[float] = None):
         c = self.c if c is None else c
         c0 = self.c0 if c0 is None else c0
-        quad = 0.0 if self.qdiag is None else 0.5 * float(self.qdiag @ (x * x))
-        return float(c @ x + c0) + quad
+        return float(c @ x + c0) + self.quadratic_value(x)
+
+    def quadratic_value(self, x: np.ndarray, rhs: Optional[np.ndarray] = None) -> float:
+        """sum over the soft rows of (a_i.x - b_i)^2 / (2 kappa_i)"""
+        if self.row_compliance is None:
+            return 0.0
+        soft = self.row_compliance > 0
+        r = (self.csr() @ x - (self.rhi if rhs is None else rhs))[soft]
+        return float(0.5 * np.sum(r * r / self.row_compliance[soft]))
 
     def max_violation(self, x, lb=None, ub=None, rlo=None, rhi=None):
         lb = self.lb if lb is None else lb
@@ -174,7 +184,8 @@ class StandardFormLP:
         ax = self.csr() @ x
         v = max(np.max(np.maximum(lb - x, 0)), np.max(np.maximum(x - ub, 0)))
         if self.m:
-            v = max(v, np.max(np.maximum(rlo - ax, 0)), np.max(np.maximum(ax - rhi, 0)))
+            hard = 1.0 if self.row_compliance is None else (self.row_compliance == 0)       # soft rows constrain nothing
+            v = max(v, np.max(np.maximum(rlo - ax, 0) * hard), np.max(np.maximum(ax - rhi, 0) * hard))
         return float(v)
 
 
@@ -200,7 +211,7 @@ class LinearBlock:
         self.row_hi: List[float] = []
         self.row_mutable: List[bool] = []
         self.expressions: Dict[str, Dict[int, LinExpr]] = {}
-        self.col_quad: Dict[int, float] = {}        # column -> weight w of an objective term (w / 2) x^2
+        self.row_soft: Dict[int, float] = {}        # row -> compliance kappa = 1 / weight of an objective term (w / 2) body^2
         self.solution: Optional[np.ndarray] = None
         self._constructed = False
         self._kept_rows: Optional[np.ndarray] = None
@@ -239,17 +250,20 @@ class LinearBlock:
     def equality(self, name, body, rhs=0.0):
         return self.constraint(name, body, rhs, rhs)
 
-    def quadratic(self, name: str, expr, weight: float) -> Var:
-        """Objective term (weight / 2) * expr^2, LIFTED so that Q stays diagonal: a free column r with the row
-        r - expr = 0 and the term (weight / 2) r^2.  A diagonal Q keeps the proximal step of the first-order solver in
-        closed form (x+ = clip((x - tau (c - A^T y)) / (1 + tau q))); the solver's ABI accepts Q in CSR but only diagonal
-        ones (include/dsp_hip.h)."""
-        if weight < 0:
-            raise ValueError("quadratic terms must be convex (weight >= 0)")
-        r = self.var(name, -INF, INF)
-        self.constraint(name + ".def", LinExpr._as(r) - LinExpr._as(expr), 0.0, 0.0, mutable=True)   # never presolved away
-        self.col_quad[r.index] = float(weight)
-        return r
+    def quadratic(self, name: str, expr, weight: float) -> int:
+        """Objective term (weight / 2) * expr^2 as a SOFT ROW: the row expr = 0 with compliance kappa = 1 / weight.
+        By convex duality (weight / 2) r^2 = max_y [-y r - y^2 / (2 weight)], so the term is an equality row whose
+        multiplier pays kappa y^2 / 2; a primal-dual first-order method then only changes the dual step of that row to
+        y+ = (y - sigma a.xbar) / (1 + sigma kappa) - no extra column, nothing else changes (include/dsp_hip.h,
+        dsp_batch::row_compliance).  Any convex quadratic objective x'Qx / 2 can be handed over this way through a
+        factorisation Q = sum_i w_i a_i a_i'.  (Round 2 first LIFTED the term to a diagonal Q on extra free columns with
+        the primal proximal step; that form needed 10-20x the iterations of the LP - tools/pdqp_proto.py.)
+        Returns the row index."""
+        if not weight > 0:
+            raise ValueError("quadratic terms must be strictly convex in their expression (weight > 0)")
+        row = self.constraint(name, expr, 0.0, 0.0, mutable=True)      # mutable: never presolved away, never propagated
+        self.row_soft[row] = 1.0 / float(weight)
+        return row
 
     def set_row_bounds(self, row: int, lo: float, hi: float):
         if self._kept_rows is not None and not self.row_mutable[row]:
@@ -364,8 +378,8 @@ class LinearBlock:
             data=np.asarray(data, np.float64), c=obj.dense(n), c0=obj.const,
             lb=lbv, ub=ubv, rlo=rlo, rhi=rhi,
             col_names=list(self.col_names), row_names=[self.row_names[i] for i in self._kept_rows],
-            qdiag=(None if not self.col_quad else
-                   np.array([self.col_quad.get(j, 0.0) for j in range(n)], np.float64)),
+            row_compliance=(None if not self.row_soft else
+                            np.array([self.row_soft.get(int(i), 0.0) for i in self._kept_rows], np.float64)),
         )
 
     def current_bounds(self):

@@ -161,7 +161,7 @@ WORKLOADS = {
     "nuclear_24h": (nuclear_batch, dict(T=24)),                  # config 2
     "nuclear_48h": (nuclear_batch, dict(T=48)),
 }
-# BASELINE config 5: the metric LP with a quadratic ramp cost rho/2 sum (P_T[t] - P_T[t-1])^2 (convex QP, diagonal Q after lifting)
+# BASELINE config 5: the metric LP with a quadratic ramp cost rho/2 sum (P_T[t] - P_T[t-1])^2 (convex QP: T - 1 soft rows)
 QP_WORKLOADS = {f"wind_battery_24h_qp{tag}": (wind_battery_batch, dict(T=24, ramp_cost=rho))
                 for tag, rho in (("001", 0.01), ("01", 0.1), ("1", 1.0))}
 

@@ -110,7 +110,7 @@ class StochasticProgramBidder(AbstractBidder):
         self._coupled = {}
         # ramp_cost rho [$/MW^2] > 0 adds (rho / 2) sum_t (P_T[t] - P_T[t-1])^2 to every scenario's cost (BASELINE config 5:
         # "stochastic bidder with quadratic ramp cost"; OUR extension - the reference has no such term): the problems
-        # become convex QPs with a diagonal Q after lifting (LinearBlock.quadratic)
+        # become convex QPs, handed to the solver as soft rows with a dual compliance (LinearBlock.quadratic)
         self.ramp_cost = float(ramp_cost)
         # strict: raise if ANY scenario fails to reach optimality; otherwise failed scenarios are left out of the bids
         # (and listed in `failed_scenarios`), and only a solve without a single optimal scenario raises

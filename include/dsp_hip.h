@@ -10,6 +10,10 @@
  *
  *     min c.x + c0   s.t.  row_lb <= A x <= row_ub,   var_lb <= x <= var_ub          (one scenario)
  *
+ * or, for the convex QPs of BASELINE config 5 (quadratic ramp cost), the same with SOFT rows (dsp_batch::row_compliance):
+ *
+ *     min c.x + c0 + sum_{i soft} (a_i.x - b_i)^2 / (2 kappa_i)      s.t. the hard rows and the column bounds
+ *
  * once (dsp_create: the CSR of A shared by every scenario) and then, per call, B dense per-scenario vectors
  * (dsp_solve).  Plain C, opaque handle, caller-owned buffers, int return codes, stream-ordered.
  * All per-scenario pointers in dsp_batch / dsp_spmv_step are DEVICE pointers (e.g. torch.Tensor.data_ptr());
@@ -24,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DSP_VERSION 4
+#define DSP_VERSION 5
 
 /* return codes (0 = ok, < 0 = API misuse / HIP error; text via dsp_strerror) */
 #define DSP_OK                 0
@@ -42,6 +46,13 @@ extern "C" {
 #define DSP_STATUS_DUAL_INFEASIBLE    3   /* reserved */
 #define DSP_STATUS_NUMERICAL          4   /* NaN in the input or NaN / Inf met in the iteration                */
 /* DSP_STATUS_DUAL_INFEASIBLE is reported by the simplex path only (an unbounded ray of a tiny LP). */
+
+/* per-scenario flag bits written to flags[B] */
+#define DSP_FLAG_OBJ_WAIVED   1   /* status OPTIMAL was reached on the eps_rel tests alone: the iteration stalled twice on
+                                     its rounding floor and the eps_obj tests were waived (dsp_options::stall_rescue) -
+                                     the 1e-6 objective accuracy is NOT guaranteed for this scenario (near-zero objectives
+                                     that are the difference of terms ~1e6 times larger)                              */
+#define DSP_FLAG_STALL_RESCUE 2   /* the primal weight was reset once by the stall rescue                              */
 
 typedef struct dsp_handle dsp_handle;
 
@@ -113,6 +124,11 @@ typedef struct dsp_options {
                                 are short the solver otherwise jumps at every opportunity (one jump per ~40
                                 iterations, thousands per scenario) and never gets the averaged iteration going:
                                 such scenarios were the 10-60x stragglers of every batch        default 3    */
+  int32_t precision;         /* 0 = float64 everywhere (the parity path).  1 = float32 iterates, matrix and SpMVs with
+                                float64 reductions / KKT tests (dsp_qp.hip: one scenario per wave, no ray jumps), for the
+                                fp64-vs-fp32 tolerance sweep of BASELINE config 5 - it cannot reach the 1e-6 objective
+                                contract on these LPs (bench.py --workload qp_sweep)             default 0    */
+  int32_t reserved0;
 } dsp_options;
 
 /* The per-call data of B scenarios.  c is required; every other input may be NULL (= no bound: -inf / +inf,
@@ -128,6 +144,16 @@ typedef struct dsp_batch {
   const double *row_lb;     int64_t row_lb_stride;
   const double *row_ub;     int64_t row_ub_stride;
   const double *obj_offset; int64_t obj_offset_stride;  /* c0: only used to scale the eps_obj tests */
+  /* NULL = LP.  Otherwise [m] (stride 0) or [B][m] (stride m) compliances kappa_i >= 0.  A row with kappa_i > 0 is SOFT:
+     it needs row_lb = row_ub = b_i (finite) and is not a constraint but the objective term (a_i.x - b_i)^2 / (2 kappa_i)
+     - a convex quadratic objective x'Qx / 2 in FACTORED form, Q = sum_i a_i a_i' / kappa_i (the ramp cost
+     (rho / 2) sum_t (P_T[t] - P_T[t-1])^2 is T - 1 such rows with kappa = 1 / rho).  By convex duality the term is an equality row
+     whose multiplier pays kappa_i y_i^2 / 2, so the solver's dual step of that row becomes the proximal step
+     y+ = (y - sigma (a_i.xbar - b_i)) / (1 + sigma kappa_i) and nothing else changes; y_i = -(a_i.x - b_i) / kappa_i at the
+     optimum, obj[] includes the quadratic term.  (SURVEY.md 8(b) proposed Q in CSR; a general Q would need a proximal
+     step with Q in the PRIMAL, which was measured 10-20x slower on these problems: tools/pdqp_proto.py.)
+     Fused kernels only (n <= 640, m <= 384, no vectors longer than the ELL width); the in-wave simplex is skipped. */
+  const double *row_compliance; int64_t row_compliance_stride;
   const double *x0;         /* [B][n] or NULL */
   const double *y0;         /* [B][m] or NULL */
   double  *primal_weight;   /* [B] in/out or NULL: > 0 on entry = initial primal weight of the scenario (rolling-
@@ -138,6 +164,7 @@ typedef struct dsp_batch {
   int32_t *status;          /* [B]     DSP_STATUS_*                                                 */
   int32_t *iters;           /* [B] or NULL   iterations used                                        */
   int32_t *jumps;           /* [B] or NULL   ray jumps taken                                        */
+  int32_t *flags;           /* [B] or NULL   DSP_FLAG_* bits of the scenario's solve                */
 } dsp_batch;
 
 /* Aggregate statistics of one dsp_solve call (filled after the call's stream work completes when
@@ -161,6 +188,8 @@ typedef struct dsp_stats {
                                      PDLP ran (state streamed from HBM every iteration: dsp_stream.hip)    */
   int64_t stream_bytes_per_iteration;  /* streaming path: algorithmic HBM bytes per scenario and plain iteration
                                           (8 n + 6 m doubles)                                          */
+  int32_t quadratic;              /* 1 = soft rows present (QP variant of the kernel ran)                */
+  int32_t precision;              /* precision the iterates were held in (dsp_options::precision)        */
 } dsp_stats;
 
 void dsp_default_options(dsp_options *opt);

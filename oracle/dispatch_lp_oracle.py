@@ -473,11 +473,11 @@ def wind_battery_price_taker(T, cf, lmp, wind_kw=847e3, wind_kw_ub=10000e3, batt
 
 
 # ---- QP variant: quadratic ramp cost on the delivered power (BASELINE config 5; OUR extension, no reference formulation) ---
-# FORMULATION ONLY.  No QP solver in this container reaches the 1e-6 bar on these degenerate problems (HiGHS' active-set QP
-# cycles for millions of iterations on the first objective plateau; a textbook Mehrotra interior-point restatement stalled
-# 1e-5 from the LP optimum on the Q = 0 pin; scipy's trust-constr + a Wolfe-dual certificate bracketed the optimum to 6e-9
-# on the product's REDUCED formulation but never converged on this un-reduced one), so the QP path has NO independent oracle
-# yet and the HIP solver refuses quadratic terms (dispatches_amd/hip_solver.py) instead of solving them unchecked.
+# No QP SOLVER in this container reaches the 1e-6 bar on these degenerate problems (HiGHS' active-set QP cycles for millions
+# of iterations on the first objective plateau; a textbook Mehrotra interior-point restatement stalled 1e-5 from the LP
+# optimum on the Q = 0 pin; scipy's trust-constr never converged on this un-reduced formulation).  The QP oracle is therefore
+# oracle/qp_cutting_plane.py: Kelley's cutting planes on top of THIS file's LP (HiGHS dual simplex), which returns a certified
+# bracket [lower, upper] of the optimal value; the Hessian below documents the term in the original variables.
 def ramp_hessian(lp, fs, rho):
     """Hessian of (rho / 2) sum_t (P_T[t] - P_T[t-1])^2 in the ORIGINAL variables (P_T[t] is a linear expression of two
     or three columns, so Q = rho E^T D^T D E is not diagonal): a formulation independent of the product's lifted one."""

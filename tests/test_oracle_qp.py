@@ -1,0 +1,109 @@
+"""The QP oracle of BASELINE config 5 (oracle/qp_cutting_plane.py: Kelley's cutting planes on the pinned LP oracle) and
+the product's soft-row formulation of the same problems, on the CPU.
+
+No reference vector exists for a quadratic ramp cost (OUR extension), so the oracle is anchored three ways: tiny QPs with
+known answers, rho = 0 against the reference golden G1, and the fact that what it returns is a certified bracket.  The
+product side is checked through the numpy executable specification of the kernel's algorithm (tools/pdqp_proto.py)."""
+import json
+import os
+import sys
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from oracle import dispatch_lp_oracle as orc                      # noqa: E402
+from oracle import qp_cutting_plane as qp                         # noqa: E402
+from tools.make_qp_fixtures import qp_scenario                     # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def _tiny(c, A, lo, hi, lb, ub):
+    return SimpleNamespace(c=np.array(c, float), c0=0.0, A=sp.csr_matrix(np.array(A, float)), lo=np.array(lo, float),
+                           hi=np.array(hi, float), lb=np.array(lb, float), ub=np.array(ub, float))
+
+
+def test_known_answers():
+    # min -x + (rho / 2) x^2 on [0, 10]: x = 1 / rho, value -1 / (2 rho)
+    P = _tiny([-1.0], [[1.0]], [-np.inf], [np.inf], [0.0], [10.0])
+    out = qp.solve_qp_bracket(P, sp.csr_matrix([[1.0]]), 0.5)
+    assert out["lower"] <= -1.0 + 1e-9 and abs(out["upper"] + 1.0) <= 2e-9 and abs(out["x"][0] - 2.0) < 1e-3
+    # the same with the bound active: x = 1, value -1 + rho / 2
+    P = _tiny([-1.0], [[1.0]], [-np.inf], [np.inf], [0.0], [1.0])
+    out = qp.solve_qp_bracket(P, sp.csr_matrix([[1.0]]), 0.5)
+    assert abs(out["upper"] - (-0.75)) <= 2e-9 and out["lower"] <= out["upper"]
+    # min -2a - b + (rho / 2)(a - b)^2, a + b <= 1.5, 0 <= a, b <= 1: on the row a = 1.5 - b the objective is
+    # b - 3 + (rho / 2)(1.5 - 2 b)^2, minimal at b = 0.75 - 1 / (4 rho) (if >= 0.5, i.e. rho >= 1)
+    rho = 4.0
+    P = _tiny([-2.0, -1.0], [[1.0, 1.0]], [-np.inf], [1.5], [0.0, 0.0], [1.0, 1.0])
+    out = qp.solve_qp_bracket(P, sp.csr_matrix([[1.0, -1.0]]), rho)
+    b = 0.75 - 1.0 / (4 * rho)
+    val = b - 3.0 + 0.5 * rho * (1.5 - 2 * b) ** 2
+    assert abs(out["upper"] - val) <= 1e-8 and 0.0 <= out["upper"] - out["lower"] <= 2e-9 * (1 + abs(val))
+
+
+def test_rho_zero_is_the_golden_lp():
+    gold = json.load(open(os.path.join(GOLD, "reference_vectors.json")))
+    # any scenario: with rho = 0 the bracket collapses on the LP optimum of the pinned LP oracle after one solve
+    cf, da, rt = qp_scenario(3)
+    out, P, fs, pda = qp.wind_battery_da_qp(24, cf, da, rt, 0.0)
+    _, f = P.solve(tight=True)
+    assert out["rounds"] == 1 and abs(out["upper"] - f) <= 1e-9 * (1 + abs(f))
+    assert abs(out["upper"] - out["lower"]) <= 1e-11 * (1 + abs(f))       # c.x re-evaluated vs HiGHS' own objective value
+    assert gold            # (G1 itself is pinned in test_oracle_golden.py; this test ties the QP entry point to that LP)
+
+
+@pytest.mark.parametrize("rho", [0.01, 0.1, 1.0])
+def test_bracket_is_tight_and_ordered_and_matches_the_fixture(rho):
+    fx = np.load(os.path.join(GOLD, "oracle_qp.npz"))
+    tag = {0.01: "001", 0.1: "01", 1.0: "1"}[rho]
+    lp_obj = np.load(os.path.join(GOLD, "oracle_objectives.npz"))["wind_battery_24h"]
+    for k in (0, 1, 599, 1217):
+        cf, da, rt = qp_scenario(k)
+        out, *_ = qp.wind_battery_da_qp(24, cf, da, rt, rho)
+        # (ordered up to the LP solver's own rounding: both numbers come out of HiGHS at 1e-9 feasibility tolerances)
+        assert -1e-11 * (1 + abs(out["upper"])) <= out["upper"] - out["lower"] <= 1e-9 * (1 + abs(out["upper"]))
+        # a ramp cost can only raise the cost; and the fixture holds this very bracket
+        assert out["lower"] >= lp_obj[k] - 1e-7 * (1 + abs(lp_obj[k]))
+        assert abs(out["upper"] - fx[f"wind_battery_24h_qp{tag}/upper"][k]) <= 1e-9 * (1 + abs(out["upper"]))
+        assert np.allclose(out["P_T"], fx[f"wind_battery_24h_qp{tag}/P_T"][k], atol=1e-3)
+
+
+def test_soft_row_flattening():
+    from dispatches_amd.lp import LinearBlock
+    b = LinearBlock()
+    x = b.var("x", 0.0, 10.0)
+    y = b.var("y", 0.0, 10.0)
+    b.constraint("cap", x + y, -np.inf, 12.0)
+    row = b.quadratic("ramp", x - y, 4.0)
+    lp = b.flatten(-1.0 * x)
+    assert lp.n == 2 and lp.m == 2 and lp.row_compliance[b.kept_row_index(row)] == 0.25
+    assert lp.rlo[b.kept_row_index(row)] == lp.rhi[b.kept_row_index(row)] == 0.0
+    pt = np.array([3.0, 1.0])
+    assert lp.objective(pt) == pytest.approx(-3.0 + 0.5 * 4.0 * 4.0)
+    assert lp.max_violation(pt) == 0.0                       # the soft row constrains nothing
+    with pytest.raises(ValueError):
+        b.quadratic("bad", x, 0.0)
+
+
+def test_product_formulation_through_the_kernel_specification_meets_the_oracle():
+    """Bidder(ramp_cost=rho) flattens to soft rows; the numpy specification of the kernel's algorithm (float64) on that
+    LP lands inside the oracle's bracket to 1e-6 - product formulation and oracle formulation are independent."""
+    from tools import pdqp_proto
+    from tools.pdlp_proto import build
+    fx = np.load(os.path.join(GOLD, "oracle_qp.npz"))
+    model, P = build("wind_battery_24h_qp01", 4)
+    assert model.lp.row_compliance is not None and np.count_nonzero(model.lp.row_compliance) == 23
+    X, Y, obj, iters, done = pdqp_proto.solve(P, model.lp.row_compliance, np.float64, eps=1e-9, eps_obj=1e-7, max_iter=40000)
+    assert done.all()
+    up, lo = fx["wind_battery_24h_qp01/upper"][:4], fx["wind_battery_24h_qp01/lower"][:4]
+    tol = 1e-6 * np.maximum(1.0, np.abs(up))
+    assert (obj >= lo - tol).all() and (obj <= up + tol).all()
+    # the model object evaluates the same objective from the solver's x
+    for k in range(4):
+        assert model.lp.objective(X[k], c=model.c[k], c0=model.c0[k]) == pytest.approx(obj[k], rel=1e-9, abs=1e-6)
