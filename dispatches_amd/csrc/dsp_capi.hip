@@ -158,7 +158,7 @@ void dsp_default_options(dsp_options *o) {
   if (!o) return;
   std::memset(o, 0, sizeof(*o));
   o->eps_rel = 1e-9;
-  o->eps_obj = 1e-7;
+  o->eps_obj = 5e-7;
   o->max_iter = 200000;
   o->check_every = 16;
   o->kkt_every = 32;
@@ -180,6 +180,7 @@ void dsp_default_options(dsp_options *o) {
   o->ruiz_iters = 10;
   o->waves_per_block = 0;
   o->precision = 0;
+  o->polish_patience = 1024;
 }
 
 int dsp_version(void) { return DSP_VERSION; }
@@ -345,7 +346,7 @@ int dsp_solve(dsp_handle *h, const dsp_batch *batch, const dsp_options *opt, dsp
   SolveArgs a{};
   a.P = h->P; a.b = *batch;
   a.opt = opt ? *opt : h->opt;
-  if (a.opt.max_iter < 1 || a.opt.check_every < 1 || a.opt.kkt_every < 0 || !(a.opt.kkt_gate >= 0) || a.opt.stall_rescue < 0 || !(a.opt.jump_rel >= 0) || !(a.opt.eps_rel > 0) || !(a.opt.eps_obj >= 0) ||
+  if (a.opt.max_iter < 1 || a.opt.check_every < 1 || a.opt.kkt_every < 0 || !(a.opt.kkt_gate >= 0) || a.opt.stall_rescue < 0 || a.opt.polish_patience < 0 || !(a.opt.jump_rel >= 0) || !(a.opt.eps_rel > 0) || !(a.opt.eps_obj >= 0) ||
       !(a.opt.pid_kp >= 0) || !(a.opt.step_scale > 0))
     return DSP_ERR_INVALID;
   a.eta = a.opt.step_scale * h->eta_unit;
@@ -421,6 +422,15 @@ int dsp_solve(dsp_handle *h, const dsp_batch *batch, const dsp_options *opt, dsp
   HIP_TRY(hipMemsetAsync(a.queue, 0, 2 * sizeof(int), st));
   a.matreg = qp ? h->matreg_qp : h->matreg;
   a.qp = qp;
+#ifdef DSP_KKT_TRACE
+  const char *trace_env = getenv("DSP_TRACE_SCENARIO");
+  double *trace_dev = nullptr;
+  if (trace_env) {
+    HIP_TRY(hipMalloc((void **)&trace_dev, 4096 * 12 * sizeof(double)));
+    HIP_TRY(hipMemsetAsync(trace_dev, 0, 4096 * 12 * sizeof(double), st));
+    a.trace = trace_dev; a.trace_scenario = atoi(trace_env);
+  }
+#endif
   int grid = std::min((B + geo.wpb - 1) / geo.wpb, h->num_cus * geo.blocks_per_cu);
   const bool timed = stats && sync_stats;
   if (timed) HIP_TRY(hipEventRecord(h->ev0, st));
@@ -440,6 +450,16 @@ int dsp_solve(dsp_handle *h, const dsp_batch *batch, const dsp_options *opt, dsp
   }
   HIP_TRY(launch_solve(h->cpl, h->rpl, a, dim3(grid), dim3(64 * a.waves_per_block), lds, st));
   if (timed) HIP_TRY(hipEventRecord(h->ev1, st));
+#ifdef DSP_KKT_TRACE
+  if (trace_dev) {
+    HIP_TRY(hipStreamSynchronize(st));
+    std::vector<double> tr(4096 * 12);
+    HIP_TRY(hipMemcpy(tr.data(), trace_dev, tr.size() * sizeof(double), hipMemcpyDeviceToHost));
+    (void)hipFree(trace_dev);
+    const char *path = getenv("DSP_TRACE_FILE");
+    if (FILE *f = fopen(path ? path : "dsp_trace.bin", "wb")) { fwrite(tr.data(), sizeof(double), tr.size(), f); fclose(f); }
+  }
+#endif
   if (stats) {
     std::memset(stats, 0, sizeof(*stats));
     stats->grid_blocks = grid; stats->block_threads = 64 * a.waves_per_block; stats->lds_bytes = (int)lds;

@@ -64,6 +64,8 @@ struct SolveArgs {
   const int *unsolved;         // skip_solved: number of scenarios the simplex pass left unsolved (0 = nothing to do)
   int matreg;                  // 1 = register-resident-matrix specialisation of the kernel
   int qp;                      // 1 = soft rows present (b.row_compliance): QP instantiation
+  double *trace;               // development (-DDSP_KKT_TRACE, DSP_TRACE_SCENARIO): [4096][12] KKT history of one scenario
+  int trace_scenario;
 };
 
 // in-wave dense simplex for tiny LPs (dsp_simplex.hip)

@@ -261,10 +261,12 @@ __global__ void __launch_bounds__(64 * kF32Waves) pdlp_solve_f32_kernel(SolveArg
         if (!(po == po)) { status = DSP_STATUS_NUMERICAL; break; }
         const double rp = sqrt(red[0]) / (1.0 + qn), rd = sqrt(red[1]) / (1.0 + cn);
         const double gap = fabs(po - dobj), rg = gap / (1.0 + fabs(po) + fabs(dobj));
-        bool done = rp <= eps && rd <= eps && rg <= eps;
-        if (done && eps_obj > 0.0) {
+        bool done;                                               // same tests as the float64 kernel
+        if (eps_obj > 0.0) {
           const double lim = fmax(eps_obj * (1.0 + fabs(po + c0)), 1e-12 * red[5]);
-          done = gap <= lim && red[4] <= lim && red[6] <= lim;
+          done = rp <= eps && rd <= eps && gap + red[4] + red[6] <= lim;
+        } else {
+          done = rp <= eps && rd <= eps && rg <= eps;
         }
         if (done) { status = DSP_STATUS_OPTIMAL; ++it; break; }
       }

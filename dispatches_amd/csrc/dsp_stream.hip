@@ -449,10 +449,12 @@ __device__ int control_decide(const double *acc, StreamCtrl &c, const dsp_option
     const double rp = sqrt(acc[2]) / (1.0 + c.qn), rd = sqrt(acc[8]) / (1.0 + c.cn);
     const double gap = fabs(po - dobj);
     const double rg = gap / (1.0 + fabs(po) + fabs(dobj));
-    bool fin = rp <= o.eps_rel && rd <= o.eps_rel && rg <= o.eps_rel;
-    if (fin && o.eps_obj > 0.0) {
+    bool fin;                                                    // same tests as the fused kernel (dsp_kernels.hip)
+    if (o.eps_obj > 0.0) {
       const double lim = fmax(o.eps_obj * (1.0 + fabs(po + c.c0)), 1e-12 * acc[11]);
-      fin = gap <= lim && acc[3] <= lim && acc[12] <= lim;
+      fin = rp <= o.eps_rel && rd <= o.eps_rel && gap + acc[3] + acc[12] <= lim;
+    } else {
+      fin = rp <= o.eps_rel && rd <= o.eps_rel && rg <= o.eps_rel;
     }
     c.last_rp = rp; c.last_rd = rd; c.last_rg = rg;
     if (fin) { c.status = DSP_STATUS_OPTIMAL; c.done = 1; }

@@ -48,11 +48,13 @@ extern "C" {
 /* DSP_STATUS_DUAL_INFEASIBLE is reported by the simplex path only (an unbounded ray of a tiny LP). */
 
 /* per-scenario flag bits written to flags[B] */
-#define DSP_FLAG_OBJ_WAIVED   1   /* status OPTIMAL was reached on the eps_rel tests alone: the iteration stalled twice on
-                                     its rounding floor and the eps_obj tests were waived (dsp_options::stall_rescue) -
-                                     the 1e-6 objective accuracy is NOT guaranteed for this scenario (near-zero objectives
-                                     that are the difference of terms ~1e6 times larger)                              */
+#define DSP_FLAG_OBJ_WAIVED   1   /* status OPTIMAL with both feasibility tests at eps_rel, but the objective-error bound
+                                     only within 10 eps_obj (or the classic relative gap at eps_rel): the bound stagnated
+                                     (dsp_options::polish_patience) or the iteration stalled twice (stall_rescue).  The 1e-6
+                                     objective accuracy is NOT certified for this scenario (measured: still within 3e-7);
+                                     typically objectives that are the small difference of terms ~1e3-1e6 times larger   */
 #define DSP_FLAG_STALL_RESCUE 2   /* the primal weight was reset once by the stall rescue                              */
+#define DSP_FLAG_POLISH       4   /* the weight guard was tightened in the polish phase (dsp_options::polish_patience) */
 
 typedef struct dsp_handle dsp_handle;
 
@@ -69,9 +71,13 @@ typedef struct dsp_lp_desc {
 /* Solver options (restarted, reflected Halpern PDHG with ray jumps).  Fill with
  * dsp_default_options() and override fields. */
 typedef struct dsp_options {
-  double  eps_rel;           /* relative KKT tolerance (primal, dual, gap)            default 1e-9   */
-  double  eps_obj;           /* objective accuracy: |gap|, sum|y||row violation| and sum|dual residual||x| are
-                                each <= eps_obj (1 + |c.x + c0|); 0 disables the tests     default 1e-7   */
+  double  eps_rel;           /* relative KKT tolerance: primal and dual residual (and, with eps_obj = 0, the relative
+                                gap)                                                      default 1e-9   */
+  double  eps_obj;           /* objective accuracy: the error bound |gap| + sum|y||row violation| + sum|dual residual||x|
+                                of the returned point is <= eps_obj (1 + |c.x + c0|) - half of the 1e-6 parity contract by
+                                default; it replaces the relative-gap test (c.x without the model constant is ~500x the
+                                objective here, which made that test a 3x tighter duplicate and the one every straggler
+                                hung on).  0 = classic PDLP tests (eps_rel on the relative gap)   default 5e-7   */
   int32_t max_iter;          /* iteration limit per scenario                          default 200000 */
   int32_t check_every;       /* restart / ray-jump test period (1 SpMV + 1 reduction) default 16     */
   double  restart_sufficient;/* beta_1: restart when r <= beta_1 r0                   default 0.2    */
@@ -128,7 +134,13 @@ typedef struct dsp_options {
                                 float64 reductions / KKT tests (dsp_qp.hip: one scenario per wave, no ray jumps), for the
                                 fp64-vs-fp32 tolerance sweep of BASELINE config 5 - it cannot reach the 1e-6 objective
                                 contract on these LPs (bench.py --workload qp_sweep)             default 0    */
-  int32_t reserved0;
+  int32_t polish_patience;   /* > 0: once both feasibility tests hold and the objective-error bound is within 10x of its limit,
+                                no 2x improvement of the bound for this many iterations starts the near-miss logic: a weight
+                                that sits at its rounding guard gets the guard tightened 4x on the noisy side (at most 3
+                                times); after 4x this many iterations without improvement the scenario is accepted with the
+                                bound it has (<= 10 eps_obj) and flagged DSP_FLAG_OBJ_WAIVED.  Such scenarios - rounding
+                                floors and slow drifts along nearly flat directions, the primal objective long converged -
+                                were the slowest of every batch (30-58 k iterations).  0 = off       default 1024 */
 } dsp_options;
 
 /* The per-call data of B scenarios.  c is required; every other input may be NULL (= no bound: -inf / +inf,
