@@ -160,7 +160,7 @@ void dsp_default_options(dsp_options *o) {
   o->eps_rel = 1e-9;
   o->eps_obj = 5e-7;
   o->max_iter = 200000;
-  o->check_every = 16;
+  o->check_every = 0;
   o->kkt_every = 32;
   o->kkt_gate = 16.0;
   o->stall_rescue = 4000;
@@ -346,7 +346,7 @@ int dsp_solve(dsp_handle *h, const dsp_batch *batch, const dsp_options *opt, dsp
   SolveArgs a{};
   a.P = h->P; a.b = *batch;
   a.opt = opt ? *opt : h->opt;
-  if (a.opt.max_iter < 1 || a.opt.check_every < 1 || a.opt.kkt_every < 0 || !(a.opt.kkt_gate >= 0) || a.opt.stall_rescue < 0 || a.opt.polish_patience < 0 || !(a.opt.jump_rel >= 0) || !(a.opt.eps_rel > 0) || !(a.opt.eps_obj >= 0) ||
+  if (a.opt.max_iter < 1 || a.opt.check_every < 0 || a.opt.kkt_every < 0 || !(a.opt.kkt_gate >= 0) || a.opt.stall_rescue < 0 || a.opt.polish_patience < 0 || !(a.opt.jump_rel >= 0) || !(a.opt.eps_rel > 0) || !(a.opt.eps_obj >= 0) ||
       !(a.opt.pid_kp >= 0) || !(a.opt.step_scale > 0))
     return DSP_ERR_INVALID;
   a.eta = a.opt.step_scale * h->eta_unit;

@@ -72,7 +72,7 @@ __global__ void __launch_bounds__(64 * kF32Waves) pdlp_solve_f32_kernel(SolveArg
   float *xbl = reinterpret_cast<float *>(xb) + lane, *ybl = reinterpret_cast<float *>(yb) + lane;
 
   const double eta = a.eta, eps = a.opt.eps_rel, eps_obj = a.opt.eps_obj;
-  const int check_every = a.opt.check_every;
+  const int check_every = a.opt.check_every > 0 ? a.opt.check_every : 16;
   const double beta_s2 = a.opt.restart_sufficient * a.opt.restart_sufficient;
   const double beta_n2 = a.opt.restart_necessary * a.opt.restart_necessary;
   constexpr double kU32 = 5.96e-8;                                      // float32 unit roundoff

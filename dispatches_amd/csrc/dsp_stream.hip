@@ -859,7 +859,7 @@ static hipError_t run(StreamSolver *S, StreamArgs &a, hipStream_t st, int *perio
     else hipLaunchKernelGGL((k_primal<SG, false>), g_primal, blk, 0, st, a);
     if (P.C.nlong) hipLaunchKernelGGL(k_primal_long_finish, dim3(fin_c), dim3(64), 0, st, a, write_xp ? 1 : 0);
   };
-  const int C = std::max(1, a.opt.check_every);
+  const int C = a.opt.check_every > 0 ? a.opt.check_every : 64;       // 0 = automatic (include/dsp_hip.h)
   const int max_periods = (a.opt.max_iter + C - 1) / C;
   const int poll = 4;                                        // check periods between two looks at the finished counter
   int period = 0;

@@ -49,7 +49,7 @@ extern "C" {
 
 /* per-scenario flag bits written to flags[B] */
 #define DSP_FLAG_OBJ_WAIVED   1   /* status OPTIMAL with both feasibility tests at eps_rel, but the objective-error bound
-                                     only within 10 eps_obj (or the classic relative gap at eps_rel): the bound stagnated
+                                     only within 10 eps_obj (or the classic relative gap at eps_rel): bound AND objective stagnated
                                      (dsp_options::polish_patience) or the iteration stalled twice (stall_rescue).  The 1e-6
                                      objective accuracy is NOT certified for this scenario (measured: still within 3e-7);
                                      typically objectives that are the small difference of terms ~1e3-1e6 times larger   */
@@ -79,7 +79,9 @@ typedef struct dsp_options {
                                 objective here, which made that test a 3x tighter duplicate and the one every straggler
                                 hung on).  0 = classic PDLP tests (eps_rel on the relative gap)   default 5e-7   */
   int32_t max_iter;          /* iteration limit per scenario                          default 200000 */
-  int32_t check_every;       /* restart / ray-jump test period (1 SpMV + 1 reduction) default 16     */
+  int32_t check_every;       /* restart / ray-jump test period (1 SpMV + 1 reduction); 0 = automatic: 16, or 32 for LPs with
+                                more than 8 owned elements per lane in the fused kernel (their check path spills), 64 on the
+                                streaming path                                            default 0      */
   double  restart_sufficient;/* beta_1: restart when r <= beta_1 r0                   default 0.2    */
   double  restart_necessary; /* beta_2: ... or r <= beta_2 r0 and r increased         default 0.8    */
   double  restart_artificial;/* beta_3: ... or k >= beta_3 * total iterations         default 0.36   */
@@ -137,8 +139,8 @@ typedef struct dsp_options {
   int32_t polish_patience;   /* > 0: once both feasibility tests hold and the objective-error bound is within 10x of its limit,
                                 no 2x improvement of the bound for this many iterations starts the near-miss logic: a weight
                                 that sits at its rounding guard gets the guard tightened 4x on the noisy side (at most 3
-                                times); after 4x this many iterations without improvement the scenario is accepted with the
-                                bound it has (<= 10 eps_obj) and flagged DSP_FLAG_OBJ_WAIVED.  Such scenarios - rounding
+                                times); after 4x this many iterations without improvement a scenario whose primal objective
+                                has not moved by more than eps_obj / 10 either is accepted and flagged DSP_FLAG_OBJ_WAIVED.  Such scenarios - rounding
                                 floors and slow drifts along nearly flat directions, the primal objective long converged -
                                 were the slowest of every batch (30-58 k iterations).  0 = off       default 1024 */
 } dsp_options;

@@ -43,7 +43,7 @@ def test_binding_mirrors_the_header(lib):
 def test_default_options(lib):
     from dispatches_amd import hip_solver
     o = hip_solver.default_options()
-    assert o.eps_rel == 1e-9 and o.eps_obj == 5e-7 and o.check_every == 16 and o.max_iter == 200000
+    assert o.eps_rel == 1e-9 and o.eps_obj == 5e-7 and o.check_every == 0 and o.max_iter == 200000
     assert o.precision == 0 and o.polish_patience == 1024
     assert o.kkt_every == 32 and o.kkt_gate == 16.0 and o.stall_rescue == 4000 and o.jump_rel == 3.0
     with pytest.raises(TypeError):

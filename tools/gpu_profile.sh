@@ -3,11 +3,14 @@
 #   1. bench.py (full default run)                          -> gpurun_out/<tag>_bench.json
 #   2. rocprofv3 --kernel-trace --stats of the same command -> gpurun_out/<tag>_kernel_stats.csv
 #   3. rocprofv3 --pmc passes (own runs, no trace domains)  -> gpurun_out/<tag>_pmc_summary.csv (mean per dispatch)
+#   optional 2nd argument: another bench workload (e.g. wind_battery_48h), profiled with --no-spmv
 tag=${1:-prof}
+wl=${2:-}
 repo="$(cd "$(dirname "$0")/.." && pwd)"
 out="$repo/gpurun_out"; mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp
 bench="python $repo/bench.py"
+[ -n "$wl" ] && bench="python $repo/bench.py --workload $wl --no-spmv"
 $bench > "$out/${tag}_bench.json" 2> "$out/${tag}_bench.err"
 tail -c 600 "$out/${tag}_bench.json"; echo
 rm -rf /tmp/prof_trace; timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_trace -- $bench --cpu-sample 0 > /dev/null 2>&1
