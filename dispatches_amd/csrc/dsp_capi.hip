@@ -285,7 +285,8 @@ int dsp_create(const dsp_lp_desc *d, int device, const dsp_options *opt, dsp_han
   SlotELL Scu = build_slot_ell(ATu, Lc, Lr, Ec.long_owner, pad_w), Sru = build_slot_ell(Au, Lr, Lc, Er.long_owner, pad_w);
   // bank-conflict-minimising slot permutation of each exchange buffer: the y buffer is gathered by the A^T entries
   // (Sc), the x buffer by the A entries (Sr)
-  SlotMap My = optimise_slots(Sc, P.m_pad), Mx = optimise_slots(Sr, P.n_pad);
+  const bool shared_slots = shared_slot_maps(cpl, rpl);
+  SlotMap My = optimise_slots(Sc, P.m_pad, 4000, shared_slots), Mx = optimise_slots(Sr, P.n_pad, 4000, shared_slots);
   h->lds_conflicts[0] = My.cost_identity; h->lds_conflicts[1] = My.cost_final;
   h->lds_conflicts[2] = Mx.cost_identity; h->lds_conflicts[3] = Mx.cost_final;
   apply_slots(Sc, My.slot);

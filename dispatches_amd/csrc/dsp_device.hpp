@@ -5,6 +5,7 @@
 #include <cstdint>
 
 #include "../../include/dsp_hip.h"
+#include "dsp_shapes.hpp"
 
 namespace dsp {
 

@@ -200,16 +200,32 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
   // LDS byte addresses of this lane's own elements in the exchange buffers (permuted slots: dsp_prepare.hpp, optimise_slots)
   using lds_cptr = const __attribute__((address_space(3))) char *;
   const uint32_t xb_lds = (uint32_t)(uintptr_t)(lds_cptr)xb, yb_lds = (uint32_t)(uintptr_t)(lds_cptr)yb;
+  // SHARED (shapes with more than 8 owned elements per lane): the host built the same slot map for every 64-position block,
+  // so ONE address register per buffer + the compile-time offsets 512 q serve all owned elements (the stores pair up into
+  // ds_write2_b64); with one address VGPR per element the 48-h kernel reloaded three of them from scratch EVERY iteration
+  // (768 B per scenario-iteration: 12 GB of fetches per 4096-scenario launch, profiles/r03c48_pmc_summary.csv).
+  constexpr bool SHARED = MATREG && shared_slot_maps(CPL, RPL);
   uint32_t xw[CPL], yw[RPL];
+  if constexpr (SHARED) {
+    xw[0] = xb_lds + 8u * (uint32_t)P.mr_slot_x[lane];
+    yw[0] = yb_lds + 8u * (uint32_t)P.mr_slot_y[lane];
+    asm volatile("" : "+v"(xw[0]));
+    asm volatile("" : "+v"(yw[0]));
 #pragma unroll
-  for (int q = 0; q < CPL; ++q) {
-    xw[q] = xb_lds + 8u * (uint32_t)(MATREG ? P.mr_slot_x[lane + 64 * q] : lane + 64 * q);
-    asm volatile("" : "+v"(xw[q]));                // opaque: keeps the address in a VGPR instead of re-adding it per store
-  }
+    for (int q = 1; q < CPL; ++q) xw[q] = xw[0] + 512u * q;
 #pragma unroll
-  for (int q = 0; q < RPL; ++q) {
-    yw[q] = yb_lds + 8u * (uint32_t)(MATREG ? P.mr_slot_y[lane + 64 * q] : lane + 64 * q);
-    asm volatile("" : "+v"(yw[q]));
+    for (int q = 1; q < RPL; ++q) yw[q] = yw[0] + 512u * q;
+  } else {
+#pragma unroll
+    for (int q = 0; q < CPL; ++q) {
+      xw[q] = xb_lds + 8u * (uint32_t)(MATREG ? P.mr_slot_x[lane + 64 * q] : lane + 64 * q);
+      asm volatile("" : "+v"(xw[q]));                // opaque: keeps the address in a VGPR instead of re-adding it per store
+    }
+#pragma unroll
+    for (int q = 0; q < RPL; ++q) {
+      yw[q] = yb_lds + 8u * (uint32_t)(MATREG ? P.mr_slot_y[lane + 64 * q] : lane + 64 * q);
+      asm volatile("" : "+v"(yw[q]));
+    }
   }
   RegEll<CPL, WC> mreg_c;                                                // tau A^T, gathers y from yb   } loaded per
   RegEll<RPL, WR> mreg_r;                                                // -sig A, gathers x from xb    } scenario / weight

@@ -14,6 +14,8 @@
 #include <numeric>
 #include <vector>
 
+#include "dsp_shapes.hpp"
+
 namespace dsp {
 
 struct HostCSR {
@@ -304,7 +306,11 @@ struct SlotMap {
   int cost_identity = 0, cost_rotation = 0, cost_final = 0;
 };
 
-inline SlotMap optimise_slots(const SlotELL &E, int npad, int sweeps = 4000) {
+// shared = true: every 64-position block gets the SAME map, slot(p + 64 q) = slot(p) + 64 q.  A lane's store addresses in an
+// exchange buffer are then ONE register + compile-time offsets 512 q (and pair up into ds_write2_b64) instead of one address
+// register per owned element - for the shapes with 11 owned elements per lane (48-h wind+battery) those registers were
+// the difference between a spill-free hot loop and three scratch reloads per iteration.
+inline SlotMap optimise_slots(const SlotELL &E, int npad, int sweeps = 4000, bool shared = false) {
   SlotMap M;
   M.slot.resize((size_t)npad);
   for (int p = 0; p < npad; ++p) M.slot[p] = p;
@@ -312,7 +318,9 @@ inline SlotMap optimise_slots(const SlotELL &E, int npad, int sweeps = 4000) {
   std::vector<int32_t> trial((size_t)npad);
   int best = M.cost_identity;
   for (uint32_t r = 1; r < 32; ++r) {
-    for (int p = 0; p < npad; ++p) trial[p] = (int32_t)rotation_slot((uint32_t)p, r);
+    for (int p = 0; p < npad; ++p)
+      trial[p] = shared ? (int32_t)(((uint32_t)p & ~31u) | (((uint32_t)p + r * (((uint32_t)p >> 5) & 1u)) & 31u))
+                        : (int32_t)rotation_slot((uint32_t)p, r);
     int c = gather_conflicts(E, trial);
     if (c < best) { best = c; M.slot = trial; }
   }
@@ -321,14 +329,22 @@ inline SlotMap optimise_slots(const SlotELL &E, int npad, int sweeps = 4000) {
   auto next = [&rng]() { rng = rng * 6364136223846793005ull + 1442695040888963407ull; return (uint32_t)(rng >> 33); };
   const int blocks = npad / 32;
   for (int it = 0; it < sweeps && best > 0; ++it) {
-    const int b = (int)(next() % (uint32_t)blocks), i = (int)(next() & 31u), j = (int)(next() & 31u);
+    const int b = (int)(next() % (uint32_t)(shared ? 2 : blocks)), i = (int)(next() & 31u), j = (int)(next() & 31u);
     if (i == j) continue;
     // store-safe moves only: same 16-lane group, or slots congruent mod 16
     if ((i >> 4) != (j >> 4) && ((M.slot[b * 32 + i] ^ M.slot[b * 32 + j]) & 15) != 0) continue;
-    std::swap(M.slot[b * 32 + i], M.slot[b * 32 + j]);
+    auto swap_all = [&]() {
+      if (!shared) { std::swap(M.slot[b * 32 + i], M.slot[b * 32 + j]); return; }
+      for (int bb = b; bb < blocks; bb += 2) {                  // the same swap in every 64-block: only the low 5 bits move
+        const int32_t si = M.slot[bb * 32 + i], sj = M.slot[bb * 32 + j];
+        M.slot[bb * 32 + i] = (si & ~31) | (sj & 31);
+        M.slot[bb * 32 + j] = (sj & ~31) | (si & 31);
+      }
+    };
+    swap_all();
     int c = gather_conflicts(E, M.slot);
     if (c <= best) best = c;
-    else std::swap(M.slot[b * 32 + i], M.slot[b * 32 + j]);
+    else swap_all();
   }
   M.cost_final = best;
   return M;

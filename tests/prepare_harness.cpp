@@ -62,7 +62,8 @@ int main(int argc, char **argv) {
   SortedLayout Lc = sorted_layout(AT, cpl, Ec.long_owner), Lr = sorted_layout(A, rpl, Er.long_owner);
   SlotELL Sc = build_slot_ell(AT, Lc, Lr, Ec.long_owner), Sr = build_slot_ell(A, Lr, Lc, Er.long_owner);
   auto t0 = std::chrono::steady_clock::now();
-  SlotMap My = optimise_slots(Sc, rpl * 64), Mx = optimise_slots(Sr, cpl * 64);
+  const bool shared = shared_slot_maps(cpl, rpl);
+  SlotMap My = optimise_slots(Sc, rpl * 64, 4000, shared), Mx = optimise_slots(Sr, cpl * 64, 4000, shared);
   double search_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   apply_slots(Sc, My.slot);
   apply_slots(Sr, Mx.slot);
@@ -84,6 +85,12 @@ int main(int argc, char **argv) {
       }
     }
   }
+  // shared maps (shapes with more than 8 owned elements per lane): the same map in every 64-position block
+  int bad_shared = 0;
+  if (shared)
+    for (const SlotMap *M : {&Mx, &My})
+      for (size_t p = 64; p < M->slot.size(); ++p)
+        if (M->slot[p] != M->slot[p & 63] + (int32_t)(p & ~(size_t)63)) bad_shared++;
   // the layouts compute the same products as the CSR
   std::vector<double> x(A.n), y(A.m);
   for (int j = 0; j < A.n; ++j) x[j] = std::sin(0.37 * j + 1.0);
@@ -102,9 +109,10 @@ int main(int argc, char **argv) {
   }
   printf("{\"scale_err\": %.3e, \"norm2\": %.15g, \"product_err\": %.3e, \"bad_perm\": %d, \"bad_store\": %d, "
          "\"conflicts_y\": [%d, %d, %d], \"conflicts_x\": [%d, %d, %d], \"search_ms\": %.1f, \"pack_c\": %u, \"pack_r\": %u, "
-         "\"long_c\": %zu, \"long_r\": %zu}\n",
+         "\"long_c\": %zu, \"long_r\": %zu, \"shared\": %d, \"bad_shared\": %d}\n",
          scale_err, norm2, err, bad_perm, bad_store, My.cost_identity, My.cost_rotation, My.cost_final, Mx.cost_identity,
-         Mx.cost_rotation, Mx.cost_final, search_ms, Sc.pack, Sr.pack, Sc.long_owner_pos.size(), Sr.long_owner_pos.size());
+         Mx.cost_rotation, Mx.cost_final, search_ms, Sc.pack, Sr.pack, Sc.long_owner_pos.size(), Sr.long_owner_pos.size(), (int)shared,
+         bad_shared);
   // the scaling vectors for the python side
   for (double d : dr) printf("%.17g ", d);
   printf("\n");

@@ -67,6 +67,8 @@ def test_preparation_of_the_dispatch_lps(harness, workload, tmp_path):
     assert res["product_err"] < 1e-12
     # slot maps: permutations within 32-slot blocks whose 16-lane store groups stay conflict-free
     assert res["bad_perm"] == 0 and res["bad_store"] == 0
+    # 11 owned elements per lane (48 h): the kernel takes ONE store address per buffer, so every 64-block has the same map
+    assert res["shared"] == (workload == "wind_battery_48h") and res["bad_shared"] == 0
     for key in ("conflicts_x", "conflicts_y"):
         ident, rot, final = res[key]
         assert final <= rot <= ident
