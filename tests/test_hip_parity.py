@@ -389,10 +389,11 @@ def test_kkt_gate_only_moves_the_stopping_time():
 @gpu
 def test_other_price_series_and_near_zero_objectives():
     """Data the defaults were not tuned on: wind+battery bidding on the bus-303 series (windows every 37 h).  The whole
-    batch must reach status optimal.  Scenario 1217 is a near-zero-price day: its objective (2.82 $) is the difference
-    of terms 1.6e5 times larger, so eps_obj cannot be reached in double precision; it stalls on the rounding floor and
-    terminates through the stall logic on the eps_rel tests alone.  Parity against the oracle is therefore asserted
-    scale-aware: 1e-6 max(1, |obj|) + 2e-10 sum |c_j x_j|."""
+    batch must reach status optimal and every scenario the solver does not FLAG must be within plain 1e-6 of the oracle.
+    Scenario 1217 is a near-zero-price day: its objective (2.82 $) is the difference of terms 1.6e5 times larger (sum |c_j x_j|
+    = 4.6e5 $); the solver's error bound stagnates there, it is accepted through the stall logic and flagged
+    (DSP_FLAG_OBJ_WAIVED), and lands 5.7e-6 $ = 2.0e-6 relative from the oracle - 1.2e-11 of the scale of its terms, below what
+    the oracle's own 1e-9 feasibility tolerance resolves.  Flagged scenarios are asserted scale-aware."""
     from dispatches_amd import scenarios
     from oracle import dispatch_lp_oracle as orc
     solver = _solver()
@@ -401,16 +402,22 @@ def test_other_price_series_and_near_zero_objectives():
     solver.solve(model)
     assert (model.status == 0).all(), np.nonzero(model.status)[0]
     assert model.iterations[1217] < 40000
+    flagged = (model.flags & 1) != 0
+    assert flagged.sum() <= 8, int(flagged.sum())
     s = scenarios.load_series("rts_gmlc_303.npz")
     N, T = len(s["rt_lmp"]), 24
-    ids = [1217] + list(range(0, 4096, 293))
+    ids = sorted(set([1217] + list(range(0, 4096, 293)) + np.nonzero(flagged)[0].tolist()))
     for k in ids:
         h0 = (37 * k) % (N - T)
         P, *_ = orc.wind_battery_da(T, s["rt_cf"][h0:h0 + T], np.clip(s["da_lmp"][h0:h0 + T], 0, 500),
                                     np.clip(s["rt_lmp"][h0:h0 + T], 0, 500))
         ref = P.solve(tight=True)[1]
-        scale = float(np.abs(model.c[k] * model.x[k]).sum())
-        assert abs(model.objective[k] - ref) <= 1e-6 * max(1.0, abs(ref)) + 2e-10 * scale, (k, model.objective[k], ref, scale)
+        err = abs(model.objective[k] - ref)
+        if flagged[k]:
+            scale = float(np.abs(model.c[k] * model.x[k]).sum())
+            assert err <= 1e-6 * max(1.0, abs(ref)) + 2e-10 * scale and err <= 1e-5 * max(1.0, abs(ref)), (k, model.objective[k], ref, scale)
+        else:
+            assert err <= 1e-6 * max(1.0, abs(ref)), (k, model.objective[k], ref)
 
 
 @gpu
