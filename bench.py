@@ -612,24 +612,59 @@ def main():
                 ATY = torch.empty((Bs, lp.n), dtype=torch.float64, device=dev)
                 for _ in range(5):
                     dlp.spmv_step(X, Y, AX, ATY)
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                for _ in range(reps):
-                    dlp.spmv_step(X, Y, AX, ATY)
-                e1.record()
                 torch.cuda.synchronize()
-                ms = e0.elapsed_time(e1) / reps
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                # The launches are replayed from a hipGraph (50 per graph) and timed with events on the replay stream: a
+                # 6-10 us kernel issued from Python through ctypes is HOST-bound (~5-8 us per call), which is not what this
+                # figure is about - the streaming solver enqueues its sweeps the same way.  The plain loop is
+                # the fallback if the capture fails.
+                ms, how = None, "hipGraph replay of 50 back-to-back launches, events on the replay stream"
+                try:
+                    per_graph = min(50, reps)
+                    side = torch.cuda.Stream(device=dev)
+                    graph = torch.cuda.CUDAGraph()
+                    with torch.cuda.stream(side):
+                        dlp.spmv_step(X, Y, AX, ATY)
+                        side.synchronize()
+                        graph.capture_begin()
+                        for _ in range(per_graph):
+                            dlp.spmv_step(X, Y, AX, ATY)
+                        graph.capture_end()
+                    torch.cuda.synchronize()
+                    graph.replay()
+                    torch.cuda.synchronize()
+                    n_rep = max(1, reps // per_graph)
+                    best = None
+                    for _ in range(3):
+                        e0.record()
+                        for _ in range(n_rep):
+                            graph.replay()
+                        e1.record()
+                        torch.cuda.synchronize()
+                        t = e0.elapsed_time(e1) / (n_rep * per_graph)
+                        best = t if best is None else min(best, t)
+                    ms = best
+                except Exception as exc:                      # noqa: BLE001
+                    how = f"plain launch loop (graph capture failed: {type(exc).__name__})"
+                if ms is None:
+                    e0.record()
+                    for _ in range(reps):
+                        dlp.spmv_step(X, Y, AX, ATY)
+                    e1.record()
+                    torch.cuda.synchronize()
+                    ms = e0.elapsed_time(e1) / reps
                 bsp = Bs * 2 * w * (lp.n + lp.m) + 2 * (lp.nnz * (w + 4) + 4 * (lp.m + 1))
                 return dict(bound="hbm", kernel="spmv_step_kernel", batch=Bs, achieved=bsp / (ms * 1e-3) / 1e9,
                             peak=HBM_PEAK_GBS, unit="GB/s", frac=bsp / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                            traffic=None, kernel_ms=ms, algorithmic_bytes_per_launch=bsp)
+                            traffic=None, kernel_ms=ms, algorithmic_bytes_per_launch=bsp, timing=how)
 
             result["spmv_step"] = time_spmv(dlp, lp, B, 200)
             result["spmv_step"]["traffic"] = _profiled_traffic("spmv_stream_kernel") or _profiled_traffic("spmv_step_kernel")
             result["spmv_step"]["note"] = ("one A x + one A^T y for every scenario of the batch with vectors streamed "
-                                           "from/to HBM (register-resident matrix, one scenario per wave, everything in "
-                                           "flight at once); events on the launch stream, back-to-back launches; a "
-                                           "20-40 MB launch is bound by one memory round trip + the launch ramp")
+                                           "from/to HBM, results through non-temporal stores (matrix staged in LDS per 8-wave "
+                                           "block, one scenario per wave, everything in flight at once); a 20 MB launch "
+                                           "is bound by one memory round trip + the dispatch ramp - the BASELINE.md "
+                                           "section 3 configuration (T = 48, 41 MB) is spmv_step_T48_B4096")
             # the same kernel on a batch large enough to be bandwidth bound (0.67 GB per launch, beyond L2 + MALL)
             if args.spmv_large_mult > 0:
                 result["spmv_step_large_batch"] = time_spmv(dlp, lp, args.spmv_large_mult * B, 20)

@@ -510,7 +510,8 @@ int dsp_spmv_step(dsp_handle *h, int32_t B, const double *X, const double *Y, do
     return DSP_OK;
   }
   // generic form (matrix staged in LDS per block): 8-wave blocks, as many as LDS admits per CU
-  a.waves_per_block = wpb_env > 0 ? std::min(wpb_env, kMaxWavesPerBlock) : kMaxWavesPerBlock;
+  constexpr int kSpmvMaxWaves = 16;                 // spmv_step_kernel is compiled with __launch_bounds__(1024)
+  a.waves_per_block = wpb_env > 0 ? std::min(wpb_env, kSpmvMaxWaves) : kMaxWavesPerBlock;
   size_t lds = lds_bytes(h->P, a.waves_per_block);
   while (lds > (size_t)h->lds_limit && a.waves_per_block > 1) lds = lds_bytes(h->P, --a.waves_per_block);
   if (lds > (size_t)h->lds_limit) return DSP_ERR_TOO_LARGE;

@@ -833,9 +833,13 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
 // ---- streaming SpMV step: AX = A X, ATY = A^T Y with vectors in HBM --------------------------------------
 // One scenario per wave; the (unscaled) ELL matrix is staged into LDS once per workgroup; each wave streams its
 // x (coalesced) into its LDS exchange buffer, forms the row products from LDS and writes them coalesced.
-// Algorithmic HBM bytes per scenario: 2*8*(n+m)  (read x,y; write Ax, A^T y).
+// Algorithmic HBM bytes per scenario: 2*8*(n+m)  (read x,y; write Ax, A^T y).  The results are written once and never read
+// back by this kernel: NON-TEMPORAL stores (no L2 write-allocate).  BASELINE.md section 3 configuration (T = 48, B = 4096,
+// 41 MB): 10.4 -> 8.8 us = 4.66 TB/s = 58 % of the 8 TB/s peak (target <= 10.2 us); metric batch (T = 24, 20.6 MB) 6.3 -> 5.8
+// us = 44 %; 131 072 scenarios 60 -> 66 % (T = 24), 70 -> 72 % (T = 48).  Non-temporal LOADS as well were measured worse
+// (48 h: 9.3 us), 16-wave blocks (half the matrix staging) gain nothing on top (profiles/r03k, r03l, r03n_spmv_*.log).
 template <int CPL, int RPL, bool LONG>
-__global__ void __launch_bounds__(512) spmv_step_kernel(SpmvArgs a) {
+__global__ void __launch_bounds__(1024) spmv_step_kernel(SpmvArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const DeviceProblem &P = a.P;
   const int lane = threadIdx.x & 63;
@@ -883,9 +887,9 @@ __global__ void __launch_bounds__(512) spmv_step_kernel(SpmvArgs a) {
     ell_product<RPL, LONG>(axv, ellr, P.Wr, xb, lane, P.long_r, tailr);
     ell_product<CPL, LONG>(atyv, ellc, P.Wc, yb, lane, P.long_c, tailc);
 #pragma unroll
-    for (int q = 0; q < RPL; ++q) { const int i = lane + 64 * q; if (i < m) a.AX[(size_t)s * m + i] = axv[q]; }
+    for (int q = 0; q < RPL; ++q) { const int i = lane + 64 * q; if (i < m) __builtin_nontemporal_store(axv[q], &a.AX[(size_t)s * m + i]); }
 #pragma unroll
-    for (int q = 0; q < CPL; ++q) { const int j = lane + 64 * q; if (j < n) a.ATY[(size_t)s * n + j] = atyv[q]; }
+    for (int q = 0; q < CPL; ++q) { const int j = lane + 64 * q; if (j < n) __builtin_nontemporal_store(atyv[q], &a.ATY[(size_t)s * n + j]); }
     wave_lds_fence();
   }
 }
