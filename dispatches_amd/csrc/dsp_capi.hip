@@ -11,6 +11,7 @@
 
 #include "dsp_device.hpp"
 #include "dsp_prepare.hpp"
+#include "dsp_rtc.hpp"
 #include "dsp_stream.hpp"
 
 using namespace dsp;
@@ -49,6 +50,11 @@ struct dsp_handle {
   Geometry geo[2];
   int matreg = 0;                 // register-resident-matrix kernel available for this shape
   int matreg_qp = 0;              // ... and its QP instantiation
+  // run-time compiled specialisation (dsp_rtc.hpp) for shapes without an ahead-of-time one: [0] LP, [1] QP instantiation
+  RtcKernel rtc[2];
+  int rtc_state[2] = {0, 0};      // 0 = not applicable, 1 = loaded, -1 = to be compiled at the first solve that needs it
+  bool rtc_long = false;
+  std::string rtc_why;            // why run-time compilation was not possible (dsp_rtc_last_message)
   int simplex = 0;                // tiny LP: the in-wave dense simplex runs first (dsp_simplex.hip)
   const double *A_dense = nullptr;   // [m][n] scaled matrix, row-major (simplex only)
   int sx_row_stride = 0;
@@ -134,7 +140,9 @@ static int solve_geometry(dsp_handle *h, int requested, int B, Geometry *g, int 
       size_t l = lds_bytes(h->P, wpb, matreg);
       if (l > (size_t)h->lds_limit) continue;
       int nb = 0;
-      hipError_t e = occupancy_solve(h->cpl, h->rpl, probe, 64 * wpb, l, &nb);
+      hipError_t e = h->rtc_state[qp] == 1
+                         ? hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&nb, h->rtc[qp].fn, 64 * wpb, l)
+                         : occupancy_solve(h->cpl, h->rpl, probe, 64 * wpb, l, &nb);
       if (e != hipSuccess) { g_last_hip_error = (int)e; return DSP_ERR_HIP; }
       if (nb * wpb > best_waves) { best_waves = nb * wpb; best.wpb = wpb; best.blocks_per_cu = nb; best.lds = l; }
     }
@@ -181,6 +189,7 @@ void dsp_default_options(dsp_options *o) {
   o->waves_per_block = 0;
   o->precision = 0;
   o->polish_patience = 1024;
+  o->no_rtc = 0;
 }
 
 int dsp_version(void) { return DSP_VERSION; }
@@ -269,8 +278,21 @@ int dsp_create(const dsp_lp_desc *d, int device, const dsp_options *opt, dsp_han
   SlotELL Sc = build_slot_ell(AT, Lc, Lr, Ec.long_owner), Sr = build_slot_ell(A, Lr, Lc, Er.long_owner);
   const bool has_long = P.long_c.count > 0 || P.long_r.count > 0;
   int pad_w = 0;
-  if (!h->opt.no_matreg && !matreg_available(cpl, rpl, Sc.pack, Sr.pack, has_long) &&
-      !matreg_available(cpl, rpl, Sc.pack, Sr.pack, has_long, true)) {
+  // no ahead-of-time specialisation for this shape: compile the tight one now (hiprtc, disk-cached).  Limits: RegEll packs
+  // at most 8 slots of width <= 15, and beyond ~32 register-resident entries per lane the kernel would live in scratch.
+  const bool aot_lp = matreg_available(cpl, rpl, Sc.pack, Sr.pack, has_long) != 0;
+  const bool aot_qp = matreg_available(cpl, rpl, Sc.pack, Sr.pack, has_long, true) != 0;
+  bool rtc_ok = false;
+  if (!h->opt.no_matreg && !h->opt.no_rtc && !aot_lp && cpl <= 8 && rpl <= 8 && Sc.total + Sr.total <= 32) {
+    bool wide = false;
+    for (int q = 0; q < Sc.slots; ++q) wide |= Sc.width[q] > 15;
+    for (int q = 0; q < Sr.slots; ++q) wide |= Sr.width[q] > 15;
+    if (!wide) {
+      rtc_ok = rtc_get_kernel(device, cpl, rpl, has_long, Sc.pack, Sr.pack, false, &h->rtc[0], &h->rtc_why);
+      if (rtc_ok) { h->rtc_state[0] = 1; h->rtc_long = has_long; if (!aot_qp && !has_long) h->rtc_state[1] = -1; }
+    }
+  }
+  if (!h->opt.no_matreg && !aot_lp && !aot_qp && !rtc_ok) {
     // no tight specialisation for this shape: the PADDED one (every slot kPadWidth wide) if the LP fits it
     int wmax = 0;
     for (int q = 0; q < Sc.slots; ++q) wmax = std::max(wmax, Sc.width[q]);
@@ -300,7 +322,7 @@ int dsp_create(const dsp_lp_desc *d, int device, const dsp_options *opt, dsp_han
   P.mr_wc_pack = Sc.pack; P.mr_wr_pack = Sr.pack;
   P.mr_tailc_entries = (int)Sc.tail_val.size(); P.mr_tailr_entries = (int)Sr.tail_val.size();
   if ((rc = fill_long(P.mr_long_c, Sc)) || (rc = fill_long(P.mr_long_r, Sr))) { delete h; return rc; }
-  h->matreg = h->opt.no_matreg ? 0 : matreg_available(cpl, rpl, Sc.pack, Sr.pack, P.long_c.count > 0 || P.long_r.count > 0);
+  h->matreg = h->opt.no_matreg ? 0 : (rtc_ok ? 1 : matreg_available(cpl, rpl, Sc.pack, Sr.pack, P.long_c.count > 0 || P.long_r.count > 0));
   h->matreg_qp = h->opt.no_matreg ? 0 : matreg_available(cpl, rpl, Sc.pack, Sr.pack, P.long_c.count > 0 || P.long_r.count > 0, true);
   std::vector<Entry> pk;
 #define UPE(val, idx, field) pack_entries(val, idx, pk); if ((rc = upload(h, pk, &P.field)) != DSP_OK) { dsp_destroy(h); return rc; }
@@ -411,6 +433,11 @@ int dsp_solve(dsp_handle *h, const dsp_batch *batch, const dsp_options *opt, dsp
     }
     return DSP_OK;
   }
+  if (qp && h->rtc_state[1] == -1) {
+    // first QP solve on a run-time specialised shape: compile its QP instantiation (the layout is the tight one already)
+    h->rtc_state[1] = rtc_get_kernel(h->device, h->cpl, h->rpl, false, h->P.mr_wc_pack, h->P.mr_wr_pack, true, &h->rtc[1], &h->rtc_why) ? 1 : 0;
+    if (h->rtc_state[1] == 1) h->matreg_qp = 1;
+  }
   Geometry geo;
   int grc = solve_geometry(h, a.opt.waves_per_block, B, &geo, qp);
   if (grc != DSP_OK) return grc;
@@ -449,7 +476,13 @@ int dsp_solve(dsp_handle *h, const dsp_batch *batch, const dsp_options *opt, dsp
     HIP_TRY(launch_simplex(sa, sgrid, h->sx_lds, st));
     a.skip_solved = 1;
   }
-  HIP_TRY(launch_solve(h->cpl, h->rpl, a, dim3(grid), dim3(64 * a.waves_per_block), lds, st));
+  if (h->rtc_state[qp] == 1 && a.matreg) {
+    size_t arg_size = sizeof(a);
+    void *config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &arg_size, HIP_LAUNCH_PARAM_END};
+    HIP_TRY(hipModuleLaunchKernel(h->rtc[qp].fn, grid, 1, 1, 64 * a.waves_per_block, 1, 1, (unsigned)lds, st, nullptr, config));
+  } else {
+    HIP_TRY(launch_solve(h->cpl, h->rpl, a, dim3(grid), dim3(64 * a.waves_per_block), lds, st));
+  }
   if (timed) HIP_TRY(hipEventRecord(h->ev1, st));
 #ifdef DSP_KKT_TRACE
   if (trace_dev) {
@@ -466,6 +499,7 @@ int dsp_solve(dsp_handle *h, const dsp_batch *batch, const dsp_options *opt, dsp
     stats->grid_blocks = grid; stats->block_threads = 64 * a.waves_per_block; stats->lds_bytes = (int)lds;
     stats->cols_per_lane = h->cpl; stats->rows_per_lane = h->rpl; stats->matreg = a.matreg; stats->simplex = h->simplex && !qp;
     stats->quadratic = qp;
+    stats->rtc = (h->rtc_state[qp] == 1 && a.matreg) ? 1 : 0;
     stats->lds_conflicts_identity = h->lds_conflicts[0] + h->lds_conflicts[2];
     stats->lds_conflicts_chosen = a.matreg ? h->lds_conflicts[1] + h->lds_conflicts[3] : stats->lds_conflicts_identity;
     if (sync_stats) {
@@ -520,6 +554,19 @@ int dsp_spmv_step(dsp_handle *h, int32_t B, const double *X, const double *Y, do
   HIP_TRY(launch_spmv(h->cpl, h->rpl, a, dim3(grid), dim3(64 * a.waves_per_block), lds, (hipStream_t)hipStream));
   return DSP_OK;
 }
+
+/* Development / test hook: compile (or fetch from the cache) the run-time specialisation of one shape WITHOUT a GPU.
+ * Returns the code-object size in bytes, or 0 with the reason in msg. */
+int dsp_rtc_compile_check(int cpl, int rpl, int has_long, unsigned wc_pack, unsigned wr_pack, int qp, char *msg, int msg_len) {
+  std::vector<char> code;
+  std::string name, why;
+  const bool ok = rtc_build_code(cpl, rpl, has_long != 0, wc_pack, wr_pack, qp != 0, &code, &name, &why);
+  if (msg && msg_len > 0) { std::snprintf(msg, (size_t)msg_len, "%s", ok ? name.c_str() : why.c_str()); }
+  return ok ? (int)code.size() : 0;
+}
+
+/* Why the last dsp_create on this handle could not (or did not need to) compile at run time; "" if it did. */
+const char *dsp_rtc_message(const dsp_handle *h) { return h ? h->rtc_why.c_str() : ""; }
 
 int dsp_get_dims(const dsp_handle *h, int32_t *n, int32_t *m, int64_t *nnz) {
   if (!h) return DSP_ERR_INVALID;

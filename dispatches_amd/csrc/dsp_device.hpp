@@ -1,8 +1,23 @@
 // dsp_device.hpp — plain structs shared by the kernels (dsp_kernels.hip) and the C ABI (dsp_capi.hip).
 #pragma once
+#ifdef __HIPCC_RTC__     /* run-time compilation (hiprtc, dsp_rtc.cpp): no system headers, the HIP device API is built in */
+#ifndef DSP_RTC_TYPES
+#define DSP_RTC_TYPES
+typedef signed char int8_t; typedef unsigned char uint8_t; typedef short int16_t; typedef unsigned short uint16_t;
+typedef int int32_t; typedef unsigned int uint32_t; typedef long long int64_t; typedef unsigned long long uint64_t;
+typedef unsigned long uintptr_t; typedef unsigned long size_t;
+#ifndef INFINITY
+#define INFINITY (__builtin_inff())
+#endif
+#ifndef NAN
+#define NAN (__builtin_nanf(""))
+#endif
+#endif
+#else
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#endif
 
 #include "../../include/dsp_hip.h"
 #include "dsp_shapes.hpp"
@@ -94,6 +109,7 @@ struct SpmvArgs {
 constexpr int kPadWidth = 4;
 inline unsigned uniform_pack(int slots, int w) { unsigned p = 0; for (int q = 0; q < slots; ++q) p |= (unsigned)w << (4 * q); return p; }
 
+#ifndef __HIPCC_RTC__
 hipError_t launch_solve(int cpl, int rpl, const SolveArgs &a, dim3 grid, dim3 block, size_t lds, hipStream_t st);
 int matreg_available(int cpl, int rpl, unsigned wc_pack, unsigned wr_pack, bool lng, bool qp = false);   // 0 / 1
 hipError_t occupancy_solve(int cpl, int rpl, const SolveArgs &a, int block_threads, size_t lds, int *blocks_per_cu);
@@ -104,5 +120,7 @@ hipError_t launch_solve_f32(int cpl, int rpl, const SolveArgs &a, int num_cus, s
                             int *threads, size_t *lds);
 hipError_t launch_spmv(int cpl, int rpl, const SpmvArgs &a, dim3 grid, dim3 block, size_t lds, hipStream_t st);
 hipError_t launch_spmv_stream(int cpl, int rpl, const SpmvArgs &a, dim3 grid, dim3 block, size_t lds, hipStream_t st);
+
+#endif
 
 }  // namespace dsp

@@ -26,11 +26,26 @@
 //
 // The streaming SpMV step kernel at the bottom keeps X/Y in HBM and is the kernel whose HBM roofline
 // SURVEY.md 8(d) defines.
+#ifdef __HIPCC_RTC__     /* run-time compilation (hiprtc, dsp_rtc.cpp): no system headers, the HIP device API is built in */
+#ifndef DSP_RTC_TYPES
+#define DSP_RTC_TYPES
+typedef signed char int8_t; typedef unsigned char uint8_t; typedef short int16_t; typedef unsigned short uint16_t;
+typedef int int32_t; typedef unsigned int uint32_t; typedef long long int64_t; typedef unsigned long long uint64_t;
+typedef unsigned long uintptr_t; typedef unsigned long size_t;
+#ifndef INFINITY
+#define INFINITY (__builtin_inff())
+#endif
+#ifndef NAN
+#define NAN (__builtin_nanf(""))
+#endif
+#endif
+#else
 #include <hip/hip_runtime.h>
 
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
+#endif
 
 #include "dsp_device.hpp"
 #include "dsp_wave.hpp"
@@ -973,6 +988,7 @@ __global__ void __launch_bounds__(256) spmv_stream_kernel(SpmvArgs a) {
   }
 }
 
+#ifndef __HIPCC_RTC__     /* everything below is host code */
 // ---- launch tables ------------------------------------------------------------------------------------------
 // Register-resident-matrix specialisations exist for the shapes of the reference's flowsheets at the benchmark
 // horizons (cols/lane, rows/lane, ELL width of A^T, ELL width of A, long vectors): everything else runs the generic
@@ -1146,5 +1162,7 @@ hipError_t launch_spmv_stream(int cpl, int rpl, const SpmvArgs &a, dim3 grid, di
   void *params[] = {&args};
   return hipLaunchKernel(fn, grid, block, params, lds, st);
 }
+
+#endif   // __HIPCC_RTC__
 
 }  // namespace dsp

@@ -1,10 +1,25 @@
 // dsp_wave.hpp — wave64 device helpers shared by the kernels (dsp_kernels.hip, dsp_simplex.hip): single-wave LDS fence,
 // VALU (DPP) reductions, LDS access through 32-bit addresses.  gfx950 only.
 #pragma once
+#ifdef __HIPCC_RTC__     /* run-time compilation (hiprtc, dsp_rtc.cpp): no system headers, the HIP device API is built in */
+#ifndef DSP_RTC_TYPES
+#define DSP_RTC_TYPES
+typedef signed char int8_t; typedef unsigned char uint8_t; typedef short int16_t; typedef unsigned short uint16_t;
+typedef int int32_t; typedef unsigned int uint32_t; typedef long long int64_t; typedef unsigned long long uint64_t;
+typedef unsigned long uintptr_t; typedef unsigned long size_t;
+#ifndef INFINITY
+#define INFINITY (__builtin_inff())
+#endif
+#ifndef NAN
+#define NAN (__builtin_nanf(""))
+#endif
+#endif
+#else
 #include <hip/hip_runtime.h>
 
 #include <cmath>
 #include <cstdint>
+#endif
 
 namespace dsp {
 

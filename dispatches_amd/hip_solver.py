@@ -28,7 +28,7 @@ class DspOptions(C.Structure):
                 ("jump_min", C.c_double), ("ray_jumps", C.c_int32), ("ruiz_iters", C.c_int32),
                 ("waves_per_block", C.c_int32), ("kkt_every", C.c_int32), ("no_matreg", C.c_int32), ("geo_iters", C.c_int32),
                 ("kkt_gate", C.c_double), ("stall_rescue", C.c_int32), ("no_simplex", C.c_int32),
-                ("jump_rel", C.c_double), ("precision", C.c_int32), ("polish_patience", C.c_int32)]
+                ("jump_rel", C.c_double), ("precision", C.c_int32), ("polish_patience", C.c_int32), ("no_rtc", C.c_int32), ("reserved1", C.c_int32)]
 
 
 class DspBatch(C.Structure):
@@ -52,7 +52,7 @@ class DspStats(C.Structure):
                 ("cols_per_lane", C.c_int32), ("rows_per_lane", C.c_int32), ("kernel_ms", C.c_float),
                 ("matreg", C.c_int32), ("lds_conflicts_identity", C.c_int32), ("lds_conflicts_chosen", C.c_int32),
                 ("simplex", C.c_int32), ("streaming", C.c_int32), ("stream_bytes_per_iteration", C.c_int64),
-                ("quadratic", C.c_int32), ("precision", C.c_int32)]
+                ("quadratic", C.c_int32), ("precision", C.c_int32), ("rtc", C.c_int32), ("reserved1", C.c_int32)]
 
 
 class DspLpDesc(C.Structure):
@@ -62,7 +62,8 @@ class DspLpDesc(C.Structure):
 
 
 EXPORTED_SYMBOLS = ("dsp_default_options", "dsp_create", "dsp_solve", "dsp_spmv_step", "dsp_get_dims",
-                    "dsp_get_scaling", "dsp_destroy", "dsp_strerror", "dsp_last_hip_error", "dsp_version")
+                    "dsp_get_scaling", "dsp_destroy", "dsp_strerror", "dsp_last_hip_error", "dsp_version",
+                    "dsp_rtc_compile_check", "dsp_rtc_message")
 
 
 ABI_VERSION = 5          # DSP_VERSION of the include/dsp_hip.h these structures mirror
@@ -98,6 +99,10 @@ def load_library(path: Optional[str] = None):
     lib.dsp_destroy.restype = C.c_int
     lib.dsp_strerror.argtypes = [C.c_int]
     lib.dsp_strerror.restype = C.c_char_p
+    lib.dsp_rtc_compile_check.argtypes = [C.c_int, C.c_int, C.c_int, C.c_uint, C.c_uint, C.c_int, C.c_char_p, C.c_int]
+    lib.dsp_rtc_compile_check.restype = C.c_int
+    lib.dsp_rtc_message.argtypes = [vp]
+    lib.dsp_rtc_message.restype = C.c_char_p
     lib.dsp_last_hip_error.restype = C.c_int
     lib.dsp_version.restype = C.c_int
     if lib.dsp_version() != ABI_VERSION:

@@ -359,6 +359,7 @@ class Bidder(StochasticProgramBidder):
             if (is_thermal and getattr(md, "include_default_p_cost", False)) else []
         pmin2 = round(md.p_min, 2)
         bids = {}
+        pairs = {}                # (power, cost) arrays of every curve: record_bids re-uses them instead of re-parsing the tuple lists
         for t_idx in model.HOUR:
             t = t_idx + hour
             keep = p2[:, t_idx] >= md.p_min
@@ -385,6 +386,8 @@ class Bidder(StochasticProgramBidder):
             p_max = float(up[-1])
             bids[t] = {gen: {"p_cost": p_cost, "p_min": md.p_min, "p_max": p_max,
                              "startup_capacity": p_max, "shutdown_capacity": p_max}}
+            pairs[(t, gen)] = (id(p_cost), up, cost)
+        self._curve_arrays = pairs
         return bids
 
     def _record_bids(self, bids, date, hour, **kwargs):
@@ -393,10 +396,16 @@ class Bidder(StochasticProgramBidder):
         keys = [(t, gen) for t in bids for gen in bids[t]]
         width = max([self.n_scenario] + [len(bids[t][gen]["p_cost"]) for t, gen in keys])
         data = np.full((len(keys), 2 * width), np.nan)
+        cached = getattr(self, "_curve_arrays", {})
         for r, (t, gen) in enumerate(keys):
-            pairs = np.asarray(bids[t][gen]["p_cost"], float).reshape(-1, 2)
-            data[r, 0:2 * len(pairs):2] = pairs[:, 0]
-            data[r, 1:2 * len(pairs):2] = pairs[:, 1]
+            hit = cached.get((t, gen))
+            if hit is not None and hit[0] == id(bids[t][gen]["p_cost"]):      # the very list _assemble_bids built: its arrays
+                pw, pc = hit[1], hit[2]
+            else:                                                               # bids from elsewhere (or edited): parse them
+                arr = np.asarray(bids[t][gen]["p_cost"], float).reshape(-1, 2)
+                pw, pc = arr[:, 0], arr[:, 1]
+            data[r, 0:2 * len(pw):2] = pw
+            data[r, 1:2 * len(pw):2] = pc
         def frame():                       # built once, in write_results
             cols = [f"{kind} {k} [{unit}]" for k in range(width) for kind, unit in (("Power", "MW"), ("Cost", "$"))]
             head = pd.DataFrame({"Generator": [g for _, g in keys], "Date": date, "Hour": [t for t, _ in keys], **kwargs})

@@ -22,7 +22,9 @@
 #ifndef DSP_HIP_H
 #define DSP_HIP_H
 
+#ifndef __HIPCC_RTC__   /* hiprtc has no system headers; the kernel sources define the fixed-width types themselves */
 #include <stdint.h>
+#endif
 
 #ifdef __cplusplus
 extern "C" {
@@ -143,6 +145,13 @@ typedef struct dsp_options {
                                 has not moved by more than eps_obj / 10 either is accepted and flagged DSP_FLAG_OBJ_WAIVED.  Such scenarios - rounding
                                 floors and slow drifts along nearly flat directions, the primal objective long converged -
                                 were the slowest of every batch (30-58 k iterations).  0 = off       default 1024 */
+  int32_t no_rtc;            /* 1 = never compile at run time (create time).  An LP without an ahead-of-time register-resident
+                                specialisation (other horizons, other flowsheets, QP variants) gets its tight instantiation
+                                compiled by hiprtc in dsp_create: 2-3 s once, then a disk cache ($DSP_RTC_CACHE or
+                                ~/.cache/dsp_hip, keyed by shape and a hash of the kernel sources).  Needs libhiprtc.so and
+                                the kernel sources ($DSP_KERNEL_SRC or csrc/ next to the library) at run time; without them
+                                the padded / LDS-matrix ahead-of-time kernels are used (dsp_rtc_message says why)  default 0 */
+  int32_t reserved1;
 } dsp_options;
 
 /* The per-call data of B scenarios.  c is required; every other input may be NULL (= no bound: -inf / +inf,
@@ -204,6 +213,8 @@ typedef struct dsp_stats {
                                           (8 n + 6 m doubles)                                          */
   int32_t quadratic;              /* 1 = soft rows present (QP variant of the kernel ran)                */
   int32_t precision;              /* precision the iterates were held in (dsp_options::precision)        */
+  int32_t rtc;                    /* 1 = the kernel that ran was compiled at run time for this LP's shape (dsp_options::no_rtc) */
+  int32_t reserved1;
 } dsp_stats;
 
 void dsp_default_options(dsp_options *opt);
@@ -227,6 +238,10 @@ int dsp_spmv_step(dsp_handle *h, int32_t B, const double *X, const double *Y, do
 
 /* Introspection */
 int dsp_get_dims(const dsp_handle *h, int32_t *n, int32_t *m, int64_t *nnz);
+/* run-time specialisation (dsp_options::no_rtc): compile one shape without a GPU (returns the code size, 0 + reason in msg);
+ * why a handle runs on an ahead-of-time kernel instead ("" if it was specialised) */
+int dsp_rtc_compile_check(int cpl, int rpl, int has_long, unsigned wc_pack, unsigned wr_pack, int qp, char *msg, int msg_len);
+const char *dsp_rtc_message(const dsp_handle *h);
 int dsp_get_scaling(const dsp_handle *h, double *row_scale /*[m]*/, double *col_scale /*[n]*/, double *step_eta);
 
 int dsp_destroy(dsp_handle *h);

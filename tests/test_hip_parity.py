@@ -443,19 +443,22 @@ def test_work_queue_turnover_stress(no_matreg, waves_per_block):
 
 
 @gpu
-@pytest.mark.parametrize("T", [20, 30])
-def test_untabulated_horizons_get_a_padded_register_resident_kernel(T):
-    """Horizons without a tight register-resident specialisation (the table in csrc/dsp_kernels.hip covers the reference's
-    12 / 24 / 36 / 48 h) must not silently drop to the 3-4x slower LDS-matrix kernel: the PADDED specialisation (every
-    slot 4 entries wide) takes any LP without long vectors whose rows and columns have <= 4 entries."""
+@pytest.mark.parametrize("T,no_rtc", [(20, 0), (30, 0), (20, 1), (30, 1)])
+def test_untabulated_horizons_get_a_register_resident_kernel(T, no_rtc):
+    """Horizons without an ahead-of-time register-resident specialisation (the table in csrc/dsp_kernels.hip covers the
+    reference's 12 / 24 / 36 / 48 h) must not silently drop to the 3-4x slower LDS-matrix kernel: dsp_create compiles the
+    TIGHT specialisation of the LP at hand with hiprtc (dsp_stats::rtc; cached on disk); with run-time compilation off
+    (or unavailable) the PADDED ahead-of-time specialisation (every slot 4 entries wide) takes any LP without long
+    vectors whose rows and columns have <= 4 entries."""
     from dispatches_amd import scenarios
     from oracle import dispatch_lp_oracle as orc
-    solver = _solver()
+    solver = _solver(no_rtc=no_rtc)
     B = 64
     bidder, model = scenarios.wind_battery_batch(B, T, solver)
     scenarios.load_prices(bidder, model)
     solver.solve(model)
-    assert solver.last_stats.matreg == 1
+    assert solver.last_stats.matreg == 1 and solver.last_stats.rtc == (0 if no_rtc else 1), \
+        (solver.last_stats.matreg, solver.last_stats.rtc, model.solve_handle.lib.dsp_rtc_message(model.solve_handle.handle))
     assert (model.status == 0).all(), np.bincount(model.status)
     s = scenarios.load_series("rts_gmlc_309.npz")
     N = len(s["rt_lmp"])
@@ -464,3 +467,65 @@ def test_untabulated_horizons_get_a_padded_register_resident_kernel(T):
         P, *_ = orc.wind_battery_da(T, s["rt_cf"][h0:h0 + T], np.clip(s["da_lmp"][h0:h0 + T], 0, 500), np.clip(s["rt_lmp"][h0:h0 + T], 0, 500))
         ref = P.solve(tight=True)[1]
         assert abs(model.objective[k] - ref) <= 1e-6 * max(1.0, abs(ref)), (k, model.objective[k], ref)
+
+
+@gpu
+def test_run_time_specialisation_of_a_qp_and_of_a_perturbed_lp():
+    """(a) A ramp-cost QP at an untabulated horizon: the LP instantiation is compiled in dsp_create, the QP instantiation at
+    the first solve with soft rows; checked against the QP oracle.  (b) An LP whose sparsity no table entry has (the 24-h
+    flowsheet + a few extra coupling rows, rows up to 6 entries wide - beyond the padded shapes too): run-time specialised,
+    checked against HiGHS on the same standard form."""
+    import torch
+    from scipy.optimize import linprog
+    from dispatches_amd import scenarios
+    from dispatches_amd.hip_solver import DeviceLP, default_options
+    from dispatches_amd.lp import StandardFormLP
+    from oracle import qp_cutting_plane as qp
+    from tools.make_qp_fixtures import qp_scenario
+    import scipy.sparse as sp
+    solver = _solver()
+    T = 20
+    bidder, model = scenarios.wind_battery_batch(16, T, solver, ramp_cost=0.1)
+    scenarios.load_prices(bidder, model)
+    solver.solve(model)
+    st = solver.last_stats
+    assert st.quadratic == 1 and st.matreg == 1 and st.rtc == 1, (st.quadratic, st.matreg, st.rtc)
+    assert (model.status == 0).all()
+    for k in (0, 5, 11):
+        cf, da, rt = qp_scenario(k, T)
+        out, *_ = qp.wind_battery_da_qp(T, cf, da, rt, 0.1)
+        assert out["lower"] - 1e-6 * max(1, abs(out["upper"])) <= model.objective[k] <= out["upper"] + 1e-6 * max(1, abs(out["upper"]))
+    # (b) perturbed sparsity
+    bidder, model = scenarios.make_batch("wind_battery_24h", 32, solver)
+    lp = model.lp
+    A = lp.csr().tolil()
+    rng = np.random.default_rng(5)
+    extra = sp.lil_matrix((6, lp.n))
+    lb, ub, rlo, rhi = [np.asarray(a, float) for a in model.scenario_bounds()]
+    ub_hi = ub.max(axis=0) if ub.ndim == 2 else ub                  # (column bounds differ per scenario: wind availability)
+    finite = np.nonzero(np.isfinite(ub_hi) & (ub_hi < 1e7))[0]
+    for r in range(6):
+        cols = rng.choice(finite, 6, replace=False)
+        extra[r, cols] = rng.uniform(0.5, 1.5, 6)
+    A2 = sp.vstack([A.tocsr(), extra.tocsr()]).tocsr()
+    A2.sort_indices()
+    cap = np.array([0.8 * float((extra.tocsr()[r].toarray().ravel() * np.where(np.isfinite(ub_hi), ub_hi, 0.0)).sum()) for r in range(6)])
+    rlo2, rhi2 = np.concatenate([rlo, np.full(6, -np.inf)]), np.concatenate([rhi, cap])
+    lp2 = StandardFormLP(n=lp.n, m=lp.m + 6, indptr=A2.indptr.astype(np.int32), indices=A2.indices.astype(np.int32), data=A2.data,
+                         c=lp.c, c0=lp.c0, lb=lb, ub=ub, rlo=rlo2, rhi=rhi2)
+    dev = torch.device("cuda", 0)
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype=np.float64), device=dev)
+    dlp = DeviceLP(lp2, 0, default_options())
+    out = dlp.solve(32, t(model.c), t(lb), t(ub), t(rlo2), t(rhi2), obj_offset=t(model.c0))
+    assert out["stats"].matreg == 1 and out["stats"].rtc == 1, (out["stats"].matreg, out["stats"].rtc, dlp.lib.dsp_rtc_message(dlp.handle))
+    assert (out["status"].cpu().numpy() == 0).all()
+    obj = out["obj"].cpu().numpy() + model.c0
+    eq = np.isfinite(rlo2) & (rlo2 == rhi2)
+    upr, dnr = np.isfinite(rhi2) & ~eq, np.isfinite(rlo2) & ~eq
+    for k in (0, 7, 19):
+        r = linprog(model.c[k], A_ub=sp.vstack([A2[upr], -A2[dnr]]).tocsr(), b_ub=np.concatenate([rhi2[upr], -rlo2[dnr]]),
+                    A_eq=A2[eq], b_eq=rhi2[eq], bounds=np.stack([lb[k] if lb.ndim == 2 else lb, ub[k] if ub.ndim == 2 else ub], 1), method="highs-ds",
+                    options=dict(primal_feasibility_tolerance=1e-9, dual_feasibility_tolerance=1e-9))
+        assert r.status == 0
+        ref = r.fun + model.c0[k]
+        assert abs(obj[k] - ref) <= 1e-6 * max(1.0, abs(ref)), (k, obj[k], ref)
