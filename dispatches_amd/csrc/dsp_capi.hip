@@ -375,9 +375,10 @@ int dsp_solve(dsp_handle *h, const dsp_batch *batch, const dsp_options *opt, dsp
   a.eta = a.opt.step_scale * h->eta_unit;
   const int qp = batch->row_compliance != nullptr;
   if (a.opt.precision != 0 && a.opt.precision != 1) return DSP_ERR_INVALID;
-  // soft rows / float32 iterates exist in the fused kernels only (not in the HBM-resident streaming form, not for LPs with
-  // vectors longer than the ELL width)
-  if ((qp || a.opt.precision) && (h->streaming || h->P.long_c.count > 0 || h->P.long_r.count > 0)) return DSP_ERR_INVALID;
+  // float32 iterates exist in the fused kernels only; soft rows in the fused kernels without long vectors and in the
+  // HBM-resident streaming form
+  if (a.opt.precision && (h->streaming || h->P.long_c.count > 0 || h->P.long_r.count > 0)) return DSP_ERR_INVALID;
+  if (qp && !h->streaming && (h->P.long_c.count > 0 || h->P.long_r.count > 0)) return DSP_ERR_INVALID;
   if (h->streaming) {
     const bool timed_s = stats && sync_stats;
     if (timed_s) HIP_TRY(hipEventRecord(h->ev0, st));
@@ -387,6 +388,7 @@ int dsp_solve(dsp_handle *h, const dsp_batch *batch, const dsp_options *opt, dsp
     if (stats) {
       std::memset(stats, 0, sizeof(*stats));
       stats->streaming = 1;
+      stats->quadratic = qp;
       stats->grid_blocks = (std::max(h->n, h->m) + 255) / 256; stats->block_threads = 256;
       stats->stream_bytes_per_iteration = (int64_t)stream_bytes_per_iteration(&h->stream);
       if (sync_stats) {

@@ -137,6 +137,12 @@ __global__ void k_init(StreamArgs a) {
     const double hi = b.row_ub ? b.row_ub[(size_t)s * b.row_ub_stride + t] : INFINITY;
     const double ls = lo * d, hs = hi * d;
     a.W.rlo[om + t] = ls; a.W.rhi[om + t] = hs;
+    if (b.row_compliance) {
+      // soft row (convex QP, include/dsp_hip.h): the term (a.x - b)^2 / (2 kappa), one finite target b = row_lb = row_ub
+      const double kp = b.row_compliance[(size_t)s * b.row_compliance_stride + t];
+      a.W.kap[om + t] = kp * d * d;
+      if (!(kp >= 0.0) || (kp > 0.0 && !(lo == hi && finite_d(lo)))) v[7] = 1.0;
+    }
     double ys = b.y0 ? b.y0[om + t] / d : 0.0;
     if (!finite_d(ls)) ys = fmin(ys, 0.0);
     if (!finite_d(hs)) ys = fmax(ys, 0.0);
@@ -297,7 +303,8 @@ __global__ void k_dual_halpern(StreamArgs a, int kofs) {
       const size_t at = (size_t)s * P.m + t;
       const double y = a.W.y[at];
       const double gy = fma(-c.sig, ax, y);
-      const double yp = gy - clampd2(gy, -c.sig * a.W.rhi[at], -c.sig * a.W.rlo[at]);
+      double yp = gy - clampd2(gy, -c.sig * a.W.rhi[at], -c.sig * a.W.rlo[at]);
+      if (a.b.row_compliance) yp /= fma(c.sig, a.W.kap[at], 1.0);          // soft rows: proximal shrink (1 for hard rows)
       const double tt = 2.0 * yp - y;
       a.W.y[at] = fma(oml, a.W.y0[at] - tt, tt);
     }
@@ -321,7 +328,8 @@ __global__ void k_dual_long_finish(StreamArgs a, int kofs) {
   const size_t at = (size_t)s * P.m + P.R.long_id[l];
   const double y = a.W.y[at];
   const double gy = fma(-c.sig, ax, y);
-  const double yp = gy - clampd2(gy, -c.sig * a.W.rhi[at], -c.sig * a.W.rlo[at]);
+  double yp = gy - clampd2(gy, -c.sig * a.W.rhi[at], -c.sig * a.W.rlo[at]);
+  if (a.b.row_compliance) yp /= fma(c.sig, a.W.kap[at], 1.0);
   const double oml = 1.0 / (double)(c.k + kofs + 3);
   const double tt = 2.0 * yp - y;
   a.W.y[at] = fma(oml, a.W.y0[at] - tt, tt);
@@ -329,7 +337,8 @@ __global__ void k_dual_long_finish(StreamArgs a, int kofs) {
 
 // ---- check iteration, rows: dual step WITHOUT averaging + residual and KKT row quantities -------------------------------
 // partial slots (per scenario, block): 0 px = |dx|^2, 1 py = sum dy (2 (-sig A dx) + dy), 2 pres^2, 3 sum |y+| viol,
-// 4 dual objective (row part), 5 |y+ - y0|^2, 6 |x+ - x0|^2
+// 4 dual objective (row part, incl. -kappa y^2 / 2 of the soft rows), 5 |y+ - y0|^2, 6 |x+ - x0|^2,
+// 7 primal objective of the soft rows sum (a.x - b)^2 / (2 kappa)
 template <int SG>
 __global__ void k_check_rows(StreamArgs a) {
   const StreamProblem &P = a.P;
@@ -344,7 +353,7 @@ __global__ void k_check_rows(StreamArgs a) {
     const int s = b0 + u;
     if (s >= a.b.B) break;
     const StreamCtrl &c = a.W.ctrl[s];
-    double v[7] = {0, 0, 0, 0, 0, 0, 0};
+    double v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (!c.done) {
       const double *__restrict__ xb = a.W.xbar + (size_t)s * P.n;
       const double *__restrict__ xpv = a.W.xp + (size_t)s * P.n;
@@ -362,16 +371,24 @@ __global__ void k_check_rows(StreamArgs a) {
         const size_t at = (size_t)s * P.m + i;
         const double y = a.W.y[at], rlo = a.W.rlo[at], rhi = a.W.rhi[at];
         const double gy = fma(-c.sig, axb, y);
-        const double yp = gy - clampd2(gy, -c.sig * rhi, -c.sig * rlo);
+        const double kp = a.b.row_compliance ? a.W.kap[at] : 0.0;
+        double yp = gy - clampd2(gy, -c.sig * rhi, -c.sig * rlo);
+        if (kp > 0.0) yp /= fma(c.sig, kp, 1.0);
         a.W.yp[at] = yp;
         const double dy = yp - y;
         const double nsadx = -c.sig * (axb - axp);                 // -sig A (x+ - x)   (xbar - x+ = x+ - x)
         v[1] = dy * fma(2.0, nsadx, dy);
-        const double viol_s = fmax(rlo - axp, 0.0) + fmax(axp - rhi, 0.0);
+        double viol_s = fmax(rlo - axp, 0.0) + fmax(axp - rhi, 0.0);
+        v[4] = fmax(yp, 0.0) * fin0(rlo) - fmax(-yp, 0.0) * fin0(rhi);
+        if (kp > 0.0) {                                              // soft row: no violation, quadratic terms of both objectives
+          const double dev = axp - rlo;
+          v[7] = 0.5 * dev * dev / kp;
+          v[4] -= 0.5 * kp * yp * yp;
+          viol_s = 0.0;
+        }
         const double viol = viol_s / P.row_scale[i];
         v[2] = viol * viol;
         v[3] = fabs(yp) * viol_s;
-        v[4] = fmax(yp, 0.0) * fin0(rlo) - fmax(-yp, 0.0) * fin0(rhi);
         const double d0 = yp - a.W.y0[at];
         v[5] = d0 * d0;
       }
@@ -383,7 +400,7 @@ __global__ void k_check_rows(StreamArgs a) {
         v[6] = d0 * d0;
       }
     }
-    block_partials<7>(v, a.W.partial + ((size_t)s * a.nblk_tot + blockIdx.x) * kNQ);
+    block_partials<8>(v, a.W.partial + ((size_t)s * a.nblk_tot + blockIdx.x) * kNQ);
   }
 }
 
@@ -444,7 +461,7 @@ __device__ int control_decide(const double *acc, StreamCtrl &c, const dsp_option
   int mode = 0;
   if (!(r == r)) { c.status = DSP_STATUS_NUMERICAL; c.done = 1; }
   else {
-    const double po = acc[9], dobj = acc[4] + acc[10];
+    const double po = acc[9] + acc[7], dobj = acc[4] + acc[10];      // acc[7]: quadratic terms of the soft rows (0 for an LP)
     c.pobj = po;
     const double rp = sqrt(acc[2]) / (1.0 + c.qn), rd = sqrt(acc[8]) / (1.0 + c.cn);
     const double gap = fabs(po - dobj);
@@ -574,6 +591,7 @@ __global__ void __launch_bounds__(1024) k_block_solve(StreamArgs a) {
   double *red = axp + m, *acc = red + (1024 / 64) * kNQ;
   __shared__ StreamCtrl c;
   __shared__ int mode_s;
+  const double *kapg = a.b.row_compliance ? a.W.kap + (size_t)s * m : nullptr;     // soft rows (convex QP), else LP
   if (t0 == 0) c = a.W.ctrl[s];
   for (int j = t0; j < n; j += NT) {
     const size_t at = (size_t)s * n + j;
@@ -620,7 +638,8 @@ __global__ void __launch_bounds__(1024) k_block_solve(StreamArgs a) {
           if (check) ax2 = fma(v, xp[id], ax2);
         }
         const double gy = fma(-sig, ax, y[i]);
-        const double v = gy - clampd2(gy, -sig * rhi[i], -sig * rlo[i]);
+        double v = gy - clampd2(gy, -sig * rhi[i], -sig * rlo[i]);
+        if (kapg) v /= fma(sig, kapg[i], 1.0);      // soft rows (compliance read from the workspace: L2-resident)
         yp[i] = v;
         if (check) axp[i] = ax2;                   // A x+  (A xbar - A x+ = A (x+ - x))
         else { const double tt = 2.0 * v - y[i]; y[i] = fma(oml, y0[i] - tt, tt); }
@@ -631,7 +650,8 @@ __global__ void __launch_bounds__(1024) k_block_solve(StreamArgs a) {
         if (t0 == 0) {
           const int i = P.R.long_id[l];
           const double gy = fma(-sig, ax, y[i]);
-          const double v = gy - clampd2(gy, -sig * rhi[i], -sig * rlo[i]);
+          double v = gy - clampd2(gy, -sig * rhi[i], -sig * rlo[i]);
+          if (kapg) v /= fma(sig, kapg[i], 1.0);
           yp[i] = v;
           if (check) axp[i] = ax2;
           else { const double tt = 2.0 * v - y[i]; y[i] = fma(oml, y0[i] - tt, tt); }
@@ -651,11 +671,17 @@ __global__ void __launch_bounds__(1024) k_block_solve(StreamArgs a) {
         const double dy = yp[i] - y[i];
         const double nsadx = -sig * (axb - axp[i]);
         v[1] += dy * fma(2.0, nsadx, dy);
-        const double viol_s = fmax(rlo[i] - axp[i], 0.0) + fmax(axp[i] - rhi[i], 0.0);
+        double viol_s = fmax(rlo[i] - axp[i], 0.0) + fmax(axp[i] - rhi[i], 0.0);
+        v[4] += fmax(yp[i], 0.0) * fin0(rlo[i]) - fmax(-yp[i], 0.0) * fin0(rhi[i]);
+        if (kapg && kapg[i] > 0.0) {
+          const double dev = axp[i] - rlo[i];
+          v[7] += 0.5 * dev * dev / kapg[i];
+          v[4] -= 0.5 * kapg[i] * yp[i] * yp[i];
+          viol_s = 0.0;
+        }
         const double viol = viol_s / P.row_scale[i];
         v[2] += viol * viol;
         v[3] += fabs(yp[i]) * viol_s;
-        v[4] += fmax(yp[i], 0.0) * fin0(rlo[i]) - fmax(-yp[i], 0.0) * fin0(rhi[i]);
         const double d0 = yp[i] - y0[i];
         v[5] += d0 * d0;
       }
@@ -826,7 +852,7 @@ static hipError_t ensure_workspace(StreamSolver *S, int B) {
   StreamWork &W = S->W;
   hipError_t e;
   double **colv[] = {&W.x, &W.x0, &W.xp, &W.xbar, &W.c, &W.lb, &W.ub};
-  double **rowv[] = {&W.y, &W.y0, &W.yp, &W.rlo, &W.rhi};
+  double **rowv[] = {&W.y, &W.y0, &W.yp, &W.rlo, &W.rhi, &W.kap};
   for (double **p : colv) if ((e = alloc((size_t)B * n * sizeof(double), (void **)p)) != hipSuccess) return e;
   for (double **p : rowv) if ((e = alloc((size_t)B * m * sizeof(double), (void **)p)) != hipSuccess) return e;
   if ((e = alloc((size_t)B * sizeof(StreamCtrl), (void **)&W.ctrl)) != hipSuccess) return e;

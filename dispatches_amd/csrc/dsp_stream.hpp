@@ -45,7 +45,7 @@ struct StreamCtrl {
 
 struct StreamWork {
   double *x, *x0, *xp, *xbar, *c, *lb, *ub;     // [B][n]  scaled space
-  double *y, *y0, *yp, *rlo, *rhi;              // [B][m]
+  double *y, *y0, *yp, *rlo, *rhi, *kap;        // [B][m]   (kap: scaled compliance of the soft rows, QP only)
   StreamCtrl *ctrl;                             // [B]
   double *partial;                              // [B][nblk_tot][16] ordered block partial sums
   double *long_partial;                         // [B][nchunk_max] chunk partials of the long vectors

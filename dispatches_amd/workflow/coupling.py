@@ -60,7 +60,10 @@ class CoupledScenarioModel:
                   [f"coupling[{j},{k},{t}]" for j, k in pairs for t in range(T)]
         self.lp = StandardFormLP(n=n, m=m, indptr=np.asarray(indptr, np.int32), indices=np.asarray(indices, np.int32),
                                  data=np.asarray(data, np.float64), c=np.zeros(n), c0=0.0, lb=np.zeros(n), ub=np.zeros(n),
-                                 rlo=np.zeros(m), rhi=np.zeros(m), col_names=names_c, row_names=names_r)
+                                 rlo=np.zeros(m), rhi=np.zeros(m), col_names=names_c, row_names=names_r,
+                                 # soft rows (quadratic ramp cost) of every scenario copy; the coupling rows are hard
+                                 row_compliance=(None if lp.row_compliance is None else
+                                                 np.concatenate([np.tile(lp.row_compliance, S), np.zeros(len(pairs) * T)])))
         self.n_scenario, self.SCENARIOS, self.HOUR = 1, range(1), model.HOUR
         self.block = model.block
         self.solve_handle = None
@@ -100,6 +103,8 @@ class CoupledScenarioModel:
         ys = self.y[0][:S * m1].reshape(S, m1)
         m0 = self.base
         obj = np.sum(np.asarray(m0.c, float) * xs, axis=1) + np.broadcast_to(m0.c0, (S,))
+        if m0.lp.row_compliance is not None:
+            obj = obj + np.array([m0.lp.quadratic_value(xs[s]) for s in range(S)])
         m0.store_solution(xs, ys, obj, np.full(S, int(self.status[0]), np.int32),
                           None if self.iterations is None else np.full(S, int(self.iterations[0])))
         m0.coupled_objective = float(self.objective[0])

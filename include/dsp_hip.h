@@ -175,7 +175,7 @@ typedef struct dsp_batch {
      y+ = (y - sigma (a_i.xbar - b_i)) / (1 + sigma kappa_i) and nothing else changes; y_i = -(a_i.x - b_i) / kappa_i at the
      optimum, obj[] includes the quadratic term.  (SURVEY.md 8(b) proposed Q in CSR; a general Q would need a proximal
      step with Q in the PRIMAL, which was measured 10-20x slower on these problems: tools/pdqp_proto.py.)
-     Fused kernels only (n <= 640, m <= 384, no vectors longer than the ELL width); the in-wave simplex is skipped. */
+     Fused kernels (no vectors longer than the ELL width; the in-wave simplex is skipped) and the HBM-resident streaming path. */
   const double *row_compliance; int64_t row_compliance_stride;
   const double *x0;         /* [B][n] or NULL */
   const double *y0;         /* [B][m] or NULL */

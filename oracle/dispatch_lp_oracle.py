@@ -511,11 +511,12 @@ def wind_battery_da_coupled(T, cf, da, rt, mode, **kw):
     `cf` is shared (one plant), `da` / `rt` are [S][T].  Returns (PreparedLP, [pda columns per scenario])."""
     lp = _LP()
     S = len(da)
-    pdas = []
+    pdas, flowsheets = [], []
     for s in range(S):
         fs = wind_battery_rows(lp, T, cf, kw.get("wind_kw", 200e3), kw.get("batt_kw", 25e3), kw.get("batt_kwh", 100e3))
         pda, _u = add_da_bidding(lp, fs, da[s], rt[s])
         pdas.append(pda)
+        flowsheets.append(fs)
     if mode == "non_anticipative":
         for s in range(1, S):
             for t in range(T):
@@ -529,4 +530,6 @@ def wind_battery_da_coupled(T, cf, da, rt, mode, **kw):
                         lp.row({pdas[k][t]: np.sign(d), pdas[j][t]: -np.sign(d)}, 0.0, np.inf)
     else:
         raise ValueError(mode)
+    if kw.get("return_flowsheets"):
+        return PreparedLP(lp), pdas, flowsheets           # (the QP oracle needs every scenario's P_T expressions)
     return PreparedLP(lp), pdas

@@ -96,3 +96,15 @@ def wind_battery_da_qp(T, cf, da, rt, rho, gap_rel=1e-9, **kw):
     out = solve_qp_bracket(P, ramp_matrix(P.lp, fs), rho, gap_rel=gap_rel)
     out["P_T"] = np.array([P.value(fs["P_T"][t], out["x"]) for t in range(T)])
     return out, P, fs, pda
+
+
+def wind_battery_da_coupled_qp(T, cf, da, rt, mode, rho, gap_rel=1e-9, **kw):
+    """The COUPLED day-ahead problem of the stochastic bidders (dispatch_lp_oracle.wind_battery_da_coupled: S scenario copies +
+    non-anticipativity / monotone-bid rows) with the ramp cost (rho / 2) sum_t (P_T[s, t] - P_T[s, t-1])^2 on every copy.
+    -> (bracket dict, PreparedLP, [day-ahead columns per scenario])."""
+    from . import dispatch_lp_oracle as orc
+    P, pdas, flowsheets = orc.wind_battery_da_coupled(T, cf, da, rt, mode, return_flowsheets=True, **kw)
+    M = sp.vstack([ramp_matrix(P.lp, fs) for fs in flowsheets]).tocsr()
+    out = solve_qp_bracket(P, M, rho, gap_rel=gap_rel)
+    out["P_T"] = np.array([[P.value(fs["P_T"][t], out["x"]) for t in range(T)] for fs in flowsheets])
+    return out, P, pdas

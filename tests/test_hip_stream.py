@@ -88,3 +88,32 @@ def test_coupled_stochastic_bidders_on_the_gpu(rts309, mode):
         for j in range(S):
             for k in range(j + 1, S):
                 assert np.all((pda[k] - pda[j]) * (da[k] - da[j]) >= -1e-3)
+
+
+@gpu
+def test_coupled_stochastic_bidder_with_a_ramp_cost(rts309):
+    """BASELINE config 5 in the upstream sense of "stochastic bidder": n_scenario = 3 DIFFERENT scenarios coupled by the
+    monotone-bid rows, each copy with the quadratic ramp cost (soft rows with a compliance).  582 columns x 477 + 69 rows:
+    beyond the fused kernels, so the HBM-resident streaming path (block-resident form) solves the QP; checked against the
+    certified bracket of the QP oracle on its independent coupled formulation."""
+    from dispatches_amd.hip_solver import HipPdlpSolver
+    from dispatches_amd.workflow import Bidder
+    from oracle import qp_cutting_plane as qp
+    from tests.test_workflow_cpu import _thermal_bidder
+    T, S, rho = 24, 3, 0.1
+    solver = HipPdlpSolver(device=0, check_every=64)
+    bidder = _thermal_bidder(rts309, solver, S, cls=Bidder, history_days=3, scenario_coupling="monotone", ramp_cost=rho)
+    bidder.compute_day_ahead_bids(date="2020-01-02")
+    model = bidder.day_ahead_model
+    st = solver.last_stats
+    assert st.streaming == 1 and st.quadratic == 1 and (model.status == 0).all(), (st.streaming, st.quadratic, model.status)
+    out, P, pdas = qp.wind_battery_da_coupled_qp(T, rts309["rt_cf"][:T], model.da_prices, model.rt_prices, "monotone", rho)
+    tol = 1e-6 * max(1.0, abs(out["upper"]))
+    assert out["lower"] - tol <= model.coupled_objective <= out["upper"] + tol, (model.coupled_objective, out["lower"], out["upper"])
+    assert float(np.sum(model.objective)) == pytest.approx(model.coupled_objective, rel=1e-9, abs=1e-6)
+    # the ramp cost really is in there: the same coupled problem without it is cheaper and ramps more
+    plain = _thermal_bidder(rts309, HipPdlpSolver(device=0, check_every=64), S, cls=Bidder, history_days=3, scenario_coupling="monotone")
+    plain.compute_day_ahead_bids(date="2020-01-02")
+    assert plain.day_ahead_model.coupled_objective < model.coupled_objective
+    ramps = lambda m: np.abs(np.diff(m.expression_values("P_T"), axis=1)).sum()
+    assert ramps(model) < ramps(plain.day_ahead_model)
