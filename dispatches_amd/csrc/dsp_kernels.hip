@@ -641,16 +641,21 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
             //      moved by more than a tenth of the limit over the whole period is accepted and FLAGGED (DSP_FLAG_OBJ_WAIVED):
             //      its certificate stands at <= 10 eps_obj, the objective itself has stopped.  (Without the objective test the
             //      acceptance let errors of 1.0e-6 - 2.6e-6 through on the 48-h batch at other check cadences - points whose
-            //      objective was still sliding; accepting only up to 2 eps_obj left the drifting scenarios running to 140 k.)  These were the slowest scenarios of every batch (rounds 1-2 waited for the stall
-            //      logic below, which cannot fire before iteration ~11 k and needs two rounds).
-            // (reaching out to 100 eps_rel in the residuals - on a rounding floor the primal residual itself hovers at 2-20
-            // eps_rel - was measured too: 3 % of the QP scenarios ended up flagged for no gain in the tail, r03a_iters.log)
-            if (!done && a.opt.polish_patience > 0 && rp <= eps && rd <= eps && err <= 10.0 * lim) {
-              const double rho_o = err / lim;
+            //      objective was still sliding; accepting only up to 2 eps_obj left the drifting scenarios running to 140 k.)
+            //      These were the slowest scenarios of every batch (rounds 1-2 waited for the stall logic below, which cannot
+            //      fire before iteration ~11 k and needs two rounds).
+            // (DSP_NEAR_RES > 1, development: let the zone reach out to that many eps_rel in the residuals for (a) - on a
+            // rounding floor the primal residual itself hovers at 2-20 eps_rel.  Measured at 30 and 100: no gain in the tail
+            // and 3 % of the QP scenarios end up flagged - profiles/r03a_iters.log, r03v_near_res.log.)
+#ifndef DSP_NEAR_RES
+#define DSP_NEAR_RES 1.0
+#endif
+            if (!done && a.opt.polish_patience > 0 && rp <= DSP_NEAR_RES * eps && rd <= DSP_NEAR_RES * eps && err <= 10.0 * lim) {
+              const double rho_o = fmax(err / lim, fmax(rp, rd) / eps);
               if (rho_o < 0.5 * pol_best) { pol_best = rho_o; pol_it = it; pol_po = po; }
-              else if (it - pol_it >= 4 * a.opt.polish_patience && fabs(po - pol_po) <= 0.1 * lim) { waive_obj = true; done = true; }
+              else if (it - pol_it >= 4 * a.opt.polish_patience && rp <= eps && rd <= eps && fabs(po - pol_po) <= 0.1 * lim) { waive_obj = true; done = true; }
               else if (it - pol_it >= a.opt.polish_patience && !pol_tried && nboost < 3) {
-                const bool primal_noise = gap + red[4] >= red[6];
+                const bool primal_noise = (rp > eps || rd > eps) ? rp >= rd : gap + red[4] >= red[6];
                 if (primal_noise && w < 2.0 * w_lo) { w_lo *= 4.0; ++nboost; boost_now = true; }
                 else if (!primal_noise && 2.0 * w > w_hi) { w_hi *= 0.25; ++nboost; boost_now = true; }
                 if (boost_now) { pol_best = INFINITY; pol_it = it; } else pol_tried = true;
