@@ -34,18 +34,23 @@ FP64_VECTOR_PEAK_TFLOPS = 78.6   # 1/2 of the 157.3 TF FP32 vector peak
 
 
 def _profiled_counters(kernel):
-    """Mean per-launch PMC counters of `kernel` from the newest committed rocprofv3 summary (profiles/rNN*_pmc_summary.csv:
-    separate --pmc passes of this same bench command, tools/gpu_profile.sh).  {} if no profile is committed."""
+    """Mean per-launch PMC counters of `kernel` from the NEWEST committed rocprofv3 summary that holds that kernel
+    (profiles/rNN*_pmc_summary.csv: separate --pmc passes of this same bench command, tools/gpu_profile.sh).  `kernel` is a
+    substring of the demangled name - the solve kernel is looked up WITH its template arguments ("pdlp_solve_kernel<4, 2,"), so
+    a 48-h run is never priced with the 24-h kernel's counters.  ({}, None) if no committed profile has the kernel."""
     import csv
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.csv")))
-    if not files:
-        return {}, None
-    out = {}
-    for row in csv.DictReader(open(files[-1])):
-        if kernel in row["kernel"]:
-            out[row["counter"]] = float(row["mean_counter_value"])
-    return out, os.path.basename(files[-1])
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.csv")), key=os.path.getmtime)
+    # (mtime is the checkout time in a fresh clone, so ties are broken by name: later round tags sort later)
+    files = sorted(files, key=lambda f: os.path.basename(f))
+    for f in reversed(files):
+        out = {}
+        for row in csv.DictReader(open(f)):
+            if kernel in row["kernel"]:
+                out[row["counter"]] = float(row["mean_counter_value"])
+        if out:
+            return out, os.path.basename(f)
+    return {}, None
 
 
 def _profiled_traffic(kernel):
@@ -550,8 +555,9 @@ def main():
         # true per-launch I/O of the fused kernel: inputs that vary per scenario + outputs (x, y, obj, status, iters, jumps)
         true_io = (sum(t.numel() for t in (c_d, lb_d, ub_d, rlo_d, rhi_d) if t.dim() == 2) * w
                    + B * w * (lp.n + lp.m + 1) + B * 12)
-        pmc, pmc_file = _profiled_counters("pdlp_solve_kernel")
-        traffic = _profiled_traffic("pdlp_solve_kernel")
+        solve_kernel = f"pdlp_solve_kernel<{int(st.cols_per_lane)}, {int(st.rows_per_lane)}," if geometry[3] else "pdlp_solve_kernel"
+        pmc, pmc_file = _profiled_counters(solve_kernel)
+        traffic = _profiled_traffic(solve_kernel)
         valu_frac = lds_frac = valu_rate = None
         if "SQ_INSTS_VALU" in pmc:
             valu_rate = pmc["SQ_INSTS_VALU"] / step_s                         # wave-instructions / s, sustained

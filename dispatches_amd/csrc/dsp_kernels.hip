@@ -443,18 +443,20 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
     double r0 = INFINITY, rprev = INFINITY;      // SQUARED residuals (no square root on the check path)
     int status = DSP_STATUS_ITERATION_LIMIT;
     double xp[CPL], yp[RPL];
-    double gx[CPL], gy[RPL];         // the last step before its projections: x - tau (c - A^T y),  y - sig A (2 x+ - x)
     double pobj = 0.0;
 #pragma unroll
     for (int q = 0; q < CPL; ++q) xp[q] = x[q];
 #pragma unroll
     for (int q = 0; q < RPL; ++q) yp[q] = y[q];
 
-// one PDHG application T(x, y) -> (xp, yp); leaves the unprojected points gx, gy behind (the ray jump uses them)
+// one PDHG application T(x, y) -> (xp, yp).  The unprojected points gx = x - tau (c - A^T y), gy = y - sig A (2 x+ - x) are
+// temporaries: the ray jump, the only other user, recomputes them in the ~1 attempt in 10 that reaches its ratio test
+// (kept live across the check they pinned 2 (CPL + RPL) VGPRs through the KKT block: scratch traffic on the 48-h shape)
 #define DSP_PDHG_STEP()                                                                                     \
   {                                                                                                         \
     _Pragma("unroll") for (int q = 0; q < RPL; ++q) lds_store_f64(yw[q], y[q]);                             \
     wave_lds_fence();                                                                                       \
+    double gx[CPL], gy[RPL];                                                                                \
     _Pragma("unroll") for (int q = 0; q < CPL; ++q) gx[q] = fma(-tau, c[q], x[q]);                          \
     col_step(gx, gx, tau);                                                                                  \
     _Pragma("unroll") for (int q = 0; q < CPL; ++q) {                                                       \
@@ -530,7 +532,7 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
         }
         wave_lds_fence();
         double adx[RPL];
-        row_step(adx, zero_r, -sig);                       // -sig A (x+ - x)
+        row_step(adx, zero_r, -sig);                   // -sig A (x+ - x)
 #pragma unroll
         for (int q = 0; q < RPL; ++q) {
           const double dy = yp[q] - y[q];
@@ -549,11 +551,11 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
           for (int q = 0; q < RPL; ++q) lds_store_f64(yw[q], yp[q]);
           wave_lds_fence();
           double atyp[CPL], axp[RPL];
-          col_step(atyp, zero_c, tau);                       // tau A^T y+
+          col_step(atyp, zero_c, tau);                   // tau A^T y+
 #pragma unroll
           for (int q = 0; q < CPL; ++q) lds_store_f64(xw[q], xp[q]);
           wave_lds_fence();
-          row_step(axp, zero_r, -sig);                       // -sig A x+
+          row_step(axp, zero_r, -sig);                   // -sig A x+
           const double itau = w * ieta, nisig = -(iw * ieta);
           // red: 0 pres^2, 1 dres^2, 2 pobj, 3 dobj, 4 sum|y| viol, 5 sum|c x|, 6 sum|dual residual| |x|
           //      (4 and 6 bound the objective error caused by the remaining infeasibility)
@@ -732,13 +734,12 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
           for (int q = 0; q < RPL; ++q) lds_store_f64(yw[q], yp[q]);
           wave_lds_fence();
           double tt[2] = {0.0, 0.0};       // |v2 - v1|^2_w, |v2|^2_w
-          double gx1[CPL], dgx[CPL], gy1[RPL], dgy[RPL];
+          double gx1[CPL], gy1[RPL];
 #pragma unroll
           for (int q = 0; q < CPL; ++q) gx1[q] = fma(-tau, c[q], xp[q]);
-          col_step(gx1, gx1, tau);           // x+ - tau (c - A^T y+)
+          col_step(gx1, gx1, tau);       // x+ - tau (c - A^T y+)
 #pragma unroll
           for (int q = 0; q < CPL; ++q) {
-            dgx[q] = gx1[q] - gx[q];
             x2[q] = clampd(gx1[q], lb[q], ub[q]);
             lds_store_f64(xw[q], 2.0 * x2[q] - xp[q]);
             const double v1 = xp[q] - x[q], v2 = x2[q] - xp[q];
@@ -746,10 +747,9 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
             tt[1] = fma(w * v2, v2, tt[1]);
           }
           wave_lds_fence();
-          row_step(gy1, yp, -sig);           // y+ - sig A (2 x2 - x+)
+          row_step(gy1, yp, -sig);       // y+ - sig A (2 x2 - x+)
 #pragma unroll
           for (int q = 0; q < RPL; ++q) {
-            dgy[q] = gy[q] - gy1[q];
             y2[q] = gy1[q] - clampd(gy1[q], ylo[q], yhi[q]);
             if constexpr (QP) y2[q] *= srow[q];
             const double v1 = yp[q] - y[q], v2 = y2[q] - yp[q];
@@ -761,12 +761,24 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
           // test: about one attempt in ten
           double alpha = 0.0;
           if (tt[1] > 0.0 && tt[0] <= a.opt.jump_tol * a.opt.jump_tol * tt[1]) {
+            // the unprojected points of the FIRST application, recomputed (bit-identical to what the step above had)
+            double g0x[CPL], g0y[RPL];
+#pragma unroll
+            for (int q = 0; q < RPL; ++q) lds_store_f64(yw[q], y[q]);
+            wave_lds_fence();
+#pragma unroll
+            for (int q = 0; q < CPL; ++q) g0x[q] = fma(-tau, c[q], x[q]);
+            col_step(g0x, g0x, tau);
+#pragma unroll
+            for (int q = 0; q < CPL; ++q) lds_store_f64(xw[q], 2.0 * xp[q] - x[q]);
+            wave_lds_fence();
+            row_step(g0y, y, -sig);
             alpha = INFINITY;
 #pragma unroll
-            for (int q = 0; q < CPL; ++q) alpha = fmin(alpha, steps_to_break(gx1[q], dgx[q], lb[q], ub[q]));
+            for (int q = 0; q < CPL; ++q) alpha = fmin(alpha, steps_to_break(gx1[q], gx1[q] - g0x[q], lb[q], ub[q]));
 #pragma unroll
             for (int q = 0; q < RPL; ++q)
-              alpha = fmin(alpha, steps_to_break(-gy1[q], dgy[q], sig * rlo[q], sig * rhi[q]));
+              alpha = fmin(alpha, steps_to_break(-gy1[q], g0y[q] - gy1[q], sig * rlo[q], sig * rhi[q]));
             alpha = wave_min(alpha);
           }
           // a ray that is too short to be worth an anchor reset reaches its breakpoint by itself in alpha steps: no
@@ -809,7 +821,7 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
         for (int q = 0; q < CPL; ++q) lds_store_f64(xw[q], xp[q]);
         wave_lds_fence();
         double axq[RPL];
-        row_step(axq, zero_r, -sig);                         // -sig A x+
+        row_step(axq, zero_r, -sig);                     // -sig A x+
 #pragma unroll
         for (int q = 0; q < RPL; ++q)
           if (kap[q] > 0.0) { const double dev = -(iw * ieta) * axq[q] - rlo[q]; po = fma(0.5 * dev, dev / kap[q], po); }
