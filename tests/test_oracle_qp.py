@@ -107,3 +107,37 @@ def test_product_formulation_through_the_kernel_specification_meets_the_oracle()
     # the model object evaluates the same objective from the solver's x
     for k in range(4):
         assert model.lp.objective(X[k], c=model.c[k], c0=model.c0[k]) == pytest.approx(obj[k], rel=1e-9, abs=1e-6)
+
+
+def test_coupled_bidder_with_ramp_cost_formulation_meets_the_coupled_qp_oracle(rts309):
+    """Bidder(n_scenario=3 different scenarios, scenario_coupling="monotone", ramp_cost=rho): ONE QP (582 x 501, 69 soft rows:
+    CoupledScenarioModel carries the compliances of every scenario copy).  The product's formulation through the numpy
+    specification of the solver's algorithm against the QP oracle's certified bracket of the independent coupled formulation."""
+    from dispatches_amd.workflow import Bidder
+    from tests.test_workflow_cpu import _thermal_bidder
+    from tools import pdqp_proto
+    from tools.pdlp_proto import Problem
+
+    class _Capture:
+        supports_warm_start = False
+
+        def solve(self, model, **kw):
+            self.model = model
+            raise RuntimeError("captured")
+
+    cap = _Capture()
+    bidder = _thermal_bidder(rts309, cap, 3, cls=Bidder, history_days=3, scenario_coupling="monotone", ramp_cost=0.1)
+    with pytest.raises(RuntimeError, match="captured"):
+        bidder.compute_day_ahead_bids(date="2020-01-02")
+    cm = cap.model
+    assert cm.lp.n == 582 and int(np.count_nonzero(cm.lp.row_compliance)) == 69
+    assert (cm.lp.row_compliance[-(cm.lp.m - 3 * cm.m1):] == 0).all()            # the coupling rows are hard
+    lb, ub, rlo, rhi = cm.scenario_bounds()
+    P = Problem(cm.lp, cm.c, lb, ub, rlo, rhi, cm.c0)
+    X, Y, obj, iters, done = pdqp_proto.solve(P, cm.lp.row_compliance, np.float64, eps=1e-9, eps_obj=5e-7, max_iter=60000,
+                                              check_every=64)
+    assert done.all()
+    m0 = bidder.day_ahead_model
+    out, _P, _pdas = qp.wind_battery_da_coupled_qp(24, rts309["rt_cf"][:24], m0.da_prices, m0.rt_prices, "monotone", 0.1)
+    tol = 1e-6 * max(1.0, abs(out["upper"]))
+    assert out["lower"] - tol <= obj[0] <= out["upper"] + tol, (obj[0], out["lower"], out["upper"])
