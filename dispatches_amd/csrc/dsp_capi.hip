@@ -160,7 +160,77 @@ static int solve_geometry(dsp_handle *h, int requested, int B, Geometry *g, int 
   return DSP_OK;
 }
 
+// ---- rolling-horizon hand-off of the wind + battery double loop: one thread per plant ------------------------------------------
+// Every product is made opaque to the optimiser before it is added (no FMA contraction: the _rn intrinsics are plain
+// operators to the compiler and `#pragma clang fp contract(off)` did not keep it from fusing them): the results are
+// bit-identical to the element-wise tensor operations this kernel replaces (dispatches_amd/rolling.py, use_fused=False),
+// which is how it is tested.
+__device__ __forceinline__ double wb_opaque(double v) { asm volatile("" : "+v"(v)); return v; }
+__global__ void __launch_bounds__(256) wb_rolling_kernel(dsp_wb_state s, dsp_wb_model rt, dsp_wb_model tr, int phase, int k) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= s.B) return;
+  const long long h = *s.hour, st0 = s.start[b];
+  auto win = [&](const double *series, int t) { return series[(st0 + h + t) % s.N]; };
+  if (phase == 0) {
+    const dsp_wb_model &m = rt;
+    const int known = min(m.T, 24 - k);
+    double *c = m.c + (size_t)b * m.n, *lb = m.lb + (size_t)b * m.n, *ub = m.ub + (size_t)b * m.n;
+    for (int t = 0; t < m.T; ++t) {
+      const double rtp = win(s.rt_series, t);
+      const double dap = t < known ? s.da_prices[(size_t)b * 24 + k + t] : win(s.da_series, t);
+      const double r3 = wb_opaque(__dmul_rn(1e-3, rtp));
+      c[m.pt_cols[t][0]] = __dsub_rn(m.base_c[m.pt_cols[t][0]], r3);
+      c[m.pt_cols[t][1]] = __dsub_rn(m.base_c[m.pt_cols[t][1]], r3);
+      c[m.pda_cols[t]] = __dsub_rn(m.base_c[m.pda_cols[t]], wb_opaque(__dsub_rn(dap, rtp)));
+      ub[m.wind_cols[t]] = __dmul_rn(m.wind_kw, win(s.cf_series, t));
+      const double fix = t < known ? s.da_offer[(size_t)b * 24 + k + t] : 0.0;
+      lb[m.pda_cols[t]] = fix;
+      ub[m.pda_cols[t]] = t < known ? fix : INFINITY;
+    }
+    lb[m.soc_init] = s.soc[b]; ub[m.soc_init] = s.soc[b];
+    lb[m.thr_init] = s.thr[b]; ub[m.thr_init] = s.thr[b];
+  } else if (phase == 1) {
+    const double *xr = rt.x + (size_t)b * rt.n;
+    double *lb = tr.lb + (size_t)b * tr.n, *ub = tr.ub + (size_t)b * tr.n;
+    double *rlo = tr.rlo + (size_t)b * tr.m, *rhi = tr.rhi + (size_t)b * tr.m;
+    for (int t = 0; t < tr.T; ++t) {
+      const double offer = __dmul_rn(1e-3, wb_opaque(__dadd_rn(xr[rt.pt_cols[t][0]], xr[rt.pt_cols[t][1]])));
+      rlo[tr.track_rows[t]] = offer;
+      rhi[tr.track_rows[t]] = offer;
+      ub[tr.wind_cols[t]] = __dmul_rn(tr.wind_kw, win(s.cf_series, t));
+    }
+    lb[tr.soc_init] = s.soc[b]; ub[tr.soc_init] = s.soc[b];
+    lb[tr.thr_init] = s.thr[b]; ub[tr.thr_init] = s.thr[b];
+  } else {
+    const double *x = tr.x + (size_t)b * tr.n;
+    const double delivered = wb_opaque(__dmul_rn(1e-3, wb_opaque(__dadd_rn(x[tr.pt_cols[0][0]], x[tr.pt_cols[0][1]]))));
+    const double rt0 = win(s.rt_series, 0);
+    s.delivered[b] = delivered;
+    s.soc[b] = __ddiv_rn(rint(wb_opaque(__dmul_rn(x[tr.soc0], 100.0))), 100.0);
+    s.thr[b] = __ddiv_rn(rint(wb_opaque(__dmul_rn(x[tr.thr0], 100.0))), 100.0);
+    const double dao = s.da_offer[(size_t)b * 24 + k], dap = s.da_prices[(size_t)b * 24 + k];
+    const double t1 = wb_opaque(__dmul_rn(delivered, rt0)), t2 = wb_opaque(__dmul_rn(dao, wb_opaque(__dsub_rn(dap, rt0))));
+    s.revenue[b] = __dadd_rn(s.revenue[b], wb_opaque(__dadd_rn(t1, t2)));
+    s.energy_mwh[b] = __dadd_rn(s.energy_mwh[b], delivered);
+  }
+}
+
+// the clock advances AFTER every plant has read it (own launch: stream order is the barrier)
+__global__ void wb_clock_kernel(long long *hour) { *hour += 1; }
+
 extern "C" {
+
+int dsp_wb_rolling_update(const dsp_wb_state *st, const dsp_wb_model *rt, const dsp_wb_model *tr, int32_t phase, int32_t k,
+                          void *hipStream) {
+  if (!st || !rt || !tr || st->B < 0 || phase < 0 || phase > 2 || k < 0 || k > 23 || rt->T < 1 || rt->T > 8 || tr->T < 1 || tr->T > 8)
+    return DSP_ERR_INVALID;
+  if (st->B == 0) return DSP_OK;
+  hipStream_t s = (hipStream_t)hipStream;
+  hipLaunchKernelGGL(wb_rolling_kernel, dim3((st->B + 255) / 256), dim3(256), 0, s, *st, *rt, *tr, (int)phase, (int)k);
+  if (phase == 2) hipLaunchKernelGGL(wb_clock_kernel, dim3(1), dim3(1), 0, s, (long long *)st->hour);
+  HIP_TRY(hipGetLastError());
+  return DSP_OK;
+}
 
 void dsp_default_options(dsp_options *o) {
   if (!o) return;

@@ -23,6 +23,7 @@
 
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 
 #include "dsp_device.hpp"
 #include "dsp_wave.hpp"
@@ -372,6 +373,351 @@ __global__ void __launch_bounds__(64) simplex_kernel(SimplexArgs a) {
   }
 }
 
+
+// ---- the same simplex with the tableau in REGISTERS ------------------------------------------------------------------------
+// The LDS-tableau kernel above is latency-bound: a LONE wave needs 4.2 us per pivot of a 20 x 54 tableau (126 us for 30
+// pivots at one LP per CU, profiles/r04c_simplex_scaling.log) - every pivot is a chain of LDS round trips (basic costs,
+// pricing sweep, entering column, broadcast scalars, row-by-row update).  Here lane j (+ 64 q) holds COLUMN j of the tableau
+// in VGPRs (MR rows x CQ slots), so
+//   * pricing is MR FMAs with the basic costs read lane by lane (v_readlane -> SGPR), no memory at all;
+//   * the entering column is one lane's registers: its MR entries are read with v_readlane once and serve both as the
+//     wave-uniform multipliers of the update and (selected by lane id) as the row lanes' ratio-test entries;
+//   * the pivot row T[r][.] is picked out of the register file with MR uniform selects, the update is MR x CQ FMAs;
+//   * every broadcast (entering bounds / value / cost, leaving variable) is a v_readlane.
+// LDS is only the 1 KB variable-value buffer used to assemble and certify the vertex.  Same pivot rules, same certificate,
+// same pivot counts.  Measured (profiles/r04d_simplex_reg.log): 4-h wind+battery LPs (20 x 54), 1024 of them 141 -> 102 us
+// (real-time bids) / 161 -> 115 us (tracking), a lone LP 126 -> 93 us; but a pivot is still ~1000 VALU instructions of ONE
+// wave (2 readlanes + 2 selects per row and use), the kernel needs 256 VGPRs (2 waves per SIMD: a 4096-batch takes two
+// passes, 286 vs 264 us) and the 36-row nuclear LP spills (841 vs 515 us).  So it is used where it wins - at most 24 rows,
+// at most 64 columns + rows, batches up to 2048 (the per-GPU shards of the double loop, the Tracker's single LPs) - and the
+// LDS-tableau kernel everywhere else.
+__device__ __forceinline__ double readlane_f64(double v, int l) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+
+template <int CQ, int MR>
+__global__ void __launch_bounds__(64, 2) simplex_reg_kernel(SimplexArgs a) {
+  __shared__ double xval[128];                       // value (or cost) of every variable: vertex assembly / certificate
+  const dsp_batch &b = a.b;
+  const int lane = threadIdx.x;
+  const int n = a.n, m = a.m, N = n + m;
+
+  for (int s = blockIdx.x; s < b.B; s += gridDim.x) {
+    double lo[CQ], hi[CQ], cost[CQ], val[CQ];
+    bool basic[CQ], upper[CQ], fixedv[CQ], live[CQ];
+    double cabs = 0.0;
+    bool bad = false;
+#pragma unroll
+    for (int q = 0; q < CQ; ++q) {
+      const int j = lane + 64 * q;
+      live[q] = j < N;
+      lo[q] = 0.0; hi[q] = 0.0; cost[q] = 0.0;
+      if (j < n) {
+        const double d = a.col_scale[j];
+        const double cu = b.c[(size_t)s * b.c_stride + j];
+        const double lu = b.var_lb ? b.var_lb[(size_t)s * b.var_lb_stride + j] : -INFINITY;
+        const double uu = b.var_ub ? b.var_ub[(size_t)s * b.var_ub_stride + j] : INFINITY;
+        cost[q] = cu * d; lo[q] = lu / d; hi[q] = uu / d;
+        if (!(lu <= uu) || !(cu == cu)) bad = true;
+      } else if (j < N) {
+        const int i = j - n;
+        const double d = a.row_scale[i];
+        const double l = b.row_lb ? b.row_lb[(size_t)s * b.row_lb_stride + i] : -INFINITY;
+        const double u = b.row_ub ? b.row_ub[(size_t)s * b.row_ub_stride + i] : INFINITY;
+        lo[q] = l * d; hi[q] = u * d;
+        if (!(l <= u)) bad = true;
+      }
+      cabs = fmax(cabs, fabs(cost[q]));
+      fixedv[q] = lo[q] == hi[q];
+      basic[q] = live[q] && j >= n;
+      const bool lo_f = is_finite(lo[q]), hi_f = is_finite(hi[q]);
+      double v = 0.0;
+      if (lo_f && (!hi_f || fabs(lo[q]) <= fabs(hi[q]))) v = lo[q];
+      else if (hi_f) v = hi[q];
+      val[q] = v;
+      upper[q] = hi_f && v == hi[q] && !(v == lo[q]);
+    }
+    if (__ballot(bad) != 0ull) {
+#pragma unroll
+      for (int q = 0; q < CQ; ++q) { const int j = lane + 64 * q; if (j < n) b.x[(size_t)s * n + j] = NAN; }
+      if (lane < m) b.y[(size_t)s * m + lane] = NAN;
+      bool nanc = false;
+#pragma unroll
+      for (int q = 0; q < CQ; ++q) nanc |= !(cost[q] == cost[q]);
+      const bool any_nan = __ballot(nanc) != 0ull;
+      if (lane == 0) {
+        b.obj[s] = NAN;
+        b.status[s] = any_nan ? DSP_STATUS_NUMERICAL : DSP_STATUS_PRIMAL_INFEASIBLE;
+        if (b.iters) b.iters[s] = 0;
+        if (b.jumps) b.jumps[s] = 0;
+      }
+      continue;
+    }
+    const double ctol = a.tol_d * (1.0 + wave_max(cabs));
+    // ---- tableau columns in registers: row i = s_i - sum_j a_ij x_j = 0, basis = slacks (coalesced loads per row) --------
+    double T[MR][CQ];
+#pragma unroll
+    for (int i = 0; i < MR; ++i) {
+#pragma unroll
+      for (int q = 0; q < CQ; ++q) {
+        const int j = lane + 64 * q;
+        double t = 0.0;
+        if (i < m && j < n) t = -a.A_dense[(size_t)i * n + j];
+        else if (i < m && j < N && j - n == i) t = 1.0;
+        T[i][q] = t;
+      }
+    }
+    // row lanes: basic variable of row i (slack n + i), its value s_i = sum_j a_ij x_j, bounds, phase-2 cost of the basic
+    int bvar = (lane < m) ? n + lane : -1;
+    double beta = 0.0, blo = -INFINITY, bhi = INFINITY, cbas = 0.0;
+#pragma unroll
+    for (int i0 = 0; i0 < MR; i0 += 4) {
+      double part[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        double t = 0.0;
+#pragma unroll
+        for (int q = 0; q < CQ; ++q) { const int j = lane + 64 * q; if (j < n) t = fma(T[i0 + u][q], val[q], t); }
+        part[u] = t;
+      }
+      wave_sums<4>(part);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) if (lane == i0 + u) beta = -part[u];
+    }
+    if (lane < m) {
+      const double d = a.row_scale[lane];
+      const double l = b.row_lb ? b.row_lb[(size_t)s * b.row_lb_stride + lane] : -INFINITY;
+      const double u = b.row_ub ? b.row_ub[(size_t)s * b.row_ub_stride + lane] : INFINITY;
+      blo = l * d; bhi = u * d;
+    } else {
+      beta = 0.0;
+    }
+    int status = -1, pivots = 0;
+    bool phase1 = false;
+
+    for (int it = 0;; ++it) {
+      const double ptol = a.tol_p * (1.0 + fmax(fabs(finite_or_zero(blo)), fabs(finite_or_zero(bhi))));
+      const bool below = lane < m && beta < blo - ptol;
+      const bool above = lane < m && beta > bhi + ptol;
+      phase1 = __ballot(below || above) != 0ull;
+      const double cb_lane = (lane < m) ? (phase1 ? (below ? -1.0 : (above ? 1.0 : 0.0)) : cbas) : 0.0;
+      // ---- pricing: d_j = c_j - sum_i cB_i T[i][j], basic costs read lane by lane ---------------------------------------
+      double dj[CQ];
+#pragma unroll
+      for (int q = 0; q < CQ; ++q) dj[q] = phase1 ? 0.0 : cost[q];
+#pragma unroll
+      for (int i = 0; i < MR; ++i) {
+        const double cb = readlane_f64(cb_lane, i);
+#pragma unroll
+        for (int q = 0; q < CQ; ++q) dj[q] = fma(-cb, T[i][q], dj[q]);
+      }
+      const double dtol = phase1 ? 1e-9 : ctol;
+      double score[CQ];
+      double best = -1.0;
+#pragma unroll
+      for (int q = 0; q < CQ; ++q) {
+        const bool free_col = !is_finite(lo[q]) && !is_finite(hi[q]);
+        const bool elig = live[q] && !basic[q] && !fixedv[q] &&
+                          (free_col ? fabs(dj[q]) > dtol : ((!upper[q] && dj[q] < -dtol) || (upper[q] && dj[q] > dtol)));
+        score[q] = elig ? fabs(dj[q]) : -1.0;
+        best = fmax(best, score[q]);
+      }
+      best = wave_max(best);
+      if (best < 0.0) { status = phase1 ? DSP_STATUS_PRIMAL_INFEASIBLE : DSP_STATUS_OPTIMAL; break; }
+      if (it >= a.max_pivots) { status = -1; break; }
+      int jin = -1;
+#pragma unroll
+      for (int q = 0; q < CQ; ++q) {
+        if (jin < 0) {
+          const unsigned long long mk = __ballot(score[q] == best);
+          if (mk) jin = first_lane(mk) + 64 * q;
+        }
+      }
+      const int jl = jin & 63, jq = jin >> 6;
+      // the entering column's owner: direction, bounds, value, cost (v_readlane from lane jl, slot jq)
+      double e_sgn = 0.0, e_lo = 0.0, e_hi = 0.0, e_val = 0.0, e_cost = 0.0;
+#pragma unroll
+      for (int q = 0; q < CQ; ++q) {
+        if (q == jq) {
+          const bool free_col = !is_finite(lo[q]) && !is_finite(hi[q]);
+          const bool down = free_col ? (dj[q] > 0.0) : upper[q];
+          e_sgn = down ? -1.0 : 1.0; e_lo = lo[q]; e_hi = hi[q]; e_val = val[q]; e_cost = cost[q];
+        }
+      }
+      const double sgn = readlane_f64(e_sgn, jl), jlo = readlane_f64(e_lo, jl), jhi = readlane_f64(e_hi, jl);
+      const double jval = readlane_f64(e_val, jl), jcost = readlane_f64(e_cost, jl);
+      // ---- entering column: row lane i picks up entry i of lane jl's column (read again, wave-uniform, in the update:
+      // keeping all MR of them between the two places costs 2 MR registers the allocator does not have) --------------------
+      double al = 0.0;
+#pragma unroll
+      for (int i = 0; i < MR; ++i) {
+        double t = T[i][0];
+#pragma unroll
+        for (int q = 1; q < CQ; ++q) t = (jq == q) ? T[i][q] : t;
+        const double ai = readlane_f64(t, jl);
+        al = (lane == i) ? ai : al;
+      }
+      const double amax = wave_max(fabs(al));
+      const double ptv = a.tol_piv * fmax(1.0, amax);
+      const double delta = -sgn * al;
+      const bool dec = delta < -ptv, inc = delta > ptv;
+      const bool feas = !below && !above;
+      double ti = kBig;
+      if (lane < m) {
+        if (feas && dec && is_finite(blo)) ti = (beta - blo) / -delta;
+        if (feas && inc && is_finite(bhi)) ti = (bhi - beta) / delta;
+        if (below && inc) ti = (blo - beta) / delta;
+        if (above && dec) ti = (beta - bhi) / -delta;
+        ti = fmax(ti, 0.0);
+      }
+      double tflip = jhi - jlo;
+      if (!is_finite(tflip)) tflip = kBig;
+      const double trow = wave_min(ti);
+      const double tmin = fmin(trow, tflip);
+      if (tmin >= kBig) { status = phase1 ? DSP_STATUS_PRIMAL_INFEASIBLE : DSP_STATUS_DUAL_INFEASIBLE; break; }
+      const bool flip = tflip <= trow;
+      const bool tie = lane < m && ti <= tmin * (1.0 + 1e-9) + 1e-12;
+      const double pv = wave_max(tie ? fabs(al) : -1.0);
+      const int r = first_lane(__ballot(tie && fabs(al) == pv));
+      // ---- move -------------------------------------------------------------------------------------------------------------
+      if (lane < m) beta = fma(delta, tmin, beta);
+      const double newval = fma(sgn, tmin, jval);
+      if (flip) {
+#pragma unroll
+        for (int q = 0; q < CQ; ++q)
+          if (q == jq && lane == jl) { val[q] = newval; upper[q] = !upper[q]; }
+        continue;
+      }
+      // leaving variable: the basic of row r, to the bound it reached (decided in lane r, read by everybody)
+      bool to_up = fabs(beta - bhi) < fabs(beta - blo);
+      if (is_finite(bhi) && !is_finite(blo)) to_up = true;
+      if (!is_finite(bhi)) to_up = false;
+      const int jout = __builtin_amdgcn_readlane(bvar, r);
+      const bool out_up = __builtin_amdgcn_readlane(to_up ? 1 : 0, r) != 0;
+      const double out_val = readlane_f64(to_up ? bhi : blo, r);
+      const double alpha_r = readlane_f64(al, r);
+      if (lane == r) { bvar = jin; beta = newval; blo = jlo; bhi = jhi; cbas = jcost; }
+#pragma unroll
+      for (int q = 0; q < CQ; ++q) {
+        const int j = lane + 64 * q;
+        if (j == jout) { basic[q] = false; val[q] = out_val; upper[q] = out_up; }
+        if (j == jin) basic[q] = true;
+      }
+      // ---- tableau update: row r /= alpha_r, rows i != r -= alpha_i * row r (all in registers) -----------------------------
+      const double inv = 1.0 / alpha_r;
+      double prow[CQ];
+#pragma unroll
+      for (int q = 0; q < CQ; ++q) prow[q] = 0.0;
+#pragma unroll
+      for (int i = 0; i < MR; ++i) {
+#pragma unroll
+        for (int q = 0; q < CQ; ++q) prow[q] = (i == r) ? T[i][q] : prow[q];
+      }
+#pragma unroll
+      for (int q = 0; q < CQ; ++q) prow[q] *= inv;
+#pragma unroll
+      for (int i = 0; i < MR; ++i) {
+        double t = T[i][0];
+#pragma unroll
+        for (int q = 1; q < CQ; ++q) t = (jq == q) ? T[i][q] : t;
+        const double ai = readlane_f64(t, jl);                  // entry i of the entering column, before row i changes
+#pragma unroll
+        for (int q = 0; q < CQ; ++q) T[i][q] = (i == r) ? prow[q] : fma(-ai, prow[q], T[i][q]);
+      }
+      ++pivots;
+    }
+
+    // ---- assemble the vertex, certify it against the original rows, store -----------------------------------------------
+#pragma unroll
+    for (int q = 0; q < CQ; ++q) { const int j = lane + 64 * q; if (j < N) xval[j] = val[q]; }
+    wave_lds_fence();
+    if (lane < m) xval[bvar] = beta;
+    wave_lds_fence();
+    double xs[CQ];
+    double po = 0.0;
+    bool okv = true, okb = true;
+#pragma unroll
+    for (int q = 0; q < CQ; ++q) {
+      const int j = lane + 64 * q;
+      xs[q] = (j < N) ? xval[j] : 0.0;
+      if (j < N) {
+        const double tol = 1e-9 * (1.0 + fmax(fabs(xs[q]), fmax(fabs(finite_or_zero(lo[q])), fabs(finite_or_zero(hi[q])))));
+        if (xs[q] < lo[q] - tol || xs[q] > hi[q] + tol || !(xs[q] == xs[q])) { okv = false; okb = false; }
+      }
+      if (j < n) po = fma(cost[q], xs[q], po);
+    }
+    po = wave_sum(po);
+    {
+      // row residuals with the ORIGINAL scaled matrix, sum_j a_ij x_j - s_i, against the scale of the whole vertex (see the
+      // LDS-tableau kernel): coalesced row loads + wave reductions, four rows at a time
+      double res = 0.0, mag = 0.0;
+      for (int i0 = 0; i0 < m; i0 += 2) {
+        double part[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int i = i0 + u;
+          if (i < m) {
+#pragma unroll
+            for (int q = 0; q < CQ; ++q) {
+              const int j = lane + 64 * q;
+              if (j < n) { const double t = a.A_dense[(size_t)i * n + j] * xs[q]; part[2 * u] += t; part[2 * u + 1] += fabs(t); }
+            }
+          }
+        }
+        wave_sums<4>(part);
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+          if (lane == i0 + u) { res = part[2 * u] - xval[n + lane]; mag = part[2 * u + 1] + fabs(xval[n + lane]); }
+      }
+      const double gmag = wave_max(mag);
+      if (lane < m && !(fabs(res) <= 1e-9 * (1.0 + gmag))) okv = false;
+    }
+    const bool certified = __ballot(!okv) == 0ull;
+    const unsigned long long bad_bounds = __ballot(!okb), bad_any = __ballot(!okv);
+    int reason = status == -1 ? 1 : 0;
+    if (status == DSP_STATUS_OPTIMAL && !certified) { status = -1; reason = 2; }
+    if (status == -1) {
+      if (lane == 0) {
+        if (a.debug_keep) {
+          b.status[s] = 50 + reason;
+          if (b.iters) b.iters[s] = pivots;
+          if (b.jumps) b.jumps[s] = bad_bounds ? 1000 + first_lane(bad_bounds) : (bad_any ? 2000 + first_lane(bad_any) : 0);
+          b.obj[s] = po;
+        } else {
+          b.status[s] = DSP_STATUS_UNSOLVED;
+          atomicAdd(a.unsolved, 1);
+        }
+      }
+      wave_lds_fence();
+      continue;
+    }
+    // duals: y_i = reduced cost of slack i with the phase-2 costs
+    double dsl[CQ];
+#pragma unroll
+    for (int q = 0; q < CQ; ++q) dsl[q] = cost[q];
+    const double cb2 = (lane < m) ? cbas : 0.0;
+#pragma unroll
+    for (int i = 0; i < MR; ++i) {
+      const double cb = readlane_f64(cb2, i);
+#pragma unroll
+      for (int q = 0; q < CQ; ++q) dsl[q] = fma(-cb, T[i][q], dsl[q]);
+    }
+#pragma unroll
+    for (int q = 0; q < CQ; ++q) {
+      const int j = lane + 64 * q;
+      if (j < n) b.x[(size_t)s * n + j] = xs[q] * a.col_scale[j];
+      else if (j < N) b.y[(size_t)s * m + (j - n)] = dsl[q] * a.row_scale[j - n];
+    }
+    if (lane == 0) {
+      b.obj[s] = po;
+      b.status[s] = status;
+      if (b.iters) b.iters[s] = pivots;
+      if (b.jumps) b.jumps[s] = 0;
+    }
+    wave_lds_fence();
+  }
+}
+
 }  // namespace
 
 size_t simplex_lds_bytes(int n, int m, int *row_stride) {
@@ -383,13 +729,19 @@ size_t simplex_lds_bytes(int n, int m, int *row_stride) {
 
 hipError_t launch_simplex(const SimplexArgs &a, int grid, size_t lds, hipStream_t st) {
   const int cq = (a.n + a.m + 63) / 64;
-  const void *fn = cq <= 1 ? reinterpret_cast<const void *>(&simplex_kernel<1>)
-                           : reinterpret_cast<const void *>(&simplex_kernel<2>);
   if (cq > 2) return hipErrorInvalidValue;
-  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if (e != hipSuccess) return e;
   SimplexArgs args = a;
   void *params[] = {&args};
+  // register-resident tableau where the rows fit (DSP_SX_LDS=1 forces the LDS-tableau kernel: development / comparison)
+  static const int force_lds = getenv("DSP_SX_LDS") ? atoi(getenv("DSP_SX_LDS")) : 0;
+  if (!force_lds && a.m <= 24 && cq <= 1 && a.b.B <= 2048) {
+    const void *fr = reinterpret_cast<const void *>(&simplex_reg_kernel<1, 24>);
+    return hipLaunchKernel(fr, dim3(a.b.B < grid ? a.b.B : grid), dim3(64), params, 0, st);
+  }
+  const void *fn = cq <= 1 ? reinterpret_cast<const void *>(&simplex_kernel<1>)
+                           : reinterpret_cast<const void *>(&simplex_kernel<2>);
+  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
   return hipLaunchKernel(fn, dim3(grid), dim3(64), params, lds, st);
 }
 

@@ -61,9 +61,27 @@ class DspLpDesc(C.Structure):
                 ("A_val", C.POINTER(C.c_double))]
 
 
+class DspWbModel(C.Structure):
+    """dsp_wb_model of include/dsp_hip.h: one hourly LP of the wind + battery double loop on the device."""
+    _fields_ = [("c", C.c_void_p), ("lb", C.c_void_p), ("ub", C.c_void_p), ("rlo", C.c_void_p), ("rhi", C.c_void_p),
+                ("base_c", C.c_void_p), ("x", C.c_void_p),
+                ("n", C.c_int32), ("m", C.c_int32), ("T", C.c_int32),
+                ("soc_init", C.c_int32), ("thr_init", C.c_int32), ("soc0", C.c_int32), ("thr0", C.c_int32),
+                ("wind_cols", C.c_int32 * 8), ("pt_cols", (C.c_int32 * 2) * 8), ("pda_cols", C.c_int32 * 8),
+                ("track_rows", C.c_int32 * 8), ("wind_kw", C.c_double)]
+
+
+class DspWbState(C.Structure):
+    """dsp_wb_state of include/dsp_hip.h: series, clock, realised state and accumulators of B plants."""
+    _fields_ = [("B", C.c_int32), ("N", C.c_int32), ("start", C.c_void_p), ("hour", C.c_void_p),
+                ("da_series", C.c_void_p), ("rt_series", C.c_void_p), ("cf_series", C.c_void_p),
+                ("soc", C.c_void_p), ("thr", C.c_void_p), ("da_offer", C.c_void_p), ("da_prices", C.c_void_p),
+                ("delivered", C.c_void_p), ("revenue", C.c_void_p), ("energy_mwh", C.c_void_p)]
+
+
 EXPORTED_SYMBOLS = ("dsp_default_options", "dsp_create", "dsp_solve", "dsp_spmv_step", "dsp_get_dims",
                     "dsp_get_scaling", "dsp_destroy", "dsp_strerror", "dsp_last_hip_error", "dsp_version",
-                    "dsp_rtc_compile_check", "dsp_rtc_message")
+                    "dsp_rtc_compile_check", "dsp_rtc_message", "dsp_wb_rolling_update")
 
 
 ABI_VERSION = 5          # DSP_VERSION of the include/dsp_hip.h these structures mirror
@@ -103,6 +121,8 @@ def load_library(path: Optional[str] = None):
     lib.dsp_rtc_compile_check.restype = C.c_int
     lib.dsp_rtc_message.argtypes = [vp]
     lib.dsp_rtc_message.restype = C.c_char_p
+    lib.dsp_wb_rolling_update.argtypes = [C.POINTER(DspWbState), C.POINTER(DspWbModel), C.POINTER(DspWbModel), i32, i32, vp]
+    lib.dsp_wb_rolling_update.restype = C.c_int
     lib.dsp_last_hip_error.restype = C.c_int
     lib.dsp_version.restype = C.c_int
     if lib.dsp_version() != ABI_VERSION:

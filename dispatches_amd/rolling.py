@@ -65,10 +65,36 @@ class _DeviceModel:
         if lp_backend is None:
             self.opts = default_options(**(hints or {}))
             self.dlp = DeviceLP(self.lp, device_index, self.opts)
+            # output buffers with fixed addresses from the start (the fused update kernel and the hipGraphs hold pointers)
+            n, m = self.lp.n, max(self.lp.m, 1)
+            self.out = dict(x=torch.zeros((B, n), dtype=torch.float64, device=dev), y=torch.zeros((B, m), dtype=torch.float64, device=dev),
+                            obj=torch.zeros(B, dtype=torch.float64, device=dev), status=torch.zeros(B, dtype=torch.int32, device=dev),
+                            iters=torch.zeros(B, dtype=torch.int32, device=dev), jumps=torch.zeros(B, dtype=torch.int32, device=dev),
+                            flags=torch.zeros(B, dtype=torch.int32, device=dev))
         else:                                   # tests: a stand-in with DeviceLP.solve's signature (CPU tensors + HiGHS)
             self.opts = None
             self.dlp = lp_backend(self.lp)
-        self.out = None
+        if lp_backend is not None:
+            self.out = None
+
+    def wb_struct(self):
+        """dsp_wb_model of this LP (include/dsp_hip.h) for the fused rolling-update kernel."""
+        from .hip_solver import DspWbModel
+        w = DspWbModel()
+        w.c, w.lb, w.ub, w.rlo, w.rhi = (t.data_ptr() for t in (self.c, self.lb, self.ub, self.rlo, self.rhi))
+        w.base_c, w.x = self.base_c.data_ptr(), self.out["x"].data_ptr()
+        w.n, w.m, w.T = self.lp.n, self.lp.m, self.T
+        w.soc_init, w.thr_init, w.soc0, w.thr0 = self.soc_init, self.thr_init, self.soc0, self.thr0
+        wc, pt = self.wind_cols.cpu().tolist(), self.pt_cols.cpu().tolist()
+        pda = self.pda_cols.cpu().tolist() if hasattr(self, "pda_cols") else []
+        trk = self.track_rows.cpu().tolist() if hasattr(self, "track_rows") else []
+        for t in range(8):
+            w.wind_cols[t] = wc[t] if t < len(wc) else -1
+            w.pt_cols[t][0], w.pt_cols[t][1] = (pt[t] if t < len(pt) else (-1, -1))
+            w.pda_cols[t] = pda[t] if t < len(pda) else -1
+            w.track_rows[t] = trk[t] if t < len(trk) else -1
+        w.wind_kw = self.wind_kw
+        return w
 
     def power_output(self, x):
         return 1e-3 * x[:, self.pt_cols].sum(dim=2)                                            # [B, T] MW
@@ -83,14 +109,17 @@ class _DeviceModel:
 class BatchedWindBatteryDoubleLoop:
     def __init__(self, n_scenarios, device=0, first_scenario=0, series="rts_gmlc_309.npz", stride=17,
                  day_ahead_horizon=48, real_time_horizon=4, tracking_horizon=4, wind_mw=200.0, batt_mw=25.0,
-                 price_cap=500.0, warm_start=False, lp_backend=None, use_graphs=True):
+                 price_cap=500.0, warm_start=False, lp_backend=None, use_graphs=True, use_fused=True):
         """lp_backend: None = the HIP solver on GPU `device`; tests pass a factory lp -> object with DeviceLP.solve's
         signature working on CPU tensors (tests/_highs_solver.py::HighsTensorLP), which runs the SAME window / objective /
         state-hand-off logic without a GPU.
         use_graphs: on the GPU, the day-ahead step and the 24 hour steps of a day (about 45 small device operations + two
         solver launches per hour) are captured into hipGraphs the first time they run and REPLAYED for every later day: the
         loop is launch-bound otherwise (one simulated day of 1024 plants: 23 ms issued from Python).  Everything a step
-        reads or writes therefore lives in persistent device tensors that are updated in place, including the clock."""
+        reads or writes therefore lives in persistent device tensors that are updated in place, including the clock.
+        use_fused: on the GPU, the ~45 element-wise tensor operations of an hour step (price / capacity-factor windows,
+        objective and bound rewrites, real-time offer -> dispatch rows, realised state, revenue) are THREE launches of one HIP
+        kernel (dsp_wb_rolling_update, include/dsp_hip.h), bit-identical to the tensor operations they replace."""
         import torch
         from .workflow import Tracker
         self.B = B = int(n_scenarios)
@@ -145,8 +174,21 @@ class BatchedWindBatteryDoubleLoop:
         self.da_prices = torch.zeros((B, 24), dtype=torch.float64, device=dev)
         self.da_pw = torch.zeros(B, dtype=torch.float64, device=dev)
         self.delivered = z()
+        self._hundred = torch.full((), 100.0, dtype=torch.float64, device=dev)
         self.solves = 0
         self.use_graphs = bool(use_graphs) and lp_backend is None and not self.warm_start
+        self.use_fused = bool(use_fused) and lp_backend is None and real_time_horizon <= 8 and tracking_horizon <= 8
+        if self.use_fused:
+            from .hip_solver import DspWbState, load_library
+            self._lib = load_library()
+            st = DspWbState()
+            st.B, st.N = B, N
+            st.start, st.hour = self.start.data_ptr(), self.hour_t.data_ptr()
+            st.da_series, st.rt_series, st.cf_series = self.da_series.data_ptr(), self.rt_series.data_ptr(), self.cf_series.data_ptr()
+            st.soc, st.thr = self.soc.data_ptr(), self.thr.data_ptr()
+            st.da_offer, st.da_prices = self.da_offer.data_ptr(), self.da_prices.data_ptr()
+            st.delivered, st.revenue, st.energy_mwh = self.delivered.data_ptr(), self.revenue.data_ptr(), self.energy_mwh.data_ptr()
+            self._wb_state, self._wb_rt, self._wb_tr = st, self.rt.wb_struct(), self.tr.wb_struct()
         self._graphs = {}                                                  # "da" / hour of day -> captured hipGraph
 
     # -- windows -----------------------------------------------------------------------------------------------------------
@@ -196,9 +238,24 @@ class BatchedWindBatteryDoubleLoop:
         self.da_prices.copy_(da[:, :24])
         self.da_energy_mwh += self.da_offer.sum(1)
 
+    def _fused(self, phase, k):
+        import ctypes as C
+        import torch
+        rc = self._lib.dsp_wb_rolling_update(C.byref(self._wb_state), C.byref(self._wb_rt), C.byref(self._wb_tr), phase, k,
+                                             C.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream))
+        if rc != 0:
+            raise RuntimeError(f"dsp_wb_rolling_update failed ({rc})")
+
     def _hour_step(self, k):
         """Device work of hour k of the day: real-time bid, stub clearing, tracking, state hand-off, clock (capturable)."""
         import torch
+        if self.use_fused:
+            self._fused(0, k)
+            self._check(self.rt.solve(self.B))
+            self._fused(1, k)
+            self._check(self.tr.solve(self.B))
+            self._fused(2, k)
+            return
         m = self.rt
         rt = self._window(self.rt_series, m.T)
         da = self._window(self.da_series, m.T).clone()
@@ -223,8 +280,10 @@ class BatchedWindBatteryDoubleLoop:
         x = out["x"]
         self.delivered.copy_(tr.power_output(x)[:, 0])
         # implemented profile -> next hour's initial state, rounded to 2 dp as update_model does
-        self.soc.copy_(torch.round(x[:, tr.soc0] * 100.0) / 100.0)
-        self.thr.copy_(torch.round(x[:, tr.thr0] * 100.0) / 100.0)
+        # (divided by a TENSOR: a Python-scalar divisor makes torch multiply by the rounded reciprocal on the GPU, 1 ulp off
+        # the correctly rounded quotient that Python's round(x, 2) and the fused kernel produce)
+        self.soc.copy_(torch.round(x[:, tr.soc0] * 100.0) / self._hundred)
+        self.thr.copy_(torch.round(x[:, tr.thr0] * 100.0) / self._hundred)
         self.revenue += self.delivered * rt[:, 0] + self.da_offer[:, k] * (self.da_prices[:, k] - rt[:, 0])
         self.energy_mwh += self.delivered
         self.hour_t += 1

@@ -236,6 +236,41 @@ int dsp_solve(dsp_handle *h, const dsp_batch *batch, const dsp_options *opt, dsp
 int dsp_spmv_step(dsp_handle *h, int32_t B, const double *X, const double *Y, double *AX, double *ATY,
                   void *hipStream);
 
+/* Rolling-horizon hand-off of the wind + battery double loop ON THE DEVICE (reference: MultiPeriodWindBattery.update_model,
+ * wind_battery_double_loop.py:181-274, and Bidder._pass_price_forecasts, done per plant and hour by Python there): one launch
+ * rewrites the per-plant objective entries, the mutable bounds and the realised state of B plants between two solves.
+ * All pointers are DEVICE pointers; `model` describes one of the hourly LPs (real-time bidding / tracking model). */
+typedef struct dsp_wb_model {
+  double *c, *lb, *ub, *rlo, *rhi;     /* [B][n] / [B][m] per-plant vectors of the LP (the dsp_batch inputs of its solves)     */
+  const double *base_c;                /* [n]  cost vector without prices                                                      */
+  const double *x;                     /* [B][n] solution of its last solve                                                    */
+  int32_t n, m, T;                     /* columns, rows, horizon (T <= 8)                                                      */
+  int32_t soc_init, thr_init;          /* columns fixed to the realised state of charge / energy throughput                   */
+  int32_t soc0, thr0;                  /* columns holding the state after the first period                                    */
+  int32_t wind_cols[8];                /* wind production column of every period (upper bound = availability)                 */
+  int32_t pt_cols[8][2];               /* P_T[t] = 1e-3 (x[a] + x[b])                                                          */
+  int32_t pda_cols[8];                 /* day-ahead power column of every period (bidding models), -1 otherwise               */
+  int32_t track_rows[8];               /* dispatch rows (tracking model), -1 otherwise                                        */
+  double wind_kw;
+} dsp_wb_model;
+
+typedef struct dsp_wb_state {
+  int32_t B, N;                        /* plants; length of the price / capacity-factor series                                */
+  const int64_t *start;                /* [B] first hour of every plant's year in the series                                  */
+  int64_t *hour;                       /* [1] the clock (hours since the start): advanced by phase 2                         */
+  const double *da_series, *rt_series, *cf_series;   /* [N]                                                                   */
+  double *soc, *thr;                   /* [B] realised state                                                                  */
+  const double *da_offer, *da_prices;  /* [B][24] cleared day-ahead dispatch and prices of the current day                    */
+  double *delivered, *revenue, *energy_mwh;          /* [B]                                                                   */
+} dsp_wb_state;
+
+/* phase 0: before the real-time bidding solve of hour-of-day k  (prices, state, wind availability, day-ahead power fixed to the
+ *          cleared dispatch for the hours of the horizon inside the cleared day) on `rt`;
+ * phase 1: between the solves: real-time offer = SCED dispatch (stub market) -> dispatch rows, state and wind of `tr`;
+ * phase 2: after the tracking solve: delivered power, realised state rounded to 2 dp, revenue, energy, clock + 1. */
+int dsp_wb_rolling_update(const dsp_wb_state *st, const dsp_wb_model *rt, const dsp_wb_model *tr, int32_t phase, int32_t k,
+                          void *hipStream);
+
 /* Introspection */
 int dsp_get_dims(const dsp_handle *h, int32_t *n, int32_t *m, int64_t *nnz);
 /* run-time specialisation (dsp_options::no_rtc): compile one shape without a GPU (returns the code size, 0 + reason in msg);

@@ -33,10 +33,13 @@ def test_binding_mirrors_the_header(lib):
     hdr = open(os.path.join(ROOT, "include", "dsp_hip.h")).read()
     assert int(re.search(r"#define DSP_VERSION (\d+)", hdr).group(1)) == hip_solver.ABI_VERSION == lib.dsp_version()
     for struct, cls in (("dsp_options", hip_solver.DspOptions), ("dsp_stats", hip_solver.DspStats),
-                        ("dsp_lp_desc", hip_solver.DspLpDesc), ("dsp_batch", hip_solver.DspBatch)):
+                        ("dsp_lp_desc", hip_solver.DspLpDesc), ("dsp_batch", hip_solver.DspBatch),
+                        ("dsp_wb_model", hip_solver.DspWbModel), ("dsp_wb_state", hip_solver.DspWbState)):
         body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (struct, struct), hdr, re.S).group(1)
         body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
-        fields = re.findall(r"\b\*?\s*\*?([A-Za-z_][A-Za-z0-9_]*)\s*;", body)
+        body = re.sub(r"\[[0-9\]\[]*\]", "", body)                     # array extents
+        fields = [f for decl in body.split(";") for f in re.findall(r"\*?\s*([A-Za-z_][A-Za-z0-9_]*)\s*(?:,|$)", decl.strip().split(" ", 1)[-1] if decl.strip() else "")]
+        fields = [f for f in fields if f not in ("const", "double", "int32_t", "int64_t")]
         assert fields == [f[0] for f in cls._fields_], (struct, fields, [f[0] for f in cls._fields_])
 
 

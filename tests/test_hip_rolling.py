@@ -74,3 +74,26 @@ def test_graph_replay_reproduces_the_eager_loop():
     for k in res[False]:
         assert np.array_equal(res[False][k], res[True][k]), k
     assert np.abs(res[True]["obj"]).max() > 0
+
+
+@gpu
+def test_fused_update_kernel_is_bit_identical_to_the_tensor_operations():
+    """dsp_wb_rolling_update (three launches per hour: prices / state / bounds before the real-time solve, offer -> dispatch
+    rows between the solves, realised state / revenue / clock after the tracking solve) against the ~45 element-wise tensor
+    operations it replaces: two simulated days, every result bit for bit."""
+    from dispatches_amd.rolling import BatchedWindBatteryDoubleLoop
+    B, days = 96, 2
+    res = {}
+    for fused in (False, True):
+        loop = BatchedWindBatteryDoubleLoop(B, device=0, use_graphs=False, use_fused=fused)
+        assert loop.use_fused == fused
+        for _ in range(days):
+            loop.run_day()
+        out, ok = loop.results()
+        assert ok and int(loop.hour_t.item()) == 24 * days
+        res[fused] = {k: v.cpu().numpy().copy() for k, v in out.items()}
+        res[fused]["rt_c"] = loop.rt.c.cpu().numpy().copy()
+        res[fused]["rt_ub"] = loop.rt.ub.cpu().numpy().copy()
+        res[fused]["tr_rlo"] = loop.tr.rlo.cpu().numpy().copy()
+    for k in res[False]:
+        assert np.array_equal(res[False][k], res[True][k]), k
