@@ -246,8 +246,8 @@ void dsp_default_options(dsp_options *o) {
   o->jump_rel = 3.0;
   o->restart_sufficient = 0.2;
   o->restart_necessary = 0.8;
-  o->restart_artificial = 0.36;
-  o->pid_kp = 0.7;
+  o->restart_artificial = 0.0;   // automatic (dsp_solve)
+  o->pid_kp = 0.0;               // automatic
   o->max_dlog_weight = std::log(30.0);
   o->step_scale = 0.998;
   o->weight_guard = 4.0;
@@ -440,10 +440,17 @@ int dsp_solve(dsp_handle *h, const dsp_batch *batch, const dsp_options *opt, dsp
   a.P = h->P; a.b = *batch;
   a.opt = opt ? *opt : h->opt;
   if (a.opt.max_iter < 1 || a.opt.check_every < 0 || a.opt.kkt_every < 0 || !(a.opt.kkt_gate >= 0) || a.opt.stall_rescue < 0 || a.opt.polish_patience < 0 || !(a.opt.jump_rel >= 0) || !(a.opt.eps_rel > 0) || !(a.opt.eps_obj >= 0) ||
-      !(a.opt.pid_kp >= 0) || !(a.opt.step_scale > 0))
+      !(a.opt.pid_kp >= 0) || !(a.opt.restart_artificial >= 0) || !(a.opt.step_scale > 0))
     return DSP_ERR_INVALID;
   a.eta = a.opt.step_scale * h->eta_unit;
   const int qp = batch->row_compliance != nullptr;
+  // 0 = automatic (include/dsp_hip.h): the fused float64 kernels restart their Halpern epochs earlier and steer the primal
+  // weight more gently than the HBM-resident and float32 paths, which keep the values they were tuned with
+  {
+    const bool fused64 = !h->streaming && a.opt.precision == 0;
+    if (a.opt.restart_artificial == 0.0) a.opt.restart_artificial = fused64 ? (qp ? 0.3 : 0.2) : 0.36;
+    if (a.opt.pid_kp == 0.0) a.opt.pid_kp = fused64 ? 0.6 : 0.7;
+  }
   if (a.opt.precision != 0 && a.opt.precision != 1) return DSP_ERR_INVALID;
   // float32 iterates exist in the fused kernels only; soft rows in the fused kernels without long vectors and in the
   // HBM-resident streaming form

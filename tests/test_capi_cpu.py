@@ -48,6 +48,7 @@ def test_default_options(lib):
     o = hip_solver.default_options()
     assert o.eps_rel == 1e-9 and o.eps_obj == 5e-7 and o.check_every == 0 and o.max_iter == 200000
     assert o.precision == 0 and o.polish_patience == 1024
+    assert o.restart_artificial == 0.0 and o.pid_kp == 0.0          # automatic (per path, resolved in dsp_solve)
     assert o.kkt_every == 32 and o.kkt_gate == 16.0 and o.stall_rescue == 4000 and o.jump_rel == 3.0
     with pytest.raises(TypeError):
         hip_solver.default_options(not_an_option=1)
