@@ -149,7 +149,10 @@ class StochasticProgramBidder(AbstractBidder):
             for t in range(1, horizon):
                 block.quadratic(f"power_ramp[{t}]", P_T[t] - P_T[t - 1], self.ramp_cost)
         model.P_T_rows = None
-        model.solver_hints = dict(getattr(self.bidding_model_object, "solver_hints", None) or {})
+        # solver hints of the model family; `bidding_solver_hints` holds the ones that belong to the bidding LPs only (the
+        # Tracker reads `solver_hints` for its own, much smaller LPs)
+        model.solver_hints = {**(getattr(self.bidding_model_object, "solver_hints", None) or {}),
+                              **(getattr(self.bidding_model_object, "bidding_solver_hints", None) or {})}
         model.cost_weight = weight
         model._tot_cost_family = cost_name
         self._refresh_cost_objective(model)

@@ -126,7 +126,7 @@ typedef struct dsp_options {
                                 days) cannot be resolved to eps_obj in double precision.  The threshold matters:
                                 scenarios that converge with a weight at the guard do so within ~10 k iterations
                                 and a rescue after 1000 slowed ~70 of the 4096 48-h scenarios 10-25x; 4000 (first
-                                possible trigger at iteration 11 k) touches none of them.  0 = off
+                                possible trigger at iteration 4000 / restart_artificial = 11-20 k) touches none of them.  0 = off
                                                                                           default 4000   */
   int32_t no_simplex;        /* 1 = never use the in-wave dense simplex (create time).  LPs with n + m <= 128 and m <= 64
                                 (the hourly real-time-bid and tracking LPs: 24 of the 25 solves of a simulated day) are
