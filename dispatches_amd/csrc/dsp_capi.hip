@@ -111,11 +111,12 @@ constexpr int kQueueStride = 16;       // ints (64 bytes) between ring slots
 constexpr int kMaxWavesPerBlock = 8;   // kernels are compiled with __launch_bounds__(512)
 
 // LDS bytes of a block with `wpb` waves
-static size_t lds_bytes(const DeviceProblem &P, int wpb, int matreg = 0) {
+// (solve kernels: + the [cpl + rpl][64] scale factors of the owned columns / rows behind the wave buffers; cpl = 0: spmv_step)
+static size_t lds_bytes(const DeviceProblem &P, int wpb, int matreg = 0, int cpl = 0, int rpl = 0) {
   size_t ent = matreg ? (size_t)P.mr_tailc_entries + P.mr_tailr_entries
                       : (size_t)P.tailc_entries + P.tailr_entries + P.ellc_entries + P.ellr_entries;
-  size_t per_wave = (size_t)(P.n_pad + P.m_pad) * 8;
-  return ent * sizeof(Entry) + (size_t)wpb * per_wave;
+  size_t per_wave = (size_t)(P.n_pad + P.m_pad) * 8 + (matreg ? (size_t)rare_lds_bytes(rpl) : 0);   // struct Rare, dsp_kernels.hip
+  return ent * sizeof(Entry) + (size_t)wpb * per_wave + (size_t)(cpl + rpl) * 512;
 }
 
 // Launch geometry of the solve kernel: waves (= scenarios in flight) per block and blocks per CU, from the runtime's
@@ -137,7 +138,7 @@ static int solve_geometry(dsp_handle *h, int requested, int B, Geometry *g, int 
     for (int step = 0; step < kMaxWavesPerBlock; ++step) {
       const int wpb = matreg ? 1 + step : kMaxWavesPerBlock - step;
       if (requested > 0 && wpb != std::min(requested, kMaxWavesPerBlock)) continue;
-      size_t l = lds_bytes(h->P, wpb, matreg);
+      size_t l = lds_bytes(h->P, wpb, matreg, h->cpl, h->rpl);
       if (l > (size_t)h->lds_limit) continue;
       int nb = 0;
       hipError_t e = h->rtc_state[qp] == 1
@@ -155,7 +156,7 @@ static int solve_geometry(dsp_handle *h, int requested, int B, Geometry *g, int 
     int per_cu = (B + h->num_cus - 1) / h->num_cus;
     int wpb = g->wpb;
     while (wpb > 1 && wpb > per_cu) wpb--;
-    if (wpb != g->wpb) { g->wpb = wpb; g->lds = lds_bytes(h->P, wpb, matreg); g->blocks_per_cu = std::max(1, per_cu / wpb); }
+    if (wpb != g->wpb) { g->wpb = wpb; g->lds = lds_bytes(h->P, wpb, matreg, h->cpl, h->rpl); g->blocks_per_cu = std::max(1, per_cu / wpb); }
   }
   return DSP_OK;
 }

@@ -180,6 +180,18 @@ __device__ __forceinline__ void stage_entries(Entry *dst, const Entry *__restric
 // QP: rows with a compliance (dsp_batch::row_compliance) are soft - the dual step of every row is followed by the
 // proximal shrink 1 / (1 + sig kappa_i) (= 1 for hard rows), the KKT test counts no violation for soft rows and adds the
 // quadratic terms to both objectives.  A separate instantiation: the LP kernels pay nothing for it.
+// A per-scenario value that only the rare blocks of the solve loop touch (KKT test, restart, ray jump, epilogue).  L = true
+// (register-resident kernels): a lane-private copy in the wave's LDS region, read where it is used - kept in registers these
+// values (2 RPL + 9 doubles per lane) are what the allocator spills first, and the rare blocks then reload them from scratch
+// one memory round trip at a time.  L = false: a plain register (the LDS-matrix kernels run 8 waves per block).
+template <bool L>
+struct Rare {
+  double v;
+  uint32_t addr;
+  __device__ __forceinline__ double get() const { if constexpr (L) return lds_load_f64(addr); else return v; }
+  __device__ __forceinline__ void set(double x) { if constexpr (L) lds_store_f64(addr, x); else v = x; }
+};
+
 template <int CPL, int RPL, bool LONG, unsigned WC, unsigned WR, bool QP = false>
 __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 2) pdlp_solve_kernel(SolveArgs a) {
   constexpr bool MATREG = WC != 0;
@@ -207,14 +219,22 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
   stage_entries(tailr, MATREG ? P.mr_tailr : P.tailr, n_tailr);
   const LongList &long_c = MATREG ? P.mr_long_c : P.long_c;
   const LongList &long_r = MATREG ? P.mr_long_r : P.long_r;
-  __syncthreads();
+  // Scale factors of the owned columns / rows, [CPL + RPL][64] doubles behind the waves' exchange buffers (every wave writes
+  // the same values): the KKT test measures its residuals in the unscaled space.  Read from global memory where they are
+  // used (`j >= 0 ? P.col_scale[j] : 1`: slot -> index -> factor), the compiler gave every slot its own block behind its own
+  // s_waitcnt - 2 (CPL + RPL) serialised L2 round trips per test, ~7 us on the 24-h shape = 16 iterations - and kept doing so
+  // when the loads were written branch-free ahead of the products (register pressure: one address / result pair at a time).
+  const uint32_t scl_lds = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char *)(wave_buf + (size_t)(blockDim.x >> 6) * ((size_t)(P.n_pad + P.m_pad) * 8 + (MATREG ? rare_lds_bytes(RPL) : 0))) + 8u * (uint32_t)lane;
   DSP_TRACE("[trace] staged: Wc=%d Wr=%d B=%d maxit=%d\n", P.Wc, P.Wr, b.B, a.opt.max_iter);
 
-  char *xb = wave_buf + (size_t)wave * (P.n_pad + P.m_pad) * 8;        // gathered by row products
+  constexpr bool RLDS = MATREG;                                        // rare per-scenario values in LDS (struct Rare)
+  const size_t wave_stride = (size_t)(P.n_pad + P.m_pad) * 8 + (RLDS ? rare_lds_bytes(RPL) : 0);
+  char *xb = wave_buf + (size_t)wave * wave_stride;                    // gathered by row products
   char *yb = xb + (size_t)P.n_pad * 8;                                 // gathered by column products
   // LDS byte addresses of this lane's own elements in the exchange buffers (permuted slots: dsp_prepare.hpp, optimise_slots)
   using lds_cptr = const __attribute__((address_space(3))) char *;
   const uint32_t xb_lds = (uint32_t)(uintptr_t)(lds_cptr)xb, yb_lds = (uint32_t)(uintptr_t)(lds_cptr)yb;
+  const uint32_t rare_lds = yb_lds + 8u * (uint32_t)P.m_pad + 8u * (uint32_t)lane;   // slot k of struct Rare at + 512 k
   // SHARED (shapes with more than 8 owned elements per lane): the host built the same slot map for every 64-position block,
   // so ONE address register per buffer + the compile-time offsets 512 q serve all owned elements (the stores pair up into
   // ds_write2_b64); with one address VGPR per element the 48-h kernel reloaded three of them from scratch EVERY iteration
@@ -255,6 +275,11 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
     if constexpr (MATREG) return P.mr_rowat[lane + 64 * q];
     else { const int i = lane + 64 * q; return i < m ? i : -1; }
   };
+#pragma unroll
+  for (int q = 0; q < CPL; ++q) { const int j = col_id(q); lds_store_f64(scl_lds + 512u * q, j >= 0 ? P.col_scale[j] : 1.0); }
+#pragma unroll
+  for (int q = 0; q < RPL; ++q) { const int i = row_id(q); lds_store_f64(scl_lds + 512u * (CPL + q), i >= 0 ? P.row_scale[i] : 1.0); }
+  __syncthreads();
   const double eta = a.eta;
   const double eps = a.opt.eps_rel;
   const double eps_obj = a.opt.eps_obj;
@@ -330,7 +355,18 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
 
     // ---- load + scale this scenario's vectors (coalesced: lane-consecutive addresses) -----------------------
     double x[CPL], x0[CPL], c[CPL], lb[CPL], ub[CPL];
-    double y[RPL], y0[RPL], rlo[RPL], rhi[RPL];
+    double y[RPL], y0[RPL];
+    Rare<RLDS> rlo[RPL], rhi[RPL], qn, cn, c0, w_lo, w_hi, w_init, pol_best, pol_po, pobj;
+    {
+      int k_ = 0;
+#pragma unroll
+      for (int q = 0; q < RPL; ++q) rlo[q].addr = rare_lds + 512u * (k_++);
+#pragma unroll
+      for (int q = 0; q < RPL; ++q) rhi[q].addr = rare_lds + 512u * (k_++);
+      qn.addr = rare_lds + 512u * (k_++); cn.addr = rare_lds + 512u * (k_++); c0.addr = rare_lds + 512u * (k_++);
+      w_lo.addr = rare_lds + 512u * (k_++); w_hi.addr = rare_lds + 512u * (k_++); w_init.addr = rare_lds + 512u * (k_++);
+      pol_best.addr = rare_lds + 512u * (k_++); pol_po.addr = rare_lds + 512u * (k_++); pobj.addr = rare_lds + 512u * (k_++);
+    }
     double kap[QP ? RPL : 1], srow[QP ? RPL : 1];        // QP: scaled compliance kappa d_r^2 and 1 / (1 + sig kappa)
     double nrm[4] = {0.0, 0.0, 0.0, 0.0};                // |q|^2 unscaled, |c|^2 unscaled, |q|^2 scaled, |c|^2 scaled
     double cmax = 0.0, qmax = 0.0;                       // largest scaled |c_j| / finite scaled |row bound|
@@ -365,8 +401,9 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
       const double d = ok ? P.row_scale[i] : 1.0;
       const double lo = (ok && b.row_lb) ? b.row_lb[(size_t)s * b.row_lb_stride + i] : -INFINITY;
       const double hi = (ok && b.row_ub) ? b.row_ub[(size_t)s * b.row_ub_stride + i] : INFINITY;
-      rlo[q] = lo * d;
-      rhi[q] = hi * d;
+      const double rlo_q = lo * d, rhi_q = hi * d;
+      rlo[q].set(rlo_q);
+      rhi[q].set(rhi_q);
       if (!(lo <= hi)) bad = 1.0;
       if constexpr (QP) {
         const double kp_ = ok ? a.b.row_compliance[(size_t)s * a.b.row_compliance_stride + i] : 0.0;
@@ -376,13 +413,13 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
       }
       const double big = fmax(fabs(finite_or_zero(lo)), fabs(finite_or_zero(hi)));
       nrm[0] += big * big;
-      const double bigs = fmax(fabs(finite_or_zero(rlo[q])), fabs(finite_or_zero(rhi[q])));
+      const double bigs = fmax(fabs(finite_or_zero(rlo_q)), fabs(finite_or_zero(rhi_q)));
       nrm[2] += bigs * bigs;
       qmax = fmax(qmax, bigs);
       double ys = (b.y0 && ok) ? b.y0[(size_t)s * m + i] / d : 0.0;
       // keep the warm start dual-feasible in sign
-      if (!is_finite(rlo[q])) ys = fmin(ys, 0.0);
-      if (!is_finite(rhi[q])) ys = fmax(ys, 0.0);
+      if (!is_finite(rlo_q)) ys = fmin(ys, 0.0);
+      if (!is_finite(rhi_q)) ys = fmax(ys, 0.0);
       y[q] = ys;
       y0[q] = ys;
     }
@@ -402,9 +439,10 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
       }
       continue;
     }
-    const double qn = sqrt(nrm[0]), cn = sqrt(nrm[1]);
+    qn.set(sqrt(nrm[0]));
+    cn.set(sqrt(nrm[1]));
     const double qs = sqrt(nrm[2]), cs = sqrt(nrm[3]);
-    const double c0 = b.obj_offset ? b.obj_offset[(size_t)s * b.obj_offset_stride] : 0.0;
+    c0.set(b.obj_offset ? b.obj_offset[(size_t)s * b.obj_offset_stride] : 0.0);
     double w = (cs > 1e-10 && qs > 1e-10) ? cs / qs : 1.0;       // primal weight
     // Rounding guard: the primal step tau = eta / w amplifies the rounding error of (c - A^T y), about 1.1e-16 |c|_max,
     // into x; once that noise reaches the primal tolerance the iteration stalls (seen when the dual has converged to
@@ -414,15 +452,15 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
     qmax = wave_max(qmax);
     const double qall = sqrt(nrm[2] + wave_sum(bs2));       // row AND column bounds (the scale of the primal test)
     // (not const: the polish phase tightens the guard on the noisy side, see the KKT block)
-    double w_lo = a.opt.weight_guard > 0.0 ? a.opt.weight_guard * eta * 1.1e-16 * cmax / (eps * (1.0 + qall)) : 0.0;
-    double w_hi = (a.opt.weight_guard > 0.0 && qmax > 0.0)
-                      ? eps * (1.0 + cs) / (a.opt.weight_guard * eta * 1.1e-16 * qmax) : INFINITY;
+    w_lo.set(a.opt.weight_guard > 0.0 ? a.opt.weight_guard * eta * 1.1e-16 * cmax / (eps * (1.0 + qall)) : 0.0);
+    w_hi.set((a.opt.weight_guard > 0.0 && qmax > 0.0)
+                 ? eps * (1.0 + cs) / (a.opt.weight_guard * eta * 1.1e-16 * qmax) : INFINITY);
     if (b.primal_weight) {
       const double wi = b.primal_weight[s];
       if (wi > 0.0 && is_finite(wi)) w = wi;
     }
 
-    const double w_init = w;
+    w_init.set(w);
     DSP_TRACE("[trace] loaded w=%g\n", w);
     int k = 0;                       // iterations since the last restart
     int it = 0;
@@ -433,17 +471,17 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
     int stalls = 0;                  // restarts forced after >= stall_rescue iterations without decay
     bool waive_obj = false;          // stalled twice: terminate on the eps_rel tests alone
     bool lastjump = false;           // the last restart of the anchor was a ray jump
-    double pol_best = INFINITY;      // polish phase (eps_rel tests hold, eps_obj tests missing): best worst-ratio seen,
+    pol_best.set(INFINITY);          // polish phase (eps_rel tests hold, eps_obj tests missing): best worst-ratio seen,
     int pol_it = 0, nboost = 0;      //   the iteration it was seen at, guard tightenings so far
     bool pol_tried = false;          //   the guard test of this stagnation period has been made
-    double pol_po = 0.0;             //   primal objective when the best ratio was seen
+    pol_po.set(0.0);                 //   primal objective when the best ratio was seen
 #ifdef DSP_KKT_TRACE
     int ntrace = 0;
 #endif
     double r0 = INFINITY, rprev = INFINITY;      // SQUARED residuals (no square root on the check path)
     int status = DSP_STATUS_ITERATION_LIMIT;
     double xp[CPL], yp[RPL];
-    double pobj = 0.0;
+    pobj.set(0.0);
 #pragma unroll
     for (int q = 0; q < CPL; ++q) xp[q] = x[q];
 #pragma unroll
@@ -493,7 +531,7 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
     iw = 1.0 / w;                                                                                           \
     tau = eta * iw;                                                                                         \
     sig = eta * w;                                                                                          \
-    _Pragma("unroll") for (int q = 0; q < RPL; ++q) { ylo[q] = -(sig * rhi[q]); yhi[q] = -(sig * rlo[q]); } \
+    _Pragma("unroll") for (int q = 0; q < RPL; ++q) { ylo[q] = -(sig * rhi[q].get()); yhi[q] = -(sig * rlo[q].get()); } \
     if constexpr (QP) { _Pragma("unroll") for (int q = 0; q < RPL; ++q) srow[q] = 1.0 / fma(sig, kap[q], 1.0); } \
     if constexpr (MATREG) {                                                                                 \
       mreg_c.load(P.mr_ellc, lane, yb_lds, tau);                                                            \
@@ -570,8 +608,7 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
             // |residual| |x|), which kept scenarios with gap = 0.72 x limit running to 31 k iterations.
             const double lp = is_finite(lb[q]) ? fmax(rc, 0.0) : 0.0;
             const double lm = is_finite(ub[q]) ? fmax(-rc, 0.0) : 0.0;
-            const int j = col_id(q);
-            const double dr_ = (rc - lp + lm) / ((j >= 0) ? P.col_scale[j] : 1.0);
+            const double dr_ = (rc - lp + lm) / lds_load_f64(scl_lds + 512u * q);
             red[1] = fma(dr_, dr_, red[1]);
             red[6] = fma(fabs(rc - lp + lm), fabs(xp[q]), red[6]);
             const double cx = c[q] * xp[q];
@@ -582,28 +619,28 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
 #pragma unroll
           for (int q = 0; q < RPL; ++q) {
             const double ax_ = nisig * axp[q];
-            double viol_s = fmax(rlo[q] - ax_, 0.0) + fmax(ax_ - rhi[q], 0.0);
+            const double rlo_q = rlo[q].get(), rhi_q = rhi[q].get();
+            double viol_s = fmax(rlo_q - ax_, 0.0) + fmax(ax_ - rhi_q, 0.0);
             if constexpr (QP) {
               if (kap[q] > 0.0) {
                 // soft row: no violation; (a.x - b)^2 / (2 kappa) joins the primal objective, -kappa y^2 / 2 the dual one
-                const double dev = ax_ - rlo[q];
+                const double dev = ax_ - rlo_q;
                 red[2] = fma(0.5 * dev, dev / kap[q], red[2]);
                 red[3] = fma(-0.5 * kap[q] * yp[q], yp[q], red[3]);
                 viol_s = 0.0;
               }
             }
-            const int i = row_id(q);
-            const double viol = viol_s / ((i >= 0) ? P.row_scale[i] : 1.0);
+            const double viol = viol_s / lds_load_f64(scl_lds + 512u * (CPL + q));
             red[0] = fma(viol, viol, red[0]);
             red[4] = fma(fabs(yp[q]), viol_s, red[4]);
-            red[3] += fmax(yp[q], 0.0) * finite_or_zero(rlo[q]) - fmax(-yp[q], 0.0) * finite_or_zero(rhi[q]);
+            red[3] += fmax(yp[q], 0.0) * finite_or_zero(rlo_q) - fmax(-yp[q], 0.0) * finite_or_zero(rhi_q);
           }
           wave_sums<7>(red);
           const double po = red[2], dobj = red[3];
-          pobj = po;
+          pobj.set(po);
           if (!(po == po)) { status = DSP_STATUS_NUMERICAL; break; }
-          const double rp = sqrt(red[0]) / (1.0 + qn);
-          const double rd = sqrt(red[1]) / (1.0 + cn);
+          const double rp = sqrt(red[0]) / (1.0 + qn.get());
+          const double rd = sqrt(red[1]) / (1.0 + cn.get());
           const double gap = fabs(po - dobj);
           const double rg = gap / (1.0 + fabs(po) + fabs(dobj));
           // Termination.  eps_obj > 0 (default): both feasibility tests AND a bound on the objective error of x+,
@@ -617,7 +654,7 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
           bool done;
           double rho;                                           // how far the worst criterion is from its limit
           if (eps_obj > 0.0 && !waive_obj) {
-            const double lim = fmax(eps_obj * (1.0 + fabs(po + c0)), 1e-12 * red[5]);
+            const double lim = fmax(eps_obj * (1.0 + fabs(po + c0.get())), 1e-12 * red[5]);
             const double err = gap + red[4] + red[6];
             done = rp <= eps && rd <= eps && err <= lim;
             rho = fmax(fmax(rp, rd) / eps, err / lim);
@@ -625,7 +662,7 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
             if (a.trace && s == a.trace_scenario && lane == 0 && ntrace < 4096) {
               double *t = a.trace + 12 * ntrace++;
               t[0] = it; t[1] = rp; t[2] = rd; t[3] = rg; t[4] = gap / lim; t[5] = red[4] / lim; t[6] = red[6] / lim;
-              t[7] = w; t[8] = k; t[9] = w_lo; t[10] = w_hi; t[11] = po + c0;
+              t[7] = w; t[8] = k; t[9] = w_lo.get(); t[10] = w_hi.get(); t[11] = po + c0.get();
             }
 #endif
             // ---- near-miss zone: feasible, the error bound within 10x of its limit.  No 2x improvement of the bound for
@@ -654,13 +691,14 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
 #endif
             if (!done && a.opt.polish_patience > 0 && rp <= DSP_NEAR_RES * eps && rd <= DSP_NEAR_RES * eps && err <= 10.0 * lim) {
               const double rho_o = fmax(err / lim, fmax(rp, rd) / eps);
-              if (rho_o < 0.5 * pol_best) { pol_best = rho_o; pol_it = it; pol_po = po; }
-              else if (it - pol_it >= 4 * a.opt.polish_patience && rp <= eps && rd <= eps && fabs(po - pol_po) <= 0.1 * lim) { waive_obj = true; done = true; }
+              if (rho_o < 0.5 * pol_best.get()) { pol_best.set(rho_o); pol_it = it; pol_po.set(po); }
+              else if (it - pol_it >= 4 * a.opt.polish_patience && rp <= eps && rd <= eps && fabs(po - pol_po.get()) <= 0.1 * lim) { waive_obj = true; done = true; }
               else if (it - pol_it >= a.opt.polish_patience && !pol_tried && nboost < 3) {
                 const bool primal_noise = (rp > eps || rd > eps) ? rp >= rd : gap + red[4] >= red[6];
-                if (primal_noise && w < 2.0 * w_lo) { w_lo *= 4.0; ++nboost; boost_now = true; }
-                else if (!primal_noise && 2.0 * w > w_hi) { w_hi *= 0.25; ++nboost; boost_now = true; }
-                if (boost_now) { pol_best = INFINITY; pol_it = it; } else pol_tried = true;
+                const double wl_ = w_lo.get(), wh_ = w_hi.get();
+                if (primal_noise && w < 2.0 * wl_) { w_lo.set(wl_ * 4.0); ++nboost; boost_now = true; }
+                else if (!primal_noise && 2.0 * w > wh_) { w_hi.set(wh_ * 0.25); ++nboost; boost_now = true; }
+                if (boost_now) { pol_best.set(INFINITY); pol_it = it; } else pol_tried = true;
               }
             } else {
               pol_it = it; pol_tried = false;
@@ -670,7 +708,7 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
             rho = fmax(fmax(rp, rd), rg) / eps;
             if (waive_obj && eps_obj > 0.0 && !done) {
               // objective tests waived by the stall logic: the classic relative gap, or the error bound at 10x its limit
-              const double lim = fmax(eps_obj * (1.0 + fabs(po + c0)), 1e-12 * red[5]);
+              const double lim = fmax(eps_obj * (1.0 + fabs(po + c0.get())), 1e-12 * red[5]);
               done = rp <= eps && rd <= eps && gap + red[4] + red[6] <= 10.0 * lim;
             }
           }
@@ -688,7 +726,7 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
         // First time, with the weight within 30x of its rounding guard: the controller has driven the weight away, reset
         // it.  From the second time on: nothing more to gain, the eps_obj tests are waived (the eps_rel tests stay).
         const bool floor_hit = do_restart && !boost_now && !decayed && a.opt.stall_rescue > 0 && k >= a.opt.stall_rescue;
-        const bool stalled = floor_hit && stalls == 0 && (w < 30.0 * w_lo || 30.0 * w > w_hi);
+        const bool stalled = floor_hit && stalls == 0 && (w < 30.0 * w_lo.get() || 30.0 * w > w_hi.get());
         if (floor_hit && ++stalls >= 2) { waive_obj = true; gate2 = INFINITY; }
 #ifdef DSP_NO_JUMP
         const bool steady = false;
@@ -710,7 +748,7 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
           wave_sums<2>(dd);
           const double w_was = w;
           if (stalled) {
-            w = sqrt(w * w_init);
+            w = sqrt(w * w_init.get());
           } else if (dd[0] > 1e-28 && dd[1] > 1e-28) {
             // log(w |dx| / |dy|) and the exponential in single precision (hardware v_log_f32 / v_exp_f32): the weight
             // is a heuristic parameter, 1e-7 relative noise on it is irrelevant and FP64 log + exp cost ~150 instructions
@@ -718,7 +756,7 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
             const float dl = fminf(fmaxf(-(float)a.opt.pid_kp * e, -(float)a.opt.max_dlog_weight), (float)a.opt.max_dlog_weight);
             w *= (double)__expf(dl);
           }
-          w = fmin(fmax(w, w_lo), fmax(w_hi, w_lo));
+          { const double wl_ = w_lo.get(); w = fmin(fmax(w, wl_), fmax(w_hi.get(), wl_)); }
           if (w != w_was) DSP_SET_STEPS()
 #pragma unroll
           for (int q = 0; q < CPL; ++q) { x[q] = xp[q]; x0[q] = xp[q]; }
@@ -778,7 +816,7 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
             for (int q = 0; q < CPL; ++q) alpha = fmin(alpha, steps_to_break(gx1[q], gx1[q] - g0x[q], lb[q], ub[q]));
 #pragma unroll
             for (int q = 0; q < RPL; ++q)
-              alpha = fmin(alpha, steps_to_break(-gy1[q], g0y[q] - gy1[q], sig * rlo[q], sig * rhi[q]));
+              alpha = fmin(alpha, steps_to_break(-gy1[q], g0y[q] - gy1[q], sig * rlo[q].get(), sig * rhi[q].get()));
             alpha = wave_min(alpha);
           }
           // a ray that is too short to be worth an anchor reset reaches its breakpoint by itself in alpha steps: no
@@ -824,9 +862,9 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
         row_step(axq, zero_r, -sig);                     // -sig A x+
 #pragma unroll
         for (int q = 0; q < RPL; ++q)
-          if (kap[q] > 0.0) { const double dev = -(iw * ieta) * axq[q] - rlo[q]; po = fma(0.5 * dev, dev / kap[q], po); }
+          if (kap[q] > 0.0) { const double dev = -(iw * ieta) * axq[q] - rlo[q].get(); po = fma(0.5 * dev, dev / kap[q], po); }
       }
-      pobj = wave_sum(po);
+      pobj.set(wave_sum(po));
     }
 #pragma unroll
     for (int q = 0; q < CPL; ++q) {
@@ -841,7 +879,7 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
     }
     DSP_TRACE("[trace] y stored %p obj %p status %p iters %p jumps %p pw %p queue %p\n", (void *)b.y, (void *)b.obj, (void *)b.status, (void *)b.iters, (void *)b.jumps, (void *)b.primal_weight, (void *)a.queue);
     if (lane == 0) {
-      b.obj[s] = pobj;
+      b.obj[s] = pobj.get();
       b.status[s] = status;
       if (b.iters) b.iters[s] = it;
 #ifdef DSP_CLOCKS

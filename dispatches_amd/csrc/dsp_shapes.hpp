@@ -8,4 +8,8 @@ namespace dsp {
 // builds the same slot map for every 64-position block (optimise_slots(shared)).  cpl / rpl = owned columns / rows per lane.
 constexpr bool shared_slot_maps(int cpl, int rpl) { return cpl + rpl > 8; }   // (>= 6 measured: -1.5 % on the 24-h metric kernel, more gather conflicts)
 
+// Register-resident solve kernels keep the per-scenario values that only their rare blocks touch (row bounds, norms, weight
+// guards, ...: struct Rare in dsp_kernels.hip) in the wave's LDS region: 2 rpl + 9 lane-private doubles.
+constexpr int rare_lds_bytes(int rpl) { return (2 * rpl + 9) * 512; }
+
 }  // namespace dsp
