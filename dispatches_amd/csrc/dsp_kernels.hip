@@ -122,11 +122,25 @@ struct RegEll {
   // so a gather needs no address arithmetic in the iteration
   // The values are stored pre-multiplied by `scale` (the solve kernel folds its step size into the matrix).
   __device__ __forceinline__ void load(const Entry *__restrict__ g, int lane, uint32_t vec_lds, double scale) {
+    // Two passes: ALL loads first, then the conversions.  (One pass - load, scale, fold the address, pin it with the asm
+    // below - made every entry wait for its own load: total() serialised L2 round trips at every restart that changes the
+    // weight, 16 on the 24-h shape = ~7800 cycles = 10 iterations, 28 on the 48-h one; tools/gpu_check_profile.py.)
+    // The lane's base address is made opaque HERE: left to itself the compiler forms the total() entry addresses once per
+    // kernel (they are loop-invariant), runs out of registers for them and reloads each from scratch before its load.
+    const Entry *gl = g + lane;
+#ifndef DSP_NO_OPAQUE_BASE
+    asm volatile("" : "+v"(gl));
+#endif
+    typedef int v4i __attribute__((ext_vector_type(4)));                 // (a plain vector type: HIP's int4 class has no
+    using gv4i = const __attribute__((address_space(1))) v4i;            //  assignment from an address-space-qualified source)
+    gv4i *gp = (gv4i *)gl;
+    v4i raw[N];
+#pragma unroll
+    for (int t = 0; t < total(); ++t) raw[t] = gp[t * 64];                                   // coalesced global loads
 #pragma unroll
     for (int t = 0; t < total(); ++t) {
-      const int4 raw = *reinterpret_cast<const int4 *>(g + t * 64 + lane);                   // coalesced global load
-      v[t] = scale * __hiloint2double(raw.y, raw.x);
-      off[t] = (uint32_t)raw.z + vec_lds;
+      v[t] = scale * __hiloint2double(raw[t].y, raw[t].x);
+      off[t] = (uint32_t)raw[t].z + vec_lds;
       asm volatile("" : "+v"(off[t]));             // keep the folded address in a VGPR (no re-add per iteration)
     }
   }
@@ -323,6 +337,14 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
   };
   const double zero_c[CPL] = {}, zero_r[RPL] = {};
 
+#ifdef DSP_PROF     /* development: where a wave's cycles go - hot loop / check base / KKT test / restart / ray jump (tools/gpu_check_profile.py) */
+  long long prof_c[6] = {0, 0, 0, 0, 0, 0}, prof_n[6] = {0, 0, 0, 0, 0, 0}, prof_t = 0;
+#define DSP_PROF_MARK() prof_t = clock64();
+#define DSP_PROF_ADD(i) { const long long t_ = clock64(); prof_c[i] += t_ - prof_t; ++prof_n[i]; prof_t = t_; }
+#else
+#define DSP_PROF_MARK()
+#define DSP_PROF_ADD(i)
+#endif
 #ifdef DSP_CLOCKS   /* development: shader clock vs constant 100 MHz clock, cycles per wave-iteration */
   const long long clk0 = clock64(), wall0 = wall_clock64();
   long long iters_done = 0;
@@ -543,11 +565,13 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
     for (it = 0;;) {
       // ---- plain iterations up to the next check: two SpMVs + elementwise work, no reduction, no branch --------
       const int plain = min(check_every - 1, a.opt.max_iter - it);
+      DSP_PROF_MARK()
       for (int u = 0; u < plain; ++u) {
         DSP_PDHG_STEP()
         ++k;
         DSP_HALPERN_STEP()
       }
+      DSP_PROF_ADD(0)
       it += plain;
       DSP_TRACE("[trace] it=%d k=%d\n", it, k);
       if (it >= a.opt.max_iter) break;
@@ -584,6 +608,7 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
         const bool kkt_now = a.opt.kkt_gate > 0.0
                                  ? (ncheck - last_kkt >= (last_kkt ? kkt_every : min(4, kkt_every)) || r <= gate2)
                                  : (ncheck % kkt_every) == 0;
+        DSP_PROF_ADD(1)
         if (kkt_now) {
 #pragma unroll
           for (int q = 0; q < RPL; ++q) lds_store_f64(yw[q], yp[q]);
@@ -606,15 +631,16 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
             // bound - was measured: identical iteration counts under the per-term tests of rounds 1-2, and under the summed
             // error bound below it counts the complementarity product of such a column twice (once inside the gap, once as
             // |residual| |x|), which kept scenarios with gap = 0.72 x limit running to 31 k iterations.
-            const double lp = is_finite(lb[q]) ? fmax(rc, 0.0) : 0.0;
-            const double lm = is_finite(ub[q]) ? fmax(-rc, 0.0) : 0.0;
+            const double lbq = lb[q], ubq = ub[q];
+            const double lp = is_finite(lbq) ? fmax(rc, 0.0) : 0.0;
+            const double lm = is_finite(ubq) ? fmax(-rc, 0.0) : 0.0;
             const double dr_ = (rc - lp + lm) / lds_load_f64(scl_lds + 512u * q);
             red[1] = fma(dr_, dr_, red[1]);
             red[6] = fma(fabs(rc - lp + lm), fabs(xp[q]), red[6]);
             const double cx = c[q] * xp[q];
             red[2] += cx;
             red[5] += fabs(cx);
-            red[3] += lp * finite_or_zero(lb[q]) - lm * finite_or_zero(ub[q]);
+            red[3] += lp * finite_or_zero(lbq) - lm * finite_or_zero(ubq);
           }
 #pragma unroll
           for (int q = 0; q < RPL; ++q) {
@@ -716,6 +742,7 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
           const double gf = fmin(1.0, a.opt.kkt_gate / rho);
           gate2 = r * gf * gf;
           last_kkt = ncheck;
+          DSP_PROF_ADD(2)
         }
         // ---- restart test (r0 = residual at the first check after a restart) ----------------------------------
         const bool first = !(r0 < INFINITY);
@@ -765,6 +792,7 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
           k = 0; r0 = INFINITY; rprev = INFINITY; jump_not_before = 0;
           lastjump = false;
           moved = true;
+          DSP_PROF_ADD(3)
         } else if (steady) {
           // ---- ray jump: second application of T from (x+, y+), translation test, ratio test ------------------
           double x2[CPL], y2[RPL];
@@ -839,10 +867,12 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
             lastjump = true;
             moved = true;
           }
+          DSP_PROF_ADD(4)
         }
       }
       ++it;
       if (!moved) DSP_HALPERN_STEP()
+      DSP_PROF_ADD(5)
     }
 #undef DSP_PDHG_STEP
 #undef DSP_SET_STEPS
@@ -891,6 +921,11 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
     }
     DSP_TRACE("[trace] scalars stored\n");
   }
+#ifdef DSP_PROF
+  if (lane == 0 && (blockIdx.x % 397) == 0 && prof_n[0] > 0)
+    printf("[prof] block %d: hot %lld cyc / %lld segments | check base %lld / %lld | kkt %lld / %lld | restart %lld / %lld | jump test %lld / %lld | tail %lld / %lld\n",
+           (int)blockIdx.x, prof_c[0], prof_n[0], prof_c[1], prof_n[1], prof_c[2], prof_n[2], prof_c[3], prof_n[3], prof_c[4], prof_n[4], prof_c[5], prof_n[5]);
+#endif
 #ifdef DSP_CLOCKS
   if (lane == 0 && (blockIdx.x % 509) == 0 && iters_done > 0) {
     const long long dc = clock64() - clk0, dw = wall_clock64() - wall0;
