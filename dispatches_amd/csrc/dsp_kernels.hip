@@ -298,9 +298,9 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
   const double eps = a.opt.eps_rel;
   const double eps_obj = a.opt.eps_obj;
   // check_every = 0: automatic - 16, or 32 for shapes with more than 8 owned elements per lane (the 48-h wind+battery LP:
-  // 246 of 256 VGPRs are live state, the check path spills ~1.6 KB per scenario-iteration to scratch - 25 GB of HBM traffic
-  // per 4096-scenario launch, profiles/r03c48_pmc_summary.csv - and every second check saved is worth more than the ~10 %
-  // extra iterations of the coarser restart cadence: 391 -> 517 k scenarios/s, profiles/r03d_check_every_48h.log)
+  // 246 of 256 VGPRs are live state and the rare blocks of its check - KKT test, restart, ray jump - still spill; a check
+  // costs ~10 iterations there against ~7 on the 24-h shape, and every second check saved is worth more than the ~7 %
+  // extra iterations of the coarser restart cadence: profiles/r03d_check_every_48h.log, re-measured r04z_rare2.log)
   const int check_every = a.opt.check_every > 0 ? a.opt.check_every : (CPL + RPL > 8 ? 32 : 16);
   const int kkt_every = a.opt.kkt_every > 0 ? a.opt.kkt_every : 1;
   // the restart / steady tests on SQUARED residuals: r <= beta r0  <=>  r^2 <= beta^2 r0^2,

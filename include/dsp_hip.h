@@ -82,7 +82,7 @@ typedef struct dsp_options {
                                 hung on).  0 = classic PDLP tests (eps_rel on the relative gap)   default 5e-7   */
   int32_t max_iter;          /* iteration limit per scenario                          default 200000 */
   int32_t check_every;       /* restart / ray-jump test period (1 SpMV + 1 reduction); 0 = automatic: 16, or 32 for LPs with
-                                more than 8 owned elements per lane in the fused kernel (their check path spills), 64 on the
+                                more than 8 owned elements per lane in the fused kernel (the rare blocks of their check spill), 64 on the
                                 streaming path                                            default 0      */
   double  restart_sufficient;/* beta_1: restart when r <= beta_1 r0                   default 0.2    */
   double  restart_necessary; /* beta_2: ... or r <= beta_2 r0 and r increased         default 0.8    */
