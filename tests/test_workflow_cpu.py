@@ -104,6 +104,21 @@ def test_track_market_dispatch_wind_pem(golden, rts309):
     assert tracker.model.fs._time_idx == 4
 
 
+def test_solver_hints_of_a_model_family_reach_the_right_lps():
+    """`solver_hints` of a model object go to all of its LPs, `bidding_solver_hints` to the bidding LPs only (the Tracker's
+    own hints for its small, badly scaled LPs must not be overridden by a bidding cadence)."""
+    from dispatches_amd import scenarios
+    bidder, model = scenarios.make_batch("wind_pem_48h", 2, HighsTestSolver())
+    assert model.solver_hints == {"check_every": 12}
+    assert bidder.real_time_model.solver_hints == {"check_every": 12}
+    bidder, model = scenarios.make_batch("nuclear_24h", 2, HighsTestSolver())
+    assert model.solver_hints == {"geo_iters": 8}
+    mp = MultiPeriodWindPEM(model_data=RenewableGeneratorModelData(**generator_params),
+                            wind_capacity_factors=[0.5] * 48, wind_pmax_mw=pmax, pem_pmax_mw=25)
+    tracker = Tracker(tracking_model_object=mp, tracking_horizon=4, n_tracking_hour=1, solver=HighsTestSolver())
+    assert tracker.model.solver_hints["check_every"] == 32 and tracker.model.solver_hints["geo_iters"] == 8
+
+
 def _perfect_forecaster(rts309):
     idx = pd.date_range("2020-01-02", periods=len(rts309["rt_cf"]), freq="h")
     df = pd.DataFrame({"309_WIND_1-RTCF": rts309["rt_cf"], "309_WIND_1-DACF": rts309["da_cf"],
