@@ -196,8 +196,15 @@ class StochasticProgramBidder(AbstractBidder):
         """Objective vectors for all scenarios at once:  c = base - RT (x) dP_T/dx - (DA-RT) on pda."""
         c = np.empty((self.n_scenario, len(model.base_c)))
         c[:] = model.base_c
-        rows, cols = np.nonzero(model.PT_matrix)                 # P_T[t] touches 1-2 columns per hour
-        np.subtract.at(c, (slice(None), cols), rt[:, rows] * model.PT_matrix[rows, cols])
+        pt = getattr(model, "_pt_nonzeros", None)
+        if pt is None:                                           # P_T[t] touches 1-2 columns per hour
+            rows, cols = np.nonzero(model.PT_matrix)
+            pt = model._pt_nonzeros = (rows, cols, model.PT_matrix[rows, cols], len(np.unique(cols)) == len(cols))
+        rows, cols, vals, distinct = pt
+        if distinct:                                             # every column belongs to one hour: plain fancy indexing
+            c[:, cols] -= rt[:, rows] * vals
+        else:
+            np.subtract.at(c, (slice(None), cols), rt[:, rows] * vals)
         c[:, model.pda_cols] -= da - rt
         model.c = c
         model.c0 = model.base_c0 - rt @ model.PT_const
@@ -363,18 +370,24 @@ class Bidder(StochasticProgramBidder):
         pmin2 = round(md.p_min, 2)
         bids = {}
         pairs = {}                # (power, cost) arrays of every curve: record_bids re-uses them instead of re-parsing the tuple lists
+        dflt_p = np.array([d[0] for d in default], float)
+        dflt_c = np.array([d[1] for d in default], float)
         for t_idx in model.HOUR:
             t = t_idx + hour
             keep = p2[:, t_idx] >= md.p_min
-            pw = np.concatenate([np.array([d[0] for d in default], float), p2[keep, t_idx]])
-            pr = np.concatenate([np.array([d[1] for d in default], float), c2[keep, t_idx]])
+            pw = np.concatenate([dflt_p, p2[keep, t_idx]])
+            pr = np.concatenate([dflt_c, c2[keep, t_idx]])
             if len(pw):
-                up, inv = np.unique(pw, return_inverse=True)              # sorted distinct powers
-                mc = np.full(len(up), -np.inf)
-                np.maximum.at(mc, inv, pr)                                  # highest price offered at each power
+                # sorted distinct powers and the highest price offered at each: ONE sort by power, then a segmented maximum over
+                # the runs of equal powers (np.unique + np.maximum.at did the same with a second pass and a scattered update)
+                order = np.argsort(pw)
+                ps, cs = pw[order], pr[order]
+                starts = np.flatnonzero(np.concatenate([[True], ps[1:] != ps[:-1]]))
+                up = ps[starts] + 0.0                                           # (+ 0.0: no negative zeros in the curves)
+                mc = np.maximum.reduceat(cs, starts)
             else:
                 up, mc = np.zeros(0), np.zeros(0)
-            if not (len(up) and (up == md.p_min).any()):
+            if not (len(up) and up[0] == md.p_min):
                 # the reference adds the p_min point at the lowest marginal price seen (0 if there is none)
                 lowest = float(mc.min()) if len(mc) else 0.0
                 k = int(np.searchsorted(up, pmin2))

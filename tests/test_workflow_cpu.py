@@ -119,6 +119,41 @@ def test_solver_hints_of_a_model_family_reach_the_right_lps():
     assert tracker.model.solver_hints["check_every"] == 32 and tracker.model.solver_hints["geo_iters"] == 8
 
 
+def test_bid_curves_match_a_pair_by_pair_assembly():
+    """The all-hours-at-once bid assembly against the reference's procedure done pair by pair (dict of power -> highest price,
+    p_min point at the lowest price, running maximum, cost integration): ties in power and price, powers below p_min."""
+    from dispatches_amd import scenarios
+    from dispatches_amd.workflow.bidder import round_decimal
+    rng = np.random.default_rng(1)
+    for B in (1, 2, 7, 200):
+        bidder, model = scenarios.make_batch("wind_battery_24h", B, HighsTestSolver())
+        md = bidder.bidding_model_object.model_data
+        nT = len(model.pda_cols)
+        X = np.zeros((B, model.lp.n))
+        X[:, model.pda_cols] = rng.choice([-1.0, 0.0, 0.004, 10.0, 10.004, 55.555, 120.0], size=(B, nT)) \
+            + (rng.random((B, nT)) < 0.3) * rng.random((B, nT)) * 50
+        model.store_solution(X, np.zeros((B, model.lp.m)), np.zeros(B), np.zeros(B, np.int32))
+        prices = rng.choice([0.0, 12.345, 12.35, 30.0, 99.99], size=(B, nT)) + (rng.random((B, nT)) < 0.5) * rng.random((B, nT)) * 40
+        bids = bidder._assemble_bids(model, prices, 3, market="Day-ahead")
+        p2, c2 = round_decimal(X[:, model.pda_cols], 2), round_decimal(prices, 2)
+        for t in model.HOUR:
+            d = {}
+            for b in range(B):
+                if p2[b, t] >= md.p_min:
+                    d[p2[b, t]] = max(d.get(p2[b, t], -np.inf), c2[b, t])
+            if md.p_min not in d:
+                d[round(md.p_min, 2)] = min(d.values()) if d else 0.0
+            ps = sorted(d)
+            mc = np.maximum.accumulate([d[p] for p in ps])
+            cost = [ps[0] * mc[0]]
+            for i in range(1, len(ps)):
+                cost.append(cost[-1] + (ps[i] - ps[i - 1]) * mc[i])
+            got = np.array(bids[t + 3][bidder.generator]["p_cost"])
+            assert got.shape == (len(ps), 2)
+            np.testing.assert_allclose(got, np.column_stack([ps, cost]), rtol=1e-12, atol=1e-9)
+            assert bids[t + 3][bidder.generator]["p_max"] == ps[-1]
+
+
 def _perfect_forecaster(rts309):
     idx = pd.date_range("2020-01-02", periods=len(rts309["rt_cf"]), freq="h")
     df = pd.DataFrame({"309_WIND_1-RTCF": rts309["rt_cf"], "309_WIND_1-DACF": rts309["da_cf"],
