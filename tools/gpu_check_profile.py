@@ -27,14 +27,18 @@ if "--sum" in sys.argv:
             print(f"   {nm:10s} {100.0 * c / tot:5.1f} % of cycles   {n / nchk:6.3f} per check   {c / max(1, n):8.0f} cycles each")
     sys.exit(0)
 
-from dispatches_amd import scenarios
-from dispatches_amd.hip_solver import HipPdlpSolver
-
-for wl in (sys.argv[1:] or ["wind_battery_24h", "wind_battery_48h"]):
-    print("==", wl, flush=True)
+if "--one" in sys.argv:                      # one workload per process: device printf output only arrives when the process ends
+    from dispatches_amd import scenarios
+    from dispatches_amd.hip_solver import HipPdlpSolver
+    wl = sys.argv[sys.argv.index("--one") + 1]
     solver = HipPdlpSolver(device=0)
     bidder, model = scenarios.make_batch(wl, 4096, solver)
     solver.solve(model)
-    import torch
-    torch.cuda.synchronize()
     print("iterations mean", model.iterations.mean(), flush=True)
+    sys.exit(0)
+
+import subprocess
+for wl in (sys.argv[1:] or ["wind_battery_24h", "wind_battery_48h"]):
+    print("==", wl, flush=True)
+    out = subprocess.run([sys.executable, os.path.abspath(__file__), "--one", wl], capture_output=True, text=True)
+    print(out.stdout + out.stderr, flush=True)
