@@ -116,7 +116,7 @@ static size_t lds_bytes(const DeviceProblem &P, int wpb, int matreg = 0, int cpl
   size_t ent = matreg ? (size_t)P.mr_tailc_entries + P.mr_tailr_entries
                       : (size_t)P.tailc_entries + P.tailr_entries + P.ellc_entries + P.ellr_entries;
   size_t per_wave = (size_t)(P.n_pad + P.m_pad) * 8 + (matreg ? (size_t)rare_lds_bytes(rpl) : 0);   // struct Rare, dsp_kernels.hip
-  return ent * sizeof(Entry) + (size_t)wpb * per_wave + (size_t)(cpl + rpl) * 512;
+  return ent * sizeof(Entry) + (size_t)wpb * per_wave + (size_t)scale_lds_bytes(cpl, rpl);
 }
 
 // Launch geometry of the solve kernel: waves (= scenarios in flight) per block and blocks per CU, from the runtime's

@@ -289,6 +289,7 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
     if constexpr (MATREG) return P.mr_rowat[lane + 64 * q];
     else { const int i = lane + 64 * q; return i < m ? i : -1; }
   };
+  static_assert(scale_lds_bytes(CPL, RPL) == (CPL + RPL) * 512, "host LDS sizing (dsp_capi.hip) and the table layout below disagree");
 #pragma unroll
   for (int q = 0; q < CPL; ++q) { const int j = col_id(q); lds_store_f64(scl_lds + 512u * q, j >= 0 ? P.col_scale[j] : 1.0); }
 #pragma unroll
