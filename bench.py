@@ -272,7 +272,8 @@ def bench_qp_sweep(args, rank, local_rank, world, dev):
     up = lambda a: torch.as_tensor(np.ascontiguousarray(a, np.float64)).to(dev)
     c_d, lb_d, ub_d, rlo_d, rhi_d = up(model.c[sl]), up(lb), up(ub), up(rlo), up(rhi)
     kap_d, c0_d = up(lp.row_compliance), up(np.ascontiguousarray(model.c0[sl]))
-    dlp = DeviceLP(lp, local_rank, default_options())
+    hints = dict(getattr(model, "solver_hints", None) or {})        # what Bidder.solve passes for this model (soft rows: weight_guard)
+    dlp = DeviceLP(lp, local_rank, default_options(**hints))
     have = min(B * world, len(fx[f"{wl}/upper"]))
     ref_up, ref_lo = fx[f"{wl}/upper"], fx[f"{wl}/lower"]
 
@@ -296,11 +297,11 @@ def bench_qp_sweep(args, rank, local_rank, world, dev):
     if rank == 0:
         for prec in (0, 1):
             for eps in (1e-3, 1e-4, 1e-5, 1e-6, 1e-7, 1e-8, 1e-9):
-                o = default_options(precision=prec, eps_rel=eps, eps_obj=0.0, max_iter=args.sweep_max_iter)
+                o = default_options(**{**hints, "precision": prec, "eps_rel": eps, "eps_obj": 0.0, "max_iter": args.sweep_max_iter})
                 lone(o)
                 sweep.append(dict(precision="f32" if prec else "f64", eps_rel=eps, **lone(o)))
     # ---- the contract setting, pipelined ---------------------------------------------------------------------------
-    opts = default_options(eps_rel=args.eps)
+    opts = default_options(**{**hints, "eps_rel": args.eps})
     depth = args.streams if args.streams > 0 else 8
     streams = [torch.cuda.Stream(device=dev) for _ in range(depth)]
     outs = [None] * depth
