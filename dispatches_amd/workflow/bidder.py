@@ -392,7 +392,7 @@ class Bidder(StochasticProgramBidder):
                 mc = np.maximum.reduceat(cs, starts)
             else:
                 up, mc = np.zeros(0), np.zeros(0)
-            if not (len(up) and up[0] == md.p_min):
+            if not (len(up) and (up == md.p_min).any()):
                 # the reference adds the p_min point at the lowest marginal price seen (0 if there is none)
                 lowest = float(mc.min()) if len(mc) else 0.0
                 k = int(np.searchsorted(up, pmin2))
