@@ -12,6 +12,7 @@ that mimic that API; it has NOT been run against a real Pyomo model):
     con.body, con.lower, con.upper, con.name          (lower / upper may be None; equality: lower == upper)
     obj.expr, obj.sense                               (sense: +1 minimise, -1 maximise)
     generate_standard_repn(expr, compute_values=True) -> .linear_vars, .linear_coefs, .constant, .is_linear()
+    (objective only)  .quadratic_vars [(v1, v2), ...], .quadratic_coefs, .is_quadratic(), .nonlinear_expr
 
 What it does (the reference's solvers do the same inside their LP writers + presolve):
   * fixed variables (``var.fixed``) are folded into row constants / the objective constant; they get no column;
@@ -19,7 +20,12 @@ What it does (the reference's solvers do the same inside their LP writers + pres
   * ``refresh()`` re-reads everything that mutable Params / ``fix()`` calls can change between solves (objective
     coefficients, variable bounds, row bounds and the constants that fixed variables contribute) and verifies that the
     constraint MATRIX did not change - the flatten-once contract of the batched solver.  A changed matrix (e.g. a
-    mutable Param that multiplies a variable inside a constraint) raises, so nothing is silently solved with stale data.
+    mutable Param that multiplies a variable inside a constraint) raises, so nothing is silently solved with stale data;
+  * a convex QUADRATIC objective (BASELINE config 5: e.g. a ramp cost written as a sum of squares and expanded by Pyomo into
+    x_i x_j products) is handed to the solver the way `LinearBlock.quadratic` does it: the form x'Hx / 2 over the free
+    variables is factored as sum_k (w_k / 2) (a_k . x)^2 by an LDL' elimination in column order (sparse a_k for banded H:
+    the tridiagonal ramp cost gives two entries per row), and each term becomes a SOFT ROW (row_lb = row_ub = 0,
+    row_compliance = 1 / w_k: include/dsp_hip.h).  A form that is not positive semidefinite raises.
 """
 from __future__ import annotations
 
@@ -30,6 +36,41 @@ import numpy as np
 from .lp import StandardFormLP
 
 INF = float("inf")
+
+
+def factor_quadratic_form(quad: Dict, n: int, tol: float = 1e-12):
+    """sum_{(i,j)} q_ij x_i x_j  (free columns i, j; any order, repeated pairs add up)  ->  [(cols, vals, w_k)] with
+    sum_ij q_ij x_i x_j = sum_k (w_k / 2) (sum_t vals[t] x_cols[t])^2, w_k > 0.
+
+    LDL' without pivoting on the support of the form, in column order: x'Hx / 2 with H_ii = 2 q_ii, H_ij = H_ji = q_ij;
+    H = L D L' (L unit lower triangular) gives x'Hx = sum_k D_k (L[:, k] . x)^2.  A negative pivot, or a zero pivot with a
+    nonzero column below it, means H is not positive semidefinite (a zero pivot with a zero column is a direction the form
+    does not see: skipped)."""
+    support = sorted({i for ij in quad for i in ij})
+    pos = {j: k for k, j in enumerate(support)}
+    sN = len(support)
+    H = np.zeros((sN, sN))
+    for (i, j), q in quad.items():
+        if i == j:
+            H[pos[i], pos[i]] += 2.0 * q
+        else:
+            H[pos[i], pos[j]] += q
+            H[pos[j], pos[i]] += q
+    scale = max(1.0, float(np.abs(H).max())) if sN else 1.0
+    rows = []
+    for k in range(sN):
+        d = H[k, k]
+        below = H[k + 1:, k]
+        if d < -tol * scale or (d <= tol * scale and np.abs(below).max(initial=0.0) > 1e-9 * scale):
+            raise ValueError("the quadratic objective is not convex (its matrix is not positive semidefinite): the HIP backend "
+                             "takes convex quadratic objectives only")
+        if d <= tol * scale:
+            continue
+        l = np.concatenate([[1.0], below / d])
+        H[k + 1:, k + 1:] -= d * np.outer(l[1:], l[1:])
+        nz = np.nonzero(np.abs(l) > 1e-14)[0]
+        rows.append(([support[k + t] for t in nz], [float(l[t]) for t in nz], float(d)))
+    return rows
 
 
 def _pyomo():
@@ -58,6 +99,8 @@ class PyomoLP:
         self._vars: List = []
         self._rows: List = []                    # constraint data objects kept as rows
         self._pattern = None
+        self._quad: Dict = {}
+        self._soft: List = []
         self.flatten()
 
     # ---- walking ------------------------------------------------------------------------------------------------------
@@ -117,17 +160,34 @@ class PyomoLP:
             names.append(con.name)
             self._rows.append(con)
         c, c0 = self._objective_vector(n)
+        # convex quadratic objective -> soft rows behind the constraint rows (module docstring)
+        self._soft = factor_quadratic_form(self._quad, n) if self._quad else []
+        compliance = [0.0] * len(self._rows)
+        for k, (cols, vals, w) in enumerate(self._soft):
+            order = np.argsort(cols)
+            indices.extend(int(cols[t]) for t in order)
+            data.extend(float(vals[t]) for t in order)
+            indptr.append(len(indices))
+            rlo.append(0.0)
+            rhi.append(0.0)
+            names.append(f"objective_quadratic[{k}]")
+            compliance.append(1.0 / w)
         lb, ub = self._bounds()
         self._pattern = (np.asarray(indptr, np.int32), np.asarray(indices, np.int32), np.asarray(data, np.float64))
-        self.lp = StandardFormLP(n=n, m=len(self._rows), indptr=self._pattern[0], indices=self._pattern[1],
+        self.lp = StandardFormLP(n=n, m=len(self._rows) + len(self._soft), indptr=self._pattern[0], indices=self._pattern[1],
                                  data=self._pattern[2], c=c, c0=c0, lb=lb, ub=ub,
                                  rlo=np.asarray(rlo, np.float64), rhi=np.asarray(rhi, np.float64),
-                                 col_names=[v.name for v in self._vars], row_names=names)
+                                 col_names=[v.name for v in self._vars], row_names=names,
+                                 row_compliance=(np.asarray(compliance, np.float64) if self._soft else None))
         return self.lp
 
     def _objective_vector(self, n):
+        """(c, c0) of the minimised objective; a quadratic part is left in self._quad as {(col_i, col_j): coefficient}."""
         obj = self._active_objective()
-        r = self._linear(obj.expr, "objective")
+        r = self._repn(obj.expr, compute_values=True)
+        quadratic = not r.is_linear()
+        if quadratic and not (getattr(r, "is_quadratic", lambda: False)() and getattr(r, "nonlinear_expr", None) is None):
+            raise ValueError("objective is neither linear nor quadratic: the HIP backend solves LPs and convex QPs only")
         sign = -1.0 if getattr(obj, "sense", 1) in (-1, "maximize") else 1.0        # the solver minimises
         c = np.zeros(n)
         c0 = float(r.constant)
@@ -136,6 +196,19 @@ class PyomoLP:
                 c0 += float(a) * float(v.value)
             else:
                 c[self._cols[id(v)]] += float(a)
+        quad: Dict = {}
+        if quadratic:
+            for (v1, v2), q in zip(r.quadratic_vars, r.quadratic_coefs):
+                q = float(q)
+                if v1.fixed and v2.fixed:
+                    c0 += q * float(v1.value) * float(v2.value)
+                elif v1.fixed or v2.fixed:
+                    fx, fr = (v1, v2) if v1.fixed else (v2, v1)
+                    c[self._cols[id(fr)]] += q * float(fx.value)
+                else:
+                    i, j = sorted((self._cols[id(v1)], self._cols[id(v2)]))
+                    quad[(i, j)] = quad.get((i, j), 0.0) + sign * q
+        self._quad = {ij: q for ij, q in quad.items() if q != 0.0}
         self.objective_sign = sign
         return sign * c, sign * c0
 
@@ -164,7 +237,13 @@ class PyomoLP:
                                  "variable there; the batched solver shares ONE matrix across solves - flatten again")
             rlo[i] = lo - const if np.isfinite(lo) else -INF
             rhi[i] = hi - const if np.isfinite(hi) else INF
+        rlo[len(self._rows):] = 0.0
+        rhi[len(self._rows):] = 0.0
+        quad_was = dict(self._quad)
         lp.c, lp.c0 = self._objective_vector(lp.n)
+        if set(quad_was) != set(self._quad) or any(abs(quad_was[k] - q) > 1e-12 * max(1.0, abs(q)) for k, q in self._quad.items()):
+            raise ValueError("the quadratic part of the objective changed since flatten(): its factors are rows of the shared "
+                             "matrix - flatten again")
         lp.lb, lp.ub = self._bounds()
         lp.rlo, lp.rhi = rlo, rhi
         return lp
@@ -176,4 +255,4 @@ class PyomoLP:
 
     def objective_value(self, x):
         """Objective in the model's own sense (a maximisation problem reports the maximum)."""
-        return self.objective_sign * (float(self.lp.c @ np.asarray(x, float)) + self.lp.c0)
+        return self.objective_sign * self.lp.objective(np.asarray(x, float))

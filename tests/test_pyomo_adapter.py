@@ -93,8 +93,34 @@ class Block:
         return iter({VarData: self.vars, ConData: self.cons, ObjData: self.objs}[ctype])
 
 
+class QuadExpr:
+    """Linear expression + products of two variables (what Pyomo holds for an expanded sum of squares)."""
+
+    def __init__(self, lin, quad):
+        self.lin, self.quad = lin, list(quad)          # quad: (coef, var1, var2)
+
+    @staticmethod
+    def square(expr, weight):
+        """(weight / 2) * expr^2 for a constant-free linear Expr, expanded into products."""
+        assert Expr._val(expr.const) == 0.0
+        q = [(0.5 * weight * Expr._val(a) * Expr._val(b), u, v) for a, u in expr.terms for b, v in expr.terms]
+        return QuadExpr(Expr(), q)
+
+    def __add__(self, o):
+        if isinstance(o, QuadExpr):
+            return QuadExpr(self.lin + o.lin, self.quad + o.quad)
+        return QuadExpr(self.lin + o, self.quad)
+
+    __radd__ = __add__
+
+
 class Repn:
     def __init__(self, expr):
+        self.quadratic_vars, self.quadratic_coefs, self.nonlinear_expr = [], [], None
+        if isinstance(expr, QuadExpr):
+            self.quadratic_vars = [(u, v) for _, u, v in expr.quad]
+            self.quadratic_coefs = [q for q, _, _ in expr.quad]
+            expr = expr.lin
         acc = {}
         for c, v in expr.terms:
             acc.setdefault(id(v), [v, 0.0])[1] += Expr._val(c)
@@ -103,11 +129,14 @@ class Repn:
         self.constant = Expr._val(expr.const)
 
     def is_linear(self):
-        return True
+        return not self.quadratic_vars
+
+    def is_quadratic(self):
+        return bool(self.quadratic_vars)
 
 
 def generate_standard_repn(expr, compute_values=True):
-    return Repn(expr if isinstance(expr, Expr) else Expr([(1.0, expr)]))
+    return Repn(expr if isinstance(expr, (Expr, QuadExpr)) else Expr([(1.0, expr)]))
 
 
 CTYPES = (VarData, ConData, ObjData)
@@ -214,3 +243,109 @@ def test_maximisation_and_nonlinear_rejection():
             return False
     with pytest.raises(ValueError, match="not linear"):
         PyomoLP(b, ctypes=CTYPES, generate_standard_repn=lambda e, compute_values=True: NL(e if isinstance(e, Expr) else Expr([(1.0, e)])))
+
+
+# ---- convex quadratic objectives (BASELINE config 5) ------------------------------------------------------------------------
+def _qp_bracket(lp):
+    """Certified bracket of the optimal value of an LP with soft rows (oracle/qp_cutting_plane.py: Kelley on the LP oracle)."""
+    from types import SimpleNamespace
+
+    import scipy.sparse as sp
+    from oracle.qp_cutting_plane import solve_qp_bracket
+    soft = lp.row_compliance > 0
+    A = lp.csr()
+    P = SimpleNamespace(A=A[~soft], c=lp.c, c0=lp.c0, lo=lp.rlo[~soft], hi=lp.rhi[~soft], lb=lp.lb, ub=lp.ub)
+    M = sp.diags(1.0 / np.sqrt(lp.row_compliance[soft])) @ A[soft]            # |M x|^2 / 2 = sum (a.x)^2 / (2 kappa)
+    return solve_qp_bracket(P, M, 1.0, gap_rel=1e-10)
+
+
+def test_quadratic_objective_becomes_sparse_soft_rows(rts309):
+    """A ramp cost (rho / 2) sum_t (P_t - P_{t-1})^2, P_t = 1e-3 (grid_t + batt_out_t), handed over the way Pyomo holds it -
+    expanded into products of variables - comes out as soft rows: same objective for any x, as many rows as the form has rank,
+    the same optimum as the formulation that lists the squares directly, and refresh() keeps it."""
+    rho = 40.0
+    cf, D = list(rts309["rt_cf"][:4]), [0.0, 1.5, 15.0, 24.5]
+    blk, cfp, disp, soc_init = build_tracking_model(cf, D)
+    G = [v for v in blk.vars if v.name.startswith("grid[")]
+    O = [v for v in blk.vars if v.name.startswith("batt_out[")]
+    obj = blk.objs[0]
+    ramps = [1e-3 * G[t] + 1e-3 * O[t] - 1e-3 * G[t - 1] - 1e-3 * O[t - 1] for t in range(1, 4)]
+    quad = QuadExpr(obj.expr, [])
+    for r in ramps:
+        quad = quad + QuadExpr.square(r, rho)
+    blk.objs[0] = ObjData(quad, sense=1)
+    P = PyomoLP(blk, ctypes=CTYPES, generate_standard_repn=generate_standard_repn)
+    lp = P.lp
+    soft = np.nonzero(lp.row_compliance > 0)[0]
+    assert len(soft) == 3 and lp.m == 8 * 4 + 3                        # rank of the form = number of ramps
+    assert (np.diff(lp.indptr)[soft] <= 4).all()                         # LDL' in column order keeps the rows short
+    assert (lp.rlo[soft] == 0).all() and (lp.rhi[soft] == 0).all()
+    # the same objective for any x
+    rng = np.random.default_rng(3)
+    cols = {v.name: j for j, v in enumerate(P._vars)}
+    for _ in range(5):
+        x = rng.random(lp.n) * 1e4
+        direct = float(lp.c @ x + lp.c0)
+        for t in range(1, 4):
+            p1 = 1e-3 * (x[cols[f"grid[{t}]"]] + x[cols[f"batt_out[{t}]"]])
+            p0 = 1e-3 * (x[cols[f"grid[{t - 1}]"]] + x[cols[f"batt_out[{t - 1}]"]])
+            direct += 0.5 * rho * (p1 - p0) ** 2
+        assert lp.objective(x) == pytest.approx(direct, rel=1e-11)
+        assert P.objective_value(x) == pytest.approx(direct, rel=1e-11)
+    # the same optimum as the squares listed directly (another factorisation of the same form)
+    got = _qp_bracket(lp)
+    import scipy.sparse as sp
+    from dispatches_amd.lp import StandardFormLP
+    hard = lp.row_compliance == 0
+    A = lp.csr()
+    rows = []
+    for t in range(1, 4):
+        r = np.zeros(lp.n)
+        for nm, sg in ((f"grid[{t}]", 1e-3), (f"batt_out[{t}]", 1e-3), (f"grid[{t - 1}]", -1e-3), (f"batt_out[{t - 1}]", -1e-3)):
+            r[cols[nm]] += sg
+        rows.append(r)
+    A2 = sp.vstack([A[hard], sp.csr_matrix(np.array(rows))]).tocsr()
+    lp2 = StandardFormLP(n=lp.n, m=A2.shape[0], indptr=A2.indptr.astype(np.int32), indices=A2.indices.astype(np.int32), data=A2.data,
+                         c=lp.c, c0=lp.c0, lb=lp.lb, ub=lp.ub, rlo=np.concatenate([lp.rlo[hard], np.zeros(3)]),
+                         rhi=np.concatenate([lp.rhi[hard], np.zeros(3)]), col_names=lp.col_names, row_names=None,
+                         row_compliance=np.concatenate([np.zeros(int(hard.sum())), np.full(3, 1.0 / rho)]))
+    ref = _qp_bracket(lp2)
+    tol = 1e-8 * (1 + abs(ref["upper"]))
+    assert got["lower"] <= ref["upper"] + tol and ref["lower"] <= got["upper"] + tol
+    assert got["upper"] - got["lower"] <= 1e-8 * (1 + abs(got["upper"]))
+    # the ramp cost must matter here (otherwise the test pins nothing): the LP optimum is lower
+    lp_only = StandardFormLP(**{**lp2.__dict__, "row_compliance": None, "m": int(hard.sum()), "indptr": A[hard].indptr.astype(np.int32),
+                                "indices": A[hard].indices.astype(np.int32), "data": A[hard].data, "rlo": lp.rlo[hard], "rhi": lp.rhi[hard]})
+    assert _solve(lp_only)[1] < ref["lower"] - 1e-3
+    # refresh: Params move the linear part, the factors stay; a changed quadratic coefficient is refused
+    disp[1].value = 3.0
+    P.refresh()
+    assert (P.lp.row_compliance[soft] > 0).all() and P.lp.rlo[8 * 1 + 7] == pytest.approx(3.0)
+    blk.objs[0] = ObjData(quad + QuadExpr.square(ramps[0], 1.0), sense=1)
+    with pytest.raises(ValueError, match="quadratic part of the objective changed"):
+        P.refresh()
+
+
+def test_nonconvex_and_concave_quadratics():
+    b = Block()
+    x, y = VarData("x", -5.0, 5.0), VarData("y", -5.0, 5.0)
+    b.vars += [x, y]
+    b.cons += [ConData("c", x + y, upper=6.0)]
+    b.objs.append(ObjData(QuadExpr(Expr([(1.0, x)]), [(1.0, x, x), (-1.0, y, y)]), sense=1))          # x^2 - y^2: indefinite
+    with pytest.raises(ValueError, match="not convex"):
+        PyomoLP(b, ctypes=CTYPES, generate_standard_repn=generate_standard_repn)
+    b.objs[0] = ObjData(QuadExpr(Expr([(1.0, x)]), [(1.0, x, y)]), sense=1)                            # x y: zero pivot, nonzero column
+    with pytest.raises(ValueError, match="not convex"):
+        PyomoLP(b, ctypes=CTYPES, generate_standard_repn=generate_standard_repn)
+    # maximising a concave form is a convex problem: max x - (x - y)^2 - y^2  ->  (x, y) = (1, 1/2), value 1/2
+    b.objs[0] = ObjData(QuadExpr(Expr([(1.0, x)]), [(-1.0, x, x), (2.0, x, y), (-2.0, y, y)]), sense=-1)
+    P = PyomoLP(b, ctypes=CTYPES, generate_standard_repn=generate_standard_repn)
+    assert (P.lp.row_compliance > 0).sum() == 2
+    assert P.objective_value(np.array([1.0, 0.5])) == pytest.approx(0.5)
+    br = _qp_bracket(P.lp)
+    assert -br["upper"] == pytest.approx(0.5, abs=1e-7) and br["x"] == pytest.approx([1.0, 0.5], abs=1e-3)
+    # a fixed variable inside a product moves into the linear part
+    y.fix(0.5)
+    P2 = PyomoLP(b, ctypes=CTYPES, generate_standard_repn=generate_standard_repn)
+    assert P2.lp.n == 1 and (P2.lp.row_compliance > 0).sum() == 1
+    assert P2.objective_value(np.array([1.0])) == pytest.approx(0.5)
