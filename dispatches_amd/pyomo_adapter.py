@@ -256,3 +256,101 @@ class PyomoLP:
     def objective_value(self, x):
         """Objective in the model's own sense (a maximisation problem reports the maximum)."""
         return self.objective_sign * self.lp.objective(np.asarray(x, float))
+
+
+class PyomoScenarioBatch:
+    """B structurally identical Pyomo blocks (the reference's `model.fs[i]`, one per price scenario) as ONE batch for
+    `HipPdlpSolver.solve`: the batch-model protocol of dispatches_amd/workflow/batch_model.py (lp, n_scenario, c, c0,
+    scenario_bounds(), store_solution(), solver_hints) over a list of `PyomoLP` views.  The blocks must flatten to the same
+    matrix (same variables, rows and coefficients in the same order; soft rows of a quadratic objective included) - they
+    differ in what a batch may differ in: objective vector and constant, variable bounds, row bounds."""
+
+    def __init__(self, blocks, objectives=None, ctypes=None, generate_standard_repn: Optional[Callable] = None,
+                 solver_hints: Optional[dict] = None):
+        blocks = list(blocks)
+        if not blocks:
+            raise ValueError("no scenario blocks")
+        objectives = list(objectives) if objectives is not None else [None] * len(blocks)
+        self.views = [PyomoLP(b, objective=o, ctypes=ctypes, generate_standard_repn=generate_standard_repn)
+                      for b, o in zip(blocks, objectives)]
+        ref = self.views[0]
+        for i, v in enumerate(self.views[1:], 1):
+            same = (v.lp.n == ref.lp.n and v.lp.m == ref.lp.m and all(np.array_equal(a, b) for a, b in zip(v._pattern, ref._pattern))
+                    and np.array_equal(v.lp.row_compliance if v.lp.row_compliance is not None else 0.0,
+                                       ref.lp.row_compliance if ref.lp.row_compliance is not None else 0.0))
+            if not same:
+                raise ValueError(f"scenario block {i} does not flatten to the matrix of block 0: a batch shares ONE constraint matrix")
+        self.lp = ref.lp
+        self.n_scenario = len(self.views)
+        self.solver_hints = dict(solver_hints or {})
+        self.solve_handle = None
+        self.x = self.y = self.objective = self.status = self.iterations = None
+        self._stack()
+
+    def _stack(self):
+        vs = self.views
+        self.c = np.stack([v.lp.c for v in vs])
+        self.c0 = np.array([v.lp.c0 for v in vs], np.float64)
+        self.lb, self.ub = np.stack([v.lp.lb for v in vs]), np.stack([v.lp.ub for v in vs])
+        self.rlo, self.rhi = np.stack([v.lp.rlo for v in vs]), np.stack([v.lp.rhi for v in vs])
+
+    def refresh(self):
+        for v in self.views:
+            v.refresh()
+        self._stack()
+
+    def scenario_bounds(self):
+        return self.lb, self.ub, self.rlo, self.rhi
+
+    def store_solution(self, x, y, objective, status, iterations=None):
+        self.x, self.y = np.asarray(x), np.asarray(y)
+        self.status = np.asarray(status)
+        self.iterations = None if iterations is None else np.asarray(iterations)
+        # objectives in the models' own sense; solutions back into the Vars of every scenario that solved
+        self.objective = np.array([v.objective_sign * float(f) for v, f in zip(self.views, np.asarray(objective))])
+        for v, xi, st in zip(self.views, self.x, self.status):
+            if st == 0:
+                v.load_solution(xi)
+
+
+class HipPyomoSolver:
+    """Drop-in for the reference's `pyo.SolverFactory(name)` object (run_double_loop_battery.py:123) on populated LINEAR /
+    convex-quadratic Pyomo models: `solve(model)` flattens once, refreshes the mutable data on every later call, solves
+    all scenario blocks in one batch on the GPU and loads the solutions back into the Vars.
+
+        solver = HipPyomoSolver(device=0)
+        results = solver.solve(m)                      # one block with its own objective
+        results = solver.solve([m.fs[i] for i in m.fs.index_set()])     # one batch of identical scenario blocks
+
+    `backend` is the batched solver object (default: `HipPdlpSolver`, which fails loudly without the HIP library or a GPU;
+    the tests inject a CPU stand-in).  Written against Pyomo's public API, never run against a real Pyomo model (module
+    docstring)."""
+
+    def __init__(self, device: int = 0, backend=None, ctypes=None, generate_standard_repn: Optional[Callable] = None,
+                 solver_hints: Optional[dict] = None, **solver_options):
+        self._backend = backend
+        self._device, self._solver_options = device, solver_options
+        self._ctypes, self._repn, self._hints = ctypes, generate_standard_repn, solver_hints
+        self._batches: Dict[tuple, PyomoScenarioBatch] = {}
+
+    def available(self, exception_flag=False):
+        b = self._get_backend()
+        return b.available(exception_flag) if hasattr(b, "available") else True
+
+    def _get_backend(self):
+        if self._backend is None:
+            from .hip_solver import HipPdlpSolver
+            self._backend = HipPdlpSolver(device=self._device, **self._solver_options)
+        return self._backend
+
+    def solve(self, model, tee=False, objectives=None, **kwargs):
+        blocks = list(model) if isinstance(model, (list, tuple)) else [model]
+        key = tuple(id(b) for b in blocks)
+        batch = self._batches.get(key)
+        if batch is None:
+            batch = self._batches[key] = PyomoScenarioBatch(blocks, objectives, self._ctypes, self._repn, self._hints)
+        else:
+            batch.refresh()
+        results = self._get_backend().solve(batch, tee=tee)
+        self.last_batch = batch
+        return results

@@ -7,7 +7,7 @@ oracle, must refresh when Params / fixed values change, and must refuse changes 
 import numpy as np
 import pytest
 
-from dispatches_amd.pyomo_adapter import PyomoLP
+from dispatches_amd.pyomo_adapter import HipPyomoSolver, PyomoLP
 
 
 # ---- stand-ins for pyomo.core (duck-typed: only what the adapter touches) -------------------------------------------------
@@ -349,3 +349,38 @@ def test_nonconvex_and_concave_quadratics():
     P2 = PyomoLP(b, ctypes=CTYPES, generate_standard_repn=generate_standard_repn)
     assert P2.lp.n == 1 and (P2.lp.row_compliance > 0).sum() == 1
     assert P2.objective_value(np.array([1.0])) == pytest.approx(0.5)
+
+
+def test_solver_object_solves_scenario_blocks_as_one_batch(rts309):
+    """Route B of INTEGRATION.md end to end with stand-ins: `HipPyomoSolver.solve([blocks])` = one batch over identical
+    scenario blocks (different capacity factors / dispatch signals), solutions back in the Vars, refresh on the second call;
+    a block with another matrix is refused."""
+    from _highs_solver import HighsTestSolver
+    from oracle import dispatch_lp_oracle as orc
+    cfs = [list(rts309["rt_cf"][k:k + 4]) for k in (0, 5, 11)]
+    Ds = [[0.0, 1.5, 15.0, 24.5], [2.0, 2.0, 30.0, 1.0], [10.0, 0.0, 0.0, 5.0]]
+    built = [build_tracking_model(cf, D) for cf, D in zip(cfs, Ds)]
+    blocks = [b[0] for b in built]
+    solver = HipPyomoSolver(backend=HighsTestSolver(), ctypes=CTYPES, generate_standard_repn=generate_standard_repn)
+    res = solver.solve(blocks)
+    assert res.solver.termination_condition == "optimal"
+    batch = solver.last_batch
+    assert batch.n_scenario == 3 and batch.c.shape == (3, batch.lp.n)
+    for i, (cf, D) in enumerate(zip(cfs, Ds)):
+        ref = orc.wind_battery_track(4, cf, D)[0].solve()[1]
+        assert batch.objective[i] == pytest.approx(ref, rel=1e-9)
+        track = [v.value for v in blocks[i].vars if v.name.startswith("grid[") or v.name.startswith("batt_out[")]
+        assert all(t is not None for t in track)                                  # solution loaded into the Vars
+    # second call: Params changed in ONE scenario -> refreshed, same handle / matrix
+    for p, v in zip(built[1][2], [1.0, 12.0, 20.0, 3.0]):
+        p.value = v
+    lp_before = batch.lp
+    solver.solve(blocks)
+    assert solver.last_batch is batch and batch.lp is lp_before
+    assert batch.objective[1] == pytest.approx(orc.wind_battery_track(4, cfs[1], [1.0, 12.0, 20.0, 3.0])[0].solve()[1], rel=1e-9)
+    assert batch.objective[0] == pytest.approx(orc.wind_battery_track(4, cfs[0], Ds[0])[0].solve()[1], rel=1e-9)
+    # a block with a different matrix cannot join the batch
+    odd, *_ = build_tracking_model(cfs[0], Ds[0])
+    odd.cons[2].body = odd.cons[2].body + Expr([(0.5, odd.vars[7])])
+    with pytest.raises(ValueError, match="does not flatten to the matrix of block 0"):
+        HipPyomoSolver(backend=HighsTestSolver(), ctypes=CTYPES, generate_standard_repn=generate_standard_repn).solve([blocks[0], odd])
