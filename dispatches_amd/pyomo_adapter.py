@@ -82,6 +82,15 @@ def _pyomo():
     return Var, Constraint, Objective, generate_standard_repn
 
 
+def _num(x):
+    """float of a Pyomo numeric thing: plain numbers, and NumericValue objects (mutable Params, expressions of them - e.g.
+    `con.upper` of a constraint whose bound is a Param), which are evaluated by calling them."""
+    try:
+        return float(x)
+    except TypeError:
+        return float(x())
+
+
 class PyomoLP:
     """StandardFormLP view of a populated Pyomo block, refreshable after Param / bound / fix changes."""
 
@@ -132,8 +141,8 @@ class PyomoLP:
                 if j is None:
                     raise ValueError(f"variable {v.name} of constraint {con.name} is not a variable of the flattened block")
                 coefs[j] = coefs.get(j, 0.0) + a
-        lo = -INF if con.lower is None else float(con.lower)
-        hi = INF if con.upper is None else float(con.upper)
+        lo = -INF if con.lower is None else _num(con.lower)
+        hi = INF if con.upper is None else _num(con.upper)
         return coefs, const, lo, hi
 
     # ---- flatten once ---------------------------------------------------------------------------------------------------
@@ -213,8 +222,8 @@ class PyomoLP:
         return sign * c, sign * c0
 
     def _bounds(self):
-        lb = np.array([-INF if v.lb is None else float(v.lb) for v in self._vars], np.float64)
-        ub = np.array([INF if v.ub is None else float(v.ub) for v in self._vars], np.float64)
+        lb = np.array([-INF if v.lb is None else _num(v.lb) for v in self._vars], np.float64)
+        ub = np.array([INF if v.ub is None else _num(v.ub) for v in self._vars], np.float64)
         return lb, ub
 
     # ---- refresh between solves ---------------------------------------------------------------------------------------

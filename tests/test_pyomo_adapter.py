@@ -232,7 +232,11 @@ def test_maximisation_and_nonlinear_rejection():
     b = Block()
     x, y = VarData("x", 0.0, 4.0), VarData("y", 0.0, None)
     b.vars += [x, y]
-    b.cons += [ConData("c", x + y, upper=6.0)]
+
+    class Callable6:                      # a bound held as a NumericValue (mutable Param / expression): evaluated by calling it
+        def __call__(self):
+            return 6.0
+    b.cons += [ConData("c", x + y, upper=Callable6())]
     b.objs.append(ObjData(3.0 * x + 2.0 * y, sense=-1))
     P = PyomoLP(b, ctypes=CTYPES, generate_standard_repn=generate_standard_repn)
     xs, f = _solve(P.lp)
