@@ -301,6 +301,8 @@ def bench_qp_sweep(args, rank, local_rank, world, dev):
                 lone(o)
                 sweep.append(dict(precision="f32" if prec else "f64", eps_rel=eps, **lone(o)))
     # ---- the contract setting, pipelined ---------------------------------------------------------------------------
+    if args.eps is None:
+        args.eps = 1e-9
     opts = default_options(**{**hints, "eps_rel": args.eps})
     depth = args.streams if args.streams > 0 else 8
     streams = [torch.cuda.Stream(device=dev) for _ in range(depth)]
@@ -367,7 +369,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="wind_battery_24h")
     ap.add_argument("--batch", type=int, default=4096, help="scenarios per GPU")
-    ap.add_argument("--eps", type=float, default=1e-9)
+    ap.add_argument("--eps", type=float, default=None,
+                    help="eps_rel; default: the model family's solver hint if it has one, else 1e-9 (the contract setting)")
     ap.add_argument("--horizon", type=int, default=8736, help="--workload price_taker: hourly periods of the design LP")
     ap.add_argument("--cpu-sample", type=int, default=-1, help="scenarios for the CPU baseline (0 = skip)")
     ap.add_argument("--streams", type=int, default=0,
@@ -414,7 +417,7 @@ def main():
         return bench_price_taker(args, rank, local_rank, world, dev)
     if args.workload == "qp_sweep":
         return bench_qp_sweep(args, rank, local_rank, world, dev)
-    solver = HipPdlpSolver(device=local_rank, eps_rel=args.eps)
+    solver = HipPdlpSolver(device=local_rank, **({} if args.eps is None else {"eps_rel": args.eps}))
     fn, kw = scenarios.WORKLOADS[args.workload]
     if args.total > 0:
         # strong scaling: the SAME total batch at every N, rank r owns the contiguous shard shard_bounds(total, N, r)
@@ -438,7 +441,8 @@ def main():
     rlo_d, rhi_d = up(pick(rlo)), up(pick(rhi))
     c0 = model.c0[sl]
     # the model family's preconditioner hints (e.g. geo_iters of the nuclear flowsheet), as HipPdlpSolver applies them
-    opts = default_options(**{**(getattr(model, "solver_hints", None) or {}), "eps_rel": args.eps})
+    opts = default_options(**{**(getattr(model, "solver_hints", None) or {}), **({} if args.eps is None else {"eps_rel": args.eps})})
+    args.eps = float(opts.eps_rel)
     dlp = DeviceLP(lp, local_rank, opts)
     def new_out():
         return dict(x=torch.empty((B, lp.n), dtype=torch.float64, device=dev),
@@ -559,6 +563,20 @@ def main():
         solve_kernel = f"pdlp_solve_kernel<{int(st.cols_per_lane)}, {int(st.rows_per_lane)}," if geometry[3] else "pdlp_solve_kernel"
         pmc, pmc_file = _profiled_counters(solve_kernel)
         traffic = _profiled_traffic(solve_kernel)
+        # The SQ counters of a launch are proportional to the scenario-iterations it runs (hot loop + checks; the per-scenario
+        # prologue is < 1 %).  A profile records the iterations of its launch (profiles/<tag>_pmc_iterations.json); when the
+        # shipped options / model hints have changed the iteration count since (e.g. the column scaling of DESIGN 5a-4, adopted
+        # after the last PMC passes of round 2), the counters are scaled by the ratio so that instructions and time belong to the
+        # same work.  `counters_scaled_by` = 1 when nothing changed or no record exists.
+        counters_scaled_by = 1.0
+        if pmc_file:
+            rec_path = os.path.join(ROOT, "profiles", pmc_file.replace("_pmc_summary.csv", "_pmc_iterations.json"))
+            if os.path.exists(rec_path):
+                rec = json.load(open(rec_path))
+                per_launch = next((v for k, v in rec.items() if k in solve_kernel or solve_kernel in k), None)
+                if per_launch:
+                    counters_scaled_by = float(np.mean(sum_iters)) / float(per_launch)
+                    pmc = {k: (v * counters_scaled_by if k.startswith("SQ_") else v) for k, v in pmc.items()}
         valu_frac = lds_frac = valu_rate = None
         if "SQ_INSTS_VALU" in pmc:
             valu_rate = pmc["SQ_INSTS_VALU"] / step_s                         # wave-instructions / s, sustained
@@ -572,7 +590,7 @@ def main():
             unit="G FP64-wave-instr/s", frac=valu_frac, frac_lds=lds_frac,
             traffic=traffic, true_io_bytes_per_launch=true_io,
             traffic_over_true_io=(traffic / true_io) if traffic else None,
-            counters_from=pmc_file, step_ms=1e3 * step_s, kernel_latency_ms=k_ms,
+            counters_from=pmc_file, counters_scaled_by=counters_scaled_by, step_ms=1e3 * step_s, kernel_latency_ms=k_ms,
             spmv_flops=dict(achieved=flops, peak=FP64_VECTOR_PEAK_TFLOPS, unit="TFLOP/s", frac=flops / FP64_VECTOR_PEAK_TFLOPS,
                             note="4 nnz flop per scenario-iteration (SURVEY 8(d)); the SpMV FMAs are 16 of the ~52 FP64 "
                                  "ops of an iteration, the rest is the PDHG update / Halpern step on the same registers"),

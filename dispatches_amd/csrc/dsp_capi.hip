@@ -290,6 +290,9 @@ int dsp_create(const dsp_lp_desc *d, int device, const dsp_options *opt, dsp_han
       if (!std::isfinite(d->A_val[p])) return DSP_ERR_INVALID;
     }
   }
+  if (d->col_scale)
+    for (int j = 0; j < d->n; ++j)
+      if (!(d->col_scale[j] > 0.0) || !std::isfinite(d->col_scale[j])) return DSP_ERR_INVALID;
   static const int kCpl[] = {1, 2, 3, 4, 5, 7, 10};
   static const int kRpl[] = {1, 2, 3, 4, 6};
   int cpl = pick(kCpl, 7, (d->n + 63) / 64);
@@ -318,7 +321,7 @@ int dsp_create(const dsp_lp_desc *d, int device, const dsp_options *opt, dsp_han
   A.idx.assign(d->A_colidx, d->A_colidx + d->nnz);
   A.val.assign(d->A_val, d->A_val + d->nnz);
   HostCSR Au = A;                                   // unscaled copy (streaming SpMV step)
-  equilibrate(A, h->opt.ruiz_iters, h->dr, h->dc, std::max(0, h->opt.geo_iters));
+  equilibrate(A, h->opt.ruiz_iters, h->dr, h->dc, std::max(0, h->opt.geo_iters), d->col_scale);
   HostCSR AT = transpose(A), ATu = transpose(Au);
   h->eta_unit = 1.0 / spectral_norm(A, AT, 500);
   if (streaming) {

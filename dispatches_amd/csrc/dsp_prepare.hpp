@@ -42,8 +42,12 @@ inline HostCSR transpose(const HostCSR &A) {
 }
 
 // Ruiz (inf-norm, `iters` passes) followed by Pock-Chambolle (alpha = 1).  A is scaled in place:
-// A <- diag(dr) A diag(dc).
-inline void equilibrate(HostCSR &A, int ruiz_iters, std::vector<double> &dr, std::vector<double> &dc, int geo_iters = 0) {
+// A <- diag(dr) A diag(dc).  `col0` (optional, [n], > 0): the caller's variable scaling factors - typical magnitudes of the
+// columns, x_j = col0_j x~_j - applied BEFORE the equilibration and folded into dc (dsp_lp_desc::col_scale): Ruiz and
+// Pock-Chambolle balance the matrix, they know nothing about the ranges the variables live in (kW next to MW next to kWh of
+// throughput: 8 decades in the wind + battery LP), and the fixed point they reach depends on where they start.
+inline void equilibrate(HostCSR &A, int ruiz_iters, std::vector<double> &dr, std::vector<double> &dc, int geo_iters = 0,
+                        const double *col0 = nullptr) {
   dr.assign(A.m, 1.0); dc.assign(A.n, 1.0);
   std::vector<double> rs(A.m), cs(A.n);
   auto apply = [&]() {
@@ -52,6 +56,11 @@ inline void equilibrate(HostCSR &A, int ruiz_iters, std::vector<double> &dr, std
     for (int i = 0; i < A.m; ++i) dr[i] *= rs[i];
     for (int j = 0; j < A.n; ++j) dc[j] *= cs[j];
   };
+  if (col0) {
+    std::fill(rs.begin(), rs.end(), 1.0);
+    for (int j = 0; j < A.n; ++j) cs[j] = col0[j];
+    apply();
+  }
   // optional geometric-mean passes: r_i = 1/sqrt(max_j|a_ij| min_j|a_ij|), then the same for columns
   for (int it = 0; it < geo_iters; ++it) {
     std::vector<double> mx(A.m, 0.0), mn(A.m, INFINITY);

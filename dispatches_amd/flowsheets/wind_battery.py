@@ -42,6 +42,10 @@ def create_multiperiod_wind_battery_model(b, n_time_points, wind_cfs, input_para
 
 
 class MultiPeriodWindBattery:
+    # scaling hint for the HIP solver: column ranges implied by the bounds (lp.implied_column_ranges) - this LP mixes kW, MW and
+    # (wind + battery) kWh of accumulated throughput; the reference sets IDAES scaling factors on the same variables
+    column_scaling = "implied_ranges"
+
     def __init__(self, model_data, wind_capacity_factors=None, wind_pmax_mw=200.0, battery_pmax_mw=25.0,
                  battery_energy_capacity_mwh=100.0):
         self.model_data = model_data

@@ -30,10 +30,14 @@ def create_multiperiod_wind_pem_model(b, n_time_points, wind_cfs, input_params):
 
 
 class MultiPeriodWindPEM:
+    # scaling hint for the HIP solver: column ranges implied by the bounds (lp.implied_column_ranges) - this LP mixes kW, MW and
+    # (wind + battery) kWh of accumulated throughput; the reference sets IDAES scaling factors on the same variables
+    column_scaling = "implied_ranges"
+
     # cadence hint for the HIP solver (include/dsp_hip.h check_every): this LP has no storage state, its active set is found
     # after a few hundred iterations and the ray jump (tested at checks) finishes it - checking every 12 iterations instead
     # of 16 takes 30 % off the iteration count (profiles/r04v_knob_scan2.log, r04w_cadence.log: 4.1 -> 5.3 M scenarios/s)
-    bidding_solver_hints = {"check_every": 12}
+    bidding_solver_hints = {"check_every": 12, "eps_rel": 1e-10}
 
     def __init__(self, model_data, wind_capacity_factors, wind_pmax_mw=200.0, pem_pmax_mw=25.0):
         self.model_data = model_data

@@ -58,7 +58,7 @@ class DspStats(C.Structure):
 class DspLpDesc(C.Structure):
     _fields_ = [("n", C.c_int32), ("m", C.c_int32), ("nnz", C.c_int64),
                 ("A_rowptr", C.POINTER(C.c_int32)), ("A_colidx", C.POINTER(C.c_int32)),
-                ("A_val", C.POINTER(C.c_double))]
+                ("A_val", C.POINTER(C.c_double)), ("col_scale", C.POINTER(C.c_double))]
 
 
 class DspWbModel(C.Structure):
@@ -84,7 +84,7 @@ EXPORTED_SYMBOLS = ("dsp_default_options", "dsp_create", "dsp_solve", "dsp_spmv_
                     "dsp_rtc_compile_check", "dsp_rtc_message", "dsp_wb_rolling_update")
 
 
-ABI_VERSION = 5          # DSP_VERSION of the include/dsp_hip.h these structures mirror
+ABI_VERSION = 6          # DSP_VERSION of the include/dsp_hip.h these structures mirror
 
 
 def load_library(path: Optional[str] = None):
@@ -173,10 +173,14 @@ class DeviceLP:
         self._rowptr = np.ascontiguousarray(lp.indptr, np.int32)
         self._colidx = np.ascontiguousarray(lp.indices, np.int32)
         self._val = np.ascontiguousarray(lp.data, np.float64)
+        # variable scaling factors of the model family (StandardFormLP.col_scale: typical column magnitudes), if it has any
+        cs = getattr(lp, "col_scale", None)
+        self._col_scale = None if cs is None else np.ascontiguousarray(cs, np.float64)
         desc = DspLpDesc(lp.n, lp.m, int(self._rowptr[-1]),
                          self._rowptr.ctypes.data_as(C.POINTER(C.c_int32)),
                          self._colidx.ctypes.data_as(C.POINTER(C.c_int32)),
-                         self._val.ctypes.data_as(C.POINTER(C.c_double)))
+                         self._val.ctypes.data_as(C.POINTER(C.c_double)),
+                         None if self._col_scale is None else self._col_scale.ctypes.data_as(C.POINTER(C.c_double)))
         h = C.c_void_p()
         torch.cuda.set_device(device)
         _check(self.lib, self.lib.dsp_create(C.byref(desc), device, C.byref(options) if options else None, C.byref(h)),

@@ -153,6 +153,9 @@ class StandardFormLP:
     # objective term (a_i.x - b_i)^2 / (2 kappa_i), b_i = its (equal) row bounds - the factored form Q = sum_i a_i a_i^T /
     # kappa_i of a convex quadratic objective, which first-order solvers take in the DUAL (LinearBlock.quadratic)
     row_compliance: Optional[np.ndarray] = None
+    # variable scaling factors: the typical magnitude of each column (x_j = s_j x~_j, x~ of order one), handed to the solver as
+    # dsp_lp_desc::col_scale - what an IDAES model carries as iscale.set_scaling_factor (there 1 / s).  None = none.
+    col_scale: Optional[np.ndarray] = None
 
     @property
     def nnz(self) -> int:
@@ -187,6 +190,42 @@ class StandardFormLP:
             hard = 1.0 if self.row_compliance is None else (self.row_compliance == 0)       # soft rows constrain nothing
             v = max(v, np.max(np.maximum(rlo - ax, 0) * hard), np.max(np.maximum(ax - rhi, 0) * hard))
         return float(v)
+
+
+def implied_column_ranges(lp: "StandardFormLP", lb=None, ub=None, passes: int = 4) -> np.ndarray:
+    """Typical magnitude of every column from what the model itself says: ub - lb where both are finite (per-scenario bound
+    arrays: the widest over the scenarios), and for an unbounded column j the largest |a_ik| range_k / |a_ij| over the rows i it
+    shares with a ranged column k - the most it can be asked to balance (`passes` Gauss-Seidel sweeps in column order so that
+    chains such as splitter outlet -> day-ahead power resolve).  Columns nothing can be said about, and fixed ones, get 1.
+
+    The flowsheets of the reference mix kW (1e5), MW (1e2) and kWh of accumulated throughput (1e8) in one LP; Ruiz / Pock-Chambolle
+    equilibration balances the MATRIX and is blind to these ranges.  Started from them the wind + battery bidding LPs need 20-30 %
+    fewer PDHG iterations, the wind + PEM ones 60 % fewer (tools/pdlp_lab.py `colscale`)."""
+    lb = lp.lb if lb is None else np.asarray(lb, float)
+    ub = lp.ub if ub is None else np.asarray(ub, float)
+    lo = lb.min(axis=0) if lb.ndim == 2 else lb
+    hi = ub.max(axis=0) if ub.ndim == 2 else ub
+    with np.errstate(invalid="ignore"):
+        rng = hi - lo
+    fill = np.where(np.isfinite(rng), rng, np.nan)
+    A = lp.csr()
+    Ac = A.tocsc()
+    absA = abs(A).tocsr()
+    for _ in range(int(passes)):
+        for j in np.nonzero(~np.isfinite(fill))[0]:
+            best = 0.0
+            for p in range(Ac.indptr[j], Ac.indptr[j + 1]):
+                i, aij = Ac.indices[p], abs(Ac.data[p])
+                if aij == 0.0:
+                    continue
+                ks = absA.indices[absA.indptr[i]:absA.indptr[i + 1]]
+                vs = absA.data[absA.indptr[i]:absA.indptr[i + 1]]
+                ok = (ks != j) & np.isfinite(fill[ks]) & (fill[ks] > 0)
+                if ok.any():
+                    best = max(best, float((vs[ok] * fill[ks[ok]]).max() / aij))
+            if best > 0.0:
+                fill[j] = best
+    return np.where(np.isfinite(fill) & (fill > 0), fill, 1.0)
 
 
 class LinearBlock:

@@ -178,6 +178,14 @@ class StochasticProgramBidder(AbstractBidder):
             model.PT_matrix = np.stack([P_T[t].dense(n) for t in model.HOUR])          # [T, n]
             model.PT_const = np.array([P_T[t].const for t in model.HOUR])
             model.pda_cols = np.array([v.index for v in model.day_ahead_power])
+            # variable scaling factors of the model family (StandardFormLP.col_scale): ranges implied by the widest bounds the
+            # columns may ever take (declared hulls), for the model objects that ask for them
+            # (only LPs the first-order kernels solve: the hourly 4-h problems go to the in-wave simplex, which works on the
+            # equilibrated tableau and was validated without them)
+            if getattr(self.bidding_model_object, "column_scaling", None) == "implied_ranges" and model.lp.n + model.lp.m > 128:
+                from ..lp import implied_column_ranges
+                hull = np.array(block.col_hull, float)
+                model.lp.col_scale = implied_column_ranges(model.lp, np.minimum(hull[:, 0], block.col_lb), np.maximum(hull[:, 1], block.col_ub))
         model.base_c = objective.dense(model.lp.n)
         model.base_c0 = objective.const
 

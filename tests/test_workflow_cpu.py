@@ -109,10 +109,20 @@ def test_solver_hints_of_a_model_family_reach_the_right_lps():
     own hints for its small, badly scaled LPs must not be overridden by a bidding cadence)."""
     from dispatches_amd import scenarios
     bidder, model = scenarios.make_batch("wind_pem_48h", 2, HighsTestSolver())
-    assert model.solver_hints == {"check_every": 12}
-    assert bidder.real_time_model.solver_hints == {"check_every": 12}
+    assert model.solver_hints == {"check_every": 12, "eps_rel": 1e-10}
+    assert bidder.real_time_model.solver_hints == model.solver_hints
+    # variable scaling factors: asked for by the wind flowsheets, for the LPs the first-order kernels solve (not the 4-h ones)
+    assert model.lp.col_scale is not None and bidder.real_time_model.lp.col_scale is None
+    names = model.lp.col_names
+    assert model.lp.col_scale[names.index("day_ahead_power[3]")] == pytest.approx(847.0)
+    assert model.lp.col_scale[names.index("splitter.grid_elec[3]")] == pytest.approx(847e3)
     bidder, model = scenarios.make_batch("nuclear_24h", 2, HighsTestSolver())
-    assert model.solver_hints == {"geo_iters": 8}
+    assert model.solver_hints == {"geo_iters": 8} and model.lp.col_scale is None
+    bidder, model = scenarios.make_batch("wind_battery_24h", 2, HighsTestSolver())
+    cs = dict(zip(model.lp.col_names, model.lp.col_scale))
+    assert cs["windpower.electricity[5]"] == pytest.approx(200e3) and cs["battery.elec_out[5]"] == pytest.approx(25e3)
+    assert cs["battery.state_of_charge[5]"] == pytest.approx(100e3) and cs["day_ahead_power[5]"] == pytest.approx(200.0)
+    assert cs["battery.energy_throughput[5]"] == pytest.approx(1e9)          # soc + 1e-4 throughput <= nameplate energy
     mp = MultiPeriodWindPEM(model_data=RenewableGeneratorModelData(**generator_params),
                             wind_capacity_factors=[0.5] * 48, wind_pmax_mw=pmax, pem_pmax_mw=25)
     tracker = Tracker(tracking_model_object=mp, tracking_horizon=4, n_tracking_hour=1, solver=HighsTestSolver())

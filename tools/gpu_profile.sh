@@ -36,3 +36,19 @@ with open(sys.argv[1], "w") as o:
             w.writerow([c, k, n, round(s / n, 1)])
 print(open(sys.argv[1]).read())
 PY
+# scenario-iterations of one launch of this command (bench.py scales the counters by live / recorded iterations when the shipped
+# options change the iteration count after a profile was taken)
+python - "$out/${tag}_bench.json" "$out/${tag}_pmc_iterations.json" <<'PY'
+import json, sys
+d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]); c = d["config"]
+grid = c.get("grid")
+key = "pdlp_solve_kernel"
+import csv, os
+summ = sys.argv[2].replace("_pmc_iterations.json", "_pmc_summary.csv")
+if os.path.exists(summ):
+    names = {r["kernel"] for r in csv.DictReader(open(summ)) if "pdlp_solve_kernel<" in r["kernel"]}
+    if len(names) == 1:
+        key = "pdlp_solve_kernel<" + ", ".join(next(iter(names)).split("pdlp_solve_kernel<")[1].split(", ")[:2]) + ","
+json.dump({key: c["mean_iterations"] * c["batch_per_gpu"]}, open(sys.argv[2], "w"))
+print(open(sys.argv[2]).read())
+PY
