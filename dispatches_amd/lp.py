@@ -208,6 +208,10 @@ def implied_column_ranges(lp: "StandardFormLP", lb=None, ub=None, passes: int = 
     with np.errstate(invalid="ignore"):
         rng = hi - lo
     fill = np.where(np.isfinite(rng), rng, np.nan)
+    # a long chain of derived columns (a storage recursion whose power bound is itself a free design variable: the price-taker
+    # LP) would multiply its way up; nothing derived may exceed 1e6 x the widest range the model states
+    stated = np.where(np.isfinite(rng) & (rng > 0), rng, 0.0)
+    cap = 1e6 * stated.max() if stated.any() else np.inf
     A = lp.csr()
     Ac = A.tocsc()
     absA = abs(A).tocsr()
@@ -224,7 +228,7 @@ def implied_column_ranges(lp: "StandardFormLP", lb=None, ub=None, passes: int = 
                 if ok.any():
                     best = max(best, float((vs[ok] * fill[ks[ok]]).max() / aij))
             if best > 0.0:
-                fill[j] = best
+                fill[j] = min(best, cap)
     return np.where(np.isfinite(fill) & (fill > 0), fill, 1.0)
 
 

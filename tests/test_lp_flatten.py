@@ -144,3 +144,26 @@ def test_presolve_never_lets_a_row_certify_itself():
     b.constraint("ramp", s1 - s0, -1e8, 1e8)
     lp = b.flatten(s1 * 1.0)
     assert lp.row_names == ["cap"]
+
+
+def test_implied_column_ranges_are_capped_along_chains():
+    """Ranges stated by bounds are kept; an unbounded column takes the largest |a_ik| range_k / |a_ij| it has to balance; a
+    recursion whose columns are all derived cannot multiply its way past 1e6 x the widest stated range."""
+    from dispatches_amd.lp import implied_column_ranges
+    b = LinearBlock()
+    x = b.var("x", 0.0, 50.0)
+    y = b.var("y")                                   # unbounded: y = 1e-3 x  ->  range 0.05
+    s0 = b.var("s[0]")                               # chain s[t] = 10 s[t-1], s[0] = x  ->  50, 500, ... capped at 5e7
+    b.equality("def_y", y - 1e-3 * x, 0.0)
+    b.equality("s_start", s0 - x, 0.0)
+    prev = s0
+    for t in range(1, 12):
+        st = b.var(f"s[{t}]")
+        b.equality(f"s_rec[{t}]", st - 10.0 * prev, 0.0)
+        prev = st
+    z = b.var("z", 3.0, 3.0)                         # fixed: nothing to scale
+    lp = b.flatten(x + y + prev + z, presolve=False)
+    r = dict(zip(lp.col_names, implied_column_ranges(lp)))
+    assert r["x"] == 50.0 and r["y"] == pytest.approx(0.05) and r["z"] == 1.0
+    assert r["s[0]"] == 50.0 and r["s[3]"] == pytest.approx(5e4)
+    assert r["s[11]"] == pytest.approx(5e7) and max(r.values()) <= 5e7 + 1
