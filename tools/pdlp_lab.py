@@ -274,10 +274,15 @@ if __name__ == "__main__":
     wl = sys.argv[1]
     ids, sub = subset(wl)
     ref = np.array([pp.highs_obj(sub, i)[0] for i in range(len(ids))])
-    variants = [dict(a.split("=") for a in v.split(",") if a and a != "gpu") if v != "gpu" else dict(GPU_DEFAULTS)
+    variants = [{**(GPU_DEFAULTS if "gpu" in v.split(",") else {}), **dict(a.split("=") for a in v.split(",") if a and a != "gpu")}
                 for v in sys.argv[2:]] or [{}]
+    # the product's variable scaling factors for this model family (lp.implied_column_ranges through the Bidder), if it asks for
+    # them: every variant runs with them unless it says colscale=0
+    product_scale = getattr(pp.build(wl, 4)[0].lp, "col_scale", None)
     for kw in variants:
-        kw = {k: (v if k in ("wrule", "r0_mode") else float(v)) for k, v in kw.items()}
+        kw = {k: (v if k in ("wrule", "r0_mode") or not isinstance(v, str) else float(v)) for k, v in kw.items()}
+        if kw.pop("colscale", 1.0) and product_scale is not None:
+            kw["colscale"] = product_scale
         t = time.time()
         X, Y, iters, nrs, done = solve(sub, **kw)
         obj = np.sum(sub.c * X, 1) + sub.c0
