@@ -29,7 +29,7 @@ def geo_scaling(A, iters=8):
 
 def solve(P, eps=1e-9, max_iter=60000, check=32, wrule="pid", kp=0.7, maxdl=np.log(30), r0_mode="k1",
           beta=(0.2, 0.8, 0.36), eta_scale=0.998, n_ruiz=10, wclamp=None, bal_gain=0.25, bal_thresh=10.0,
-          c0_gap=True, verbose=False, colscale=None, stall=0, stall_frac=0.5, kp_decay=0.5, xinit=0, term=0, eps_obj=1e-7, jump=0, jtol=1e-2, jsteady=0.05, jmin=4.0, winit=0.0, geo=0, jumpw=0, wfloor=0.0, jk=2.0, jacc=0.0, jchain=0, jland=-1.0, wfreeze=0, wfreeze_err=0.0, retry=0.0, retry_kps=(0.5, 0.35, 0.7, 0.25), rescue_k=0, rescue_mode=0, rescue_zone=0.0, jrel=0.0, polish=0, polish_mult=4.0, polish_max=3):
+          c0_gap=True, verbose=False, colscale=None, stall=0, stall_frac=0.5, kp_decay=0.5, xinit=0, term=0, eps_obj=1e-7, jump=0, jtol=1e-2, jsteady=0.05, jmin=4.0, winit=0.0, geo=0, jumpw=0, wfloor=0.0, jk=2.0, jacc=0.0, jchain=0, jland=-1.0, wfreeze=0, wfreeze_err=0.0, retry=0.0, retry_kps=(0.5, 0.35, 0.7, 0.25), rescue_k=0, rescue_mode=0, rescue_zone=0.0, jrel=0.0, polish=0, polish_mult=4.0, polish_max=3, refl=1.0, lam_shift=0.0):
     lp = P.lp
     A0 = P.A
     if colscale is not None:
@@ -243,9 +243,11 @@ def solve(P, eps=1e-9, max_iter=60000, check=32, wrule="pid", kp=0.7, maxdl=np.l
                 jumped = jumped | rt
                 if verbose: print(it + 1, 'RETRY', np.nonzero(rt)[0], attempt[rt])
         keep = ~(rs | jumped)
-        lam = ((k + 1) / (k + 2))[:, None]
-        x = np.where(keep[:, None], lam * (2 * xp - x) + (1 - lam) * x0, x)
-        y = np.where(keep[:, None], lam * (2 * yp - y) + (1 - lam) * y0, y)
+        # refl: reflection strength rho of the relaxed operator (1 + rho) T - rho I (the kernel: 1); lam_shift: anchor weight
+        # (k + 1 + s) / (k + 2 + s) - exploration only
+        lam = ((k + 1 + lam_shift) / (k + 2 + lam_shift))[:, None]
+        x = np.where(keep[:, None], lam * ((1 + refl) * xp - refl * x) + (1 - lam) * x0, x)
+        y = np.where(keep[:, None], lam * ((1 + refl) * yp - refl * y) + (1 - lam) * y0, y)
     Xo[~done], Yo[~done] = (xp * dc)[~done], (yp * dr)[~done]
     solve.last_jumps = (njump, jtot); solve.last_w = w; solve.last_attempts = attempt
     return Xo, Yo, iters, nrs, done
@@ -287,5 +289,5 @@ if __name__ == "__main__":
         X, Y, iters, nrs, done = solve(sub, **kw)
         obj = np.sum(sub.c * X, 1) + sub.c0
         err = np.abs(obj - ref) / np.maximum(1, np.abs(ref))
-        print(kw, f"done {done.sum()}/{len(ids)} mean {iters.mean():.0f} med {np.median(iters):.0f} max {iters.max()} "
+        print({k: v for k, v in kw.items() if k != "colscale"}, "scaled" if "colscale" in kw else "unscaled", f"done {done.sum()}/{len(ids)} mean {iters.mean():.0f} med {np.median(iters):.0f} max {iters.max()} "
               f"hard {iters[:len(HARD.get(wl, []))]} jumps {solve.last_jumps[0].sum()} jsum {solve.last_jumps[1].sum():.0f} maxerr {err[done].max():.2e} t {time.time()-t:.1f}s", flush=True)
