@@ -84,6 +84,42 @@ struct SolveArgs {
   int trace_scenario;
 };
 
+// Layout token of the kernarg buffer: a run-time compiled kernel (dsp_rtc.hpp) receives SolveArgs as raw bytes and is compiled
+// from whatever csrc/ is on disk, so the library and the code object must agree on the structure AND on the development
+// switches that change what the kernel does with it.  The token is compiled into both sides (the code object exports it as
+// `dsp_rtc_layout_token`); a mismatch - a stale libdsp_hip.so next to newer sources, a -DDSP_KKT_TRACE build of one side
+// only - refuses the run-time kernel instead of running it on a mis-read buffer.
+#ifdef DSP_KKT_TRACE
+#define DSP_SW_TRACE 1ull
+#else
+#define DSP_SW_TRACE 0ull
+#endif
+#ifdef DSP_PROF
+#define DSP_SW_PROF 2ull
+#else
+#define DSP_SW_PROF 0ull
+#endif
+#ifdef DSP_CLOCKS
+#define DSP_SW_CLOCKS 4ull
+#else
+#define DSP_SW_CLOCKS 0ull
+#endif
+#ifdef DSP_LEGACY_PULL
+#define DSP_SW_PULL 8ull
+#else
+#define DSP_SW_PULL 0ull
+#endif
+#ifdef DSP_NO_JUMP
+#define DSP_SW_NOJUMP 16ull
+#else
+#define DSP_SW_NOJUMP 0ull
+#endif
+constexpr unsigned long long kBuildSwitches = DSP_SW_TRACE | DSP_SW_PROF | DSP_SW_CLOCKS | DSP_SW_PULL | DSP_SW_NOJUMP;
+constexpr unsigned long long kSolveArgsToken =
+    ((unsigned long long)sizeof(SolveArgs) << 40) ^ ((unsigned long long)__builtin_offsetof(SolveArgs, opt) << 28) ^
+    ((unsigned long long)__builtin_offsetof(SolveArgs, queue) << 16) ^ ((unsigned long long)sizeof(DeviceProblem) << 52) ^
+    ((unsigned long long)DSP_VERSION << 8) ^ kBuildSwitches;
+
 // in-wave dense simplex for tiny LPs (dsp_simplex.hip)
 struct SimplexArgs {
   int n, m;

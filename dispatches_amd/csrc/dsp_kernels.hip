@@ -1079,6 +1079,12 @@ __global__ void __launch_bounds__(256) spmv_stream_kernel(SpmvArgs a) {
   }
 }
 
+#ifdef __HIPCC_RTC__      /* run-time compiled code objects carry the layout token they were compiled with (dsp_device.hpp) */
+}  // namespace dsp
+extern "C" __device__ __attribute__((used)) const unsigned long long dsp_rtc_layout_token = dsp::kSolveArgsToken;
+namespace dsp {
+#endif
+
 #ifndef __HIPCC_RTC__     /* everything below is host code */
 // ---- launch tables ------------------------------------------------------------------------------------------
 // Register-resident-matrix specialisations exist for the shapes of the reference's flowsheets at the benchmark

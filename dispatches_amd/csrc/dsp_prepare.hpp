@@ -105,24 +105,39 @@ inline void equilibrate(HostCSR &A, int ruiz_iters, std::vector<double> &dr, std
   apply();
 }
 
-inline double spectral_norm(const HostCSR &A, const HostCSR &AT, int iters = 300) {
+// ||A||_2 by power iteration on A^T A.  The iterates' estimates increase monotonically towards sigma_max, i.e. every stop
+// is an UNDER-estimate, and eta = step_scale / estimate with an estimate short by more than 1 - step_scale (0.2 %) makes the PDHG
+// operator expansive: the iteration drifts off at constant speed instead of converging.  Small LPs converge to machine precision
+// within `iters`; the long-horizon price-taker LPs (block-bidiagonal in time: a near-continuous top of the spectrum) do not -
+// 200 iterations are 0.6 % short at T = 1344 (tools/stream_lab.py), which is what kept the T = 8736 solves of round 2 from ever
+// converging.  So: at least `iters` iterations (unchanged results where those suffice), then on until the estimate has stopped
+// growing (relative growth < 1e-10 over 50 iterations) or `max_iters`; if it is still growing, the bound of the
+// Pock-Chambolle scaling that `equilibrate` always ends with (alpha = 1: ||D_r A D_c||_2 <= 1) is returned instead.
+inline double spectral_norm(const HostCSR &A, const HostCSR &AT, int iters = 300, int max_iters = 20000, double pc_bound = 1.0) {
   if (A.nnz() == 0) return 1.0;
   std::vector<double> v(A.n), u(A.m);
   uint64_t s = 0x9E3779B97F4A7C15ull;                       // fixed-seed xorshift start vector
   for (auto &x : v) { s ^= s << 13; s ^= s >> 7; s ^= s << 17; x = (double)(s >> 11) / 9007199254740992.0 - 0.5; }
-  double nrm = 0;
+  double nrm = 0, ref = 0;
   auto normalise = [&](std::vector<double> &w) {
     double t = 0; for (double x : w) t += x * x; t = std::sqrt(t);
     if (t > 0) for (double &x : w) x /= t;
     return t;
   };
   normalise(v);
-  for (int it = 0; it < iters; ++it) {
+  bool converged = false;
+  for (int it = 0; it < max_iters; ++it) {
     for (int i = 0; i < A.m; ++i) { double t = 0; for (int p = A.ptr[i]; p < A.ptr[i + 1]; ++p) t += A.val[p] * v[A.idx[p]]; u[i] = t; }
     for (int j = 0; j < AT.m; ++j) { double t = 0; for (int p = AT.ptr[j]; p < AT.ptr[j + 1]; ++p) t += AT.val[p] * u[AT.idx[p]]; v[j] = t; }
     nrm = std::sqrt(normalise(v));                           // ||A^T A v|| -> sigma_max^2
+    if ((it + 1) % 50 == 0) {
+      converged = it + 1 > 50 && nrm - ref <= 1e-10 * nrm;
+      ref = nrm;
+      if (it + 1 >= iters && converged) break;
+    }
   }
-  return nrm > 0 ? nrm : 1.0;
+  if (!(nrm > 0)) return 1.0;
+  return converged ? nrm : std::max(nrm, pc_bound);
 }
 
 // Lane-major ELL of a CSR whose "rows" are the vectors owned by lanes: vector v is owned by lane v % 64,

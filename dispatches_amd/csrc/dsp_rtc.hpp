@@ -23,6 +23,8 @@
 #include <string>
 #include <vector>
 
+#include "dsp_device.hpp"
+
 namespace dsp {
 
 struct RtcKernel {
@@ -81,10 +83,24 @@ inline std::string rtc_source_dir() {
   return "csrc";
 }
 
+// "" = no disk cache: without $DSP_RTC_CACHE and without $HOME there is no private place for it (a world-writable /tmp
+// directory would let another user plant code objects that this process loads)
 inline std::string rtc_cache_dir() {
   if (const char *e = getenv("DSP_RTC_CACHE")) return e;
   const char *home = getenv("HOME");
-  return std::string(home ? home : "/tmp") + "/.cache/dsp_hip";
+  return home && *home ? std::string(home) + "/.cache/dsp_hip" : std::string();
+}
+
+// the development switches this library was compiled with, as compiler options for the run-time kernel (same switches on
+// both sides; they are part of the layout token and of the cache key)
+inline std::vector<std::string> rtc_build_defines() {
+  std::vector<std::string> d;
+  if (kBuildSwitches & DSP_SW_TRACE) d.push_back("-DDSP_KKT_TRACE");
+  if (kBuildSwitches & DSP_SW_PROF) d.push_back("-DDSP_PROF");
+  if (kBuildSwitches & DSP_SW_CLOCKS) d.push_back("-DDSP_CLOCKS");
+  if (kBuildSwitches & DSP_SW_PULL) d.push_back("-DDSP_LEGACY_PULL");
+  if (kBuildSwitches & DSP_SW_NOJUMP) d.push_back("-DDSP_NO_JUMP");
+  return d;
 }
 
 inline uint64_t rtc_hash_file(const std::string &path, uint64_t h) {
@@ -123,11 +139,13 @@ inline bool rtc_build_code(int cpl, int rpl, bool lng, unsigned wc, unsigned wr,
   struct stat sb;
   if (stat((dir + "/dsp_kernels.hip").c_str(), &sb) != 0) { *why = "kernel sources not found in " + dir; return false; }
   const std::string expr = rtc_kernel_expr(cpl, rpl, lng, wc, wr, qp);
-  char key[200];
-  snprintf(key, sizeof key, "pdlp_%d_%d_%d_%x_%x_%d_%016llx", cpl, rpl, (int)lng, wc, wr, (int)qp, (unsigned long long)rtc_source_hash(dir));
+  char key[240];
+  // key: shape, sources, and the library's layout token (structure sizes / offsets, ABI version, development switches)
+  snprintf(key, sizeof key, "pdlp_%d_%d_%d_%x_%x_%d_%016llx_%016llx", cpl, rpl, (int)lng, wc, wr, (int)qp,
+           (unsigned long long)rtc_source_hash(dir), (unsigned long long)kSolveArgsToken);
   const std::string cdir = rtc_cache_dir(), cpath = cdir + "/" + key + ".hsaco", npath = cdir + "/" + key + ".name";
   // disk cache
-  if (FILE *f = fopen(cpath.c_str(), "rb")) {
+  if (FILE *f = cdir.empty() ? nullptr : fopen(cpath.c_str(), "rb")) {
     fseek(f, 0, SEEK_END);
     const long sz = ftell(f);
     fseek(f, 0, SEEK_SET);
@@ -147,8 +165,10 @@ inline bool rtc_build_code(int cpl, int rpl, bool lng, unsigned wc, unsigned wr,
   if (api.create(&prog, src.c_str(), "dsp_rtc_unit.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) { *why = "hiprtcCreateProgram failed"; return false; }
   api.add_name(prog, expr.c_str());
   const std::string inc = "-I" + dir;
-  const char *opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", inc.c_str()};
-  const hiprtcResult r = api.compile(prog, 4, opts);
+  const std::vector<std::string> defs = rtc_build_defines();
+  std::vector<const char *> opts = {"--offload-arch=gfx950", "-O3", "-std=c++17", inc.c_str()};
+  for (const std::string &d : defs) opts.push_back(d.c_str());
+  const hiprtcResult r = api.compile(prog, (int)opts.size(), opts.data());
   if (r != HIPRTC_SUCCESS) {
     size_t ls = 0;
     api.log_size(prog, &ls);
@@ -169,9 +189,10 @@ inline bool rtc_build_code(int cpl, int rpl, bool lng, unsigned wc, unsigned wr,
   code->resize(cs);
   api.code(prog, code->data());
   api.destroy(&prog);
-  // best-effort cache write (atomic rename; a failure just means the next process compiles again)
-  mkdir((std::string(getenv("HOME") ? getenv("HOME") : "/tmp") + "/.cache").c_str(), 0755);
-  mkdir(cdir.c_str(), 0755);
+  // best-effort cache write (atomic rename; a failure just means the next process compiles again); private directory
+  if (cdir.empty()) return true;
+  if (!getenv("DSP_RTC_CACHE")) mkdir((std::string(getenv("HOME")) + "/.cache").c_str(), 0700);
+  mkdir(cdir.c_str(), 0700);
   const std::string tmp = cpath + ".tmp" + std::to_string((long)getpid());
   if (FILE *f = fopen(tmp.c_str(), "wb")) {
     const bool ok = fwrite(code->data(), 1, code->size(), f) == code->size();
@@ -200,6 +221,21 @@ inline bool rtc_get_kernel(int device, int cpl, int rpl, bool lng, unsigned wc, 
   if (rtc_build_code(cpl, rpl, lng, wc, wr, qp, &code, &name, why)) {
     if (hipModuleLoadData(&k.mod, code.data()) != hipSuccess) { *why = "hipModuleLoadData failed"; k = RtcKernel{}; }
     else if (hipModuleGetFunction(&k.fn, k.mod, name.c_str()) != hipSuccess) { *why = "hipModuleGetFunction failed for " + name; k = RtcKernel{}; }
+    else {
+      // the code object must have been compiled against THIS library's SolveArgs layout and switches (dsp_device.hpp)
+      hipDeviceptr_t tok = nullptr;
+      size_t tok_bytes = 0;
+      unsigned long long theirs = 0;
+      if (hipModuleGetGlobal(&tok, &tok_bytes, k.mod, "dsp_rtc_layout_token") != hipSuccess || tok_bytes != sizeof(theirs) ||
+          hipMemcpy(&theirs, tok, sizeof(theirs), hipMemcpyDeviceToHost) != hipSuccess || theirs != kSolveArgsToken) {
+        char msg[200];
+        snprintf(msg, sizeof msg, "layout token mismatch (library %016llx, code object %016llx): stale libdsp_hip.so or other build "
+                 "switches than the kernel sources - run-time kernel refused", (unsigned long long)kSolveArgsToken, theirs);
+        *why = msg;
+        (void)hipModuleUnload(k.mod);
+        k = RtcKernel{};
+      }
+    }
   }
   table[key] = k;            // failures are remembered too: one attempt per shape and process
   *out = k;

@@ -104,6 +104,7 @@ __global__ void __launch_bounds__(64) simplex_kernel(SimplexArgs a) {
         b.status[s] = any_nan ? DSP_STATUS_NUMERICAL : DSP_STATUS_PRIMAL_INFEASIBLE;
         if (b.iters) b.iters[s] = 0;
         if (b.jumps) b.jumps[s] = 0;
+        if (b.flags) b.flags[s] = 0;
       }
       continue;
     }
@@ -328,6 +329,11 @@ __global__ void __launch_bounds__(64) simplex_kernel(SimplexArgs a) {
     const unsigned long long bad_bounds = __ballot(!okb), bad_any = __ballot(!okv);
     int reason = status == -1 ? 1 : 0;                       // 1 = pivot limit
     if (status == DSP_STATUS_OPTIMAL && !certified) { status = -1; reason = 2; }   // 2 = vertex failed its certificate
+    // 3 = a phase-1 stop / an empty ratio test: only OPTIMAL vertices carry a certificate against the original rows, and on a
+    // degenerate hourly LP either stop can be a tolerance artefact (no |d_j| above 1e-9, every ratio below the pivot tolerance).
+    // Not reported as infeasible / unbounded: the PDLP pass takes the scenario (a genuinely infeasible LP ends there at the
+    // iteration limit - dispatch LPs carry slack columns, so that is an input error, not a regular outcome).
+    if (status == DSP_STATUS_PRIMAL_INFEASIBLE || status == DSP_STATUS_DUAL_INFEASIBLE) { status = -1; reason = 3; }
     if (status == -1) {
       if (lane == 0) {
         if (a.debug_keep) {                                  // development: report why instead of handing over to PDLP
@@ -335,6 +341,7 @@ __global__ void __launch_bounds__(64) simplex_kernel(SimplexArgs a) {
           if (b.iters) b.iters[s] = pivots;
           if (b.jumps) b.jumps[s] = bad_bounds ? 1000 + first_lane(bad_bounds) : (bad_any ? 2000 + first_lane(bad_any) : 0);
           b.obj[s] = po;
+          if (b.flags) b.flags[s] = 0;
         } else {
           b.status[s] = DSP_STATUS_UNSOLVED;                 // the PDLP kernel takes it from here
           atomicAdd(a.unsolved, 1);
@@ -368,6 +375,7 @@ __global__ void __launch_bounds__(64) simplex_kernel(SimplexArgs a) {
       b.status[s] = status;
       if (b.iters) b.iters[s] = pivots;
       if (b.jumps) b.jumps[s] = 0;
+      if (b.flags) b.flags[s] = 0;
     }
     wave_lds_fence();
   }
@@ -450,6 +458,7 @@ __global__ void __launch_bounds__(64, 2) simplex_reg_kernel(SimplexArgs a) {
         b.status[s] = any_nan ? DSP_STATUS_NUMERICAL : DSP_STATUS_PRIMAL_INFEASIBLE;
         if (b.iters) b.iters[s] = 0;
         if (b.jumps) b.jumps[s] = 0;
+        if (b.flags) b.flags[s] = 0;
       }
       continue;
     }
@@ -676,6 +685,7 @@ __global__ void __launch_bounds__(64, 2) simplex_reg_kernel(SimplexArgs a) {
     const unsigned long long bad_bounds = __ballot(!okb), bad_any = __ballot(!okv);
     int reason = status == -1 ? 1 : 0;
     if (status == DSP_STATUS_OPTIMAL && !certified) { status = -1; reason = 2; }
+    if (status == DSP_STATUS_PRIMAL_INFEASIBLE || status == DSP_STATUS_DUAL_INFEASIBLE) { status = -1; reason = 3; }   // see the LDS-tableau kernel
     if (status == -1) {
       if (lane == 0) {
         if (a.debug_keep) {
@@ -683,6 +693,7 @@ __global__ void __launch_bounds__(64, 2) simplex_reg_kernel(SimplexArgs a) {
           if (b.iters) b.iters[s] = pivots;
           if (b.jumps) b.jumps[s] = bad_bounds ? 1000 + first_lane(bad_bounds) : (bad_any ? 2000 + first_lane(bad_any) : 0);
           b.obj[s] = po;
+          if (b.flags) b.flags[s] = 0;
         } else {
           b.status[s] = DSP_STATUS_UNSOLVED;
           atomicAdd(a.unsolved, 1);
@@ -713,6 +724,7 @@ __global__ void __launch_bounds__(64, 2) simplex_reg_kernel(SimplexArgs a) {
       b.status[s] = status;
       if (b.iters) b.iters[s] = pivots;
       if (b.jumps) b.jumps[s] = 0;
+      if (b.flags) b.flags[s] = 0;
     }
     wave_lds_fence();
   }

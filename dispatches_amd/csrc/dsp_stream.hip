@@ -748,6 +748,7 @@ __global__ void k_finalize(StreamArgs a) {
     b.status[s] = c.status;
     if (b.iters) b.iters[s] = c.it;
     if (b.jumps) b.jumps[s] = 0;
+    if (b.flags) b.flags[s] = 0;
     if (b.primal_weight) b.primal_weight[s] = c.w;
   }
 }
@@ -911,8 +912,23 @@ static hipError_t run(StreamSolver *S, StreamArgs &a, hipStream_t st, int *perio
   return hipGetLastError();
 }
 
+// BLOCKING and one call at a time per handle (include/dsp_hip.h, dsp_solve): the per-scenario state lives in ONE workspace per
+// handle (reallocated when a larger batch arrives) and the host polls the device's finished-counter while it enqueues the
+// iteration launches, so - unlike the fused path with its ring of work queues - two solves of one handle cannot overlap.  The
+// mutex serialises callers on different threads / streams; the call returns after its stream work has completed.
+static hipError_t stream_solve_locked(StreamSolver *S, const dsp_batch &batch, const dsp_options &opt, double eta, hipStream_t st,
+                                      int *periods_run);
+
 hipError_t stream_solve(StreamSolver *S, const dsp_batch &batch, const dsp_options &opt, double eta, hipStream_t st,
                         int *periods_run) {
+  std::lock_guard<std::mutex> lock(S->mu);
+  hipError_t e = stream_solve_locked(S, batch, opt, eta, st, periods_run);
+  const hipError_t es = hipStreamSynchronize(st);
+  return e != hipSuccess ? e : es;
+}
+
+static hipError_t stream_solve_locked(StreamSolver *S, const dsp_batch &batch, const dsp_options &opt, double eta, hipStream_t st,
+                                      int *periods_run) {
   const int B = batch.B;
   hipError_t e = ensure_workspace(S, B);
   if (e != hipSuccess) return e;

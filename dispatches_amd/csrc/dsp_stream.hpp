@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <mutex>
 #include <vector>
 
 #include "../../include/dsp_hip.h"
@@ -70,6 +71,7 @@ struct StreamSolver {
   int work_B = 0;
   std::vector<void *> allocs, work_allocs;
   int *ndone_host = nullptr;
+  std::mutex mu;          // one solve at a time per handle: the workspace above is per handle, not per call (stream_solve)
   size_t lds_limit = 160 * 1024 - 2048;   // dynamic LDS available to the block-resident form (static __shared__ on top)
 };
 

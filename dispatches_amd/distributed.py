@@ -77,7 +77,7 @@ def solve_sharded(model, solver, group=None, gather_solution: bool = False):
     """Solve `model`'s scenarios sharded over the ranks of `group` and all-gather the results.
 
     Every rank must call this with an identical `model` (same LP, same per-scenario data).  After the call
-    ``model.objective`` / ``model.status`` / ``model.iterations`` hold ALL scenarios on every rank;
+    ``model.objective`` / ``model.status`` / ``model.iterations`` / ``model.flags`` hold ALL scenarios on every rank;
     ``model.x`` / ``model.y`` hold all scenarios if `gather_solution`, otherwise only the local shard is valid
     (rows outside the shard are NaN).  Returns (lo, hi), the shard this rank solved.
 
@@ -97,10 +97,10 @@ def solve_sharded(model, solver, group=None, gather_solution: bool = False):
         model.solve_handle = view.solve_handle
     n, m = model.lp.n, model.lp.m
     per = max(shard_bounds(B, world, r)[1] - shard_bounds(B, world, r)[0] for r in range(world))
-    width = 3 + ((n + m) if gather_solution else 0)          # objective, status, iterations [, x, y]
+    width = 4 + ((n + m) if gather_solution else 0)          # objective, status, iterations, flags [, x, y]
     on_gpu = dist.is_initialized() and dist.get_backend(group) == "nccl"
     dev = torch.device("cuda", torch.cuda.current_device()) if on_gpu else torch.device("cpu")
-    columns = ("obj", "status", "iters") + (("x", "y") if gather_solution else ())
+    columns = ("obj", "status", "iters", "flags") + (("x", "y") if gather_solution else ())
     dev_out = getattr(solver, "last_device_out", None) if on_gpu else None
     if hi > lo and dev_out is not None and dev_out["obj"].shape[0] == hi - lo:
         # device path: objective is c.x on the device, the model's constant is added after the gather
@@ -110,7 +110,9 @@ def solve_sharded(model, solver, group=None, gather_solution: bool = False):
         out["obj"] = out["obj"] + c0_local
     elif hi > lo:
         it = view.iterations if view.iterations is not None else np.zeros(hi - lo)
-        host = dict(obj=view.objective, status=view.status, iters=it, x=view.x, y=np.reshape(view.y, (hi - lo, m)))
+        fl = getattr(view, "flags", None)
+        host = dict(obj=view.objective, status=view.status, iters=it, flags=(np.zeros(hi - lo) if fl is None else fl), x=view.x,
+                    y=np.reshape(view.y, (hi - lo, m)))
         out = {k: torch.as_tensor(np.ascontiguousarray(host[k], np.float64)).to(dev) for k in columns}
     else:
         out = None
@@ -133,15 +135,20 @@ def solve_sharded(model, solver, group=None, gather_solution: bool = False):
     obj = np.empty(B)
     status = np.empty(B, np.int32)
     iters = np.empty(B, np.int64)
+    flags = np.zeros(B, np.int32)
     x = np.full((B, n), np.nan)
     y = np.full((B, m), np.nan)
     for r in range(world):
         a, b = shard_bounds(B, world, r)
         blk = everything[r, :b - a]
         obj[a:b], status[a:b], iters[a:b] = blk[:, 0], blk[:, 1].astype(np.int32), blk[:, 2].astype(np.int64)
+        flags[a:b] = blk[:, 3].astype(np.int32)
         if gather_solution:
-            x[a:b], y[a:b] = blk[:, 3:3 + n], blk[:, 3 + n:3 + n + m]
+            x[a:b], y[a:b] = blk[:, 4:4 + n], blk[:, 4 + n:4 + n + m]
     if not gather_solution and hi > lo:
         x[lo:hi], y[lo:hi] = view.x, np.reshape(view.y, (hi - lo, m))
     model.store_solution(x, y, obj, status, iters)
+    # DSP_FLAG_* bits of every scenario on every rank: a scenario accepted without a certified objective accuracy on ANOTHER
+    # rank must not look certified here (Bidder / Tracker read model.flags)
+    model.flags = flags
     return lo, hi

@@ -30,8 +30,64 @@ PA = ((1 + DISCOUNT_RATE) ** YEARS - 1) / (DISCOUNT_RATE * (1 + DISCOUNT_RATE) *
 DURATION = 4.0
 
 
+def _prefix_network(b, leaves, fan_out=6):
+    """Exclusive prefix sums of the expressions `leaves` as the variables of a work-efficient parallel-prefix network
+    (up-sweep block sums + down-sweep prefixes) instead of a T-long integrator chain.  Returns the list of LinExpr
+    `before[t] = sum_{s < t} leaves[s]`.
+
+    Why: the reference accumulates the battery's energy throughput through T linked equalities E_t = E_{t-1} + (I_t + O_t) / 2
+    (battery.py:155-159 + the linking pairs wind_battery_LMP.py:22-37) and E_t enters every period's state-of-charge bound
+    with the degradation rate (battery.py:161-165).  For a first-order method that chain is a T-step integrator: information
+    moves one period per iteration and the iteration count grows LINEARLY with T (lab, tools/stream_lab.py: 7.9 k / 19 k /
+    39 k iterations at T = 168 / 336 / 672, against 5.1 k / 6.3 k / 7.8 k with the chain cut).  The same prefix sums written as a
+    network of depth 2 log2 T - every variable the sum of two others, every variable used a bounded number of times - are
+    the same LP (an exact linear change of variables: E_t = before[t] + leaf_t) with a dependency depth of ~27 instead of
+    8736.  `fan_out`: a down-sweep prefix handed down a left spine is copied into a fresh variable after this many uses,
+    which bounds the column length (the streaming kernels keep columns of <= 8 entries in their ELL part)."""
+    T = len(leaves)
+    block_sum = {}
+
+    def up(lo, hi):                                     # variable (or leaf expression) of sum_{lo <= s < hi} leaves[s]
+        if hi - lo == 1:
+            return leaves[lo]
+        key = (lo, hi)
+        if key not in block_sum:
+            mid = (lo + hi) // 2
+            v = b.var(f"throughput_sum[{lo}:{hi}]")
+            b.equality(f"throughput_sum_def[{lo}:{hi}]", v - up(lo, mid) - up(mid, hi), 0.0)
+            block_sum[key] = v
+        return block_sum[key]
+
+    before = [None] * T
+
+    def down(lo, hi, prefix, uses):                     # prefix: LinExpr / Var of sum_{s < lo} leaves[s], or None for zero
+        if hi - lo == 1:
+            before[lo] = LinExpr() if prefix is None else LinExpr._as(prefix)
+            return
+        mid = (lo + hi) // 2
+        if prefix is not None and uses >= fan_out:      # bound the column length: continue with a copy
+            cp = b.var(f"throughput_before_copy[{lo}:{hi}]")
+            b.equality(f"throughput_before_copy_def[{lo}:{hi}]", cp - prefix, 0.0)
+            prefix, uses = cp, 0
+        left_sum = up(lo, mid)
+        if prefix is None:
+            right_prefix = left_sum                     # alias: the prefix before `mid` IS the left block's sum
+            down(lo, mid, None, 0)
+            down(mid, hi, right_prefix, 1 if hi - lo > 2 else 0)
+            return
+        rp = b.var(f"throughput_before[{mid}]")
+        b.equality(f"throughput_before_def[{mid}]", rp - prefix - left_sum, 0.0)
+        down(lo, mid, prefix, uses + 1)
+        down(mid, hi, rp, 0)
+
+    import sys
+    sys.setrecursionlimit(max(sys.getrecursionlimit(), 10000))
+    down(0, T, None, 0)
+    return before
+
+
 def wind_battery_price_taker(n_time_points, capacity_factors, lmps, wind_mw=847.0, wind_mw_ub=10000.0, batt_mw=0.0,
-                             extant_wind=True):
+                             extant_wind=True, throughput="chain"):
     """Build the LP.  `lmps` in $/MWh (the reference multiplies by 1e-3: $/kWh, :249); returns (block, objective,
     handles) where objective is the LinExpr of  -NPV * 1e-5  to MINIMISE."""
     if not extant_wind:
@@ -50,25 +106,38 @@ def wind_battery_price_taker(n_time_points, capacity_factors, lmps, wind_mw=847.
     per = []
     soc_prev = thr_prev = None
     revenue = LinExpr()
+    if throughput not in ("chain", "scan"):
+        raise ValueError("throughput: 'chain' (the reference's linked equalities) or 'scan' (parallel-prefix network)")
+    cols = []
     for t in range(T):
         W = b.var(f"windpower.electricity[{t}]", 0.0, wind_kw * cf[t])
         G = b.var(f"splitter.grid_elec[{t}]")
         I = b.var(f"splitter.battery_elec[{t}]")
         O = b.var(f"battery.elec_out[{t}]")
         S = b.var(f"battery.state_of_charge[{t}]", 0.0, 0.0 if t == T - 1 else np.inf)   # periodic: S_{T-1} = S_init = 0 (:40-51, :199)
-        E = b.var(f"battery.energy_throughput[{t}]")
+        E = b.var(f"battery.energy_throughput[{t}]") if throughput == "chain" else None
+        cols.append((W, G, I, O, S, E))
+    if throughput == "scan":
+        before = _prefix_network(b, [0.5 * I + 0.5 * O for (_W, _G, I, O, _S, _E) in cols])
+    for t, (W, G, I, O, S, E) in enumerate(cols):
         b.equality(f"splitter.sum_split[{t}]", W - G - I, 0.0)
         soc_rhs = S - eta_c * I + O / eta_d
-        thr_rhs = E - 0.5 * I - 0.5 * O
         if soc_prev is not None:
-            soc_rhs, thr_rhs = soc_rhs - soc_prev, thr_rhs - thr_prev
+            soc_rhs = soc_rhs - soc_prev
         b.equality(f"battery.state_evolution[{t}]", soc_rhs, 0.0)                  # initial SOC / throughput fixed 0 (:199-200)
-        b.equality(f"battery.accumulate_energy_throughput[{t}]", thr_rhs, 0.0)
-        b.constraint(f"battery.state_of_charge_bounds[{t}]", S + d * E - DURATION * P, -np.inf, 0.0)
+        if throughput == "chain":
+            thr_rhs = E - 0.5 * I - 0.5 * O
+            if thr_prev is not None:
+                thr_rhs = thr_rhs - thr_prev
+            b.equality(f"battery.accumulate_energy_throughput[{t}]", thr_rhs, 0.0)
+            Et = LinExpr._as(E)
+        else:
+            Et = before[t] + 0.5 * I + 0.5 * O                                      # the same E_t, as an expression
+        b.constraint(f"battery.state_of_charge_bounds[{t}]", S + d * Et - DURATION * P, -np.inf, 0.0)
         b.constraint(f"battery.power_bound_in[{t}]", I - P, -np.inf, 0.0)
         b.constraint(f"battery.power_bound_out[{t}]", O - P, -np.inf, 0.0)
         revenue = revenue + (G + O) * float(lmp[t])
-        per.append(dict(wind=W, grid_elec=G, elec_in=I, elec_out=O, state_of_charge=S, energy_throughput=E))
+        per.append(dict(wind=W, grid_elec=G, elec_in=I, elec_out=O, state_of_charge=S, energy_throughput=Et))
         soc_prev, thr_prev = S, E
     n_weeks = T / (7 * 24)
     op_cost = (Cw * (prm.wind_op_cost / 8760) + Pb * (BATT_OP_COST / 8760)) * T

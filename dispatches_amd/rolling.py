@@ -168,6 +168,7 @@ class BatchedWindBatteryDoubleLoop:
         self.soc, self.thr = z(), z()
         self.revenue, self.energy_mwh, self.da_energy_mwh = z(), z(), z()
         self.bad = torch.zeros((), dtype=torch.bool, device=dev)          # any non-optimal status so far
+        self.uncertified = torch.zeros((), dtype=torch.int64, device=dev)  # solves accepted with DSP_FLAG_OBJ_WAIVED so far
         self.hour = 0
         self.hour_t = torch.zeros((), dtype=torch.int64, device=dev)      # the clock ON THE DEVICE (graphs replay across days)
         self.da_offer = torch.zeros((B, 24), dtype=torch.float64, device=dev)
@@ -215,6 +216,10 @@ class BatchedWindBatteryDoubleLoop:
 
     def _check(self, out):
         self.bad |= (out["status"] != 0).any()
+        # accepted without a certified objective accuracy (DSP_FLAG_OBJ_WAIVED): counted, on the device (the loop is replayed
+        # from hipGraphs: no host round trip to re-solve them here); results() reports the count next to `ok`
+        if out.get("flags") is not None:
+            self.uncertified += ((out["flags"] & 1) != 0).sum()
 
     # -- one simulated day -------------------------------------------------------------------------------------------------
     def _day_ahead_step(self):

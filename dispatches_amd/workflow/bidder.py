@@ -290,7 +290,11 @@ class StochasticProgramBidder(AbstractBidder):
     def _check_solution(self, model, market, date, hour):
         """Never turn an unconverged / invalid scenario into a bid: the solver reports ITERATION_LIMIT, and NaN x for the
         invalid-input statuses (include/dsp_hip.h).  `model.ok` is the mask the bid assembly uses."""
-        status = np.asarray(model.status)
+        status = np.asarray(model.status).copy()
+        # "optimal" without a certified objective accuracy (DSP_FLAG_OBJ_WAIVED left after the solver's re-solves) is not optimal
+        # for a bid: report it under its own code and leave it out like an unconverged scenario
+        from ..hip_solver import STATUS_UNCERTIFIED, uncertified
+        status[uncertified(status, getattr(model, "flags", None))] = STATUS_UNCERTIFIED
         ok = status == 0
         model.ok = ok
         if ok.all():
@@ -298,7 +302,7 @@ class StochasticProgramBidder(AbstractBidder):
         bad = np.nonzero(~ok)[0]
         self.failed_scenarios[(str(date), hour, market)] = {int(i): int(status[i]) for i in bad}
         msg = (f"{market} bidding problem of {self.generator} ({date}, hour {hour}): {len(bad)} of {len(status)} scenarios "
-               f"did not reach optimality (scenario: status) {dict(list(self.failed_scenarios[(str(date), hour, market)].items())[:8])}")
+               f"did not reach optimality (scenario: status; 1 iteration limit, 5 objective accuracy not certified) {dict(list(self.failed_scenarios[(str(date), hour, market)].items())[:8])}")
         if self.strict or not ok.any():
             raise RuntimeError(msg)
         import warnings

@@ -122,11 +122,14 @@ class Tracker:
             self.solver.solve(self.model, tee=False, warm_start=True, shift=self.n_tracking_hour)
         else:
             self.solver.solve(self.model, tee=False)
-        status = np.asarray(self.model.status)
+        status = np.asarray(self.model.status).copy()
+        from ..hip_solver import STATUS_UNCERTIFIED, uncertified
+        status[uncertified(status, getattr(self.model, "flags", None))] = STATUS_UNCERTIFIED
         if not (status == 0).all():
-            # an unconverged (or NaN) solution must never become the implemented profile / the next fixed SOC
+            # an unconverged (or NaN, or uncertified) solution must never become the implemented profile / the next fixed SOC
             raise RuntimeError(f"tracking problem ({date}, hour {hour}) did not reach optimality: solver status "
-                               f"{status.tolist()} (0 optimal, 1 iteration limit, 2 infeasible input, 4 numerical)")
+                               f"{status.tolist()} (0 optimal, 1 iteration limit, 2 infeasible input, 4 numerical, "
+                               f"5 objective accuracy not certified)")
         self.record_results(date=date, hour=hour)
         profiles = self.tracking_model_object.get_implemented_profile(
             b=self.model.fs, last_implemented_time_step=self.n_tracking_hour - 1)

@@ -45,9 +45,10 @@ extern "C" {
 #define DSP_STATUS_ITERATION_LIMIT    1
 #define DSP_STATUS_PRIMAL_INFEASIBLE  2   /* crossed bounds (var_lb > var_ub or row_lb > row_ub) in the input; infeasibility
                                              that needs a Farkas ray is NOT detected (dispatch LPs carry slack columns) */
-#define DSP_STATUS_DUAL_INFEASIBLE    3   /* reserved */
+#define DSP_STATUS_DUAL_INFEASIBLE    3   /* reserved: never reported (the in-wave simplex certifies OPTIMAL vertices only; a phase-1
+                                             stop or an unbounded ray it meets is handed to the PDLP pass, which ends at
+                                             ITERATION_LIMIT on a genuinely infeasible / unbounded LP)                */
 #define DSP_STATUS_NUMERICAL          4   /* NaN in the input or NaN / Inf met in the iteration                */
-/* DSP_STATUS_DUAL_INFEASIBLE is reported by the simplex path only (an unbounded ray of a tiny LP). */
 
 /* per-scenario flag bits written to flags[B] */
 #define DSP_FLAG_OBJ_WAIVED   1   /* status OPTIMAL with both feasibility tests at eps_rel, but the objective-error bound
@@ -236,7 +237,13 @@ int dsp_create(const dsp_lp_desc *desc, int device, const dsp_options *opt, dsp_
 
 /* Solve the B scenarios of `batch`.  hipStream: a hipStream_t (NULL = default stream).  The call enqueues
  * work and returns; if `stats` is non-NULL and sync_stats != 0 it synchronises the stream and fills the
- * statistics.  `opt` may be NULL (= the options given to dsp_create). */
+ * statistics.  `opt` may be NULL (= the options given to dsp_create).
+ * Fused kernels and in-wave simplex (n <= 640, m <= 384): stream-ordered, capturable into a hipGraph, several calls of one
+ * handle may be in flight on different streams.  HBM-resident streaming path (larger LPs, dsp_stats::streaming): BLOCKING and
+ * one call at a time per handle - the per-scenario state (13 vectors of n / m doubles per scenario) is a per-handle
+ * workspace and the host polls a finished-counter while it enqueues the iteration launches; concurrent callers are
+ * serialised by a mutex inside the handle, the call returns after its stream work has completed, and it cannot be captured
+ * into a hipGraph. */
 int dsp_solve(dsp_handle *h, const dsp_batch *batch, const dsp_options *opt, dsp_stats *stats, int sync_stats,
               void *hipStream);
 

@@ -76,3 +76,32 @@ def test_solver_fails_loudly_without_gpu():
     bidder, model = scenarios.make_batch("nuclear_24h", 2, solver)
     with pytest.raises(DspError):
         solver.solve(model)
+
+
+def test_integration_stub_matches_the_binding(lib):
+    """INTEGRATION.md section 2 is what a maintainer copies: its structure definitions must be the current ABI's (round 2
+    shipped a 6-field dsp_lp_desc stub next to a 7-field header: dsp_create would have read 8 bytes past the caller's struct)."""
+    from dispatches_amd import hip_solver
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    block = re.search(r"## 2\..*?```python\n(.*?)```", doc, re.S).group(1)
+    # the structure definitions of the stub, executed on their own (the rest of the block needs a GPU)
+    classes = re.findall(r"^(class \w+\(C\.Structure\):.*?)(?=^\S)", block, re.S | re.M)
+    assert classes, "section 2 no longer defines its structures"
+    ns = {"C": C}
+    for src in classes:
+        exec(src, ns)                                                    # noqa: S102 - our own documentation
+    checked = 0
+    for name, cls in ns.items():
+        ours = getattr(hip_solver, name, None)
+        if isinstance(cls, type) and issubclass(cls, C.Structure) and ours is not None:
+            assert [f[0] for f in cls._fields_] == [f[0] for f in ours._fields_], name
+            assert C.sizeof(cls) == C.sizeof(ours), (name, C.sizeof(cls), C.sizeof(ours))
+            checked += 1
+    assert checked >= 1
+    # every structure the stub does NOT define itself is imported from the binding, and the version it asserts is the header's
+    for name in ("DspOptions", "DspBatch", "DspStats"):
+        assert name in ns or re.search(r"from dispatches_amd\.hip_solver import[^\n]*\b%s\b" % name, block), name
+    assert int(re.search(r"lib\.dsp_version\(\) == (\d+)", block).group(1)) == hip_solver.ABI_VERSION
+    # every dsp_batch / dsp_lp_desc field the stub assigns exists
+    for field in set(re.findall(r"\bb\.([a-z_0-9]+)\b", block)):
+        assert field in {f[0] for f in hip_solver.DspBatch._fields_}, field
