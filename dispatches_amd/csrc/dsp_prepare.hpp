@@ -113,7 +113,7 @@ inline void equilibrate(HostCSR &A, int ruiz_iters, std::vector<double> &dr, std
 // converging.  So: at least `iters` iterations (unchanged results where those suffice), then on until the estimate has stopped
 // growing (relative growth < 1e-10 over 50 iterations) or `max_iters`; if it is still growing, the bound of the
 // Pock-Chambolle scaling that `equilibrate` always ends with (alpha = 1: ||D_r A D_c||_2 <= 1) is returned instead.
-inline double spectral_norm(const HostCSR &A, const HostCSR &AT, int iters = 300, int max_iters = 20000, double pc_bound = 1.0) {
+inline double spectral_norm(const HostCSR &A, const HostCSR &AT, int iters = 300, int max_iters = 4000, double pc_bound = 1.0) {
   if (A.nnz() == 0) return 1.0;
   std::vector<double> v(A.n), u(A.m);
   uint64_t s = 0x9E3779B97F4A7C15ull;                       // fixed-seed xorshift start vector

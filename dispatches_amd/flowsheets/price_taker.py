@@ -159,4 +159,25 @@ def wind_battery_price_taker(n_time_points, capacity_factors, lmps, wind_mw=847.
         c[Pb.index] = -k * T * BATT_OP_COST / 8760 + 1e-5 * batt_cap_factor * (BATT_CAP_COST_KW + BATT_CAP_COST_KWH * DURATION)
         return c
     handles["objective_vector"] = objective_vector
+
+    def column_scales(n_cols=None):
+        """Variable scaling factors (dsp_lp_desc::col_scale: typical magnitude of every column), the physical ones a flowsheet
+        knows - the reference sets them with iscale.set_scaling_factor on exactly these variables (RE_flowsheet.py:229-296,
+        there as reciprocals).  Every kW column at the wind plant's nameplate, the state of charge at DURATION hours of it, the
+        accumulated throughput at the energy a quarter-duty battery of that size moves up to its place in the horizon.  The
+        ranges the BOUNDS imply (lp.implied_column_ranges) are meaningless here: the battery is a free design variable."""
+        s = np.full(len(b.col_names) if n_cols is None else n_cols, wind_kw)
+        duty = 0.25
+        for j, name in enumerate(b.col_names):
+            if name.startswith("battery.state_of_charge["):
+                s[j] = DURATION * wind_kw
+            elif name.startswith("battery.energy_throughput["):
+                s[j] = wind_kw * max(T / 2, 1)
+            elif name.startswith("throughput_sum[") or name.startswith("throughput_before_copy["):
+                lo, hi = map(int, name[name.index("[") + 1:-1].split(":"))
+                s[j] = wind_kw * duty * ((hi - lo) if name.startswith("throughput_sum[") else max(lo, 1))
+            elif name.startswith("throughput_before["):
+                s[j] = wind_kw * duty * max(int(name[name.index("[") + 1:-1]), 1)
+        return s
+    handles["column_scales"] = column_scales
     return b, objective, handles

@@ -299,6 +299,7 @@ def price_taker_batch(T, B, solver, wind_mw=847.0, throughput="chain"):
     fam = [PRICE_TAKER_FAMILY[i % len(PRICE_TAKER_FAMILY)] for i in range(B)]
     model.c = np.stack([handles["objective_vector"](model.lp.n, lmp_multiplier=lm, batt_cap_factor=bf) for bf, lm in fam])
     model.c0 = np.full(B, model.lp.c0)
+    model.lp.col_scale = handles["column_scales"](model.lp.n)       # physical scaling factors of the flowsheet's variables
     model.family = fam
     model.solver = solver
     return handles, model
