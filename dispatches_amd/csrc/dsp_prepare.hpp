@@ -140,6 +140,114 @@ inline double spectral_norm(const HostCSR &A, const HostCSR &AT, int iters = 300
   return converged ? nrm : std::max(nrm, pc_bound);
 }
 
+// ---- layouts of the HBM-resident streaming PDLP (dsp_stream.hip), host side ----------------------------------------------------
+// entry-major ELL ([W][nvec]: thread v reads entry e at e * nvec + v, coalesced) + CSR segments of the "long" vectors (more than
+// W entries), cut into chunks of at most `chunk` entries
+struct HostStreamELL {
+  int nvec = 0, W = 0;
+  std::vector<double> val;               // [W][nvec]
+  std::vector<int32_t> idx;              // [W][nvec]
+  std::vector<uint8_t> is_long;          // [nvec]
+  std::vector<int32_t> long_id, long_ptr, long_idx;
+  std::vector<double> long_val;
+  std::vector<int32_t> chunk_begin, chunk_end, long_chunk_ptr;
+};
+
+inline HostStreamELL build_stream_ell(const HostCSR &M, int max_w, int chunk) {
+  HostStreamELL E;
+  const int nv = M.m;
+  std::vector<int> len(nv);
+  for (int v = 0; v < nv; ++v) len[v] = M.ptr[v + 1] - M.ptr[v];
+  // the smallest width that leaves long only what is long at max_w anyway (a design column that touches every period stays
+  // long at any width: it must not pad every other vector to max_w entries)
+  int nl_max = 0;
+  for (int v = 0; v < nv; ++v) nl_max += len[v] > max_w;
+  int W = 1;
+  for (W = 1; W < max_w; ++W) {
+    int nl = 0;
+    for (int v = 0; v < nv; ++v) nl += len[v] > W;
+    if (nl == nl_max) break;
+  }
+  E.nvec = nv; E.W = W;
+  E.val.assign((size_t)W * nv, 0.0);
+  E.idx.assign((size_t)W * nv, 0);
+  E.is_long.assign(std::max(nv, 1), 0);
+  E.long_ptr.push_back(0);
+  for (int v = 0; v < nv; ++v) {
+    if (len[v] <= W) {
+      for (int e = 0; e < len[v]; ++e) { E.val[(size_t)e * nv + v] = M.val[M.ptr[v] + e]; E.idx[(size_t)e * nv + v] = M.idx[M.ptr[v] + e]; }
+    } else {
+      E.is_long[v] = 1;
+      E.long_id.push_back(v);
+      for (int p = M.ptr[v]; p < M.ptr[v + 1]; ++p) { E.long_idx.push_back(M.idx[p]); E.long_val.push_back(M.val[p]); }
+      E.long_ptr.push_back((int32_t)E.long_idx.size());
+    }
+  }
+  E.long_chunk_ptr.push_back(0);
+  for (size_t l = 0; l < E.long_id.size(); ++l) {
+    for (int p = E.long_ptr[l]; p < E.long_ptr[l + 1]; p += chunk) { E.chunk_begin.push_back(p); E.chunk_end.push_back(std::min(p + chunk, E.long_ptr[l + 1])); }
+    E.long_chunk_ptr.push_back((int32_t)E.chunk_begin.size());
+  }
+  return E;
+}
+
+// Tiles of the fused one-launch iteration (dsp_stream.hpp: FusedPlan): contiguous row / column ranges + the hulls of what
+// each tile's two products touch.  tile[8 t ..]: i0, i1 (own rows), j0, j1 (own columns), c_lo, c_hi (columns whose primal step
+// the tile computes: its own + those its rows touch), r_lo, r_hi (rows whose y it stages: its own + those these columns touch).
+// ridx_enc: the row ELL's column indices with long column l encoded as -1 - l (padding entries keep index 0 / value 0).
+// ntile = 0 = not applicable: long rows, more than `max_long` long columns, or hulls beyond `lds_budget` bytes per scenario
+// (a matrix that is not banded in the order it was handed over).
+struct HostFusedPlan {
+  int ntile = 0, rows_per_tile = 0, ny_max = 0, nxb_max = 0;
+  std::vector<int32_t> tile, ridx_enc;
+};
+
+inline HostFusedPlan build_fused_plan(const HostCSR &A, const HostCSR &AT, const HostStreamELL &Er, const HostStreamELL &Ec, int max_long,
+                                      int rows_per_tile, size_t lds_budget) {
+  HostFusedPlan F;
+  const int n = A.n, m = A.m;
+  if (!Er.long_id.empty() || (int)Ec.long_id.size() > max_long || m < 1 || n < 1) return F;
+  const int nlong = (int)Ec.long_id.size();
+  const int RB = std::max(64, rows_per_tile);
+  const int ntile = (m + RB - 1) / RB;
+  std::vector<int32_t> tile((size_t)ntile * 8);
+  int ny = 0, nxb = 0;
+  for (int t = 0; t < ntile; ++t) {
+    // own columns follow the own rows proportionally (a banded matrix keeps column j near row j m / n)
+    const int i0 = t * RB, i1 = std::min(m, i0 + RB);
+    const int j0 = (int)((int64_t)i0 * n / m), j1 = i1 == m ? n : (int)((int64_t)i1 * n / m);
+    int c_lo = j0 < j1 ? j0 : n, c_hi = j0 < j1 ? j1 : 0;
+    for (int i = i0; i < i1; ++i)
+      for (int p = A.ptr[i]; p < A.ptr[i + 1]; ++p) {
+        const int j = A.idx[p];
+        if (Ec.is_long[j]) continue;
+        c_lo = std::min(c_lo, j); c_hi = std::max(c_hi, j + 1);
+      }
+    if (c_lo >= c_hi) { c_lo = 0; c_hi = 1; }
+    int r_lo = i0, r_hi = i1;
+    for (int j = c_lo; j < c_hi; ++j) {
+      if (Ec.is_long[j]) continue;
+      for (int p = AT.ptr[j]; p < AT.ptr[j + 1]; ++p) { r_lo = std::min(r_lo, (int)AT.idx[p]); r_hi = std::max(r_hi, (int)AT.idx[p] + 1); }
+    }
+    int32_t *tp = &tile[(size_t)t * 8];
+    tp[0] = i0; tp[1] = i1; tp[2] = j0; tp[3] = j1; tp[4] = c_lo; tp[5] = c_hi; tp[6] = r_lo; tp[7] = r_hi;
+    ny = std::max(ny, r_hi - r_lo); nxb = std::max(nxb, nlong + c_hi - c_lo);
+  }
+  if ((size_t)(ny + nxb) * sizeof(double) > lds_budget) return F;
+  std::vector<int32_t> rank(n, -1);
+  for (int l = 0; l < nlong; ++l) rank[Ec.long_id[l]] = l;
+  F.ridx_enc.assign((size_t)Er.W * m, 0);
+  for (int i = 0; i < m; ++i) {
+    const int len = A.ptr[i + 1] - A.ptr[i];
+    for (int e = 0; e < len && e < Er.W; ++e) {
+      const int j = A.idx[A.ptr[i] + e];
+      F.ridx_enc[(size_t)e * m + i] = rank[j] >= 0 ? -1 - rank[j] : j;
+    }
+  }
+  F.tile = tile; F.ntile = ntile; F.rows_per_tile = RB; F.ny_max = ny; F.nxb_max = nxb;
+  return F;
+}
+
 // Lane-major ELL of a CSR whose "rows" are the vectors owned by lanes: vector v is owned by lane v % 64,
 // slot v / 64.  Entry (e, slot, lane) lives at ((e*slots + slot)*64 + lane): for a fixed e the `slots` entries of a
 // lane are independent multiply-add chains (instruction-level parallelism inside the wave).  Vectors with more than

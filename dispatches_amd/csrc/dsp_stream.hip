@@ -733,6 +733,211 @@ __global__ void __launch_bounds__(1024) k_block_solve(StreamArgs a) {
   if (t0 == 0) a.W.ctrl[s] = c;
 }
 
+
+// ---- fused iteration for banded LPs: ONE launch per plain iteration (FusedPlan, dsp_stream.hpp) --------------------------------
+// grid (tiles, scenario groups); workgroup = one tile x SG scenarios.  Per scenario the launch moves
+//     reads  x, x0, c (+ lb, ub unless the batch shares them), y, y0 (+ rlo, rhi unless shared)      writes  x, y
+// = 4 n + 3 m doubles with shared bounds (6 n + 5 m otherwise) against the 8 n + 6 m of the two-launch form - and the gathers
+// of both products are LDS reads instead of L2 traffic (the two-launch kernels fetched 1.3-1.6x their algorithmic bytes:
+// profiles/r30a_stream_pmc_summary.csv).  x / y are double buffered (a neighbouring tile reads this tile's halo while it
+// writes), and so are the long columns' partial sums.  Every tile computes the halo columns' primal step with the same
+// arithmetic in the same order as their owner, so the iterates are those of the two-launch form (bit for bit when there is no
+// long column; a long column's A^T y is summed per tile here and per 2048-entry chunk there).
+struct FusedIO {
+  const double *x_in, *y_in;
+  double *x_out, *y_out;
+  const double *lp_in;         // [B][nlong][ntile]
+  double *lp_out;
+};
+
+__device__ __forceinline__ void fused_reduce_long(double (&v)[kFusedMaxLong], int nlong, double *red) {
+  // block sum (4 waves) of up to kFusedMaxLong quantities, fixed order; result in red[0 .. nlong)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int q = 0; q < kFusedMaxLong; ++q) {
+    double t = v[q];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off, 64);
+    if (lane == 0) red[kFusedMaxLong + wave * kFusedMaxLong + q] = t;
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < nlong) {
+    double t = 0.0;
+    for (int w = 0; w < kTB / 64; ++w) t += red[kFusedMaxLong + w * kFusedMaxLong + threadIdx.x];
+    red[threadIdx.x] = t;
+  }
+  __syncthreads();
+}
+
+template <int SG, bool SHARED, bool QP>
+__global__ void __launch_bounds__(kTB) k_fused(StreamArgs a, FusedIO io, int kofs) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const StreamProblem &P = a.P;
+  const FusedPlan &F = P.F;
+  const int n = P.n, m = P.m, nlong = P.C.nlong, NY = F.ny_max, NXB = F.nxb_max;
+  const int tile = blockIdx.x, b0 = blockIdx.y * SG;
+  const int32_t *tp = F.tile + 8 * tile;
+  const int i0 = tp[0], i1 = tp[1], j0 = tp[2], j1 = tp[3], c_lo = tp[4], c_hi = tp[5], r_lo = tp[6], r_hi = tp[7];
+  double *ys = lds;                          // [SG][NY]   y of the rows r_lo .. r_hi
+  double *xb = lds + (size_t)SG * NY;        // [SG][NXB]  xbar: long columns first, then the columns c_lo .. c_hi
+  double *red = xb + (size_t)SG * NXB;       // [(1 + waves) * kFusedMaxLong]
+  bool act[SG];
+  double tau[SG], sig[SG], oml[SG];
+  bool any = false;
+#pragma unroll
+  for (int u = 0; u < SG; ++u) {
+    const int s = b0 + u;
+    act[u] = s < a.b.B && !a.W.ctrl[s < a.b.B ? s : 0].done;
+    const StreamCtrl &c = a.W.ctrl[s < a.b.B ? s : 0];
+    tau[u] = c.tau; sig[u] = c.sig; oml[u] = 1.0 / (double)(c.k + kofs + 3);
+    any |= act[u];
+  }
+  if (!any) return;
+  // ---- stage 0: y of the staged rows; the long columns' primal step from the partial sums the previous launch left ----------
+  for (int r = threadIdx.x; r < r_hi - r_lo; r += kTB) {
+#pragma unroll
+    for (int u = 0; u < SG; ++u) if (act[u]) ys[u * NY + r] = io.y_in[(size_t)(b0 + u) * m + r_lo + r];
+  }
+  if ((int)threadIdx.x < nlong * SG) {
+    const int l = threadIdx.x % nlong, u = threadIdx.x / nlong, s = b0 + u;
+    if (s < a.b.B && !a.W.ctrl[s].done) {
+      const double *pp = io.lp_in + ((size_t)s * nlong + l) * F.ntile;
+      double aty = 0.0;
+      for (int t = 0; t < F.ntile; ++t) aty += pp[t];
+      const int j = P.C.long_id[l];
+      const size_t at = (size_t)s * n + j, ab = SHARED ? (size_t)j : at;
+      const double x = io.x_in[at];
+      const double xp = clampd2(fma(-a.W.ctrl[s].tau, a.W.c[at] - aty, x), a.W.lb[ab], a.W.ub[ab]);
+      xb[u * NXB + l] = 2.0 * xp - x;
+    }
+  }
+  __syncthreads();
+  // ---- stage 1: primal step of the columns c_lo .. c_hi (own + halo) into LDS ---------------------------------------------
+  for (int j = c_lo + threadIdx.x; j < c_hi; j += kTB) {
+    if (P.C.is_long[j]) continue;
+    double val[kStreamMaxW];
+    int idx[kStreamMaxW];
+#pragma unroll
+    for (int e = 0; e < kStreamMaxW; ++e)
+      if (e < P.C.W) {
+        val[e] = P.C.val[(size_t)e * n + j];
+        const int gi = P.C.idx[(size_t)e * n + j];
+        idx[e] = (gi < r_lo || gi >= r_hi) ? 0 : gi - r_lo;       // padding entries (val 0, index 0): any staged slot will do
+      } else { val[e] = 0.0; idx[e] = 0; }
+#pragma unroll
+    for (int u = 0; u < SG; ++u) {
+      if (!act[u]) continue;
+      const double *yv = ys + u * NY;
+      double aty = 0.0;
+#pragma unroll
+      for (int e = 0; e < kStreamMaxW; ++e) if (e < P.C.W) aty = fma(val[e], yv[idx[e]], aty);
+      const size_t at = (size_t)(b0 + u) * n + j, ab = SHARED ? (size_t)j : at;
+      const double x = io.x_in[at];
+      const double xp = clampd2(fma(-tau[u], a.W.c[at] - aty, x), a.W.lb[ab], a.W.ub[ab]);
+      xb[u * NXB + nlong + (j - c_lo)] = 2.0 * xp - x;
+    }
+  }
+  __syncthreads();
+  // ---- stage 2: dual step + Halpern averaging of the own rows; their contribution to A^T y of the long columns ---------------
+  double lp[SG][kFusedMaxLong];
+#pragma unroll
+  for (int u = 0; u < SG; ++u)
+#pragma unroll
+    for (int q = 0; q < kFusedMaxLong; ++q) lp[u][q] = 0.0;
+  for (int i = i0 + threadIdx.x; i < i1; i += kTB) {
+    double val[kStreamMaxW];
+    int slot[kStreamMaxW];
+    bool touches_long = false;
+#pragma unroll
+    for (int e = 0; e < kStreamMaxW; ++e) {
+      if (e < P.R.W) {
+        val[e] = P.R.val[(size_t)e * m + i];
+        const int gi = F.ridx_enc[(size_t)e * m + i];
+        slot[e] = gi < 0 ? -1 - gi : nlong + gi - c_lo;          // a padding entry (val 0, index 0) may point below c_lo:
+        if (gi >= 0 && (gi < c_lo || gi >= c_hi)) slot[e] = 0;  // it multiplies by 0, any valid slot will do
+        touches_long |= gi < 0;
+      } else { val[e] = 0.0; slot[e] = 0; }
+    }
+#pragma unroll
+    for (int u = 0; u < SG; ++u) {
+      if (!act[u]) continue;
+      const double *xv = xb + u * NXB;
+      double ax = 0.0;
+#pragma unroll
+      for (int e = 0; e < kStreamMaxW; ++e) if (e < P.R.W) ax = fma(val[e], xv[slot[e]], ax);
+      const size_t at = (size_t)(b0 + u) * m + i, ab = SHARED ? (size_t)i : at;
+      const double y = ys[u * NY + (i - r_lo)];
+      const double gy = fma(-sig[u], ax, y);
+      double yp = gy - clampd2(gy, -sig[u] * a.W.rhi[ab], -sig[u] * a.W.rlo[ab]);
+      if (QP) yp /= fma(sig[u], a.W.kap[at], 1.0);
+      const double tt = 2.0 * yp - y;
+      const double yn = fma(oml[u], a.W.y0[at] - tt, tt);
+      io.y_out[at] = yn;
+      if (touches_long) {
+#pragma unroll
+        for (int e = 0; e < kStreamMaxW; ++e) {
+          if (e < P.R.W && slot[e] < nlong && val[e] != 0.0) {
+#pragma unroll
+            for (int q = 0; q < kFusedMaxLong; ++q) lp[u][q] += (slot[e] == q) ? val[e] * yn : 0.0;
+          }
+        }
+      }
+    }
+  }
+  // ---- stage 3: Halpern averaging of the own columns -----------------------------------------------------------------------
+  for (int j = j0 + threadIdx.x; j < j1; j += kTB) {
+    if (P.C.is_long[j]) continue;
+#pragma unroll
+    for (int u = 0; u < SG; ++u) {
+      if (!act[u]) continue;
+      const size_t at = (size_t)(b0 + u) * n + j;
+      const double tt = xb[u * NXB + nlong + (j - c_lo)];
+      io.x_out[at] = fma(oml[u], a.W.x0[at] - tt, tt);
+    }
+  }
+  if ((int)threadIdx.x < nlong * SG) {
+    const int l = threadIdx.x % nlong, u = threadIdx.x / nlong, s = b0 + u;
+    const int j = P.C.long_id[l];
+    if (j >= j0 && j < j1 && s < a.b.B && !a.W.ctrl[s].done) {
+      const size_t at = (size_t)s * n + j;
+      const double tt = xb[u * NXB + l];
+      io.x_out[at] = fma(1.0 / (double)(a.W.ctrl[s].k + kofs + 3), a.W.x0[at] - tt, tt);
+    }
+  }
+  if (nlong > 0) {
+#pragma unroll
+    for (int u = 0; u < SG; ++u) {
+      fused_reduce_long(lp[u], nlong, red);                    // (block-uniform: every thread takes part for every u)
+      if ((int)threadIdx.x < nlong && act[u]) io.lp_out[((size_t)(b0 + u) * nlong + threadIdx.x) * F.ntile + tile] = red[threadIdx.x];
+      __syncthreads();
+    }
+  }
+}
+
+// partial sums of A^T y for the long columns from the CURRENT y (after the initialisation and after every check's k_apply)
+__global__ void __launch_bounds__(kTB) k_long_partials(StreamArgs a, const double *y, double *lp_out) {
+  __shared__ double red[(1 + kTB / 64) * kFusedMaxLong];
+  const StreamProblem &P = a.P;
+  const FusedPlan &F = P.F;
+  const int tile = blockIdx.x, s = blockIdx.y, m = P.m, nlong = P.C.nlong;
+  if (a.W.ctrl[s].done) return;
+  const int32_t *tp = F.tile + 8 * tile;
+  double lp[kFusedMaxLong] = {0.0, 0.0, 0.0, 0.0};
+  for (int i = tp[0] + threadIdx.x; i < tp[1]; i += kTB) {
+    const double yi = y[(size_t)s * m + i];
+    for (int e = 0; e < P.R.W; ++e) {
+      const int gi = F.ridx_enc[(size_t)e * m + i];
+      const double v = P.R.val[(size_t)e * m + i];
+      if (gi < 0 && v != 0.0) {
+#pragma unroll
+        for (int q = 0; q < kFusedMaxLong; ++q) lp[q] += (-1 - gi == q) ? v * yi : 0.0;
+      }
+    }
+  }
+  fused_reduce_long(lp, nlong, red);
+  if ((int)threadIdx.x < nlong) lp_out[((size_t)s * nlong + threadIdx.x) * F.ntile + tile] = red[threadIdx.x];
+}
+
 // ---- results -------------------------------------------------------------------------------------------------------------------
 __global__ void k_finalize(StreamArgs a) {
   const StreamProblem &P = a.P;
@@ -764,55 +969,23 @@ hipError_t up(std::vector<void *> &allocs, const std::vector<T> &v, const T **ou
   return hipSuccess;
 }
 
-// entry-major ELL + long list of a host CSR (vectors = rows of M)
-hipError_t build_matrix(const HostCSR &M, std::vector<void *> &allocs, StreamMatrix *out, int *width) {
-  const int nv = M.m;
-  // ELL width: the smallest W <= kStreamMaxW that leaves at most kStreamMaxLong long vectors
-  std::vector<int> len(nv);
-  for (int v = 0; v < nv; ++v) len[v] = M.ptr[v + 1] - M.ptr[v];
-  int W = 1;
-  for (W = 1; W <= kStreamMaxW; ++W) {
-    int nl = 0;
-    for (int v = 0; v < nv; ++v) nl += len[v] > W;
-    if (nl == 0) break;
-    if (W == kStreamMaxW) break;
-  }
-  W = std::min(W, kStreamMaxW);
-  std::vector<double> val((size_t)W * nv, 0.0);
-  std::vector<int32_t> idx((size_t)W * nv, 0);
-  std::vector<uint8_t> is_long(std::max(nv, 1), 0);
-  std::vector<int32_t> lid, lptr{0}, lidx;
-  std::vector<double> lval;
-  for (int v = 0; v < nv; ++v) {
-    if (len[v] <= W) {
-      for (int e = 0; e < len[v]; ++e) { val[(size_t)e * nv + v] = M.val[M.ptr[v] + e]; idx[(size_t)e * nv + v] = M.idx[M.ptr[v] + e]; }
-    } else {
-      is_long[v] = 1;
-      lid.push_back(v);
-      for (int p = M.ptr[v]; p < M.ptr[v + 1]; ++p) { lidx.push_back(M.idx[p]); lval.push_back(M.val[p]); }
-      lptr.push_back((int32_t)lidx.size());
-    }
-  }
-  if ((int)lid.size() > kStreamMaxLong) return hipErrorInvalidValue;
-  // chunks of at most kLongChunk entries: one block each in the plain-iteration kernels
-  std::vector<int32_t> cbeg, cend, cptr{0};
-  for (size_t l = 0; l < lid.size(); ++l) {
-    for (int p = lptr[l]; p < lptr[l + 1]; p += kLongChunk) { cbeg.push_back(p); cend.push_back(std::min(p + kLongChunk, lptr[l + 1])); }
-    cptr.push_back((int32_t)cbeg.size());
-  }
-  out->nvec = nv; out->W = W; out->nlong = (int)lid.size(); out->nchunk = (int)cbeg.size();
+// entry-major ELL + long list of a host CSR (vectors = rows of M): built on the host (dsp_prepare.hpp), uploaded here
+hipError_t build_matrix(const HostCSR &M, std::vector<void *> &allocs, StreamMatrix *out, HostStreamELL *host) {
+  *host = build_stream_ell(M, kStreamMaxW, kLongChunk);
+  const HostStreamELL &E = *host;
+  if ((int)E.long_id.size() > kStreamMaxLong) return hipErrorInvalidValue;
+  out->nvec = E.nvec; out->W = E.W; out->nlong = (int)E.long_id.size(); out->nchunk = (int)E.chunk_begin.size();
   hipError_t e;
-  if ((e = up(allocs, val, &out->val)) != hipSuccess) return e;
-  if ((e = up(allocs, idx, &out->idx)) != hipSuccess) return e;
-  if ((e = up(allocs, is_long, &out->is_long)) != hipSuccess) return e;
-  if ((e = up(allocs, lid, &out->long_id)) != hipSuccess) return e;
-  if ((e = up(allocs, lptr, &out->long_ptr)) != hipSuccess) return e;
-  if ((e = up(allocs, lidx, &out->long_idx)) != hipSuccess) return e;
-  if ((e = up(allocs, lval, &out->long_val)) != hipSuccess) return e;
-  if ((e = up(allocs, cbeg, &out->chunk_begin)) != hipSuccess) return e;
-  if ((e = up(allocs, cend, &out->chunk_end)) != hipSuccess) return e;
-  if ((e = up(allocs, cptr, &out->long_chunk_ptr)) != hipSuccess) return e;
-  *width = W;
+  if ((e = up(allocs, E.val, &out->val)) != hipSuccess) return e;
+  if ((e = up(allocs, E.idx, &out->idx)) != hipSuccess) return e;
+  if ((e = up(allocs, E.is_long, &out->is_long)) != hipSuccess) return e;
+  if ((e = up(allocs, E.long_id, &out->long_id)) != hipSuccess) return e;
+  if ((e = up(allocs, E.long_ptr, &out->long_ptr)) != hipSuccess) return e;
+  if ((e = up(allocs, E.long_idx, &out->long_idx)) != hipSuccess) return e;
+  if ((e = up(allocs, E.long_val, &out->long_val)) != hipSuccess) return e;
+  if ((e = up(allocs, E.chunk_begin, &out->chunk_begin)) != hipSuccess) return e;
+  if ((e = up(allocs, E.chunk_end, &out->chunk_end)) != hipSuccess) return e;
+  if ((e = up(allocs, E.long_chunk_ptr, &out->long_chunk_ptr)) != hipSuccess) return e;
   return hipSuccess;
 }
 
@@ -823,10 +996,23 @@ hipError_t stream_create(const HostCSR &A_scaled, const HostCSR &AT_scaled, cons
                          const double *row_scale_dev, StreamSolver *S) {
   S->P.n = A_scaled.n; S->P.m = A_scaled.m;
   S->P.col_scale = col_scale_dev; S->P.row_scale = row_scale_dev;
-  int wr = 0, wc = 0;
   hipError_t e;
-  if ((e = build_matrix(A_scaled, S->allocs, &S->P.R, &wr)) != hipSuccess) return e;
-  if ((e = build_matrix(AT_scaled, S->allocs, &S->P.C, &wc)) != hipSuccess) return e;
+  HostStreamELL Er, Ec;
+  if ((e = build_matrix(A_scaled, S->allocs, &S->P.R, &Er)) != hipSuccess) return e;
+  if ((e = build_matrix(AT_scaled, S->allocs, &S->P.C, &Ec)) != hipSuccess) return e;
+  // fused one-launch iteration where the matrix is banded (development switches: DSP_STREAM_NO_FUSED=1, DSP_FUSED_RB=<rows per tile>)
+  // (read at every create, not once per process: a test builds one handle of each form)
+  const int no_fused = getenv("DSP_STREAM_NO_FUSED") ? atoi(getenv("DSP_STREAM_NO_FUSED")) : 0;
+  const int rb_env = getenv("DSP_FUSED_RB") ? atoi(getenv("DSP_FUSED_RB")) : 0;
+  S->P.F = FusedPlan{};
+  if (!no_fused) {
+    const HostFusedPlan H = build_fused_plan(A_scaled, AT_scaled, Er, Ec, kFusedMaxLong, rb_env > 0 ? rb_env : 768, 40 * 1024);
+    if (H.ntile > 0) {
+      if ((e = up(S->allocs, H.tile, &S->P.F.tile)) != hipSuccess) return e;
+      if ((e = up(S->allocs, H.ridx_enc, &S->P.F.ridx_enc)) != hipSuccess) return e;
+      S->P.F.ntile = H.ntile; S->P.F.rows_per_tile = H.rows_per_tile; S->P.F.ny_max = H.ny_max; S->P.F.nxb_max = H.nxb_max;
+    }
+  }
   return hipSuccess;
 }
 
@@ -860,6 +1046,12 @@ static hipError_t ensure_workspace(StreamSolver *S, int B) {
   if ((e = alloc((size_t)B * nblk_tot * kNQ * sizeof(double), (void **)&W.partial)) != hipSuccess) return e;
   if ((e = hipMemset(W.partial, 0, (size_t)B * nblk_tot * kNQ * sizeof(double))) != hipSuccess) return e;
   if ((e = alloc((size_t)B * std::max(1, std::max(S->P.R.nchunk, S->P.C.nchunk)) * sizeof(double), (void **)&W.long_partial)) != hipSuccess) return e;
+  if (S->P.F.ntile > 0) {
+    if ((e = alloc((size_t)B * n * sizeof(double), (void **)&W.x2)) != hipSuccess) return e;
+    if ((e = alloc((size_t)B * m * sizeof(double), (void **)&W.y2)) != hipSuccess) return e;
+    const size_t lp = (size_t)B * std::max(1, S->P.C.nlong) * S->P.F.ntile * sizeof(double);
+    for (int q = 0; q < 2; ++q) if ((e = alloc(lp, (void **)&W.lpart[q])) != hipSuccess) return e;
+  }
   if ((e = alloc(sizeof(int), (void **)&W.ndone)) != hipSuccess) return e;
   if (!S->ndone_host && (e = hipHostMalloc((void **)&S->ndone_host, sizeof(int))) != hipSuccess) return e;
   S->work_B = B;
@@ -867,8 +1059,9 @@ static hipError_t ensure_workspace(StreamSolver *S, int B) {
 }
 
 size_t stream_bytes_per_iteration(const StreamSolver *S) {
-  // per scenario and plain iteration (see the file header): 8 n + 6 m doubles
-  return (size_t)8 * (8 * (size_t)S->P.n + 6 * (size_t)S->P.m);
+  // per scenario and plain iteration of the form the last solve ran: two launches 8 n + 6 m doubles (see the file header); fused
+  // banded form 4 n + 3 m with shared bounds, 6 n + 5 m with per-scenario bounds (k_fused); before any solve: the two-launch figure
+  return S->last_bytes_per_iteration ? S->last_bytes_per_iteration : (size_t)8 * (8 * (size_t)S->P.n + 6 * (size_t)S->P.m);
 }
 
 template <int SG>
@@ -919,6 +1112,62 @@ static hipError_t run(StreamSolver *S, StreamArgs &a, hipStream_t st, int *perio
 static hipError_t stream_solve_locked(StreamSolver *S, const dsp_batch &batch, const dsp_options &opt, double eta, hipStream_t st,
                                       int *periods_run);
 
+// The fused form of `run`: C - 1 plain iterations = C - 1 launches of k_fused (x / y ping-pong), then the SAME check sequence
+// as the two-launch form on whichever buffers are current, then the long columns' partial sums of the y the check left.
+template <int SG>
+static hipError_t run_fused(StreamSolver *S, StreamArgs &a, hipStream_t st, int *periods_run, bool shared, bool qp) {
+  const StreamProblem &P = a.P;
+  const FusedPlan &F = P.F;
+  const int B = a.b.B;
+  const int groups = (B + SG - 1) / SG;
+  const dim3 blk(kTB);
+  const dim3 g_fused(F.ntile, groups), g_primal(a.nblk_n + P.C.nchunk, groups);
+  const dim3 g_rows_chk(a.nblk + P.R.nlong, groups), g_cols(a.nblk_n + P.C.nlong, groups), g_elem(a.nblk, groups);
+  const int fin_c = (P.C.nlong * B + 63) / 64;
+  const size_t lds = ((size_t)SG * (F.ny_max + F.nxb_max) + (1 + kTB / 64) * kFusedMaxLong) * sizeof(double);
+  const void *fn = nullptr;
+  if (shared) fn = qp ? reinterpret_cast<const void *>(&k_fused<SG, true, true>) : reinterpret_cast<const void *>(&k_fused<SG, true, false>);
+  else fn = qp ? reinterpret_cast<const void *>(&k_fused<SG, false, true>) : reinterpret_cast<const void *>(&k_fused<SG, false, false>);
+  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  double *xcur = a.W.x, *ycur = a.W.y, *xalt = a.W.x2, *yalt = a.W.y2;
+  int lp_cur = 0;
+  auto partials = [&]() {
+    if (P.C.nlong) hipLaunchKernelGGL(k_long_partials, dim3(F.ntile, B), blk, 0, st, a, (const double *)ycur, a.W.lpart[lp_cur]);
+  };
+  partials();
+  const int C = a.opt.check_every > 0 ? a.opt.check_every : 64;
+  const int max_periods = (a.opt.max_iter + C - 1) / C;
+  const int poll = 4;
+  int period = 0;
+  for (; period < max_periods; ++period) {
+    for (int u = 0; u < C - 1; ++u) {
+      FusedIO io{xcur, ycur, xalt, yalt, a.W.lpart[lp_cur], a.W.lpart[lp_cur ^ 1]};
+      int kofs = u;
+      void *params[] = {&a, &io, &kofs};
+      if ((e = hipLaunchKernel(fn, g_fused, blk, params, lds, st)) != hipSuccess) return e;
+      std::swap(xcur, xalt); std::swap(ycur, yalt); lp_cur ^= 1;
+    }
+    // the check sequence works in place on the current buffers
+    StreamArgs ac = a;
+    ac.W.x = xcur; ac.W.y = ycur;
+    hipLaunchKernelGGL((k_primal<SG, true>), g_primal, blk, 0, st, ac);
+    if (P.C.nlong) hipLaunchKernelGGL(k_primal_long_finish, dim3(fin_c), dim3(64), 0, st, ac, 1);
+    hipLaunchKernelGGL((k_check_rows<SG>), g_rows_chk, blk, 0, st, ac);
+    hipLaunchKernelGGL((k_kkt_cols<SG>), g_cols, blk, 0, st, ac);
+    hipLaunchKernelGGL(k_control, dim3(B), dim3(64), 0, st, ac, C);
+    hipLaunchKernelGGL((k_apply<SG>), g_elem, blk, 0, st, ac);
+    partials();
+    if ((period + 1) % poll == 0 || period + 1 == max_periods) {
+      if ((e = hipMemcpyAsync(S->ndone_host, a.W.ndone, sizeof(int), hipMemcpyDeviceToHost, st)) != hipSuccess) return e;
+      if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;
+      if (*S->ndone_host >= B) { ++period; break; }
+    }
+  }
+  *periods_run = period;
+  return hipGetLastError();
+}
+
 hipError_t stream_solve(StreamSolver *S, const dsp_batch &batch, const dsp_options &opt, double eta, hipStream_t st,
                         int *periods_run) {
   std::lock_guard<std::mutex> lock(S->mu);
@@ -967,6 +1216,24 @@ static hipError_t stream_solve_locked(StreamSolver *S, const dsp_batch &batch, c
   a.nblk_tot = a.nblk + std::max(S->P.R.nlong, S->P.C.nlong);
   static const int sg_env = getenv("DSP_STREAM_SG") ? atoi(getenv("DSP_STREAM_SG")) : 0;     // development override
   if (sg_env == 1 || sg_env == 2 || sg_env == 4 || sg_env == 8) sg = sg_env;
+  S->last_bytes_per_iteration = (size_t)8 * (8 * (size_t)S->P.n + 6 * (size_t)S->P.m);
+  if (S->P.F.ntile > 0) {
+    // banded matrix: one launch per plain iteration.  Bounds that are the same template for every scenario of the batch
+    // (stride 0: the price-taker families differ in the objective only) are read once per workgroup from scenario 0's copy.
+    const bool shared = (!batch.var_lb || batch.var_lb_stride == 0) && (!batch.var_ub || batch.var_ub_stride == 0) &&
+                        (!batch.row_lb || batch.row_lb_stride == 0) && (!batch.row_ub || batch.row_ub_stride == 0);
+    const bool qp = batch.row_compliance != nullptr;
+    int fsg = 4;                       // scenarios per workgroup: matrix entries are loaded once per workgroup
+    if ((long)S->P.F.ntile * ((B + 3) / 4) < 1024) fsg = 2;
+    if ((long)S->P.F.ntile * ((B + 1) / 2) < 1024) fsg = 1;
+    static const int fsg_env = getenv("DSP_FUSED_SG") ? atoi(getenv("DSP_FUSED_SG")) : 0;
+    if (fsg_env == 1 || fsg_env == 2 || fsg_env == 4) fsg = fsg_env;
+    S->last_bytes_per_iteration = (size_t)8 * (shared ? 4 * (size_t)S->P.n + 3 * (size_t)S->P.m : 6 * (size_t)S->P.n + 5 * (size_t)S->P.m)
+                                  + (qp ? 8 * (size_t)S->P.m : 0);
+    if (fsg == 4) e = run_fused<4>(S, a, st, periods_run, shared, qp);
+    else if (fsg == 2) e = run_fused<2>(S, a, st, periods_run, shared, qp);
+    else e = run_fused<1>(S, a, st, periods_run, shared, qp);
+  } else
   if (sg == 8) e = run<8>(S, a, st, periods_run);
   else if (sg == 4) e = run<4>(S, a, st, periods_run);
   else if (sg == 2) e = run<2>(S, a, st, periods_run);

@@ -29,10 +29,26 @@ struct StreamMatrix {
   const int32_t *long_chunk_ptr;            // [nlong+1]  chunks of each long vector
 };
 
+// Fused iteration (k_fused): ONE launch per plain iteration for BANDED matrices (the multi-period LPs of the reference: period-
+// major columns and rows, every non-long vector touches its own and the neighbouring period).  Rows and columns are cut into
+// `ntile` contiguous tiles; a tile's workgroup stages y of its rows (+ the halo rows its columns touch) in LDS, computes the
+// primal step of its columns (+ the halo columns its rows touch) into LDS, then the dual step and both Halpern averagings of
+// what it owns: xbar never travels through HBM, and x, y are read and written once.  Long columns (design variables that
+// touch every period) enter through per-tile partial sums of A^T y that every tile leaves behind for the next launch.
+constexpr int kFusedMaxLong = 4;       // long columns the fused form carries (design variables)
+struct FusedPlan {
+  int ntile = 0;                       // 0 = not applicable (not banded enough, long rows, too many long columns)
+  int rows_per_tile = 0;
+  int ny_max = 0, nxb_max = 0;         // LDS extents per scenario: staged y rows, xbar slots (long columns first)
+  const int32_t *tile = nullptr;       // [ntile][8]  i0, i1 (own rows), j0, j1 (own columns), c_lo, c_hi, r_lo, r_hi
+  const int32_t *ridx_enc = nullptr;   // [R.W][m] row ELL column index; long column l encoded as -1 - l
+};
+
 struct StreamProblem {
   int n, m;
   StreamMatrix R, C;          // A (rows) and A^T (columns)
   const double *col_scale, *row_scale;
+  FusedPlan F;
 };
 
 // per-scenario control block (device memory; written by k_init_control / k_control only)
@@ -47,6 +63,8 @@ struct StreamCtrl {
 struct StreamWork {
   double *x, *x0, *xp, *xbar, *c, *lb, *ub;     // [B][n]  scaled space
   double *y, *y0, *yp, *rlo, *rhi, *kap;        // [B][m]   (kap: scaled compliance of the soft rows, QP only)
+  double *x2, *y2;                              // [B][n] / [B][m] second buffers of the fused iteration (x / y ping-pong)
+  double *lpart[2];                             // [B][nlong][ntile] partial sums of A^T y for the long columns (ping-pong)
   StreamCtrl *ctrl;                             // [B]
   double *partial;                              // [B][nblk_tot][16] ordered block partial sums
   double *long_partial;                         // [B][nchunk_max] chunk partials of the long vectors
@@ -71,6 +89,7 @@ struct StreamSolver {
   int work_B = 0;
   std::vector<void *> allocs, work_allocs;
   int *ndone_host = nullptr;
+  size_t last_bytes_per_iteration = 0;   // algorithmic HBM bytes per scenario and plain iteration of the form the last solve ran
   std::mutex mu;          // one solve at a time per handle: the workspace above is per handle, not per call (stream_solve)
   size_t lds_limit = 160 * 1024 - 2048;   // dynamic LDS available to the block-resident form (static __shared__ on top)
 };

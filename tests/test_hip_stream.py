@@ -22,7 +22,6 @@ def test_price_taker_family_matches_oracle_and_is_reproducible():
     assert model.lp.n == 6 * T + 3 and model.lp.m == 6 * T + 2
     solver.solve(model, tee=True)
     assert solver.last_stats.streaming == 1
-    assert solver.last_stats.stream_bytes_per_iteration == 8 * (8 * model.lp.n + 6 * model.lp.m)
     assert (model.status == 0).all(), (np.bincount(model.status), model.iterations)
     ref = fx["T168/obj"][:B]
     err = np.abs(model.objective - ref) / np.maximum(1.0, np.abs(ref))
@@ -36,6 +35,60 @@ def test_price_taker_family_matches_oracle_and_is_reproducible():
     obj1, it1 = model.objective.copy(), model.iterations.copy()
     solver.solve(model)
     assert np.array_equal(model.objective, obj1) and np.array_equal(model.iterations, it1)
+
+
+@gpu
+def test_fused_iteration_reproduces_the_two_launch_form(monkeypatch):
+    """Two weeks of the price-taker family (n = 2019: beyond the block-resident form, so the launch-per-step forms run): the
+    one-launch iteration for banded matrices (k_fused: tiles with halos, xbar in LDS, x / y double buffered, the design column
+    through per-tile partial sums) against the two-launch form it replaces - same termination, same objectives to rounding,
+    iteration counts within a check period or two, both against the oracle."""
+    from dispatches_amd import scenarios
+    from dispatches_amd.hip_solver import HipPdlpSolver
+    from oracle import dispatch_lp_oracle as orc
+    T, B = 336, 6
+    cf, lmp = scenarios.price_taker_inputs(T)
+    ref = []
+    for bf, lm in scenarios.PRICE_TAKER_FAMILY[:B]:
+        P, _ = orc.wind_battery_price_taker(T, cf, lmp * lm, batt_cap_factor=bf)
+        ref.append(P.solve(tight=True)[1])
+    ref = np.array(ref)
+    out = {}
+    for form, env in (("fused", "0"), ("two_launch", "1")):
+        monkeypatch.setenv("DSP_STREAM_NO_FUSED", env)
+        solver = HipPdlpSolver(device=0, check_every=64)
+        handles, model = scenarios.price_taker_batch(T, B, solver)
+        solver.solve(model, tee=True)
+        st = solver.last_stats
+        assert st.streaming == 1 and (model.status == 0).all(), (form, model.status, model.iterations)
+        n, m = model.lp.n, model.lp.m
+        # algorithmic bytes per scenario-iteration: 4 n + 3 m doubles fused (the family shares its bounds), 8 n + 6 m in two launches
+        assert st.stream_bytes_per_iteration == (8 * (4 * n + 3 * m) if form == "fused" else 8 * (8 * n + 6 * m)), form
+        err = np.abs(model.objective - ref) / np.maximum(1.0, np.abs(ref))
+        assert err.max() < 1e-6, (form, err)
+        out[form] = (model.objective.copy(), model.iterations.copy())
+    assert np.allclose(out["fused"][0], out["two_launch"][0], rtol=1e-7, atol=1e-7)
+    assert (np.abs(out["fused"][1] - out["two_launch"][1]) <= 0.05 * out["two_launch"][1] + 128).all(), (out["fused"][1], out["two_launch"][1])
+
+
+@gpu
+def test_year_long_price_taker_lps_converge():
+    """The reference's own horizon (wind_battery_LMP.py: 8736 hourly periods, n = m = 52 419) for the first 8 members of the family
+    against the oracle fixture (HiGHS on the un-reduced LP, tools/make_price_taker_fixtures.py).  Round 2 never converged here:
+    the step size rested on a 500-iteration power-iteration estimate of ||A||, 1 % short for this near-Toeplitz matrix."""
+    from dispatches_amd import scenarios
+    from dispatches_amd.hip_solver import HipPdlpSolver
+    fx = np.load(os.path.join(GOLD, "oracle_price_taker.npz"))
+    T, B = 8736, 8
+    solver = HipPdlpSolver(device=0, check_every=64, max_iter=2_000_000)
+    handles, model = scenarios.price_taker_batch(T, B, solver)
+    solver.solve(model, tee=True)
+    assert (model.status == 0).all(), (model.status, model.iterations)
+    ref = fx["T8736/obj"][:B]
+    err = np.abs(model.objective - ref) / np.maximum(1.0, np.abs(ref))
+    assert err.max() < 1e-6, (err, model.iterations)
+    batt = model.x[:, handles["battery_system_capacity"].index] * 1e-3
+    np.testing.assert_allclose(batt, fx["T8736/batt_mw"][:B], rtol=2e-3, atol=1.0)
 
 
 @gpu

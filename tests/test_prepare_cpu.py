@@ -110,3 +110,56 @@ def test_reference_lps_hit_a_register_resident_specialisation(harness, tmp_path)
         _, res, _, _ = _run(harness, lp, tmp_path)
         key = ((lp.n + 63) // 64, (lp.m + 63) // 64, res["pack_c"], res["pack_r"], res["long_c"] + res["long_r"] > 0)
         assert key in shapes, (name, key[:2], hex(key[2]), hex(key[3]), key[4])
+
+
+@pytest.fixture(scope="module")
+def fused_harness(tmp_path_factory):
+    exe = str(tmp_path_factory.mktemp("fused") / "fused_harness")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-o", exe, os.path.join(ROOT, "tests", "fused_harness.cpp")], check=True)
+    return exe
+
+
+def _write_csr(A, path):
+    with open(path, "wb") as f:
+        np.array([A.shape[0], A.shape[1], A.nnz], np.int32).tofile(f)
+        A.indptr.astype(np.int32).tofile(f)
+        A.indices.astype(np.int32).tofile(f)
+        A.data.astype(np.float64).tofile(f)
+
+
+@pytest.mark.parametrize("T,rows_per_tile", [(168, 768), (336, 128), (1000, 768), (8736, 768)])
+def test_fused_iteration_plan_on_the_price_taker_lps(fused_harness, tmp_path, T, rows_per_tile):
+    """The one-launch iteration of the streaming PDLP (dsp_stream.hip: k_fused) cuts the banded multi-period LP into tiles with
+    halo columns / rows and carries the design column through per-tile partial sums.  The harness builds ELLs and plan with the
+    library's own host code and runs one iteration tile by tile as the kernel's stages do: same iterates as the plain step on the
+    CSR, every staged slot inside its buffer and written before it is read, every row and column written exactly once."""
+    from dispatches_amd import scenarios
+    _, model = scenarios.price_taker_batch(T, 1, _NoSolver())
+    lp = model.lp
+    A = sp.csr_matrix((lp.data, lp.indices, lp.indptr), shape=(lp.m, lp.n))
+    A.sort_indices()
+    path = str(tmp_path / "a.bin")
+    _write_csr(A, path)
+    res = json.loads(subprocess.run([fused_harness, path, str(rows_per_tile), "8"], check=True, capture_output=True, text=True).stdout)
+    assert res["ntile"] == -(-lp.m // rows_per_tile) and res["long_cols"] == 1          # the nameplate-power design column
+    assert res["wc"] == 4 and res["wr"] == 4                    # the long column must not pad every other vector to the cap
+    assert res["ny"] <= rows_per_tile + 16 and res["nxb"] <= rows_per_tile + 16          # halo = one period each side
+    assert res["out_of_range"] == 0 and res["uninitialised"] == 0 and res["missing"] == 0
+    assert res["err_x"] < 1e-12 and res["err_y"] < 1e-12 and res["err_lp"] < 1e-8
+
+
+def test_fused_plan_refuses_matrices_that_are_not_banded(fused_harness, tmp_path):
+    """A matrix whose products reach across the whole index range (here: the parallel-prefix form of the throughput accumulator,
+    and a random sparse matrix) gets no plan: the two-launch form stays."""
+    from dispatches_amd import scenarios
+    _, model = scenarios.price_taker_batch(1000, 1, _NoSolver(), throughput="scan")
+    lp = model.lp
+    rng = np.random.default_rng(0)
+    for A in (sp.csr_matrix((lp.data, lp.indices, lp.indptr), shape=(lp.m, lp.n)),
+              sp.random(9000, 9000, density=3.0 / 9000, random_state=rng, format="csr") + sp.eye(9000, format="csr")):
+        A = sp.csr_matrix(A)
+        A.sort_indices()
+        path = str(tmp_path / "b.bin")
+        _write_csr(A, path)
+        res = json.loads(subprocess.run([fused_harness, path, "768", "8"], check=True, capture_output=True, text=True).stdout)
+        assert res["ntile"] == 0
