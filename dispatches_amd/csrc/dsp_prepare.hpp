@@ -199,6 +199,8 @@ inline HostStreamELL build_stream_ell(const HostCSR &M, int max_w, int chunk) {
 // (a matrix that is not banded in the order it was handed over).
 struct HostFusedPlan {
   int ntile = 0, rows_per_tile = 0, ny_max = 0, nxb_max = 0;
+  int own_max = 0;                     // most rows or columns any tile owns
+  int halo_max = 0;                    // most halo rows or halo columns (hull minus own range) of any tile
   std::vector<int32_t> tile, ridx_enc;
 };
 
@@ -232,6 +234,8 @@ inline HostFusedPlan build_fused_plan(const HostCSR &A, const HostCSR &AT, const
     int32_t *tp = &tile[(size_t)t * 8];
     tp[0] = i0; tp[1] = i1; tp[2] = j0; tp[3] = j1; tp[4] = c_lo; tp[5] = c_hi; tp[6] = r_lo; tp[7] = r_hi;
     ny = std::max(ny, r_hi - r_lo); nxb = std::max(nxb, nlong + c_hi - c_lo);
+    F.own_max = std::max(F.own_max, std::max(i1 - i0, j1 - j0));
+    F.halo_max = std::max(F.halo_max, std::max((r_hi - r_lo) - (i1 - i0), (c_hi - c_lo) - (j1 - j0)));
   }
   if ((size_t)(ny + nxb) * sizeof(double) > lds_budget) return F;
   std::vector<int32_t> rank(n, -1);

@@ -798,16 +798,22 @@ __global__ void __launch_bounds__(kTB) k_fused(StreamArgs a, FusedIO io, int kof
 #pragma unroll
     for (int u = 0; u < SG; ++u) if (act[u]) ys[u * NY + r] = io.y_in[(size_t)(b0 + u) * m + r_lo + r];
   }
-  if ((int)threadIdx.x < nlong * SG) {
-    const int l = threadIdx.x % nlong, u = threadIdx.x / nlong, s = b0 + u;
-    if (s < a.b.B && !a.W.ctrl[s].done) {
-      const double *pp = io.lp_in + ((size_t)s * nlong + l) * F.ntile;
-      double aty = 0.0;
-      for (int t = 0; t < F.ntile; ++t) aty += pp[t];
+  // (one wave per (scenario, long column): the ntile partial sums are loaded by the lanes side by side and reduced in a fixed
+  // order - a single thread adding them one after the other was a chain of ntile L2 round trips at the head of EVERY workgroup:
+  // 115 us per launch at 69 tiles, 155 us at 137, profiles/r30b_fused_scan.log)
+  for (int q = threadIdx.x >> 6; q < nlong * SG; q += kTB / 64) {
+    const int l = q % nlong, u = q / nlong, s = b0 + u, lane = threadIdx.x & 63;
+    if (!act[u]) continue;
+    const double *pp = io.lp_in + ((size_t)s * nlong + l) * F.ntile;
+    double aty = 0.0;
+    for (int t = lane; t < F.ntile; t += 64) aty += pp[t];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) aty += __shfl_down(aty, off, 64);
+    if (lane == 0) {
       const int j = P.C.long_id[l];
       const size_t at = (size_t)s * n + j, ab = SHARED ? (size_t)j : at;
       const double x = io.x_in[at];
-      const double xp = clampd2(fma(-a.W.ctrl[s].tau, a.W.c[at] - aty, x), a.W.lb[ab], a.W.ub[ab]);
+      const double xp = clampd2(fma(-tau[u], a.W.c[at] - aty, x), a.W.lb[ab], a.W.ub[ab]);
       xb[u * NXB + l] = 2.0 * xp - x;
     }
   }
@@ -914,6 +920,220 @@ __global__ void __launch_bounds__(kTB) k_fused(StreamArgs a, FusedIO io, int kof
   }
 }
 
+// ---- the same iteration with ONE memory phase ---------------------------------------------------------------------------------
+// k_fused walks through four dependent global-memory phases per workgroup (y -> LDS | x, c | y0 | x0) with a barrier between
+// them: at three workgroups per CU the launch is latency-bound (2.5 TB/s of real traffic, profiles/r30b_*).  Here every thread
+// owns K rows and K columns of the tile (row i0 + tid + k NT, column j0 + tid + k NT) and issues ALL its global loads up front
+// - y, y0 of its rows, x, c, x0 of its columns for SG scenarios, the ELL entries of both, the few halo elements - before the
+// first barrier; after that the workgroup only talks to LDS (y staged, xbar staged) and writes x, y.  MW = the ELL width the
+// register arrays are sized for (4 or 8: at 8 the entries of K = 2 rows + columns alone are 96 VGPRs).
+template <int SG, int K, int MW, bool SHARED, bool QP>
+__global__ void __launch_bounds__(kTB) k_fused_pre(StreamArgs a, FusedIO io, int kofs) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const StreamProblem &P = a.P;
+  const FusedPlan &F = P.F;
+  const int n = P.n, m = P.m, nlong = P.C.nlong, NY = F.ny_max, NXB = F.nxb_max;
+  const int tile = blockIdx.x, b0 = blockIdx.y * SG, tid = threadIdx.x;
+  const int32_t *tp = F.tile + 8 * tile;
+  const int i0 = tp[0], i1 = tp[1], j0 = tp[2], j1 = tp[3], c_lo = tp[4], c_hi = tp[5], r_lo = tp[6], r_hi = tp[7];
+  double *ys = lds, *xb = lds + (size_t)SG * NY, *red = xb + (size_t)SG * NXB;
+  bool act[SG];
+  double tau[SG], sig[SG], oml[SG];
+  bool any = false;
+#pragma unroll
+  for (int u = 0; u < SG; ++u) {
+    const int s = b0 + u;
+    const StreamCtrl &c = a.W.ctrl[s < a.b.B ? s : 0];
+    act[u] = s < a.b.B && !c.done;
+    tau[u] = c.tau; sig[u] = c.sig; oml[u] = 1.0 / (double)(c.k + kofs + 3);
+    any |= act[u];
+  }
+  if (!any) return;
+  // ---- phase A: every global load of the workgroup -----------------------------------------------------------------------------
+  double yr[K][SG], y0r[K][SG], xr[K][SG], cr[K][SG], x0r[K][SG], lbr[K], ubr[K], rlor[K], rhir[K];
+  double cval[K][MW], rval[K][MW];
+  int cidx[K][MW], rslot[K][MW];
+  bool rowok[K], colok[K], row_long[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const int i = i0 + tid + k * kTB, j = j0 + tid + k * kTB;
+    rowok[k] = i < i1;
+    colok[k] = j < j1 && !P.C.is_long[j < j1 ? j : j0];
+    row_long[k] = false;
+#pragma unroll
+    for (int u = 0; u < SG; ++u) {
+      yr[k][u] = y0r[k][u] = xr[k][u] = cr[k][u] = x0r[k][u] = 0.0;
+      if (rowok[k] && act[u]) { const size_t at = (size_t)(b0 + u) * m + i; yr[k][u] = io.y_in[at]; y0r[k][u] = a.W.y0[at]; }
+      if (colok[k] && act[u]) { const size_t at = (size_t)(b0 + u) * n + j; xr[k][u] = io.x_in[at]; cr[k][u] = a.W.c[at]; x0r[k][u] = a.W.x0[at]; }
+    }
+    lbr[k] = ubr[k] = rlor[k] = rhir[k] = 0.0;
+    if (SHARED) {
+      if (colok[k]) { lbr[k] = a.W.lb[j]; ubr[k] = a.W.ub[j]; }
+      if (rowok[k]) { rlor[k] = a.W.rlo[i]; rhir[k] = a.W.rhi[i]; }
+    }
+#pragma unroll
+    for (int e = 0; e < MW; ++e) {
+      cval[k][e] = 0.0; cidx[k][e] = 0; rval[k][e] = 0.0; rslot[k][e] = 0;
+      if (e < P.C.W && colok[k]) {
+        cval[k][e] = P.C.val[(size_t)e * n + j];
+        const int gi = P.C.idx[(size_t)e * n + j];
+        cidx[k][e] = (gi < r_lo || gi >= r_hi) ? 0 : gi - r_lo;
+      }
+      if (e < P.R.W && rowok[k]) {
+        rval[k][e] = P.R.val[(size_t)e * m + i];
+        const int gi = F.ridx_enc[(size_t)e * m + i];
+        int sl = gi < 0 ? -1 - gi : nlong + gi - c_lo;
+        if (gi >= 0 && (gi < c_lo || gi >= c_hi)) sl = 0;
+        rslot[k][e] = sl;
+        row_long[k] |= gi < 0 && rval[k][e] != 0.0;
+      }
+    }
+  }
+  // halo rows (staged y only) and halo columns (their xbar only): the few elements of the hulls outside the own ranges
+  const int nhr = (i0 - r_lo) + (r_hi - i1), nhc = (j0 - c_lo) + (c_hi - j1);
+  for (int h = tid; h < nhr; h += kTB) {
+    const int i = h < i0 - r_lo ? r_lo + h : i1 + (h - (i0 - r_lo));
+#pragma unroll
+    for (int u = 0; u < SG; ++u) if (act[u]) ys[u * NY + (i - r_lo)] = io.y_in[(size_t)(b0 + u) * m + i];
+  }
+  // (halo columns: one thread each - there are at most a few periods' worth; loaded here, used in phase C)
+  const bool halo_col = tid < nhc;
+  const int hj = halo_col ? (tid < j0 - c_lo ? c_lo + tid : j1 + (tid - (j0 - c_lo))) : c_lo;
+  const bool halo_ok = halo_col && !P.C.is_long[hj];
+  double hx[SG], hc[SG], hval[MW], hlb = 0.0, hub = 0.0;
+  int hidx[MW];
+#pragma unroll
+  for (int u = 0; u < SG; ++u) {
+    hx[u] = hc[u] = 0.0;
+    if (halo_ok && act[u]) { const size_t at = (size_t)(b0 + u) * n + hj; hx[u] = io.x_in[at]; hc[u] = a.W.c[at]; }
+  }
+  if (SHARED && halo_ok) { hlb = a.W.lb[hj]; hub = a.W.ub[hj]; }
+#pragma unroll
+  for (int e = 0; e < MW; ++e) {
+    hval[e] = 0.0; hidx[e] = 0;
+    if (e < P.C.W && halo_ok) {
+      hval[e] = P.C.val[(size_t)e * n + hj];
+      const int gi = P.C.idx[(size_t)e * n + hj];
+      hidx[e] = (gi < r_lo || gi >= r_hi) ? 0 : gi - r_lo;
+    }
+  }
+  // long columns' A^T y from the per-tile partial sums (one wave per (scenario, long column), fixed order)
+  for (int q = tid >> 6; q < nlong * SG; q += kTB / 64) {
+    const int l = q % nlong, u = q / nlong, s = b0 + u, lane = tid & 63;
+    if (!act[u]) continue;
+    const double *pp = io.lp_in + ((size_t)s * nlong + l) * F.ntile;
+    double aty = 0.0;
+    for (int t = lane; t < F.ntile; t += 64) aty += pp[t];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) aty += __shfl_down(aty, off, 64);
+    if (lane == 0) {
+      const int j = P.C.long_id[l];
+      const size_t at = (size_t)s * n + j, ab = SHARED ? (size_t)j : at;
+      const double x = io.x_in[at];
+      const double xp = clampd2(fma(-tau[u], a.W.c[at] - aty, x), a.W.lb[ab], a.W.ub[ab]);
+      xb[u * NXB + l] = 2.0 * xp - x;
+    }
+  }
+  // ---- phase B: own y into LDS ---------------------------------------------------------------------------------------------------
+#pragma unroll
+  for (int k = 0; k < K; ++k)
+    if (rowok[k]) {
+      const int i = i0 + tid + k * kTB;
+#pragma unroll
+      for (int u = 0; u < SG; ++u) if (act[u]) ys[u * NY + (i - r_lo)] = yr[k][u];
+    }
+  __syncthreads();
+  // ---- phase C: primal step of the own columns (registers) and of the halo columns -> xbar in LDS; x written ------------------------
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    if (!colok[k]) continue;
+    const int j = j0 + tid + k * kTB;
+#pragma unroll
+    for (int u = 0; u < SG; ++u) {
+      if (!act[u]) continue;
+      const double *yv = ys + u * NY;
+      double aty = 0.0;
+#pragma unroll
+      for (int e = 0; e < MW; ++e) if (e < P.C.W) aty = fma(cval[k][e], yv[cidx[k][e]], aty);
+      const size_t at = (size_t)(b0 + u) * n + j;
+      const double lo = SHARED ? lbr[k] : a.W.lb[at], hi = SHARED ? ubr[k] : a.W.ub[at];
+      const double xp = clampd2(fma(-tau[u], cr[k][u] - aty, xr[k][u]), lo, hi);
+      const double tt = 2.0 * xp - xr[k][u];
+      xb[u * NXB + nlong + (j - c_lo)] = tt;
+      io.x_out[at] = fma(oml[u], x0r[k][u] - tt, tt);
+    }
+  }
+  if (halo_ok) {
+#pragma unroll
+    for (int u = 0; u < SG; ++u) {
+      if (!act[u]) continue;
+      const double *yv = ys + u * NY;
+      double aty = 0.0;
+#pragma unroll
+      for (int e = 0; e < MW; ++e) if (e < P.C.W) aty = fma(hval[e], yv[hidx[e]], aty);
+      const size_t at = (size_t)(b0 + u) * n + hj;
+      const double lo = SHARED ? hlb : a.W.lb[at], hi = SHARED ? hub : a.W.ub[at];
+      const double xp = clampd2(fma(-tau[u], hc[u] - aty, hx[u]), lo, hi);
+      xb[u * NXB + nlong + (hj - c_lo)] = 2.0 * xp - hx[u];
+    }
+  }
+  if (tid < nlong * SG) {                       // the long columns this tile owns: their Halpern step (xbar written in phase A)
+    const int l = tid % nlong, u = tid / nlong, s = b0 + u;
+    const int j = P.C.long_id[l];
+    if (j >= j0 && j < j1 && s < a.b.B && !a.W.ctrl[s].done) {
+      const size_t at = (size_t)s * n + j;
+      const double tt = xb[u * NXB + l];
+      io.x_out[at] = fma(1.0 / (double)(a.W.ctrl[s].k + kofs + 3), a.W.x0[at] - tt, tt);
+    }
+  }
+  __syncthreads();
+  // ---- phase D: dual step + Halpern averaging of the own rows, partial sums for the long columns ------------------------------------
+  double lp[SG][kFusedMaxLong];
+#pragma unroll
+  for (int u = 0; u < SG; ++u)
+#pragma unroll
+    for (int q = 0; q < kFusedMaxLong; ++q) lp[u][q] = 0.0;
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    if (!rowok[k]) continue;
+    const int i = i0 + tid + k * kTB;
+#pragma unroll
+    for (int u = 0; u < SG; ++u) {
+      if (!act[u]) continue;
+      const double *xv = xb + u * NXB;
+      double ax = 0.0;
+#pragma unroll
+      for (int e = 0; e < MW; ++e) if (e < P.R.W) ax = fma(rval[k][e], xv[rslot[k][e]], ax);
+      const size_t at = (size_t)(b0 + u) * m + i;
+      const double lo = SHARED ? rlor[k] : a.W.rlo[at], hi = SHARED ? rhir[k] : a.W.rhi[at];
+      const double y = yr[k][u];
+      const double gy = fma(-sig[u], ax, y);
+      double yp = gy - clampd2(gy, -sig[u] * hi, -sig[u] * lo);
+      if (QP) yp /= fma(sig[u], a.W.kap[at], 1.0);
+      const double tt = 2.0 * yp - y;
+      const double yn = fma(oml[u], y0r[k][u] - tt, tt);
+      io.y_out[at] = yn;
+      if (row_long[k]) {
+#pragma unroll
+        for (int e = 0; e < MW; ++e) {
+          if (e < P.R.W && rslot[k][e] < nlong && rval[k][e] != 0.0) {
+#pragma unroll
+            for (int q = 0; q < kFusedMaxLong; ++q) lp[u][q] += (rslot[k][e] == q) ? rval[k][e] * yn : 0.0;
+          }
+        }
+      }
+    }
+  }
+  if (nlong > 0) {
+#pragma unroll
+    for (int u = 0; u < SG; ++u) {
+      fused_reduce_long(lp[u], nlong, red);
+      if (tid < nlong && act[u]) io.lp_out[((size_t)(b0 + u) * nlong + tid) * F.ntile + tile] = red[tid];
+      __syncthreads();
+    }
+  }
+}
+
 // partial sums of A^T y for the long columns from the CURRENT y (after the initialisation and after every check's k_apply)
 __global__ void __launch_bounds__(kTB) k_long_partials(StreamArgs a, const double *y, double *lp_out) {
   __shared__ double red[(1 + kTB / 64) * kFusedMaxLong];
@@ -1006,11 +1226,12 @@ hipError_t stream_create(const HostCSR &A_scaled, const HostCSR &AT_scaled, cons
   const int rb_env = getenv("DSP_FUSED_RB") ? atoi(getenv("DSP_FUSED_RB")) : 0;
   S->P.F = FusedPlan{};
   if (!no_fused) {
-    const HostFusedPlan H = build_fused_plan(A_scaled, AT_scaled, Er, Ec, kFusedMaxLong, rb_env > 0 ? rb_env : 768, 40 * 1024);
+    const HostFusedPlan H = build_fused_plan(A_scaled, AT_scaled, Er, Ec, kFusedMaxLong, rb_env > 0 ? rb_env : 500, 40 * 1024);
     if (H.ntile > 0) {
       if ((e = up(S->allocs, H.tile, &S->P.F.tile)) != hipSuccess) return e;
       if ((e = up(S->allocs, H.ridx_enc, &S->P.F.ridx_enc)) != hipSuccess) return e;
       S->P.F.ntile = H.ntile; S->P.F.rows_per_tile = H.rows_per_tile; S->P.F.ny_max = H.ny_max; S->P.F.nxb_max = H.nxb_max;
+      S->P.F.own_max = H.own_max; S->P.F.halo_max = H.halo_max;
     }
   }
   return hipSuccess;
@@ -1125,8 +1346,21 @@ static hipError_t run_fused(StreamSolver *S, StreamArgs &a, hipStream_t st, int 
   const dim3 g_rows_chk(a.nblk + P.R.nlong, groups), g_cols(a.nblk_n + P.C.nlong, groups), g_elem(a.nblk, groups);
   const int fin_c = (P.C.nlong * B + 63) / 64;
   const size_t lds = ((size_t)SG * (F.ny_max + F.nxb_max) + (1 + kTB / 64) * kFusedMaxLong) * sizeof(double);
+  // k_fused_pre (all loads up front) where a thread can own its K <= 4 rows and columns and the halo columns fit one pass;
+  // k_fused (staged phases) otherwise.  DSP_FUSED_V=1 forces the staged form (development).
   const void *fn = nullptr;
-  if (shared) fn = qp ? reinterpret_cast<const void *>(&k_fused<SG, true, true>) : reinterpret_cast<const void *>(&k_fused<SG, true, false>);
+  static const int v_env = getenv("DSP_FUSED_V") ? atoi(getenv("DSP_FUSED_V")) : 0;
+  const int K = (F.own_max + kTB - 1) / kTB;
+  const int mw = std::max(P.C.W, P.R.W);
+  const bool pre = v_env != 1 && K >= 1 && K <= 3 && mw <= 8 && F.halo_max <= kTB;
+#define DSP_PICK2(KK, MM)                                                                                                            \
+  (shared ? (qp ? reinterpret_cast<const void *>(&k_fused_pre<SG, KK, MM, true, true>) : reinterpret_cast<const void *>(&k_fused_pre<SG, KK, MM, true, false>)) \
+          : (qp ? reinterpret_cast<const void *>(&k_fused_pre<SG, KK, MM, false, true>) : reinterpret_cast<const void *>(&k_fused_pre<SG, KK, MM, false, false>)))
+#define DSP_PICK(KK) (mw <= 4 ? DSP_PICK2(KK, 4) : DSP_PICK2(KK, 8))
+  if (pre) fn = K == 1 ? DSP_PICK(1) : K == 2 ? DSP_PICK(2) : DSP_PICK(3);
+#undef DSP_PICK2
+#undef DSP_PICK
+  else if (shared) fn = qp ? reinterpret_cast<const void *>(&k_fused<SG, true, true>) : reinterpret_cast<const void *>(&k_fused<SG, true, false>);
   else fn = qp ? reinterpret_cast<const void *>(&k_fused<SG, false, true>) : reinterpret_cast<const void *>(&k_fused<SG, false, false>);
   hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;

@@ -40,6 +40,8 @@ struct FusedPlan {
   int ntile = 0;                       // 0 = not applicable (not banded enough, long rows, too many long columns)
   int rows_per_tile = 0;
   int ny_max = 0, nxb_max = 0;         // LDS extents per scenario: staged y rows, xbar slots (long columns first)
+  int own_max = 0;                     // most rows or columns any tile owns (k_fused_pre: K = ceil(own_max / 256) per thread)
+  int halo_max = 0;                    // most halo rows / columns of any tile (k_fused_pre handles halo columns in one pass: <= 256)
   const int32_t *tile = nullptr;       // [ntile][8]  i0, i1 (own rows), j0, j1 (own columns), c_lo, c_hi, r_lo, r_hi
   const int32_t *ridx_enc = nullptr;   // [R.W][m] row ELL column index; long column l encoded as -1 - l
 };

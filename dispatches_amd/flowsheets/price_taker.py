@@ -181,3 +181,93 @@ def wind_battery_price_taker(n_time_points, capacity_factors, lmps, wind_mw=847.
         return s
     handles["column_scales"] = column_scales
     return b, objective, handles
+
+
+PEM_CAP_COST = prm.pem_cap_cost          # $/kW  load_parameters.py:49
+
+
+def wind_battery_pem_price_taker(time_points, capacity_factors, lmps, h2_price_per_kg=2.0, design_opt=True, wind_mw=847.0):
+    """Wind + battery + PEM price-taker design LP: the reference's ``wind_battery_pem_optimize``
+    (``dispatches/case_studies/renewables_case/wind_battery_PEM_LMP.py:180-298``) on a LinearBlock.
+
+    The LP #4 flowsheet plus an electrolyzer per period (splitter outlet `pem_elec` = `pem.electricity`, RE_flowsheet.py:391-398;
+    hydrogen flow 0.00275984 mol/s per kW, :131) and the design column `pem_system_capacity` (:226, :243).  What differs from
+    ``wind_battery_optimize``: only block 0's initial THROUGHPUT is fixed (:222) - its initial state of charge is a free column tied
+    to the last period's by the periodic pair (:36-47); hydrogen is sold at `h2_price_per_kg` (:281: price * flow_mol / 500 *
+    3600 per hour); the PEM pays 0.03 * 1200 $/kW-yr on its capacity (:275-277) and 1200 $/kW in the NPV (:291-294);
+    `design_opt="PEM"` fixes the battery's nameplate power to 0 (:237-238); the wind farm is extant (capacity fixed, no capital
+    cost: :234, :254-255 - the reference's default input parameters).  Same reductions as LP #4 (one nameplate-power column, 4-h
+    energy substituted).  Returns (block, objective LinExpr of -NPV * 1e-5, handles)."""
+    T = int(time_points)
+    cf = np.asarray(capacity_factors, float)[:T]
+    lmp = np.asarray(lmps, float)[:T] * 1e-3                                          # $/kWh (:280)
+    if design_opt not in (True, "PEM"):
+        raise NotImplementedError("design_opt: True (battery and PEM sized) or 'PEM' (battery fixed at 0)")
+    b = LinearBlock("pem_price_taker")
+    wind_kw = wind_mw * 1e3
+    Pb = b.var("battery_system_capacity", 0.0, np.inf)
+    Cp = b.var("pem_system_capacity", 0.0, np.inf)
+    P = b.var("battery.nameplate_power", 0.0, 0.0 if design_opt == "PEM" else 1e8)
+    S_init = b.var("battery.initial_state_of_charge[0]")
+    b.constraint("battery_max_p", P - Pb, -np.inf, 0.0)                               # :242
+    eta_c, eta_d, d = prm.battery_charging_eta, prm.battery_discharging_eta, prm.battery_degradation_rate
+    h2_per_kwh = prm.pem_electricity_to_mol / prm.h2_mols_per_kg * 3600.0            # kg of hydrogen per kWh into the PEM
+    per = []
+    soc_prev, thr_prev = S_init, None
+    rev_e, h2_kg = LinExpr(), LinExpr()
+    for t in range(T):
+        W = b.var(f"windpower.electricity[{t}]", 0.0, wind_kw * cf[t])
+        G = b.var(f"splitter.grid_elec[{t}]")
+        I = b.var(f"splitter.battery_elec[{t}]")
+        X = b.var(f"splitter.pem_elec[{t}]")
+        O = b.var(f"battery.elec_out[{t}]")
+        S = b.var(f"battery.state_of_charge[{t}]")
+        E = b.var(f"battery.energy_throughput[{t}]")
+        b.equality(f"splitter.sum_split[{t}]", W - G - I - X, 0.0)
+        b.equality(f"battery.state_evolution[{t}]", S - soc_prev - eta_c * I + O / eta_d, 0.0)
+        thr = E - 0.5 * I - 0.5 * O
+        b.equality(f"battery.accumulate_energy_throughput[{t}]", thr if thr_prev is None else thr - thr_prev, 0.0)
+        b.constraint(f"battery.state_of_charge_bounds[{t}]", S + d * E - DURATION * P, -np.inf, 0.0)
+        b.constraint(f"battery.power_bound_in[{t}]", I - P, -np.inf, 0.0)
+        b.constraint(f"battery.power_bound_out[{t}]", O - P, -np.inf, 0.0)
+        b.constraint(f"pem_max_p[{t}]", X - Cp, -np.inf, 0.0)                         # :243
+        rev_e = rev_e + (G + O) * float(lmp[t])
+        h2_kg = h2_kg + X * h2_per_kwh
+        per.append(dict(wind=W, grid_elec=G, elec_in=I, pem_elec=X, elec_out=O, state_of_charge=S, energy_throughput=E))
+        soc_prev, thr_prev = S, E
+    b.equality("battery.periodic_state_of_charge", soc_prev - S_init, 0.0)            # :36-47
+    k = 52 / (T / (7 * 24))
+    fixed = (wind_kw * (prm.wind_op_cost / 8760) + Pb * (BATT_OP_COST / 8760) + Cp * (prm.pem_op_cost / 8760)) * T
+    annual = (rev_e + h2_kg * float(h2_price_per_kg) - fixed) * k
+    npv = annual * PA - Pb * (BATT_CAP_COST_KW + BATT_CAP_COST_KWH * DURATION) - Cp * PEM_CAP_COST
+    objective = npv * -1e-5
+    b.expression("NPV", 0, npv)
+    b.expression("annual_rev_E", 0, rev_e * k)
+    b.expression("annual_rev_h2", 0, h2_kg * (float(h2_price_per_kg) * k))
+    handles = dict(periods=per, battery_system_capacity=Pb, pem_system_capacity=Cp, nameplate_power=P, initial_state_of_charge=S_init)
+
+    def objective_vector(n_cols, h2_price=h2_price_per_kg, pem_cap_factor=1.0, lmp_multiplier=1.0):
+        """Dense cost vector of -NPV * 1e-5 for a member of the family (hydrogen price, PEM capital-cost factor, LMP multiplier):
+        matrix and bounds stay the same."""
+        c = np.zeros(n_cols)
+        kk = PA * k * -1e-5
+        sell = np.array([[p["grid_elec"].index, p["elec_out"].index] for p in per])
+        c[sell[:, 0]] = c[sell[:, 1]] = kk * lmp * lmp_multiplier
+        c[[p["pem_elec"].index for p in per]] = kk * h2_per_kwh * h2_price
+        c[Pb.index] = -kk * T * BATT_OP_COST / 8760 + 1e-5 * (BATT_CAP_COST_KW + BATT_CAP_COST_KWH * DURATION)
+        c[Cp.index] = -kk * T * prm.pem_op_cost / 8760 + 1e-5 * pem_cap_factor * PEM_CAP_COST
+        return c
+    handles["objective_vector"] = objective_vector
+    handles["objective_constant"] = lambda: -PA * k * T * wind_kw * (prm.wind_op_cost / 8760) * -1e-5
+
+    def column_scales(n_cols=None):
+        """Physical scaling factors (see wind_battery_price_taker)."""
+        s = np.full(len(b.col_names) if n_cols is None else n_cols, wind_kw)
+        for j, name in enumerate(b.col_names):
+            if "state_of_charge" in name:
+                s[j] = DURATION * wind_kw
+            elif name.startswith("battery.energy_throughput["):
+                s[j] = wind_kw * max(T / 2, 1)
+        return s
+    handles["column_scales"] = column_scales
+    return b, objective, handles

@@ -16,6 +16,10 @@ Parity status: PINNED against every known-answer vector the reference holds for 
   G4     nuclear DA bidding objective (IPOPT log)      (nuclear_flowsheet_double_loop.ipynb:716)
   G5/G6  wind+battery DA / RT objectives (Xpress log)  (DoubleLoopOptimization.ipynb:657,726,1139)
   G7     battery unit-model rows                       (unit_models/tests/test_battery.py:57-58,119)
+  G8     LP #4 price-taker design: NPV, annual revenue (renewables_case/tests/test_RE_flowsheet.py:123-133), through the
+         PySAM-free restatement of the wind resource model, itself pinned by
+  G9     the wind unit model's two known answers       (unit_models/tests/test_wind_power.py:49-50,78)
+  G10    LP #5 wind + battery + PEM price-taker design (test_RE_flowsheet.py:136-161)
 UNPINNED (no reference vector exists): n_scenario > 1 with *different* scenarios (cross-scenario coupling
 rows of the upstream Bidder), and the QP ramp-cost variant (our extension).
 
@@ -470,6 +474,132 @@ def wind_battery_price_taker(T, cf, lmp, wind_kw=847e3, wind_kw_ub=10000e3, batt
                - batt_cap_factor * (BATT_CAP_COST_KW + BATT_CAP_COST_KWH * BATTERY_DURATION))   # scenario family: scaled battery capital cost
     lp.add_cost((npv, 0.0), -1e-5)
     return PreparedLP(lp), dict(Cw=Cw, Pb=Pb, npv=(npv, 0.0), elec=elec, annual_scale=k)
+
+
+# ---- wind resource: capacity factor from a wind speed (THIRD-PARTY arithmetic: NREL-PySAM, unpinned `nrel-pysam` in the
+# reference's setup.py:124; absent from this container) ------------------------------------------------------------------------
+# The reference's price-taker tests feed hourly wind speeds (test_RE_flowsheet.py:33-40) to Wind_Power.setup_resource
+# (wind_power.py:163-177), which runs PySAM's Windpower module once per hour in its WEIBULL resource mode
+# (wind_resource_model_choice = 1) with weibull_k_factor = 100 - a distribution so narrow that it is "this speed" -,
+# reference height = hub height = 110 m, the ATB 5 MW power curve of wind_power.py:128-143 on 1 m/s bins, one turbine, and
+# capacity_factor = Outputs.capacity_factor / 100.  SSC's published algorithm for that mode (lib_windwatts.cpp,
+# windTurbine::turbineOutputUsingWeibull): with lambda = v / Gamma(1 + 1/k) the probability of bin i is
+# F(ws_i + 0.125) - F(ws_{i-1} + 0.125), F the Weibull CDF (the 0.125 m/s is half of SAM's default 0.25 m/s bin), each bin
+# produces the power-curve value AT ws_i, and the annual energy is derated by the product of SAM's default wind-farm loss
+# categories (WindpowerSingleowner defaults: availability 0.5 / 1.5 / 3.58 %, electrical 1.91 / 0.1 %, environmental 1.8 / 0.4 /
+# 0 / 0.21 %, operational 1 / 0.84 / 0.99 / 0 %, turbine 1.7 / 0.4 / 1.1 / 0.81 %, wake 1.1 / 0 / 0 % -> multiplier 0.834447).
+# PINNED by two reference vectors (tests/test_oracle_golden.py): the unit test's 30083.39 kW for 10 m/s on a 50 MW system
+# (test_wind_power.py:78; this restatement: 30083.3875) and, through LP #4, the price-taker NPV / annual revenue
+# (test_RE_flowsheet.py:127-132; this restatement + HiGHS: 666 049 366.27 vs 666 049 365).  The DISTRIBUTION mode of the same
+# module (wind_power.py:147-162, a single (speed, direction, probability) point) interpolates the power curve at the speed and
+# applies the same losses: 0.68968 x 0.834447 = 0.5755 (test_wind_power.py:49).
+ATB_POWER_CURVE_KW = (0, 0, 0, 40.5, 177.7, 403.9, 737.6, 1187.2, 1771.1, 2518.6, 3448.4, 4562.5, 5000, 5000, 5000, 5000, 5000,
+                      5000, 5000, 5000, 5000, 5000, 5000, 5000, 5000, 5000, 0, 0)          # wind_power.py:136-138, speeds 0 .. 27 m/s
+SAM_WIND_LOSSES_PERCENT = (0.5, 1.5, 3.58, 1.91, 0.1, 1.8, 0.4, 0.0, 0.21, 1.0, 0.84, 0.99, 0.0, 1.7, 0.4, 1.1, 0.81, 1.1, 0.0, 0.0)
+
+
+def sam_loss_multiplier():
+    return float(np.prod([1.0 - p / 100.0 for p in SAM_WIND_LOSSES_PERCENT]))
+
+
+def sam_weibull_capacity_factor(speed_m_s, k=100.0):
+    """Capacity factor PySAM's Windpower returns for wind_power.py's `resource_speed` path (see the block comment above)."""
+    from math import exp, lgamma
+    power = np.asarray(ATB_POWER_CURVE_KW, float)
+    edges = np.arange(len(power)) + 0.125
+    out = []
+    for v in np.atleast_1d(np.asarray(speed_m_s, float)):
+        lam = v / exp(lgamma(1.0 + 1.0 / k))
+        if lam <= 0.0:
+            out.append(0.0)
+            continue
+        cdf = 1.0 - np.exp(-(edges / lam) ** k)
+        prob = np.diff(cdf)                                  # bin i (i >= 1): (ws_{i-1} + 0.125, ws_i + 0.125] -> power at ws_i
+        out.append(sam_loss_multiplier() * float(prob @ power[1:]) / power.max())
+    out = np.array(out)
+    return out if np.ndim(speed_m_s) else float(out[0])
+
+
+def sam_distribution_capacity_factor(speed_m_s):
+    """Capacity factor of the single-point `resource_probability_density` path (wind_power.py:147-162): power curve interpolated
+    at the speed, SAM's default losses."""
+    power = np.asarray(ATB_POWER_CURVE_KW, float)
+    return sam_loss_multiplier() * float(np.interp(speed_m_s, np.arange(len(power)), power)) / power.max()
+
+
+# ---- LP #5: wind + battery + PEM price-taker design problem (SURVEY.md 8(f)-4) -----------------------------------------------
+# Reference: wind_battery_pem_optimize, dispatches/case_studies/renewables_case/wind_battery_PEM_LMP.py:180-298: the LP #4 flowsheet
+# plus a PEM electrolyzer per period (pem_electrolyzer.py:111-114: H2 flow = 0.00275984 mol/s per kW, RE_flowsheet.py:131) and the
+# design column pem_system_capacity (:226, :243).  Differences from LP #4 that matter: only the initial THROUGHPUT of block 0 is
+# fixed (:222) - the initial state of charge is free and tied to the final one by the periodic pair (:36-47); hydrogen revenue
+# h2_price * flow_mol / 500 * 3600 per hour (:281); PEM fixed O&M 0.03 * 1200 $/kW-yr on the capacity (:275-277), PEM capital
+# 1200 $/kW in the NPV (:291-294); design_opt = "PEM" fixes the battery's nameplate power to 0 (:237-238).
+PEM_CAP_COST = 1200.0             # $/kW    load_parameters.py:49
+
+
+def wind_battery_pem_price_taker(T, cf, lmp, h2_price_per_kg=2.0, design_opt=True, wind_kw=847e3):
+    """Returns (PreparedLP of  min -NPV * 1e-5, info); lmp in $/MWh (:280 multiplies by 1e-3); design_opt True or "PEM"."""
+    lp = _LP()
+    Cw = lp.var("wind_system_capacity", wind_kw, wind_kw)                     # extant wind: fixed (:234)
+    Pb = lp.var("battery_system_capacity", 0.0, np.inf)                       # :225
+    Cp = lp.var("pem_system_capacity", 0.0, np.inf)                           # :226
+    S_init = lp.var("S_init")                                                 # initial state of charge of block 0: free (only
+    elec, h2 = [], []                                                         # the initial throughput is fixed, :222)
+    prev = None
+    p_ub = 0.0 if design_opt == "PEM" else 1e8
+    for t in range(T):
+        cap = lp.var(f"cap{t}", wind_kw, wind_kw)
+        W = lp.var(f"W{t}")
+        G = lp.var(f"G{t}")
+        I = lp.var(f"I{t}")
+        X = lp.var(f"X{t}")                                                   # splitter.pem_elec = pem.electricity
+        O = lp.var(f"O{t}")
+        S = lp.var(f"S{t}")
+        E = lp.var(f"E{t}")
+        P = lp.var(f"P{t}", 0.0, p_ub)
+        En = lp.var(f"En{t}", 0.0, 1e9)
+        lp.row({W: 1, cap: -cf[t]}, -np.inf, 0.0)                             # wind_power.py:120-122
+        lp.row({W: 1, G: -1, I: -1, X: -1}, 0.0, 0.0)                         # elec_splitter.py:115-117 (three outlets)
+        if prev is None:
+            lp.row({S: 1, S_init: -1, I: -ETA_C, O: 1 / ETA_D}, 0.0, 0.0)
+            lp.row({E: 1, I: -0.5, O: -0.5}, 0.0, 0.0)                        # initial throughput fixed 0 (:222)
+            lp.row({S: 1, S_init: -1}, -BATTERY_RAMP_RATE, BATTERY_RAMP_RATE)
+        else:
+            lp.row({S: 1, prev["S"]: -1, I: -ETA_C, O: 1 / ETA_D}, 0.0, 0.0)
+            lp.row({E: 1, prev["E"]: -1, I: -0.5, O: -0.5}, 0.0, 0.0)
+            lp.row({P: 1, prev["P"]: -1}, 0.0, 0.0)
+            lp.row({S: 1, prev["S"]: -1}, -BATTERY_RAMP_RATE, BATTERY_RAMP_RATE)
+        lp.row({S: 1, E: DEGRADATION, En: -1}, -np.inf, 0.0)
+        lp.row({I: 1, P: -1}, -np.inf, 0.0)
+        lp.row({O: 1, P: -1}, -np.inf, 0.0)
+        lp.row({P: BATTERY_DURATION, En: -1}, 0.0, 0.0)
+        lp.row({cap: 1, Cw: -1}, -np.inf, 0.0)                                # :241
+        lp.row({P: 1, Pb: -1}, -np.inf, 0.0)                                  # :242
+        lp.row({X: 1, Cp: -1}, -np.inf, 0.0)                                  # :243
+        elec.append((G, O))
+        h2.append(X)
+        prev = dict(S=S, E=E, P=P)
+    lp.row({prev["S"]: 1, S_init: -1}, 0.0, 0.0)                              # periodic pair (:36-47)
+    k = 52 / (T / (7 * 24))
+    h2_per_kwh = h2_price_per_kg * PEM_MOL_PER_KW_S / H2_MOLS_PER_KG * 3600    # $ per kWh of PEM electricity (:281)
+    rev_e, rev_h = {}, {}
+    for t, (G, O) in enumerate(elec):
+        for j in (G, O):
+            rev_e[j] = rev_e.get(j, 0.0) + lmp[t] * 1e-3
+        rev_h[h2[t]] = h2_per_kwh
+    annual = {}
+    for j, v in list(rev_e.items()) + list(rev_h.items()):
+        annual[j] = annual.get(j, 0.0) + k * v
+    annual[Cw] = -k * T * WIND_OP_COST / 8760
+    annual[Pb] = -k * T * BATT_OP_COST / 8760
+    annual[Cp] = -k * T * PEM_OP_COST / 8760
+    npv = {j: PRESENT_VALUE_FACTOR * v for j, v in annual.items()}
+    npv[Pb] = npv.get(Pb, 0.0) - (BATT_CAP_COST_KW + BATT_CAP_COST_KWH * BATTERY_DURATION)
+    npv[Cp] = npv.get(Cp, 0.0) - PEM_CAP_COST
+    lp.add_cost((npv, 0.0), -1e-5)
+    info = dict(Cw=Cw, Pb=Pb, Cp=Cp, npv=(npv, 0.0), annual_rev_E=({j: k * v for j, v in rev_e.items()}, 0.0),
+                annual_rev_h2=({j: k * v for j, v in rev_h.items()}, 0.0), elec=elec, h2=h2)
+    return PreparedLP(lp), info
 
 
 # ---- QP variant: quadratic ramp cost on the delivered power (BASELINE config 5; OUR extension, no reference formulation) ---

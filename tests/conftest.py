@@ -51,3 +51,11 @@ def rts309():
 def rts303():
     d = np.load(os.path.join(ROOT, "dispatches_amd", "data", "rts_gmlc_303.npz"))
     return {k: d[k] for k in d.files}
+
+
+@pytest.fixture(scope="session")
+def price_taker_inputs():
+    """Inputs of the reference's price-taker design tests (8760 wind speeds of the SRW file, 8736 day-ahead LMPs):
+    tools/extract_reference_data.py."""
+    d = np.load(os.path.join(ROOT, "dispatches_amd", "data", "price_taker_inputs.npz"))
+    return {k: d[k] for k in d.files}

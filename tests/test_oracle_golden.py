@@ -111,3 +111,49 @@ def test_marginal_to_actual_costs(golden, rts309):
         grid = max(0, rt_wind - 25)
         out.append(orc.marginal_to_actual_costs([(0, 0), (grid, 0), (rt_wind, 30)])[-1][1])
     assert out == pytest.approx(g, rel=1e-2)
+
+
+def test_G9_wind_resource_model(golden):
+    """PySAM-free restatement of the wind resource model (oracle: sam_weibull_capacity_factor / sam_distribution_capacity_factor)
+    against the two known answers of the reference's unit test (test_wind_power.py:49-50,78)."""
+    g = golden["G9_wind_unit_model"]
+    cap = g["system_capacity_kw"]
+    assert orc.sam_weibull_capacity_factor(g["speed_m_s"]) * cap == pytest.approx(g["weibull_model_electricity_kw"], rel=1e-6)     # reference: 1e-2
+    assert orc.sam_distribution_capacity_factor(g["speed_m_s"]) == pytest.approx(g["distribution_model_capacity_factor"], rel=1e-4)
+    assert orc.sam_distribution_capacity_factor(g["speed_m_s"]) * cap == pytest.approx(g["distribution_model_electricity_kw"], rel=1e-6)
+    assert orc.sam_weibull_capacity_factor(0.0) == 0.0 and orc.sam_weibull_capacity_factor(30.0) < 1e-6        # below cut-in, beyond cut-out
+    assert orc.sam_weibull_capacity_factor(np.array([3.0, 12.5, 20.0]))[1:] == pytest.approx(orc.sam_loss_multiplier(), rel=1e-6)   # rated
+
+
+def test_G8_price_taker_wind_battery(golden, price_taker_inputs):
+    """LP #4 (wind_battery_optimize, one week) reproduces the reference test's NPV and annual revenue
+    (test_RE_flowsheet.py:123-133: rel 1e-3; here 2e-9) - capacity factors from the SRW wind speeds through the restated wind model,
+    LMPs capped at 200 $/MWh as the test fixture does."""
+    g = golden["G8_price_taker_wind_battery"]
+    T = g["n_time_points"]
+    cf = orc.sam_weibull_capacity_factor(price_taker_inputs["wind_speed_m_s"][:T])
+    lmp = np.minimum(price_taker_inputs["da_lmp"][:T], 200.0)
+    P, info = orc.wind_battery_price_taker(T, cf, lmp)
+    x, obj = P.solve(tight=True)
+    npv = P.value(info["npv"], x)
+    assert npv == pytest.approx(g["NPV"], rel=1e-7)                                       # reference: rel 1e-3
+    assert npv / orc.PRESENT_VALUE_FACTOR == pytest.approx(g["annual_revenue"], rel=1e-7)   # no battery: NPV = PA x annual revenue
+    assert x[info["Pb"]] == pytest.approx(g["battery_nameplate_power_kw"], abs=g["battery_abs"])
+    assert obj == pytest.approx(-npv * 1e-5, rel=1e-12)
+
+
+@pytest.mark.parametrize("design_opt", ["PEM", True])
+def test_G10_price_taker_wind_battery_pem(golden, price_taker_inputs, design_opt):
+    """LP #5 (wind_battery_pem_optimize, six days, hydrogen at 2.5 $/kg) reproduces both reference tests
+    (test_RE_flowsheet.py:136-161): PEM size, hydrogen and electricity revenue, NPV."""
+    g = golden["G10_price_taker_wind_battery_pem"]
+    T = g["time_points"]
+    cf = orc.sam_weibull_capacity_factor(price_taker_inputs["wind_speed_m_s"][:T])
+    lmp = np.minimum(price_taker_inputs["da_lmp"][:T], 200.0)
+    P, info = orc.wind_battery_pem_price_taker(T, cf, lmp, g["h2_price_per_kg"], design_opt)
+    x, obj = P.solve(tight=True)
+    assert x[info["Pb"]] * 1e-3 == pytest.approx(g["batt_mw"], abs=1e-3)
+    assert x[info["Cp"]] * 1e-3 == pytest.approx(g["pem_mw"], abs=g["pem_mw_abs_full_design"])
+    assert P.value(info["annual_rev_h2"], x) == pytest.approx(g["annual_rev_h2"], rel=1e-6)       # reference: rel 1e-2
+    assert P.value(info["annual_rev_E"], x) == pytest.approx(g["annual_rev_E"], rel=1e-6)
+    assert P.value(info["npv"], x) == pytest.approx(g["NPV"], rel=1e-6)

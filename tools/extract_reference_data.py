@@ -11,6 +11,10 @@ Writes (data only, no reference source code):
         <- .../renewables_case/data/303_LMPs_15_reserve_500_shortfall.parquet
   dispatches_amd/data/nuclear_lmp_signal.npz  3100 x 24 day-signals in (set, year, cluster) order
         <- .../nuclear_case/lmp_signal.json
+  dispatches_amd/data/price_taker_inputs.npz  inputs of the reference's price-taker design tests: 8760 hourly wind speeds
+        <- .../renewables_case/data/44.21_-101.94_windtoolkit_2012_60min_80m.srw (column 3, m/s at 80 m; what PySAM's
+        SRW_to_wind_data hands to tests/test_RE_flowsheet.py:33-34) and 8736 day-ahead LMPs
+        <- .../renewables_case/tests/rts_results_all_prices.npy (second array, test_RE_flowsheet.py:25-27)
   tests/golden/reference_vectors.json    the known-answer vectors held by the reference's own tests and
         notebooks for this path, with file:line provenance.
 
@@ -58,6 +62,15 @@ def main():
                 d = j[s][y][c]
                 days.append([d[str(h)] for h in range(1, 25)])
     np.savez_compressed(os.path.join(out, "nuclear_lmp_signal.npz"), lmp=np.asarray(days, np.float64))
+
+    # ---- inputs of the price-taker design tests (test_RE_flowsheet.py:22-43) ----------------------------
+    with open(REF + "renewables_case/tests/rts_results_all_prices.npy", "rb") as f:
+        _ = np.load(f)
+        da_lmp = np.load(f)
+    srw = open(REF + "renewables_case/data/44.21_-101.94_windtoolkit_2012_60min_80m.srw").read().split("\n")
+    speeds = np.array([float(line.split(",")[2]) for line in srw[5:5 + 8760]])
+    assert da_lmp.shape == (8736,) and speeds.shape == (8760,)
+    np.savez_compressed(os.path.join(out, "price_taker_inputs.npz"), wind_speed_m_s=speeds, da_lmp=np.asarray(da_lmp, np.float64))
 
     # ---- known-answer vectors of the reference's own tests / committed notebook outputs --------------
     golden = {
@@ -140,6 +153,26 @@ def main():
             "source": "dispatches/unit_models/tests/test_battery.py:57-58,119",
             "case_a": {"elec_in": 5, "elec_out": 0, "soc0": 0, "e0": 0, "soc": 4.75, "throughput": 2.5},
             "case_b": {"soc0": 5, "e0": 5, "elec_out": 5, "soc": 0, "elec_in": 0.27701, "throughput": 7.6385},
+        },
+        "G8_price_taker_wind_battery": {
+            "source": "dispatches/case_studies/renewables_case/tests/test_RE_flowsheet.py:123-133 (wind_battery_optimize, CBC; inputs "
+                      ":22-43: LMPs capped at 200, wind speeds of the SRW file through PySAM's Weibull wind model)",
+            "n_time_points": 168, "NPV": 666049365, "annual_revenue": 59163455, "rel": 1e-3,
+            "battery_nameplate_power_kw": 0, "battery_abs": 1,
+        },
+        "G9_wind_unit_model": {
+            "source": "dispatches/unit_models/tests/test_wind_power.py:49-50,78 (PySAM Windpower, ATB 5 MW turbine of "
+                      "wind_power.py:128-143, 50 MW system, 10 m/s)",
+            "speed_m_s": 10, "system_capacity_kw": 50000,
+            "weibull_model_electricity_kw": 30083.39,          # resource_speed path (what the price-taker tests use)
+            "distribution_model_capacity_factor": 0.5755, "distribution_model_electricity_kw": 28775.06, "rel": 1e-2,
+        },
+        "G10_price_taker_wind_battery_pem": {
+            "source": "dispatches/case_studies/renewables_case/tests/test_RE_flowsheet.py:136-161 (wind_battery_pem_optimize, CBC, "
+                      "6 x 24 periods, h2_price_per_kg = 2.5; first test design_opt = 'PEM' with batt_mw = 0, second the full design)",
+            "time_points": 144, "h2_price_per_kg": 2.5,
+            "batt_mw": 0, "pem_mw": 487, "annual_rev_h2": 155129116, "annual_rev_E": 68599396, "NPV": 1339462317, "rel": 1e-2,
+            "pem_mw_abs_full_design": 1,
         },
         "constants": {
             "source": "dispatches/case_studies/renewables_case/load_parameters.py:24-79 + wind_battery_cost_parameter.json",
