@@ -172,7 +172,9 @@ def bench_double_loop(args, rank, local_rank, world, dev):
             "metric": f"plant-days simulated/sec, RTS-GMLC rolling double loop (config 4), {total} plants", "value": total * days / elapsed,
             "unit": "plant-days/s", "n_gpus": world, "steps": days, "warmup": max(1, args.warmup), "ms_per_step": 1e3 * elapsed / days,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "world_size": world, "collective_backend": (f"nccl(RCCL) {'.'.join(map(str, torch.cuda.nccl.version()))}" if world > 1 else None),
+            "world_size": world, "collective_backend": (("gloo on host copies (REHEARSAL: ranks share cuda:0)" if os.environ.get("DSP_BENCH_SHARE_GPU") == "1" else
+                                                         f"nccl(RCCL) {'.'.join(map(str, torch.cuda.nccl.version()))}") if world > 1 else None),
+            "rehearsal": os.environ.get("DSP_BENCH_SHARE_GPU") == "1",
             "config": {"workload": f"double_loop: {total} wind+battery plants ({per} per GPU), per simulated day 1 x 48-h day-ahead LP (PDLP "
                                    "kernel) + 24 x (4-h real-time LP + 4-h tracking LP) (in-wave simplex), stub market, state hand-off on device",
                        "lp_solves_per_s": total * days * 49 / elapsed, "all_optimal": bool(okt.item()),
@@ -399,11 +401,21 @@ def main():
     if args.gpus != world and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU path)"
+    # DSP_BENCH_SHARE_GPU=1: REHEARSAL of the N-rank launch on a box with fewer GPUs than ranks - every rank uses cuda:0 and the
+    # collectives run over gloo on host copies (RCCL cannot put two ranks on one device).  Same sharding, packing, barriers,
+    # MAX-over-ranks timing and JSON line as the real N-GPU run; the numbers it prints are NOT scaling numbers (the ranks share one
+    # GPU) and carry "rehearsal": true.  tests/test_hip_multirank.py runs it so that the first real 8-GPU launch cannot fail on plumbing.
+    share_gpu = os.environ.get("DSP_BENCH_SHARE_GPU") == "1"
+    if share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if share_gpu:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=dev)
 
     import __graft_entry__ as g
     if rank == 0:
@@ -630,8 +642,10 @@ def main():
             "lone_batch_scenarios_per_s": world * B / (1e-3 * single_batch_ms),
             "scaling": "strong" if args.total > 0 else "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "world_size": world, "collective_backend": (f"nccl(RCCL) {'.'.join(map(str, torch.cuda.nccl.version()))}"
+            "world_size": world, "collective_backend": (("gloo on host copies (REHEARSAL: ranks share cuda:0)" if share_gpu else
+                                                         f"nccl(RCCL) {'.'.join(map(str, torch.cuda.nccl.version()))}")
                                                         if world > 1 else None),
+            "rehearsal": bool(share_gpu),
             "config": {"workload": f"{args.workload}: {B_max} scenarios/GPU x {len(model.HOUR)} h day-ahead bidding LP "
                                    f"(n={lp.n}, m={lp.m}, nnz={lp.nnz}), synthetic scenarios from the in-tree RTS-GMLC / nuclear "
                                    f"LMP series (dispatches_amd/scenarios.py)",

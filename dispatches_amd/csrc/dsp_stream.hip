@@ -932,158 +932,144 @@ __global__ void __launch_bounds__(kTB) k_fused_pre(StreamArgs a, FusedIO io, int
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const StreamProblem &P = a.P;
   const FusedPlan &F = P.F;
-  const int n = P.n, m = P.m, nlong = P.C.nlong, NY = F.ny_max, NXB = F.nxb_max;
+  const int n = P.n, m = P.m, nlong = P.C.nlong, NY = F.ny_max, NXB = F.nxb_max, WC = P.C.W, WR = P.R.W;
   const int tile = blockIdx.x, b0 = blockIdx.y * SG, tid = threadIdx.x;
   const int32_t *tp = F.tile + 8 * tile;
   const int i0 = tp[0], i1 = tp[1], j0 = tp[2], j1 = tp[3], c_lo = tp[4], c_hi = tp[5], r_lo = tp[6], r_hi = tp[7];
   double *ys = lds, *xb = lds + (size_t)SG * NY, *red = xb + (size_t)SG * NXB;
+  // Phase A is written WITHOUT data-dependent control flow: every load goes to a clamped (always valid) address and is issued
+  // before anything that was loaded is looked at; validity (row / column inside the tile, long column, scenario alive) only
+  // masks the stores and LDS writes at the end.  The first version predicated each load and turned each loaded index into
+  // a local slot on the spot: the compiler emitted s_waitcnt vmcnt(0) after nearly every load and the launch ran 20 % slower
+  // than the staged kernel (profiles/r30c_fused_scan.log).
+  int su[SG];
   bool act[SG];
   double tau[SG], sig[SG], oml[SG];
-  bool any = false;
 #pragma unroll
   for (int u = 0; u < SG; ++u) {
-    const int s = b0 + u;
-    const StreamCtrl &c = a.W.ctrl[s < a.b.B ? s : 0];
-    act[u] = s < a.b.B && !c.done;
+    su[u] = min(b0 + u, a.b.B - 1);
+    const StreamCtrl &c = a.W.ctrl[su[u]];
+    act[u] = b0 + u < a.b.B && !c.done;
     tau[u] = c.tau; sig[u] = c.sig; oml[u] = 1.0 / (double)(c.k + kofs + 3);
-    any |= act[u];
   }
-  if (!any) return;
   // ---- phase A: every global load of the workgroup -----------------------------------------------------------------------------
-  double yr[K][SG], y0r[K][SG], xr[K][SG], cr[K][SG], x0r[K][SG], lbr[K], ubr[K], rlor[K], rhir[K];
+  int ik[K], jk[K];
+  double yr[K][SG], y0r[K][SG], xr[K][SG], cr[K][SG], x0r[K][SG], lbr[K][SHARED ? 1 : SG], ubr[K][SHARED ? 1 : SG],
+      rlor[K][SHARED ? 1 : SG], rhir[K][SHARED ? 1 : SG], kapr[K][QP ? SG : 1];
   double cval[K][MW], rval[K][MW];
-  int cidx[K][MW], rslot[K][MW];
-  bool rowok[K], colok[K], row_long[K];
+  int cgi[K][MW], rgi[K][MW];
+  unsigned char clong[K];
 #pragma unroll
   for (int k = 0; k < K; ++k) {
-    const int i = i0 + tid + k * kTB, j = j0 + tid + k * kTB;
-    rowok[k] = i < i1;
-    colok[k] = j < j1 && !P.C.is_long[j < j1 ? j : j0];
-    row_long[k] = false;
+    ik[k] = min(i0 + tid + k * kTB, m - 1);
+    jk[k] = min(j0 + tid + k * kTB, n - 1);
+    clong[k] = P.C.is_long[jk[k]];
 #pragma unroll
     for (int u = 0; u < SG; ++u) {
-      yr[k][u] = y0r[k][u] = xr[k][u] = cr[k][u] = x0r[k][u] = 0.0;
-      if (rowok[k] && act[u]) { const size_t at = (size_t)(b0 + u) * m + i; yr[k][u] = io.y_in[at]; y0r[k][u] = a.W.y0[at]; }
-      if (colok[k] && act[u]) { const size_t at = (size_t)(b0 + u) * n + j; xr[k][u] = io.x_in[at]; cr[k][u] = a.W.c[at]; x0r[k][u] = a.W.x0[at]; }
+      const size_t ar = (size_t)su[u] * m + ik[k], ac = (size_t)su[u] * n + jk[k];
+      yr[k][u] = io.y_in[ar]; y0r[k][u] = a.W.y0[ar];
+      xr[k][u] = io.x_in[ac]; cr[k][u] = a.W.c[ac]; x0r[k][u] = a.W.x0[ac];
+      if (!SHARED) { lbr[k][u] = a.W.lb[ac]; ubr[k][u] = a.W.ub[ac]; rlor[k][u] = a.W.rlo[ar]; rhir[k][u] = a.W.rhi[ar]; }
+      if (QP) kapr[k][u] = a.W.kap[ar];
     }
-    lbr[k] = ubr[k] = rlor[k] = rhir[k] = 0.0;
-    if (SHARED) {
-      if (colok[k]) { lbr[k] = a.W.lb[j]; ubr[k] = a.W.ub[j]; }
-      if (rowok[k]) { rlor[k] = a.W.rlo[i]; rhir[k] = a.W.rhi[i]; }
-    }
+    if (SHARED) { lbr[k][0] = a.W.lb[jk[k]]; ubr[k][0] = a.W.ub[jk[k]]; rlor[k][0] = a.W.rlo[ik[k]]; rhir[k][0] = a.W.rhi[ik[k]]; }
 #pragma unroll
     for (int e = 0; e < MW; ++e) {
-      cval[k][e] = 0.0; cidx[k][e] = 0; rval[k][e] = 0.0; rslot[k][e] = 0;
-      if (e < P.C.W && colok[k]) {
-        cval[k][e] = P.C.val[(size_t)e * n + j];
-        const int gi = P.C.idx[(size_t)e * n + j];
-        cidx[k][e] = (gi < r_lo || gi >= r_hi) ? 0 : gi - r_lo;
-      }
-      if (e < P.R.W && rowok[k]) {
-        rval[k][e] = P.R.val[(size_t)e * m + i];
-        const int gi = F.ridx_enc[(size_t)e * m + i];
-        int sl = gi < 0 ? -1 - gi : nlong + gi - c_lo;
-        if (gi >= 0 && (gi < c_lo || gi >= c_hi)) sl = 0;
-        rslot[k][e] = sl;
-        row_long[k] |= gi < 0 && rval[k][e] != 0.0;
-      }
+      const int ec = min(e, WC - 1), er = min(e, WR - 1);
+      cval[k][e] = P.C.val[(size_t)ec * n + jk[k]]; cgi[k][e] = P.C.idx[(size_t)ec * n + jk[k]];
+      rval[k][e] = P.R.val[(size_t)er * m + ik[k]]; rgi[k][e] = F.ridx_enc[(size_t)er * m + ik[k]];
     }
   }
-  // halo rows (staged y only) and halo columns (their xbar only): the few elements of the hulls outside the own ranges
+  // one halo column and one halo row (staged y only) per thread: at most a few periods' worth (host: halo_max <= 256)
   const int nhr = (i0 - r_lo) + (r_hi - i1), nhc = (j0 - c_lo) + (c_hi - j1);
-  for (int h = tid; h < nhr; h += kTB) {
-    const int i = h < i0 - r_lo ? r_lo + h : i1 + (h - (i0 - r_lo));
-#pragma unroll
-    for (int u = 0; u < SG; ++u) if (act[u]) ys[u * NY + (i - r_lo)] = io.y_in[(size_t)(b0 + u) * m + i];
-  }
-  // (halo columns: one thread each - there are at most a few periods' worth; loaded here, used in phase C)
-  const bool halo_col = tid < nhc;
-  const int hj = halo_col ? (tid < j0 - c_lo ? c_lo + tid : j1 + (tid - (j0 - c_lo))) : c_lo;
-  const bool halo_ok = halo_col && !P.C.is_long[hj];
-  double hx[SG], hc[SG], hval[MW], hlb = 0.0, hub = 0.0;
-  int hidx[MW];
+  const int hi_ = min(tid < i0 - r_lo ? r_lo + tid : i1 + (tid - (i0 - r_lo)), m - 1);
+  const int hj = min(tid < j0 - c_lo ? c_lo + tid : j1 + (tid - (j0 - c_lo)), n - 1);
+  double hy[SG], hx[SG], hc[SG], hlb[SHARED ? 1 : SG], hub[SHARED ? 1 : SG], hval[MW];
+  int hgi[MW];
+  const unsigned char hlong = P.C.is_long[hj];
 #pragma unroll
   for (int u = 0; u < SG; ++u) {
-    hx[u] = hc[u] = 0.0;
-    if (halo_ok && act[u]) { const size_t at = (size_t)(b0 + u) * n + hj; hx[u] = io.x_in[at]; hc[u] = a.W.c[at]; }
+    hy[u] = io.y_in[(size_t)su[u] * m + hi_];
+    const size_t ac = (size_t)su[u] * n + hj;
+    hx[u] = io.x_in[ac]; hc[u] = a.W.c[ac];
+    if (!SHARED) { hlb[u] = a.W.lb[ac]; hub[u] = a.W.ub[ac]; }
   }
-  if (SHARED && halo_ok) { hlb = a.W.lb[hj]; hub = a.W.ub[hj]; }
+  if (SHARED) { hlb[0] = a.W.lb[hj]; hub[0] = a.W.ub[hj]; }
 #pragma unroll
-  for (int e = 0; e < MW; ++e) {
-    hval[e] = 0.0; hidx[e] = 0;
-    if (e < P.C.W && halo_ok) {
-      hval[e] = P.C.val[(size_t)e * n + hj];
-      const int gi = P.C.idx[(size_t)e * n + hj];
-      hidx[e] = (gi < r_lo || gi >= r_hi) ? 0 : gi - r_lo;
-    }
-  }
+  for (int e = 0; e < MW; ++e) { const int ec = min(e, WC - 1); hval[e] = P.C.val[(size_t)ec * n + hj]; hgi[e] = P.C.idx[(size_t)ec * n + hj]; }
   // long columns' A^T y from the per-tile partial sums (one wave per (scenario, long column), fixed order)
   for (int q = tid >> 6; q < nlong * SG; q += kTB / 64) {
-    const int l = q % nlong, u = q / nlong, s = b0 + u, lane = tid & 63;
-    if (!act[u]) continue;
-    const double *pp = io.lp_in + ((size_t)s * nlong + l) * F.ntile;
+    const int l = q % nlong, u = q / nlong, lane = tid & 63;
+    const double *pp = io.lp_in + ((size_t)su[u] * nlong + l) * F.ntile;
     double aty = 0.0;
     for (int t = lane; t < F.ntile; t += 64) aty += pp[t];
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) aty += __shfl_down(aty, off, 64);
     if (lane == 0) {
       const int j = P.C.long_id[l];
-      const size_t at = (size_t)s * n + j, ab = SHARED ? (size_t)j : at;
+      const size_t at = (size_t)su[u] * n + j, ab = SHARED ? (size_t)j : at;
       const double x = io.x_in[at];
       const double xp = clampd2(fma(-tau[u], a.W.c[at] - aty, x), a.W.lb[ab], a.W.ub[ab]);
       xb[u * NXB + l] = 2.0 * xp - x;
     }
   }
-  // ---- phase B: own y into LDS ---------------------------------------------------------------------------------------------------
+  // ---- phase B: y into LDS (own rows + halo rows) ----------------------------------------------------------------------------------
+  bool rowok[K], colok[K];
 #pragma unroll
-  for (int k = 0; k < K; ++k)
+  for (int k = 0; k < K; ++k) {
+    rowok[k] = i0 + tid + k * kTB < i1;
+    colok[k] = j0 + tid + k * kTB < j1 && !clong[k];
     if (rowok[k]) {
-      const int i = i0 + tid + k * kTB;
 #pragma unroll
-      for (int u = 0; u < SG; ++u) if (act[u]) ys[u * NY + (i - r_lo)] = yr[k][u];
+      for (int u = 0; u < SG; ++u) ys[u * NY + (ik[k] - r_lo)] = yr[k][u];
     }
+  }
+  if (tid < nhr) {
+#pragma unroll
+    for (int u = 0; u < SG; ++u) ys[u * NY + (hi_ - r_lo)] = hy[u];
+  }
   __syncthreads();
   // ---- phase C: primal step of the own columns (registers) and of the halo columns -> xbar in LDS; x written ------------------------
 #pragma unroll
   for (int k = 0; k < K; ++k) {
-    if (!colok[k]) continue;
-    const int j = j0 + tid + k * kTB;
+    int cl[MW];
+#pragma unroll
+    for (int e = 0; e < MW; ++e) cl[e] = (e >= WC || cgi[k][e] < r_lo || cgi[k][e] >= r_hi) ? 0 : cgi[k][e] - r_lo;
 #pragma unroll
     for (int u = 0; u < SG; ++u) {
-      if (!act[u]) continue;
       const double *yv = ys + u * NY;
       double aty = 0.0;
 #pragma unroll
-      for (int e = 0; e < MW; ++e) if (e < P.C.W) aty = fma(cval[k][e], yv[cidx[k][e]], aty);
-      const size_t at = (size_t)(b0 + u) * n + j;
-      const double lo = SHARED ? lbr[k] : a.W.lb[at], hi = SHARED ? ubr[k] : a.W.ub[at];
-      const double xp = clampd2(fma(-tau[u], cr[k][u] - aty, xr[k][u]), lo, hi);
+      for (int e = 0; e < MW; ++e) aty = fma(e < WC ? cval[k][e] : 0.0, yv[cl[e]], aty);
+      const double xp = clampd2(fma(-tau[u], cr[k][u] - aty, xr[k][u]), lbr[k][SHARED ? 0 : u], ubr[k][SHARED ? 0 : u]);
       const double tt = 2.0 * xp - xr[k][u];
-      xb[u * NXB + nlong + (j - c_lo)] = tt;
-      io.x_out[at] = fma(oml[u], x0r[k][u] - tt, tt);
+      if (colok[k]) {
+        xb[u * NXB + nlong + (jk[k] - c_lo)] = tt;
+        if (act[u]) io.x_out[(size_t)su[u] * n + jk[k]] = fma(oml[u], x0r[k][u] - tt, tt);
+      }
     }
   }
-  if (halo_ok) {
+  {
+    int cl[MW];
+#pragma unroll
+    for (int e = 0; e < MW; ++e) cl[e] = (e >= WC || hgi[e] < r_lo || hgi[e] >= r_hi) ? 0 : hgi[e] - r_lo;
 #pragma unroll
     for (int u = 0; u < SG; ++u) {
-      if (!act[u]) continue;
       const double *yv = ys + u * NY;
       double aty = 0.0;
 #pragma unroll
-      for (int e = 0; e < MW; ++e) if (e < P.C.W) aty = fma(hval[e], yv[hidx[e]], aty);
-      const size_t at = (size_t)(b0 + u) * n + hj;
-      const double lo = SHARED ? hlb : a.W.lb[at], hi = SHARED ? hub : a.W.ub[at];
-      const double xp = clampd2(fma(-tau[u], hc[u] - aty, hx[u]), lo, hi);
-      xb[u * NXB + nlong + (hj - c_lo)] = 2.0 * xp - hx[u];
+      for (int e = 0; e < MW; ++e) aty = fma(e < WC ? hval[e] : 0.0, yv[cl[e]], aty);
+      const double xp = clampd2(fma(-tau[u], hc[u] - aty, hx[u]), hlb[SHARED ? 0 : u], hub[SHARED ? 0 : u]);
+      if (tid < nhc && !hlong) xb[u * NXB + nlong + (hj - c_lo)] = 2.0 * xp - hx[u];
     }
   }
   if (tid < nlong * SG) {                       // the long columns this tile owns: their Halpern step (xbar written in phase A)
-    const int l = tid % nlong, u = tid / nlong, s = b0 + u;
+    const int l = tid % nlong, u = tid / nlong;
     const int j = P.C.long_id[l];
-    if (j >= j0 && j < j1 && s < a.b.B && !a.W.ctrl[s].done) {
-      const size_t at = (size_t)s * n + j;
+    if (j >= j0 && j < j1 && act[u]) {
+      const size_t at = (size_t)su[u] * n + j;
       const double tt = xb[u * NXB + l];
-      io.x_out[at] = fma(1.0 / (double)(a.W.ctrl[s].k + kofs + 3), a.W.x0[at] - tt, tt);
+      io.x_out[at] = fma(oml[u], a.W.x0[at] - tt, tt);
     }
   }
   __syncthreads();
@@ -1095,31 +1081,35 @@ __global__ void __launch_bounds__(kTB) k_fused_pre(StreamArgs a, FusedIO io, int
     for (int q = 0; q < kFusedMaxLong; ++q) lp[u][q] = 0.0;
 #pragma unroll
   for (int k = 0; k < K; ++k) {
-    if (!rowok[k]) continue;
-    const int i = i0 + tid + k * kTB;
+    int sl[MW];
+    double rv[MW];
+#pragma unroll
+    for (int e = 0; e < MW; ++e) {
+      const int gi = rgi[k][e];
+      int t = gi < 0 ? -1 - gi : nlong + gi - c_lo;
+      if (e >= WR || (gi >= 0 && (gi < c_lo || gi >= c_hi))) t = 0;
+      sl[e] = t;
+      rv[e] = e < WR ? rval[k][e] : 0.0;
+    }
 #pragma unroll
     for (int u = 0; u < SG; ++u) {
-      if (!act[u]) continue;
       const double *xv = xb + u * NXB;
       double ax = 0.0;
 #pragma unroll
-      for (int e = 0; e < MW; ++e) if (e < P.R.W) ax = fma(rval[k][e], xv[rslot[k][e]], ax);
-      const size_t at = (size_t)(b0 + u) * m + i;
-      const double lo = SHARED ? rlor[k] : a.W.rlo[at], hi = SHARED ? rhir[k] : a.W.rhi[at];
+      for (int e = 0; e < MW; ++e) ax = fma(rv[e], xv[sl[e]], ax);
       const double y = yr[k][u];
       const double gy = fma(-sig[u], ax, y);
-      double yp = gy - clampd2(gy, -sig[u] * hi, -sig[u] * lo);
-      if (QP) yp /= fma(sig[u], a.W.kap[at], 1.0);
+      double yp = gy - clampd2(gy, -sig[u] * rhir[k][SHARED ? 0 : u], -sig[u] * rlor[k][SHARED ? 0 : u]);
+      if (QP) yp /= fma(sig[u], kapr[k][u], 1.0);
       const double tt = 2.0 * yp - y;
       const double yn = fma(oml[u], y0r[k][u] - tt, tt);
-      io.y_out[at] = yn;
-      if (row_long[k]) {
+      if (rowok[k] && act[u]) {
+        io.y_out[(size_t)su[u] * m + ik[k]] = yn;
 #pragma unroll
         for (int e = 0; e < MW; ++e) {
-          if (e < P.R.W && rslot[k][e] < nlong && rval[k][e] != 0.0) {
+          const double w = (rgi[k][e] < 0 && e < WR) ? rv[e] * yn : 0.0;
 #pragma unroll
-            for (int q = 0; q < kFusedMaxLong; ++q) lp[u][q] += (rslot[k][e] == q) ? rval[k][e] * yn : 0.0;
-          }
+          for (int q = 0; q < kFusedMaxLong; ++q) lp[u][q] += (sl[e] == q) ? w : 0.0;
         }
       }
     }
@@ -1128,7 +1118,7 @@ __global__ void __launch_bounds__(kTB) k_fused_pre(StreamArgs a, FusedIO io, int
 #pragma unroll
     for (int u = 0; u < SG; ++u) {
       fused_reduce_long(lp[u], nlong, red);
-      if (tid < nlong && act[u]) io.lp_out[((size_t)(b0 + u) * nlong + tid) * F.ntile + tile] = red[tid];
+      if (tid < nlong && act[u]) io.lp_out[((size_t)su[u] * nlong + tid) * F.ntile + tile] = red[tid];
       __syncthreads();
     }
   }

@@ -12,6 +12,8 @@ price-scenario axis of Bidder.compute_day_ahead_bids.
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
 
 
@@ -69,7 +71,14 @@ def gather_device_results(out, buffers, per_rank=None, group=None, columns=("obj
         w = 1 if t.dim() == 1 else t.shape[1]
         local[:b, col:col + w] = t.reshape(b, w)            # dtype conversion (int32 status -> float64) happens here
         col += w
-    dist.all_gather_into_tensor(everything, local, group=group)
+    if local.is_cuda and dist.get_backend(group) != "nccl":
+        # REHEARSAL of the multi-GPU path on a box with one GPU (several ranks sharing cuda:0 cannot form an RCCL communicator):
+        # the same device-side packing, the collective itself on host copies through gloo, the result back on the device.
+        host_all = everything.cpu()
+        dist.all_gather_into_tensor(host_all, local.cpu(), group=group)
+        everything.copy_(host_all)
+    else:
+        dist.all_gather_into_tensor(everything, local, group=group)
     return everything.view(-1, per, local.shape[1])
 
 
@@ -98,7 +107,10 @@ def solve_sharded(model, solver, group=None, gather_solution: bool = False):
     n, m = model.lp.n, model.lp.m
     per = max(shard_bounds(B, world, r)[1] - shard_bounds(B, world, r)[0] for r in range(world))
     width = 4 + ((n + m) if gather_solution else 0)          # objective, status, iterations, flags [, x, y]
-    on_gpu = dist.is_initialized() and dist.get_backend(group) == "nccl"
+    # DSP_REHEARSE_ON_DEVICE=1: take the device path under gloo too (ranks sharing one GPU: gather_device_results stages the
+    # collective through the host) - what the single-GPU rehearsal of the multi-GPU bench uses
+    on_gpu = dist.is_initialized() and (dist.get_backend(group) == "nccl" or
+                                        (os.environ.get("DSP_REHEARSE_ON_DEVICE") == "1" and torch.cuda.is_available()))
     dev = torch.device("cuda", torch.cuda.current_device()) if on_gpu else torch.device("cpu")
     columns = ("obj", "status", "iters", "flags") + (("x", "y") if gather_solution else ())
     dev_out = getattr(solver, "last_device_out", None) if on_gpu else None

@@ -92,6 +92,53 @@ def test_year_long_price_taker_lps_converge():
 
 
 @gpu
+def test_reference_price_taker_goldens_on_the_gpu(golden):
+    """The reference's own price-taker tests (renewables_case/tests/test_RE_flowsheet.py:123-161) through the HIP path: LP #4 (wind +
+    battery, one week) and LP #5 (wind + battery + PEM, six days, hydrogen at 2.5 $/kg) on the reference's inputs - SRW wind speeds
+    through the PySAM-free wind resource model, LMPs capped at 200 - reproduce its NPV / revenues / PEM size (the reference asserts
+    rel 1e-3 / 1e-2; here 1e-6), and every member of the two scenario families matches the independent oracle to 1e-6."""
+    from dispatches_amd import scenarios
+    from dispatches_amd.hip_solver import HipPdlpSolver
+    from oracle import dispatch_lp_oracle as orc
+    g8, g10 = golden["G8_price_taker_wind_battery"], golden["G10_price_taker_wind_battery_pem"]
+    solver = HipPdlpSolver(device=0, check_every=64, max_iter=1_000_000)
+    # ---- LP #4 ------------------------------------------------------------------------------------------------------------
+    T, B = g8["n_time_points"], 4
+    handles, model = scenarios.price_taker_batch(T, B, solver, inputs="reference")
+    solver.solve(model, tee=True)
+    assert solver.last_stats.streaming == 1 and (model.status == 0).all(), (model.status, model.iterations)
+    cf, lmp = scenarios.price_taker_reference_inputs(T)
+    assert np.abs(cf - orc.sam_weibull_capacity_factor(np.load(os.path.join(os.path.dirname(GOLD), "..", "dispatches_amd", "data",
+                                                                              "price_taker_inputs.npz"))["wind_speed_m_s"][:T])).max() < 1e-12
+    ref = np.array([orc.wind_battery_price_taker(T, cf, lmp * lm, batt_cap_factor=bf)[0].solve(tight=True)[1] for bf, lm in model.family])
+    assert (np.abs(model.objective - ref) / np.maximum(1.0, np.abs(ref))).max() < 1e-6, (model.objective, ref)
+    x = model.x[0]
+    assert model.block.expressions["NPV"][0].value(x) == pytest.approx(g8["NPV"], rel=1e-6)
+    assert model.block.expressions["annual_revenue"][0].value(x) == pytest.approx(g8["annual_revenue"], rel=1e-6)
+    assert x[handles["nameplate_power"].index] == pytest.approx(0.0, abs=g8["battery_abs"])
+    # ---- LP #5 ------------------------------------------------------------------------------------------------------------
+    T, B = g10["time_points"], 8
+    handles, model = scenarios.pem_price_taker_batch(T, B, solver, design_opt=True)
+    solver.solve(model, tee=True)
+    assert solver.last_stats.streaming == 1 and (model.status == 0).all(), (model.status, model.iterations)
+    cf, lmp = scenarios.price_taker_reference_inputs(T)
+    ref = []
+    for h2, pf in model.family:
+        P, info = orc.wind_battery_pem_price_taker(T, cf, lmp, h2, True)
+        c = P.c.copy()
+        c[info["Cp"]] += 1e-5 * (pf - 1.0) * orc.PEM_CAP_COST                 # the family's PEM capital-cost factor
+        ref.append(P.solve(c=c, tight=True)[1])
+    ref = np.array(ref)
+    assert (np.abs(model.objective - ref) / np.maximum(1.0, np.abs(ref))).max() < 1e-6, (model.objective, ref, model.iterations)
+    x = model.x[1]                                                             # member 1 = the reference test's setting
+    assert -model.objective[1] * 1e5 == pytest.approx(g10["NPV"], rel=1e-6)
+    assert x[handles["pem_system_capacity"].index] * 1e-3 == pytest.approx(g10["pem_mw"], abs=g10["pem_mw_abs_full_design"])
+    assert x[handles["battery_system_capacity"].index] * 1e-3 == pytest.approx(g10["batt_mw"], abs=0.5)
+    assert model.block.expressions["annual_rev_E"][0].value(x) == pytest.approx(g10["annual_rev_E"], rel=1e-4)
+    assert model.block.expressions["annual_rev_h2"][0].value(x) / 2.0 * g10["h2_price_per_kg"] == pytest.approx(g10["annual_rev_h2"], rel=1e-4)
+
+
+@gpu
 def test_streaming_edge_cases():
     """B = 1, an invalid scenario (crossed bounds), the iteration limit."""
     from dispatches_amd import scenarios

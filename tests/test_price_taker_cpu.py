@@ -1,0 +1,56 @@
+"""The long-horizon price-taker design flowsheets of the product (dispatches_amd/flowsheets/price_taker.py, wind_resource.py) on
+the CPU: their flattened LPs, solved by the HiGHS test solver, reproduce the reference's own known answers (the same vectors
+tests/test_oracle_golden.py pins the independent oracle to), and the product's wind resource model reproduces the unit model's.
+The HIP path is checked against the same numbers in tests/test_hip_stream.py."""
+import numpy as np
+import pytest
+
+from _highs_solver import HighsTestSolver
+from dispatches_amd import scenarios
+from dispatches_amd.flowsheets import wind_resource as wr
+
+
+def test_wind_resource_model_known_answers(golden, price_taker_inputs):
+    g = golden["G9_wind_unit_model"]
+    cap = g["system_capacity_kw"]
+    assert wr.capacity_factor_from_speed(float(g["speed_m_s"])) * cap == pytest.approx(g["weibull_model_electricity_kw"], rel=1e-6)
+    assert wr.capacity_factor_from_distribution_point(g["speed_m_s"]) == pytest.approx(g["distribution_model_capacity_factor"], rel=1e-4)
+    cf = wr.capacity_factor_from_speed(price_taker_inputs["wind_speed_m_s"])
+    assert cf.shape == (8760,) and cf.min() >= 0.0 and cf.max() <= wr.loss_factor() + 1e-12
+    assert wr.capacity_factor_from_speed(0.0) == 0.0 and wr.capacity_factor_from_speed(2.0) < 1e-9 and wr.capacity_factor_from_speed(27.0) < 1e-3
+    # independent of the oracle's restatement (written separately): same numbers
+    from oracle import dispatch_lp_oracle as orc
+    assert np.abs(cf - orc.sam_weibull_capacity_factor(price_taker_inputs["wind_speed_m_s"])).max() < 1e-12
+
+
+def test_wind_battery_price_taker_reproduces_the_reference_golden(golden):
+    g = golden["G8_price_taker_wind_battery"]
+    handles, model = scenarios.price_taker_batch(g["n_time_points"], 1, HighsTestSolver(), inputs="reference")
+    model.solver.solve(model)
+    x = model.x[0]
+    npv = model.block.expressions["NPV"][0].value(x)
+    assert npv == pytest.approx(g["NPV"], rel=1e-7)                      # reference test: rel 1e-3
+    assert model.block.expressions["annual_revenue"][0].value(x) == pytest.approx(g["annual_revenue"], rel=1e-7)
+    assert x[handles["nameplate_power"].index] == pytest.approx(g["battery_nameplate_power_kw"], abs=g["battery_abs"])
+    assert model.objective[0] == pytest.approx(-npv * 1e-5, rel=1e-9)
+
+
+@pytest.mark.parametrize("design_opt", ["PEM", True])
+def test_wind_battery_pem_price_taker_reproduces_the_reference_goldens(golden, design_opt):
+    g = golden["G10_price_taker_wind_battery_pem"]
+    handles, model = scenarios.pem_price_taker_batch(g["time_points"], 2, HighsTestSolver(), design_opt=design_opt)
+    assert scenarios.PEM_PRICE_TAKER_FAMILY[1] == (g["h2_price_per_kg"], 1.0)
+    model.solver.solve(model)
+    x = model.x[1]                                                        # member 1: hydrogen at 2.5 $/kg, nominal PEM cost
+    ex = model.block.expressions
+    h2_kg = ex["annual_rev_h2"][0].value(x) / 2.0 * g["h2_price_per_kg"]   # the expression carries the template's price (2 $/kg)
+    assert x[handles["battery_system_capacity"].index] * 1e-3 == pytest.approx(g["batt_mw"], abs=1e-3)
+    assert x[handles["pem_system_capacity"].index] * 1e-3 == pytest.approx(g["pem_mw"], abs=g["pem_mw_abs_full_design"])
+    assert h2_kg == pytest.approx(g["annual_rev_h2"], rel=1e-6)            # reference test: rel 1e-2
+    assert ex["annual_rev_E"][0].value(x) == pytest.approx(g["annual_rev_E"], rel=1e-6)
+    assert -model.objective[1] * 1e5 == pytest.approx(g["NPV"], rel=1e-6)
+    # the cheaper the electrolyzer and the dearer the hydrogen, the bigger the plant
+    handles, fam = scenarios.pem_price_taker_batch(g["time_points"], 8, HighsTestSolver(), design_opt=design_opt)
+    fam.solver.solve(fam)
+    pem = fam.x[:, handles["pem_system_capacity"].index]
+    assert (np.diff(pem[:4]) >= -1e-6).all() and (pem[4:8] >= pem[:4] - 1e-6).all()
