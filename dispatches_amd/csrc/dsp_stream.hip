@@ -933,7 +933,18 @@ __global__ void __launch_bounds__(kTB) k_fused_pre(StreamArgs a, FusedIO io, int
   const StreamProblem &P = a.P;
   const FusedPlan &F = P.F;
   const int n = P.n, m = P.m, nlong = P.C.nlong, NY = F.ny_max, NXB = F.nxb_max, WC = P.C.W, WR = P.R.W;
-  const int tile = blockIdx.x, b0 = blockIdx.y * SG, tid = threadIdx.x;
+  // XCD-aware order (gridDim.y == 1): workgroups go round-robin to the 8 XCDs, each with its own L2.  Linear id -> XCD id % 8,
+  // and WITHIN an XCD consecutive workgroups take the scenario groups of ONE tile before the next tile: the tile's slice of the
+  // matrix (a few tens of KB) is fetched into that L2 once and hit by all the scenario groups that follow, instead of coming
+  // over the fabric again for every (tile, group) workgroup (B / SG x 5 MB per launch: profiles/r30e_*).
+  int tile = blockIdx.x, grp = blockIdx.y;
+  if (gridDim.y == 1) {
+    const int groups = (a.b.B + SG - 1) / SG, lin = blockIdx.x;
+    tile = ((lin >> 3) / groups) * 8 + (lin & 7);
+    grp = (lin >> 3) % groups;
+    if (tile >= F.ntile) return;
+  }
+  const int b0 = grp * SG, tid = threadIdx.x;
   const int32_t *tp = F.tile + 8 * tile;
   const int i0 = tp[0], i1 = tp[1], j0 = tp[2], j1 = tp[3], c_lo = tp[4], c_hi = tp[5], r_lo = tp[6], r_hi = tp[7];
   double *ys = lds, *xb = lds + (size_t)SG * NY, *red = xb + (size_t)SG * NXB;
@@ -1626,7 +1637,9 @@ static hipError_t run_fused(StreamSolver *S, StreamArgs &a, hipStream_t st, int 
 #undef DSP_PICK2
   // persistent tiles (k_fused_loop): gridDim.y workgroups per tile stride through the scenario groups, matrix entries in registers
   // for all of them, the next group's vectors in flight while the current one is computed.  DSP_FUSED_V=2 keeps k_fused_pre.
-  const bool loop = pre && v_env != 2 && K <= 2 && F.ntile <= 256 && P.C.nlong * SG <= 8;
+  const bool loop = pre && v_env == 3 && K <= 2 && F.ntile <= 256 && P.C.nlong * SG <= 8;      // (measured slower: development only)
+  static const int xcd_env = getenv("DSP_FUSED_XCD") ? atoi(getenv("DSP_FUSED_XCD")) : 1;
+  const bool xcd = pre && !loop && xcd_env != 0;
   static const int gy_env = getenv("DSP_FUSED_GY") ? atoi(getenv("DSP_FUSED_GY")) : 0;
   int gy = groups;
   if (loop) {
@@ -1658,7 +1671,8 @@ static hipError_t run_fused(StreamSolver *S, StreamArgs &a, hipStream_t st, int 
       FusedIO io{xcur, ycur, xalt, yalt, a.W.lpart[lp_cur], a.W.lpart[lp_cur ^ 1]};
       int kofs = u, ng = groups;
       void *params[] = {&a, &io, &kofs, &ng};                     // (k_fused / k_fused_pre take the first three)
-      if ((e = hipLaunchKernel(fn, loop ? dim3(F.ntile, gy) : g_fused, blk, params, lds, st)) != hipSuccess) return e;
+      const dim3 grid = loop ? dim3(F.ntile, gy) : (xcd ? dim3(((F.ntile + 7) / 8) * 8 * groups, 1) : g_fused);
+      if ((e = hipLaunchKernel(fn, grid, blk, params, lds, st)) != hipSuccess) return e;
       std::swap(xcur, xalt); std::swap(ycur, yalt); lp_cur ^= 1;
     }
     // the check sequence works in place on the current buffers

@@ -271,3 +271,99 @@ def wind_battery_pem_price_taker(time_points, capacity_factors, lmps, h2_price_p
         return s
     handles["column_scales"] = column_scales
     return b, objective, handles
+
+
+# ---- nuclear + PEM price-taker enumeration -----------------------------------------------------------------------
+# Reference: dispatches/case_studies/nuclear_case/report/price_taker_analysis.py - build_ne_flowsheet (:116-172), the
+# MultiPeriodModel of 366 x 24 hourly flowsheets linked by the tank holdup (:175-222), hourly cash flow (:225-254), annualised NPV
+# (:257-322) and `run_exhaustive_enumeration` (:353-419): 6 hydrogen prices x 10 PEM capacities = 60 LPs that share ONE constraint
+# matrix and differ in the objective (hydrogen price) and in one fixed design column (pem_capacity) - the natural batch.
+NP_CAPACITY_MW = 400.0            # :140
+H2_PROD_RATE = 20.0               # kg of hydrogen per MWh into the electrolyzer (:42)
+TURBINE_MWH_PER_KG = 0.0125       # :160-163
+NUCLEAR_H2_PRICES = (0.75, 1.0, 1.25, 1.5, 1.75, 2.0)                       # $/kg  (:358)
+NUCLEAR_PEM_FRACTIONS = tuple(i / 100 for i in range(5, 51, 5))              # of the plant's 400 MW (:359)
+
+
+def nuclear_price_taker(n_time_points, lmps, h2_demand=NP_CAPACITY_MW * H2_PROD_RATE, pem_capex=1200.0, vom_npp=2.3, vom_pem=0.0,
+                        vom_turbine=4.25, plant_life=30, tax_rate=0.2, discount_rate=0.08, capex_tank=29.0, capex_turbine=947.0,
+                        fom_turbine=7.0):
+    """The LP of one enumeration point as the reference builds it (tank and turbine present in the flowsheet, their capacities fixed
+    to 0 by the study, :374-377; variable hydrogen demand: h2_to_pipeline <= 400 * 20 kg/h, :360-361, :218-219).  `lmps` in $/MWh.
+    Objective: MAXIMISE the annualised NPV  net_profit - capex / constant_cf_factor  (:318-322), returned as the LinExpr to
+    MINIMISE (its negative, scaled by 1e-6: the reference reports million $).  pem_capacity is a column whose bounds the caller
+    fixes per scenario (`m.pem_capacity.fix(pc * 400)`, :399).  Returns (block, objective, handles)."""
+    T = int(n_time_points)
+    lmp = np.asarray(lmps, float)[:T]
+    b = LinearBlock("nuclear_price_taker")
+    pem_cap = b.var("pem_capacity", 0.0, np.inf, mutable=True, hull=(0.0, NP_CAPACITY_MW))
+    tank_cap = b.var("tank_capacity", 0.0, 0.0)                                  # fixed to 0 by the study (:376)
+    turb_cap = b.var("h2_turbine_capacity", 0.0, 0.0)                            # (:377)
+    per = []
+    hold_prev = None
+    cash = LinExpr()
+    for t in range(T):
+        g = b.var(f"fs.np_to_grid[{t}]")
+        e = b.var(f"fs.np_to_electrolyzer[{t}]")
+        h = b.var(f"fs.h2_production[{t}]")
+        hold = b.var(f"fs.tank_holdup[{t}]")
+        pipe = b.var(f"fs.h2_to_pipeline[{t}]", 0.0, h2_demand)
+        turb_in = b.var(f"fs.h2_to_turbine[{t}]")
+        turb_p = b.var(f"fs.h2_turbine_power[{t}]")
+        net = b.var(f"fs.net_power[{t}]")
+        b.equality(f"fs.np_power_balance[{t}]", g + e, NP_CAPACITY_MW)                         # np_power fixed at 400 (:140-146)
+        b.equality(f"fs.calc_h2_production_rate[{t}]", h - H2_PROD_RATE * e, 0.0)              # :149-152
+        bal = hold - h + pipe + turb_in                                                       # :154-157; holdup_previous[0] = 0 (:375)
+        b.equality(f"fs.tank_mass_balance[{t}]", bal if hold_prev is None else bal - hold_prev, 0.0)
+        b.equality(f"fs.calc_turbine_power[{t}]", turb_p - TURBINE_MWH_PER_KG * turb_in, 0.0)  # :164-167
+        b.equality(f"fs.grid_power_balance[{t}]", net - g - turb_p, 0.0)                       # :169-171
+        b.constraint(f"pem_capacity_constraint[{t}]", e - pem_cap, -np.inf, 0.0)               # :200-202
+        b.constraint(f"tank_capacity_constraint[{t}]", hold - tank_cap, -np.inf, 0.0)          # :204-206
+        b.constraint(f"turbine_capacity_constraint[{t}]", turb_p - turb_cap, -np.inf, 0.0)     # :208-210
+        cash = cash + net * float(lmp[t]) - e * vom_pem - turb_p * vom_turbine                 # :239-254 (hydrogen revenue: objective_vector)
+        per.append(dict(np_to_grid=g, np_to_electrolyzer=e, h2_production=h, tank_holdup=hold, h2_to_pipeline=pipe,
+                        h2_to_turbine=turb_in, h2_turbine_power=turb_p, net_power=net))
+        hold_prev = hold
+    cf_factor = (1 - (1 + discount_rate) ** (-plant_life)) / discount_rate                    # :308
+    fom_pem = 0.03 * pem_capex                                                                 # :395
+    capex = pem_cap * (pem_capex * 1000) + tank_cap * (capex_tank * 33.3) + turb_cap * (capex_turbine * 1000)        # :274-283
+    fixed_om = pem_cap * (1000 * fom_pem) + turb_cap * (1000 * fom_turbine) + 120 * 1000 * NP_CAPACITY_MW            # :277-290
+    npp_vom = vom_npp * NP_CAPACITY_MW * T
+
+    def annualised_npv(h2_price):
+        inflow = cash - npp_vom
+        for p in per:
+            inflow = inflow + p["h2_to_pipeline"] * float(h2_price)
+        depreciation = capex / plant_life                                                      # :298-301
+        net_profit = depreciation + (inflow - fixed_om - depreciation) * (1 - tax_rate)       # :303-305
+        return net_profit - capex * (1 / cf_factor), net_profit                               # :318-322
+    npv, net_profit = annualised_npv(NUCLEAR_H2_PRICES[0])
+    objective = npv * -1e-6
+    b.expression("annualised_npv", 0, npv)
+    b.expression("net_profit", 0, net_profit)
+    handles = dict(periods=per, pem_capacity=pem_cap, tank_capacity=tank_cap, h2_turbine_capacity=turb_cap)
+
+    def objective_vector(n_cols, h2_price):
+        """Dense cost vector of -annualised NPV * 1e-6 at hydrogen price `h2_price` (matrix and all other data unchanged)."""
+        c = np.zeros(n_cols)
+        k = -1e-6 * (1 - tax_rate)
+        for t, p in enumerate(per):
+            c[p["net_power"].index] = k * lmp[t]
+            c[p["np_to_electrolyzer"].index] = -k * vom_pem
+            c[p["h2_turbine_power"].index] = -k * vom_turbine
+            c[p["h2_to_pipeline"].index] = k * h2_price
+        # design columns: depreciation tax shield, fixed O&M, annualised capital
+        for col, cap, fom in ((pem_cap, pem_capex * 1000, 1000 * fom_pem), (tank_cap, capex_tank * 33.3, 0.0), (turb_cap, capex_turbine * 1000, 1000 * fom_turbine)):
+            c[col.index] = -1e-6 * (cap / plant_life * tax_rate - (1 - tax_rate) * fom - cap / cf_factor)
+        return c
+    handles["objective_vector"] = objective_vector
+    handles["objective_constant"] = -1e-6 * (1 - tax_rate) * (-npp_vom - 120 * 1000 * NP_CAPACITY_MW)
+
+    def column_scales(n_cols=None):
+        s = np.full(len(b.col_names) if n_cols is None else n_cols, NP_CAPACITY_MW)
+        for j, name in enumerate(b.col_names):
+            if any(k in name for k in ("h2_production", "tank_holdup", "h2_to_pipeline", "h2_to_turbine", "tank_capacity")):
+                s[j] = NP_CAPACITY_MW * H2_PROD_RATE
+        return s
+    handles["column_scales"] = column_scales
+    return b, objective, handles

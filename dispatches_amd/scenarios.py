@@ -317,6 +317,33 @@ def pem_price_taker_batch(T, B, solver, design_opt=True, inputs="reference"):
     return handles, model
 
 
+def nuclear_price_taker_batch(T, B, solver, market="RT", pem_capex=1200.0):
+    """The nuclear + PEM price-taker enumeration of the reference (nuclear_case/report/price_taker_analysis.py:353-419) as ONE batch:
+    scenario k = (hydrogen price, PEM capacity) point k of the 6 x 10 grid (hydrogen price outermost, as the reference's loops),
+    all sharing the constraint matrix; they differ in the objective (hydrogen price) and in the bounds of the one fixed design column
+    `pem_capacity`.  T hourly periods of the bus-Attlee LMPs (`market`: "RT", "DA" or "Max-DA-RT", :45-113; the reference uses all
+    8784).  Returns (handles, model)."""
+    from .flowsheets.price_taker import NUCLEAR_H2_PRICES, NUCLEAR_PEM_FRACTIONS, NP_CAPACITY_MW, nuclear_price_taker
+    from .workflow.batch_model import ScenarioBatchModel
+    d = load_series("nuclear_price_taker_lmps.npz")
+    lmp = {"RT": d["rt_lmp"], "DA": d["da_lmp"], "Max-DA-RT": np.maximum(d["rt_lmp"], d["da_lmp"])}[market][:T]
+    block, objective, handles = nuclear_price_taker(T, lmp, pem_capex=pem_capex)
+    model = ScenarioBatchModel(block, B, T, indexed=True)
+    model.finalize(objective)
+    grid = [(hp, pc) for hp in NUCLEAR_H2_PRICES for pc in NUCLEAR_PEM_FRACTIONS]
+    fam = [grid[i % len(grid)] for i in range(B)]
+    model.c = np.stack([handles["objective_vector"](model.lp.n, hp) for hp, _ in fam])
+    model.c0 = np.full(B, model.lp.c0)
+    lb, ub, _, _ = block.current_bounds()
+    model.lb, model.ub = np.tile(lb, (B, 1)), np.tile(ub, (B, 1))
+    j = handles["pem_capacity"].index
+    model.lb[:, j] = model.ub[:, j] = [pc * NP_CAPACITY_MW for _, pc in fam]
+    model.lp.col_scale = handles["column_scales"](model.lp.n)
+    model.family, model.lmp = fam, lmp
+    model.solver = solver
+    return handles, model
+
+
 def price_taker_batch(T, B, solver, wind_mw=847.0, throughput="chain", inputs="rts303"):
     """Wind + battery price-taker design LP over T hourly periods (reference wind_battery_optimize) for the first B members
     of PRICE_TAKER_FAMILY: scenarios differ in the objective only.  n = 6 T + 3, m = 6 T + 2: beyond the fused kernels for

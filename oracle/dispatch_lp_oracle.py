@@ -602,6 +602,76 @@ def wind_battery_pem_price_taker(T, cf, lmp, h2_price_per_kg=2.0, design_opt=Tru
     return PreparedLP(lp), info
 
 
+# ---- LP #6: nuclear + PEM price-taker enumeration ------------------------------------------------------------------
+# Reference: dispatches/case_studies/nuclear_case/report/price_taker_analysis.py: build_ne_flowsheet :116-172 (np_power fixed 400 MW,
+# 20 kg of hydrogen per MWh, tank balance, turbine 0.0125 MWh/kg), build_deterministic_model :181-222 (capacity rows, variable hydrogen
+# demand), append_op_costs_revenue :225-254, append_npv_calculations :257-308, annualised objective :318-322,
+# run_exhaustive_enumeration :353-419 (tank and turbine capacities and the first holdup fixed to 0, vom_pem = 0, fom_pem = 3 % of the
+# PEM capex, pem_capacity fixed to a fraction of 400 MW).  NO reference vector exists for this study (its json results are not in the
+# tree): parity unpinned by the reference; the oracle is checked against the closed form below instead (with the tank at zero the hours
+# decouple: the electrolyzer runs at capacity exactly when 20 kg/MWh x hydrogen price beats the LMP).
+def nuclear_price_taker(T, lmp, h2_price, pem_mw, pem_capex=1200.0, h2_demand=8000.0, tax_rate=0.2, plant_life=30, discount_rate=0.08):
+    """Returns (PreparedLP of  min -annualised NPV * 1e-6, info)."""
+    lp = _LP()
+    pem = lp.var("pem_capacity", pem_mw, pem_mw)                                # m.pem_capacity.fix(pc * 400)  (:399)
+    tank = lp.var("tank_capacity", 0.0, 0.0)                                    # :376
+    turb = lp.var("h2_turbine_capacity", 0.0, 0.0)                              # :377
+    inflow = {}
+    prev = None
+    for t in range(T):
+        npw = lp.var(f"np_power{t}", 400.0, 400.0)
+        g = lp.var(f"np_to_grid{t}")
+        e = lp.var(f"np_to_electrolyzer{t}")
+        h = lp.var(f"h2_production{t}")
+        hold = lp.var(f"tank_holdup{t}")
+        hold_prev = lp.var(f"tank_holdup_previous{t}", 0.0, 0.0 if t == 0 else np.inf)      # :375
+        pipe = lp.var(f"h2_to_pipeline{t}", 0.0, h2_demand)                     # :218-219
+        tin = lp.var(f"h2_to_turbine{t}")
+        tp = lp.var(f"h2_turbine_power{t}")
+        net = lp.var(f"net_power{t}")
+        lp.row({npw: 1, g: -1, e: -1}, 0.0, 0.0)                                # :143-146
+        lp.row({h: 1, e: -20.0}, 0.0, 0.0)                                      # :149-152
+        lp.row({hold: 1, hold_prev: -1, h: -1, pipe: 1, tin: 1}, 0.0, 0.0)      # :154-157
+        lp.row({tp: 1, tin: -0.0125}, 0.0, 0.0)                                 # :164-167
+        lp.row({net: 1, g: -1, tp: -1}, 0.0, 0.0)                               # :169-171
+        if prev is not None:
+            lp.row({hold_prev: 1, prev: -1}, 0.0, 0.0)                          # linking pair (:175-178)
+        lp.row({e: 1, pem: -1}, -np.inf, 0.0)                                   # :200-202
+        lp.row({hold: 1, tank: -1}, -np.inf, 0.0)                               # :204-206
+        lp.row({tp: 1, turb: -1}, -np.inf, 0.0)                                 # :208-210
+        inflow[net] = lmp[t]                                                    # :243
+        inflow[pipe] = h2_price                                                 # :250
+        inflow[tp] = inflow.get(tp, 0.0) - 4.25                                 # vom: turbine 4.25, npp 2.3, pem 0 (:239-241, :362)
+        inflow[npw] = -2.3
+        prev = hold
+    cf = (1 - (1 + discount_rate) ** (-plant_life)) / discount_rate
+    capex = {pem: pem_capex * 1000, tank: 29 * 33.3, turb: 947 * 1000}          # :274-276
+    fom = {pem: 1000 * 0.03 * pem_capex, turb: 1000 * 7.0}                     # :277-278, :395
+    fom_const = 120 * 1000 * 400                                                # :285
+    # net_profit = dep + (1 - tax)(inflow - fom - dep),  dep = capex / life;  objective = net_profit - capex / cf
+    npv = {j: (1 - tax_rate) * v for j, v in inflow.items()}
+    for j, cx in capex.items():
+        npv[j] = npv.get(j, 0.0) + cx / plant_life * tax_rate - cx / cf - (1 - tax_rate) * fom.get(j, 0.0)
+    lp.add_cost((npv, -(1 - tax_rate) * fom_const), -1e-6)
+    return PreparedLP(lp), dict(npv=(npv, -(1 - tax_rate) * fom_const), pem=pem)
+
+
+def nuclear_price_taker_closed_form(lmp, h2_price, pem_mw, pem_capex=1200.0, tax_rate=0.2, plant_life=30, discount_rate=0.08):
+    """Annualised NPV [$] of one enumeration point without any LP: with no tank the hours decouple, and hour t sends pem_mw to the
+    electrolyzer iff 20 h2_price > lmp_t (the 8000 kg/h demand cap never binds for pem_mw <= 400)."""
+    lmp = np.asarray(lmp, float)
+    e = np.where(H_PER_MWH * h2_price > lmp, pem_mw, 0.0)
+    inflow = np.sum(lmp * (400.0 - e) + h2_price * H_PER_MWH * e) - 2.3 * 400.0 * len(lmp)
+    cf = (1 - (1 + discount_rate) ** (-plant_life)) / discount_rate
+    capex = pem_capex * 1000 * pem_mw
+    fom = 1000 * 0.03 * pem_capex * pem_mw + 120 * 1000 * 400
+    dep = capex / plant_life
+    return dep + (1 - tax_rate) * (inflow - fom - dep) - capex / cf
+
+
+H_PER_MWH = 20.0
+
+
 # ---- QP variant: quadratic ramp cost on the delivered power (BASELINE config 5; OUR extension, no reference formulation) ---
 # No QP SOLVER in this container reaches the 1e-6 bar on these degenerate problems (HiGHS' active-set QP cycles for millions
 # of iterations on the first objective plateau; a textbook Mehrotra interior-point restatement stalled 1e-5 from the LP

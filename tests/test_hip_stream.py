@@ -139,6 +139,37 @@ def test_reference_price_taker_goldens_on_the_gpu(golden):
 
 
 @gpu
+def test_nuclear_price_taker_enumeration_on_the_gpu():
+    """The reference's 60-point nuclear + PEM enumeration (price_taker_analysis.py:353-419) at its own horizon, 366 x 24 hourly
+    periods (n = 70 275), as ONE streaming batch sharing the constraint matrix - per-scenario objective AND per-scenario bounds
+    (the fixed pem_capacity column), three design columns that touch every period - against the closed form (no tank: the hours
+    decouple) and, for three points, the oracle's HiGHS solve of a shorter horizon through the same code path."""
+    from dispatches_amd import scenarios
+    from dispatches_amd.hip_solver import HipPdlpSolver
+    from oracle import dispatch_lp_oracle as orc
+    solver = HipPdlpSolver(device=0, check_every=64, max_iter=400_000)
+    T, B = 8784, 60
+    handles, model = scenarios.nuclear_price_taker_batch(T, B, solver)
+    solver.solve(model, tee=True)
+    assert solver.last_stats.streaming == 1 and (model.status == 0).all(), (np.bincount(model.status), model.iterations)
+    closed = np.array([-1e-6 * orc.nuclear_price_taker_closed_form(model.lmp, hp, pc * 400.0) for hp, pc in model.family])
+    err = np.abs(model.objective - closed) / np.maximum(1.0, np.abs(closed))
+    assert err.max() < 1e-6, (err.max(), model.iterations)
+    # n (incl. 3 design columns) and the fused form's algorithmic bytes with per-scenario bounds: 6 n + 5 m doubles
+    n, m = model.lp.n, model.lp.m
+    assert n == 8 * T + 3 and solver.last_stats.stream_bytes_per_iteration == 8 * (6 * n + 5 * m)
+    # the same path at a horizon the oracle solves in seconds
+    T2, B2 = 720, 12
+    handles, small = scenarios.nuclear_price_taker_batch(T2, B2, solver)
+    solver.solve(small)
+    assert (small.status == 0).all()
+    for k in (0, 5, 11):
+        hp, pc = small.family[k]
+        ref = orc.nuclear_price_taker(T2, small.lmp, hp, pc * 400.0)[0].solve(tight=True)[1]
+        assert abs(small.objective[k] - ref) <= 1e-6 * max(1.0, abs(ref))
+
+
+@gpu
 def test_streaming_edge_cases():
     """B = 1, an invalid scenario (crossed bounds), the iteration limit."""
     from dispatches_amd import scenarios

@@ -54,3 +54,29 @@ def test_wind_battery_pem_price_taker_reproduces_the_reference_goldens(golden, d
     fam.solver.solve(fam)
     pem = fam.x[:, handles["pem_system_capacity"].index]
     assert (np.diff(pem[:4]) >= -1e-6).all() and (pem[4:8] >= pem[:4] - 1e-6).all()
+
+
+def test_nuclear_price_taker_enumeration_product_oracle_and_closed_form():
+    """The 60-point (hydrogen price x PEM capacity) enumeration of the nuclear case study (price_taker_analysis.py:353-419) as one
+    batch sharing its matrix: the product's flattened LP (HiGHS test solver), the oracle's un-reduced restatement and the closed form
+    (no tank: the hours decouple) agree on every point.  No reference vector exists for this study."""
+    from dispatches_amd.flowsheets.price_taker import NUCLEAR_H2_PRICES, NUCLEAR_PEM_FRACTIONS
+    from oracle import dispatch_lp_oracle as orc
+    T, B = 240, 60
+    handles, model = scenarios.nuclear_price_taker_batch(T, B, HighsTestSolver())
+    assert len(model.family) == 60 and model.family[0] == (NUCLEAR_H2_PRICES[0], NUCLEAR_PEM_FRACTIONS[0]) and model.family[10][0] == NUCLEAR_H2_PRICES[1]
+    assert np.ptp(model.lb[:, handles["pem_capacity"].index]) > 0 and (np.delete(model.lb, handles["pem_capacity"].index, 1) == np.delete(model.lb, handles["pem_capacity"].index, 1)[0]).all()
+    model.solver.solve(model)
+    closed = np.array([-1e-6 * orc.nuclear_price_taker_closed_form(model.lmp, hp, pc * 400.0) for hp, pc in model.family])
+    assert np.abs(model.objective - closed).max() < 1e-9 * np.abs(closed).max()
+    for k in (0, 17, 59):
+        hp, pc = model.family[k]
+        P, info = orc.nuclear_price_taker(T, model.lmp, hp, pc * 400.0)
+        x, obj = P.solve(tight=True)
+        assert obj == pytest.approx(model.objective[k], rel=1e-10)
+    # electrolyzer on exactly when 20 kg/MWh x price beats the LMP
+    k = 35
+    hp, pc = model.family[k]
+    e = model.x[k][[p["np_to_electrolyzer"].index for p in handles["periods"]]]
+    on = 20.0 * hp > model.lmp
+    assert np.allclose(e[on], pc * 400.0, atol=1e-6) and np.allclose(e[~on & (20.0 * hp < model.lmp)], 0.0, atol=1e-6)

@@ -15,6 +15,8 @@ Writes (data only, no reference source code):
         <- .../renewables_case/data/44.21_-101.94_windtoolkit_2012_60min_80m.srw (column 3, m/s at 80 m; what PySAM's
         SRW_to_wind_data hands to tests/test_RE_flowsheet.py:33-34) and 8736 day-ahead LMPs
         <- .../renewables_case/tests/rts_results_all_prices.npy (second array, test_RE_flowsheet.py:25-27)
+  dispatches_amd/data/nuclear_price_taker_lmps.npz  8784 hourly LMPs (real-time and day-ahead) at bus Attlee
+        <- .../nuclear_case/report/rts_gmlc_15_500.csv (price_taker_analysis.py:45-113)
   tests/golden/reference_vectors.json    the known-answer vectors held by the reference's own tests and
         notebooks for this path, with file:line provenance.
 
@@ -71,6 +73,12 @@ def main():
     speeds = np.array([float(line.split(",")[2]) for line in srw[5:5 + 8760]])
     assert da_lmp.shape == (8736,) and speeds.shape == (8760,)
     np.savez_compressed(os.path.join(out, "price_taker_inputs.npz"), wind_speed_m_s=speeds, da_lmp=np.asarray(da_lmp, np.float64))
+
+    # ---- LMPs of the nuclear price-taker analysis (nuclear_case/report/price_taker_analysis.py:45-113) -----
+    nd = pd.read_csv(REF + "nuclear_case/report/rts_gmlc_15_500.csv")
+    assert len(nd) == 8784
+    np.savez_compressed(os.path.join(out, "nuclear_price_taker_lmps.npz"), rt_lmp=nd["LMP"].to_numpy(np.float64),
+                        da_lmp=nd["LMP DA"].to_numpy(np.float64))
 
     # ---- known-answer vectors of the reference's own tests / committed notebook outputs --------------
     golden = {
