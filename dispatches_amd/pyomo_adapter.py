@@ -73,6 +73,11 @@ def factor_quadratic_form(quad: Dict, n: int, tol: float = 1e-12):
     return rows
 
 
+class MatrixChanged(ValueError):
+    """refresh() found a different constraint matrix than flatten() saw (a variable was fixed / unfixed, a mutable Param that
+    multiplies a variable changed, the quadratic objective changed): the flattened LP must be rebuilt."""
+
+
 def _pyomo():
     """Import the pieces of Pyomo this adapter uses (only when no stand-ins are injected)."""
     from pyomo.core.base.constraint import Constraint
@@ -160,6 +165,8 @@ class PyomoLP:
                 if const < lo - tol or const > hi + tol:
                     raise ValueError(f"constraint {con.name} is infeasible once the fixed variables are substituted")
                 continue
+            if lo > hi:
+                raise ValueError(f"constraint {con.name} has crossed bounds ({lo} > {hi})")
             for j in sorted(coefs):
                 indices.append(j)
                 data.append(coefs[j])
@@ -232,7 +239,7 @@ class PyomoLP:
         fixed variables and the matrix must be what flatten() saw."""
         now_free = [v for v in self.block.component_data_objects(self._Var, active=True, descend_into=True) if not v.fixed]
         if len(now_free) != len(self._vars) or any(a is not b for a, b in zip(now_free, self._vars)):
-            raise ValueError("the set of fixed variables changed since flatten(): flatten again (new constraint matrix)")
+            raise MatrixChanged("the set of fixed variables changed since flatten(): flatten again (new constraint matrix)")
         lp = self.lp
         indptr, indices, data = self._pattern
         rlo, rhi = np.empty(lp.m), np.empty(lp.m)
@@ -242,8 +249,8 @@ class PyomoLP:
             a, b = indptr[i], indptr[i + 1]
             if len(cols) != b - a or any(cj != ij for cj, ij in zip(cols, indices[a:b])) or \
                     any(abs(coefs[cj] - dv) > 1e-12 * max(1.0, abs(dv)) for cj, dv in zip(cols, data[a:b])):
-                raise ValueError(f"constraint {con.name} changed its coefficients since flatten(): a mutable Param multiplies a "
-                                 "variable there; the batched solver shares ONE matrix across solves - flatten again")
+                raise MatrixChanged(f"constraint {con.name} changed its coefficients since flatten(): a mutable Param multiplies a "
+                                    "variable there; the batched solver shares ONE matrix across solves - flatten again")
             rlo[i] = lo - const if np.isfinite(lo) else -INF
             rhi[i] = hi - const if np.isfinite(hi) else INF
         rlo[len(self._rows):] = 0.0
@@ -251,8 +258,8 @@ class PyomoLP:
         quad_was = dict(self._quad)
         lp.c, lp.c0 = self._objective_vector(lp.n)
         if set(quad_was) != set(self._quad) or any(abs(quad_was[k] - q) > 1e-12 * max(1.0, abs(q)) for k, q in self._quad.items()):
-            raise ValueError("the quadratic part of the objective changed since flatten(): its factors are rows of the shared "
-                             "matrix - flatten again")
+            raise MatrixChanged("the quadratic part of the objective changed since flatten(): its factors are rows of the shared "
+                                "matrix - flatten again")
         lp.lb, lp.ub = self._bounds()
         lp.rlo, lp.rhi = rlo, rhi
         return lp
@@ -341,6 +348,7 @@ class HipPyomoSolver:
         self._device, self._solver_options = device, solver_options
         self._ctypes, self._repn, self._hints = ctypes, generate_standard_repn, solver_hints
         self._batches: Dict[tuple, PyomoScenarioBatch] = {}
+        self.reflattened = 0             # how many times a structural change between two solves forced a new flatten
 
     def available(self, exception_flag=False):
         b = self._get_backend()
@@ -359,7 +367,15 @@ class HipPyomoSolver:
         if batch is None:
             batch = self._batches[key] = PyomoScenarioBatch(blocks, objectives, self._ctypes, self._repn, self._hints)
         else:
-            batch.refresh()
+            try:
+                batch.refresh()
+            except MatrixChanged:
+                # the model changed structurally between two solves (the reference's model objects do this legitimately: e.g.
+                # transform_design_model_to_operation_model fixes design variables after a first solve, a Var is unfixed for a
+                # sweep): what a Pyomo solver object does on every call - write the model again - happens here only now.  The
+                # old device handle goes with the old batch object.
+                self.reflattened += 1
+                batch = self._batches[key] = PyomoScenarioBatch(blocks, objectives, self._ctypes, self._repn, self._hints)
         results = self._get_backend().solve(batch, tee=tee)
         self.last_batch = batch
         return results

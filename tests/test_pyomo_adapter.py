@@ -19,17 +19,31 @@ class Param:
 class Expr:
     """Linear expression sum coef * Var + const; coefficients may be Params (mutable) or products of them."""
 
-    def __init__(self, terms=None, const=0.0):
+    def __init__(self, terms=None, const=0.0, subs=None):
         self.terms = list(terms or [])          # (coef or Param or callable, var)
         self.const = const
+        self.subs = list(subs or [])            # (scale, named sub-expression): resolved when the expression is READ (Repn)
 
     @staticmethod
     def _val(c):
         return c.value if isinstance(c, Param) else (c() if callable(c) else float(c))
 
     def __add__(self, o):
+        if getattr(o, "is_named", False):
+            return Expr(self.terms, self.const, self.subs + [(1.0, o)])
+        if getattr(self, "is_named", False):
+            return Expr(subs=[(1.0, self)]) + o
         o = o if isinstance(o, Expr) else (Expr([(1.0, o)]) if isinstance(o, VarData) else Expr(const=o))
-        return Expr(self.terms + o.terms, _sum(self.const, o.const))
+        return Expr(self.terms + o.terms, _sum(self.const, o.const), self.subs + o.subs)
+
+    def flat(self):
+        """(terms, const) with the named sub-expressions read through (recursively) NOW."""
+        terms, const = list(self.terms), self.const
+        for scale, sub in self.subs:
+            t2, c2 = sub.inner.flat()
+            terms += [(_mul(scale, c), v) for c, v in t2]
+            const = _sum(const, _mul(scale, c2))
+        return terms, const
 
     __radd__ = __add__
 
@@ -37,7 +51,7 @@ class Expr:
         return self + (-1.0) * (o if isinstance(o, Expr) else (Expr([(1.0, o)]) if isinstance(o, VarData) else Expr(const=o)))
 
     def __rmul__(self, s):
-        return Expr([(_mul(s, c), v) for c, v in self.terms], _mul(s, self.const))
+        return Expr([(_mul(s, c), v) for c, v in self.terms], _mul(s, self.const), [(_mul(s, k), e) for k, e in self.subs])
 
     __mul__ = __rmul__
 
@@ -122,11 +136,12 @@ class Repn:
             self.quadratic_coefs = [q for q, _, _ in expr.quad]
             expr = expr.lin
         acc = {}
-        for c, v in expr.terms:
+        terms, const = expr.flat()
+        for c, v in terms:
             acc.setdefault(id(v), [v, 0.0])[1] += Expr._val(c)
         self.linear_vars = [v for v, _ in acc.values()]
         self.linear_coefs = [a for _, a in acc.values()]
-        self.constant = Expr._val(expr.const)
+        self.constant = Expr._val(const)
 
     def is_linear(self):
         return not self.quadratic_vars
@@ -388,3 +403,220 @@ def test_solver_object_solves_scenario_blocks_as_one_batch(rts309):
     odd.cons[2].body = odd.cons[2].body + Expr([(0.5, odd.vars[7])])
     with pytest.raises(ValueError, match="does not flatten to the matrix of block 0"):
         HipPyomoSolver(backend=HighsTestSolver(), ctypes=CTYPES, generate_standard_repn=generate_standard_repn).solve([blocks[0], odd])
+
+
+# ---- behaviours of real Pyomo models the first stand-ins did not imitate (round-2 review) ------------------------------------
+class NamedExpr(Expr):
+    """A named `Expression` component (indexed ones are dicts of these): a node that holds an inner expression which may be
+    REPLACED between solves (`.set_value`), as IDAES flowsheets do for cost / power expressions.  It stays a NODE of the
+    expressions that use it and is read through when they are read (Expr.flat), as generate_standard_repn does."""
+    is_named = True
+
+    def __init__(self, inner):
+        super().__init__()
+        self.inner = inner
+
+    def set_value(self, inner):
+        self.inner = inner
+
+    def flat(self):
+        return self.inner.flat()
+
+
+def test_structural_changes_between_solves_reflatten_instead_of_failing(rts309):
+    """What the reference's model objects legitimately do between two `solver.solve(model)` calls - fix a design variable after a
+    first solve, unfix it again for a sweep, replace a named Expression - changes the MATRIX.  A Pyomo solver object writes the
+    model again on every call; HipPyomoSolver notices (refresh raises MatrixChanged) and flattens again, once."""
+    from _highs_solver import HighsTestSolver
+    from oracle import dispatch_lp_oracle as orc
+    cf, D = list(rts309["rt_cf"][:4]), [0.0, 1.5, 15.0, 24.5]
+    blk, cfp, disp, soc_init = build_tracking_model(cf, D)
+    solver = HipPyomoSolver(backend=HighsTestSolver(), ctypes=CTYPES, generate_standard_repn=generate_standard_repn)
+    solver.solve(blk)
+    f0, n0 = solver.last_batch.objective[0], solver.last_batch.lp.n
+    assert f0 == pytest.approx(orc.wind_battery_track(4, cf, D)[0].solve()[1], rel=1e-9) and solver.reflattened == 0
+    # (1) Var.fixed toggled: the initial state of charge becomes a decision (unfix), bounded to [0, 5000]
+    soc_init.fixed = False
+    soc_init.lb, soc_init.ub = 0.0, 5000.0
+    solver.solve(blk)
+    assert solver.reflattened == 1 and solver.last_batch.lp.n == n0 + 1
+    f1 = solver.last_batch.objective[0]
+    assert f1 <= f0 + 1e-9                                            # one more degree of freedom
+    assert soc_init.value is not None and 0.0 <= soc_init.value <= 5000.0 + 1e-6
+    # ... and fixed again at the value it took: same optimum, matrix back to the first shape
+    soc_init.fix(soc_init.value)
+    solver.solve(blk)
+    assert solver.reflattened == 2 and solver.last_batch.lp.n == n0
+    assert solver.last_batch.objective[0] == pytest.approx(f1, rel=1e-9)
+    # (2) a second solve WITHOUT structural change refreshes in place (no third flatten)
+    disp[2].value = 10.0
+    solver.solve(blk)
+    assert solver.reflattened == 2
+    assert solver.last_batch.objective[0] == pytest.approx(orc.wind_battery_track(4, cf, [0.0, 1.5, 10.0, 24.5], soc0=soc_init.value)[0].solve()[1], rel=1e-9)
+
+
+def test_named_and_indexed_expressions_are_read_through(rts309):
+    """Named (indexed) Expressions inside constraint bodies and the objective - P_T[t], tot_cost[t] of the reference's model objects
+    (wind_battery_double_loop.py:169-177) - are resolved at flatten AND at refresh: replacing an expression's CONSTANT part is a
+    right-hand-side change, replacing its variable part is a new matrix."""
+    cf, D = list(rts309["rt_cf"][:4]), [0.0, 1.5, 15.0, 24.5]
+    blk, cfp, disp, soc_init = build_tracking_model(cf, D)
+    G = [v for v in blk.vars if v.name.startswith("grid[")]
+    O = [v for v in blk.vars if v.name.startswith("batt_out[")]
+    un = [v for v in blk.vars if v.name.startswith("under[")]
+    ov = [v for v in blk.vars if v.name.startswith("over[")]
+    P_T = {t: NamedExpr(1e-3 * G[t] + 1e-3 * O[t]) for t in range(4)}                 # indexed Expression
+    for t in range(4):
+        k = [i for i, c in enumerate(blk.cons) if c.name == f"track[{t}]"][0]
+        blk.cons[k] = ConData(f"track[{t}]", P_T[t] + un[t] - ov[t] - Expr(const=lambda d=disp[t]: d.value), 0.0, 0.0)
+    ref = PyomoLP(build_tracking_model(cf, D)[0], ctypes=CTYPES, generate_standard_repn=generate_standard_repn).lp
+    P = PyomoLP(blk, ctypes=CTYPES, generate_standard_repn=generate_standard_repn)
+    assert np.array_equal(P.lp.indptr, ref.indptr) and np.array_equal(P.lp.indices, ref.indices) and np.allclose(P.lp.data, ref.data)
+    assert np.allclose(P.lp.rlo, ref.rlo) and np.allclose(P.lp.rhi, ref.rhi)
+    # constant part replaced (an auxiliary load of 2 MW served first): rows move, matrix stays
+    P_T[1].set_value(1e-3 * G[1] + 1e-3 * O[1] - Expr(const=2.0))
+    P.refresh()
+    k1 = [i for i, nm in enumerate(P.lp.row_names) if nm == "track[1]"][0]
+    assert P.lp.rlo[k1] == pytest.approx(ref.rlo[k1] + 2.0) and P.lp.rhi[k1] == pytest.approx(ref.rhi[k1] + 2.0)
+    # variable part replaced: a new matrix
+    P_T[2].set_value(2e-3 * G[2] + 1e-3 * O[2])
+    from dispatches_amd.pyomo_adapter import MatrixChanged
+    with pytest.raises(MatrixChanged, match="changed its coefficients"):
+        P.refresh()
+
+
+def test_free_one_sided_and_ranged_rows():
+    """Constraint bounds as Pyomo holds them: None on either side, both (ranged), both None (a row whose bounds were relaxed);
+    crossed bounds are refused at flatten."""
+    b = Block()
+    x, y, z = VarData("x", 0.0, 10.0), VarData("y", 0.0, 10.0), VarData("z", None, None)
+    b.vars += [x, y, z]
+    b.cons += [ConData("ranged", x + y, 2.0, 6.0), ConData("upper_only", x - y, None, 1.0), ConData("lower_only", z - x, 0.5, None),
+               ConData("free", x + y + z, None, None)]
+    b.objs.append(ObjData(1.0 * x + 2.0 * y + 1.0 * z, sense=1))
+    P = PyomoLP(b, ctypes=CTYPES, generate_standard_repn=generate_standard_repn)
+    lp = P.lp
+    assert lp.m == 4 and list(lp.rlo) == [2.0, -np.inf, 0.5, -np.inf] and list(lp.rhi) == [6.0, 1.0, np.inf, np.inf]
+    assert list(lp.lb) == [0.0, 0.0, -np.inf] and list(lp.ub) == [10.0, 10.0, np.inf]
+    xs, f = _solve(lp)
+    assert f == pytest.approx(4.5)                        # x + y = 2, z = x + 0.5: cost 2 x + 2 y + 0.5 (x and y tie)
+    assert xs[0] + xs[1] == pytest.approx(2.0) and xs[2] == pytest.approx(xs[0] + 0.5) and xs[0] - xs[1] <= 1.0 + 1e-9
+    b.cons[0] = ConData("ranged", x + y, 6.0, 2.0)
+    with pytest.raises(ValueError, match="crossed bounds"):
+        PyomoLP(b, ctypes=CTYPES, generate_standard_repn=generate_standard_repn)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_linear_block_and_pyomo_walk_flatten_to_the_same_lp(seed):
+    """Property test: a random sparse model written twice - on the product's LinearBlock and as stand-in Pyomo objects (some
+    variables fixed, coefficients held as mutable Params, bounds None / numbers / callables) - flattens to the same standard
+    form: same CSR, bounds, objective; fixed variables folded into the same right-hand sides."""
+    from dispatches_amd.lp import LinearBlock, LinExpr
+    rng = np.random.default_rng(seed)
+    nv, nc = int(rng.integers(6, 14)), int(rng.integers(5, 12))
+    lb = np.where(rng.random(nv) < 0.3, -np.inf, np.round(rng.normal(0, 2, nv), 2))
+    ub = np.where(rng.random(nv) < 0.3, np.inf, lb + np.round(rng.random(nv) * 5 + 0.1, 2))
+    ub = np.where(np.isfinite(lb), ub, np.where(rng.random(nv) < 0.5, np.inf, np.round(rng.normal(3, 1, nv), 2)))
+    fixed = rng.random(nv) < 0.25
+    fixval = np.round(rng.normal(1, 1, nv), 2)
+    cost = np.round(rng.normal(0, 1, nv), 3)
+    rows = []
+    for i in range(nc):
+        cols = rng.choice(nv, size=int(rng.integers(1, 5)), replace=False)
+        coef = np.round(rng.normal(0, 2, len(cols)), 3)
+        coef[coef == 0] = 1.0
+        kind = rng.integers(0, 4)
+        lo = -np.inf if kind == 1 else float(np.round(rng.normal(-1, 1), 2))
+        hi = np.inf if kind == 2 else (lo if kind == 3 else (lo if np.isfinite(lo) else 0.0) + float(np.round(rng.random() * 4, 2)))
+        rows.append((cols, coef, lo, hi, float(np.round(rng.normal(0, 1), 2))))
+    # --- native
+    B = LinearBlock("rand")
+    free_cols, lv = {}, []
+    for j in range(nv):
+        if fixed[j]:
+            lv.append(None)
+        else:
+            v = B.var(f"v[{j}]", float(lb[j]), float(ub[j]))
+            free_cols[j] = v
+            lv.append(v)
+    obj = LinExpr()
+    for j in range(nv):
+        obj = obj + (lv[j] * float(cost[j]) if lv[j] is not None else float(cost[j] * fixval[j]))
+    kept = []
+    for i, (cols, coef, lo, hi, const) in enumerate(rows):
+        e = LinExpr(None, const)
+        for j, a in zip(cols, coef):
+            e = e + (lv[j] * float(a) if lv[j] is not None else float(a * fixval[j]))
+        if e.coef:
+            B.constraint(f"r[{i}]", e, lo, hi)
+            kept.append(i)
+    native = B.flatten(obj, presolve=False)
+    # --- "Pyomo"
+    pb = Block()
+    pv = []
+    for j in range(nv):
+        mk = lambda val: (None if not np.isfinite(val) else (float(val) if rng.random() < 0.5 else (lambda val=val: float(val))))
+        v = VarData(f"v[{j}]", mk(lb[j]), mk(ub[j]))
+        if fixed[j]:
+            v.fix(fixval[j])
+        pv.append(v)
+    pb.vars += pv
+    pobj = Expr()
+    for j in range(nv):
+        pobj = pobj + Param(cost[j]) * pv[j]
+    for i, (cols, coef, lo, hi, const) in enumerate(rows):
+        e = Expr(const=const)
+        for j, a in zip(cols, coef):
+            e = e + (Param(a) if rng.random() < 0.5 else float(a)) * pv[j]
+        pb.cons.append(ConData(f"r[{i}]", e, None if not np.isfinite(lo) else lo, None if not np.isfinite(hi) else hi))
+    pb.objs.append(ObjData(pobj, sense=1))
+    try:
+        walked = PyomoLP(pb, ctypes=CTYPES, generate_standard_repn=generate_standard_repn).lp
+    except ValueError as exc:                      # a row of fixed variables only that its bounds exclude: the native side has no such row
+        assert "infeasible once the fixed variables are substituted" in str(exc)
+        return
+    assert walked.n == native.n and walked.m == native.m == len(kept)
+    assert np.array_equal(walked.indptr, native.indptr) and np.array_equal(walked.indices, native.indices)
+    assert np.allclose(walked.data, native.data, rtol=1e-14, atol=0)
+    for a, b_ in ((walked.lb, native.lb), (walked.ub, native.ub), (walked.rlo, native.rlo), (walked.rhi, native.rhi), (walked.c, native.c)):
+        assert np.allclose(a, b_, rtol=1e-12, atol=1e-12, equal_nan=True)
+    assert walked.c0 == pytest.approx(native.c0, abs=1e-12)
+
+
+def test_real_pyomo_model_when_pyomo_is_installed():
+    """Runs only where Pyomo exists (it does not in the build container): the same tracking LP written with real Pyomo components -
+    indexed Var / Param(mutable) / Expression / Constraint - flattens to the LP of the stand-in model and refreshes."""
+    pyo = pytest.importorskip("pyomo.environ")
+    T = 4
+    cf, D = [0.0056, 0.0079, 0.1026, 0.1297], [0.0, 1.5, 15.0, 24.5]
+    m = pyo.ConcreteModel()
+    m.T = pyo.RangeSet(0, T - 1)
+    m.cf = pyo.Param(m.T, initialize=dict(enumerate(cf)), mutable=True)
+    m.dispatch = pyo.Param(m.T, initialize=dict(enumerate(D)), mutable=True)
+    m.cap = pyo.Var(initialize=200e3); m.cap.fix(200e3)
+    m.pw = pyo.Var(initialize=25e3); m.pw.fix(25e3)
+    m.soc_init = pyo.Var(initialize=0.0); m.soc_init.fix(0.0)
+    m.thr_init = pyo.Var(initialize=0.0); m.thr_init.fix(0.0)
+    for nm in ("W", "G", "I", "O", "S", "E", "un", "ov"):
+        setattr(m, nm, pyo.Var(m.T, domain=pyo.NonNegativeReals))
+    m.P_T = pyo.Expression(m.T, rule=lambda m, t: 1e-3 * (m.G[t] + m.O[t]))
+    m.wind_cf = pyo.Constraint(m.T, rule=lambda m, t: m.W[t] <= m.cf[t] * m.cap)
+    m.split = pyo.Constraint(m.T, rule=lambda m, t: m.W[t] == m.G[t] + m.I[t])
+    m.soc = pyo.Constraint(m.T, rule=lambda m, t: m.S[t] == (m.S[t - 1] if t else m.soc_init) + 0.95 * m.I[t] - m.O[t] / 0.95)
+    m.thr = pyo.Constraint(m.T, rule=lambda m, t: m.E[t] == (m.E[t - 1] if t else m.thr_init) + 0.5 * m.I[t] + 0.5 * m.O[t])
+    m.soc_cap = pyo.Constraint(m.T, rule=lambda m, t: m.S[t] + 1e-4 * m.E[t] <= 4 * m.pw)
+    m.pin = pyo.Constraint(m.T, rule=lambda m, t: m.I[t] <= m.pw)
+    m.pout = pyo.Constraint(m.T, rule=lambda m, t: m.O[t] <= m.pw)
+    m.track = pyo.Constraint(m.T, rule=lambda m, t: m.P_T[t] + m.un[t] - m.ov[t] == m.dispatch[t])
+    m.obj = pyo.Objective(expr=sum((41.78 / 8760) * m.cap + 1e-4 * 29.545625 * (m.E[t] - (m.E[t - 1] if t else m.thr_init))
+                                   + 1e3 * 1e-3 * (m.cf[t] * m.cap - m.W[t]) + 1e4 * (m.un[t] + m.ov[t]) for t in m.T))
+    P = PyomoLP(m)
+    assert P.lp.n == 8 * T and P.lp.m == 8 * T
+    x, f = _solve(P.lp)
+    stand_in = PyomoLP(build_tracking_model(cf, D)[0], ctypes=CTYPES, generate_standard_repn=generate_standard_repn).lp
+    assert f == pytest.approx(_solve(stand_in)[1], rel=1e-9)
+    m.dispatch[2] = 10.0
+    m.soc_init.fix(1234.57)
+    P.refresh()
+    blk2, *_ = build_tracking_model(cf, [0.0, 1.5, 10.0, 24.5], soc0=1234.57)
+    assert _solve(P.lp)[1] == pytest.approx(_solve(PyomoLP(blk2, ctypes=CTYPES, generate_standard_repn=generate_standard_repn).lp)[1], rel=1e-9)
