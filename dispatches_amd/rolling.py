@@ -151,6 +151,8 @@ class BatchedWindBatteryDoubleLoop:
         self.tr = _DeviceModel(tr_model, B, dev, device, hints=getattr(tr_model, "solver_hints", None), lp_backend=lp_backend)
         idx = lambda cols: torch.as_tensor(np.asarray(cols, np.int64), device=dev)
         self.da.pda_cols, self.rt.pda_cols = idx(da_model.pda_cols), idx(rt_model.pda_cols)
+        # column handles of the hourly models' periods (tests map device solutions into the oracle's variables through these)
+        self.rt_periods, self.tr_periods = rt_model.block.windBattery["periods"], tr_model.block.windBattery["periods"]
         # OPTIONAL rolling warm start of the day-ahead LP: day d + 1's 48-h problem is day d's shifted by 24 h, so period t
         # starts from yesterday's period t + 24 (the last 24 periods keep their own old values); x, y and the primal weight
         # stay on the device (dsp_batch::x0 / y0 / primal_weight).  OFF by default - measured (1024 plants, 4 days): 15 k

@@ -97,3 +97,14 @@ def test_fused_update_kernel_is_bit_identical_to_the_tensor_operations():
         res[fused]["tr_rlo"] = loop.tr.rlo.cpu().numpy().copy()
     for k in res[False]:
         assert np.array_equal(res[False][k], res[True][k]), k
+
+
+@gpu
+def test_rolling_hours_are_optimal_for_the_oracles_lps():
+    """Oracle-anchored check of the device-resident loop (tests/_rolling_oracle.py): every hourly solution of the HIP loop, mapped
+    into the oracle's variables, is feasible and optimal for the oracle's own real-time bidding / tracking LP of the loop's state."""
+    from dispatches_amd.rolling import BatchedWindBatteryDoubleLoop
+    from tests._rolling_oracle import check_rolling_hours_against_the_oracle
+    loop = BatchedWindBatteryDoubleLoop(12, device=0, stride=17, use_graphs=False)
+    check_rolling_hours_against_the_oracle(loop, hours=8, stride=17)
+    assert int(loop.uncertified.item()) == 0

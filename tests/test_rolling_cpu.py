@@ -115,3 +115,13 @@ def test_double_loop_shards_world2_gloo():
         flat = np.concatenate([everything[r, :b - a, 0] for r, (a, b) in
                                enumerate([(0, 2), (2, 3)])])
         np.testing.assert_allclose(flat, ref, rtol=1e-9, atol=1e-6)
+
+
+def test_rolling_hours_are_optimal_for_the_oracles_lps_cpu_backend():
+    """The same oracle-anchored check as the GPU tier (tests/_rolling_oracle.py) with the HiGHS stand-in as the loop's LP backend:
+    pins the loop's window / state / objective hand-off to the ORACLE's formulation of the hourly LPs, not to the product's."""
+    from dispatches_amd.rolling import BatchedWindBatteryDoubleLoop
+    from tests._highs_solver import HighsTensorLP
+    from tests._rolling_oracle import check_rolling_hours_against_the_oracle
+    loop = BatchedWindBatteryDoubleLoop(4, stride=17, lp_backend=HighsTensorLP)
+    check_rolling_hours_against_the_oracle(loop, hours=5, stride=17)
