@@ -185,22 +185,32 @@ def bench_double_loop(args, rank, local_rank, world, dev):
 
 
 def bench_price_taker(args, rank, local_rank, world, dev):
-    """The HBM-bound workload of the path: the reference's long-horizon price-taker design LP (wind_battery_optimize, T =
-    --horizon hourly periods, n = m = 6 T) for --batch scenarios of the (battery cost x LMP) family per GPU on the
-    HBM-resident streaming PDLP.  One step = one check period (check_every = 64 PDHG iterations) of the whole batch; the
-    solve is capped at steps x 64 iterations (year-long horizons do not converge within that: this measures the
-    iteration RATE).  roofline.bound = "hbm": algorithmic bytes (8 n + 6 m doubles per scenario-iteration) /
-    HIP-event time of the solve on its stream."""
+    """The HBM-bound workloads of the path: the reference's long-horizon price-taker design LPs on the HBM-resident streaming PDLP,
+    --batch scenarios per GPU sharing ONE constraint matrix:
+        price_taker          wind + battery, wind_battery_optimize (T = --horizon hourly periods, default 8736; n = m = 6 T)
+        pem_price_taker      wind + battery + PEM, wind_battery_pem_optimize (n = 7 T)
+        nuclear_price_taker  the 60-point (hydrogen price x PEM capacity) enumeration of the nuclear case (n = 8 T; per-scenario bounds)
+    One step = one check period (64 PDHG iterations) of the whole batch; the solve is capped at steps x 64 iterations (this measures
+    the iteration RATE; convergence of the year-long horizons is a test: tests/test_hip_stream.py).  roofline.bound = "hbm":
+    algorithmic bytes per scenario-iteration of the form that ran (dsp_stats::stream_bytes_per_iteration: fused one-launch iteration
+    4 n + 3 m doubles with shared bounds, 6 n + 5 m with per-scenario bounds; two-launch form 8 n + 6 m) / HIP-event time of the
+    solve on its stream; `traffic` = FETCH_SIZE x 2 + WRITE_SIZE of the iteration kernel per launch from the newest committed
+    rocprofv3 PMC summary that holds it (profiles/*_stream_pmc_summary.csv)."""
     import torch
     import torch.distributed as dist
     from dispatches_amd import scenarios
     from dispatches_amd.hip_solver import HipPdlpSolver
-    T, B, ce = args.horizon, (args.batch if args.batch != 4096 else 64), 64
+    default_T = {"price_taker": 8736, "pem_price_taker": 8736, "nuclear_price_taker": 8784}[args.workload]
+    T = args.horizon if args.horizon != 8736 or args.workload != "nuclear_price_taker" else default_T
+    B, ce = (args.batch if args.batch != 4096 else (60 if args.workload == "nuclear_price_taker" else 64)), 64
+    build = {"price_taker": lambda s: scenarios.price_taker_batch(T, B, s)[1],
+             "pem_price_taker": lambda s: scenarios.pem_price_taker_batch(T, B, s, inputs="rts303")[1],
+             "nuclear_price_taker": lambda s: scenarios.nuclear_price_taker_batch(T, B, s)[1]}[args.workload]
 
     def run(periods):
-        solver = HipPdlpSolver(device=local_rank, check_every=ce, max_iter=periods * ce)
+        solver = HipPdlpSolver(device=local_rank, check_every=ce, max_iter=periods * ce, recertify=0)
         if not hasattr(run, "model"):
-            run.model = scenarios.price_taker_batch(T, B, solver)[1]
+            run.model = build(solver)
         run.model.solve_handle = None          # the handle carries its options (max_iter): a fresh one per run
         solver.solve(run.model)
         return solver.last_stats, run.model
@@ -215,24 +225,38 @@ def bench_price_taker(args, rank, local_rank, world, dev):
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     if rank == 0:
+        import csv
+        import glob
         k_s = float(t[1].item())
         its = int(model.iterations.sum())
         byt = float(st.stream_bytes_per_iteration) * its
+        n, m = model.lp.n, model.lp.m
+        traffic = src = None
+        for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_stream_pmc_summary*.csv")), key=os.path.basename, reverse=True):
+            c = {}
+            for row in csv.DictReader(open(f)):
+                if "k_fused" in row["kernel"]:
+                    c[row["counter"]] = float(row["mean_counter_value"])
+            if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+                traffic, src = (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0, os.path.basename(f)
+                break
         print(json.dumps({
-            "metric": f"PDHG scenario-iterations/sec, wind+battery price-taker design LP, T={T} (n={model.lp.n}, m={model.lp.m}), batch={B}",
+            "metric": f"PDHG scenario-iterations/sec, {args.workload} design LP, T={T} (n={n}, m={m}), batch={B}",
             "value": world * its / k_s, "unit": "scenario-iterations/s", "n_gpus": world, "steps": args.steps, "warmup": max(1, args.warmup),
             "ms_per_step": 1e3 * k_s / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic", "world_size": world,
-            "config": {"workload": f"price_taker: {B} scenarios/GPU of the (battery capital cost x LMP multiplier) family, T = {T} h, "
-                                   f"streaming PDLP capped at {args.steps} check periods of {ce} iterations",
+            "config": {"workload": f"{args.workload}: {B} scenarios/GPU sharing one constraint matrix, T = {T} h, streaming PDLP capped at "
+                                   f"{args.steps} check periods of {ce} iterations",
                        "iterations_per_scenario": float(model.iterations.mean()), "status_counts": np.bincount(model.status, minlength=5).tolist(),
-                       "host_wall_s": float(t[0].item())},
-            "roofline": {"bound": "hbm", "kernel": "k_primal + k_dual_halpern (+ check sequence every 64 iterations)", "achieved": byt / k_s / 1e9,
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": byt / k_s / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                       "us_per_batch_iteration": 1e6 * k_s / max(1, int(model.iterations.max())), "host_wall_s": float(t[0].item())},
+            "roofline": {"bound": "hbm", "kernel": "k_fused_pre / k_fused (+ check sequence every 64 iterations)", "achieved": byt / k_s / 1e9,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": byt / k_s / 1e9 / HBM_PEAK_GBS,
+                         "traffic": traffic, "traffic_from": src, "traffic_note": "per launch of the iteration kernel at the batch of that profile (64)",
                          "algorithmic_bytes_per_scenario_iteration": int(st.stream_bytes_per_iteration),
-                         "note": "HBM-resident PDLP: 8 n + 6 m doubles per scenario and plain iteration (x, c, lb, ub read + xbar written; "
-                                 "y, y0, rlo, rhi, xbar, x0 read + y, x written; gathers and the shared matrix are L2 traffic and not "
-                                 "counted); time = HIP events around the whole solve on its stream (includes the check sequences)"}}))
+                         "two_launch_form_bytes_per_scenario_iteration": 8 * (8 * n + 6 * m),
+                         "note": "HBM-resident PDLP, fused one-launch iteration for banded matrices: x, x0, c, y, y0 read + x, y written "
+                                 "(+ bounds when they differ per scenario); xbar and both products' gathers stay in LDS; time = HIP events "
+                                 "around the whole solve on its stream (includes the check sequences)"}}))
     if world > 1:
         dist.destroy_process_group()
 
@@ -428,7 +452,7 @@ def main():
     from dispatches_amd.distributed import shard_bounds
     if args.workload == "double_loop":
         return bench_double_loop(args, rank, local_rank, world, dev)
-    if args.workload == "price_taker":
+    if args.workload in ("price_taker", "pem_price_taker", "nuclear_price_taker"):
         return bench_price_taker(args, rank, local_rank, world, dev)
     if args.workload == "qp_sweep":
         return bench_qp_sweep(args, rank, local_rank, world, dev)

@@ -933,17 +933,7 @@ __global__ void __launch_bounds__(kTB) k_fused_pre(StreamArgs a, FusedIO io, int
   const StreamProblem &P = a.P;
   const FusedPlan &F = P.F;
   const int n = P.n, m = P.m, nlong = P.C.nlong, NY = F.ny_max, NXB = F.nxb_max, WC = P.C.W, WR = P.R.W;
-  // XCD-aware order (gridDim.y == 1): workgroups go round-robin to the 8 XCDs, each with its own L2.  Linear id -> XCD id % 8,
-  // and WITHIN an XCD consecutive workgroups take the scenario groups of ONE tile before the next tile: the tile's slice of the
-  // matrix (a few tens of KB) is fetched into that L2 once and hit by all the scenario groups that follow, instead of coming
-  // over the fabric again for every (tile, group) workgroup (B / SG x 5 MB per launch: profiles/r30e_*).
-  int tile = blockIdx.x, grp = blockIdx.y;
-  if (gridDim.y == 1) {
-    const int groups = (a.b.B + SG - 1) / SG, lin = blockIdx.x;
-    tile = ((lin >> 3) / groups) * 8 + (lin & 7);
-    grp = (lin >> 3) % groups;
-    if (tile >= F.ntile) return;
-  }
+  const int tile = blockIdx.x, grp = blockIdx.y;
   const int b0 = grp * SG, tid = threadIdx.x;
   const int32_t *tp = F.tile + 8 * tile;
   const int i0 = tp[0], i1 = tp[1], j0 = tp[2], j1 = tp[3], c_lo = tp[4], c_hi = tp[5], r_lo = tp[6], r_hi = tp[7];
@@ -1135,281 +1125,6 @@ __global__ void __launch_bounds__(kTB) k_fused_pre(StreamArgs a, FusedIO io, int
   }
 }
 
-// ---- the iteration as a PERSISTENT tile: one workgroup per tile walks through the scenario groups ----------------------------------
-// What the two forms above still pay (profiles/r30c / r30d: ~100 us per launch at B = 64 whatever the tile size, 2.4-3.4 TB/s of
-// real traffic): (i) the matrix - every (tile, scenario group) workgroup fetches its ELL slice again, and with the vectors
-// streaming through a 4 MB L2 that is B / SG x 5 MB of fabric traffic per launch (80 MB at SG = 4, 320 MB at SG = 1) next to 188 MB
-// of vectors; (ii) the duty cycle - a workgroup loads, then computes with nothing in flight, and two or three of them per CU do
-// not cover each other.  Here the workgroup keeps its tile's matrix entries, local slots and (shared) bounds in registers for
-// ALL scenario groups it walks through (gridDim.y strides), and the next group's vectors are loaded while the current group is
-// computed: barriers wait for LDS only (lgkmcnt), never for the prefetch in flight.
-__device__ __forceinline__ void lds_barrier() {
-  // workgroup barrier that orders LDS traffic only: __syncthreads() also waits for every outstanding global load (vmcnt(0)),
-  // i.e. for the prefetch of the next scenario group
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-  __builtin_amdgcn_s_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
-}
-
-template <int SG, int K, int MW, bool SHARED, bool QP>
-struct FusedGroupData {                 // everything one scenario group needs from global memory
-  double y[K][SG], y0[K][SG], x[K][SG], c[K][SG], x0[K][SG];
-  double lb[SHARED ? 1 : K][SHARED ? 1 : SG], ub[SHARED ? 1 : K][SHARED ? 1 : SG], rlo[SHARED ? 1 : K][SHARED ? 1 : SG], rhi[SHARED ? 1 : K][SHARED ? 1 : SG];
-  double kap[QP ? K : 1][QP ? SG : 1];
-  double hy[SG], hx[SG], hc[SG], hlb[SHARED ? 1 : SG], hub[SHARED ? 1 : SG];
-  double tau[SG], sig[SG];
-  int kk[SG], done[SG];
-  double lpv[2][4], lx[2], lc[2], lx0[2], llb[2], lub[2]; // long columns handled by this wave: partial sums (<= 256 tiles), x, c, x0, bounds
-};
-
-template <int SG, int K, int MW, bool SHARED, bool QP>
-__global__ void __launch_bounds__(kTB) k_fused_loop(StreamArgs a, FusedIO io, int kofs, int ngroups) {
-  extern __shared__ __attribute__((aligned(16))) double lds[];
-  const StreamProblem &P = a.P;
-  const FusedPlan &F = P.F;
-  const int n = P.n, m = P.m, nlong = P.C.nlong, NY = F.ny_max, NXB = F.nxb_max, WC = P.C.W, WR = P.R.W, B = a.b.B;
-  const int tile = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int32_t *tp = F.tile + 8 * tile;
-  const int i0 = tp[0], i1 = tp[1], j0 = tp[2], j1 = tp[3], c_lo = tp[4], c_hi = tp[5], r_lo = tp[6], r_hi = tp[7];
-  double *ys = lds, *xb = lds + (size_t)SG * NY, *red = xb + (size_t)SG * NXB;
-  // ---- loop-invariant part: geometry, matrix entries with their LOCAL slots, shared bounds ----------------------------------------
-  int ik[K], jk[K];
-  bool rowok[K], colok[K];
-  double cval[K][MW], rval[K][MW], lbs[K], ubs[K], rlos[K], rhis[K];
-  int cl[K][MW], sl[K][MW];
-  bool rlong[K][MW];
-#pragma unroll
-  for (int k = 0; k < K; ++k) {
-    ik[k] = min(i0 + tid + k * kTB, m - 1);
-    jk[k] = min(j0 + tid + k * kTB, n - 1);
-    rowok[k] = i0 + tid + k * kTB < i1;
-    colok[k] = j0 + tid + k * kTB < j1 && !P.C.is_long[jk[k]];
-    lbs[k] = a.W.lb[jk[k]]; ubs[k] = a.W.ub[jk[k]]; rlos[k] = a.W.rlo[ik[k]]; rhis[k] = a.W.rhi[ik[k]];     // scenario 0's copy (SHARED)
-#pragma unroll
-    for (int e = 0; e < MW; ++e) {
-      const int ec = min(e, WC - 1), er = min(e, WR - 1);
-      const double cv = P.C.val[(size_t)ec * n + jk[k]], rv = P.R.val[(size_t)er * m + ik[k]];
-      const int cg = P.C.idx[(size_t)ec * n + jk[k]], rg = F.ridx_enc[(size_t)er * m + ik[k]];
-      cval[k][e] = e < WC ? cv : 0.0;
-      cl[k][e] = (e >= WC || cg < r_lo || cg >= r_hi) ? 0 : cg - r_lo;
-      rval[k][e] = e < WR ? rv : 0.0;
-      int t = rg < 0 ? -1 - rg : nlong + rg - c_lo;
-      if (e >= WR || (rg >= 0 && (rg < c_lo || rg >= c_hi))) t = 0;
-      sl[k][e] = t;
-      rlong[k][e] = e < WR && rg < 0 && rv != 0.0;
-    }
-  }
-  const int nhr = (i0 - r_lo) + (r_hi - i1), nhc = (j0 - c_lo) + (c_hi - j1);
-  const int hi_ = min(tid < i0 - r_lo ? r_lo + tid : i1 + (tid - (i0 - r_lo)), m - 1);
-  const int hj = min(tid < j0 - c_lo ? c_lo + tid : j1 + (tid - (j0 - c_lo)), n - 1);
-  const bool halo_row = tid < nhr, halo_col = tid < nhc && !P.C.is_long[hj];
-  double hval[MW];
-  int hcl[MW];
-#pragma unroll
-  for (int e = 0; e < MW; ++e) {
-    const int ec = min(e, WC - 1);
-    const double v = P.C.val[(size_t)ec * n + hj];
-    const int g = P.C.idx[(size_t)ec * n + hj];
-    hval[e] = e < WC ? v : 0.0;
-    hcl[e] = (e >= WC || g < r_lo || g >= r_hi) ? 0 : g - r_lo;
-  }
-  const double hlbs = a.W.lb[hj], hubs = a.W.ub[hj];
-  // long columns: combos q = u * nlong + l; this wave handles q = wave and q = wave + 4
-  const int ncombo = nlong * SG;
-  int lj[2];
-#pragma unroll
-  for (int h = 0; h < 2; ++h) { const int q = min(wave + 4 * h, max(ncombo - 1, 0)); lj[h] = nlong ? P.C.long_id[q % nlong] : 0; }
-
-  using GD = FusedGroupData<SG, K, MW, SHARED, QP>;
-#define DSP_LOAD_GROUP(g, d)                                                                                               \
-  {                                                                                                                       \
-_Pragma("unroll") \
-    for (int u = 0; u < SG; ++u) { \
-      const int s = min(g * SG + u, B - 1); \
-      const StreamCtrl &c = a.W.ctrl[s]; \
-      d.tau[u] = c.tau; d.sig[u] = c.sig; d.kk[u] = c.k; d.done[u] = (g * SG + u >= B) | c.done; \
-_Pragma("unroll") \
-      for (int k = 0; k < K; ++k) { \
-        const size_t ar = (size_t)s * m + ik[k], ac = (size_t)s * n + jk[k]; \
-        d.y[k][u] = io.y_in[ar]; d.y0[k][u] = a.W.y0[ar]; \
-        d.x[k][u] = io.x_in[ac]; d.c[k][u] = a.W.c[ac]; d.x0[k][u] = a.W.x0[ac]; \
-        if (!SHARED) { d.lb[k][u] = a.W.lb[ac]; d.ub[k][u] = a.W.ub[ac]; d.rlo[k][u] = a.W.rlo[ar]; d.rhi[k][u] = a.W.rhi[ar]; } \
-        if (QP) d.kap[k][u] = a.W.kap[ar]; \
-      } \
-      d.hy[u] = io.y_in[(size_t)s * m + hi_]; \
-      const size_t ah = (size_t)s * n + hj; \
-      d.hx[u] = io.x_in[ah]; d.hc[u] = a.W.c[ah]; \
-      if (!SHARED) { d.hlb[u] = a.W.lb[ah]; d.hub[u] = a.W.ub[ah]; } \
-    } \
-_Pragma("unroll") \
-    for (int h = 0; h < 2; ++h) { \
-      const int q = min(wave + 4 * h, max(ncombo - 1, 0)); \
-      const int u = nlong ? q / nlong : 0, l = nlong ? q % nlong : 0, s = min(g * SG + u, B - 1); \
-      const double *pp = io.lp_in + ((size_t)s * max(nlong, 1) + l) * F.ntile; \
-_Pragma("unroll") \
-      for (int t = 0; t < 4; ++t) d.lpv[h][t] = pp[min(lane + 64 * t, F.ntile - 1)]; \
-      const size_t at = (size_t)s * n + lj[h], ab = SHARED ? (size_t)lj[h] : at; \
-      d.lx[h] = io.x_in[at]; d.lc[h] = a.W.c[at]; d.lx0[h] = a.W.x0[at]; d.llb[h] = a.W.lb[ab]; d.lub[h] = a.W.ub[ab]; \
-    } \
-  }
-  GD cur, nxt;
-  int g = blockIdx.y;
-  if (g >= ngroups) return;
-  DSP_LOAD_GROUP(g, cur)
-  for (; g < ngroups; g += gridDim.y) {
-    const int gn = g + gridDim.y;
-    { const int gl = min(gn, ngroups - 1); DSP_LOAD_GROUP(gl, nxt) }   // in flight while this group is computed (the last pass
-                                                                        // reloads its own group: unconditional, branch-free)
-    bool act[SG];
-    double oml[SG];
-#pragma unroll
-    for (int u = 0; u < SG; ++u) { act[u] = !cur.done[u]; oml[u] = 1.0 / (double)(cur.kk[u] + kofs + 3); }
-    // ---- long columns: A^T y from the per-tile partial sums, primal step -> xbar slot ------------------------------------------
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int q = wave + 4 * h;
-      double aty = 0.0;
-#pragma unroll
-      for (int t = 0; t < 4; ++t) aty += (lane + 64 * t < F.ntile) ? cur.lpv[h][t] : 0.0;
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) aty += __shfl_down(aty, off, 64);
-      if (q < ncombo && lane == 0) {
-        const int u = q / nlong, l = q % nlong;
-        double tau_u = 0.0, oml_u = 0.0;                          // (u is a run-time value: selects, not an indexed register array)
-        bool act_u = false;
-#pragma unroll
-        for (int v = 0; v < SG; ++v) { tau_u = v == u ? cur.tau[v] : tau_u; oml_u = v == u ? oml[v] : oml_u; act_u = v == u ? act[v] : act_u; }
-        const double xp = clampd2(fma(-tau_u, cur.lc[h] - aty, cur.lx[h]), cur.llb[h], cur.lub[h]);
-        const double tt = 2.0 * xp - cur.lx[h];
-        xb[u * NXB + l] = tt;
-        const int j = lj[h];                                      // the tile that owns the column also takes its Halpern step
-        if (j >= j0 && j < j1 && act_u) io.x_out[(size_t)min(g * SG + u, B - 1) * n + j] = fma(oml_u, cur.lx0[h] - tt, tt);
-      }
-    }
-    // ---- y into LDS (own rows + halo rows) ---------------------------------------------------------------------------------------
-#pragma unroll
-    for (int k = 0; k < K; ++k)
-      if (rowok[k]) {
-#pragma unroll
-        for (int u = 0; u < SG; ++u) ys[u * NY + (ik[k] - r_lo)] = cur.y[k][u];
-      }
-    if (halo_row) {
-#pragma unroll
-      for (int u = 0; u < SG; ++u) ys[u * NY + (hi_ - r_lo)] = cur.hy[u];
-    }
-    lds_barrier();
-    // ---- primal step of the own and halo columns -> xbar in LDS; x written -----------------------------------------------------------
-#pragma unroll
-    for (int k = 0; k < K; ++k) {
-#pragma unroll
-      for (int u = 0; u < SG; ++u) {
-        const double *yv = ys + u * NY;
-        double aty = 0.0;
-#pragma unroll
-        for (int e = 0; e < MW; ++e) aty = fma(cval[k][e], yv[cl[k][e]], aty);
-        const double lo = SHARED ? lbs[k] : cur.lb[SHARED ? 0 : k][SHARED ? 0 : u], hi = SHARED ? ubs[k] : cur.ub[SHARED ? 0 : k][SHARED ? 0 : u];
-        const double xp = clampd2(fma(-cur.tau[u], cur.c[k][u] - aty, cur.x[k][u]), lo, hi);
-        const double tt = 2.0 * xp - cur.x[k][u];
-        if (colok[k]) {
-          xb[u * NXB + nlong + (jk[k] - c_lo)] = tt;
-          if (act[u]) io.x_out[(size_t)min(g * SG + u, B - 1) * n + jk[k]] = fma(oml[u], cur.x0[k][u] - tt, tt);
-        }
-      }
-    }
-    if (halo_col) {
-#pragma unroll
-      for (int u = 0; u < SG; ++u) {
-        const double *yv = ys + u * NY;
-        double aty = 0.0;
-#pragma unroll
-        for (int e = 0; e < MW; ++e) aty = fma(hval[e], yv[hcl[e]], aty);
-        const double lo = SHARED ? hlbs : cur.hlb[SHARED ? 0 : u], hi = SHARED ? hubs : cur.hub[SHARED ? 0 : u];
-        const double xp = clampd2(fma(-cur.tau[u], cur.hc[u] - aty, cur.hx[u]), lo, hi);
-        xb[u * NXB + nlong + (hj - c_lo)] = 2.0 * xp - cur.hx[u];
-      }
-    }
-    lds_barrier();
-    // ---- dual step + Halpern averaging of the own rows, partial sums for the long columns ----------------------------------------------
-    double lp[SG][kFusedMaxLong];
-#pragma unroll
-    for (int u = 0; u < SG; ++u)
-#pragma unroll
-      for (int q = 0; q < kFusedMaxLong; ++q) lp[u][q] = 0.0;
-#pragma unroll
-    for (int k = 0; k < K; ++k) {
-#pragma unroll
-      for (int u = 0; u < SG; ++u) {
-        const double *xv = xb + u * NXB;
-        double ax = 0.0;
-#pragma unroll
-        for (int e = 0; e < MW; ++e) ax = fma(rval[k][e], xv[sl[k][e]], ax);
-        const double lo = SHARED ? rlos[k] : cur.rlo[SHARED ? 0 : k][SHARED ? 0 : u], hi = SHARED ? rhis[k] : cur.rhi[SHARED ? 0 : k][SHARED ? 0 : u];
-        const double y = cur.y[k][u];
-        const double gy = fma(-cur.sig[u], ax, y);
-        double yp = gy - clampd2(gy, -cur.sig[u] * hi, -cur.sig[u] * lo);
-        if (QP) yp /= fma(cur.sig[u], cur.kap[QP ? k : 0][QP ? u : 0], 1.0);
-        const double tt = 2.0 * yp - y;
-        const double yn = fma(oml[u], cur.y0[k][u] - tt, tt);
-        if (rowok[k] && act[u]) {
-          io.y_out[(size_t)min(g * SG + u, B - 1) * m + ik[k]] = yn;
-#pragma unroll
-          for (int e = 0; e < MW; ++e) {
-            const double w = rlong[k][e] ? rval[k][e] * yn : 0.0;
-#pragma unroll
-            for (int q = 0; q < kFusedMaxLong; ++q) lp[u][q] += (sl[k][e] == q) ? w : 0.0;
-          }
-        }
-      }
-    }
-    if (nlong > 0) {
-      // block sums of the SG x nlong partials in a fixed order (LDS-only barriers)
-#pragma unroll
-      for (int u = 0; u < SG; ++u) {
-#pragma unroll
-        for (int q = 0; q < kFusedMaxLong; ++q) {
-          double t = lp[u][q];
-#pragma unroll
-          for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off, 64);
-          if (lane == 0) red[(u * kFusedMaxLong + q) * (kTB / 64) + wave] = t;
-        }
-      }
-      lds_barrier();
-      if (tid < SG * kFusedMaxLong) {
-        const int u = tid / kFusedMaxLong, q = tid % kFusedMaxLong;
-        double t = 0.0;
-#pragma unroll
-        for (int w = 0; w < kTB / 64; ++w) t += red[(u * kFusedMaxLong + q) * (kTB / 64) + w];
-        bool act_u = false;
-#pragma unroll
-        for (int v = 0; v < SG; ++v) act_u = v == u ? act[v] : act_u;
-        if (q < nlong && act_u) io.lp_out[((size_t)min(g * SG + u, B - 1) * nlong + q) * F.ntile + tile] = t;
-      }
-    }
-    lds_barrier();                                               // ys / xb / red are rewritten by the next group
-    // cur = nxt, member by member (a struct assignment left one of the two structures in scratch memory)
-#pragma unroll
-    for (int u = 0; u < SG; ++u) {
-#pragma unroll
-      for (int k = 0; k < K; ++k) {
-        cur.y[k][u] = nxt.y[k][u]; cur.y0[k][u] = nxt.y0[k][u]; cur.x[k][u] = nxt.x[k][u]; cur.c[k][u] = nxt.c[k][u]; cur.x0[k][u] = nxt.x0[k][u];
-        if (!SHARED) { cur.lb[SHARED ? 0 : k][SHARED ? 0 : u] = nxt.lb[SHARED ? 0 : k][SHARED ? 0 : u]; cur.ub[SHARED ? 0 : k][SHARED ? 0 : u] = nxt.ub[SHARED ? 0 : k][SHARED ? 0 : u];
-                       cur.rlo[SHARED ? 0 : k][SHARED ? 0 : u] = nxt.rlo[SHARED ? 0 : k][SHARED ? 0 : u]; cur.rhi[SHARED ? 0 : k][SHARED ? 0 : u] = nxt.rhi[SHARED ? 0 : k][SHARED ? 0 : u]; }
-        if (QP) cur.kap[QP ? k : 0][QP ? u : 0] = nxt.kap[QP ? k : 0][QP ? u : 0];
-      }
-      cur.hy[u] = nxt.hy[u]; cur.hx[u] = nxt.hx[u]; cur.hc[u] = nxt.hc[u];
-      if (!SHARED) { cur.hlb[SHARED ? 0 : u] = nxt.hlb[SHARED ? 0 : u]; cur.hub[SHARED ? 0 : u] = nxt.hub[SHARED ? 0 : u]; }
-      cur.tau[u] = nxt.tau[u]; cur.sig[u] = nxt.sig[u]; cur.kk[u] = nxt.kk[u]; cur.done[u] = nxt.done[u];
-    }
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-#pragma unroll
-      for (int t = 0; t < 4; ++t) cur.lpv[h][t] = nxt.lpv[h][t];
-      cur.lx[h] = nxt.lx[h]; cur.lc[h] = nxt.lc[h]; cur.lx0[h] = nxt.lx0[h]; cur.llb[h] = nxt.llb[h]; cur.lub[h] = nxt.lub[h];
-    }
-  }
-#undef DSP_LOAD_GROUP
-}
-
 // partial sums of A^T y for the long columns from the CURRENT y (after the initialisation and after every check's k_apply)
 __global__ void __launch_bounds__(kTB) k_long_partials(StreamArgs a, const double *y, double *lp_out) {
   __shared__ double red[(1 + kTB / 64) * kFusedMaxLong];
@@ -1502,7 +1217,7 @@ hipError_t stream_create(const HostCSR &A_scaled, const HostCSR &AT_scaled, cons
   const int rb_env = getenv("DSP_FUSED_RB") ? atoi(getenv("DSP_FUSED_RB")) : 0;
   S->P.F = FusedPlan{};
   if (!no_fused) {
-    const HostFusedPlan H = build_fused_plan(A_scaled, AT_scaled, Er, Ec, kFusedMaxLong, rb_env > 0 ? rb_env : 250, 40 * 1024);
+    const HostFusedPlan H = build_fused_plan(A_scaled, AT_scaled, Er, Ec, kFusedMaxLong, rb_env > 0 ? rb_env : 500, 40 * 1024);
     if (H.ntile > 0) {
       if ((e = up(S->allocs, H.tile, &S->P.F.tile)) != hipSuccess) return e;
       if ((e = up(S->allocs, H.ridx_enc, &S->P.F.ridx_enc)) != hipSuccess) return e;
@@ -1621,7 +1336,7 @@ static hipError_t run_fused(StreamSolver *S, StreamArgs &a, hipStream_t st, int 
   const dim3 g_fused(F.ntile, groups), g_primal(a.nblk_n + P.C.nchunk, groups);
   const dim3 g_rows_chk(a.nblk + P.R.nlong, groups), g_cols(a.nblk_n + P.C.nlong, groups), g_elem(a.nblk, groups);
   const int fin_c = (P.C.nlong * B + 63) / 64;
-  const size_t lds = ((size_t)SG * (F.ny_max + F.nxb_max) + std::max((1 + kTB / 64) * kFusedMaxLong, SG * kFusedMaxLong * (kTB / 64))) * sizeof(double);
+  const size_t lds = ((size_t)SG * (F.ny_max + F.nxb_max) + (1 + kTB / 64) * kFusedMaxLong) * sizeof(double);
   // k_fused_pre (all loads up front) where a thread can own its K <= 4 rows and columns and the halo columns fit one pass;
   // k_fused (staged phases) otherwise.  DSP_FUSED_V=1 forces the staged form (development).
   const void *fn = nullptr;
@@ -1635,25 +1350,6 @@ static hipError_t run_fused(StreamSolver *S, StreamArgs &a, hipStream_t st, int 
 #define DSP_PICK(KK) (mw <= 4 ? DSP_PICK2(KK, 4) : DSP_PICK2(KK, 8))
   if (pre) fn = K == 1 ? DSP_PICK(1) : K == 2 ? DSP_PICK(2) : DSP_PICK(3);
 #undef DSP_PICK2
-  // persistent tiles (k_fused_loop): gridDim.y workgroups per tile stride through the scenario groups, matrix entries in registers
-  // for all of them, the next group's vectors in flight while the current one is computed.  DSP_FUSED_V=2 keeps k_fused_pre.
-  const bool loop = pre && v_env == 3 && K <= 2 && F.ntile <= 256 && P.C.nlong * SG <= 8;      // (measured slower: development only)
-  static const int xcd_env = getenv("DSP_FUSED_XCD") ? atoi(getenv("DSP_FUSED_XCD")) : 1;
-  const bool xcd = pre && !loop && xcd_env != 0;
-  static const int gy_env = getenv("DSP_FUSED_GY") ? atoi(getenv("DSP_FUSED_GY")) : 0;
-  int gy = groups;
-  if (loop) {
-#define DSP_PICKL2(KK, MM)                                                                                                           \
-  (shared ? (qp ? reinterpret_cast<const void *>(&k_fused_loop<SG, KK, MM, true, true>) : reinterpret_cast<const void *>(&k_fused_loop<SG, KK, MM, true, false>)) \
-          : (qp ? reinterpret_cast<const void *>(&k_fused_loop<SG, KK, MM, false, true>) : reinterpret_cast<const void *>(&k_fused_loop<SG, KK, MM, false, false>)))
-    fn = K == 1 ? (mw <= 4 ? DSP_PICKL2(1, 4) : DSP_PICKL2(1, 8)) : (mw <= 4 ? DSP_PICKL2(2, 4) : DSP_PICKL2(2, 8));
-#undef DSP_PICKL2
-    // enough workgroups for ~3 per CU (768), at most one per scenario group
-    gy = gy_env > 0 ? gy_env : std::max(1, std::min(groups, (768 + F.ntile - 1) / F.ntile));
-  }
-#undef DSP_PICK
-  else if (shared) fn = qp ? reinterpret_cast<const void *>(&k_fused<SG, true, true>) : reinterpret_cast<const void *>(&k_fused<SG, true, false>);
-  else fn = qp ? reinterpret_cast<const void *>(&k_fused<SG, false, true>) : reinterpret_cast<const void *>(&k_fused<SG, false, false>);
   hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
   double *xcur = a.W.x, *ycur = a.W.y, *xalt = a.W.x2, *yalt = a.W.y2;
@@ -1669,10 +1365,9 @@ static hipError_t run_fused(StreamSolver *S, StreamArgs &a, hipStream_t st, int 
   for (; period < max_periods; ++period) {
     for (int u = 0; u < C - 1; ++u) {
       FusedIO io{xcur, ycur, xalt, yalt, a.W.lpart[lp_cur], a.W.lpart[lp_cur ^ 1]};
-      int kofs = u, ng = groups;
-      void *params[] = {&a, &io, &kofs, &ng};                     // (k_fused / k_fused_pre take the first three)
-      const dim3 grid = loop ? dim3(F.ntile, gy) : (xcd ? dim3(((F.ntile + 7) / 8) * 8 * groups, 1) : g_fused);
-      if ((e = hipLaunchKernel(fn, grid, blk, params, lds, st)) != hipSuccess) return e;
+      int kofs = u;
+      void *params[] = {&a, &io, &kofs};
+      if ((e = hipLaunchKernel(fn, g_fused, blk, params, lds, st)) != hipSuccess) return e;
       std::swap(xcur, xalt); std::swap(ycur, yalt); lp_cur ^= 1;
     }
     // the check sequence works in place on the current buffers
