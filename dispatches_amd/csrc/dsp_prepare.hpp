@@ -153,11 +153,21 @@ struct HostStreamELL {
   std::vector<int32_t> chunk_begin, chunk_end, long_chunk_ptr;
 };
 
-inline HostStreamELL build_stream_ell(const HostCSR &M, int max_w, int chunk) {
+// `span_limit` > 0: a vector whose entries span more than that many indices is "long" whatever its length (the wrap-around
+// column of a periodic boundary condition: two entries, first and last period - left in the ELL part it would stretch the
+// hull of its tile over the whole matrix and cost the LP its banded plan; as a long vector it goes through the partial sums)
+inline HostStreamELL build_stream_ell(const HostCSR &M, int max_w, int chunk, int span_limit = 0) {
   HostStreamELL E;
   const int nv = M.m;
   std::vector<int> len(nv);
-  for (int v = 0; v < nv; ++v) len[v] = M.ptr[v + 1] - M.ptr[v];
+  for (int v = 0; v < nv; ++v) {
+    len[v] = M.ptr[v + 1] - M.ptr[v];
+    if (span_limit > 0 && len[v] > 1) {
+      int lo = M.idx[M.ptr[v]], hi = lo;
+      for (int p = M.ptr[v]; p < M.ptr[v + 1]; ++p) { lo = std::min(lo, (int)M.idx[p]); hi = std::max(hi, (int)M.idx[p]); }
+      if (hi - lo > span_limit) len[v] = max_w + 1 + len[v];            // classified long below (its true length is re-read there)
+    }
+  }
   // the smallest width that leaves long only what is long at max_w anyway (a design column that touches every period stays
   // long at any width: it must not pad every other vector to max_w entries)
   int nl_max = 0;

@@ -983,8 +983,10 @@ __global__ void __launch_bounds__(kTB) k_fused_pre(StreamArgs a, FusedIO io, int
   }
   // one halo column and one halo row (staged y only) per thread: at most a few periods' worth (host: halo_max <= 256)
   const int nhr = (i0 - r_lo) + (r_hi - i1), nhc = (j0 - c_lo) + (c_hi - j1);
-  const int hi_ = min(tid < i0 - r_lo ? r_lo + tid : i1 + (tid - (i0 - r_lo)), m - 1);
-  const int hj = min(tid < j0 - c_lo ? c_lo + tid : j1 + (tid - (j0 - c_lo)), n - 1);
+  // (threads beyond the halo all read ONE valid address: letting them run on past the tile fetched 256 extra rows and
+  //  columns per workgroup - half as much again as the tile's own y, x and c: profiles/r30h_stream_pmc_summary.csv)
+  const int hi_ = tid < nhr ? min(tid < i0 - r_lo ? r_lo + tid : i1 + (tid - (i0 - r_lo)), m - 1) : r_lo;
+  const int hj = tid < nhc ? min(tid < j0 - c_lo ? c_lo + tid : j1 + (tid - (j0 - c_lo)), n - 1) : c_lo;
   double hy[SG], hx[SG], hc[SG], hlb[SHARED ? 1 : SG], hub[SHARED ? 1 : SG], hval[MW];
   int hgi[MW];
   const unsigned char hlong = P.C.is_long[hj];
@@ -1181,8 +1183,8 @@ hipError_t up(std::vector<void *> &allocs, const std::vector<T> &v, const T **ou
 }
 
 // entry-major ELL + long list of a host CSR (vectors = rows of M): built on the host (dsp_prepare.hpp), uploaded here
-hipError_t build_matrix(const HostCSR &M, std::vector<void *> &allocs, StreamMatrix *out, HostStreamELL *host) {
-  *host = build_stream_ell(M, kStreamMaxW, kLongChunk);
+hipError_t build_matrix(const HostCSR &M, std::vector<void *> &allocs, StreamMatrix *out, HostStreamELL *host, int span_limit = 0) {
+  *host = build_stream_ell(M, kStreamMaxW, kLongChunk, span_limit);
   const HostStreamELL &E = *host;
   if ((int)E.long_id.size() > kStreamMaxLong) return hipErrorInvalidValue;
   out->nvec = E.nvec; out->W = E.W; out->nlong = (int)E.long_id.size(); out->nchunk = (int)E.chunk_begin.size();
@@ -1210,14 +1212,15 @@ hipError_t stream_create(const HostCSR &A_scaled, const HostCSR &AT_scaled, cons
   hipError_t e;
   HostStreamELL Er, Ec;
   if ((e = build_matrix(A_scaled, S->allocs, &S->P.R, &Er)) != hipSuccess) return e;
-  if ((e = build_matrix(AT_scaled, S->allocs, &S->P.C, &Ec)) != hipSuccess) return e;
+  // columns that wrap around the horizon (periodic boundary conditions) are long: see build_stream_ell
+  if ((e = build_matrix(AT_scaled, S->allocs, &S->P.C, &Ec, std::max(4096, A_scaled.m / 4))) != hipSuccess) return e;
   // fused one-launch iteration where the matrix is banded (development switches: DSP_STREAM_NO_FUSED=1, DSP_FUSED_RB=<rows per tile>)
   // (read at every create, not once per process: a test builds one handle of each form)
   const int no_fused = getenv("DSP_STREAM_NO_FUSED") ? atoi(getenv("DSP_STREAM_NO_FUSED")) : 0;
   const int rb_env = getenv("DSP_FUSED_RB") ? atoi(getenv("DSP_FUSED_RB")) : 0;
   S->P.F = FusedPlan{};
   if (!no_fused) {
-    const HostFusedPlan H = build_fused_plan(A_scaled, AT_scaled, Er, Ec, kFusedMaxLong, rb_env > 0 ? rb_env : 500, 40 * 1024);
+    const HostFusedPlan H = build_fused_plan(A_scaled, AT_scaled, Er, Ec, kFusedMaxLong, rb_env > 0 ? rb_env : (std::max(Er.W, Ec.W) > 4 ? 250 : 500), 40 * 1024);   // (wide ELL rows: one row + column per thread keeps k_fused_pre at two waves per SIMD)
     if (H.ntile > 0) {
       if ((e = up(S->allocs, H.tile, &S->P.F.tile)) != hipSuccess) return e;
       if ((e = up(S->allocs, H.ridx_enc, &S->P.F.ridx_enc)) != hipSuccess) return e;

@@ -136,7 +136,7 @@ def wind_battery_price_taker(n_time_points, capacity_factors, lmps, wind_mw=847.
         b.constraint(f"battery.state_of_charge_bounds[{t}]", S + d * Et - DURATION * P, -np.inf, 0.0)
         b.constraint(f"battery.power_bound_in[{t}]", I - P, -np.inf, 0.0)
         b.constraint(f"battery.power_bound_out[{t}]", O - P, -np.inf, 0.0)
-        revenue = revenue + (G + O) * float(lmp[t])
+        revenue.accumulate(G, float(lmp[t])).accumulate(O, float(lmp[t]))
         per.append(dict(wind=W, grid_elec=G, elec_in=I, elec_out=O, state_of_charge=S, energy_throughput=Et))
         soc_prev, thr_prev = S, E
     n_weeks = T / (7 * 24)
@@ -231,8 +231,8 @@ def wind_battery_pem_price_taker(time_points, capacity_factors, lmps, h2_price_p
         b.constraint(f"battery.power_bound_in[{t}]", I - P, -np.inf, 0.0)
         b.constraint(f"battery.power_bound_out[{t}]", O - P, -np.inf, 0.0)
         b.constraint(f"pem_max_p[{t}]", X - Cp, -np.inf, 0.0)                         # :243
-        rev_e = rev_e + (G + O) * float(lmp[t])
-        h2_kg = h2_kg + X * h2_per_kwh
+        rev_e.accumulate(G, float(lmp[t])).accumulate(O, float(lmp[t]))
+        h2_kg.accumulate(X, h2_per_kwh)
         per.append(dict(wind=W, grid_elec=G, elec_in=I, pem_elec=X, elec_out=O, state_of_charge=S, energy_throughput=E))
         soc_prev, thr_prev = S, E
     b.equality("battery.periodic_state_of_charge", soc_prev - S_init, 0.0)            # :36-47
@@ -320,7 +320,7 @@ def nuclear_price_taker(n_time_points, lmps, h2_demand=NP_CAPACITY_MW * H2_PROD_
         b.constraint(f"pem_capacity_constraint[{t}]", e - pem_cap, -np.inf, 0.0)               # :200-202
         b.constraint(f"tank_capacity_constraint[{t}]", hold - tank_cap, -np.inf, 0.0)          # :204-206
         b.constraint(f"turbine_capacity_constraint[{t}]", turb_p - turb_cap, -np.inf, 0.0)     # :208-210
-        cash = cash + net * float(lmp[t]) - e * vom_pem - turb_p * vom_turbine                 # :239-254 (hydrogen revenue: objective_vector)
+        cash.accumulate(net, float(lmp[t])).accumulate(e, -vom_pem).accumulate(turb_p, -vom_turbine)   # :239-254 (hydrogen revenue below)
         per.append(dict(np_to_grid=g, np_to_electrolyzer=e, h2_production=h, tank_holdup=hold, h2_to_pipeline=pipe,
                         h2_to_turbine=turb_in, h2_turbine_power=turb_p, net_power=net))
         hold_prev = hold
@@ -333,7 +333,7 @@ def nuclear_price_taker(n_time_points, lmps, h2_demand=NP_CAPACITY_MW * H2_PROD_
     def annualised_npv(h2_price):
         inflow = cash - npp_vom
         for p in per:
-            inflow = inflow + p["h2_to_pipeline"] * float(h2_price)
+            inflow.accumulate(p["h2_to_pipeline"], float(h2_price))
         depreciation = capex / plant_life                                                      # :298-301
         net_profit = depreciation + (inflow - fixed_om - depreciation) * (1 - tax_rate)       # :303-305
         return net_profit - capex * (1 / cf_factor), net_profit                               # :318-322

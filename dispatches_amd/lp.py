@@ -67,6 +67,16 @@ class LinExpr:
     def __truediv__(self, s):
         return self * (1.0 / float(s))
 
+    def accumulate(self, other, scale: float = 1.0) -> "LinExpr":
+        """self += scale * other IN PLACE (returns self).  For sums over thousands of periods: `total = total + term` copies the
+        growing dictionary every time - quadratic in the horizon (the year-long price-taker objectives took minutes)."""
+        o = LinExpr._as(other)
+        s = float(scale)
+        for j, v in o.coef.items():
+            self.coef[j] = self.coef.get(j, 0.0) + s * v
+        self.const += s * o.const
+        return self
+
     def value(self, x: np.ndarray) -> float:
         return self.const + sum(v * x[j] for j, v in self.coef.items())
 
@@ -233,6 +243,8 @@ def implied_column_ranges(lp: "StandardFormLP", lb=None, ub=None, passes: int = 
 
 
 class LinearBlock:
+    presolve_sequential_limit = 256      # candidates confirmed one at a time up to this many, in one batch beyond (flatten)
+
     """The block a model object's ``populate_model(b, horizon)`` fills (stand-in for a Pyomo Block).
 
     Columns, rows and named expression families are appended in call order.  ``flatten()`` produces the
@@ -401,11 +413,23 @@ class LinearBlock:
         if presolve and m_all:
             lb, ub = self._propagate_bounds(keep)
             candidates = [i for i in range(m_all) if self._never_binds(i, lb, ub)]
-            for i in candidates:
-                keep[i] = False
+            if len(candidates) <= self.presolve_sequential_limit:
+                for i in candidates:
+                    keep[i] = False
+                    lb, ub = self._propagate_bounds(keep)
+                    if not self._never_binds(i, lb, ub):
+                        keep[i] = True
+            else:
+                # Many candidates (a year-long horizon has thousands of never-binding capacity / ramp rows): one propagation per
+                # candidate is quadratic in the horizon (the 8784-period nuclear LP: hours).  All candidates are set aside AT
+                # ONCE and each is confirmed against the bounds that the NON-candidate rows and the declared hulls imply - no row
+                # vouches for itself or for another candidate, so the rule of the docstring holds a fortiori; a candidate whose
+                # proof needed another candidate stays in the LP (harmless: it never binds).
+                keep[candidates] = False
                 lb, ub = self._propagate_bounds(keep)
-                if not self._never_binds(i, lb, ub):
-                    keep[i] = True
+                for i in candidates:
+                    if not self._never_binds(i, lb, ub):
+                        keep[i] = True
         self._kept_rows = np.nonzero(keep)[0]
         indptr, indices, data = [0], [], []
         for i in self._kept_rows:

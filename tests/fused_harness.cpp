@@ -27,7 +27,7 @@ int main(int argc, char **argv) {
   fclose(f);
   const int n = A.n, m = A.m;
   HostCSR AT = transpose(A);
-  HostStreamELL Er = build_stream_ell(A, max_w, 2048), Ec = build_stream_ell(AT, max_w, 2048);
+  HostStreamELL Er = build_stream_ell(A, max_w, 2048), Ec = build_stream_ell(AT, max_w, 2048, std::max(4096, A.m / 4));   // as stream_create
   HostFusedPlan F = build_fused_plan(A, AT, Er, Ec, 4, rows_per_tile, 40 * 1024);
   const int nlong = (int)Ec.long_id.size();
   if (F.ntile == 0) { printf("{\"ntile\": 0, \"long_rows\": %zu, \"long_cols\": %d}\n", Er.long_id.size(), nlong); return 0; }
