@@ -735,7 +735,7 @@ __global__ void __launch_bounds__(1024) k_block_solve(StreamArgs a) {
 
 
 // ---- fused iteration for banded LPs: ONE launch per plain iteration (FusedPlan, dsp_stream.hpp) --------------------------------
-// grid (tiles, scenario groups); workgroup = one tile x SG scenarios.  Per scenario the launch moves
+// grid (scenario groups, tiles); workgroup = one tile x SG scenarios.  Per scenario the launch moves
 //     reads  x, x0, c (+ lb, ub unless the batch shares them), y, y0 (+ rlo, rhi unless shared)      writes  x, y
 // = 4 n + 3 m doubles with shared bounds (6 n + 5 m otherwise) against the 8 n + 6 m of the two-launch form - and the gathers
 // of both products are LDS reads instead of L2 traffic (the two-launch kernels fetched 1.3-1.6x their algorithmic bytes:
@@ -775,7 +775,7 @@ __global__ void __launch_bounds__(kTB) k_fused(StreamArgs a, FusedIO io, int kof
   const StreamProblem &P = a.P;
   const FusedPlan &F = P.F;
   const int n = P.n, m = P.m, nlong = P.C.nlong, NY = F.ny_max, NXB = F.nxb_max;
-  const int tile = blockIdx.x, b0 = blockIdx.y * SG;
+  const int tile = blockIdx.y, b0 = blockIdx.x * SG;           // grid (scenario groups, tiles): see k_fused_pre
   const int32_t *tp = F.tile + 8 * tile;
   const int i0 = tp[0], i1 = tp[1], j0 = tp[2], j1 = tp[3], c_lo = tp[4], c_hi = tp[5], r_lo = tp[6], r_hi = tp[7];
   double *ys = lds;                          // [SG][NY]   y of the rows r_lo .. r_hi
@@ -933,7 +933,9 @@ __global__ void __launch_bounds__(kTB) k_fused_pre(StreamArgs a, FusedIO io, int
   const StreamProblem &P = a.P;
   const FusedPlan &F = P.F;
   const int n = P.n, m = P.m, nlong = P.C.nlong, NY = F.ny_max, NXB = F.nxb_max, WC = P.C.W, WR = P.R.W;
-  const int tile = blockIdx.x, grp = blockIdx.y;
+  // grid (scenario groups, tiles): the groups of ONE tile have consecutive workgroup ids, i.e. they are dispatched at nearly the same
+  // time, two or more of them to each XCD - whose L2 then serves the tile's slice of the matrix to all but the first
+  const int tile = blockIdx.y, grp = blockIdx.x;
   const int b0 = grp * SG, tid = threadIdx.x;
   const int32_t *tp = F.tile + 8 * tile;
   const int i0 = tp[0], i1 = tp[1], j0 = tp[2], j1 = tp[3], c_lo = tp[4], c_hi = tp[5], r_lo = tp[6], r_hi = tp[7];
@@ -1336,7 +1338,7 @@ static hipError_t run_fused(StreamSolver *S, StreamArgs &a, hipStream_t st, int 
   const int B = a.b.B;
   const int groups = (B + SG - 1) / SG;
   const dim3 blk(kTB);
-  const dim3 g_fused(F.ntile, groups), g_primal(a.nblk_n + P.C.nchunk, groups);
+  const dim3 g_fused(groups, F.ntile), g_primal(a.nblk_n + P.C.nchunk, groups);
   const dim3 g_rows_chk(a.nblk + P.R.nlong, groups), g_cols(a.nblk_n + P.C.nlong, groups), g_elem(a.nblk, groups);
   const int fin_c = (P.C.nlong * B + 63) / 64;
   const size_t lds = ((size_t)SG * (F.ny_max + F.nxb_max) + (1 + kTB / 64) * kFusedMaxLong) * sizeof(double);
