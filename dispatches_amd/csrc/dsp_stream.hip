@@ -1222,7 +1222,7 @@ hipError_t stream_create(const HostCSR &A_scaled, const HostCSR &AT_scaled, cons
   const int rb_env = getenv("DSP_FUSED_RB") ? atoi(getenv("DSP_FUSED_RB")) : 0;
   S->P.F = FusedPlan{};
   if (!no_fused) {
-    const HostFusedPlan H = build_fused_plan(A_scaled, AT_scaled, Er, Ec, kFusedMaxLong, rb_env > 0 ? rb_env : (std::max(Er.W, Ec.W) > 4 ? 250 : 500), 40 * 1024);   // (wide ELL rows: one row + column per thread keeps k_fused_pre at two waves per SIMD)
+    const HostFusedPlan H = build_fused_plan(A_scaled, AT_scaled, Er, Ec, kFusedMaxLong, rb_env > 0 ? rb_env : 250, 40 * 1024);     // one row + one column per thread (K = 1): measured best, profiles/r30j_fused_scan.log
     if (H.ntile > 0) {
       if ((e = up(S->allocs, H.tile, &S->P.F.tile)) != hipSuccess) return e;
       if ((e = up(S->allocs, H.ridx_enc, &S->P.F.ridx_enc)) != hipSuccess) return e;
@@ -1450,9 +1450,8 @@ static hipError_t stream_solve_locked(StreamSolver *S, const dsp_batch &batch, c
     const bool shared = (!batch.var_lb || batch.var_lb_stride == 0) && (!batch.var_ub || batch.var_ub_stride == 0) &&
                         (!batch.row_lb || batch.row_lb_stride == 0) && (!batch.row_ub || batch.row_ub_stride == 0);
     const bool qp = batch.row_compliance != nullptr;
-    int fsg = 4;                       // scenarios per workgroup: matrix entries are loaded once per workgroup
-    if ((long)S->P.F.ntile * ((B + 3) / 4) < 1024) fsg = 2;
-    if ((long)S->P.F.ntile * ((B + 1) / 2) < 1024) fsg = 1;
+    int fsg = 2;                       // scenarios per workgroup (matrix entries are loaded once per workgroup): 2 measured best with
+    if ((long)S->P.F.ntile * ((B + 1) / 2) < 1024) fsg = 1;      // 250-row tiles (81 vs 89-91 us at 4, 102 at 1: profiles/r30j_fused_scan.log)
     static const int fsg_env = getenv("DSP_FUSED_SG") ? atoi(getenv("DSP_FUSED_SG")) : 0;
     if (fsg_env == 1 || fsg_env == 2 || fsg_env == 4) fsg = fsg_env;
     S->last_bytes_per_iteration = (size_t)8 * (shared ? 4 * (size_t)S->P.n + 3 * (size_t)S->P.m : 6 * (size_t)S->P.n + 5 * (size_t)S->P.m)
