@@ -507,10 +507,21 @@ __global__ void k_control(StreamArgs a, int iters_this_period) {
   const int s = blockIdx.x;
   StreamCtrl &c = a.W.ctrl[s];
   if (c.done) return;
+  // 256 threads: quantity q = t % 16, the blocks' partials in 16 interleaved strands (strand t / 16), strands added in order.  (16
+  // threads walking through all the blocks one load after the other took 80 us per check at T = 8736: profiles/r30a_stream_kernel_stats.csv)
+  __shared__ double strand[16][kNQ];
   __shared__ double acc[kNQ];
+  {
+    const int q = threadIdx.x & (kNQ - 1), p = threadIdx.x >> 4;
+    double t = 0.0;
+    for (int blk = p; blk < a.nblk_tot; blk += 16) t += a.W.partial[((size_t)s * a.nblk_tot + blk) * kNQ + q];
+    strand[p][q] = t;
+  }
+  __syncthreads();
   if (threadIdx.x < kNQ) {
     double t = 0.0;
-    for (int blk = 0; blk < a.nblk_tot; ++blk) t += a.W.partial[((size_t)s * a.nblk_tot + blk) * kNQ + threadIdx.x];
+#pragma unroll
+    for (int p = 0; p < 16; ++p) t += strand[p][threadIdx.x];
     acc[threadIdx.x] = t;
   }
   __syncthreads();
@@ -1310,7 +1321,7 @@ static hipError_t run(StreamSolver *S, StreamArgs &a, hipStream_t st, int *perio
     primal(true);
     hipLaunchKernelGGL((k_check_rows<SG>), g_rows_chk, blk, 0, st, a);
     hipLaunchKernelGGL((k_kkt_cols<SG>), g_cols, blk, 0, st, a);
-    hipLaunchKernelGGL(k_control, dim3(B), dim3(64), 0, st, a, C);
+    hipLaunchKernelGGL(k_control, dim3(B), dim3(256), 0, st, a, C);
     hipLaunchKernelGGL((k_apply<SG>), g_elem, blk, 0, st, a);
     if ((period + 1) % poll == 0 || period + 1 == max_periods) {
       if ((e = hipMemcpyAsync(S->ndone_host, a.W.ndone, sizeof(int), hipMemcpyDeviceToHost, st)) != hipSuccess) return e;
@@ -1382,7 +1393,7 @@ static hipError_t run_fused(StreamSolver *S, StreamArgs &a, hipStream_t st, int 
     if (P.C.nlong) hipLaunchKernelGGL(k_primal_long_finish, dim3(fin_c), dim3(64), 0, st, ac, 1);
     hipLaunchKernelGGL((k_check_rows<SG>), g_rows_chk, blk, 0, st, ac);
     hipLaunchKernelGGL((k_kkt_cols<SG>), g_cols, blk, 0, st, ac);
-    hipLaunchKernelGGL(k_control, dim3(B), dim3(64), 0, st, ac, C);
+    hipLaunchKernelGGL(k_control, dim3(B), dim3(256), 0, st, ac, C);
     hipLaunchKernelGGL((k_apply<SG>), g_elem, blk, 0, st, ac);
     partials();
     if ((period + 1) % poll == 0 || period + 1 == max_periods) {
