@@ -759,6 +759,7 @@ struct FusedIO {
   double *x_out, *y_out;
   const double *lp_in;         // [B][nlong][ntile]
   double *lp_out;
+  int xcd_full;                // k_fused_pre: workgroups [0, xcd_full) are renumbered XCD-major (0 = grid order)
 };
 
 __device__ __forceinline__ void fused_reduce_long(double (&v)[kFusedMaxLong], int nlong, double *red) {
@@ -946,7 +947,20 @@ __global__ void __launch_bounds__(kTB) k_fused_pre(StreamArgs a, FusedIO io, int
   const int n = P.n, m = P.m, nlong = P.C.nlong, NY = F.ny_max, NXB = F.nxb_max, WC = P.C.W, WR = P.R.W;
   // grid (scenario groups, tiles): the groups of ONE tile have consecutive workgroup ids, i.e. they are dispatched at nearly the same
   // time, two or more of them to each XCD - whose L2 then serves the tile's slice of the matrix to all but the first
-  const int tile = blockIdx.y, grp = blockIdx.x;
+  // XCD-major renumbering (io.xcd_full > 0): workgroups go to the 8 XCDs round-robin in launch order, so with the plain grid order
+  // every XCD sees every tile and fetches its matrix slice into its own L2.  Workgroup 8 q + c (XCD c) takes group q % G of tile
+  // 8 (q / G) + c instead: ALL groups of a tile run on ONE XCD, back to back.  Only whole rounds of 8 tiles are renumbered
+  // (xcd_full = 8 G (ntile / 8)); the last ntile % 8 tiles keep the grid order (a renumbering that ran on into tile ids beyond
+  // ntile was the memory fault of the first attempt, profiles/r30f_*).
+  int tile = blockIdx.y, grp = blockIdx.x;
+  {
+    const int G = gridDim.x, lin = blockIdx.x + G * blockIdx.y;
+    if (lin < io.xcd_full) {
+      const int q = lin >> 3, c = lin & 7;
+      tile = 8 * (q / G) + c;
+      grp = q % G;
+    }
+  }
   const int b0 = grp * SG, tid = threadIdx.x;
   const int32_t *tp = F.tile + 8 * tile;
   const int i0 = tp[0], i1 = tp[1], j0 = tp[2], j1 = tp[3], c_lo = tp[4], c_hi = tp[5], r_lo = tp[6], r_hi = tp[7];
@@ -1017,15 +1031,18 @@ __global__ void __launch_bounds__(kTB) k_fused_pre(StreamArgs a, FusedIO io, int
   for (int q = tid >> 6; q < nlong * SG; q += kTB / 64) {
     const int l = q % nlong, u = q / nlong, lane = tid & 63;
     const double *pp = io.lp_in + ((size_t)su[u] * nlong + l) * F.ntile;
+    // (the column's own x, c and bounds are requested BEFORE the partial sums are added up - every lane the same address - so
+    //  that they arrive with them: loaded by lane 0 after the reduction they were a second memory round trip ahead of the
+    //  workgroup's first barrier)
+    const int j = P.C.long_id[l];
+    const size_t at = (size_t)su[u] * n + j, ab = SHARED ? (size_t)j : at;
+    const double x = io.x_in[at], cj = a.W.c[at], lbj = a.W.lb[ab], ubj = a.W.ub[ab];
     double aty = 0.0;
     for (int t = lane; t < F.ntile; t += 64) aty += pp[t];
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) aty += __shfl_down(aty, off, 64);
     if (lane == 0) {
-      const int j = P.C.long_id[l];
-      const size_t at = (size_t)su[u] * n + j, ab = SHARED ? (size_t)j : at;
-      const double x = io.x_in[at];
-      const double xp = clampd2(fma(-tau[u], a.W.c[at] - aty, x), a.W.lb[ab], a.W.ub[ab]);
+      const double xp = clampd2(fma(-tau[u], cj - aty, x), lbj, ubj);
       xb[u * NXB + l] = 2.0 * xp - x;
     }
   }
@@ -1356,7 +1373,7 @@ static hipError_t run_fused(StreamSolver *S, StreamArgs &a, hipStream_t st, int 
   // k_fused_pre (all loads up front) where a thread can own its K <= 4 rows and columns and the halo columns fit one pass;
   // k_fused (staged phases) otherwise.  DSP_FUSED_V=1 forces the staged form (development).
   const void *fn = nullptr;
-  static const int v_env = getenv("DSP_FUSED_V") ? atoi(getenv("DSP_FUSED_V")) : 0;
+  const int v_env = getenv("DSP_FUSED_V") ? atoi(getenv("DSP_FUSED_V")) : 0;      // (read per solve: tests switch forms)
   const int K = (F.own_max + kTB - 1) / kTB;
   const int mw = std::max(P.C.W, P.R.W);
   const bool pre = v_env != 1 && K >= 1 && K <= 3 && mw <= 8 && F.halo_max <= kTB;
@@ -1365,9 +1382,14 @@ static hipError_t run_fused(StreamSolver *S, StreamArgs &a, hipStream_t st, int 
           : (qp ? reinterpret_cast<const void *>(&k_fused_pre<SG, KK, MM, false, true>) : reinterpret_cast<const void *>(&k_fused_pre<SG, KK, MM, false, false>)))
 #define DSP_PICK(KK) (mw <= 4 ? DSP_PICK2(KK, 4) : DSP_PICK2(KK, 8))
   if (pre) fn = K == 1 ? DSP_PICK(1) : K == 2 ? DSP_PICK(2) : DSP_PICK(3);
+  else fn = shared ? (qp ? reinterpret_cast<const void *>(&k_fused<SG, true, true>) : reinterpret_cast<const void *>(&k_fused<SG, true, false>))
+                   : (qp ? reinterpret_cast<const void *>(&k_fused<SG, false, true>) : reinterpret_cast<const void *>(&k_fused<SG, false, false>));
+#undef DSP_PICK
 #undef DSP_PICK2
   hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
+  const int xcd_env = getenv("DSP_FUSED_XCD") ? atoi(getenv("DSP_FUSED_XCD")) : 0;
+  const int xcd_full = (pre && xcd_env) ? 8 * groups * (F.ntile / 8) : 0;
   double *xcur = a.W.x, *ycur = a.W.y, *xalt = a.W.x2, *yalt = a.W.y2;
   int lp_cur = 0;
   auto partials = [&]() {
@@ -1380,7 +1402,7 @@ static hipError_t run_fused(StreamSolver *S, StreamArgs &a, hipStream_t st, int 
   int period = 0;
   for (; period < max_periods; ++period) {
     for (int u = 0; u < C - 1; ++u) {
-      FusedIO io{xcur, ycur, xalt, yalt, a.W.lpart[lp_cur], a.W.lpart[lp_cur ^ 1]};
+      FusedIO io{xcur, ycur, xalt, yalt, a.W.lpart[lp_cur], a.W.lpart[lp_cur ^ 1], xcd_full};
       int kofs = u;
       void *params[] = {&a, &io, &kofs};
       if ((e = hipLaunchKernel(fn, g_fused, blk, params, lds, st)) != hipSuccess) return e;

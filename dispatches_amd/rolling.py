@@ -159,7 +159,9 @@ class BatchedWindBatteryDoubleLoop:
         # PDHG iterations on average instead of 4 k from the cold start, and iteration-limit failures: the shifted point is
         # feasible for neither the new state nor the new prices, and the restart scheme pays for the bad anchor.
         from .hip_solver import period_shift_maps
-        self.warm_start = bool(warm_start) and day_ahead_horizon > 24
+        # warm_start = "weight": cold point, only the primal weight of yesterday's solve is carried over
+        self.weight_only = warm_start == "weight"
+        self.warm_start = bool(warm_start) and not self.weight_only and day_ahead_horizon > 24
         cmap, rmap = period_shift_maps(da_model.lp, 24)
         self.da_cmap, self.da_rmap = idx(cmap), idx(rmap)
         self.da_prev = None
@@ -236,7 +238,8 @@ class BatchedWindBatteryDoubleLoop:
             x_prev, y_prev, pw = self.da_prev
             out = m.solve(self.B, x0=x_prev[:, self.da_cmap].contiguous(), y0=y_prev[:, self.da_rmap].contiguous(), primal_weight=pw)
         else:
-            self.da_pw.zero_()
+            if not self.weight_only:
+                self.da_pw.zero_()
             out = m.solve(self.B, primal_weight=self.da_pw)
         self._check(out)
         if self.warm_start:

@@ -54,8 +54,15 @@ def test_fused_iteration_reproduces_the_two_launch_form(monkeypatch):
         ref.append(P.solve(tight=True)[1])
     ref = np.array(ref)
     out = {}
-    for form, env in (("fused", "0"), ("two_launch", "1")):
+    # fused = k_fused_pre (all loads up front); fused_staged = k_fused (the form for tiles k_fused_pre does not cover);
+    # fused_xcd = k_fused_pre with the XCD-major workgroup order
+    for form, env, extra in (("fused", "0", {}), ("fused_staged", "0", {"DSP_FUSED_V": "1"}),
+                             ("fused_xcd", "0", {"DSP_FUSED_XCD": "1"}), ("two_launch", "1", {})):
         monkeypatch.setenv("DSP_STREAM_NO_FUSED", env)
+        for k in ("DSP_FUSED_V", "DSP_FUSED_XCD"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in extra.items():
+            monkeypatch.setenv(k, v)
         solver = HipPdlpSolver(device=0, check_every=64)
         handles, model = scenarios.price_taker_batch(T, B, solver)
         solver.solve(model, tee=True)
@@ -63,11 +70,16 @@ def test_fused_iteration_reproduces_the_two_launch_form(monkeypatch):
         assert st.streaming == 1 and (model.status == 0).all(), (form, model.status, model.iterations)
         n, m = model.lp.n, model.lp.m
         # algorithmic bytes per scenario-iteration: 4 n + 3 m doubles fused (the family shares its bounds), 8 n + 6 m in two launches
-        assert st.stream_bytes_per_iteration == (8 * (4 * n + 3 * m) if form == "fused" else 8 * (8 * n + 6 * m)), form
+        assert st.stream_bytes_per_iteration == (8 * (4 * n + 3 * m) if form.startswith("fused") else 8 * (8 * n + 6 * m)), form
         err = np.abs(model.objective - ref) / np.maximum(1.0, np.abs(ref))
         assert err.max() < 1e-6, (form, err)
         out[form] = (model.objective.copy(), model.iterations.copy())
     assert np.allclose(out["fused"][0], out["two_launch"][0], rtol=1e-7, atol=1e-7)
+    # the workgroup order does not touch the arithmetic: identical iteration counts and objectives; the staged kernel is a
+    # different instruction stream for the same formulas
+    assert (out["fused_xcd"][1] == out["fused"][1]).all() and (out["fused_xcd"][0] == out["fused"][0]).all()
+    assert np.allclose(out["fused_staged"][0], out["fused"][0], rtol=1e-9, atol=1e-9)
+    assert (np.abs(out["fused_staged"][1] - out["fused"][1]) <= 2 * 64).all(), (out["fused_staged"][1], out["fused"][1])
     assert (np.abs(out["fused"][1] - out["two_launch"][1]) <= 0.05 * out["two_launch"][1] + 128).all(), (out["fused"][1], out["two_launch"][1])
 
 

@@ -1,13 +1,13 @@
 """GPU dev tool / config-4 driver: the device-resident batched double loop for B plants over `days` simulated days.
-    python tools/gpu_rolling_year.py [B] [days]"""
+    python tools/gpu_rolling_year.py [B] [days] [warm: 0 cold | 1 shifted point + weight | 2 weight only]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from dispatches_amd.rolling import BatchedWindBatteryDoubleLoop
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 days = int(sys.argv[2]) if len(sys.argv) > 2 else 3
-warm = int(sys.argv[3]) if len(sys.argv) > 3 else 1
-loop = BatchedWindBatteryDoubleLoop(B, device=0, warm_start=bool(warm))
+warm = int(sys.argv[3]) if len(sys.argv) > 3 else 1            # 0 cold, 1 shifted point + weight, 2 weight only
+loop = BatchedWindBatteryDoubleLoop(B, device=0, warm_start={0: False, 1: True, 2: "weight"}[warm])
 loop.run_day(); torch.cuda.synchronize()                          # warm-up day (handles, code objects)
 t0 = time.perf_counter()
 for d in range(days):
