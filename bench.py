@@ -139,7 +139,8 @@ def bench_double_loop(args, rank, local_rank, world, dev):
     lo, hi = shard_bounds(total, world, rank)
     B = hi - lo
     per = max(shard_bounds(total, world, r)[1] - shard_bounds(total, world, r)[0] for r in range(world))
-    loop = BatchedWindBatteryDoubleLoop(B, device=local_rank, first_scenario=lo)
+    kw = {} if args.warm_start < 0 else {"warm_start": bool(args.warm_start)}
+    loop = BatchedWindBatteryDoubleLoop(B, device=local_rank, first_scenario=lo, **kw)
     buffers = make_gather_buffers(world, per, dev, width=2) if world > 1 else None
     status_ok = torch.zeros(B, dtype=torch.float64, device=dev)
 
@@ -178,6 +179,9 @@ def bench_double_loop(args, rank, local_rank, world, dev):
             "config": {"workload": f"double_loop: {total} wind+battery plants ({per} per GPU), per simulated day 1 x 48-h day-ahead LP (PDLP "
                                    "kernel) + 24 x (4-h real-time LP + 4-h tracking LP) (in-wave simplex), stub market, state hand-off on device",
                        "lp_solves_per_s": total * days * 49 / elapsed, "all_optimal": bool(okt.item()),
+                       "day_ahead_warm_start": bool(loop.warm_start),
+                       "day_ahead_iterations_last_day": {"mean": float(loop.da.out["iters"].float().mean().item()),
+                                                         "max": int(loop.da.out["iters"].max().item())},
                        "seconds_per_simulated_year": 366 * elapsed / days,
                        "mean_revenue_per_plant_day": float(res["obj"].mean().item()) / (days + max(1, args.warmup))}}))
     if world > 1:
@@ -410,6 +414,8 @@ def main():
     ap.add_argument("--min-time", type=float, default=0.5,
                     help="the burst of --steps steps is repeated until the timed bursts cover this many seconds; the median burst is reported")
     ap.add_argument("--max-bursts", type=int, default=500)
+    ap.add_argument("--warm-start", type=int, default=-1,
+                    help="--workload double_loop: 1 / 0 = rolling warm start of the day-ahead LP on / off (-1 = the loop's default)")
     ap.add_argument("--no-spmv", action="store_true", help="skip the streaming SpMV-step roofline measurement")
     ap.add_argument("--spmv-large-mult", type=int, default=32,
                     help="also time spmv_step on a batch this many times larger (0 = skip; the PMC passes skip it so "

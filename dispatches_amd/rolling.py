@@ -153,18 +153,22 @@ class BatchedWindBatteryDoubleLoop:
         self.da.pda_cols, self.rt.pda_cols = idx(da_model.pda_cols), idx(rt_model.pda_cols)
         # column handles of the hourly models' periods (tests map device solutions into the oracle's variables through these)
         self.rt_periods, self.tr_periods = rt_model.block.windBattery["periods"], tr_model.block.windBattery["periods"]
-        # OPTIONAL rolling warm start of the day-ahead LP: day d + 1's 48-h problem is day d's shifted by 24 h, so period t
+        # Rolling warm start of the day-ahead LP (warm_start=True): day d + 1's 48-h problem is day d's shifted by 24 h, so period t
         # starts from yesterday's period t + 24 (the last 24 periods keep their own old values); x, y and the primal weight
-        # stay on the device (dsp_batch::x0 / y0 / primal_weight).  OFF by default - measured (1024 plants, 4 days): 15 k
-        # PDHG iterations on average instead of 4 k from the cold start, and iteration-limit failures: the shifted point is
-        # feasible for neither the new state nor the new prices, and the restart scheme pays for the bad anchor.
+        # stay on the device (dsp_batch::x0 / y0 / primal_weight) in PERSISTENT buffers that start at zero - which is the cold
+        # start (x = clamp(0), y = 0, weight 0 = automatic) - so the first day needs no special case and the day-ahead step is ONE
+        # hipGraph for every day.  Round 2 measured this WORSE (15 k iterations against 4 k, iteration-limit failures: before the
+        # variable scaling and the objective-error termination); round 3 (profiles/r30m_warm_start.log, 1024 plants): mean 2.3 k
+        # against 3.4-3.9 k iterations, slowest plant 6-9 k against 10-14 k, all optimal.  warm_start="weight" carries the primal
+        # weight only (3.0-3.2 k).
         from .hip_solver import period_shift_maps
-        # warm_start = "weight": cold point, only the primal weight of yesterday's solve is carried over
         self.weight_only = warm_start == "weight"
         self.warm_start = bool(warm_start) and not self.weight_only and day_ahead_horizon > 24
         cmap, rmap = period_shift_maps(da_model.lp, 24)
         self.da_cmap, self.da_rmap = idx(cmap), idx(rmap)
-        self.da_prev = None
+        if self.warm_start:
+            self.da_x0 = torch.zeros((B, da_model.lp.n), dtype=torch.float64, device=dev)
+            self.da_y0 = torch.zeros((B, max(da_model.lp.m, 1)), dtype=torch.float64, device=dev)
         self.tr.track_rows = idx([tr_model.block.kept_row_index(r) for r in tr_model.tracking_rows])
         self.tr.c[:] = t(tr_model.c[0])
         # ---- realised state + annual accumulators (device) -----------------------------------------------------------
@@ -181,7 +185,7 @@ class BatchedWindBatteryDoubleLoop:
         self.delivered = z()
         self._hundred = torch.full((), 100.0, dtype=torch.float64, device=dev)
         self.solves = 0
-        self.use_graphs = bool(use_graphs) and lp_backend is None and not self.warm_start
+        self.use_graphs = bool(use_graphs) and lp_backend is None
         self.use_fused = bool(use_fused) and lp_backend is None and real_time_horizon <= 8 and tracking_horizon <= 8
         if self.use_fused:
             from .hip_solver import DspWbState, load_library
@@ -228,22 +232,22 @@ class BatchedWindBatteryDoubleLoop:
     # -- one simulated day -------------------------------------------------------------------------------------------------
     def _day_ahead_step(self):
         """Device work of the day-ahead bids (capturable: reads / writes persistent tensors only)."""
+        import torch
         m = self.da
         da, rt = self._window(self.da_series, m.T), self._window(self.rt_series, m.T)
         self._set_prices(m, da, rt)
         self._set_state(m)
         m.lb.index_fill_(1, m.pda_cols, 0.0)          # (index_fill_, not lb[:, cols] = 0.0: a Python scalar on the right-hand
         m.ub.index_fill_(1, m.pda_cols, float("inf"))  #  side becomes a host-to-device copy, which a graph capture refuses)
-        if self.warm_start and self.da_prev is not None:
-            x_prev, y_prev, pw = self.da_prev
-            out = m.solve(self.B, x0=x_prev[:, self.da_cmap].contiguous(), y0=y_prev[:, self.da_rmap].contiguous(), primal_weight=pw)
+        if self.warm_start:
+            out = m.solve(self.B, x0=self.da_x0, y0=self.da_y0, primal_weight=self.da_pw)
+            torch.index_select(out["x"], 1, self.da_cmap, out=self.da_x0)
+            torch.index_select(out["y"], 1, self.da_rmap, out=self.da_y0)
         else:
             if not self.weight_only:
                 self.da_pw.zero_()
             out = m.solve(self.B, primal_weight=self.da_pw)
         self._check(out)
-        if self.warm_start:
-            self.da_prev = (out["x"].clone(), out["y"].clone(), self.da_pw)
         self.da_offer.copy_(out["x"][:, m.pda_cols][:, :24])
         self.da_prices.copy_(da[:, :24])
         self.da_energy_mwh += self.da_offer.sum(1)

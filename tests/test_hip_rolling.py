@@ -108,3 +108,31 @@ def test_rolling_hours_are_optimal_for_the_oracles_lps():
     loop = BatchedWindBatteryDoubleLoop(12, device=0, stride=17, use_graphs=False)
     check_rolling_hours_against_the_oracle(loop, hours=8, stride=17)
     assert int(loop.uncertified.item()) == 0
+
+
+@gpu
+@pytest.mark.parametrize("graphs", [False, True])
+def test_day_ahead_warm_start_solves_the_same_lps_in_fewer_iterations(graphs):
+    """Rolling warm start of the 48-h day-ahead LP (yesterday's solution shifted by a day + its primal weight, persistent device
+    buffers, one hipGraph for every day): on day 3 the warm solve reaches the SAME objectives as a cold solve of the same LP data
+    (1e-6), every plant optimal and certified, in fewer iterations on average."""
+    import torch
+    from dispatches_amd.rolling import BatchedWindBatteryDoubleLoop
+    B = 256
+    loop = BatchedWindBatteryDoubleLoop(B, device=0, warm_start=True, use_graphs=graphs)
+    loop.run_day()
+    loop.run_day()
+    loop.day_ahead()                                    # day 3: warm (replayed from the graph when graphs are on)
+    torch.cuda.synchronize()
+    out = loop.da.out
+    obj_w, it_w = out["obj"].cpu().numpy().copy(), out["iters"].cpu().numpy().copy()
+    assert (out["status"].cpu().numpy() == 0).all() and loop.da_x0.abs().sum().item() > 0
+    cold = loop.da.solve(B)                             # the same vectors, cold start, automatic weight
+    torch.cuda.synchronize()
+    obj_c, it_c = cold["obj"].cpu().numpy(), cold["iters"].cpu().numpy()
+    assert (cold["status"].cpu().numpy() == 0).all()
+    err = np.abs(obj_w - obj_c) / np.maximum(1.0, np.abs(obj_c))
+    assert err.max() < 1e-6, err.max()
+    assert it_w.mean() < 0.85 * it_c.mean(), (it_w.mean(), it_c.mean())
+    res, ok = loop.results()
+    assert ok and int(loop.uncertified.item()) == 0

@@ -54,12 +54,16 @@ def test_fused_iteration_reproduces_the_two_launch_form(monkeypatch):
         ref.append(P.solve(tight=True)[1])
     ref = np.array(ref)
     out = {}
-    # fused = k_fused_pre (all loads up front); fused_staged = k_fused (the form for tiles k_fused_pre does not cover);
-    # fused_xcd = k_fused_pre with the XCD-major workgroup order
+    # fused = k_fused_pre (all loads up front, XCD-major workgroup order: the default); fused_staged = k_fused (the form for tiles
+    # k_fused_pre does not cover); fused_grid_order = k_fused_pre with the plain grid order
     for form, env, extra in (("fused", "0", {}), ("fused_staged", "0", {"DSP_FUSED_V": "1"}),
-                             ("fused_xcd", "0", {"DSP_FUSED_XCD": "1"}), ("two_launch", "1", {})):
+                             ("fused_grid_order", "0", {"DSP_FUSED_XCD": "0"}),
+                             # 64-row tiles: 16 tiles = two whole rounds of 8 for the XCD-major order, 3 scenario groups per tile
+                             ("fused_small_tiles", "0", {"DSP_FUSED_RB": "64"}),
+                             ("fused_small_tiles_grid_order", "0", {"DSP_FUSED_RB": "64", "DSP_FUSED_XCD": "0"}),
+                             ("two_launch", "1", {})):
         monkeypatch.setenv("DSP_STREAM_NO_FUSED", env)
-        for k in ("DSP_FUSED_V", "DSP_FUSED_XCD"):
+        for k in ("DSP_FUSED_V", "DSP_FUSED_XCD", "DSP_FUSED_RB"):
             monkeypatch.delenv(k, raising=False)
         for k, v in extra.items():
             monkeypatch.setenv(k, v)
@@ -77,7 +81,10 @@ def test_fused_iteration_reproduces_the_two_launch_form(monkeypatch):
     assert np.allclose(out["fused"][0], out["two_launch"][0], rtol=1e-7, atol=1e-7)
     # the workgroup order does not touch the arithmetic: identical iteration counts and objectives; the staged kernel is a
     # different instruction stream for the same formulas
-    assert (out["fused_xcd"][1] == out["fused"][1]).all() and (out["fused_xcd"][0] == out["fused"][0]).all()
+    assert (out["fused_grid_order"][1] == out["fused"][1]).all() and (out["fused_grid_order"][0] == out["fused"][0]).all()
+    assert (out["fused_small_tiles_grid_order"][1] == out["fused_small_tiles"][1]).all()
+    assert (out["fused_small_tiles_grid_order"][0] == out["fused_small_tiles"][0]).all()
+    assert np.allclose(out["fused_small_tiles"][0], out["fused"][0], rtol=1e-7, atol=1e-7)
     assert np.allclose(out["fused_staged"][0], out["fused"][0], rtol=1e-9, atol=1e-9)
     assert (np.abs(out["fused_staged"][1] - out["fused"][1]) <= 2 * 64).all(), (out["fused_staged"][1], out["fused"][1])
     assert (np.abs(out["fused"][1] - out["two_launch"][1]) <= 0.05 * out["two_launch"][1] + 128).all(), (out["fused"][1], out["two_launch"][1])

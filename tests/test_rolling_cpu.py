@@ -125,3 +125,33 @@ def test_rolling_hours_are_optimal_for_the_oracles_lps_cpu_backend():
     from tests._rolling_oracle import check_rolling_hours_against_the_oracle
     loop = BatchedWindBatteryDoubleLoop(4, stride=17, lp_backend=HighsTensorLP)
     check_rolling_hours_against_the_oracle(loop, hours=5, stride=17)
+
+
+def test_day_ahead_warm_start_buffers_hold_yesterdays_solution_shifted_by_a_day():
+    """warm_start=True: after a day-ahead solve the persistent start buffers hold period t + 24 of its solution in period t
+    (the last 24 periods keep their own values) - columns by their names, whatever order the flattener emitted them in."""
+    import re
+    from dispatches_amd.rolling import BatchedWindBatteryDoubleLoop
+    from tests._highs_solver import HighsTensorLP
+    loop = BatchedWindBatteryDoubleLoop(2, stride=17, lp_backend=HighsTensorLP, warm_start=True)
+    assert not loop.da_x0.any() and not loop.da_y0.any()               # zero = the cold start of the first day
+    loop.day_ahead()
+    x, x0 = loop.da.out["x"].numpy(), loop.da_x0.numpy()
+    names = loop.da.lp.col_names
+    where = {nm: k for k, nm in enumerate(names)}
+    pat = re.compile(r"^(.*)\[(\d+)\]$")
+    shifted = kept = 0
+    for k, nm in enumerate(names):
+        mt = pat.match(nm)
+        src = where.get(f"{mt.group(1)}[{int(mt.group(2)) + 24}]") if mt else None
+        if src is None:
+            assert (x0[:, k] == x[:, k]).all(), nm
+            kept += 1
+        else:
+            assert (x0[:, k] == x[:, src]).all(), nm
+            shifted += 1
+    assert shifted >= 24 * 6 and kept >= 24 * 6
+    # the second day starts from the buffers and is still an optimal day (HiGHS ignores the start point: same offers as cold)
+    cold = BatchedWindBatteryDoubleLoop(2, stride=17, lp_backend=HighsTensorLP)
+    cold.day_ahead()
+    assert np.allclose(cold.da_offer.numpy(), loop.da_offer.numpy())
