@@ -157,10 +157,12 @@ class BatchedWindBatteryDoubleLoop:
         # starts from yesterday's period t + 24 (the last 24 periods keep their own old values); x, y and the primal weight
         # stay on the device (dsp_batch::x0 / y0 / primal_weight) in PERSISTENT buffers that start at zero - which is the cold
         # start (x = clamp(0), y = 0, weight 0 = automatic) - so the first day needs no special case and the day-ahead step is ONE
-        # hipGraph for every day.  Round 2 measured this WORSE (15 k iterations against 4 k, iteration-limit failures: before the
-        # variable scaling and the objective-error termination); round 3 (profiles/r30m_warm_start.log, 1024 plants): mean 2.3 k
-        # against 3.4-3.9 k iterations, slowest plant 6-9 k against 10-14 k, all optimal.  warm_start="weight" carries the primal
-        # weight only (3.0-3.2 k).
+        # hipGraph for every day.  OFF by default.  Round 2 measured it far worse (15 k iterations against 4 k: before the variable
+        # scaling and the objective-error termination).  Round 3 (profiles/r30n_warm_start_60d.log, r30n_double_loop.jsonl: 1024
+        # plants, 60 days): the MEAN drops to 2248 iterations from 3564 (63 %), but a day of the loop is ONE batch whose time is its
+        # slowest plant, and the tail gets heavier - mean daily maximum 10.9 k against 8.5 k iterations, and one plant-day of 61 440
+        # ran into the iteration limit: 14.1 ms per simulated day against 11.8 ms cold.  A caller that pipelines many batches
+        # (throughput, not latency) gets the mean.  warm_start="weight" carries the primal weight only (3.0-3.2 k, r30m).
         from .hip_solver import period_shift_maps
         self.weight_only = warm_start == "weight"
         self.warm_start = bool(warm_start) and not self.weight_only and day_ahead_horizon > 24
