@@ -939,7 +939,9 @@ __global__ void __launch_bounds__(kTB) k_fused(StreamArgs a, FusedIO io, int kof
 // - y, y0 of its rows, x, c, x0 of its columns for SG scenarios, the ELL entries of both, the few halo elements - before the
 // first barrier; after that the workgroup only talks to LDS (y staged, xbar staged) and writes x, y.  MW = the ELL width the
 // register arrays are sized for (4 or 8: at 8 the entries of K = 2 rows + columns alone are 96 VGPRs).
-template <int SG, int K, int MW, bool SHARED, bool QP>
+// DEFER: the ELL entries of the own / halo columns are requested after the first barrier and those of the own rows after the
+// column products (they come from L2, the vectors from HBM): 24 + 12 fewer registers while the HBM loads are in flight.
+template <int SG, int K, int MW, bool SHARED, bool QP, int DEFER = 0>
 __global__ void __launch_bounds__(kTB) k_fused_pre(StreamArgs a, FusedIO io, int kofs) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const StreamProblem &P = a.P;
@@ -1001,11 +1003,13 @@ __global__ void __launch_bounds__(kTB) k_fused_pre(StreamArgs a, FusedIO io, int
       if (QP) kapr[k][u] = a.W.kap[ar];
     }
     if (SHARED) { lbr[k][0] = a.W.lb[jk[k]]; ubr[k][0] = a.W.ub[jk[k]]; rlor[k][0] = a.W.rlo[ik[k]]; rhir[k][0] = a.W.rhi[ik[k]]; }
+    if (!DEFER) {
 #pragma unroll
-    for (int e = 0; e < MW; ++e) {
-      const int ec = min(e, WC - 1), er = min(e, WR - 1);
-      cval[k][e] = P.C.val[(size_t)ec * n + jk[k]]; cgi[k][e] = P.C.idx[(size_t)ec * n + jk[k]];
-      rval[k][e] = P.R.val[(size_t)er * m + ik[k]]; rgi[k][e] = F.ridx_enc[(size_t)er * m + ik[k]];
+      for (int e = 0; e < MW; ++e) {
+        const int ec = min(e, WC - 1), er = min(e, WR - 1);
+        cval[k][e] = P.C.val[(size_t)ec * n + jk[k]]; cgi[k][e] = P.C.idx[(size_t)ec * n + jk[k]];
+        rval[k][e] = P.R.val[(size_t)er * m + ik[k]]; rgi[k][e] = F.ridx_enc[(size_t)er * m + ik[k]];
+      }
     }
   }
   // one halo column and one halo row (staged y only) per thread: at most a few periods' worth (host: halo_max <= 256)
@@ -1025,8 +1029,10 @@ __global__ void __launch_bounds__(kTB) k_fused_pre(StreamArgs a, FusedIO io, int
     if (!SHARED) { hlb[u] = a.W.lb[ac]; hub[u] = a.W.ub[ac]; }
   }
   if (SHARED) { hlb[0] = a.W.lb[hj]; hub[0] = a.W.ub[hj]; }
+  if (!DEFER) {
 #pragma unroll
-  for (int e = 0; e < MW; ++e) { const int ec = min(e, WC - 1); hval[e] = P.C.val[(size_t)ec * n + hj]; hgi[e] = P.C.idx[(size_t)ec * n + hj]; }
+    for (int e = 0; e < MW; ++e) { const int ec = min(e, WC - 1); hval[e] = P.C.val[(size_t)ec * n + hj]; hgi[e] = P.C.idx[(size_t)ec * n + hj]; }
+  }
   // long columns' A^T y from the per-tile partial sums (one wave per (scenario, long column), fixed order)
   for (int q = tid >> 6; q < nlong * SG; q += kTB / 64) {
     const int l = q % nlong, u = q / nlong, lane = tid & 63;
@@ -1063,6 +1069,17 @@ __global__ void __launch_bounds__(kTB) k_fused_pre(StreamArgs a, FusedIO io, int
   }
   __syncthreads();
   // ---- phase C: primal step of the own columns (registers) and of the halo columns -> xbar in LDS; x written ------------------------
+  if (DEFER) {
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+#pragma unroll
+      for (int e = 0; e < MW; ++e) {
+        const int ec = min(e, WC - 1);
+        cval[k][e] = P.C.val[(size_t)ec * n + jk[k]]; cgi[k][e] = P.C.idx[(size_t)ec * n + jk[k]];
+      }
+#pragma unroll
+    for (int e = 0; e < MW; ++e) { const int ec = min(e, WC - 1); hval[e] = P.C.val[(size_t)ec * n + hj]; hgi[e] = P.C.idx[(size_t)ec * n + hj]; }
+  }
 #pragma unroll
   for (int k = 0; k < K; ++k) {
     int cl[MW];
@@ -1095,6 +1112,15 @@ __global__ void __launch_bounds__(kTB) k_fused_pre(StreamArgs a, FusedIO io, int
       const double xp = clampd2(fma(-tau[u], hc[u] - aty, hx[u]), hlb[SHARED ? 0 : u], hub[SHARED ? 0 : u]);
       if (tid < nhc && !hlong) xb[u * NXB + nlong + (hj - c_lo)] = 2.0 * xp - hx[u];
     }
+  }
+  if (DEFER) {                                  // (requested ahead of the barrier: the L2 round trip overlaps the wait)
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+#pragma unroll
+      for (int e = 0; e < MW; ++e) {
+        const int er = min(e, WR - 1);
+        rval[k][e] = P.R.val[(size_t)er * m + ik[k]]; rgi[k][e] = F.ridx_enc[(size_t)er * m + ik[k]];
+      }
   }
   if (tid < nlong * SG) {                       // the long columns this tile owns: their Halpern step (xbar written in phase A)
     const int l = tid % nlong, u = tid / nlong;
@@ -1377,15 +1403,18 @@ static hipError_t run_fused(StreamSolver *S, StreamArgs &a, hipStream_t st, int 
   const int K = (F.own_max + kTB - 1) / kTB;
   const int mw = std::max(P.C.W, P.R.W);
   const bool pre = v_env != 1 && K >= 1 && K <= 3 && mw <= 8 && F.halo_max <= kTB;
-#define DSP_PICK2(KK, MM)                                                                                                            \
-  (shared ? (qp ? reinterpret_cast<const void *>(&k_fused_pre<SG, KK, MM, true, true>) : reinterpret_cast<const void *>(&k_fused_pre<SG, KK, MM, true, false>)) \
-          : (qp ? reinterpret_cast<const void *>(&k_fused_pre<SG, KK, MM, false, true>) : reinterpret_cast<const void *>(&k_fused_pre<SG, KK, MM, false, false>)))
+  const int defer_env = getenv("DSP_FUSED_DEFER") ? atoi(getenv("DSP_FUSED_DEFER")) : 0;
+#define DSP_PICK3(KK, MM, DD)                                                                                                        \
+  (shared ? (qp ? reinterpret_cast<const void *>(&k_fused_pre<SG, KK, MM, true, true, DD>) : reinterpret_cast<const void *>(&k_fused_pre<SG, KK, MM, true, false, DD>)) \
+          : (qp ? reinterpret_cast<const void *>(&k_fused_pre<SG, KK, MM, false, true, DD>) : reinterpret_cast<const void *>(&k_fused_pre<SG, KK, MM, false, false, DD>)))
+#define DSP_PICK2(KK, MM) (defer_env ? DSP_PICK3(KK, MM, 1) : DSP_PICK3(KK, MM, 0))
 #define DSP_PICK(KK) (mw <= 4 ? DSP_PICK2(KK, 4) : DSP_PICK2(KK, 8))
   if (pre) fn = K == 1 ? DSP_PICK(1) : K == 2 ? DSP_PICK(2) : DSP_PICK(3);
   else fn = shared ? (qp ? reinterpret_cast<const void *>(&k_fused<SG, true, true>) : reinterpret_cast<const void *>(&k_fused<SG, true, false>))
                    : (qp ? reinterpret_cast<const void *>(&k_fused<SG, false, true>) : reinterpret_cast<const void *>(&k_fused<SG, false, false>));
 #undef DSP_PICK
 #undef DSP_PICK2
+#undef DSP_PICK3
   hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
   const int xcd_env = getenv("DSP_FUSED_XCD") ? atoi(getenv("DSP_FUSED_XCD")) : 1;   // default on (DSP_FUSED_XCD=0: grid order)
