@@ -941,8 +941,18 @@ __global__ void __launch_bounds__(kTB) k_fused(StreamArgs a, FusedIO io, int kof
 // register arrays are sized for (4 or 8: at 8 the entries of K = 2 rows + columns alone are 96 VGPRs).
 // DEFER: the ELL entries of the own / halo columns are requested after the first barrier and those of the own rows after the
 // column products (they come from L2, the vectors from HBM): 24 + 12 fewer registers while the HBM loads are in flight.
+// Resident waves per SIMD the register allocator is held to (second __launch_bounds__ argument) for the instantiations where it
+// gets there WITHOUT scratch (-Rpass-analysis=kernel-resource-usage): the year-long families run <2, 1, 4, shared, LP> (80 VGPRs = 6
+// waves; 85 unconstrained) and <2, 1, 4, per-scenario bounds, LP> (94 = 5 waves; 99 unconstrained).  Everything else: unconstrained.
+#ifndef DSP_FUSED_WAVES
+#define DSP_FUSED_WAVES 1
+#endif
+constexpr int fused_pre_waves(int sg, int k, int mw, bool shared, bool qp, int defer) {
+  if (!DSP_FUSED_WAVES || !defer || sg != 2 || k != 1 || mw != 4) return 1;
+  return shared ? (qp ? 5 : 6) : (qp ? 1 : 5);
+}
 template <int SG, int K, int MW, bool SHARED, bool QP, int DEFER = 0>
-__global__ void __launch_bounds__(kTB) k_fused_pre(StreamArgs a, FusedIO io, int kofs) {
+__global__ void __launch_bounds__(kTB, fused_pre_waves(SG, K, MW, SHARED, QP, DEFER)) k_fused_pre(StreamArgs a, FusedIO io, int kofs) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const StreamProblem &P = a.P;
   const FusedPlan &F = P.F;
@@ -967,6 +977,9 @@ __global__ void __launch_bounds__(kTB) k_fused_pre(StreamArgs a, FusedIO io, int
   const int32_t *tp = F.tile + 8 * tile;
   const int i0 = tp[0], i1 = tp[1], j0 = tp[2], j1 = tp[3], c_lo = tp[4], c_hi = tp[5], r_lo = tp[6], r_hi = tp[7];
   double *ys = lds, *xb = lds + (size_t)SG * NY, *red = xb + (size_t)SG * NXB;
+  // DEFER: what only the dual step needs is not carried in registers through the column products - y is read back from its staged
+  // copy, y0 (and per-scenario row bounds) wait in a thread-private LDS slot, shared row bounds are requested with the row entries
+  double *park = red + (1 + kTB / 64) * kFusedMaxLong + tid;      // slot q of this thread at park[q * kTB]
   // Phase A is written WITHOUT data-dependent control flow: every load goes to a clamped (always valid) address and is issued
   // before anything that was loaded is looked at; validity (row / column inside the tile, long column, scenario alive) only
   // masks the stores and LDS writes at the end.  The first version predicated each load and turned each loaded index into
@@ -1002,7 +1015,10 @@ __global__ void __launch_bounds__(kTB) k_fused_pre(StreamArgs a, FusedIO io, int
       if (!SHARED) { lbr[k][u] = a.W.lb[ac]; ubr[k][u] = a.W.ub[ac]; rlor[k][u] = a.W.rlo[ar]; rhir[k][u] = a.W.rhi[ar]; }
       if (QP) kapr[k][u] = a.W.kap[ar];
     }
-    if (SHARED) { lbr[k][0] = a.W.lb[jk[k]]; ubr[k][0] = a.W.ub[jk[k]]; rlor[k][0] = a.W.rlo[ik[k]]; rhir[k][0] = a.W.rhi[ik[k]]; }
+    if (SHARED) {
+      lbr[k][0] = a.W.lb[jk[k]]; ubr[k][0] = a.W.ub[jk[k]];
+      if (!DEFER) { rlor[k][0] = a.W.rlo[ik[k]]; rhir[k][0] = a.W.rhi[ik[k]]; }
+    }
     if (!DEFER) {
 #pragma unroll
       for (int e = 0; e < MW; ++e) {
@@ -1037,18 +1053,18 @@ __global__ void __launch_bounds__(kTB) k_fused_pre(StreamArgs a, FusedIO io, int
   for (int q = tid >> 6; q < nlong * SG; q += kTB / 64) {
     const int l = q % nlong, u = q / nlong, lane = tid & 63;
     const double *pp = io.lp_in + ((size_t)su[u] * nlong + l) * F.ntile;
-    // (the column's own x, c and bounds are requested BEFORE the partial sums are added up - every lane the same address - so
-    //  that they arrive with them: loaded by lane 0 after the reduction they were a second memory round trip ahead of the
-    //  workgroup's first barrier)
-    const int j = P.C.long_id[l];
-    const size_t at = (size_t)su[u] * n + j, ab = SHARED ? (size_t)j : at;
-    const double x = io.x_in[at], cj = a.W.c[at], lbj = a.W.lb[ab], ubj = a.W.ub[ab];
+    // (the column's own x, c and bounds are loaded by lane 0 AFTER the reduction: requested up front - one memory round trip
+    //  less for two of the four waves - they changed nothing in the time and cost 8 registers at the kernel's peak, which is
+    //  here: profiles/r30m_fused_ab.log)
     double aty = 0.0;
     for (int t = lane; t < F.ntile; t += 64) aty += pp[t];
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) aty += __shfl_down(aty, off, 64);
     if (lane == 0) {
-      const double xp = clampd2(fma(-tau[u], cj - aty, x), lbj, ubj);
+      const int j = P.C.long_id[l];
+      const size_t at = (size_t)su[u] * n + j, ab = SHARED ? (size_t)j : at;
+      const double x = io.x_in[at];
+      const double xp = clampd2(fma(-tau[u], a.W.c[at] - aty, x), a.W.lb[ab], a.W.ub[ab]);
       xb[u * NXB + l] = 2.0 * xp - x;
     }
   }
@@ -1061,6 +1077,16 @@ __global__ void __launch_bounds__(kTB) k_fused_pre(StreamArgs a, FusedIO io, int
     if (rowok[k]) {
 #pragma unroll
       for (int u = 0; u < SG; ++u) ys[u * NY + (ik[k] - r_lo)] = yr[k][u];
+    }
+    if (DEFER) {
+#pragma unroll
+      for (int u = 0; u < SG; ++u) {
+        park[(size_t)((k * SG + u) * (SHARED ? 1 : 3)) * kTB] = y0r[k][u];
+        if (!SHARED) {
+          park[(size_t)((k * SG + u) * 3 + 1) * kTB] = rlor[k][u];
+          park[(size_t)((k * SG + u) * 3 + 2) * kTB] = rhir[k][u];
+        }
+      }
     }
   }
   if (tid < nhr) {
@@ -1121,6 +1147,10 @@ __global__ void __launch_bounds__(kTB) k_fused_pre(StreamArgs a, FusedIO io, int
         const int er = min(e, WR - 1);
         rval[k][e] = P.R.val[(size_t)er * m + ik[k]]; rgi[k][e] = F.ridx_enc[(size_t)er * m + ik[k]];
       }
+    if (SHARED) {
+#pragma unroll
+      for (int k = 0; k < K; ++k) { rlor[k][0] = a.W.rlo[ik[k]]; rhir[k][0] = a.W.rhi[ik[k]]; }
+    }
   }
   if (tid < nlong * SG) {                       // the long columns this tile owns: their Halpern step (xbar written in phase A)
     const int l = tid % nlong, u = tid / nlong;
@@ -1156,12 +1186,20 @@ __global__ void __launch_bounds__(kTB) k_fused_pre(StreamArgs a, FusedIO io, int
       double ax = 0.0;
 #pragma unroll
       for (int e = 0; e < MW; ++e) ax = fma(rv[e], xv[sl[e]], ax);
-      const double y = yr[k][u];
+      double y, y0v, rlo_, rhi_;
+      if (DEFER) {
+        y = (ys + u * NY)[rowok[k] ? ik[k] - r_lo : 0];
+        y0v = park[(size_t)((k * SG + u) * (SHARED ? 1 : 3)) * kTB];
+        rlo_ = SHARED ? rlor[k][0] : park[(size_t)((k * SG + u) * 3 + 1) * kTB];
+        rhi_ = SHARED ? rhir[k][0] : park[(size_t)((k * SG + u) * 3 + 2) * kTB];
+      } else {
+        y = yr[k][u]; y0v = y0r[k][u]; rlo_ = rlor[k][SHARED ? 0 : u]; rhi_ = rhir[k][SHARED ? 0 : u];
+      }
       const double gy = fma(-sig[u], ax, y);
-      double yp = gy - clampd2(gy, -sig[u] * rhir[k][SHARED ? 0 : u], -sig[u] * rlor[k][SHARED ? 0 : u]);
+      double yp = gy - clampd2(gy, -sig[u] * rhi_, -sig[u] * rlo_);
       if (QP) yp /= fma(sig[u], kapr[k][u], 1.0);
       const double tt = 2.0 * yp - y;
-      const double yn = fma(oml[u], y0r[k][u] - tt, tt);
+      const double yn = fma(oml[u], y0v - tt, tt);
       if (rowok[k] && act[u]) {
         io.y_out[(size_t)su[u] * m + ik[k]] = yn;
 #pragma unroll
@@ -1395,7 +1433,9 @@ static hipError_t run_fused(StreamSolver *S, StreamArgs &a, hipStream_t st, int 
   const dim3 g_fused(groups, F.ntile), g_primal(a.nblk_n + P.C.nchunk, groups);
   const dim3 g_rows_chk(a.nblk + P.R.nlong, groups), g_cols(a.nblk_n + P.C.nlong, groups), g_elem(a.nblk, groups);
   const int fin_c = (P.C.nlong * B + 63) / 64;
-  const size_t lds = ((size_t)SG * (F.ny_max + F.nxb_max) + (1 + kTB / 64) * kFusedMaxLong) * sizeof(double);
+  const int K_own = (F.own_max + kTB - 1) / kTB;
+  // (+ the thread-private slots of k_fused_pre's deferred form: y0, and the row bounds when they differ per scenario)
+  const size_t lds = ((size_t)SG * (F.ny_max + F.nxb_max) + (1 + kTB / 64) * kFusedMaxLong + (size_t)K_own * SG * (shared ? 1 : 3) * kTB) * sizeof(double);
   // k_fused_pre (all loads up front) where a thread can own its K <= 4 rows and columns and the halo columns fit one pass;
   // k_fused (staged phases) otherwise.  DSP_FUSED_V=1 forces the staged form (development).
   const void *fn = nullptr;
@@ -1403,7 +1443,7 @@ static hipError_t run_fused(StreamSolver *S, StreamArgs &a, hipStream_t st, int 
   const int K = (F.own_max + kTB - 1) / kTB;
   const int mw = std::max(P.C.W, P.R.W);
   const bool pre = v_env != 1 && K >= 1 && K <= 3 && mw <= 8 && F.halo_max <= kTB;
-  const int defer_env = getenv("DSP_FUSED_DEFER") ? atoi(getenv("DSP_FUSED_DEFER")) : 0;
+  const int defer_env = getenv("DSP_FUSED_DEFER") ? atoi(getenv("DSP_FUSED_DEFER")) : 1;      // default: deferred form (0: all loads up front)
 #define DSP_PICK3(KK, MM, DD)                                                                                                        \
   (shared ? (qp ? reinterpret_cast<const void *>(&k_fused_pre<SG, KK, MM, true, true, DD>) : reinterpret_cast<const void *>(&k_fused_pre<SG, KK, MM, true, false, DD>)) \
           : (qp ? reinterpret_cast<const void *>(&k_fused_pre<SG, KK, MM, false, true, DD>) : reinterpret_cast<const void *>(&k_fused_pre<SG, KK, MM, false, false, DD>)))

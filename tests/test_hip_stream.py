@@ -58,12 +58,15 @@ def test_fused_iteration_reproduces_the_two_launch_form(monkeypatch):
     # k_fused_pre does not cover); fused_grid_order = k_fused_pre with the plain grid order
     for form, env, extra in (("fused", "0", {}), ("fused_staged", "0", {"DSP_FUSED_V": "1"}),
                              ("fused_grid_order", "0", {"DSP_FUSED_XCD": "0"}),
+                             # every global load ahead of the first barrier (round 3's first form; the default requests the matrix
+                             # entries after the barriers and parks y0 in LDS: fewer registers, more resident waves)
+                             ("fused_loads_up_front", "0", {"DSP_FUSED_DEFER": "0"}),
                              # 64-row tiles: 16 tiles = two whole rounds of 8 for the XCD-major order, 3 scenario groups per tile
                              ("fused_small_tiles", "0", {"DSP_FUSED_RB": "64"}),
                              ("fused_small_tiles_grid_order", "0", {"DSP_FUSED_RB": "64", "DSP_FUSED_XCD": "0"}),
                              ("two_launch", "1", {})):
         monkeypatch.setenv("DSP_STREAM_NO_FUSED", env)
-        for k in ("DSP_FUSED_V", "DSP_FUSED_XCD", "DSP_FUSED_RB"):
+        for k in ("DSP_FUSED_V", "DSP_FUSED_XCD", "DSP_FUSED_RB", "DSP_FUSED_DEFER"):
             monkeypatch.delenv(k, raising=False)
         for k, v in extra.items():
             monkeypatch.setenv(k, v)
@@ -82,6 +85,7 @@ def test_fused_iteration_reproduces_the_two_launch_form(monkeypatch):
     # the workgroup order does not touch the arithmetic: identical iteration counts and objectives; the staged kernel is a
     # different instruction stream for the same formulas
     assert (out["fused_grid_order"][1] == out["fused"][1]).all() and (out["fused_grid_order"][0] == out["fused"][0]).all()
+    assert (out["fused_loads_up_front"][1] == out["fused"][1]).all() and (out["fused_loads_up_front"][0] == out["fused"][0]).all()
     assert (out["fused_small_tiles_grid_order"][1] == out["fused_small_tiles"][1]).all()
     assert (out["fused_small_tiles_grid_order"][0] == out["fused_small_tiles"][0]).all()
     assert np.allclose(out["fused_small_tiles"][0], out["fused"][0], rtol=1e-7, atol=1e-7)
