@@ -85,7 +85,8 @@ def test_fused_iteration_reproduces_the_two_launch_form(monkeypatch):
     # the workgroup order does not touch the arithmetic: identical iteration counts and objectives; the staged kernel is a
     # different instruction stream for the same formulas
     assert (out["fused_grid_order"][1] == out["fused"][1]).all() and (out["fused_grid_order"][0] == out["fused"][0]).all()
-    assert (out["fused_loads_up_front"][1] == out["fused"][1]).all() and (out["fused_loads_up_front"][0] == out["fused"][0]).all()
+    assert np.allclose(out["fused_loads_up_front"][0], out["fused"][0], rtol=1e-9, atol=1e-9)
+    assert (np.abs(out["fused_loads_up_front"][1] - out["fused"][1]) <= 2 * 64).all()
     assert (out["fused_small_tiles_grid_order"][1] == out["fused_small_tiles"][1]).all()
     assert (out["fused_small_tiles_grid_order"][0] == out["fused_small_tiles"][0]).all()
     assert np.allclose(out["fused_small_tiles"][0], out["fused"][0], rtol=1e-7, atol=1e-7)
