@@ -37,6 +37,7 @@
 
 #include "dsp_device.hpp"
 #include "dsp_stream.hpp"
+#include "dsp_wave.hpp"
 
 namespace dsp {
 
@@ -979,7 +980,7 @@ __global__ void __launch_bounds__(kTB, fused_pre_waves(SG, K, MW, SHARED, QP, DE
   double *ys = lds, *xb = lds + (size_t)SG * NY, *red = xb + (size_t)SG * NXB;
   // DEFER: what only the dual step needs is not carried in registers through the column products - y is read back from its staged
   // copy, y0 (and per-scenario row bounds) wait in a thread-private LDS slot, shared row bounds are requested with the row entries
-  double *park = red + (1 + kTB / 64) * kFusedMaxLong + tid;      // slot q of this thread at park[q * kTB]
+  double *park = red + (1 + kTB / 64) * kFusedMaxLong * SG + tid;  // slot q of this thread at park[q * kTB]
   // Phase A is written WITHOUT data-dependent control flow: every load goes to a clamped (always valid) address and is issued
   // before anything that was loaded is looked at; validity (row / column inside the tile, long column, scenario alive) only
   // masks the stores and LDS writes at the end.  The first version predicated each load and turned each loaded index into
@@ -1202,21 +1203,44 @@ __global__ void __launch_bounds__(kTB, fused_pre_waves(SG, K, MW, SHARED, QP, DE
       const double yn = fma(oml[u], y0v - tt, tt);
       if (rowok[k] && act[u]) {
         io.y_out[(size_t)su[u] * m + ik[k]] = yn;
+        // this row's terms of A^T y for the long columns.  ONE long column (the design variable of the price-taker families) is the
+        // common case: whatever entry is long belongs to it - the select over kFusedMaxLong accumulators per entry was a sixth of
+        // the kernel's VALU instructions (ISA count: 83 v_cndmask + 33 v_cmp + 32 of the v_add_f64 in this phase)
+        if (nlong == 1) {
 #pragma unroll
-        for (int e = 0; e < MW; ++e) {
-          const double w = (rgi[k][e] < 0 && e < WR) ? rv[e] * yn : 0.0;
+          for (int e = 0; e < MW; ++e) lp[u][0] += (rgi[k][e] < 0 && e < WR) ? rv[e] * yn : 0.0;
+        } else if (nlong > 1) {
 #pragma unroll
-          for (int q = 0; q < kFusedMaxLong; ++q) lp[u][q] += (sl[e] == q) ? w : 0.0;
+          for (int e = 0; e < MW; ++e) {
+            const double w = (rgi[k][e] < 0 && e < WR) ? rv[e] * yn : 0.0;
+#pragma unroll
+            for (int q = 0; q < kFusedMaxLong; ++q) lp[u][q] += (sl[e] == q) ? w : 0.0;
+          }
         }
       }
     }
   }
   if (nlong > 0) {
+    // block sums of the SG x nlong partial sums: wave totals on the VALU (DPP), ONE barrier, thread (u, q) adds the four wave totals
+    // in wave order and writes the tile's partial sum (fixed order: bit-reproducible)
+    const int lane = tid & 63, wave = tid >> 6;
 #pragma unroll
-    for (int u = 0; u < SG; ++u) {
-      fused_reduce_long(lp[u], nlong, red);
-      if (tid < nlong && act[u]) io.lp_out[((size_t)su[u] * nlong + tid) * F.ntile + tile] = red[tid];
-      __syncthreads();
+    for (int u = 0; u < SG; ++u)
+#pragma unroll
+      for (int q = 0; q < kFusedMaxLong; ++q)
+        if (q < nlong) {
+          const double t = wave_sum(lp[u][q]);
+          if (lane == 0) red[(wave * SG + u) * kFusedMaxLong + q] = t;
+        }
+    __syncthreads();
+    if (tid < SG * kFusedMaxLong) {
+      const int u = tid / kFusedMaxLong, q = tid % kFusedMaxLong;
+      if (q < nlong && act[u]) {
+        double t = 0.0;
+#pragma unroll
+        for (int w = 0; w < kTB / 64; ++w) t += red[(w * SG + u) * kFusedMaxLong + q];
+        io.lp_out[((size_t)su[u] * nlong + q) * F.ntile + tile] = t;
+      }
     }
   }
 }
@@ -1435,7 +1459,7 @@ static hipError_t run_fused(StreamSolver *S, StreamArgs &a, hipStream_t st, int 
   const int fin_c = (P.C.nlong * B + 63) / 64;
   const int K_own = (F.own_max + kTB - 1) / kTB;
   // (+ the thread-private slots of k_fused_pre's deferred form: y0, and the row bounds when they differ per scenario)
-  const size_t lds = ((size_t)SG * (F.ny_max + F.nxb_max) + (1 + kTB / 64) * kFusedMaxLong + (size_t)K_own * SG * (shared ? 1 : 3) * kTB) * sizeof(double);
+  const size_t lds = ((size_t)SG * (F.ny_max + F.nxb_max) + (1 + kTB / 64) * kFusedMaxLong * SG + (size_t)K_own * SG * (shared ? 1 : 3) * kTB) * sizeof(double);
   // k_fused_pre (all loads up front) where a thread can own its K <= 4 rows and columns and the halo columns fit one pass;
   // k_fused (staged phases) otherwise.  DSP_FUSED_V=1 forces the staged form (development).
   const void *fn = nullptr;
