@@ -33,6 +33,7 @@
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 #include <vector>
 
 #include "dsp_device.hpp"
@@ -948,6 +949,14 @@ __global__ void __launch_bounds__(kTB) k_fused(StreamArgs a, FusedIO io, int kof
 #ifndef DSP_FUSED_WAVES
 #define DSP_FUSED_WAVES 1
 #endif
+// element `off` of a global array through a byte offset computed in the offset's OWN width: with 32-bit offsets (deferred form; the
+// host checks that every array of the solve stays below 4 GiB) a load is `global_load v, v_off, s[base]` - one 32-bit register and no
+// 64-bit address arithmetic per access (33 v_lshl_add_u64 + 18 other 64-bit VALU instructions per phase before)
+template <class T, class O>
+__device__ __forceinline__ T &gat(T *base, O off) {
+  using C = typename std::conditional<std::is_const<T>::value, const char, char>::type;
+  return *reinterpret_cast<T *>(reinterpret_cast<C *>(base) + (size_t)(O)(off * (O)sizeof(T)));
+}
 constexpr int fused_pre_waves(int sg, int k, int mw, bool shared, bool qp, int defer) {
   if (!DSP_FUSED_WAVES || !defer || sg != 2 || k != 1 || mw != 4) return 1;
   return shared ? (qp ? 5 : 6) : (qp ? 1 : 5);
@@ -955,6 +964,7 @@ constexpr int fused_pre_waves(int sg, int k, int mw, bool shared, bool qp, int d
 template <int SG, int K, int MW, bool SHARED, bool QP, int DEFER = 0>
 __global__ void __launch_bounds__(kTB, fused_pre_waves(SG, K, MW, SHARED, QP, DEFER)) k_fused_pre(StreamArgs a, FusedIO io, int kofs) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
+  using off_t = typename std::conditional<(DEFER != 0), uint32_t, size_t>::type;
   const StreamProblem &P = a.P;
   const FusedPlan &F = P.F;
   const int n = P.n, m = P.m, nlong = P.C.nlong, NY = F.ny_max, NXB = F.nxb_max, WC = P.C.W, WR = P.R.W;
@@ -979,7 +989,7 @@ __global__ void __launch_bounds__(kTB, fused_pre_waves(SG, K, MW, SHARED, QP, DE
   const int i0 = tp[0], i1 = tp[1], j0 = tp[2], j1 = tp[3], c_lo = tp[4], c_hi = tp[5], r_lo = tp[6], r_hi = tp[7];
   double *ys = lds, *xb = lds + (size_t)SG * NY, *red = xb + (size_t)SG * NXB;
   // DEFER: what only the dual step needs is not carried in registers through the column products - y is read back from its staged
-  // copy, y0 (and per-scenario row bounds) wait in a thread-private LDS slot, shared row bounds are requested with the row entries
+  // copy, y0, x0 (and per-scenario row bounds) wait in thread-private LDS slots, shared row bounds are requested with the row entries
   double *park = red + (1 + kTB / 64) * kFusedMaxLong * SG + tid;  // slot q of this thread at park[q * kTB]
   // Phase A is written WITHOUT data-dependent control flow: every load goes to a clamped (always valid) address and is issued
   // before anything that was loaded is looked at; validity (row / column inside the tile, long column, scenario alive) only
@@ -1007,25 +1017,25 @@ __global__ void __launch_bounds__(kTB, fused_pre_waves(SG, K, MW, SHARED, QP, DE
   for (int k = 0; k < K; ++k) {
     ik[k] = min(i0 + tid + k * kTB, m - 1);
     jk[k] = min(j0 + tid + k * kTB, n - 1);
-    clong[k] = P.C.is_long[jk[k]];
+    clong[k] = gat(P.C.is_long, (off_t)jk[k]);
 #pragma unroll
     for (int u = 0; u < SG; ++u) {
-      const size_t ar = (size_t)su[u] * m + ik[k], ac = (size_t)su[u] * n + jk[k];
-      yr[k][u] = io.y_in[ar]; y0r[k][u] = a.W.y0[ar];
-      xr[k][u] = io.x_in[ac]; cr[k][u] = a.W.c[ac]; x0r[k][u] = a.W.x0[ac];
-      if (!SHARED) { lbr[k][u] = a.W.lb[ac]; ubr[k][u] = a.W.ub[ac]; rlor[k][u] = a.W.rlo[ar]; rhir[k][u] = a.W.rhi[ar]; }
-      if (QP) kapr[k][u] = a.W.kap[ar];
+      const off_t ar = (off_t)su[u] * (off_t)m + (off_t)ik[k], ac = (off_t)su[u] * (off_t)n + (off_t)jk[k];
+      yr[k][u] = gat(io.y_in, ar); y0r[k][u] = gat(a.W.y0, ar);
+      xr[k][u] = gat(io.x_in, ac); cr[k][u] = gat(a.W.c, ac); x0r[k][u] = gat(a.W.x0, ac);
+      if (!SHARED) { lbr[k][u] = gat(a.W.lb, ac); ubr[k][u] = gat(a.W.ub, ac); rlor[k][u] = gat(a.W.rlo, ar); rhir[k][u] = gat(a.W.rhi, ar); }
+      if (QP) kapr[k][u] = gat(a.W.kap, ar);
     }
     if (SHARED) {
-      lbr[k][0] = a.W.lb[jk[k]]; ubr[k][0] = a.W.ub[jk[k]];
-      if (!DEFER) { rlor[k][0] = a.W.rlo[ik[k]]; rhir[k][0] = a.W.rhi[ik[k]]; }
+      lbr[k][0] = gat(a.W.lb, (off_t)jk[k]); ubr[k][0] = gat(a.W.ub, (off_t)jk[k]);
+      if (!DEFER) { rlor[k][0] = gat(a.W.rlo, (off_t)ik[k]); rhir[k][0] = gat(a.W.rhi, (off_t)ik[k]); }
     }
     if (!DEFER) {
 #pragma unroll
       for (int e = 0; e < MW; ++e) {
-        const int ec = min(e, WC - 1), er = min(e, WR - 1);
-        cval[k][e] = P.C.val[(size_t)ec * n + jk[k]]; cgi[k][e] = P.C.idx[(size_t)ec * n + jk[k]];
-        rval[k][e] = P.R.val[(size_t)er * m + ik[k]]; rgi[k][e] = F.ridx_enc[(size_t)er * m + ik[k]];
+        const off_t oc = (off_t)min(e, WC - 1) * (off_t)n + (off_t)jk[k], orow = (off_t)min(e, WR - 1) * (off_t)m + (off_t)ik[k];
+        cval[k][e] = gat(P.C.val, oc); cgi[k][e] = gat(P.C.idx, oc);
+        rval[k][e] = gat(P.R.val, orow); rgi[k][e] = gat(F.ridx_enc, orow);
       }
     }
   }
@@ -1037,18 +1047,18 @@ __global__ void __launch_bounds__(kTB, fused_pre_waves(SG, K, MW, SHARED, QP, DE
   const int hj = tid < nhc ? min(tid < j0 - c_lo ? c_lo + tid : j1 + (tid - (j0 - c_lo)), n - 1) : c_lo;
   double hy[SG], hx[SG], hc[SG], hlb[SHARED ? 1 : SG], hub[SHARED ? 1 : SG], hval[MW];
   int hgi[MW];
-  const unsigned char hlong = P.C.is_long[hj];
+  const unsigned char hlong = gat(P.C.is_long, (off_t)hj);
 #pragma unroll
   for (int u = 0; u < SG; ++u) {
-    hy[u] = io.y_in[(size_t)su[u] * m + hi_];
-    const size_t ac = (size_t)su[u] * n + hj;
-    hx[u] = io.x_in[ac]; hc[u] = a.W.c[ac];
-    if (!SHARED) { hlb[u] = a.W.lb[ac]; hub[u] = a.W.ub[ac]; }
+    hy[u] = gat(io.y_in, (off_t)su[u] * (off_t)m + (off_t)hi_);
+    const off_t ac = (off_t)su[u] * (off_t)n + (off_t)hj;
+    hx[u] = gat(io.x_in, ac); hc[u] = gat(a.W.c, ac);
+    if (!SHARED) { hlb[u] = gat(a.W.lb, ac); hub[u] = gat(a.W.ub, ac); }
   }
-  if (SHARED) { hlb[0] = a.W.lb[hj]; hub[0] = a.W.ub[hj]; }
+  if (SHARED) { hlb[0] = gat(a.W.lb, (off_t)hj); hub[0] = gat(a.W.ub, (off_t)hj); }
   if (!DEFER) {
 #pragma unroll
-    for (int e = 0; e < MW; ++e) { const int ec = min(e, WC - 1); hval[e] = P.C.val[(size_t)ec * n + hj]; hgi[e] = P.C.idx[(size_t)ec * n + hj]; }
+    for (int e = 0; e < MW; ++e) { const off_t oc = (off_t)min(e, WC - 1) * (off_t)n + (off_t)hj; hval[e] = gat(P.C.val, oc); hgi[e] = gat(P.C.idx, oc); }
   }
   // long columns' A^T y from the per-tile partial sums (one wave per (scenario, long column), fixed order)
   for (int q = tid >> 6; q < nlong * SG; q += kTB / 64) {
@@ -1082,10 +1092,11 @@ __global__ void __launch_bounds__(kTB, fused_pre_waves(SG, K, MW, SHARED, QP, DE
     if (DEFER) {
 #pragma unroll
       for (int u = 0; u < SG; ++u) {
-        park[(size_t)((k * SG + u) * (SHARED ? 1 : 3)) * kTB] = y0r[k][u];
+        park[(size_t)((k * SG + u) * (SHARED ? 2 : 4)) * kTB] = y0r[k][u];
+        park[(size_t)((k * SG + u) * (SHARED ? 2 : 4) + 1) * kTB] = x0r[k][u];
         if (!SHARED) {
-          park[(size_t)((k * SG + u) * 3 + 1) * kTB] = rlor[k][u];
-          park[(size_t)((k * SG + u) * 3 + 2) * kTB] = rhir[k][u];
+          park[(size_t)((k * SG + u) * 4 + 2) * kTB] = rlor[k][u];
+          park[(size_t)((k * SG + u) * 4 + 3) * kTB] = rhir[k][u];
         }
       }
     }
@@ -1101,11 +1112,11 @@ __global__ void __launch_bounds__(kTB, fused_pre_waves(SG, K, MW, SHARED, QP, DE
     for (int k = 0; k < K; ++k)
 #pragma unroll
       for (int e = 0; e < MW; ++e) {
-        const int ec = min(e, WC - 1);
-        cval[k][e] = P.C.val[(size_t)ec * n + jk[k]]; cgi[k][e] = P.C.idx[(size_t)ec * n + jk[k]];
+        const off_t oc = (off_t)min(e, WC - 1) * (off_t)n + (off_t)jk[k];
+        cval[k][e] = gat(P.C.val, oc); cgi[k][e] = gat(P.C.idx, oc);
       }
 #pragma unroll
-    for (int e = 0; e < MW; ++e) { const int ec = min(e, WC - 1); hval[e] = P.C.val[(size_t)ec * n + hj]; hgi[e] = P.C.idx[(size_t)ec * n + hj]; }
+    for (int e = 0; e < MW; ++e) { const off_t oc = (off_t)min(e, WC - 1) * (off_t)n + (off_t)hj; hval[e] = gat(P.C.val, oc); hgi[e] = gat(P.C.idx, oc); }
   }
 #pragma unroll
   for (int k = 0; k < K; ++k) {
@@ -1122,7 +1133,10 @@ __global__ void __launch_bounds__(kTB, fused_pre_waves(SG, K, MW, SHARED, QP, DE
       const double tt = 2.0 * xp - xr[k][u];
       if (colok[k]) {
         xb[u * NXB + nlong + (jk[k] - c_lo)] = tt;
-        if (act[u]) io.x_out[(size_t)su[u] * n + jk[k]] = fma(oml[u], x0r[k][u] - tt, tt);
+        if (act[u]) {
+          const double x0v = DEFER ? park[(size_t)((k * SG + u) * (SHARED ? 2 : 4) + 1) * kTB] : x0r[k][u];
+          gat(io.x_out, (off_t)su[u] * (off_t)n + (off_t)jk[k]) = fma(oml[u], x0v - tt, tt);
+        }
       }
     }
   }
@@ -1145,12 +1159,12 @@ __global__ void __launch_bounds__(kTB, fused_pre_waves(SG, K, MW, SHARED, QP, DE
     for (int k = 0; k < K; ++k)
 #pragma unroll
       for (int e = 0; e < MW; ++e) {
-        const int er = min(e, WR - 1);
-        rval[k][e] = P.R.val[(size_t)er * m + ik[k]]; rgi[k][e] = F.ridx_enc[(size_t)er * m + ik[k]];
+        const off_t orow = (off_t)min(e, WR - 1) * (off_t)m + (off_t)ik[k];
+        rval[k][e] = gat(P.R.val, orow); rgi[k][e] = gat(F.ridx_enc, orow);
       }
     if (SHARED) {
 #pragma unroll
-      for (int k = 0; k < K; ++k) { rlor[k][0] = a.W.rlo[ik[k]]; rhir[k][0] = a.W.rhi[ik[k]]; }
+      for (int k = 0; k < K; ++k) { rlor[k][0] = gat(a.W.rlo, (off_t)ik[k]); rhir[k][0] = gat(a.W.rhi, (off_t)ik[k]); }
     }
   }
   if (tid < nlong * SG) {                       // the long columns this tile owns: their Halpern step (xbar written in phase A)
@@ -1190,9 +1204,9 @@ __global__ void __launch_bounds__(kTB, fused_pre_waves(SG, K, MW, SHARED, QP, DE
       double y, y0v, rlo_, rhi_;
       if (DEFER) {
         y = (ys + u * NY)[rowok[k] ? ik[k] - r_lo : 0];
-        y0v = park[(size_t)((k * SG + u) * (SHARED ? 1 : 3)) * kTB];
-        rlo_ = SHARED ? rlor[k][0] : park[(size_t)((k * SG + u) * 3 + 1) * kTB];
-        rhi_ = SHARED ? rhir[k][0] : park[(size_t)((k * SG + u) * 3 + 2) * kTB];
+        y0v = park[(size_t)((k * SG + u) * (SHARED ? 2 : 4)) * kTB];
+        rlo_ = SHARED ? rlor[k][0] : park[(size_t)((k * SG + u) * 4 + 2) * kTB];
+        rhi_ = SHARED ? rhir[k][0] : park[(size_t)((k * SG + u) * 4 + 3) * kTB];
       } else {
         y = yr[k][u]; y0v = y0r[k][u]; rlo_ = rlor[k][SHARED ? 0 : u]; rhi_ = rhir[k][SHARED ? 0 : u];
       }
@@ -1202,7 +1216,7 @@ __global__ void __launch_bounds__(kTB, fused_pre_waves(SG, K, MW, SHARED, QP, DE
       const double tt = 2.0 * yp - y;
       const double yn = fma(oml[u], y0v - tt, tt);
       if (rowok[k] && act[u]) {
-        io.y_out[(size_t)su[u] * m + ik[k]] = yn;
+        gat(io.y_out, (off_t)su[u] * (off_t)m + (off_t)ik[k]) = yn;
         // this row's terms of A^T y for the long columns.  ONE long column (the design variable of the price-taker families) is the
         // common case: whatever entry is long belongs to it - the select over kFusedMaxLong accumulators per entry was a sixth of
         // the kernel's VALU instructions (ISA count: 83 v_cndmask + 33 v_cmp + 32 of the v_add_f64 in this phase)
@@ -1458,8 +1472,8 @@ static hipError_t run_fused(StreamSolver *S, StreamArgs &a, hipStream_t st, int 
   const dim3 g_rows_chk(a.nblk + P.R.nlong, groups), g_cols(a.nblk_n + P.C.nlong, groups), g_elem(a.nblk, groups);
   const int fin_c = (P.C.nlong * B + 63) / 64;
   const int K_own = (F.own_max + kTB - 1) / kTB;
-  // (+ the thread-private slots of k_fused_pre's deferred form: y0, and the row bounds when they differ per scenario)
-  const size_t lds = ((size_t)SG * (F.ny_max + F.nxb_max) + (1 + kTB / 64) * kFusedMaxLong * SG + (size_t)K_own * SG * (shared ? 1 : 3) * kTB) * sizeof(double);
+  // (+ the thread-private slots of k_fused_pre's deferred form: y0, x0, and the row bounds when they differ per scenario)
+  const size_t lds = ((size_t)SG * (F.ny_max + F.nxb_max) + (1 + kTB / 64) * kFusedMaxLong * SG + (size_t)K_own * SG * (shared ? 2 : 4) * kTB) * sizeof(double);
   // k_fused_pre (all loads up front) where a thread can own its K <= 4 rows and columns and the halo columns fit one pass;
   // k_fused (staged phases) otherwise.  DSP_FUSED_V=1 forces the staged form (development).
   const void *fn = nullptr;
@@ -1467,7 +1481,9 @@ static hipError_t run_fused(StreamSolver *S, StreamArgs &a, hipStream_t st, int 
   const int K = (F.own_max + kTB - 1) / kTB;
   const int mw = std::max(P.C.W, P.R.W);
   const bool pre = v_env != 1 && K >= 1 && K <= 3 && mw <= 8 && F.halo_max <= kTB;
-  const int defer_env = getenv("DSP_FUSED_DEFER") ? atoi(getenv("DSP_FUSED_DEFER")) : 1;      // default: deferred form (0: all loads up front)
+  // the deferred form addresses with 32-bit byte offsets: every array it touches must stay below 4 GiB
+  const bool narrow_ok = (uint64_t)std::max(B, mw) * (uint64_t)std::max(P.n, P.m) * 8ull < (1ull << 32);
+  const int defer_env = (getenv("DSP_FUSED_DEFER") ? atoi(getenv("DSP_FUSED_DEFER")) : 1) && narrow_ok;   // default: deferred form (0: all loads up front)
 #define DSP_PICK3(KK, MM, DD)                                                                                                        \
   (shared ? (qp ? reinterpret_cast<const void *>(&k_fused_pre<SG, KK, MM, true, true, DD>) : reinterpret_cast<const void *>(&k_fused_pre<SG, KK, MM, true, false, DD>)) \
           : (qp ? reinterpret_cast<const void *>(&k_fused_pre<SG, KK, MM, false, true, DD>) : reinterpret_cast<const void *>(&k_fused_pre<SG, KK, MM, false, false, DD>)))
