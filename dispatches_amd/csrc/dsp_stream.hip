@@ -1596,6 +1596,16 @@ static hipError_t stream_solve_locked(StreamSolver *S, const dsp_batch &batch, c
     if ((long)S->P.F.ntile * ((B + 1) / 2) < 1024) fsg = 1;      // 250-row tiles (81 vs 89-91 us at 4, 102 at 1: profiles/r30j_fused_scan.log)
     static const int fsg_env = getenv("DSP_FUSED_SG") ? atoi(getenv("DSP_FUSED_SG")) : 0;
     if (fsg_env == 1 || fsg_env == 2 || fsg_env == 4) fsg = fsg_env;
+    // the workgroup's LDS (staged y + xbar per scenario, the deferred form's thread-private slots) must fit a CU's 160 KB: plans
+    // with wide hulls (the host admits up to 40 KB per scenario) run with fewer scenarios per workgroup
+    {
+      const FusedPlan &F = S->P.F;
+      const size_t k_own = (size_t)(F.own_max + kTB - 1) / kTB;
+      auto lds_need = [&](int g) {
+        return ((size_t)g * (F.ny_max + F.nxb_max) + (size_t)(1 + kTB / 64) * kFusedMaxLong * g + k_own * g * (shared ? 2 : 4) * kTB) * sizeof(double);
+      };
+      while (fsg > 1 && lds_need(fsg) > (size_t)160 * 1024) fsg /= 2;
+    }
     S->last_bytes_per_iteration = (size_t)8 * (shared ? 4 * (size_t)S->P.n + 3 * (size_t)S->P.m : 6 * (size_t)S->P.n + 5 * (size_t)S->P.m)
                                   + (qp ? 8 * (size_t)S->P.m : 0);
     if (fsg == 4) e = run_fused<4>(S, a, st, periods_run, shared, qp);
