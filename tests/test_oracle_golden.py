@@ -102,6 +102,53 @@ def test_G7_battery_rows(golden):
     assert x[v["E"]] == pytest.approx(b["throughput"], rel=1e-3)
 
 
+def test_G12_nuclear_unit_rows(golden):
+    # the PEM conversion and the simplified tank's holdup balance of the nuclear flowsheet, at the reference's own test points
+    g = golden["G12_nuclear_unit_rows"]
+    pem_kw = g["np_capacity_mw"] * 1e3 * (1 - g["split_frac_grid"])
+    assert pem_kw * orc.NUC_PEM_MOL_PER_KW_S == pytest.approx(g["pem_outlet_flow_mol"], rel=1e-6)
+    lp = orc._LP()
+    fs = orc.nuclear_rows(lp, 1, holdup0=0.0, h2_demand=1e9)
+    v = fs["vars"][0]
+    lp.lb[v["p"]] = lp.ub[v["p"]] = pem_kw
+    lp.lb[v["f"]] = lp.ub[v["f"]] = g["flow_mol_to_pipeline"]
+    x, _ = orc.PreparedLP(lp).solve()
+    assert x[v["g"]] == pytest.approx(orc.NP_CAPACITY_KW - pem_kw)       # splitter row (the double-loop plant is 500 MW, the test's 1000)
+    assert x[v["h"]] == pytest.approx(g["tank_holdup_after_one_hour_mol"], rel=1e-9)
+    # the same two rows at the unit tests' points: 25 mol/s in = p k, 20 mol/s out, one hour
+    tk = g["tank_unit"]
+    lp = orc._LP()
+    fs = orc.nuclear_rows(lp, 1, holdup0=tk["holdup_previous"], h2_demand=1e9)
+    v = fs["vars"][0]
+    lp.lb[v["p"]] = lp.ub[v["p"]] = tk["inlet_mol_s"] / orc.NUC_PEM_MOL_PER_KW_S
+    lp.lb[v["f"]] = lp.ub[v["f"]] = sum(tk["outlets_mol_s"])
+    x, _ = orc.PreparedLP(lp).solve()
+    assert x[v["h"]] == pytest.approx(tk["tank_holdup"], rel=1e-9)
+
+
+def test_G12_nuclear_unit_rows_in_the_product_flowsheet(golden):
+    """The product's own restatement of the two rows (flowsheets/units.py, parameters.py) at the same reference points."""
+    from scipy.optimize import linprog
+    from dispatches_amd.flowsheets import parameters as prm
+    from dispatches_amd.flowsheets.units import hydrogen_tank
+    from dispatches_amd.lp import LinearBlock
+    g = golden["G12_nuclear_unit_rows"]
+    pem_kw = g["np_capacity_mw"] * 1e3 * (1 - g["split_frac_grid"])
+    assert prm.nuclear_pem_electricity_to_mol * pem_kw == pytest.approx(g["pem_outlet_flow_mol"], rel=1e-6)
+    for inlet_mol_s, out_mol_s, want in ((prm.nuclear_pem_electricity_to_mol * pem_kw, g["flow_mol_to_pipeline"], g["tank_holdup_after_one_hour_mol"]),
+                                         (g["tank_unit"]["inlet_mol_s"], sum(g["tank_unit"]["outlets_mol_s"]), g["tank_unit"]["tank_holdup"])):
+        b = LinearBlock()
+        inlet = b.var("inlet", inlet_mol_s, inlet_mol_s)
+        prev = b.var("prev", 0.0, 0.0)
+        tank = hydrogen_tank(b, 0, prev, inlet, dt_s=3600.0, demand_ub_mol_s=out_mol_s)
+        lp = b.flatten()
+        lb, ub = np.array(lp.lb, float), np.array(lp.ub, float)
+        lb[tank["outlet_to_pipeline"].index] = out_mol_s
+        A = lp.csr()
+        res = linprog(np.zeros(lp.n), A_eq=A, b_eq=np.asarray(lp.rlo, float), bounds=list(zip(lb, ub)), method="highs")
+        assert res.status == 0 and res.x[tank["tank_holdup"].index] == pytest.approx(want, rel=1e-9)
+
+
 def test_marginal_to_actual_costs(golden, rts309):
     # test_wind_PEM_double_loop.py:211-213 pins cumulative sum(mc * dP)
     g = golden["G3d_pem_parametrized_rt_last_cost"]["values"]
