@@ -118,6 +118,25 @@ class PyomoLP:
         self.flatten()
 
     # ---- walking ------------------------------------------------------------------------------------------------------
+    def scaling_factors(self):
+        """The model's own scaling factors of the flattened columns (Pyomo `scaling_factor` Suffix on the variable's parent
+        block, where IDAES' `iscale.set_scaling_factor` puts them; the indexed parent component's entry as a fallback): array
+        [n] with 1 where a variable has none, or None when no variable has one."""
+        out, found = np.ones(len(self._vars)), False
+        for j, v in enumerate(self._vars):
+            try:
+                suffix = getattr(v.parent_block(), "scaling_factor", None)
+            except AttributeError:
+                suffix = None
+            if suffix is None:
+                continue
+            val = suffix.get(v, None)
+            if val is None and hasattr(v, "parent_component"):
+                val = suffix.get(v.parent_component(), None)
+            if val is not None and float(val) > 0.0:
+                out[j], found = float(val), True
+        return out if found else None
+
     def _active_objective(self):
         if self._objective is not None:
             return self._objective
@@ -282,7 +301,7 @@ class PyomoScenarioBatch:
     differ in what a batch may differ in: objective vector and constant, variable bounds, row bounds."""
 
     def __init__(self, blocks, objectives=None, ctypes=None, generate_standard_repn: Optional[Callable] = None,
-                 solver_hints: Optional[dict] = None):
+                 solver_hints: Optional[dict] = None, column_scaling: Optional[str] = "auto"):
         blocks = list(blocks)
         if not blocks:
             raise ValueError("no scenario blocks")
@@ -302,6 +321,33 @@ class PyomoScenarioBatch:
         self.solve_handle = None
         self.x = self.y = self.objective = self.status = self.iterations = None
         self._stack()
+        self.column_scaling = column_scaling
+        self.lp.col_scale = self._column_scales(column_scaling)
+
+    def _column_scales(self, mode):
+        """Variable scaling factors for the solver (dsp_lp_desc::col_scale = typical magnitude of every column), so that a
+        flowsheet handed over as a Pyomo model gets what the product's own model objects give their LPs (Bidder, column_scaling =
+        "implied_ranges") without per-model hints:
+          "suffix"          the reciprocals of the scaling factors the model carries (IDAES: `iscale.set_scaling_factor(var, s)` =
+                            `var.parent_block().scaling_factor[var] = s`; 1 where a variable has none)
+          "implied_ranges"  dispatches_amd.lp.implied_column_ranges over the batch's current bounds
+          "auto" (default)  the suffix if any variable carries a factor other than 1, else the implied ranges for LPs beyond the
+                            in-wave simplex (n + m > 128), else none
+          None              none."""
+        if mode is None:
+            return None
+        if mode not in ("auto", "suffix", "implied_ranges"):
+            raise ValueError(f"column_scaling = {mode!r}")
+        if mode in ("auto", "suffix"):
+            sf = self.views[0].scaling_factors()
+            if sf is not None and (mode == "suffix" or np.any(sf != 1.0)):
+                return 1.0 / sf
+            if mode == "suffix":
+                return None
+        if mode == "implied_ranges" or self.lp.n + self.lp.m > 128:
+            from .lp import implied_column_ranges
+            return implied_column_ranges(self.lp, self.lb, self.ub)
+        return None
 
     def _stack(self):
         vs = self.views
@@ -343,8 +389,9 @@ class HipPyomoSolver:
     docstring)."""
 
     def __init__(self, device: int = 0, backend=None, ctypes=None, generate_standard_repn: Optional[Callable] = None,
-                 solver_hints: Optional[dict] = None, **solver_options):
+                 solver_hints: Optional[dict] = None, column_scaling: Optional[str] = "auto", **solver_options):
         self._backend = backend
+        self._column_scaling = column_scaling
         self._device, self._solver_options = device, solver_options
         self._ctypes, self._repn, self._hints = ctypes, generate_standard_repn, solver_hints
         self._batches: Dict[tuple, PyomoScenarioBatch] = {}
@@ -365,7 +412,7 @@ class HipPyomoSolver:
         key = tuple(id(b) for b in blocks)
         batch = self._batches.get(key)
         if batch is None:
-            batch = self._batches[key] = PyomoScenarioBatch(blocks, objectives, self._ctypes, self._repn, self._hints)
+            batch = self._batches[key] = PyomoScenarioBatch(blocks, objectives, self._ctypes, self._repn, self._hints, self._column_scaling)
         else:
             try:
                 batch.refresh()
@@ -375,7 +422,7 @@ class HipPyomoSolver:
                 # sweep): what a Pyomo solver object does on every call - write the model again - happens here only now.  The
                 # old device handle goes with the old batch object.
                 self.reflattened += 1
-                batch = self._batches[key] = PyomoScenarioBatch(blocks, objectives, self._ctypes, self._repn, self._hints)
+                batch = self._batches[key] = PyomoScenarioBatch(blocks, objectives, self._ctypes, self._repn, self._hints, self._column_scaling)
         results = self._get_backend().solve(batch, tee=tee)
         self.last_batch = batch
         return results

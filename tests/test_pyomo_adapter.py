@@ -583,6 +583,45 @@ def test_linear_block_and_pyomo_walk_flatten_to_the_same_lp(seed):
     assert walked.c0 == pytest.approx(native.c0, abs=1e-12)
 
 
+def test_column_scaling_of_pyomo_batches(rts309):
+    """What the solver is told about the variables' magnitudes (dsp_lp_desc::col_scale) for a flowsheet handed over as a Pyomo
+    model: the model's own scaling factors where it carries any (IDAES suffix), else the ranges its bounds imply for LPs beyond
+    the in-wave simplex, else nothing - and nothing when switched off."""
+    from dispatches_amd.lp import implied_column_ranges
+    from dispatches_amd.pyomo_adapter import PyomoScenarioBatch
+    kw = dict(ctypes=CTYPES, generate_standard_repn=generate_standard_repn)
+    cf = list(rts309["rt_cf"][:4])
+    blocks = [build_tracking_model(cf, [0.0, 1.5, 15.0, 24.5])[0] for _ in range(2)]
+    small = PyomoScenarioBatch(blocks, **kw)
+    assert small.lp.n + small.lp.m <= 128 and small.lp.col_scale is None            # in-wave simplex: exact, unscaled
+    forced = PyomoScenarioBatch(blocks, column_scaling="implied_ranges", **kw)
+    assert np.array_equal(forced.lp.col_scale, implied_column_ranges(forced.lp, forced.lb, forced.ub))
+    assert (forced.lp.col_scale > 0).all()
+    assert PyomoScenarioBatch(blocks, column_scaling=None, **kw).lp.col_scale is None
+    assert PyomoScenarioBatch(blocks, column_scaling="suffix", **kw).lp.col_scale is None      # the model carries none
+    with pytest.raises(ValueError):
+        PyomoScenarioBatch(blocks, column_scaling="ruiz", **kw)
+
+    # an IDAES-style suffix on the variables' parent block: scaling factor s = 1 / typical magnitude
+    class Suffix(dict):
+        def get(self, key, default=None):
+            return dict.get(self, id(key), default)
+
+    for blk in blocks:
+        sfx = Suffix()
+        for v in blk.vars:
+            v.parent_block = (lambda blk=blk: blk)
+            if v.name.startswith("grid[") or v.name.startswith("wind["):
+                sfx[id(v)] = 1e-5
+        blk.scaling_factor = sfx
+    scaled = PyomoScenarioBatch(blocks, **kw)
+    cs = scaled.lp.col_scale
+    names = [v.name for v in scaled.views[0]._vars]
+    assert cs is not None and len(cs) == scaled.lp.n
+    for nm, s in zip(names, cs):
+        assert s == pytest.approx(1e5 if nm.startswith("grid[") or nm.startswith("wind[") else 1.0)
+
+
 def test_real_pyomo_model_when_pyomo_is_installed():
     """Runs only where Pyomo exists (it does not in the build container): the same tracking LP written with real Pyomo components -
     indexed Var / Param(mutable) / Expression / Constraint - flattens to the LP of the stand-in model and refreshes."""
