@@ -391,9 +391,10 @@ def test_other_price_series_and_near_zero_objectives():
     """Data the defaults were not tuned on: wind+battery bidding on the bus-303 series (windows every 37 h).  The whole
     batch must reach status optimal and every scenario the solver does not FLAG must be within plain 1e-6 of the oracle.
     Scenario 1217 is a near-zero-price day: its objective (2.82 $) is the difference of terms 1.6e5 times larger (sum |c_j x_j|
-    = 4.6e5 $); the solver's error bound stagnates there, it is accepted through the stall logic and flagged
-    (DSP_FLAG_OBJ_WAIVED), and lands 5.7e-6 $ = 2.0e-6 relative from the oracle - 1.2e-11 of the scale of its terms, below what
-    the oracle's own 1e-9 feasibility tolerance resolves.  Flagged scenarios are asserted scale-aware."""
+    = 4.6e5 $); in round 2 the solver's error bound stagnated there, the scenario was accepted through the stall logic, FLAGGED
+    (DSP_FLAG_OBJ_WAIVED) and landed 2.0e-6 relative from the oracle.  Since the variable scaling no scenario of this batch is
+    flagged (profiles/r30a_recertify.log) and 1217 meets plain 1e-6 like the rest; what the solver would still flag after its
+    re-solves is UNCERTIFIED (hip_solver.uncertified: report code 5, never a bid) and must be marked so."""
     from dispatches_amd import scenarios
     from oracle import dispatch_lp_oracle as orc
     solver = _solver()
@@ -403,7 +404,7 @@ def test_other_price_series_and_near_zero_objectives():
     assert (model.status == 0).all(), np.nonzero(model.status)[0]
     assert model.iterations[1217] < 40000
     flagged = (model.flags & 1) != 0
-    assert flagged.sum() <= 8, int(flagged.sum())
+    assert flagged.sum() <= 2 and model.uncertified[flagged].all(), int(flagged.sum())       # (round 2: 4; none since the variable scaling)
     s = scenarios.load_series("rts_gmlc_303.npz")
     N, T = len(s["rt_lmp"]), 24
     ids = sorted(set([1217] + list(range(0, 4096, 293)) + np.nonzero(flagged)[0].tolist()))
@@ -413,10 +414,9 @@ def test_other_price_series_and_near_zero_objectives():
                                     np.clip(s["rt_lmp"][h0:h0 + T], 0, 500))
         ref = P.solve(tight=True)[1]
         err = abs(model.objective[k] - ref)
-        if flagged[k]:
-            scale = float(np.abs(model.c[k] * model.x[k]).sum())
-            assert err <= 1e-6 * max(1.0, abs(ref)) + 2e-10 * scale and err <= 1e-5 * max(1.0, abs(ref)), (k, model.objective[k], ref, scale)
-        else:
+        if flagged[k]:                              # uncertified: reported as such and never a bid; still close
+            assert err <= 1e-5 * max(1.0, abs(ref)), (k, model.objective[k], ref)
+        else:                                       # everything returned as optimal: the contract, scenario 1217 included
             assert err <= 1e-6 * max(1.0, abs(ref)), (k, model.objective[k], ref)
 
 

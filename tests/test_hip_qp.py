@@ -43,7 +43,9 @@ def test_qp_batch_parity_vs_oracle_brackets(workload):
     err = _bracket_error(model.objective, lo, up)
     waived = (model.flags & 1) != 0
     assert (err[~waived] < 1e-6).all(), (float(err[~waived].max()), int(np.nonzero(~waived)[0][err[~waived].argmax()]))
-    assert waived.sum() <= 16 and (err[waived] < 2e-5).all(), (int(waived.sum()), err[waived])
+    # whatever is still flagged after the solver's re-solves is reported as UNCERTIFIED (never a bid: workflow/bidder.py); with the
+    # variable scaling on none is left on these workloads (profiles/r30a_recertify.log) - round 2 allowed 16 of them up to 2e-5
+    assert waived.sum() <= 2 and model.uncertified[waived].all() and not model.uncertified[~waived].any(), int(waived.sum())
     print(f"{workload}: max bracket error {err.max():.2e}, flagged (objective tests waived): {int(waived.sum())} of {B}; "
           f"iterations mean {model.iterations.mean():.0f} max {model.iterations.max()}; kernel {st.kernel_ms:.2f} ms")
     # the reported objective is the objective of the returned point (linear part + soft rows)
