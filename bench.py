@@ -236,7 +236,13 @@ def bench_price_taker(args, rank, local_rank, world, dev):
         byt = float(st.stream_bytes_per_iteration) * its
         n, m = model.lp.n, model.lp.m
         traffic = src = None
-        for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_stream_pmc_summary*.csv")), key=os.path.basename, reverse=True):
+        # counters of THIS workload's iteration kernel: profiles/r*_stream_pmc_summary_<workload>.csv; the summaries without a
+        # workload in their name were collected on the wind+battery price-taker LP (tools/gpu_stream.py) and serve only that one
+        pats = [f"r*_stream_pmc_summary_{args.workload}.csv"] + (["r*_stream_pmc_summary*.csv"] if args.workload == "price_taker" else [])
+        files = [f for pat in pats for f in glob.glob(os.path.join(ROOT, "profiles", pat))
+                 if args.workload == "price_taker" or f.endswith(f"_{args.workload}.csv")]
+        files = [f for f in files if not any(f.endswith(f"_{w}.csv") for w in ("pem_price_taker", "nuclear_price_taker") if w != args.workload)]
+        for f in sorted(set(files), key=os.path.basename, reverse=True):
             c = {}
             for row in csv.DictReader(open(f)):
                 if "k_fused" in row["kernel"]:
@@ -255,7 +261,7 @@ def bench_price_taker(args, rank, local_rank, world, dev):
                        "us_per_batch_iteration": 1e6 * k_s / max(1, int(model.iterations.max())), "host_wall_s": float(t[0].item())},
             "roofline": {"bound": "hbm", "kernel": "k_fused_pre / k_fused (+ check sequence every 64 iterations)", "achieved": byt / k_s / 1e9,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": byt / k_s / 1e9 / HBM_PEAK_GBS,
-                         "traffic": traffic, "traffic_from": src, "traffic_note": "per launch of the iteration kernel at the batch of that profile (64)",
+                         "traffic": traffic, "traffic_from": src, "traffic_note": "HBM bytes per launch of the iteration kernel (FETCH_SIZE x 2 + WRITE_SIZE) from the newest committed counter summary of this workload; null if none",
                          "algorithmic_bytes_per_scenario_iteration": int(st.stream_bytes_per_iteration),
                          "two_launch_form_bytes_per_scenario_iteration": 8 * (8 * n + 6 * m),
                          "note": "HBM-resident PDLP, fused one-launch iteration for banded matrices: x, x0, c, y, y0 read + x, y written "
