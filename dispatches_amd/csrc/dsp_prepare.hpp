@@ -214,6 +214,29 @@ struct HostFusedPlan {
   std::vector<int32_t> tile, ridx_enc;
 };
 
+// Workgroup -> (tile, scenario group) of the fused iteration's launch (grid: G groups x ntile tiles, linear id lin = group + G tile).
+// Workgroups go to the 8 XCDs round-robin in launch order; the XCD-major renumbering gives workgroup 8 q + c (XCD c) group q mod G
+// of tile 8 (q / G) + c, so that ALL groups of a tile run on ONE XCD, back to back, and the tile's slice of the matrix is fetched
+// into one L2 once.  Only whole rounds of 8 tiles are renumbered (xcd_full = 8 G (ntile / 8) workgroups); the last ntile mod 8
+// tiles keep the grid order - a renumbering that runs on into tile ids beyond the plan reads outside every array (the memory
+// fault of the first attempt).  Shared by the kernel and the CPU test (tests/fused_harness.cpp: a bijection for every G, ntile).
+#if defined(__HIPCC__)
+#define DSP_HOST_DEVICE __host__ __device__
+#else
+#define DSP_HOST_DEVICE
+#endif
+DSP_HOST_DEVICE inline void fused_workgroup(int lin, int G, int xcd_full, int &tile, int &grp) {
+  if (lin < xcd_full) {
+    const int q = lin >> 3, c = lin & 7;
+    tile = 8 * (q / G) + c;
+    grp = q % G;
+  } else {
+    tile = lin / G;
+    grp = lin % G;
+  }
+}
+inline int fused_xcd_full(int G, int ntile) { return 8 * G * (ntile / 8); }
+
 inline HostFusedPlan build_fused_plan(const HostCSR &A, const HostCSR &AT, const HostStreamELL &Er, const HostStreamELL &Ec, int max_long,
                                       int rows_per_tile, size_t lds_budget) {
   HostFusedPlan F;

@@ -970,20 +970,10 @@ __global__ void __launch_bounds__(kTB, fused_pre_waves(SG, K, MW, SHARED, QP, DE
   const int n = P.n, m = P.m, nlong = P.C.nlong, NY = F.ny_max, NXB = F.nxb_max, WC = P.C.W, WR = P.R.W;
   // grid (scenario groups, tiles): the groups of ONE tile have consecutive workgroup ids, i.e. they are dispatched at nearly the same
   // time, two or more of them to each XCD - whose L2 then serves the tile's slice of the matrix to all but the first
-  // XCD-major renumbering (io.xcd_full > 0): workgroups go to the 8 XCDs round-robin in launch order, so with the plain grid order
-  // every XCD sees every tile and fetches its matrix slice into its own L2.  Workgroup 8 q + c (XCD c) takes group q % G of tile
-  // 8 (q / G) + c instead: ALL groups of a tile run on ONE XCD, back to back.  Only whole rounds of 8 tiles are renumbered
-  // (xcd_full = 8 G (ntile / 8)); the last ntile % 8 tiles keep the grid order (a renumbering that ran on into tile ids beyond
-  // ntile was the memory fault of the first attempt, profiles/r30f_*).
-  int tile = blockIdx.y, grp = blockIdx.x;
-  {
-    const int G = gridDim.x, lin = blockIdx.x + G * blockIdx.y;
-    if (lin < io.xcd_full) {
-      const int q = lin >> 3, c = lin & 7;
-      tile = 8 * (q / G) + c;
-      grp = q % G;
-    }
-  }
+  // XCD-major renumbering of the workgroups (io.xcd_full > 0; dsp_prepare.hpp::fused_workgroup): all scenario groups of a tile on
+  // ONE XCD, whose L2 then fetches the tile's slice of the matrix once instead of once per XCD
+  int tile, grp;
+  fused_workgroup((int)(blockIdx.x + gridDim.x * blockIdx.y), (int)gridDim.x, io.xcd_full, tile, grp);
   const int b0 = grp * SG, tid = threadIdx.x;
   const int32_t *tp = F.tile + 8 * tile;
   const int i0 = tp[0], i1 = tp[1], j0 = tp[2], j1 = tp[3], c_lo = tp[4], c_hi = tp[5], r_lo = tp[6], r_hi = tp[7];
@@ -1498,7 +1488,7 @@ static hipError_t run_fused(StreamSolver *S, StreamArgs &a, hipStream_t st, int 
   hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
   const int xcd_env = getenv("DSP_FUSED_XCD") ? atoi(getenv("DSP_FUSED_XCD")) : 1;   // default on (DSP_FUSED_XCD=0: grid order)
-  const int xcd_full = (pre && xcd_env) ? 8 * groups * (F.ntile / 8) : 0;
+  const int xcd_full = (pre && xcd_env) ? fused_xcd_full(groups, F.ntile) : 0;
   double *xcur = a.W.x, *ycur = a.W.y, *xalt = a.W.x2, *yalt = a.W.y2;
   int lp_cur = 0;
   auto partials = [&]() {

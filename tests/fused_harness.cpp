@@ -6,13 +6,42 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <string>
+#include <vector>
 #include "../dispatches_amd/csrc/dsp_prepare.hpp"
 
 using namespace dsp;
 
 static double clampd(double v, double lo, double hi) { return std::fmin(std::fmax(v, lo), hi); }
 
+// every (groups, tiles) shape: the XCD-major renumbering of the fused launch's workgroups is a bijection onto groups x tiles, the
+// renumbered part puts all groups of a tile on ONE XCD (workgroup id mod 8), and nothing maps beyond the plan
+static int check_workgroup_order() {
+  for (int G = 1; G <= 40; ++G)
+    for (int ntile = 1; ntile <= 70; ++ntile) {
+      const int full = fused_xcd_full(G, ntile), total = G * ntile;
+      std::vector<int> seen(total, 0), xcd_of_tile(ntile, -1);
+      for (int lin = 0; lin < total; ++lin) {
+        int tile = -1, grp = -1;
+        fused_workgroup(lin, G, full, tile, grp);
+        if (tile < 0 || tile >= ntile || grp < 0 || grp >= G) { printf("{\"ok\": false, \"G\": %d, \"ntile\": %d, \"lin\": %d}\n", G, ntile, lin); return 1; }
+        if (seen[tile * G + grp]++) { printf("{\"ok\": false, \"dup\": true, \"G\": %d, \"ntile\": %d}\n", G, ntile); return 1; }
+        if (lin < full) {
+          if (xcd_of_tile[tile] < 0) xcd_of_tile[tile] = lin & 7;
+          if (xcd_of_tile[tile] != (lin & 7)) { printf("{\"ok\": false, \"split\": true, \"G\": %d, \"ntile\": %d}\n", G, ntile); return 1; }
+        }
+        // grid order off: identity
+        int t0, g0;
+        fused_workgroup(lin, G, 0, t0, g0);
+        if (t0 != lin / G || g0 != lin % G) return 1;
+      }
+    }
+  printf("{\"ok\": true}\n");
+  return 0;
+}
+
 int main(int argc, char **argv) {
+  if (argc == 2 && std::string(argv[1]) == "--workgroup-order") return check_workgroup_order();
   if (argc < 4) return 2;
   FILE *f = fopen(argv[1], "rb");
   if (!f) return 3;

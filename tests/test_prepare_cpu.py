@@ -163,3 +163,11 @@ def test_fused_plan_refuses_matrices_that_are_not_banded(fused_harness, tmp_path
         _write_csr(A, path)
         res = json.loads(subprocess.run([fused_harness, path, "768", "8"], check=True, capture_output=True, text=True).stdout)
         assert res["ntile"] == 0
+
+
+def test_xcd_major_workgroup_order_is_a_bijection(fused_harness):
+    """The renumbering of the fused launch's workgroups (dsp_prepare.hpp::fused_workgroup, the function the kernel calls) for every
+    shape up to 40 scenario groups x 70 tiles: each (tile, group) exactly once, all groups of a renumbered tile on one XCD,
+    nothing beyond the plan (the first version ran on into tile ids that do not exist: a memory fault on the GPU)."""
+    res = json.loads(subprocess.run([fused_harness, "--workgroup-order"], check=True, capture_output=True, text=True).stdout)
+    assert res == {"ok": True}
