@@ -408,13 +408,43 @@ __global__ void k_check_rows(StreamArgs a) {
 
 // ---- check iteration, columns: reduced costs at y+ -----------------------------------------------------------------------
 // partial slots: 8 dres^2, 9 pobj = c.x+, 10 dual objective (column part), 11 sum |c x|, 12 sum |dual residual| |x|
+// the five column quantities of one column (slots 8 .. 12) from its reduced cost
+__device__ __forceinline__ void kkt_col_terms(const StreamArgs &a, int s, int j, double aty, double (&v)[5]) {
+  const StreamProblem &P = a.P;
+  const size_t at = (size_t)s * P.n + j;
+  const double cj = a.W.c[at], lb = a.W.lb[at], ub = a.W.ub[at], xp = a.W.xp[at];
+  const double rc = cj - aty;
+  const double lp = finite_d(lb) ? fmax(rc, 0.0) : 0.0;
+  const double lm = finite_d(ub) ? fmax(-rc, 0.0) : 0.0;
+  const double dr = (rc - lp + lm) / P.col_scale[j];
+  v[0] = dr * dr;
+  v[1] = cj * xp;
+  v[2] = lp * fin0(lb) - lm * fin0(ub);
+  v[3] = fabs(cj * xp);
+  v[4] = fabs(rc - lp + lm) * fabs(xp);
+}
+
+// grid: (column blocks + one block per CHUNK of a long column, scenario groups).  A long column (the design variable of the
+// price-taker LPs: 26 k entries at T = 8736) used to be walked chunk after chunk by ONE workgroup: 142 us per check whatever the
+// batch - a fifth of a lone scenario's time per iteration.  Its chunks are separate blocks now, as in k_primal; k_kkt_long_finish adds
+// their partial sums in chunk order (the same order: bit-identical) and writes the column's five quantities.
 template <int SG>
 __global__ void k_kkt_cols(StreamArgs a) {
   const StreamProblem &P = a.P;
   const int b0 = blockIdx.y * SG;
+  if ((int)blockIdx.x >= a.nblk_n) {
+    const int ch = blockIdx.x - a.nblk_n;
+    for (int u = 0; u < SG; ++u) {
+      const int s = b0 + u;
+      if (s >= a.b.B) break;
+      if (a.W.ctrl[s].done) continue;
+      const double part = long_dot(P.C, ch, a.W.yp + (size_t)s * P.m);
+      if (threadIdx.x == 0) a.W.long_partial[(size_t)s * a.nchunk_max + ch] = part;
+    }
+    return;
+  }
   const int t = blockIdx.x * kTB + threadIdx.x;
-  const bool is_long_block = (int)blockIdx.x >= a.nblk_n;
-  const bool col = !is_long_block && t < P.n && !P.C.is_long[t < P.n ? t : 0];
+  const bool col = t < P.n && !P.C.is_long[t < P.n ? t : 0];
   double val[kStreamMaxW];
   int idx[kStreamMaxW];
   if (col) for (int e = 0; e < P.C.W; ++e) { val[e] = P.C.val[(size_t)e * P.n + t]; idx[e] = P.C.idx[(size_t)e * P.n + t]; }
@@ -423,34 +453,31 @@ __global__ void k_kkt_cols(StreamArgs a) {
     if (s >= a.b.B) break;
     const StreamCtrl &c = a.W.ctrl[s];
     double v[5] = {0, 0, 0, 0, 0};
-    if (!c.done) {
+    if (!c.done && col) {
       const double *__restrict__ ypv = a.W.yp + (size_t)s * P.m;
-      int j = -1;
       double aty = 0.0;
-      if (is_long_block) {
-        const int l = blockIdx.x - a.nblk_n;
-        const double t1 = long_dot_all(P.C, l, ypv);
-        if (threadIdx.x == 0) { j = P.C.long_id[l]; aty = t1; }
-      } else if (col) {
-        j = t;
-        for (int e = 0; e < P.C.W; ++e) aty = fma(val[e], ypv[idx[e]], aty);
-      }
-      if (j >= 0) {
-        const size_t at = (size_t)s * P.n + j;
-        const double cj = a.W.c[at], lb = a.W.lb[at], ub = a.W.ub[at], xp = a.W.xp[at];
-        const double rc = cj - aty;
-        const double lp = finite_d(lb) ? fmax(rc, 0.0) : 0.0;
-        const double lm = finite_d(ub) ? fmax(-rc, 0.0) : 0.0;
-        const double dr = (rc - lp + lm) / P.col_scale[j];
-        v[0] = dr * dr;
-        v[1] = cj * xp;
-        v[2] = lp * fin0(lb) - lm * fin0(ub);
-        v[3] = fabs(cj * xp);
-        v[4] = fabs(rc - lp + lm) * fabs(xp);
-      }
+      for (int e = 0; e < P.C.W; ++e) aty = fma(val[e], ypv[idx[e]], aty);
+      kkt_col_terms(a, s, t, aty, v);
     }
     block_partials<5>(v, a.W.partial + ((size_t)s * a.nblk_tot + blockIdx.x) * kNQ + 8);
   }
+}
+
+// one thread per (long column, scenario): ordered sum of the chunk partials of A^T y+, then the column's quantities into the partial
+// slot of block nblk_n + l (the slot the one-block-per-long-column form wrote; k_control adds the blocks' slots in order)
+__global__ void k_kkt_long_finish(StreamArgs a) {
+  const StreamProblem &P = a.P;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= P.C.nlong * a.b.B) return;
+  const int l = t % P.C.nlong, s = t / P.C.nlong;
+  if (a.W.ctrl[s].done) return;
+  double aty = 0.0;
+  for (int ch = P.C.long_chunk_ptr[l]; ch < P.C.long_chunk_ptr[l + 1]; ++ch) aty += a.W.long_partial[(size_t)s * a.nchunk_max + ch];
+  double v[5];
+  kkt_col_terms(a, s, P.C.long_id[l], aty, v);
+  double *out = a.W.partial + ((size_t)s * a.nblk_tot + a.nblk_n + l) * kNQ + 8;
+#pragma unroll
+  for (int q = 0; q < 5; ++q) out[q] = v[q];
 }
 
 // ---- control: the restart / termination decision of one scenario from its check sums (slot layout: k_check_rows / k_kkt_cols)
@@ -1408,7 +1435,7 @@ static hipError_t run(StreamSolver *S, StreamArgs &a, hipStream_t st, int *perio
   const int groups = (B + SG - 1) / SG;
   const dim3 blk(kTB);
   const dim3 g_primal(a.nblk_n + P.C.nchunk, groups), g_dual(a.nblk + P.R.nchunk, groups);
-  const dim3 g_rows_chk(a.nblk + P.R.nlong, groups), g_cols(a.nblk_n + P.C.nlong, groups);
+  const dim3 g_rows_chk(a.nblk + P.R.nlong, groups), g_cols(a.nblk_n + P.C.nchunk, groups);
   const dim3 g_elem(a.nblk, groups);
   const int fin_c = (P.C.nlong * B + 63) / 64, fin_r = (P.R.nlong * B + 63) / 64;
   auto primal = [&](bool write_xp) {
@@ -1430,6 +1457,7 @@ static hipError_t run(StreamSolver *S, StreamArgs &a, hipStream_t st, int *perio
     primal(true);
     hipLaunchKernelGGL((k_check_rows<SG>), g_rows_chk, blk, 0, st, a);
     hipLaunchKernelGGL((k_kkt_cols<SG>), g_cols, blk, 0, st, a);
+    if (P.C.nlong) hipLaunchKernelGGL(k_kkt_long_finish, dim3((P.C.nlong * B + 63) / 64), dim3(64), 0, st, a);
     hipLaunchKernelGGL(k_control, dim3(B), dim3(256), 0, st, a, C);
     hipLaunchKernelGGL((k_apply<SG>), g_elem, blk, 0, st, a);
     if ((period + 1) % poll == 0 || period + 1 == max_periods) {
@@ -1459,7 +1487,7 @@ static hipError_t run_fused(StreamSolver *S, StreamArgs &a, hipStream_t st, int 
   const int groups = (B + SG - 1) / SG;
   const dim3 blk(kTB);
   const dim3 g_fused(groups, F.ntile), g_primal(a.nblk_n + P.C.nchunk, groups);
-  const dim3 g_rows_chk(a.nblk + P.R.nlong, groups), g_cols(a.nblk_n + P.C.nlong, groups), g_elem(a.nblk, groups);
+  const dim3 g_rows_chk(a.nblk + P.R.nlong, groups), g_cols(a.nblk_n + P.C.nchunk, groups), g_elem(a.nblk, groups);
   const int fin_c = (P.C.nlong * B + 63) / 64;
   const int K_own = (F.own_max + kTB - 1) / kTB;
   // (+ the thread-private slots of k_fused_pre's deferred form: y0, x0, and the row bounds when they differ per scenario)
@@ -1514,6 +1542,7 @@ static hipError_t run_fused(StreamSolver *S, StreamArgs &a, hipStream_t st, int 
     if (P.C.nlong) hipLaunchKernelGGL(k_primal_long_finish, dim3(fin_c), dim3(64), 0, st, ac, 1);
     hipLaunchKernelGGL((k_check_rows<SG>), g_rows_chk, blk, 0, st, ac);
     hipLaunchKernelGGL((k_kkt_cols<SG>), g_cols, blk, 0, st, ac);
+    if (P.C.nlong) hipLaunchKernelGGL(k_kkt_long_finish, dim3(fin_c), dim3(64), 0, st, ac);
     hipLaunchKernelGGL(k_control, dim3(B), dim3(256), 0, st, ac, C);
     hipLaunchKernelGGL((k_apply<SG>), g_elem, blk, 0, st, ac);
     partials();
