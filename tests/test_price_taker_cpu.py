@@ -23,9 +23,12 @@ def test_wind_resource_model_known_answers(golden, price_taker_inputs):
     assert np.abs(cf - orc.sam_weibull_capacity_factor(price_taker_inputs["wind_speed_m_s"])).max() < 1e-12
 
 
-def test_wind_battery_price_taker_reproduces_the_reference_golden(golden):
+@pytest.mark.parametrize("throughput", ["chain", "scan", "hier"])
+def test_wind_battery_price_taker_reproduces_the_reference_golden(golden, throughput):
+    """... in the reference's own form of the throughput accumulator (linked equalities) and in the two exact reformulations of it:
+    the parallel-prefix network and the hierarchical basis (flowsheets/price_taker.py)."""
     g = golden["G8_price_taker_wind_battery"]
-    handles, model = scenarios.price_taker_batch(g["n_time_points"], 1, HighsTestSolver(), inputs="reference")
+    handles, model = scenarios.price_taker_batch(g["n_time_points"], 1, HighsTestSolver(), inputs="reference", throughput=throughput)
     model.solver.solve(model)
     x = model.x[0]
     npv = model.block.expressions["NPV"][0].value(x)
@@ -80,3 +83,37 @@ def test_nuclear_price_taker_enumeration_product_oracle_and_closed_form():
     e = model.x[k][[p["np_to_electrolyzer"].index for p in handles["periods"]]]
     on = 20.0 * hp > model.lmp
     assert np.allclose(e[on], pc * 400.0, atol=1e-6) and np.allclose(e[~on & (20.0 * hp < model.lmp)], 0.0, atol=1e-6)
+
+
+def test_hierarchical_throughput_basis_is_an_exact_change_of_variables():
+    """`throughput="hier"`: the T columns E_t become T coefficients of hierarchical hat functions.  Same optimum as the chain on a
+    family member that builds a battery (so the accumulator matters), the expressions E_t reproduce the running sum of (I + O) / 2,
+    the columns of the difference block are mutually orthogonal (what makes the block well conditioned), and the matrix has the
+    announced size."""
+    T = 96
+    out = {}
+    for thr in ("chain", "hier"):
+        handles, model = scenarios.price_taker_batch(T, 6, HighsTestSolver(), throughput=thr)
+        model.solver.solve(model)
+        out[thr] = (handles, model)
+    (hc, mc), (hh, mh) = out["chain"], out["hier"]
+    assert np.allclose(mc.objective, mh.objective, rtol=1e-9, atol=1e-9)
+    assert mh.lp.n == mc.lp.n and mh.lp.m == mc.lp.m
+    k = int(np.argmax([x[hc["nameplate_power"].index] for x in mc.x]))
+    assert mc.x[k][hc["nameplate_power"].index] > 1.0                       # a member that builds a battery
+    x = mh.x[k]
+    run = 0.0
+    for t, p in enumerate(hh["periods"]):
+        run += 0.5 * (x[p["elec_in"].index] + x[p["elec_out"].index])
+        assert p["energy_throughput"].value(x) == pytest.approx(run, rel=1e-9, abs=1e-6)
+    # the accumulate rows restricted to the hierarchical columns: orthogonal columns
+    lp = mh.lp
+    A = lp.csr().tocsc()
+    rows = np.array([i for i, nm in enumerate(lp.row_names) if nm.startswith("battery.accumulate_energy_throughput[")])
+    cols = np.array([j for j, nm in enumerate(lp.col_names) if nm.startswith("throughput_hier[")])
+    assert len(cols) == T and len(rows) == T
+    D = A[rows][:, cols].toarray()
+    gram = D.T @ D
+    off = gram - np.diag(np.diag(gram))
+    assert np.abs(off).max() <= 1e-12 * np.abs(np.diag(gram)).max()
+    assert lp.nnz <= 3 * T * (2 + int(np.ceil(np.log2(T)))) + 6 * T
