@@ -227,7 +227,8 @@ def wind_battery_price_taker(n_time_points, capacity_factors, lmps, wind_mw=847.
 PEM_CAP_COST = prm.pem_cap_cost          # $/kW  load_parameters.py:49
 
 
-def wind_battery_pem_price_taker(time_points, capacity_factors, lmps, h2_price_per_kg=2.0, design_opt=True, wind_mw=847.0):
+def wind_battery_pem_price_taker(time_points, capacity_factors, lmps, h2_price_per_kg=2.0, design_opt=True, wind_mw=847.0,
+                                 throughput="chain"):
     """Wind + battery + PEM price-taker design LP: the reference's ``wind_battery_pem_optimize``
     (``dispatches/case_studies/renewables_case/wind_battery_PEM_LMP.py:180-298``) on a LinearBlock.
 
@@ -238,7 +239,10 @@ def wind_battery_pem_price_taker(time_points, capacity_factors, lmps, h2_price_p
     3600 per hour); the PEM pays 0.03 * 1200 $/kW-yr on its capacity (:275-277) and 1200 $/kW in the NPV (:291-294);
     `design_opt="PEM"` fixes the battery's nameplate power to 0 (:237-238); the wind farm is extant (capacity fixed, no capital
     cost: :234, :254-255 - the reference's default input parameters).  Same reductions as LP #4 (one nameplate-power column, 4-h
-    energy substituted).  Returns (block, objective LinExpr of -NPV * 1e-5, handles)."""
+    energy substituted).  `throughput="hier"`: the accumulated-throughput chain in the hierarchical basis (`_hierarchical_basis`: an
+    exact change of variables).  Returns (block, objective LinExpr of -NPV * 1e-5, handles)."""
+    if throughput not in ("chain", "hier"):
+        raise ValueError("throughput: 'chain' (the reference's linked equalities) or 'hier' (the chain in a hierarchical basis)")
     T = int(time_points)
     cf = np.asarray(capacity_factors, float)[:T]
     lmp = np.asarray(lmps, float)[:T] * 1e-3                                          # $/kWh (:280)
@@ -256,6 +260,9 @@ def wind_battery_pem_price_taker(time_points, capacity_factors, lmps, h2_price_p
     per = []
     soc_prev, thr_prev = S_init, None
     rev_e, h2_kg = LinExpr(), LinExpr()
+    hier = None
+    if throughput == "hier":                                                          # (columns after the design variables)
+        hier = _hierarchical_basis(b, T)
     for t in range(T):
         W = b.var(f"windpower.electricity[{t}]", 0.0, wind_kw * cf[t])
         G = b.var(f"splitter.grid_elec[{t}]")
@@ -263,7 +270,7 @@ def wind_battery_pem_price_taker(time_points, capacity_factors, lmps, h2_price_p
         X = b.var(f"splitter.pem_elec[{t}]")
         O = b.var(f"battery.elec_out[{t}]")
         S = b.var(f"battery.state_of_charge[{t}]")
-        E = b.var(f"battery.energy_throughput[{t}]")
+        E = b.var(f"battery.energy_throughput[{t}]") if hier is None else hier[t]
         b.equality(f"splitter.sum_split[{t}]", W - G - I - X, 0.0)
         b.equality(f"battery.state_evolution[{t}]", S - soc_prev - eta_c * I + O / eta_d, 0.0)
         thr = E - 0.5 * I - 0.5 * O
@@ -307,7 +314,7 @@ def wind_battery_pem_price_taker(time_points, capacity_factors, lmps, h2_price_p
         for j, name in enumerate(b.col_names):
             if "state_of_charge" in name:
                 s[j] = DURATION * wind_kw
-            elif name.startswith("battery.energy_throughput["):
+            elif name.startswith("battery.energy_throughput[") or name.startswith("throughput_hier["):
                 s[j] = wind_kw * max(T / 2, 1)
         return s
     handles["column_scales"] = column_scales

@@ -38,10 +38,10 @@ def test_wind_battery_price_taker_reproduces_the_reference_golden(golden, throug
     assert model.objective[0] == pytest.approx(-npv * 1e-5, rel=1e-9)
 
 
-@pytest.mark.parametrize("design_opt", ["PEM", True])
-def test_wind_battery_pem_price_taker_reproduces_the_reference_goldens(golden, design_opt):
+@pytest.mark.parametrize("design_opt,throughput", [("PEM", "chain"), (True, "chain"), (True, "hier")])
+def test_wind_battery_pem_price_taker_reproduces_the_reference_goldens(golden, design_opt, throughput):
     g = golden["G10_price_taker_wind_battery_pem"]
-    handles, model = scenarios.pem_price_taker_batch(g["time_points"], 2, HighsTestSolver(), design_opt=design_opt)
+    handles, model = scenarios.pem_price_taker_batch(g["time_points"], 2, HighsTestSolver(), design_opt=design_opt, throughput=throughput)
     assert scenarios.PEM_PRICE_TAKER_FAMILY[1] == (g["h2_price_per_kg"], 1.0)
     model.solver.solve(model)
     x = model.x[1]                                                        # member 1: hydrogen at 2.5 $/kg, nominal PEM cost
@@ -53,7 +53,7 @@ def test_wind_battery_pem_price_taker_reproduces_the_reference_goldens(golden, d
     assert ex["annual_rev_E"][0].value(x) == pytest.approx(g["annual_rev_E"], rel=1e-6)
     assert -model.objective[1] * 1e5 == pytest.approx(g["NPV"], rel=1e-6)
     # the cheaper the electrolyzer and the dearer the hydrogen, the bigger the plant
-    handles, fam = scenarios.pem_price_taker_batch(g["time_points"], 8, HighsTestSolver(), design_opt=design_opt)
+    handles, fam = scenarios.pem_price_taker_batch(g["time_points"], 8, HighsTestSolver(), design_opt=design_opt, throughput=throughput)
     fam.solver.solve(fam)
     pem = fam.x[:, handles["pem_system_capacity"].index]
     assert (np.diff(pem[:4]) >= -1e-6).all() and (pem[4:8] >= pem[:4] - 1e-6).all()
