@@ -119,8 +119,46 @@ def _hierarchical_basis(b, T):
     return [LinExpr(dict(tm)) for tm in terms]
 
 
+def _two_level_basis(b, T, n_nodes=3):
+    """The accumulated throughput as `n_nodes` coarse values + local deviations (`throughput="two_level"`): E_t = the piecewise-linear
+    interpolant of the node values v_k (nodes at the ends of `n_nodes` equal stretches of the horizon, 0 before the first period)
+    + e_t, with e_t a column of its own for every period that is not a node.  Still T columns, an exact change of variables, rows no
+    longer than before (a period touches at most two node columns) - and the ONLY columns that are not local are the `n_nodes` node
+    columns, which span two stretches each: with 3 nodes the LP has 4 long columns (these + the battery's power), what the fused
+    streaming iteration carries through per-tile partial sums today (csrc/dsp_stream.hpp, kFusedMaxLong), and stays banded otherwise.
+
+    Why it is enough: the chain's trouble is its smallest singular value ~ 1 / T - ONE slow mode per stretch of the horizon; the node
+    columns move whole stretches at once and leave the deviations a chain of length T / n_nodes whose ends are pinned.  Lab
+    (tools/stream_hier_lab.py, profiles/r30_lab_hierarchical.log): T = 2688: 171 k iterations -> 44 k with 4 nodes (40 k with 8 or 16;
+    the full hierarchical basis: 39 k)."""
+    K = max(1, int(n_nodes))
+    nodes = sorted({min(T - 1, max(0, int(round((k + 1) * T / K)) - 1)) for k in range(K)} | {T - 1})
+    v = [b.var(f"throughput_node[{t}]", -np.inf, np.inf) for t in nodes]
+    where = {}
+    k = 0                                               # the stretch (nodes[k-1], nodes[k]] that holds t
+    for t in range(T):
+        while t > nodes[k]:
+            k += 1
+        lo = nodes[k - 1] if k > 0 else -1
+        w = (t - lo) / (nodes[k] - lo)
+        terms = {v[k].index: w}
+        if k > 0 and w < 1.0:
+            terms[v[k - 1].index] = 1.0 - w
+        where[t] = (terms, t != nodes[k])
+
+    def expression(t, fine_var):
+        """E_t; `fine_var(t)` creates period t's deviation column (called by the flowsheet where it creates the period's other columns, so
+        that the matrix stays banded in the order it is handed over)"""
+        terms, has_fine = where[t]
+        terms = dict(terms)
+        if has_fine:
+            terms[fine_var(t).index] = 1.0
+        return LinExpr(terms)
+    return expression
+
+
 def wind_battery_price_taker(n_time_points, capacity_factors, lmps, wind_mw=847.0, wind_mw_ub=10000.0, batt_mw=0.0,
-                             extant_wind=True, throughput="chain"):
+                             extant_wind=True, throughput="chain", coarse_nodes=3):
     """Build the LP.  `lmps` in $/MWh (the reference multiplies by 1e-3: $/kWh, :249); returns (block, objective,
     handles) where objective is the LinExpr of  -NPV * 1e-5  to MINIMISE."""
     if not extant_wind:
@@ -139,10 +177,11 @@ def wind_battery_price_taker(n_time_points, capacity_factors, lmps, wind_mw=847.
     per = []
     soc_prev = thr_prev = None
     revenue = LinExpr()
-    if throughput not in ("chain", "scan", "hier"):
-        raise ValueError("throughput: 'chain' (the reference's linked equalities), 'scan' (parallel-prefix network) or 'hier' "
-                         "(the chain in a hierarchical basis)")
+    if throughput not in ("chain", "scan", "hier", "two_level"):
+        raise ValueError("throughput: 'chain' (the reference's linked equalities), 'scan' (parallel-prefix network), 'hier' "
+                         "(the chain in a hierarchical basis) or 'two_level' (coarse node values + local deviations)")
     cols = []
+    two_level = _two_level_basis(b, T, coarse_nodes) if throughput == "two_level" else None
     for t in range(T):
         W = b.var(f"windpower.electricity[{t}]", 0.0, wind_kw * cf[t])
         G = b.var(f"splitter.grid_elec[{t}]")
@@ -150,10 +189,12 @@ def wind_battery_price_taker(n_time_points, capacity_factors, lmps, wind_mw=847.
         O = b.var(f"battery.elec_out[{t}]")
         S = b.var(f"battery.state_of_charge[{t}]", 0.0, 0.0 if t == T - 1 else np.inf)   # periodic: S_{T-1} = S_init = 0 (:40-51, :199)
         E = b.var(f"battery.energy_throughput[{t}]") if throughput == "chain" else None
+        if throughput == "two_level":
+            E = two_level(t, lambda tt: b.var(f"throughput_fine[{tt}]", -np.inf, np.inf))
         cols.append((W, G, I, O, S, E))
     if throughput == "scan":
         before = _prefix_network(b, [0.5 * I + 0.5 * O for (_W, _G, I, O, _S, _E) in cols])
-    hier = _hierarchical_basis(b, T) if throughput == "hier" else None
+    hier = _hierarchical_basis(b, T) if throughput == "hier" else [c[5] for c in cols] if throughput == "two_level" else None
     for t, (W, G, I, O, S, E) in enumerate(cols):
         b.equality(f"splitter.sum_split[{t}]", W - G - I, 0.0)
         soc_rhs = S - eta_c * I + O / eta_d
@@ -166,7 +207,7 @@ def wind_battery_price_taker(n_time_points, capacity_factors, lmps, wind_mw=847.
                 thr_rhs = thr_rhs - thr_prev
             b.equality(f"battery.accumulate_energy_throughput[{t}]", thr_rhs, 0.0)
             Et = LinExpr._as(E)
-        elif throughput == "hier":
+        elif throughput in ("hier", "two_level"):
             Et = hier[t]
             thr_rhs = Et - 0.5 * I - 0.5 * O
             if t > 0:
@@ -179,7 +220,7 @@ def wind_battery_price_taker(n_time_points, capacity_factors, lmps, wind_mw=847.
         b.constraint(f"battery.power_bound_out[{t}]", O - P, -np.inf, 0.0)
         revenue.accumulate(G, float(lmp[t])).accumulate(O, float(lmp[t]))
         per.append(dict(wind=W, grid_elec=G, elec_in=I, elec_out=O, state_of_charge=S, energy_throughput=Et))
-        soc_prev, thr_prev = S, E
+        soc_prev, thr_prev = S, (E if throughput == "chain" else None)
     n_weeks = T / (7 * 24)
     op_cost = (Cw * (prm.wind_op_cost / 8760) + Pb * (BATT_OP_COST / 8760)) * T
     annual_revenue = (revenue - op_cost) * (52 / n_weeks)
@@ -212,7 +253,7 @@ def wind_battery_price_taker(n_time_points, capacity_factors, lmps, wind_mw=847.
         for j, name in enumerate(b.col_names):
             if name.startswith("battery.state_of_charge["):
                 s[j] = DURATION * wind_kw
-            elif name.startswith("battery.energy_throughput[") or name.startswith("throughput_hier["):
+            elif name.startswith(("battery.energy_throughput[", "throughput_hier[", "throughput_node[", "throughput_fine[")):
                 s[j] = wind_kw * max(T / 2, 1)
             elif name.startswith("throughput_sum[") or name.startswith("throughput_before_copy["):
                 lo, hi = map(int, name[name.index("[") + 1:-1].split(":"))
