@@ -127,6 +127,24 @@ def _write_csr(A, path):
         A.data.astype(np.float64).tofile(f)
 
 
+def test_fused_iteration_plan_carries_the_two_level_throughput_basis(fused_harness, tmp_path):
+    """The price-taker LP with the accumulated throughput as 3 node values + local deviations (flowsheets/price_taker.py,
+    throughput="two_level"): 4 long columns (the nodes + the battery's power), rows of up to 6 entries, otherwise banded - the plan
+    of the one-launch iteration exists and one iteration run tile by tile as the kernel's stages do reproduces the plain step."""
+    from dispatches_amd import scenarios
+    _, model = scenarios.price_taker_batch(1344, 1, _NoSolver(), throughput="two_level")
+    lp = model.lp
+    A = sp.csr_matrix((lp.data, lp.indices, lp.indptr), shape=(lp.m, lp.n))
+    A.sort_indices()
+    path = str(tmp_path / "a.bin")
+    _write_csr(A, path)
+    res = json.loads(subprocess.run([fused_harness, path, "250", "8"], check=True, capture_output=True, text=True).stdout)
+    assert res["ntile"] == -(-lp.m // 250) and res["long_cols"] == 4 and res["wr"] == 6 and res["wc"] == 4
+    assert res["ny"] <= 250 + 16 and res["nxb"] <= 250 + 16
+    assert res["out_of_range"] == 0 and res["uninitialised"] == 0 and res["missing"] == 0
+    assert res["err_x"] < 1e-12 and res["err_y"] < 1e-12 and res["err_lp"] < 1e-8
+
+
 @pytest.mark.parametrize("T,rows_per_tile", [(168, 768), (336, 128), (1000, 768), (8736, 768)])
 def test_fused_iteration_plan_on_the_price_taker_lps(fused_harness, tmp_path, T, rows_per_tile):
     """The one-launch iteration of the streaming PDLP (dsp_stream.hip: k_fused) cuts the banded multi-period LP into tiles with

@@ -23,10 +23,10 @@ def test_wind_resource_model_known_answers(golden, price_taker_inputs):
     assert np.abs(cf - orc.sam_weibull_capacity_factor(price_taker_inputs["wind_speed_m_s"])).max() < 1e-12
 
 
-@pytest.mark.parametrize("throughput", ["chain", "scan", "hier"])
+@pytest.mark.parametrize("throughput", ["chain", "scan", "hier", "two_level"])
 def test_wind_battery_price_taker_reproduces_the_reference_golden(golden, throughput):
     """... in the reference's own form of the throughput accumulator (linked equalities) and in the two exact reformulations of it:
-    the parallel-prefix network and the hierarchical basis (flowsheets/price_taker.py)."""
+    the parallel-prefix network, the hierarchical basis and the two-level basis (flowsheets/price_taker.py)."""
     g = golden["G8_price_taker_wind_battery"]
     handles, model = scenarios.price_taker_batch(g["n_time_points"], 1, HighsTestSolver(), inputs="reference", throughput=throughput)
     model.solver.solve(model)
@@ -117,3 +117,38 @@ def test_hierarchical_throughput_basis_is_an_exact_change_of_variables():
     off = gram - np.diag(np.diag(gram))
     assert np.abs(off).max() <= 1e-12 * np.abs(np.diag(gram)).max()
     assert lp.nnz <= 3 * T * (2 + int(np.ceil(np.log2(T)))) + 6 * T
+
+
+@pytest.mark.parametrize("nodes", [1, 3, 5])
+def test_two_level_throughput_basis_is_exact_and_keeps_the_lp_banded(nodes):
+    """`throughput="two_level"`: node values + local deviations of the accumulated throughput.  Same optima as the chain, E_t still
+    the running sum, and the structure the fused streaming iteration needs: rows no longer than 6, every column but the node
+    columns and the battery's power short (<= 4 entries), and those few in period order next to their period's other columns."""
+    T = 96
+    out = {}
+    for thr in ("chain", "two_level"):
+        handles, model = scenarios.price_taker_batch(T, 6, HighsTestSolver(), throughput=thr, coarse_nodes=nodes)
+        model.solver.solve(model)
+        out[thr] = (handles, model)
+    (hc, mc), (ht, mt) = out["chain"], out["two_level"]
+    assert np.allclose(mc.objective, mt.objective, rtol=1e-9, atol=1e-9)
+    assert mt.lp.n == mc.lp.n and mt.lp.m == mc.lp.m
+    k = int(np.argmax([x[hc["nameplate_power"].index] for x in mc.x]))
+    x = mt.x[k]
+    run = 0.0
+    for p in ht["periods"]:
+        run += 0.5 * (x[p["elec_in"].index] + x[p["elec_out"].index])
+        assert p["energy_throughput"].value(x) == pytest.approx(run, rel=1e-9, abs=1e-6)
+    lp = mt.lp
+    A = lp.csr()
+    assert np.diff(A.indptr).max() <= 6
+    collen = np.diff(A.tocsc().indptr)
+    names = np.array(lp.col_names)
+    wide = names[collen > 4]
+    assert set(wide) <= {"battery.nameplate_power"} | {nm for nm in names if nm.startswith("throughput_node[")}
+    assert sum(nm.startswith("throughput_node[") for nm in names) == nodes
+    # banded: a deviation column sits among its period's columns
+    pos = {nm: j for j, nm in enumerate(names)}
+    for t in range(1, T - 1):
+        if f"throughput_fine[{t}]" in pos:
+            assert abs(pos[f"throughput_fine[{t}]"] - pos[f"battery.state_of_charge[{t}]"]) <= 2
