@@ -269,7 +269,7 @@ PEM_CAP_COST = prm.pem_cap_cost          # $/kW  load_parameters.py:49
 
 
 def wind_battery_pem_price_taker(time_points, capacity_factors, lmps, h2_price_per_kg=2.0, design_opt=True, wind_mw=847.0,
-                                 throughput="chain"):
+                                 throughput="chain", coarse_nodes=1):
     """Wind + battery + PEM price-taker design LP: the reference's ``wind_battery_pem_optimize``
     (``dispatches/case_studies/renewables_case/wind_battery_PEM_LMP.py:180-298``) on a LinearBlock.
 
@@ -280,10 +280,14 @@ def wind_battery_pem_price_taker(time_points, capacity_factors, lmps, h2_price_p
     3600 per hour); the PEM pays 0.03 * 1200 $/kW-yr on its capacity (:275-277) and 1200 $/kW in the NPV (:291-294);
     `design_opt="PEM"` fixes the battery's nameplate power to 0 (:237-238); the wind farm is extant (capacity fixed, no capital
     cost: :234, :254-255 - the reference's default input parameters).  Same reductions as LP #4 (one nameplate-power column, 4-h
-    energy substituted).  `throughput="hier"`: the accumulated-throughput chain in the hierarchical basis (`_hierarchical_basis`: an
-    exact change of variables).  Returns (block, objective LinExpr of -NPV * 1e-5, handles)."""
-    if throughput not in ("chain", "hier"):
-        raise ValueError("throughput: 'chain' (the reference's linked equalities) or 'hier' (the chain in a hierarchical basis)")
+    energy substituted).  `throughput="hier"` / `"two_level"`: the accumulated-throughput chain in the hierarchical basis
+    (`_hierarchical_basis`) or as `coarse_nodes` node values + local deviations (`_two_level_basis`; this LP already has three
+    columns that span the horizon - battery power, PEM capacity, the periodic initial state of charge - so ONE node keeps it within
+    the four the fused streaming iteration carries): exact changes of variables.  Returns (block, objective LinExpr of
+    -NPV * 1e-5, handles)."""
+    if throughput not in ("chain", "hier", "two_level"):
+        raise ValueError("throughput: 'chain' (the reference's linked equalities), 'hier' (the chain in a hierarchical basis) or "
+                         "'two_level' (coarse node values + local deviations)")
     T = int(time_points)
     cf = np.asarray(capacity_factors, float)[:T]
     lmp = np.asarray(lmps, float)[:T] * 1e-3                                          # $/kWh (:280)
@@ -304,6 +308,7 @@ def wind_battery_pem_price_taker(time_points, capacity_factors, lmps, h2_price_p
     hier = None
     if throughput == "hier":                                                          # (columns after the design variables)
         hier = _hierarchical_basis(b, T)
+    two_level = _two_level_basis(b, T, coarse_nodes) if throughput == "two_level" else None
     for t in range(T):
         W = b.var(f"windpower.electricity[{t}]", 0.0, wind_kw * cf[t])
         G = b.var(f"splitter.grid_elec[{t}]")
@@ -311,7 +316,10 @@ def wind_battery_pem_price_taker(time_points, capacity_factors, lmps, h2_price_p
         X = b.var(f"splitter.pem_elec[{t}]")
         O = b.var(f"battery.elec_out[{t}]")
         S = b.var(f"battery.state_of_charge[{t}]")
-        E = b.var(f"battery.energy_throughput[{t}]") if hier is None else hier[t]
+        if two_level is not None:
+            E = two_level(t, lambda tt: b.var(f"throughput_fine[{tt}]", -np.inf, np.inf))
+        else:
+            E = b.var(f"battery.energy_throughput[{t}]") if hier is None else hier[t]
         b.equality(f"splitter.sum_split[{t}]", W - G - I - X, 0.0)
         b.equality(f"battery.state_evolution[{t}]", S - soc_prev - eta_c * I + O / eta_d, 0.0)
         thr = E - 0.5 * I - 0.5 * O
@@ -355,7 +363,7 @@ def wind_battery_pem_price_taker(time_points, capacity_factors, lmps, h2_price_p
         for j, name in enumerate(b.col_names):
             if "state_of_charge" in name:
                 s[j] = DURATION * wind_kw
-            elif name.startswith("battery.energy_throughput[") or name.startswith("throughput_hier["):
+            elif name.startswith(("battery.energy_throughput[", "throughput_hier[", "throughput_node[", "throughput_fine[")):
                 s[j] = wind_kw * max(T / 2, 1)
         return s
     handles["column_scales"] = column_scales

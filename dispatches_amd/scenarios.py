@@ -299,13 +299,13 @@ def price_taker_reference_inputs(T):
 PEM_PRICE_TAKER_FAMILY = [(h2, pf) for pf in (1.0, 0.75, 0.5, 1.25) for h2 in (2.0, 2.5, 3.0, 4.0)]
 
 
-def pem_price_taker_batch(T, B, solver, design_opt=True, inputs="reference", throughput="chain"):
+def pem_price_taker_batch(T, B, solver, design_opt=True, inputs="reference", throughput="chain", coarse_nodes=1):
     """Wind + battery + PEM price-taker design LP over T hourly periods (reference wind_battery_pem_optimize) for the first B members
     of PEM_PRICE_TAKER_FAMILY: scenarios differ in the objective only (hydrogen price, PEM capital cost).  Returns (handles, model)."""
     from .flowsheets.price_taker import wind_battery_pem_price_taker
     from .workflow.batch_model import ScenarioBatchModel
     cf, lmp = price_taker_reference_inputs(T) if inputs == "reference" else price_taker_inputs(T)
-    block, objective, handles = wind_battery_pem_price_taker(T, cf, lmp, design_opt=design_opt, throughput=throughput)
+    block, objective, handles = wind_battery_pem_price_taker(T, cf, lmp, design_opt=design_opt, throughput=throughput, coarse_nodes=coarse_nodes)
     model = ScenarioBatchModel(block, B, T, indexed=True)
     model.finalize(objective)
     fam = [PEM_PRICE_TAKER_FAMILY[i % len(PEM_PRICE_TAKER_FAMILY)] for i in range(B)]

@@ -38,7 +38,7 @@ def test_wind_battery_price_taker_reproduces_the_reference_golden(golden, throug
     assert model.objective[0] == pytest.approx(-npv * 1e-5, rel=1e-9)
 
 
-@pytest.mark.parametrize("design_opt,throughput", [("PEM", "chain"), (True, "chain"), (True, "hier")])
+@pytest.mark.parametrize("design_opt,throughput", [("PEM", "chain"), (True, "chain"), (True, "hier"), (True, "two_level")])
 def test_wind_battery_pem_price_taker_reproduces_the_reference_goldens(golden, design_opt, throughput):
     g = golden["G10_price_taker_wind_battery_pem"]
     handles, model = scenarios.pem_price_taker_batch(g["time_points"], 2, HighsTestSolver(), design_opt=design_opt, throughput=throughput)
