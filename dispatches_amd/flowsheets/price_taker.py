@@ -120,41 +120,13 @@ def _hierarchical_basis(b, T):
 
 
 def _two_level_basis(b, T, n_nodes=3):
-    """The accumulated throughput as `n_nodes` coarse values + local deviations (`throughput="two_level"`): E_t = the piecewise-linear
-    interpolant of the node values v_k (nodes at the ends of `n_nodes` equal stretches of the horizon, 0 before the first period)
-    + e_t, with e_t a column of its own for every period that is not a node.  Still T columns, an exact change of variables, rows no
-    longer than before (a period touches at most two node columns) - and the ONLY columns that are not local are the `n_nodes` node
-    columns, which span two stretches each: with 3 nodes the LP has 4 long columns (these + the battery's power), what the fused
-    streaming iteration carries through per-tile partial sums today (csrc/dsp_stream.hpp, kFusedMaxLong), and stays banded otherwise.
-
-    Why it is enough: the chain's trouble is its smallest singular value ~ 1 / T - ONE slow mode per stretch of the horizon; the node
-    columns move whole stretches at once and leave the deviations a chain of length T / n_nodes whose ends are pinned.  Lab
-    (tools/stream_hier_lab.py, profiles/r30_lab_hierarchical.log): T = 2688: 171 k iterations -> 44 k with 4 nodes (40 k with 8 or 16;
-    the full hierarchical basis: 39 k)."""
-    K = max(1, int(n_nodes))
-    nodes = sorted({min(T - 1, max(0, int(round((k + 1) * T / K)) - 1)) for k in range(K)} | {T - 1})
-    v = [b.var(f"throughput_node[{t}]", -np.inf, np.inf) for t in nodes]
-    where = {}
-    k = 0                                               # the stretch (nodes[k-1], nodes[k]] that holds t
-    for t in range(T):
-        while t > nodes[k]:
-            k += 1
-        lo = nodes[k - 1] if k > 0 else -1
-        w = (t - lo) / (nodes[k] - lo)
-        terms = {v[k].index: w}
-        if k > 0 and w < 1.0:
-            terms[v[k - 1].index] = 1.0 - w
-        where[t] = (terms, t != nodes[k])
-
-    def expression(t, fine_var):
-        """E_t; `fine_var(t)` creates period t's deviation column (called by the flowsheet where it creates the period's other columns, so
-        that the matrix stays banded in the order it is handed over)"""
-        terms, has_fine = where[t]
-        terms = dict(terms)
-        if has_fine:
-            terms[fine_var(t).index] = 1.0
-        return LinExpr(terms)
-    return expression
+    """The accumulated throughput as `n_nodes` coarse values + local deviations (`throughput="two_level"`; units.two_level_accumulator,
+    starting from the fixed initial throughput 0).  With 3 nodes the LP has 4 long columns (the nodes + the battery's power) - what the
+    fused streaming iteration carries through per-tile partial sums today (csrc/dsp_stream.hpp, kFusedMaxLong) - and stays banded
+    otherwise.  Lab (tools/stream_hier_lab.py, profiles/r30_lab_hierarchical.log): T = 2688: 171 k iterations -> 44 k with 4 nodes (40 k
+    with 8 or 16; the full hierarchical basis: 39 k); GPU, T = 8736: 404 k -> 75 k on average (profiles/r30_two_level_probe_B16.log)."""
+    from .units import two_level_accumulator
+    return two_level_accumulator(b, T, n_nodes, base=None, prefix="throughput")
 
 
 def wind_battery_price_taker(n_time_points, capacity_factors, lmps, wind_mw=847.0, wind_mw_ub=10000.0, batt_mw=0.0,

@@ -26,8 +26,49 @@ def splitter(b: LinearBlock, t: int, inlet, outlet_names):
     return outs
 
 
+def two_level_accumulator(b: LinearBlock, T: int, n_nodes: int, base=None, prefix="throughput"):
+    """A running sum E_0 .. E_{T-1} (the battery's accumulated energy throughput) as `n_nodes` node values + local deviations:
+    E_t = base + the piecewise-linear interpolant of the node values v_k (nodes at the ends of `n_nodes` equal stretches of the
+    horizon; 0 before the first period) + e_t, with e_t a column of its own for every period that is not a node.  `base`: the
+    column (or None = 0) the sum starts from.  Still one column per period, an exact change of variables; a period touches at
+    most two node columns, and the node columns are the only ones that are not local.
+
+    Why: E_t - E_{t-1} = (in + out) / 2 is a first difference over the whole horizon - one slow mode per stretch of it, a smallest
+    singular value ~ 1 / T, O(T) PDHG iterations.  The node columns move whole stretches at once and leave the deviations a chain of
+    length T / n_nodes whose ends are pinned (DESIGN.md 9 item 2: year-long price-taker LPs 404 k -> 75 k iterations on the GPU;
+    the 24-h / 48-h bidding LPs 1213 -> 896 / 2386 -> 1360 in the lab with 2 nodes).
+
+    Returns expression(t, fine_var): the LinExpr of E_t; `fine_var(t)` must create period t's deviation column - called where the
+    flowsheet creates the period's other columns, so that a multi-period matrix stays banded in the order it is handed over."""
+    from ..lp import LinExpr
+    K = max(1, int(n_nodes))
+    nodes = sorted({min(T - 1, max(0, int(round((k + 1) * T / K)) - 1)) for k in range(K)} | {T - 1})
+    v = [b.var(f"{prefix}_node[{t}]", -INF, INF) for t in nodes]
+    where = {}
+    k = 0                                               # the stretch (nodes[k-1], nodes[k]] that holds t
+    for t in range(T):
+        while t > nodes[k]:
+            k += 1
+        lo = nodes[k - 1] if k > 0 else -1
+        w = (t - lo) / (nodes[k] - lo)
+        terms = {v[k].index: w}
+        if k > 0 and w < 1.0:
+            terms[v[k - 1].index] = 1.0 - w
+        if base is not None:
+            terms[base.index] = 1.0
+        where[t] = (terms, t != nodes[k])
+
+    def expression(t, fine_var):
+        terms, has_fine = where[t]
+        terms = dict(terms)
+        if has_fine:
+            terms[fine_var(t).index] = 1.0
+        return LinExpr(terms)
+    return expression
+
+
 def battery(b: LinearBlock, t: int, elec_in, soc_prev, thr_prev, nameplate_power_kw, nameplate_energy_kwh,
-            charging_eta=0.95, discharging_eta=0.95, degradation_rate=1e-4, ramp_rate=None):
+            charging_eta=0.95, discharging_eta=0.95, degradation_rate=1e-4, ramp_rate=None, throughput=None):
     """Battery storage rows for one period (dt = 1 h).
 
     Reference: dispatches/unit_models/battery.py
@@ -37,12 +78,13 @@ def battery(b: LinearBlock, t: int, elec_in, soc_prev, thr_prev, nameplate_power
       :159-165 power bounds            elec_in, elec_out <= nameplate_power   (column bounds here)
     and the (never-binding, 1e8) energy ramp rows of wind_battery_LMP.py:139-142 when `ramp_rate` is given.
     `elec_in` is an existing column (the splitter outlet; arcs RE_flowsheet.py:389,396 equate them).
+    `throughput`: the period's accumulated throughput as an EXPRESSION (two_level_accumulator) instead of a column of its own.
     """
     if elec_in.ub > nameplate_power_kw:
         elec_in.setub(nameplate_power_kw)
     elec_out = b.var(f"battery.elec_out[{t}]", 0.0, nameplate_power_kw)
     soc = b.var(f"battery.state_of_charge[{t}]")
-    thr = b.var(f"battery.energy_throughput[{t}]")
+    thr = b.var(f"battery.energy_throughput[{t}]") if throughput is None else throughput
     b.equality(f"battery.state_evolution[{t}]",
                soc - soc_prev - charging_eta * elec_in + elec_out / discharging_eta, 0.0)
     b.equality(f"battery.accumulate_energy_throughput[{t}]",

@@ -58,7 +58,9 @@ class _DeviceModel:
         idx = lambda cols: torch.as_tensor(np.asarray(cols, np.int64), device=dev)
         self.wind_cols = idx([p["wind"].index for p in per])
         self.soc_init, self.thr_init = fam["soc_init"].index, fam["thr_init"].index
-        self.soc0, self.thr0 = per[0]["state_of_charge"].index, per[0]["energy_throughput"].index
+        # (period 0's throughput is a column in the reference's form of the accumulator; in the two-level form it is an expression and
+        #  this model cannot hand the realised state over - the loop takes it from the tracking model, whose horizon keeps the chain)
+        self.soc0, self.thr0 = per[0]["state_of_charge"].index, getattr(per[0]["energy_throughput"], "index", -1)
         self.wind_kw = float(fam["wind_kw"])
         # P_T[t] = 1e-3 (grid_elec[t] + elec_out[t]): the two columns of every hour
         self.pt_cols = idx([[p["grid_elec"].index, p["elec_out"].index] for p in per])       # [T, 2]

@@ -71,7 +71,7 @@ def _apply_cf_windows(model, wind_cols, wind_kw, cf_windows, cf_template, waste_
 
 
 def wind_battery_batch(B, T, solver, series="rts_gmlc_309.npz", stride=17, wind_mw=200.0, batt_mw=25.0,
-                       price_cap=500.0, ramp_cost=0.0):
+                       price_cap=500.0, ramp_cost=0.0, throughput_nodes=0):
     """LP #1 (wind + battery) day-ahead bidding, B scenarios x T hours (BASELINE metric workload: T=24, B=4096;
     config 4 shape: T=48, bus 309, start hours (17 k) mod (N - T))."""
     s = load_series(series)
@@ -80,7 +80,7 @@ def wind_battery_batch(B, T, solver, series="rts_gmlc_309.npz", stride=17, wind_
     fc = WindowForecaster(s["da_lmp"], s["rt_lmp"], starts, clip=(0.0, price_cap))
     mp = MultiPeriodWindBattery(_thermal_data("309_WIND_1", "Carter", wind_mw, batt_mw),
                                 wind_capacity_factors=list(s["rt_cf"]), wind_pmax_mw=wind_mw,
-                                battery_pmax_mw=batt_mw, battery_energy_capacity_mwh=4 * batt_mw)
+                                battery_pmax_mw=batt_mw, battery_energy_capacity_mwh=4 * batt_mw, throughput_nodes=throughput_nodes)
     bidder = Bidder(mp, day_ahead_horizon=T, real_time_horizon=4, n_scenario=B, solver=solver, forecaster=fc,
                     ramp_cost=ramp_cost)
     model = bidder.day_ahead_model
@@ -166,8 +166,17 @@ QP_WORKLOADS = {f"wind_battery_24h_qp{tag}": (wind_battery_batch, dict(T=24, ram
                 for tag, rho in (("001", 0.01), ("01", 0.1), ("1", 1.0))}
 
 
+# NOT part of the measured workloads (no oracle fixtures, no ahead-of-time kernel specialisation): the bidding LPs with the two-level
+# form of the battery's throughput accumulator (flowsheets/units.py::two_level_accumulator) - same optima, fewer PDHG iterations in
+# the lab; for the labs (tools/pdlp_lab.py) and the first GPU measurements of the next round
+EXPERIMENTAL_WORKLOADS = {
+    "wind_battery_24h_tl2": (wind_battery_batch, dict(T=24, throughput_nodes=2)),
+    "wind_battery_48h_tl2": (wind_battery_batch, dict(T=48, throughput_nodes=2)),
+}
+
+
 def make_batch(name, B, solver):
-    fn, kw = (WORKLOADS.get(name) or QP_WORKLOADS[name])
+    fn, kw = (WORKLOADS.get(name) or QP_WORKLOADS.get(name) or EXPERIMENTAL_WORKLOADS[name])
     bidder, model = fn(B=B, solver=solver, **kw)
     load_prices(bidder, model)
     return bidder, model

@@ -378,3 +378,45 @@ def test_coupled_scenarios_match_the_oracle(rts309, cls, mode):
     indep = _thermal_bidder(rts309, HighsTestSolver(), S, cls=Bidder, history_days=3)
     indep.compute_day_ahead_bids(date="2020-01-02")
     assert float(np.sum(indep.day_ahead_model.objective)) <= ref + 1e-6 * abs(ref)
+
+
+@pytest.mark.parametrize("nodes", [1, 2, 3])
+def test_two_level_throughput_accumulator_gives_the_reference_bids(golden, rts309, nodes):
+    """MultiPeriodWindBattery(throughput_nodes = K): the day-ahead LP carries the battery's accumulated throughput as K node values +
+    local deviations instead of the reference's linked columns (flowsheets/units.py::two_level_accumulator; the 4-h real-time and
+    tracking LPs keep the chain).  An exact change of variables: the reference's golden self-schedule (G1) and bid curves (G2) come
+    out, same LP size, the realised profile is read through the expressions, update_model works on the same initial columns."""
+    kw = dict(wind_capacity_factors=rts309["rt_cf"], wind_pmax_mw=pmax, battery_pmax_mw=25, battery_energy_capacity_mwh=100,
+              throughput_nodes=nodes)
+    mp = MultiPeriodWindBattery(model_data=RenewableGeneratorModelData(**generator_params), **kw)
+    bidder = SelfScheduler(bidding_model_object=mp, day_ahead_horizon=48, real_time_horizon=4, n_scenario=1,
+                           solver=HighsTestSolver(), forecaster=_backcaster(rts309))
+    bids = bidder.compute_day_ahead_bids(date="2020-01-02")
+    assert np.max(np.abs(np.array([i["309_WIND_1"]["p_max"] for i in bids.values()]) - golden["G1_self_schedule_p_max_mw"]["values"])) < 5e-5
+    m = bidder.day_ahead_model
+    assert m.lp.n == 8 * 48 + 2 and m.lp.m == 5 * 48                      # still one throughput column per period
+    names = m.lp.col_names
+    assert sum(nm.startswith("battery.throughput_node[") for nm in names) == nodes
+    assert not any(nm.startswith("battery.energy_throughput[") for nm in names)
+    assert any(nm.startswith("battery.energy_throughput[") for nm in bidder.real_time_model.lp.col_names)     # 4-h LP: the chain
+    # E_t read through the expressions = initial throughput + running sum of (in + out) / 2
+    blk = m.fs[0]
+    prof = mp.get_implemented_profile(blk, 47)
+    per = blk.windBattery["periods"]
+    run = blk.windBattery["thr_init"].value
+    for t, e in enumerate(prof["realized_energy_throughput"]):
+        run += 0.5 * (per[t]["elec_in"].value + per[t]["elec_out"].value)
+        assert e == pytest.approx(run, rel=1e-9, abs=1e-6)
+    mp.record_results(blk, date="2020-01-02", hour=0)
+    # thermal-generator bidder: the golden bid curve
+    mp2 = MultiPeriodWindBattery(model_data=ThermalGeneratorModelData(**thermal_params()), **{**kw, "wind_pmax_mw": 200})
+    b2 = Bidder(bidding_model_object=mp2, day_ahead_horizon=48, real_time_horizon=4, n_scenario=1,
+                solver=HighsTestSolver(), forecaster=_backcaster(rts309))
+    prices = [b["309_WIND_1"]["p_cost"][-1][1] for b in b2.compute_day_ahead_bids(date="2020-01-02").values()]
+    assert np.max(np.abs(np.array(prices) - golden["G2_bidder_last_point_cost"]["values"])) < 5e-3
+    # rolling update: the same initial-condition columns
+    b2.update_day_ahead_model(realized_soc=[1234.5678], realized_energy_throughput=[617.28391])
+    blk2 = b2.day_ahead_model.block
+    assert blk2.windBattery["thr_init"].lb == blk2.windBattery["thr_init"].ub == 617.28
+    bids = b2.compute_day_ahead_bids(date="2020-01-03")
+    assert b2.day_ahead_model.status.tolist() == [0] and len(bids) == 48
