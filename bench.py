@@ -207,8 +207,9 @@ def bench_price_taker(args, rank, local_rank, world, dev):
     default_T = {"price_taker": 8736, "pem_price_taker": 8736, "nuclear_price_taker": 8784}[args.workload]
     T = args.horizon if args.horizon != 8736 or args.workload != "nuclear_price_taker" else default_T
     B, ce = (args.batch if args.batch != 4096 else (60 if args.workload == "nuclear_price_taker" else 64)), 64
-    build = {"price_taker": lambda s: scenarios.price_taker_batch(T, B, s)[1],
-             "pem_price_taker": lambda s: scenarios.pem_price_taker_batch(T, B, s, inputs="rts303")[1],
+    thr = args.throughput                   # "chain" (the reference's form, default) | "two_level" | "hier": flowsheets/price_taker.py
+    build = {"price_taker": lambda s: scenarios.price_taker_batch(T, B, s, throughput=thr)[1],
+             "pem_price_taker": lambda s: scenarios.pem_price_taker_batch(T, B, s, inputs="rts303", throughput=thr)[1],
              "nuclear_price_taker": lambda s: scenarios.nuclear_price_taker_batch(T, B, s)[1]}[args.workload]
 
     def run(periods):
@@ -256,7 +257,8 @@ def bench_price_taker(args, rank, local_rank, world, dev):
             "ms_per_step": 1e3 * k_s / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic", "world_size": world,
             "config": {"workload": f"{args.workload}: {B} scenarios/GPU sharing one constraint matrix, T = {T} h, streaming PDLP capped at "
-                                   f"{args.steps} check periods of {ce} iterations",
+                                   f"{args.steps} check periods of {ce} iterations" + ("" if thr == "chain" else f", throughput accumulator in its {thr} form"),
+                       "throughput_form": thr, "solved_to_optimality": int((model.status == 0).sum()),
                        "iterations_per_scenario": float(model.iterations.mean()), "status_counts": np.bincount(model.status, minlength=5).tolist(),
                        "us_per_batch_iteration": 1e6 * k_s / max(1, int(model.iterations.max())), "host_wall_s": float(t[0].item())},
             "roofline": {"bound": "hbm", "kernel": "k_fused_pre / k_fused (+ check sequence every 64 iterations)", "achieved": byt / k_s / 1e9,
@@ -420,6 +422,9 @@ def main():
     ap.add_argument("--min-time", type=float, default=0.5,
                     help="the burst of --steps steps is repeated until the timed bursts cover this many seconds; the median burst is reported")
     ap.add_argument("--max-bursts", type=int, default=500)
+    ap.add_argument("--throughput", default="chain", choices=["chain", "two_level", "hier"],
+                    help="--workload price_taker / pem_price_taker: form of the battery's throughput accumulator (flowsheets/price_taker.py); "
+                         "with --steps large enough the batch runs to optimality and config.solved_to_optimality / iterations_per_scenario tell")
     ap.add_argument("--warm-start", type=int, default=-1,
                     help="--workload double_loop: 1 / 0 = rolling warm start of the day-ahead LP on / off (-1 = the loop's default)")
     ap.add_argument("--no-spmv", action="store_true", help="skip the streaming SpMV-step roofline measurement")
