@@ -96,18 +96,24 @@ def test_fused_iteration_reproduces_the_two_launch_form(monkeypatch):
 
 
 @gpu
-def test_year_long_price_taker_lps_converge():
+@pytest.mark.parametrize("throughput", ["chain", "two_level"])
+def test_year_long_price_taker_lps_converge(throughput):
     """The reference's own horizon (wind_battery_LMP.py: 8736 hourly periods, n = m = 52 419) for the first 8 members of the family
     against the oracle fixture (HiGHS on the un-reduced LP, tools/make_price_taker_fixtures.py).  Round 2 never converged here:
-    the step size rested on a 500-iteration power-iteration estimate of ||A||, 1 % short for this near-Toeplitz matrix."""
+    the step size rested on a 500-iteration power-iteration estimate of ||A||, 1 % short for this near-Toeplitz matrix.
+    `two_level`: the same LPs with the battery's accumulated throughput as 3 node values + local deviations (an exact change of
+    variables, flowsheets/price_taker.py): same optima on the same kernels in a fifth of the iterations (the 16 scenarios of the
+    fixture: 404 k -> 75 k on average, slowest 770 k -> 139 k; profiles/r30_two_level_probe_B16.log)."""
     from dispatches_amd import scenarios
     from dispatches_amd.hip_solver import HipPdlpSolver
     fx = np.load(os.path.join(GOLD, "oracle_price_taker.npz"))
     T, B = 8736, 8
     solver = HipPdlpSolver(device=0, check_every=64, max_iter=2_000_000)
-    handles, model = scenarios.price_taker_batch(T, B, solver)
+    handles, model = scenarios.price_taker_batch(T, B, solver, throughput=throughput)
     solver.solve(model, tee=True)
     assert (model.status == 0).all(), (model.status, model.iterations)
+    if throughput == "two_level":
+        assert solver.last_stats.streaming == 1 and model.iterations.max() < 250_000, model.iterations
     ref = fx["T8736/obj"][:B]
     err = np.abs(model.objective - ref) / np.maximum(1.0, np.abs(ref))
     assert err.max() < 1e-6, (err, model.iterations)
