@@ -14,6 +14,8 @@ from __future__ import annotations
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional
 
+import math
+
 import numpy as np
 
 INF = float("inf")
@@ -358,34 +360,42 @@ class LinearBlock:
     def _propagate_bounds(self, active):
         """Implied column bounds from the rows flagged in `active` (bound propagation), starting from immutable bounds /
         declared hulls only.  Mutable columns are never tightened."""
-        lb = np.array([h[0] for h in self.col_hull])
-        ub = np.array([h[1] for h in self.col_hull])
-        rows = [(list(self.row_expr[i].items()), self.row_lo[i], self.row_hi[i])
+        # (plain Python floats and lists: the same arithmetic in the same order as the first version on numpy scalars, several times
+        #  faster - this pass was 80 % of the 6 s a year-long price-taker LP took to flatten)
+        isfinite = math.isfinite
+        lb = [float(h[0]) for h in self.col_hull]
+        ub = [float(h[1]) for h in self.col_hull]
+        mutable = self.col_mutable
+        rows = [([(j, float(a)) for j, a in self.row_expr[i].items()], float(self.row_lo[i]), float(self.row_hi[i]))
                 for i in range(len(self.row_expr)) if active[i] and not self.row_mutable[i]]
         for _ in range(3):
             for items, lo, hi in rows:
                 mins = [(a * lb[j] if a > 0 else a * ub[j]) for j, a in items]
                 maxs = [(a * ub[j] if a > 0 else a * lb[j]) for j, a in items]
                 smin, smax = sum(mins), sum(maxs)
+                hi_ok, lo_ok = isfinite(hi), isfinite(lo)
                 for k, (j, a) in enumerate(items):
-                    if self.col_mutable[j]:
+                    if mutable[j]:
                         continue
-                    if np.isfinite(hi):
-                        rest = smin - mins[k] if np.isfinite(mins[k]) else sum(mins[:k]) + sum(mins[k + 1:])
-                        if np.isfinite(rest):
+                    if hi_ok:
+                        rest = smin - mins[k] if isfinite(mins[k]) else sum(mins[:k]) + sum(mins[k + 1:])
+                        if isfinite(rest):
                             b = (hi - rest) / a
                             if a > 0:
-                                ub[j] = min(ub[j], b)
-                            else:
-                                lb[j] = max(lb[j], b)
-                    if np.isfinite(lo):
-                        rest = smax - maxs[k] if np.isfinite(maxs[k]) else sum(maxs[:k]) + sum(maxs[k + 1:])
-                        if np.isfinite(rest):
+                                if b < ub[j]:
+                                    ub[j] = b
+                            elif b > lb[j]:
+                                lb[j] = b
+                    if lo_ok:
+                        rest = smax - maxs[k] if isfinite(maxs[k]) else sum(maxs[:k]) + sum(maxs[k + 1:])
+                        if isfinite(rest):
                             b = (lo - rest) / a
                             if a > 0:
-                                lb[j] = max(lb[j], b)
-                            else:
-                                ub[j] = min(ub[j], b)
+                                if b > lb[j]:
+                                    lb[j] = b
+                            elif b < ub[j]:
+                                ub[j] = b
+        lb, ub = np.array(lb), np.array(ub)
         return lb, ub
 
     def _row_range(self, i, lb, ub):
