@@ -60,10 +60,11 @@ def _instance(gen):
     return SimpleNamespace(data={"elements": {"generator": {gen: {"generator_type": "thermal"}}}})
 
 
-def _run_double_loop(solver_factory, tmp_path, rts309, thermal=True):
+def _run_double_loop(solver_factory, tmp_path, rts309, thermal=True, throughput_nodes=0):
     md = ThermalGeneratorModelData(**thermal_params()) if thermal else RenewableGeneratorModelData(**generator_params)
     mk = lambda: MultiPeriodWindBattery(model_data=md, wind_capacity_factors=list(rts309["rt_cf"][:400]),
-                                        wind_pmax_mw=200, battery_pmax_mw=25, battery_energy_capacity_mwh=100)
+                                        wind_pmax_mw=200, battery_pmax_mw=25, battery_energy_capacity_mwh=100,
+                                        throughput_nodes=throughput_nodes)
     fc = Backcaster({"Carter": rts309["da_lmp"][:48].tolist()}, {"Carter": rts309["rt_lmp"][:48].tolist()})
     cls = Bidder if thermal else SelfScheduler
     bidder = cls(bidding_model_object=mk(), day_ahead_horizon=24, real_time_horizon=4, n_scenario=1,
@@ -140,6 +141,19 @@ def test_double_loop_stub_cpu(tmp_path, rts309):
     from tests._highs_solver import HighsTestSolver
     p_da, delivered, _ = _run_double_loop(HighsTestSolver, tmp_path, rts309)
     assert (p_da >= -1e-9).all() and (p_da <= 225 + 1e-6).all()
+
+
+def test_double_loop_stub_with_the_two_level_throughput_accumulator(tmp_path, rts309):
+    """The whole plugin sequence (bids, clearing, real-time hours through tracker and projection tracker, next day's bids after
+    update_day_ahead_model) with the day-ahead LP in the two-level form of the battery's throughput accumulator
+    (MultiPeriodWindBattery(throughput_nodes=2)): the same day-0 objective and offers as the reference's form."""
+    from tests._highs_solver import HighsTestSolver
+    (tmp_path / "a").mkdir()
+    (tmp_path / "b").mkdir()
+    p0, d0, obj0 = _run_double_loop(HighsTestSolver, tmp_path / "a", rts309)
+    p2, d2, obj2 = _run_double_loop(HighsTestSolver, tmp_path / "b", rts309, throughput_nodes=2)
+    assert obj2 == pytest.approx(obj0, rel=1e-9, abs=1e-6)
+    assert (p2 >= -1e-9).all() and (p2 <= 225 + 1e-6).all() and len(d2) == len(d0)
 
 
 @pytest.mark.gpu
