@@ -167,17 +167,20 @@ def wind_battery_price_taker(n_time_points, capacity_factors, lmps, wind_mw=847.
     if throughput == "scan":
         before = _prefix_network(b, [0.5 * I + 0.5 * O for (_W, _G, I, O, _S, _E) in cols])
     hier = _hierarchical_basis(b, T) if throughput == "hier" else [c[5] for c in cols] if throughput == "two_level" else None
+    # (rows written as coefficient dictionaries: the operator form `S - eta_c * I + O / eta_d - soc_prev` copies a dictionary per
+    #  operator - half of the time a year-long LP took to build; same coefficients to the bit)
+    c_in, c_out = -(1.0 * eta_c), 1.0 * (1.0 / eta_d)
     for t, (W, G, I, O, S, E) in enumerate(cols):
-        b.equality(f"splitter.sum_split[{t}]", W - G - I, 0.0)
-        soc_rhs = S - eta_c * I + O / eta_d
+        b.equality(f"splitter.sum_split[{t}]", LinExpr({W.index: 1.0, G.index: -1.0, I.index: -1.0}), 0.0)
+        soc_row = {S.index: 1.0, I.index: c_in, O.index: c_out}
         if soc_prev is not None:
-            soc_rhs = soc_rhs - soc_prev
-        b.equality(f"battery.state_evolution[{t}]", soc_rhs, 0.0)                  # initial SOC / throughput fixed 0 (:199-200)
+            soc_row[soc_prev.index] = -1.0
+        b.equality(f"battery.state_evolution[{t}]", LinExpr(soc_row), 0.0)         # initial SOC / throughput fixed 0 (:199-200)
         if throughput == "chain":
-            thr_rhs = E - 0.5 * I - 0.5 * O
+            thr_row = {E.index: 1.0, I.index: -0.5, O.index: -0.5}
             if thr_prev is not None:
-                thr_rhs = thr_rhs - thr_prev
-            b.equality(f"battery.accumulate_energy_throughput[{t}]", thr_rhs, 0.0)
+                thr_row[thr_prev.index] = -1.0
+            b.equality(f"battery.accumulate_energy_throughput[{t}]", LinExpr(thr_row), 0.0)
             Et = LinExpr._as(E)
         elif throughput in ("hier", "two_level"):
             Et = hier[t]
@@ -188,8 +191,8 @@ def wind_battery_price_taker(n_time_points, capacity_factors, lmps, wind_mw=847.
         else:
             Et = before[t] + 0.5 * I + 0.5 * O                                      # the same E_t, as an expression
         b.constraint(f"battery.state_of_charge_bounds[{t}]", S + d * Et - DURATION * P, -np.inf, 0.0)
-        b.constraint(f"battery.power_bound_in[{t}]", I - P, -np.inf, 0.0)
-        b.constraint(f"battery.power_bound_out[{t}]", O - P, -np.inf, 0.0)
+        b.constraint(f"battery.power_bound_in[{t}]", LinExpr({I.index: 1.0, P.index: -1.0}), -np.inf, 0.0)
+        b.constraint(f"battery.power_bound_out[{t}]", LinExpr({O.index: 1.0, P.index: -1.0}), -np.inf, 0.0)
         revenue.accumulate(G, float(lmp[t])).accumulate(O, float(lmp[t]))
         per.append(dict(wind=W, grid_elec=G, elec_in=I, elec_out=O, state_of_charge=S, energy_throughput=Et))
         soc_prev, thr_prev = S, (E if throughput == "chain" else None)
