@@ -18,7 +18,7 @@ for set in FETCH_SIZE WRITE_SIZE "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_I
   d=/tmp/sp_tl_$(echo $set | tr ' ' '_' | cut -c1-30); rm -rf $d
   STREAM_THROUGHPUT=two_level timeout 200 rocprofv3 --pmc $set --output-format csv -d $d -- python $repo/tools/gpu_stream.py 8736 64 1024 64 > /dev/null 2>&1
 done
-python - "$out/r40a_stream_pmc_summary_two_level.csv" <<'PY'
+python - "$out/r40a_two_level_pmc_summary.csv" <<'PY'
 import csv, glob, sys, collections
 acc = collections.OrderedDict()
 for f in sorted(glob.glob("/tmp/sp_tl_*/**/*counter_collection.csv", recursive=True)):
