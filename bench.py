@@ -207,7 +207,9 @@ def bench_price_taker(args, rank, local_rank, world, dev):
     default_T = {"price_taker": 8736, "pem_price_taker": 8736, "nuclear_price_taker": 8784}[args.workload]
     T = args.horizon if args.horizon != 8736 or args.workload != "nuclear_price_taker" else default_T
     B, ce = (args.batch if args.batch != 4096 else (60 if args.workload == "nuclear_price_taker" else 64)), 64
-    thr = args.throughput                   # "chain" (the reference's form, default) | "two_level" | "hier": flowsheets/price_taker.py
+    # form of the throughput accumulator (flowsheets/price_taker.py): "two_level" is the wind + battery family's default since round 4
+    # (scenarios.price_taker_batch), the PEM family keeps the reference's chain (the electrolyzer takes the energy a battery would cycle)
+    thr = args.throughput or ("two_level" if args.workload == "price_taker" else "chain")
     build = {"price_taker": lambda s: scenarios.price_taker_batch(T, B, s, throughput=thr)[1],
              "pem_price_taker": lambda s: scenarios.pem_price_taker_batch(T, B, s, inputs="rts303", throughput=thr)[1],
              "nuclear_price_taker": lambda s: scenarios.nuclear_price_taker_batch(T, B, s)[1]}[args.workload]
@@ -422,7 +424,7 @@ def main():
     ap.add_argument("--min-time", type=float, default=0.5,
                     help="the burst of --steps steps is repeated until the timed bursts cover this many seconds; the median burst is reported")
     ap.add_argument("--max-bursts", type=int, default=500)
-    ap.add_argument("--throughput", default="chain", choices=["chain", "two_level", "hier"],
+    ap.add_argument("--throughput", default=None, choices=["chain", "two_level", "hier"],
                     help="--workload price_taker / pem_price_taker: form of the battery's throughput accumulator (flowsheets/price_taker.py); "
                          "with --steps large enough the batch runs to optimality and config.solved_to_optimality / iterations_per_scenario tell")
     ap.add_argument("--warm-start", type=int, default=-1,

@@ -204,7 +204,7 @@ inline HostStreamELL build_stream_ell(const HostCSR &M, int max_w, int chunk, in
 // Tiles of the fused one-launch iteration (dsp_stream.hpp: FusedPlan): contiguous row / column ranges + the hulls of what
 // each tile's two products touch.  tile[8 t ..]: i0, i1 (own rows), j0, j1 (own columns), c_lo, c_hi (columns whose primal step
 // the tile computes: its own + those its rows touch), r_lo, r_hi (rows whose y it stages: its own + those these columns touch).
-// ridx_enc: the row ELL's column indices with long column l encoded as -1 - l (padding entries keep index 0 / value 0).
+// ridx_enc: the row ELL's column indices with long column l encoded as -1 - l (padding entries: value 0, index of the row's first entry).
 // ntile = 0 = not applicable: long rows, more than `max_long` long columns, or hulls beyond `lds_budget` bytes per scenario
 // (a matrix that is not banded in the order it was handed over).
 struct HostFusedPlan {
@@ -273,11 +273,15 @@ inline HostFusedPlan build_fused_plan(const HostCSR &A, const HostCSR &AT, const
   if ((size_t)(ny + nxb) * sizeof(double) > lds_budget) return F;
   std::vector<int32_t> rank(n, -1);
   for (int l = 0; l < nlong; ++l) rank[Ec.long_id[l]] = l;
-  F.ridx_enc.assign((size_t)Er.W * m, 0);
+  // Padding entries (value 0) repeat the row's FIRST real entry: a slot the tile has written whatever the hull looks like.  (They
+  // used to keep index 0; when column 0 is a long column inside the hull of the first tiles - the nuclear price-taker LP: columns
+  // 0 .. 2 are its design variables - that is the hull slot of a column no phase writes, and 0 x stale-LDS-bits can be NaN.)
+  F.ridx_enc.assign((size_t)Er.W * m, nlong > 0 ? -1 : 0);
   for (int i = 0; i < m; ++i) {
     const int len = A.ptr[i + 1] - A.ptr[i];
-    for (int e = 0; e < len && e < Er.W; ++e) {
-      const int j = A.idx[A.ptr[i] + e];
+    for (int e = 0; e < Er.W; ++e) {
+      if (len == 0) break;                                          // an empty row keeps long slot 0 / column 0 (clamped by the kernel)
+      const int j = A.idx[A.ptr[i] + (e < len ? e : 0)];
       F.ridx_enc[(size_t)e * m + i] = rank[j] >= 0 ? -1 - rank[j] : j;
     }
   }

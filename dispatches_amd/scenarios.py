@@ -353,10 +353,13 @@ def nuclear_price_taker_batch(T, B, solver, market="RT", pem_capex=1200.0):
     return handles, model
 
 
-def price_taker_batch(T, B, solver, wind_mw=847.0, throughput="chain", inputs="rts303", coarse_nodes=3):
+def price_taker_batch(T, B, solver, wind_mw=847.0, throughput="two_level", inputs="rts303", coarse_nodes=3):
     """Wind + battery price-taker design LP over T hourly periods (reference wind_battery_optimize) for the first B members
     of PRICE_TAKER_FAMILY: scenarios differ in the objective only.  n = 6 T + 3, m = 6 T + 2: beyond the fused kernels for
-    T >= 107, i.e. solved by the HBM-resident streaming PDLP.  Returns (handles, model)."""
+    T >= 107, i.e. solved by the HBM-resident streaming PDLP.  `throughput`: the statement of the battery's accumulated-throughput
+    chain (flowsheets/price_taker.py) - "two_level" (default since round 4: `coarse_nodes` node values + local deviations, an exact
+    change of variables with the reference's optima, 5 x fewer PDHG iterations at the year-long horizon) or "chain" (the reference's
+    own linked columns).  Returns (handles, model)."""
     from .flowsheets.price_taker import wind_battery_price_taker
     from .workflow.batch_model import ScenarioBatchModel
     cf, lmp = price_taker_reference_inputs(T) if inputs == "reference" else price_taker_inputs(T)

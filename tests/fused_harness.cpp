@@ -141,8 +141,8 @@ int main(int argc, char **argv) {
         slot[e] = gi < 0 ? -1 - gi : nlong + gi - c_lo;
         if (gi >= 0 && (gi < c_lo || gi >= c_hi)) { if (v != 0.0) oob++; slot[e] = 0; }
         if (slot[e] < 0 || slot[e] >= NXB) { oob++; slot[e] = 0; }
-        if (v != 0.0 && std::isnan(xb[slot[e]])) uninit++;
-        ax = std::fma(v, std::isnan(xb[slot[e]]) ? 0.0 : xb[slot[e]], ax);
+        if (std::isnan(xb[slot[e]])) uninit++;            // the kernel multiplies whatever the slot holds, padding entries (v = 0) included
+        ax = std::fma(v, xb[slot[e]], ax);
       }
       const double yv = ys[i - r_lo];
       const double gy = std::fma(-sig, ax, yv);

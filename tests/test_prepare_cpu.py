@@ -152,7 +152,7 @@ def test_fused_iteration_plan_on_the_price_taker_lps(fused_harness, tmp_path, T,
     library's own host code and runs one iteration tile by tile as the kernel's stages do: same iterates as the plain step on the
     CSR, every staged slot inside its buffer and written before it is read, every row and column written exactly once."""
     from dispatches_amd import scenarios
-    _, model = scenarios.price_taker_batch(T, 1, _NoSolver())
+    _, model = scenarios.price_taker_batch(T, 1, _NoSolver(), throughput="chain")
     lp = model.lp
     A = sp.csr_matrix((lp.data, lp.indices, lp.indptr), shape=(lp.m, lp.n))
     A.sort_indices()
@@ -162,6 +162,23 @@ def test_fused_iteration_plan_on_the_price_taker_lps(fused_harness, tmp_path, T,
     assert res["ntile"] == -(-lp.m // rows_per_tile) and res["long_cols"] == 1          # the nameplate-power design column
     assert res["wc"] == 4 and res["wr"] == 4                    # the long column must not pad every other vector to the cap
     assert res["ny"] <= rows_per_tile + 16 and res["nxb"] <= rows_per_tile + 16          # halo = one period each side
+    assert res["out_of_range"] == 0 and res["uninitialised"] == 0 and res["missing"] == 0
+    assert res["err_x"] < 1e-12 and res["err_y"] < 1e-12 and res["err_lp"] < 1e-8
+
+
+def test_fused_iteration_plan_with_long_columns_at_index_zero(fused_harness, tmp_path):
+    """The nuclear price-taker LP's design variables are columns 0 .. 2 - long columns INSIDE the hull of the first tiles.  The row
+    ELL's padding entries used to keep index 0, i.e. the hull slot of a column no phase of the kernel writes: 0 x stale LDS bits
+    (round-3 advisor finding).  The harness poisons every staged slot with NaN and multiplies padding entries like the kernel does."""
+    from dispatches_amd import scenarios
+    _, model = scenarios.nuclear_price_taker_batch(720, 1, _NoSolver())
+    lp = model.lp
+    A = sp.csr_matrix((lp.data, lp.indices, lp.indptr), shape=(lp.m, lp.n))
+    A.sort_indices()
+    path = str(tmp_path / "a.bin")
+    _write_csr(A, path)
+    res = json.loads(subprocess.run([fused_harness, path, "250", "8"], check=True, capture_output=True, text=True).stdout)
+    assert res["ntile"] > 0 and res["long_cols"] == 3
     assert res["out_of_range"] == 0 and res["uninitialised"] == 0 and res["missing"] == 0
     assert res["err_x"] < 1e-12 and res["err_y"] < 1e-12 and res["err_lp"] < 1e-8
 

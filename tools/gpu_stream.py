@@ -7,7 +7,7 @@ from dispatches_amd.hip_solver import HipPdlpSolver
 T = int(sys.argv[1]); B = int(sys.argv[2]); mi = int(sys.argv[3]) if len(sys.argv) > 3 else 200000
 ce = int(sys.argv[4]) if len(sys.argv) > 4 else 64
 solver = HipPdlpSolver(device=0, check_every=ce, max_iter=mi)
-t = time.time(); handles, model = scenarios.price_taker_batch(T, B, solver, throughput=os.environ.get('STREAM_THROUGHPUT', 'chain')); tb = time.time() - t
+t = time.time(); handles, model = scenarios.price_taker_batch(T, B, solver, throughput=os.environ.get('STREAM_THROUGHPUT', 'two_level')); tb = time.time() - t
 for rep in range(int(os.environ.get("STREAM_REPS", 1))):
     t = time.time(); solver.solve(model); ts = time.time() - t
     st = solver.last_stats
