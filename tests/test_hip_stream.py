@@ -213,7 +213,9 @@ def test_streaming_edge_cases():
     handles, model = scenarios.price_taker_batch(168, 3, solver)
     lb, ub, _, _ = model.block.current_bounds()
     model.ub = np.tile(ub, (3, 1))
-    model.ub[1, 5] = -1.0                                   # below the column's lower bound
+    j = model.lp.col_names.index("splitter.grid_elec[0]")
+    assert lb[j] == 0.0
+    model.ub[1, j] = -1.0                                   # below the column's lower bound
     solver.solve(model)
     assert model.status.tolist() == [0, 2, 0] and np.isnan(model.objective[1])
     limited = HipPdlpSolver(device=0, check_every=64, max_iter=128)
