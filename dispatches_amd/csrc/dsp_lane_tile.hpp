@@ -1,0 +1,332 @@
+// dsp_lane_tile.hpp — one lane's walk through one tile of the lane-per-scenario streaming iteration (plan: dsp_lane_plan.hpp,
+// kernels: dsp_stream_lane.hip).  The SAME code is compiled for the device (one call per lane of a wave, `lane` = threadIdx & 63,
+// rings in LDS) and for the host (tests/lane_harness.cpp calls it lane after lane on plain arrays): lanes never exchange iterates,
+// so the host run is the kernel's arithmetic, operation for operation.
+//
+// Storage: every per-scenario vector is scenario-minor, v[(element) * 64 + lane] inside its group's block (the caller passes the
+// group's base pointers).  Rings: ring[(index & mask) * 64 + lane].
+//
+// RECORDS.  What depends on the element only - matrix entries, their indices, shared bounds, scale factors - is one record per
+// column (CREC bytes) and one per row (RREC bytes), contiguous in element order:
+//     column  val[WC] | idx[WC] | lb, ub | col_scale, -            row  val[WR] | idx[WR] | rlo, rhi | al[NLP] | row_scale, -
+// (idx: row / column indices of the SHORT entries; padding entries repeat the first one with value 0; bit 30 of a column's idx[0]
+// marks a long column; al: the row's coefficients on the long columns.)  A unit's records are one contiguous block per kind, so
+// the wave fetches them with ONE 16-byte-per-lane load each, together with the unit's rows of x, c, y ... one unit ahead, parks them
+// in its LDS stage when the unit's turn comes, and every lane reads the same 16 bytes back (broadcast ds_read_b128).  The first
+// version read the records through the scalar unit: each record was a scalar-cache miss (~0.25 us) behind an s_waitcnt lgkmcnt(0)
+// - scalar loads return out of order, so every use drains the whole queue - 17 such waits per unit of 4 columns + 4 rows: 4.5 us
+// per unit, the whole launch latency-bound at 46 us whatever the batch (profiles/r40c_lane_kernel_stats_B64.csv).
+// Host build: the records are read where they lie (no stage): lanes run one after the other there.
+//
+// MODE 0  plain iteration:  x+ = clip(x - tau (c - A^T y)),  xbar = 2 x+ - x,  y+ = prox(y - sig A xbar),  both reflected and
+//         averaged with the anchors (x0, y0): x, y written to the other buffer; the long columns' partial sums of A^T y_new.
+// MODE 1  check iteration:  x+, y+ themselves are written (xp, yp: no averaging) and the tile's terms of the fixed-point residual
+//         and of the row part of the KKT sums are accumulated per lane (slots as k_check_rows of dsp_stream.hip); the long
+//         columns' partial sums are those of A^T y+.
+// MODE 2  column part of the KKT sums at (x+, y+): reduced costs of the own columns from yp (slots 8 .. 12).
+#pragma once
+#include <cmath>
+#include <cstdint>
+
+#if defined(__HIPCC__)
+#define DSP_LANE_HD __host__ __device__ __forceinline__
+#else
+#define DSP_LANE_HD inline
+#endif
+
+namespace dsp {
+
+template <int N> struct LaneVecD { double v[N]; };
+template <int N> struct LaneVecI { int32_t v[N]; };
+#if defined(__HIPCC__)
+typedef uint32_t LaneQuad __attribute__((ext_vector_type(4)));      // 16 bytes of a record block (a register quad on the device)
+#else
+struct LaneQuad { uint32_t v[4]; };
+#endif
+
+constexpr int lane_crec(int wc) { return wc * 12 + 32; }
+constexpr int lane_rrec(int wr, int nlp) { return wr * 12 + 32 + nlp * 8; }
+constexpr int kLaneStageBytes = 2048;    // LDS stage per wave: 64 lanes x 16 bytes of column records, the same of row records
+
+// wave-uniform load through the scalar unit (tile table, unit list: one per unit, requested a unit ahead)
+template <class T>
+DSP_LANE_HD T ldu(const T *p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  typedef const T __attribute__((address_space(4))) CT;
+  return *reinterpret_cast<CT *>(reinterpret_cast<uintptr_t>(p));
+#else
+  return *p;
+#endif
+}
+
+// element (e, lane) of a group's block [elements][64] through a 32-bit byte offset on the block's wave-uniform base:
+// global_load v, v_off, s[base] - one 32-bit add per access (e * 512 is scalar), no 64-bit vector address arithmetic.  A group's
+// block of one vector is 512 bytes per element: 4 GiB = 8 M elements (checked by the host).
+DSP_LANE_HD const double &lane_ld(const double *base, int e, uint32_t lane8) {
+  return *reinterpret_cast<const double *>(reinterpret_cast<const char *>(base) + ((uint32_t)e * 512u + lane8));
+}
+DSP_LANE_HD double &lane_st(double *base, int e, uint32_t lane8) {
+  return *reinterpret_cast<double *>(reinterpret_cast<char *>(base) + ((uint32_t)e * 512u + lane8));
+}
+
+// (device) the value must be in its register HERE: the wait for its load is placed at this point of straight-line code, with an
+// exact count, instead of inside the unit loop - where the merge over the back edge makes it s_waitcnt vmcnt(0), i.e. a wait for
+// the prefetched rows of the next unit as well
+DSP_LANE_HD void lane_pin(double &v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("" : "+v"(v));
+#else
+  (void)v;
+#endif
+}
+
+DSP_LANE_HD double lane_clamp(double v, double lo, double hi) { return fmin(fmax(v, lo), hi); }
+DSP_LANE_HD double lane_fin0(double v) { return (fabs(v) < INFINITY) ? v : 0.0; }
+DSP_LANE_HD bool lane_finite(double v) { return fabs(v) < INFINITY; }
+
+struct LaneProblem {                 // per handle (+ the shared bounds of the solve, written into the records)
+  int n, m, nl;
+  const char *crec, *rrec;                       // [n] column records, [m] row records (+ 1 KiB of slack behind each)
+  const int32_t *tiles, *units;                  // [ntile][8], [nunit][8]
+  int ntile, ring_mask;
+};
+
+struct LaneGroup {                   // one scenario group's block of every array (pointers already offset to the group)
+  const double *x_in, *y_in, *x0, *c, *y0;
+  double *x_out, *y_out;
+  const double *lb, *ub, *rlo, *rhi;             // per-scenario bounds (!SHARED)
+  const double *kap;                             // soft rows' compliances (QP)
+  const double *xbl;                             // [NLP][64] xbar of the long columns
+  const double *xpl;                             // [NLP][64] x+ of the long columns (MODE 1)
+  double *xp, *yp;                               // MODE 1 out; MODE 2 in
+};
+
+struct LaneScalars { double tau, sig, oml; bool done; };
+
+// per-lane result of a tile: lp[l] = the tile's part of (A^T y)_long_l; v[0 .. 12] the check sums (MODE 1: 0 .. 7, MODE 2: 8 .. 12)
+template <int NLP> struct LaneOut { double lp[NLP]; double v[13]; };
+
+template <int WC, int WR, int NLP, int CH, bool SHARED, bool QP, int MODE>
+struct LaneTile {
+  static constexpr int CREC = lane_crec(WC), RREC = lane_rrec(WR, NLP);
+  static_assert(CH * CREC <= 1024 && CH * RREC <= 1024, "a unit's records must fit one 16-byte-per-lane load");
+  struct Unit { int ys0, nys, cx0, ncx, rd0, nrd; };
+  struct Regs {
+    double ys[CH], x[CH], c[CH], x0[CH], y0[CH];
+    double lb[SHARED ? 1 : CH], ub[SHARED ? 1 : CH], rlo[SHARED ? 1 : CH], rhi[SHARED ? 1 : CH];
+    double kap[QP ? CH : 1];
+    double xp[MODE == 2 ? CH : 1];
+    LaneQuad cq, rq;                              // this lane's 16 bytes of the unit's column / row records
+  };
+
+  static DSP_LANE_HD Unit load_unit(const LaneProblem &P, int u) {
+    const LaneVecI<8> d = ldu(reinterpret_cast<const LaneVecI<8> *>(P.units) + u);
+    Unit q;
+    q.ys0 = d.v[0]; q.nys = d.v[1]; q.cx0 = d.v[2]; q.ncx = d.v[3]; q.rd0 = d.v[4]; q.nrd = d.v[5];
+    return q;
+  }
+
+  // every global load of a unit, unconditionally, to clamped addresses (no data-dependent control flow between the loads)
+  static DSP_LANE_HD void load_regs(const LaneProblem &P, const LaneGroup &G, const Unit &q, int lane, Regs &r) {
+    const uint32_t l8 = (uint32_t)lane * 8u;
+#if defined(__HIP_DEVICE_COMPILE__)
+    r.cq = *reinterpret_cast<const LaneQuad *>(P.crec + ((uint32_t)q.cx0 * (uint32_t)CREC + (uint32_t)lane * 16u));
+    if (MODE != 2) r.rq = *reinterpret_cast<const LaneQuad *>(P.rrec + ((uint32_t)q.rd0 * (uint32_t)RREC + (uint32_t)lane * 16u));
+#else
+    (void)P;
+#endif
+#pragma unroll
+    for (int k = 0; k < CH; ++k) r.ys[k] = lane_ld(MODE == 2 ? G.yp : G.y_in, q.ys0 + (k < q.nys ? k : 0), l8);
+#pragma unroll
+    for (int k = 0; k < CH; ++k) {
+      const int j = q.cx0 + (k < q.ncx ? k : 0);
+      r.c[k] = lane_ld(G.c, j, l8);
+      if (MODE == 2) r.xp[k] = lane_ld(G.xp, j, l8);
+      else { r.x[k] = lane_ld(G.x_in, j, l8); r.x0[k] = lane_ld(G.x0, j, l8); }
+      if (!SHARED) { r.lb[k] = lane_ld(G.lb, j, l8); r.ub[k] = lane_ld(G.ub, j, l8); }
+    }
+    if (MODE != 2) {
+#pragma unroll
+      for (int k = 0; k < CH; ++k) {
+        const int i = q.rd0 + (k < q.nrd ? k : 0);
+        r.y0[k] = lane_ld(G.y0, i, l8);
+        if (!SHARED) { r.rlo[k] = lane_ld(G.rlo, i, l8); r.rhi[k] = lane_ld(G.rhi, i, l8); }
+        if (QP) r.kap[k] = lane_ld(G.kap, i, l8);
+      }
+    }
+  }
+
+  template <class T>
+  static DSP_LANE_HD T rec(const char *base, int off) { return *reinterpret_cast<const T *>(base + off); }
+
+  // ring layout: [0, R) y window, [R, 2R) xbar window, [2R, 3R) x+ window (MODE 1); `stage`: the wave's record stage (device).
+  // Each of the three phases (stage, primal, dual) is BRANCH-FREE over its CH slots: a slot beyond the unit's count repeats the
+  // unit's first element - the same arithmetic on the same inputs, the same value stored to the same places - so the compiler is
+  // free to interleave the CH dependent chains (record read -> ring gathers -> arithmetic -> store); only sums are masked.
+  // Columns the tile does not own (halo, long) store their x to the SINK row (row n of every [n + 1][64] column block).
+  static DSP_LANE_HD void compute(const LaneProblem &P, const LaneGroup &G, const Unit &q, const Regs &r, const LaneScalars &sc,
+                                  int j0, int j1, int lane, double *ring, char *stage, const double (&xbl)[NLP], const double (&xpl)[NLP],
+                                  LaneOut<NLP> &out) {
+    const int M = P.ring_mask, R = M + 1;
+    const uint32_t l8 = (uint32_t)lane * 8u;
+    double *yr = ring + lane, *xr = ring + (size_t)R * 64 + lane, *xpr = ring + (size_t)2 * R * 64 + lane;
+#if defined(__HIP_DEVICE_COMPILE__)
+    // park the unit's records: lane L's 16 bytes at byte 16 L of each half of the stage; the LDS serves one wave's accesses in order
+    *reinterpret_cast<LaneQuad *>(stage + lane * 16) = r.cq;
+    if (MODE != 2) *reinterpret_cast<LaneQuad *>(stage + 1024 + lane * 16) = r.rq;
+    const char *cbase = stage, *rbase = stage + 1024;
+#else
+    (void)stage;
+    const char *cbase = P.crec + (size_t)q.cx0 * CREC, *rbase = P.rrec + (size_t)q.rd0 * RREC;
+#endif
+    if (q.nys > 0) {
+#pragma unroll
+      for (int k = 0; k < CH; ++k) yr[(size_t)((q.ys0 + (k < q.nys ? k : 0)) & M) * 64] = r.ys[k];
+    }
+    if (q.ncx > 0) {
+#pragma unroll
+      for (int k = 0; k < CH; ++k) {
+        const bool live = k < q.ncx;
+        const int kk = live ? k : 0, j = q.cx0 + kk;
+        const char *cr = cbase + kk * CREC;
+        const LaneVecD<WC> av = rec<LaneVecD<WC>>(cr, 0);
+        const LaneVecI<WC> ix = rec<LaneVecI<WC>>(cr, WC * 8);
+        const bool own = j >= j0 && j < j1 && (ix.v[0] >> 30) == 0;       // bit 30 of the first index: long column
+        double aty = 0.0;
+#pragma unroll
+        for (int e = 0; e < WC; ++e) aty = fma(av.v[e], yr[(size_t)(ix.v[e] & M) * 64], aty);
+        double lbv, ubv;
+        if (SHARED) { const LaneVecD<2> b = rec<LaneVecD<2>>(cr, WC * 12); lbv = b.v[0]; ubv = b.v[1]; }
+        else { lbv = r.lb[k]; ubv = r.ub[k]; }
+        if (MODE == 2) {
+          // reduced cost at y+ (kkt_col_terms of dsp_stream.hip); only the own columns count
+          const double w = (own && live) ? 1.0 : 0.0;
+          const double cj = r.c[k], xp = r.xp[k];
+          const double rc = cj - aty;
+          const double lp = lane_finite(lbv) ? fmax(rc, 0.0) : 0.0;
+          const double lm = lane_finite(ubv) ? fmax(-rc, 0.0) : 0.0;
+          const double dr = (rc - lp + lm) / rec<double>(cr, WC * 12 + 16);
+          out.v[8] = fma(w, dr * dr, out.v[8]);
+          out.v[9] = fma(w, cj * xp, out.v[9]);
+          out.v[10] = fma(w, lp * lane_fin0(lbv) - lm * lane_fin0(ubv), out.v[10]);
+          out.v[11] = fma(w, fabs(cj * xp), out.v[11]);
+          out.v[12] = fma(w, fabs(rc - lp + lm) * fabs(xp), out.v[12]);
+        } else {
+          const double x = r.x[k];
+          const double xp = lane_clamp(fma(-sc.tau, r.c[k] - aty, x), lbv, ubv);
+          const double tt = 2.0 * xp - x;
+          xr[(size_t)(j & M) * 64] = tt;
+          if (MODE == 1) xpr[(size_t)(j & M) * 64] = xp;
+          const int jw = own ? j : P.n;                                     // not ours: the sink row
+          if (MODE == 0) lane_st(G.x_out, jw, l8) = fma(sc.oml, r.x0[k] - tt, tt);
+          else {
+            lane_st(G.xp, (own && !sc.done) ? j : P.n, l8) = xp;
+            const double w = (own && live) ? 1.0 : 0.0;
+            const double dx = xp - x, d0 = xp - r.x0[k];
+            out.v[0] = fma(w, dx * dx, out.v[0]);
+            out.v[6] = fma(w, d0 * d0, out.v[6]);
+          }
+        }
+      }
+    }
+    if (MODE == 2 || q.nrd <= 0) return;
+#pragma unroll
+    for (int k = 0; k < CH; ++k) {
+      const bool live = k < q.nrd;
+      const int kk = live ? k : 0, i = q.rd0 + kk;
+      const char *rr = rbase + kk * RREC;
+      const LaneVecD<WR> av = rec<LaneVecD<WR>>(rr, 0);
+      const LaneVecI<WR> ix = rec<LaneVecI<WR>>(rr, WR * 8);
+      const LaneVecD<NLP> al = rec<LaneVecD<NLP>>(rr, WR * 12 + 16);
+      double ax = 0.0, axp = 0.0;
+#pragma unroll
+      for (int e = 0; e < WR; ++e) {
+        ax = fma(av.v[e], xr[(size_t)(ix.v[e] & M) * 64], ax);
+        if (MODE == 1) axp = fma(av.v[e], xpr[(size_t)(ix.v[e] & M) * 64], axp);
+      }
+#pragma unroll
+      for (int l = 0; l < NLP; ++l) {
+        ax = fma(al.v[l], xbl[l], ax);
+        if (MODE == 1) axp = fma(al.v[l], xpl[l], axp);
+      }
+      double rlo, rhi;
+      if (SHARED) { const LaneVecD<2> b = rec<LaneVecD<2>>(rr, WR * 12); rlo = b.v[0]; rhi = b.v[1]; }
+      else { rlo = r.rlo[k]; rhi = r.rhi[k]; }
+      const double y = yr[(size_t)(i & M) * 64];
+      const double gy = fma(-sc.sig, ax, y);
+      double yp = gy - lane_clamp(gy, -sc.sig * rhi, -sc.sig * rlo);
+      const double kp = QP ? r.kap[k] : 0.0;
+      if (QP) yp /= fma(sc.sig, kp, 1.0);                          // soft rows: proximal shrink (kappa = 0: hard row)
+      if (MODE == 0) {
+        const double tt = 2.0 * yp - y;
+        const double yn = fma(sc.oml, r.y0[k] - tt, tt);
+        lane_st(G.y_out, i, l8) = yn;
+        const double yw = live ? yn : 0.0;
+#pragma unroll
+        for (int l = 0; l < NLP; ++l) out.lp[l] = fma(al.v[l], yw, out.lp[l]);
+      } else {
+        lane_st(G.yp, sc.done ? P.m : i, l8) = yp;                  // (a finished scenario keeps the x+, y+ it finished with)
+        const double w = live ? 1.0 : 0.0;
+        const double yw = live ? yp : 0.0;
+#pragma unroll
+        for (int l = 0; l < NLP; ++l) out.lp[l] = fma(al.v[l], yw, out.lp[l]);
+        const double dy = yp - y;
+        const double nsadx = -sc.sig * (ax - axp);                 // -sig A (x+ - x)   (xbar - x+ = x+ - x)
+        out.v[1] = fma(w, dy * fma(2.0, nsadx, dy), out.v[1]);
+        double viol_s = fmax(rlo - axp, 0.0) + fmax(axp - rhi, 0.0);
+        double dobj = fmax(yp, 0.0) * lane_fin0(rlo) - fmax(-yp, 0.0) * lane_fin0(rhi);
+        double soft = 0.0;
+        if (QP && kp > 0.0) {                                      // soft row: no violation, quadratic terms of both objectives
+          const double dev = axp - rlo;
+          soft = 0.5 * dev * dev / kp;
+          dobj -= 0.5 * kp * yp * yp;
+          viol_s = 0.0;
+        }
+        out.v[7] = fma(w, soft, out.v[7]);
+        out.v[4] = fma(w, dobj, out.v[4]);
+        const double viol = viol_s / rec<double>(rr, WR * 12 + 16 + NLP * 8);
+        out.v[2] = fma(w, viol * viol, out.v[2]);
+        out.v[3] = fma(w, fabs(yp) * viol_s, out.v[3]);
+        const double d0 = yp - r.y0[k];
+        out.v[5] = fma(w, d0 * d0, out.v[5]);
+      }
+    }
+  }
+
+  // the whole tile: units [ubeg, uend), the next unit's rows requested before the current one is computed (two register sets,
+  // the loop unrolled by two: no copies between them)
+  static DSP_LANE_HD void run(const LaneProblem &P, const LaneGroup &G, int tile, int lane, const LaneScalars &sc_in, double *ring, char *stage,
+                              LaneOut<NLP> &out) {
+    LaneScalars sc = sc_in;
+    const LaneVecI<8> tp = ldu(reinterpret_cast<const LaneVecI<8> *>(P.tiles) + tile);
+    const int j0 = tp.v[2], j1 = tp.v[3], ubeg = tp.v[4], uend = tp.v[5];
+    const uint32_t l8 = (uint32_t)lane * 8u;
+    double xbl[NLP], xpl[NLP];
+#pragma unroll
+    for (int l = 0; l < NLP; ++l) {
+      xbl[l] = MODE == 2 ? 0.0 : lane_ld(G.xbl, l, l8);
+      xpl[l] = MODE == 1 ? lane_ld(G.xpl, l, l8) : 0.0;
+      out.lp[l] = 0.0;
+    }
+#pragma unroll
+    for (int q = 0; q < 13; ++q) out.v[q] = 0.0;
+    Unit qa = load_unit(P, ubeg), qb = qa;
+    Regs ra, rb;
+    load_regs(P, G, qa, lane, ra);
+#pragma unroll
+    for (int l = 0; l < NLP; ++l) { lane_pin(xbl[l]); if (MODE == 1) lane_pin(xpl[l]); }
+    lane_pin(sc.tau); lane_pin(sc.sig); lane_pin(sc.oml);
+    // the rings start from zeros: a padding entry of an empty vector multiplies whatever its slot holds by 0
+    const int R = P.ring_mask + 1;
+    for (int s = 0; s < (MODE == 1 ? 3 : 2) * R; ++s) ring[(size_t)s * 64 + lane] = 0.0;
+    for (int u = ubeg; u < uend; u += 2) {
+      if (u + 1 < uend) { qb = load_unit(P, u + 1); load_regs(P, G, qb, lane, rb); }
+      compute(P, G, qa, ra, sc, j0, j1, lane, ring, stage, xbl, xpl, out);
+      if (u + 1 >= uend) break;
+      if (u + 2 < uend) { qa = load_unit(P, u + 2); load_regs(P, G, qa, lane, ra); }
+      compute(P, G, qb, rb, sc, j0, j1, lane, ring, stage, xbl, xpl, out);
+    }
+  }
+};
+
+}  // namespace dsp

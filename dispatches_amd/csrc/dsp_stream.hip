@@ -480,57 +480,6 @@ __global__ void k_kkt_long_finish(StreamArgs a) {
   for (int q = 0; q < 5; ++q) out[q] = v[q];
 }
 
-// ---- control: the restart / termination decision of one scenario from its check sums (slot layout: k_check_rows / k_kkt_cols)
-// returns the mode for the apply step (0 = Halpern step, 1 = restart at (x+, y+)); sets c.done / c.status on termination
-__device__ int control_decide(const double *acc, StreamCtrl &c, const dsp_options &o, double eta, int iters_this_period) {
-  c.it += iters_this_period;
-  c.k += iters_this_period;
-  const double w = c.w, iw = 1.0 / w;
-  const double r = fmax(w * acc[0] + iw * acc[1], 0.0);        // squared fixed-point residual in the PDHG metric
-  int mode = 0;
-  if (!(r == r)) { c.status = DSP_STATUS_NUMERICAL; c.done = 1; }
-  else {
-    const double po = acc[9] + acc[7], dobj = acc[4] + acc[10];      // acc[7]: quadratic terms of the soft rows (0 for an LP)
-    c.pobj = po;
-    const double rp = sqrt(acc[2]) / (1.0 + c.qn), rd = sqrt(acc[8]) / (1.0 + c.cn);
-    const double gap = fabs(po - dobj);
-    const double rg = gap / (1.0 + fabs(po) + fabs(dobj));
-    bool fin;                                                    // same tests as the fused kernel (dsp_kernels.hip)
-    if (o.eps_obj > 0.0) {
-      const double lim = fmax(o.eps_obj * (1.0 + fabs(po + c.c0)), 1e-12 * acc[11]);
-      fin = rp <= o.eps_rel && rd <= o.eps_rel && gap + acc[3] + acc[12] <= lim;
-    } else {
-      fin = rp <= o.eps_rel && rd <= o.eps_rel && rg <= o.eps_rel;
-    }
-    c.last_rp = rp; c.last_rd = rd; c.last_rg = rg;
-    if (fin) { c.status = DSP_STATUS_OPTIMAL; c.done = 1; }
-    else if (c.it >= o.max_iter) { c.status = DSP_STATUS_ITERATION_LIMIT; c.done = 1; }
-    else {
-      const double bs2 = o.restart_sufficient * o.restart_sufficient, bn2 = o.restart_necessary * o.restart_necessary;
-      const bool first = !(c.r0 < INFINITY);
-      const bool decayed = (r <= bs2 * c.r0) || (r <= bn2 * c.r0 && r > c.rprev);
-      const bool artificial = (double)c.k >= o.restart_artificial * (double)c.it;
-      if (first) c.r0 = r;
-      c.rprev = r;
-      if (!first && (decayed || artificial)) {
-        double wn = w;
-        if (acc[6] > 1e-28 && acc[5] > 1e-28) {
-          const double e = log(w) + 0.5 * (log(acc[6]) - log(acc[5]));
-          const double dl = fmin(fmax(-o.pid_kp * e, -o.max_dlog_weight), o.max_dlog_weight);
-          wn = w * exp(dl);
-        }
-        wn = fmin(fmax(wn, c.w_lo), fmax(c.w_hi, c.w_lo));
-        c.w = wn; c.tau = eta / wn; c.sig = eta * wn;
-        c.k = 0; c.r0 = INFINITY; c.rprev = INFINITY;
-        c.nrestart += 1;
-        mode = 1;
-      }
-    }
-  }
-  c.mode = mode;
-  return mode;
-}
-
 // one block per scenario sums the check partials in a fixed order and decides
 __global__ void k_control(StreamArgs a, int iters_this_period) {
   const int s = blockIdx.x;
@@ -1377,10 +1326,12 @@ hipError_t stream_create(const HostCSR &A_scaled, const HostCSR &AT_scaled, cons
       S->P.F.own_max = H.own_max; S->P.F.halo_max = H.halo_max;
     }
   }
-  return hipSuccess;
+  // lane-per-scenario form (round 4): banded matrices with at most 8 long columns
+  return lane_create(A_scaled, AT_scaled, S);
 }
 
 void stream_destroy(StreamSolver *S) {
+  lane_destroy(S);
   for (void *p : S->allocs) (void)hipFree(p);
   for (void *p : S->work_allocs) (void)hipFree(p);
   S->allocs.clear(); S->work_allocs.clear();
@@ -1593,6 +1544,15 @@ static hipError_t stream_solve_locked(StreamSolver *S, const dsp_batch &batch, c
       hipLaunchKernelGGL(k_block_solve, dim3(B), dim3(nt), lds, st, a);
       hipLaunchKernelGGL(k_finalize, dim3(a.nblk, B), dim3(kTB), 0, st, a);
       *periods_run = -1;
+      return hipGetLastError();
+    }
+  }
+  // banded matrix with a handful of long columns: the lane-per-scenario form (dsp_stream_lane.hip)
+  {
+    bool used = false;
+    if ((e = lane_run(S, a, st, periods_run, &used)) != hipSuccess) return e;
+    if (used) {
+      hipLaunchKernelGGL(k_finalize, dim3(a.nblk, B), dim3(kTB), 0, st, a);
       return hipGetLastError();
     }
   }

@@ -62,6 +62,61 @@ struct StreamCtrl {
   int k, it, status, done, mode, nrestart;
 };
 
+#if defined(__HIPCC__)
+// ---- control: the restart / termination decision of one scenario from its check sums (slot layout: k_check_rows / k_kkt_cols of dsp_stream.hip;
+// shared with the lane-per-scenario form, dsp_stream_lane.hip)
+// returns the mode for the apply step (0 = Halpern step, 1 = restart at (x+, y+)); sets c.done / c.status on termination
+__device__ inline int control_decide(const double *acc, StreamCtrl &c, const dsp_options &o, double eta, int iters_this_period) {
+  c.it += iters_this_period;
+  c.k += iters_this_period;
+  const double w = c.w, iw = 1.0 / w;
+  const double r = fmax(w * acc[0] + iw * acc[1], 0.0);        // squared fixed-point residual in the PDHG metric
+  int mode = 0;
+  if (!(r == r)) { c.status = DSP_STATUS_NUMERICAL; c.done = 1; }
+  else {
+    const double po = acc[9] + acc[7], dobj = acc[4] + acc[10];      // acc[7]: quadratic terms of the soft rows (0 for an LP)
+    c.pobj = po;
+    const double rp = sqrt(acc[2]) / (1.0 + c.qn), rd = sqrt(acc[8]) / (1.0 + c.cn);
+    const double gap = fabs(po - dobj);
+    const double rg = gap / (1.0 + fabs(po) + fabs(dobj));
+    bool fin;                                                    // same tests as the fused kernel (dsp_kernels.hip)
+    if (o.eps_obj > 0.0) {
+      const double lim = fmax(o.eps_obj * (1.0 + fabs(po + c.c0)), 1e-12 * acc[11]);
+      fin = rp <= o.eps_rel && rd <= o.eps_rel && gap + acc[3] + acc[12] <= lim;
+    } else {
+      fin = rp <= o.eps_rel && rd <= o.eps_rel && rg <= o.eps_rel;
+    }
+    c.last_rp = rp; c.last_rd = rd; c.last_rg = rg;
+    if (fin) { c.status = DSP_STATUS_OPTIMAL; c.done = 1; }
+    else if (c.it >= o.max_iter) { c.status = DSP_STATUS_ITERATION_LIMIT; c.done = 1; }
+    else {
+      const double bs2 = o.restart_sufficient * o.restart_sufficient, bn2 = o.restart_necessary * o.restart_necessary;
+      const bool first = !(c.r0 < INFINITY);
+      const bool decayed = (r <= bs2 * c.r0) || (r <= bn2 * c.r0 && r > c.rprev);
+      const bool artificial = (double)c.k >= o.restart_artificial * (double)c.it;
+      if (first) c.r0 = r;
+      c.rprev = r;
+      if (!first && (decayed || artificial)) {
+        double wn = w;
+        if (acc[6] > 1e-28 && acc[5] > 1e-28) {
+          const double e = log(w) + 0.5 * (log(acc[6]) - log(acc[5]));
+          const double dl = fmin(fmax(-o.pid_kp * e, -o.max_dlog_weight), o.max_dlog_weight);
+          wn = w * exp(dl);
+        }
+        wn = fmin(fmax(wn, c.w_lo), fmax(c.w_hi, c.w_lo));
+        c.w = wn; c.tau = eta / wn; c.sig = eta * wn;
+        c.k = 0; c.r0 = INFINITY; c.rprev = INFINITY;
+        c.nrestart += 1;
+        mode = 1;
+      }
+    }
+  }
+  c.mode = mode;
+  return mode;
+}
+
+#endif
+
 struct StreamWork {
   double *x, *x0, *xp, *xbar, *c, *lb, *ub;     // [B][n]  scaled space
   double *y, *y0, *yp, *rlo, *rhi, *kap;        // [B][m]   (kap: scaled compliance of the soft rows, QP only)
@@ -85,12 +140,15 @@ struct StreamArgs {
   int nchunk_max;  // stride of long_partial
 };
 
+struct LaneState;                      // lane-per-scenario form (dsp_stream_lane.hip); nullptr = not applicable to this matrix
+
 struct StreamSolver {
   StreamProblem P{};
   StreamWork W{};
   int work_B = 0;
   std::vector<void *> allocs, work_allocs;
   int *ndone_host = nullptr;
+  LaneState *lane = nullptr;
   size_t last_bytes_per_iteration = 0;   // algorithmic HBM bytes per scenario and plain iteration of the form the last solve ran
   std::mutex mu;          // one solve at a time per handle: the workspace above is per handle, not per call (stream_solve)
   size_t lds_limit = 160 * 1024 - 2048;   // dynamic LDS available to the block-resident form (static __shared__ on top)
@@ -102,5 +160,10 @@ void stream_destroy(StreamSolver *S);
 hipError_t stream_solve(StreamSolver *S, const dsp_batch &batch, const dsp_options &opt, double eta, hipStream_t st,
                         int *periods_run);
 size_t stream_bytes_per_iteration(const StreamSolver *S);
+
+// dsp_stream_lane.hip
+hipError_t lane_create(const HostCSR &A_scaled, const HostCSR &AT_scaled, StreamSolver *S);
+void lane_destroy(StreamSolver *S);
+hipError_t lane_run(StreamSolver *S, StreamArgs &a, hipStream_t st, int *periods_run, bool *used);
 
 }  // namespace dsp

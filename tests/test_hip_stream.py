@@ -38,11 +38,13 @@ def test_price_taker_family_matches_oracle_and_is_reproducible():
 
 
 @gpu
-def test_fused_iteration_reproduces_the_two_launch_form(monkeypatch):
-    """Two weeks of the price-taker family (n = 2019: beyond the block-resident form, so the launch-per-step forms run): the
-    one-launch iteration for banded matrices (k_fused: tiles with halos, xbar in LDS, x / y double buffered, the design column
-    through per-tile partial sums) against the two-launch form it replaces - same termination, same objectives to rounding,
-    iteration counts within a check period or two, both against the oracle."""
+def test_one_launch_forms_reproduce_the_two_launch_form(monkeypatch):
+    """Two weeks of the price-taker family (n = 2019: beyond the block-resident form, so the launch-per-step forms run) in every form
+    of the streaming iteration: the lane-per-scenario form (round 4, the default: scenario-minor storage, one lane per scenario
+    walking a tile of rows and columns alone, rings in LDS, scalar matrix loads; default tiling and 12-row tiles), the round-3
+    workgroup-per-tile form (k_fused_pre / k_fused, DSP_STREAM_NO_LANE=1) and the two-launch form all three replace - same
+    termination, same objectives to rounding, iteration counts within a check period or two, every form against the oracle; with the
+    reference's chain and with the two-level accumulator (4 long columns)."""
     from dispatches_amd import scenarios
     from dispatches_amd.hip_solver import HipPdlpSolver
     from oracle import dispatch_lp_oracle as orc
@@ -53,46 +55,37 @@ def test_fused_iteration_reproduces_the_two_launch_form(monkeypatch):
         P, _ = orc.wind_battery_price_taker(T, cf, lmp * lm, batt_cap_factor=bf)
         ref.append(P.solve(tight=True)[1])
     ref = np.array(ref)
-    out = {}
-    # fused = k_fused_pre (all loads up front, XCD-major workgroup order: the default); fused_staged = k_fused (the form for tiles
-    # k_fused_pre does not cover); fused_grid_order = k_fused_pre with the plain grid order
-    for form, env, extra in (("fused", "0", {}), ("fused_staged", "0", {"DSP_FUSED_V": "1"}),
-                             ("fused_grid_order", "0", {"DSP_FUSED_XCD": "0"}),
-                             # every global load ahead of the first barrier (round 3's first form; the default requests the matrix
-                             # entries after the barriers and parks y0 in LDS: fewer registers, more resident waves)
-                             ("fused_loads_up_front", "0", {"DSP_FUSED_DEFER": "0"}),
-                             # 64-row tiles: 16 tiles = two whole rounds of 8 for the XCD-major order, 3 scenario groups per tile
-                             ("fused_small_tiles", "0", {"DSP_FUSED_RB": "64"}),
-                             ("fused_small_tiles_grid_order", "0", {"DSP_FUSED_RB": "64", "DSP_FUSED_XCD": "0"}),
-                             ("two_launch", "1", {})):
-        monkeypatch.setenv("DSP_STREAM_NO_FUSED", env)
-        for k in ("DSP_FUSED_V", "DSP_FUSED_XCD", "DSP_FUSED_RB", "DSP_FUSED_DEFER"):
+    keys = ("DSP_STREAM_NO_LANE", "DSP_STREAM_NO_FUSED", "DSP_FUSED_V", "DSP_FUSED_XCD", "DSP_FUSED_RB", "DSP_FUSED_DEFER", "DSP_LANE_ROWS")
+    for thr in ("chain", "two_level"):
+        out = {}
+        for form, extra in (("lane", {}), ("lane_small_tiles", {"DSP_LANE_ROWS": "12"}), ("lane_large_tiles", {"DSP_LANE_ROWS": "400"}),
+                            ("fused", {"DSP_STREAM_NO_LANE": "1"}), ("fused_staged", {"DSP_STREAM_NO_LANE": "1", "DSP_FUSED_V": "1"}),
+                            ("fused_small_tiles", {"DSP_STREAM_NO_LANE": "1", "DSP_FUSED_RB": "64"}),
+                            ("two_launch", {"DSP_STREAM_NO_LANE": "1", "DSP_STREAM_NO_FUSED": "1"})):
+            for k in keys:
+                monkeypatch.delenv(k, raising=False)
+            for k, v in extra.items():
+                monkeypatch.setenv(k, v)
+            solver = HipPdlpSolver(device=0, check_every=64)
+            handles, model = scenarios.price_taker_batch(T, B, solver, throughput=thr)
+            solver.solve(model, tee=True)
+            st = solver.last_stats
+            assert st.streaming == 1 and (model.status == 0).all(), (thr, form, model.status, model.iterations)
+            n, m = model.lp.n, model.lp.m
+            # algorithmic bytes per scenario-iteration: 4 n + 3 m doubles in one launch (the family shares its bounds), 8 n + 6 m in two
+            assert st.stream_bytes_per_iteration == (8 * (8 * n + 6 * m) if form == "two_launch" else 8 * (4 * n + 3 * m)), (thr, form)
+            err = np.abs(model.objective - ref) / np.maximum(1.0, np.abs(ref))
+            assert err.max() < 1e-6, (thr, form, err)
+            out[form] = (model.objective.copy(), model.iterations.copy())
+        for k in keys:
             monkeypatch.delenv(k, raising=False)
-        for k, v in extra.items():
-            monkeypatch.setenv(k, v)
-        solver = HipPdlpSolver(device=0, check_every=64)
-        handles, model = scenarios.price_taker_batch(T, B, solver)
-        solver.solve(model, tee=True)
-        st = solver.last_stats
-        assert st.streaming == 1 and (model.status == 0).all(), (form, model.status, model.iterations)
-        n, m = model.lp.n, model.lp.m
-        # algorithmic bytes per scenario-iteration: 4 n + 3 m doubles fused (the family shares its bounds), 8 n + 6 m in two launches
-        assert st.stream_bytes_per_iteration == (8 * (4 * n + 3 * m) if form.startswith("fused") else 8 * (8 * n + 6 * m)), form
-        err = np.abs(model.objective - ref) / np.maximum(1.0, np.abs(ref))
-        assert err.max() < 1e-6, (form, err)
-        out[form] = (model.objective.copy(), model.iterations.copy())
-    assert np.allclose(out["fused"][0], out["two_launch"][0], rtol=1e-7, atol=1e-7)
-    # the workgroup order does not touch the arithmetic: identical iteration counts and objectives; the staged kernel is a
-    # different instruction stream for the same formulas
-    assert (out["fused_grid_order"][1] == out["fused"][1]).all() and (out["fused_grid_order"][0] == out["fused"][0]).all()
-    assert np.allclose(out["fused_loads_up_front"][0], out["fused"][0], rtol=1e-9, atol=1e-9)
-    assert (np.abs(out["fused_loads_up_front"][1] - out["fused"][1]) <= 2 * 64).all()
-    assert (out["fused_small_tiles_grid_order"][1] == out["fused_small_tiles"][1]).all()
-    assert (out["fused_small_tiles_grid_order"][0] == out["fused_small_tiles"][0]).all()
-    assert np.allclose(out["fused_small_tiles"][0], out["fused"][0], rtol=1e-7, atol=1e-7)
-    assert np.allclose(out["fused_staged"][0], out["fused"][0], rtol=1e-9, atol=1e-9)
-    assert (np.abs(out["fused_staged"][1] - out["fused"][1]) <= 2 * 64).all(), (out["fused_staged"][1], out["fused"][1])
-    assert (np.abs(out["fused"][1] - out["two_launch"][1]) <= 0.05 * out["two_launch"][1] + 128).all(), (out["fused"][1], out["two_launch"][1])
+        for form in out:
+            assert np.allclose(out[form][0], out["two_launch"][0], rtol=1e-7, atol=1e-7), (thr, form)
+            assert (np.abs(out[form][1] - out["two_launch"][1]) <= 0.05 * out["two_launch"][1] + 128).all(), (thr, form, out[form][1], out["two_launch"][1])
+        # the tiling changes the summation order of the long columns' A^T y only
+        assert np.allclose(out["lane_small_tiles"][0], out["lane"][0], rtol=1e-9, atol=1e-9)
+        assert np.allclose(out["lane_large_tiles"][0], out["lane"][0], rtol=1e-9, atol=1e-9)
+        assert np.allclose(out["fused_staged"][0], out["fused"][0], rtol=1e-9, atol=1e-9)
 
 
 @gpu
@@ -185,9 +178,11 @@ def test_nuclear_price_taker_enumeration_on_the_gpu():
     closed = np.array([-1e-6 * orc.nuclear_price_taker_closed_form(model.lmp, hp, pc * 400.0) for hp, pc in model.family])
     err = np.abs(model.objective - closed) / np.maximum(1.0, np.abs(closed))
     assert err.max() < 1e-6, (err.max(), model.iterations)
-    # n (incl. 3 design columns) and the fused form's algorithmic bytes with per-scenario bounds: 6 n + 5 m doubles
+    # n (incl. 3 design columns) and the algorithmic bytes: the members differ in the bounds of ONE design column (a long column, whose
+    # bounds the lane form keeps per scenario in any case), so the batch shares every other bound: 4 n + 3 m doubles (the round-3
+    # form read all bounds per scenario: 6 n + 5 m)
     n, m = model.lp.n, model.lp.m
-    assert n == 8 * T + 3 and solver.last_stats.stream_bytes_per_iteration == 8 * (6 * n + 5 * m)
+    assert n == 8 * T + 3 and solver.last_stats.stream_bytes_per_iteration == 8 * (4 * n + 3 * m)
     # the same path at a horizon the oracle solves in seconds
     T2, B2 = 720, 12
     handles, small = scenarios.nuclear_price_taker_batch(T2, B2, solver)

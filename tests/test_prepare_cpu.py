@@ -183,6 +183,66 @@ def test_fused_iteration_plan_with_long_columns_at_index_zero(fused_harness, tmp
     assert res["err_x"] < 1e-12 and res["err_y"] < 1e-12 and res["err_lp"] < 1e-8
 
 
+@pytest.fixture(scope="module")
+def lane_harness(tmp_path_factory):
+    exe = str(tmp_path_factory.mktemp("lane") / "lane_harness")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-o", exe, os.path.join(ROOT, "tests", "lane_harness.cpp")], check=True)
+    return exe
+
+
+def _lane_case(name, T):
+    from dispatches_amd import scenarios
+    if name == "wind_battery_chain":
+        return scenarios.price_taker_batch(T, 1, _NoSolver(), throughput="chain")[1]
+    if name == "wind_battery_two_level":
+        return scenarios.price_taker_batch(T, 1, _NoSolver())[1]
+    if name == "pem_chain":
+        return scenarios.pem_price_taker_batch(T, 1, _NoSolver(), inputs="rts303")[1]
+    if name == "pem_two_level":
+        return scenarios.pem_price_taker_batch(T, 1, _NoSolver(), inputs="rts303", throughput="two_level", coarse_nodes=3)[1]
+    return scenarios.nuclear_price_taker_batch(T, 1, _NoSolver())[1]
+
+
+@pytest.mark.parametrize("family,T,rows,long_cols,widths", [
+    ("wind_battery_chain", 336, 12, 1, (4, 4, 4)), ("wind_battery_chain", 336, 100, 1, (4, 4, 4)),
+    ("wind_battery_two_level", 1344, 24, 4, (4, 4, 4)), ("wind_battery_two_level", 1344, 96, 4, (4, 4, 4)),
+    ("pem_chain", 1000, 24, 3, (4, 4, 4)), ("pem_two_level", 1000, 48, 6, (4, 4, 8)),
+    ("nuclear", 720, 16, 3, (4, 8, 4)), ("nuclear", 720, 96, 3, (4, 8, 4))])
+def test_lane_form_of_the_streaming_iteration(lane_harness, tmp_path, family, T, rows, long_cols, widths):
+    """The lane-per-scenario form of the streaming iteration (round 4; csrc/dsp_lane_plan.hpp, dsp_lane_tile.hpp, dsp_stream_lane.hip):
+    the harness builds records, tiles and walks with the library's host code and runs the SAME per-lane routine the kernel runs
+    (LaneTile::run: rings poisoned with NaN, three scenarios with their own step sizes and anchor weights) for the plain iteration,
+    the check iteration and the reduced costs: iterates, x+ / y+, the thirteen check sums and the long columns' partial sums of
+    A^T y against their definitions on the CSR; every row and column is written."""
+    lp = _lane_case(family, T).lp
+    A = sp.csr_matrix((lp.data, lp.indices, lp.indptr), shape=(lp.m, lp.n))
+    A.sort_indices()
+    path = str(tmp_path / "a.bin")
+    _write_csr(A, path)
+    res = json.loads(subprocess.run([lane_harness, path, str(rows)], check=True, capture_output=True, text=True).stdout)
+    assert res["ok"], res
+    assert res["long_cols"] == long_cols and (res["wc"], res["wr"], res["nlp"]) == widths
+    assert res["ntile"] == -(-lp.m // rows) and res["ring"] <= 32
+    assert res["missing"] == 0 and res["nan_partials"] == 0
+    assert max(res["err_x"], res["err_y"], res["err_xp"], res["err_yp"]) < 1e-11 and res["err_sums"] < 1e-11
+    assert res["err_lp"] < 1e-7                                    # (absolute, on sums of thousands of unscaled terms)
+    assert res["nunit"] <= 2.2 * -(-lp.m // 4)                     # the walks keep their units reasonably full
+
+
+def test_lane_plan_refuses_matrices_that_are_not_banded(lane_harness, tmp_path):
+    """The parallel-prefix form of the accumulator reaches across the whole horizon: no walk fits the ring budget, the handle keeps
+    the two-launch form."""
+    from dispatches_amd import scenarios
+    _, model = scenarios.price_taker_batch(1000, 1, _NoSolver(), throughput="scan")
+    lp = model.lp
+    A = sp.csr_matrix((lp.data, lp.indices, lp.indptr), shape=(lp.m, lp.n))
+    A.sort_indices()
+    path = str(tmp_path / "a.bin")
+    _write_csr(A, path)
+    res = json.loads(subprocess.run([lane_harness, path, "64"], check=True, capture_output=True, text=True).stdout)
+    assert not res["ok"]
+
+
 def test_fused_plan_refuses_matrices_that_are_not_banded(fused_harness, tmp_path):
     """A matrix whose products reach across the whole index range (here: the parallel-prefix form of the throughput accumulator,
     and a random sparse matrix) gets no plan: the two-launch form stays."""
