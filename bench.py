@@ -188,18 +188,39 @@ def bench_double_loop(args, rank, local_rank, world, dev):
         dist.destroy_process_group()
 
 
+STREAM_FORMS = {0: "none", 1: "two_launch", 2: "tile", 3: "lane", 4: "block"}
+STREAM_KERNELS = {1: "k_primal + k_dual_halpern", 2: "k_fused_pre / k_fused", 3: "k_lane<.., 0> (+ k_lane_long<0>)", 4: "k_block_solve"}
+
+
+def _price_taker_cpu_worker(args):
+    """CPU baseline leg of --workload price_taker --solve: one member of the family by the oracle (HiGHS on the un-reduced LP)."""
+    T, k = args
+    sys.path.insert(0, ROOT)
+    from dispatches_amd import scenarios
+    from oracle import dispatch_lp_oracle as orc
+    cf, lmp = scenarios.price_taker_inputs(T)
+    bf, lm = scenarios.PRICE_TAKER_FAMILY[k % len(scenarios.PRICE_TAKER_FAMILY)]
+    t = time.perf_counter()
+    P, _ = orc.wind_battery_price_taker(T, cf, lmp * lm, batt_cap_factor=bf)
+    x, obj = P.solve(tight=True)
+    return k, float(obj), time.perf_counter() - t
+
+
 def bench_price_taker(args, rank, local_rank, world, dev):
     """The HBM-bound workloads of the path: the reference's long-horizon price-taker design LPs on the HBM-resident streaming PDLP,
     --batch scenarios per GPU sharing ONE constraint matrix:
         price_taker          wind + battery, wind_battery_optimize (T = --horizon hourly periods, default 8736; n = m = 6 T)
         pem_price_taker      wind + battery + PEM, wind_battery_pem_optimize (n = 7 T)
-        nuclear_price_taker  the 60-point (hydrogen price x PEM capacity) enumeration of the nuclear case (n = 8 T; per-scenario bounds)
-    One step = one check period (64 PDHG iterations) of the whole batch; the solve is capped at steps x 64 iterations (this measures
-    the iteration RATE; convergence of the year-long horizons is a test: tests/test_hip_stream.py).  roofline.bound = "hbm":
-    algorithmic bytes per scenario-iteration of the form that ran (dsp_stats::stream_bytes_per_iteration: fused one-launch iteration
-    4 n + 3 m doubles with shared bounds, 6 n + 5 m with per-scenario bounds; two-launch form 8 n + 6 m) / HIP-event time of the
-    solve on its stream; `traffic` = FETCH_SIZE x 2 + WRITE_SIZE of the iteration kernel per launch from the newest committed
-    rocprofv3 PMC summary that holds it (profiles/*_stream_pmc_summary.csv)."""
+        nuclear_price_taker  the 60-point (hydrogen price x PEM capacity) enumeration of the nuclear case (n = 8 T; the members differ
+                             in the bounds of one design column)
+    Default: one step = one check period (64 PDHG iterations) of the whole batch; the solve is capped at steps x 64 iterations (the
+    iteration RATE).  --solve: the batch is solved to optimality instead (value = year-long LPs solved / s; `seconds_per_batch`;
+    objectives against the committed oracle fixture where it holds them) and `cpu_baseline` times the oracle (HiGHS, un-reduced LP)
+    on a bounded sample of the same members on the host's cores.  roofline.bound = "hbm": algorithmic bytes per scenario-iteration
+    of the form that ran (dsp_stats::stream_form / stream_bytes_per_iteration: one-launch forms 4 n + 3 m doubles with shared bounds,
+    two-launch form 8 n + 6 m) / HIP-event time of the solve on its stream (check sequences included); `traffic` = FETCH_SIZE x 2 +
+    WRITE_SIZE per launch of the iteration kernel OF THAT FORM from the newest committed rocprofv3 PMC summary of this round
+    (profiles/r4*_pmc_summary*.csv, named in `traffic_from`; null if there is none: it is an archived measurement, not one of this run)."""
     import torch
     import torch.distributed as dist
     from dispatches_amd import scenarios
@@ -225,7 +246,7 @@ def bench_price_taker(args, rank, local_rank, world, dev):
     if world > 1:
         dist.barrier()
     t0 = time.perf_counter()
-    st, model = run(args.steps)
+    st, model = run(40000 if args.solve else args.steps)
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     t = torch.tensor([elapsed, st.kernel_ms * 1e-3], dtype=torch.float64, device=dev)
@@ -238,39 +259,70 @@ def bench_price_taker(args, rank, local_rank, world, dev):
         its = int(model.iterations.sum())
         byt = float(st.stream_bytes_per_iteration) * its
         n, m = model.lp.n, model.lp.m
+        form = int(getattr(st, "stream_form", 0))
+        # archived counters of the iteration kernel of the form that ran, this round's summaries only
         traffic = src = None
-        # counters of THIS workload's iteration kernel: profiles/r*_stream_pmc_summary_<workload>.csv; the summaries without a
-        # workload in their name were collected on the wind+battery price-taker LP (tools/gpu_stream.py) and serve only that one
-        pats = [f"r*_stream_pmc_summary_{args.workload}.csv"] + (["r*_stream_pmc_summary*.csv"] if args.workload == "price_taker" else [])
-        files = [f for pat in pats for f in glob.glob(os.path.join(ROOT, "profiles", pat))
-                 if args.workload == "price_taker" or f.endswith(f"_{args.workload}.csv")]
-        files = [f for f in files if not any(f.endswith(f"_{w}.csv") for w in ("pem_price_taker", "nuclear_price_taker") if w != args.workload)]
-        for f in sorted(set(files), key=os.path.basename, reverse=True):
-            c = {}
-            for row in csv.DictReader(open(f)):
-                if "k_fused" in row["kernel"]:
-                    c[row["counter"]] = float(row["mean_counter_value"])
-            if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
-                traffic, src = (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0, os.path.basename(f)
-                break
-        print(json.dumps({
+        kname = {3: "k_lane<", 2: "k_fused"}.get(form)
+        if kname:
+            pats = [f"r4*_pmc_summary*{args.workload}*.csv"] + (["r4*_lane_pmc_summary_B*.csv", "r4*_stream_pmc_summary*.csv"] if args.workload == "price_taker" else [])
+            files = [f for pat in pats for f in glob.glob(os.path.join(ROOT, "profiles", pat))]
+            for f in sorted(set(files), key=os.path.basename, reverse=True):
+                c = {}
+                for row in csv.DictReader(open(f)):
+                    if kname in row["kernel"] and ("0>" in row["kernel"] or form == 2):
+                        c.setdefault(row["counter"], float(row["mean_counter_value"]))
+                if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+                    traffic, src = (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0, os.path.basename(f)
+                    break
+        line = {
             "metric": f"PDHG scenario-iterations/sec, {args.workload} design LP, T={T} (n={n}, m={m}), batch={B}",
             "value": world * its / k_s, "unit": "scenario-iterations/s", "n_gpus": world, "steps": args.steps, "warmup": max(1, args.warmup),
-            "ms_per_step": 1e3 * k_s / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+            "ms_per_step": 1e3 * k_s / max(1, args.steps), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic", "world_size": world,
-            "config": {"workload": f"{args.workload}: {B} scenarios/GPU sharing one constraint matrix, T = {T} h, streaming PDLP capped at "
-                                   f"{args.steps} check periods of {ce} iterations" + ("" if thr == "chain" else f", throughput accumulator in its {thr} form"),
-                       "throughput_form": thr, "solved_to_optimality": int((model.status == 0).sum()),
-                       "iterations_per_scenario": float(model.iterations.mean()), "status_counts": np.bincount(model.status, minlength=5).tolist(),
+            "config": {"workload": f"{args.workload}: {B} scenarios/GPU sharing one constraint matrix, T = {T} h, streaming PDLP "
+                                   + ("solved to optimality" if args.solve else f"capped at {args.steps} check periods of {ce} iterations")
+                                   + ("" if thr == "chain" else f", throughput accumulator in its {thr} form"),
+                       "throughput_form": thr, "stream_form": STREAM_FORMS.get(form, str(form)), "solved_to_optimality": int((model.status == 0).sum()),
+                       "iterations_per_scenario": float(model.iterations.mean()), "max_iterations": int(model.iterations.max()),
+                       "status_counts": np.bincount(model.status, minlength=5).tolist(),
                        "us_per_batch_iteration": 1e6 * k_s / max(1, int(model.iterations.max())), "host_wall_s": float(t[0].item())},
-            "roofline": {"bound": "hbm", "kernel": "k_fused_pre / k_fused (+ check sequence every 64 iterations)", "achieved": byt / k_s / 1e9,
+            "roofline": {"bound": "hbm", "kernel": STREAM_KERNELS.get(form, "?") + f" (+ check sequence every {ce} iterations)", "achieved": byt / k_s / 1e9,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": byt / k_s / 1e9 / HBM_PEAK_GBS,
-                         "traffic": traffic, "traffic_from": src, "traffic_note": "HBM bytes per launch of the iteration kernel (FETCH_SIZE x 2 + WRITE_SIZE) from the newest committed counter summary of this workload; null if none",
+                         "traffic": traffic, "traffic_from": src,
+                         "traffic_note": "ARCHIVED: HBM bytes per launch of the iteration kernel of this form (FETCH_SIZE x 2 + WRITE_SIZE) from the newest committed "
+                                         "counter summary of this round, at the batch it was collected on (its file name); null if none - not measured in this run",
                          "algorithmic_bytes_per_scenario_iteration": int(st.stream_bytes_per_iteration),
                          "two_launch_form_bytes_per_scenario_iteration": 8 * (8 * n + 6 * m),
-                         "note": "HBM-resident PDLP, fused one-launch iteration for banded matrices: x, x0, c, y, y0 read + x, y written "
-                                 "(+ bounds when they differ per scenario); xbar and both products' gathers stay in LDS; time = HIP events "
-                                 "around the whole solve on its stream (includes the check sequences)"}}))
+                         "note": "HBM-resident PDLP: x, x0, c, y, y0 read + x, y written per scenario-iteration (bounds are shared by the batch or kept per "
+                                 "scenario for the long columns only); xbar and both products' gathers stay in LDS; time = HIP events around the whole "
+                                 "solve on its stream (includes the long-column launches and the check sequences; with --solve also the iterations "
+                                 "finished scenarios no longer take part in: frac then understates the kernel)"}}
+        if args.solve:
+            line["metric"] = f"year-long design LPs solved/sec, {args.workload}, T={T} (n={n}, m={m}), batch={B}"
+            line["value"] = world * int((model.status == 0).sum()) / k_s
+            line["unit"] = "LPs/s"
+            line["steps"] = 1
+            line["ms_per_step"] = 1e3 * k_s
+            line["config"]["seconds_per_batch"] = k_s
+            fx_path = os.path.join(ROOT, "tests", "golden", "oracle_price_taker.npz")
+            if args.workload == "price_taker" and os.path.exists(fx_path):
+                fx = np.load(fx_path)
+                if f"T{T}/obj" in fx.files:
+                    ref = fx[f"T{T}/obj"][np.arange(B) % len(scenarios.PRICE_TAKER_FAMILY)]
+                    line["config"]["max_rel_objective_error_vs_oracle_fixture"] = float((np.abs(model.objective - ref) / np.maximum(1.0, np.abs(ref))).max())
+            if args.workload == "price_taker" and args.cpu_sample != 0:
+                import multiprocessing as mp
+                nsample = max(1, min(B, len(scenarios.PRICE_TAKER_FAMILY), (os.cpu_count() or 1), args.cpu_sample if args.cpu_sample > 0 else 16))
+                t1 = time.perf_counter()
+                with mp.get_context("spawn").Pool(nsample) as pool:
+                    res = pool.map(_price_taker_cpu_worker, [(T, k) for k in range(nsample)])
+                wall = time.perf_counter() - t1
+                err = max(abs(model.objective[k] - obj) / max(1.0, abs(obj)) for k, obj, _ in res)
+                line["cpu_baseline"] = {"value": nsample / wall, "unit": "LPs/s", "cores": nsample, "kind": "port",
+                                        "sample": f"{nsample} members of the same family, one HiGHS process each (oracle/dispatch_lp_oracle.py: the un-reduced LP, "
+                                                  f"feasibility tolerances 1e-9), wall {wall:.1f} s, {np.mean([r[2] for r in res]):.1f} s per member",
+                                        "max_rel_objective_difference_gpu_vs_these": float(err)}
+        print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()
 
@@ -424,6 +476,7 @@ def main():
     ap.add_argument("--min-time", type=float, default=0.5,
                     help="the burst of --steps steps is repeated until the timed bursts cover this many seconds; the median burst is reported")
     ap.add_argument("--max-bursts", type=int, default=500)
+    ap.add_argument("--solve", action="store_true", help="--workload price_taker / pem_price_taker / nuclear_price_taker: solve the batch to optimality (full-solve line)")
     ap.add_argument("--throughput", default=None, choices=["chain", "two_level", "hier"],
                     help="--workload price_taker / pem_price_taker: form of the battery's throughput accumulator (flowsheets/price_taker.py); "
                          "with --steps large enough the batch runs to optimality and config.solved_to_optimality / iterations_per_scenario tell")

@@ -50,7 +50,7 @@ inline HostLanePlan build_lane_plan(const HostCSR &A, const HostCSR &AT, int spa
   HostLanePlan P;
   const int n = A.n, m = A.m;
   P.n = n; P.m = m;
-  if (n < 1 || m < 1) return P;
+  if (n < 1 || m < 1 || std::max(n, m) >= (1 << 22)) return P;         // (record indices are stored << 9, sign bit = flag)
   P.long_rank.assign(n, -1);
   for (int j = 0; j < n; ++j) {
     const int len = AT.ptr[j + 1] - AT.ptr[j];
@@ -122,14 +122,18 @@ inline void pack_lane_records(const HostLanePlan &P, std::vector<char> &crec, st
   for (int j = 0; j < P.n; ++j) {
     char *r = &crec[(size_t)j * CREC];
     std::memcpy(r, &P.cval[(size_t)j * P.WC], (size_t)P.WC * 8);
-    std::memcpy(r + P.WC * 8, &P.cidx[(size_t)j * P.WC], (size_t)P.WC * 4);
+    for (int e = 0; e < P.WC; ++e) {                       // index << 9, long flag (bit 30 of the plan's index) -> sign bit
+      const int32_t v = P.cidx[(size_t)j * P.WC + e];
+      const uint32_t enc = ((uint32_t)(v & 0x3fffffff) << 9) | ((v >> 30) & 1 ? 0x80000000u : 0u);
+      std::memcpy(r + P.WC * 8 + e * 4, &enc, 4);
+    }
     const double lo = -inf;
     std::memcpy(r + P.WC * 12, &lo, 8); std::memcpy(r + P.WC * 12 + 8, &inf, 8); std::memcpy(r + P.WC * 12 + 16, &one, 8);
   }
   for (int i = 0; i < P.m; ++i) {
     char *r = &rrec[(size_t)i * RREC];
     std::memcpy(r, &P.rval[(size_t)i * P.WR], (size_t)P.WR * 8);
-    std::memcpy(r + P.WR * 8, &P.ridx[(size_t)i * P.WR], (size_t)P.WR * 4);
+    for (int e = 0; e < P.WR; ++e) { const uint32_t enc = (uint32_t)P.ridx[(size_t)i * P.WR + e] << 9; std::memcpy(r + P.WR * 8 + e * 4, &enc, 4); }
     const double lo = -inf;
     std::memcpy(r + P.WR * 12, &lo, 8); std::memcpy(r + P.WR * 12 + 8, &inf, 8);
     std::memcpy(r + P.WR * 12 + 16, &P.ral[(size_t)i * P.NLP], (size_t)P.NLP * 8);
@@ -207,10 +211,12 @@ inline HostLaneTiles build_lane_tiles_ring(const HostLanePlan &P, int rows_per_t
   return T;
 }
 
-// the smallest ring (8 .. kLaneMaxRing slots per window; LDS per wave = 2 or 3 windows x ring x 512 bytes) whose walks are within 3 %
-// of the fewest units any ring needs: a ring that only just holds the band leaves the three streams of a walk (stage, primal, dual)
-// waiting for each other, i.e. half-empty units
-inline HostLaneTiles build_lane_tiles(const HostLanePlan &P, int rows_per_tile, int CH, int ring_min = 8, int ring_max = kLaneMaxRing) {
+// The smallest ring (8 .. kLaneMaxRing slots per window; LDS per wave = 2 or 3 windows x ring x 512 bytes) that holds the band.  A
+// ring that only just holds it leaves the three streams of a walk (stage, primal, dual) waiting for each other - 20 % more, emptier
+// units on the wind + battery LPs at 8 slots than at 16 - but halves the LDS of a wave: twice the resident waves were worth more
+// than the fuller units (year-long batch of 256: 157 vs 176 us per iteration, profiles/r40d_lane_rates.log).  `slack` > 1 prefers
+// the smallest ring within that factor of the fewest units any ring needs instead.
+inline HostLaneTiles build_lane_tiles(const HostLanePlan &P, int rows_per_tile, int CH, int ring_min = 8, int ring_max = kLaneMaxRing, double slack = 0.0) {
   HostLaneTiles best;
   if (!P.ok) return best;
   std::vector<HostLaneTiles> cand;
@@ -221,7 +227,8 @@ inline HostLaneTiles build_lane_tiles(const HostLanePlan &P, int rows_per_tile, 
   if (cand.empty()) return best;
   int fewest = INT_MAX;
   for (const HostLaneTiles &T : cand) fewest = std::min(fewest, T.nunit);
-  for (HostLaneTiles &T : cand) if ((double)T.nunit <= 1.03 * fewest) return std::move(T);
+  if (slack <= 1.0) return std::move(cand.front());
+  for (HostLaneTiles &T : cand) if ((double)T.nunit <= slack * fewest) return std::move(T);
   return std::move(cand.back());
 }
 

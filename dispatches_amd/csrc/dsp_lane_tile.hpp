@@ -9,8 +9,8 @@
 // RECORDS.  What depends on the element only - matrix entries, their indices, shared bounds, scale factors - is one record per
 // column (CREC bytes) and one per row (RREC bytes), contiguous in element order:
 //     column  val[WC] | idx[WC] | lb, ub | col_scale, -            row  val[WR] | idx[WR] | rlo, rhi | al[NLP] | row_scale, -
-// (idx: row / column indices of the SHORT entries; padding entries repeat the first one with value 0; bit 30 of a column's idx[0]
-// marks a long column; al: the row's coefficients on the long columns.)  A unit's records are one contiguous block per kind, so
+// (idx: row / column indices of the SHORT entries, stored as index << 9 = the byte offset of the index's ring slot before masking;
+// padding entries repeat the first one with value 0; the sign bit of a column's idx[0] marks a long column; al: the row's coefficients on the long columns.)  A unit's records are one contiguous block per kind, so
 // the wave fetches them with ONE 16-byte-per-lane load each, together with the unit's rows of x, c, y ... one unit ahead, parks them
 // in its LDS stage when the unit's turn comes, and every lane reads the same 16 bytes back (broadcast ds_read_b128).  The first
 // version read the records through the scalar unit: each record was a scalar-cache miss (~0.25 us) behind an s_waitcnt lgkmcnt(0)
@@ -101,7 +101,9 @@ struct LaneGroup {                   // one scenario group's block of every arra
   double *xp, *yp;                               // MODE 1 out; MODE 2 in
 };
 
-struct LaneScalars { double tau, sig, oml; bool done; };
+// active: the lane has a scenario that is still iterating.  Lanes without one take part in fetching and parking the unit's records
+// (a wave's 16-byte-per-lane block) and in nothing else: none of their loads or stores reaches the memory system.
+struct LaneScalars { double tau, sig, oml; bool done, active; };
 
 // per-lane result of a tile: lp[l] = the tile's part of (A^T y)_long_l; v[0 .. 12] the check sums (MODE 1: 0 .. 7, MODE 2: 8 .. 12)
 template <int NLP> struct LaneOut { double lp[NLP]; double v[13]; };
@@ -127,7 +129,7 @@ struct LaneTile {
   }
 
   // every global load of a unit, unconditionally, to clamped addresses (no data-dependent control flow between the loads)
-  static DSP_LANE_HD void load_regs(const LaneProblem &P, const LaneGroup &G, const Unit &q, int lane, Regs &r) {
+  static DSP_LANE_HD void load_regs(const LaneProblem &P, const LaneGroup &G, const Unit &q, int lane, bool active, Regs &r) {
     const uint32_t l8 = (uint32_t)lane * 8u;
 #if defined(__HIP_DEVICE_COMPILE__)
     r.cq = *reinterpret_cast<const LaneQuad *>(P.crec + ((uint32_t)q.cx0 * (uint32_t)CREC + (uint32_t)lane * 16u));
@@ -135,6 +137,7 @@ struct LaneTile {
 #else
     (void)P;
 #endif
+    if (!active) return;
 #pragma unroll
     for (int k = 0; k < CH; ++k) r.ys[k] = lane_ld(MODE == 2 ? G.yp : G.y_in, q.ys0 + (k < q.nys ? k : 0), l8);
 #pragma unroll
@@ -158,18 +161,28 @@ struct LaneTile {
 
   template <class T>
   static DSP_LANE_HD T rec(const char *base, int off) { return *reinterpret_cast<const T *>(base + off); }
+  // ring slot of a record index (stored as index << 9 = byte offset of its slot in an unbounded window; bit 31 of a column's first
+  // index flags a long column): (idx9 & mask9) | (lane * 8) - one v_and_or_b32 per gather
+  static DSP_LANE_HD const double &slot(const char *win, uint32_t idx9, uint32_t mask9, uint32_t l8) {
+    return *reinterpret_cast<const double *>(win + ((idx9 & mask9) | l8));
+  }
 
   // ring layout: [0, R) y window, [R, 2R) xbar window, [2R, 3R) x+ window (MODE 1); `stage`: the wave's record stage (device).
-  // Each of the three phases (stage, primal, dual) is BRANCH-FREE over its CH slots: a slot beyond the unit's count repeats the
-  // unit's first element - the same arithmetic on the same inputs, the same value stored to the same places - so the compiler is
-  // free to interleave the CH dependent chains (record read -> ring gathers -> arithmetic -> store); only sums are masked.
+  // Each phase (stage, primal, dual) is BRANCH-FREE over its CH slots - a slot beyond the unit's count repeats the unit's first
+  // element: the same arithmetic on the same inputs, the same value stored to the same places; only sums are masked - and written
+  // in STEPS over all CH slots: every record read, then every ring gather, then the arithmetic.  A wave is one in-order instruction
+  // stream: written element by element (record -> index -> gather -> four dependent FMAs -> clamp -> store) every LDS round trip
+  // of every element was exposed, 85 s_waitcnt per unit, and the launch was bound by that chain (37 us for a 28-row tile whatever
+  // the batch: profiles/r40d_lane_kernel_stats_B64.csv, r40e_lane_variants.log); in steps the CH chains overlap.
   // Columns the tile does not own (halo, long) store their x to the SINK row (row n of every [n + 1][64] column block).
   static DSP_LANE_HD void compute(const LaneProblem &P, const LaneGroup &G, const Unit &q, const Regs &r, const LaneScalars &sc,
                                   int j0, int j1, int lane, double *ring, char *stage, const double (&xbl)[NLP], const double (&xpl)[NLP],
                                   LaneOut<NLP> &out) {
     const int M = P.ring_mask, R = M + 1;
-    const uint32_t l8 = (uint32_t)lane * 8u;
+    const uint32_t l8 = (uint32_t)lane * 8u, M9 = (uint32_t)M << 9;
     double *yr = ring + lane, *xr = ring + (size_t)R * 64 + lane, *xpr = ring + (size_t)2 * R * 64 + lane;
+    const char *ywin = reinterpret_cast<const char *>(ring), *xwin = reinterpret_cast<const char *>(ring + (size_t)R * 64),
+               *xpwin = reinterpret_cast<const char *>(ring + (size_t)2 * R * 64);
 #if defined(__HIP_DEVICE_COMPILE__)
     // park the unit's records: lane L's 16 bytes at byte 16 L of each half of the stage; the LDS serves one wave's accesses in order
     *reinterpret_cast<LaneQuad *>(stage + lane * 16) = r.cq;
@@ -179,25 +192,38 @@ struct LaneTile {
     (void)stage;
     const char *cbase = P.crec + (size_t)q.cx0 * CREC, *rbase = P.rrec + (size_t)q.rd0 * RREC;
 #endif
+    if (!sc.active) return;
     if (q.nys > 0) {
 #pragma unroll
       for (int k = 0; k < CH; ++k) yr[(size_t)((q.ys0 + (k < q.nys ? k : 0)) & M) * 64] = r.ys[k];
     }
     if (q.ncx > 0) {
+      LaneVecD<WC> av[CH];
+      LaneVecI<WC> ix[CH];
+      LaneVecD<2> bd[CH];
+      double cs[CH], gy[CH][WC];
 #pragma unroll
-      for (int k = 0; k < CH; ++k) {
+      for (int k = 0; k < CH; ++k) {                                 // step 1: the records
+        const char *cr = cbase + (k < q.ncx ? k : 0) * CREC;
+        av[k] = rec<LaneVecD<WC>>(cr, 0);
+        ix[k] = rec<LaneVecI<WC>>(cr, WC * 8);
+        if (SHARED) bd[k] = rec<LaneVecD<2>>(cr, WC * 12);
+        else { bd[k].v[0] = r.lb[k]; bd[k].v[1] = r.ub[k]; }
+        cs[k] = MODE == 2 ? rec<double>(cr, WC * 12 + 16) : 1.0;
+      }
+#pragma unroll
+      for (int k = 0; k < CH; ++k)                                    // step 2: the gathers of y
+#pragma unroll
+        for (int e = 0; e < WC; ++e) gy[k][e] = slot(ywin, (uint32_t)ix[k].v[e], M9, l8);
+#pragma unroll
+      for (int k = 0; k < CH; ++k) {                                 // step 3: the arithmetic
         const bool live = k < q.ncx;
-        const int kk = live ? k : 0, j = q.cx0 + kk;
-        const char *cr = cbase + kk * CREC;
-        const LaneVecD<WC> av = rec<LaneVecD<WC>>(cr, 0);
-        const LaneVecI<WC> ix = rec<LaneVecI<WC>>(cr, WC * 8);
-        const bool own = j >= j0 && j < j1 && (ix.v[0] >> 30) == 0;       // bit 30 of the first index: long column
+        const int j = q.cx0 + (live ? k : 0);
+        const bool own = j >= j0 && j < j1 && ix[k].v[0] >= 0;         // sign bit of the first index: long column
         double aty = 0.0;
 #pragma unroll
-        for (int e = 0; e < WC; ++e) aty = fma(av.v[e], yr[(size_t)(ix.v[e] & M) * 64], aty);
-        double lbv, ubv;
-        if (SHARED) { const LaneVecD<2> b = rec<LaneVecD<2>>(cr, WC * 12); lbv = b.v[0]; ubv = b.v[1]; }
-        else { lbv = r.lb[k]; ubv = r.ub[k]; }
+        for (int e = 0; e < WC; ++e) aty = fma(av[k].v[e], gy[k][e], aty);
+        const double lbv = bd[k].v[0], ubv = bd[k].v[1];
         if (MODE == 2) {
           // reduced cost at y+ (kkt_col_terms of dsp_stream.hip); only the own columns count
           const double w = (own && live) ? 1.0 : 0.0;
@@ -205,7 +231,7 @@ struct LaneTile {
           const double rc = cj - aty;
           const double lp = lane_finite(lbv) ? fmax(rc, 0.0) : 0.0;
           const double lm = lane_finite(ubv) ? fmax(-rc, 0.0) : 0.0;
-          const double dr = (rc - lp + lm) / rec<double>(cr, WC * 12 + 16);
+          const double dr = (rc - lp + lm) / cs[k];
           out.v[8] = fma(w, dr * dr, out.v[8]);
           out.v[9] = fma(w, cj * xp, out.v[9]);
           out.v[10] = fma(w, lp * lane_fin0(lbv) - lm * lane_fin0(ubv), out.v[10]);
@@ -230,65 +256,85 @@ struct LaneTile {
       }
     }
     if (MODE == 2 || q.nrd <= 0) return;
+    {
+      LaneVecD<WR> av[CH];
+      LaneVecI<WR> ix[CH];
+      LaneVecD<2> bd[CH];
+      LaneVecD<NLP> al[CH];
+      double rs[CH], gx[CH][WR], gxp[CH][MODE == 1 ? WR : 1], yv[CH];
 #pragma unroll
-    for (int k = 0; k < CH; ++k) {
-      const bool live = k < q.nrd;
-      const int kk = live ? k : 0, i = q.rd0 + kk;
-      const char *rr = rbase + kk * RREC;
-      const LaneVecD<WR> av = rec<LaneVecD<WR>>(rr, 0);
-      const LaneVecI<WR> ix = rec<LaneVecI<WR>>(rr, WR * 8);
-      const LaneVecD<NLP> al = rec<LaneVecD<NLP>>(rr, WR * 12 + 16);
-      double ax = 0.0, axp = 0.0;
-#pragma unroll
-      for (int e = 0; e < WR; ++e) {
-        ax = fma(av.v[e], xr[(size_t)(ix.v[e] & M) * 64], ax);
-        if (MODE == 1) axp = fma(av.v[e], xpr[(size_t)(ix.v[e] & M) * 64], axp);
+      for (int k = 0; k < CH; ++k) {                                 // step 1: the records
+        const char *rr = rbase + (k < q.nrd ? k : 0) * RREC;
+        av[k] = rec<LaneVecD<WR>>(rr, 0);
+        ix[k] = rec<LaneVecI<WR>>(rr, WR * 8);
+        if (SHARED) bd[k] = rec<LaneVecD<2>>(rr, WR * 12);
+        else { bd[k].v[0] = r.rlo[k]; bd[k].v[1] = r.rhi[k]; }
+        al[k] = rec<LaneVecD<NLP>>(rr, WR * 12 + 16);
+        rs[k] = MODE == 1 ? rec<double>(rr, WR * 12 + 16 + NLP * 8) : 1.0;
       }
 #pragma unroll
-      for (int l = 0; l < NLP; ++l) {
-        ax = fma(al.v[l], xbl[l], ax);
-        if (MODE == 1) axp = fma(al.v[l], xpl[l], axp);
-      }
-      double rlo, rhi;
-      if (SHARED) { const LaneVecD<2> b = rec<LaneVecD<2>>(rr, WR * 12); rlo = b.v[0]; rhi = b.v[1]; }
-      else { rlo = r.rlo[k]; rhi = r.rhi[k]; }
-      const double y = yr[(size_t)(i & M) * 64];
-      const double gy = fma(-sc.sig, ax, y);
-      double yp = gy - lane_clamp(gy, -sc.sig * rhi, -sc.sig * rlo);
-      const double kp = QP ? r.kap[k] : 0.0;
-      if (QP) yp /= fma(sc.sig, kp, 1.0);                          // soft rows: proximal shrink (kappa = 0: hard row)
-      if (MODE == 0) {
-        const double tt = 2.0 * yp - y;
-        const double yn = fma(sc.oml, r.y0[k] - tt, tt);
-        lane_st(G.y_out, i, l8) = yn;
-        const double yw = live ? yn : 0.0;
+      for (int k = 0; k < CH; ++k) {                                 // step 2: the gathers of xbar (and x+), the row's own y
 #pragma unroll
-        for (int l = 0; l < NLP; ++l) out.lp[l] = fma(al.v[l], yw, out.lp[l]);
-      } else {
-        lane_st(G.yp, sc.done ? P.m : i, l8) = yp;                  // (a finished scenario keeps the x+, y+ it finished with)
-        const double w = live ? 1.0 : 0.0;
-        const double yw = live ? yp : 0.0;
-#pragma unroll
-        for (int l = 0; l < NLP; ++l) out.lp[l] = fma(al.v[l], yw, out.lp[l]);
-        const double dy = yp - y;
-        const double nsadx = -sc.sig * (ax - axp);                 // -sig A (x+ - x)   (xbar - x+ = x+ - x)
-        out.v[1] = fma(w, dy * fma(2.0, nsadx, dy), out.v[1]);
-        double viol_s = fmax(rlo - axp, 0.0) + fmax(axp - rhi, 0.0);
-        double dobj = fmax(yp, 0.0) * lane_fin0(rlo) - fmax(-yp, 0.0) * lane_fin0(rhi);
-        double soft = 0.0;
-        if (QP && kp > 0.0) {                                      // soft row: no violation, quadratic terms of both objectives
-          const double dev = axp - rlo;
-          soft = 0.5 * dev * dev / kp;
-          dobj -= 0.5 * kp * yp * yp;
-          viol_s = 0.0;
+        for (int e = 0; e < WR; ++e) {
+          gx[k][e] = slot(xwin, (uint32_t)ix[k].v[e], M9, l8);
+          if (MODE == 1) gxp[k][e] = slot(xpwin, (uint32_t)ix[k].v[e], M9, l8);
         }
-        out.v[7] = fma(w, soft, out.v[7]);
-        out.v[4] = fma(w, dobj, out.v[4]);
-        const double viol = viol_s / rec<double>(rr, WR * 12 + 16 + NLP * 8);
-        out.v[2] = fma(w, viol * viol, out.v[2]);
-        out.v[3] = fma(w, fabs(yp) * viol_s, out.v[3]);
-        const double d0 = yp - r.y0[k];
-        out.v[5] = fma(w, d0 * d0, out.v[5]);
+        yv[k] = yr[(size_t)((q.rd0 + (k < q.nrd ? k : 0)) & M) * 64];
+      }
+#pragma unroll
+      for (int k = 0; k < CH; ++k) {                                 // step 3: the arithmetic
+        const bool live = k < q.nrd;
+        const int i = q.rd0 + (live ? k : 0);
+        double ax = 0.0, axp = 0.0;
+#pragma unroll
+        for (int e = 0; e < WR; ++e) {
+          ax = fma(av[k].v[e], gx[k][e], ax);
+          if (MODE == 1) axp = fma(av[k].v[e], gxp[k][e], axp);
+        }
+#pragma unroll
+        for (int l = 0; l < NLP; ++l) {
+          ax = fma(al[k].v[l], xbl[l], ax);
+          if (MODE == 1) axp = fma(al[k].v[l], xpl[l], axp);
+        }
+        const double rlo = bd[k].v[0], rhi = bd[k].v[1];
+        const double y = yv[k];
+        const double gyy = fma(-sc.sig, ax, y);
+        double yp = gyy - lane_clamp(gyy, -sc.sig * rhi, -sc.sig * rlo);
+        const double kp = QP ? r.kap[k] : 0.0;
+        if (QP) yp /= fma(sc.sig, kp, 1.0);                          // soft rows: proximal shrink (kappa = 0: hard row)
+        if (MODE == 0) {
+          const double tt = 2.0 * yp - y;
+          const double yn = fma(sc.oml, r.y0[k] - tt, tt);
+          lane_st(G.y_out, i, l8) = yn;
+          const double yw = live ? yn : 0.0;
+#pragma unroll
+          for (int l = 0; l < NLP; ++l) out.lp[l] = fma(al[k].v[l], yw, out.lp[l]);
+        } else {
+          lane_st(G.yp, sc.done ? P.m : i, l8) = yp;                  // (a finished scenario keeps the x+, y+ it finished with)
+          const double w = live ? 1.0 : 0.0;
+          const double yw = live ? yp : 0.0;
+#pragma unroll
+          for (int l = 0; l < NLP; ++l) out.lp[l] = fma(al[k].v[l], yw, out.lp[l]);
+          const double dy = yp - y;
+          const double nsadx = -sc.sig * (ax - axp);                 // -sig A (x+ - x)   (xbar - x+ = x+ - x)
+          out.v[1] = fma(w, dy * fma(2.0, nsadx, dy), out.v[1]);
+          double viol_s = fmax(rlo - axp, 0.0) + fmax(axp - rhi, 0.0);
+          double dobj = fmax(yp, 0.0) * lane_fin0(rlo) - fmax(-yp, 0.0) * lane_fin0(rhi);
+          double soft = 0.0;
+          if (QP && kp > 0.0) {                                      // soft row: no violation, quadratic terms of both objectives
+            const double dev = axp - rlo;
+            soft = 0.5 * dev * dev / kp;
+            dobj -= 0.5 * kp * yp * yp;
+            viol_s = 0.0;
+          }
+          out.v[7] = fma(w, soft, out.v[7]);
+          out.v[4] = fma(w, dobj, out.v[4]);
+          const double viol = viol_s / rs[k];
+          out.v[2] = fma(w, viol * viol, out.v[2]);
+          out.v[3] = fma(w, fabs(yp) * viol_s, out.v[3]);
+          const double d0 = yp - r.y0[k];
+          out.v[5] = fma(w, d0 * d0, out.v[5]);
+        }
       }
     }
   }
@@ -304,15 +350,27 @@ struct LaneTile {
     double xbl[NLP], xpl[NLP];
 #pragma unroll
     for (int l = 0; l < NLP; ++l) {
-      xbl[l] = MODE == 2 ? 0.0 : lane_ld(G.xbl, l, l8);
-      xpl[l] = MODE == 1 ? lane_ld(G.xpl, l, l8) : 0.0;
+      xbl[l] = (MODE == 2 || !sc.active) ? 0.0 : lane_ld(G.xbl, l, l8);
+      xpl[l] = (MODE == 1 && sc.active) ? lane_ld(G.xpl, l, l8) : 0.0;
       out.lp[l] = 0.0;
     }
 #pragma unroll
     for (int q = 0; q < 13; ++q) out.v[q] = 0.0;
+#ifndef DSP_LANE_PREFETCH
+    // one register set: a second one, loaded a unit ahead, measured no faster (profiles/r40e_lane_variants.log) and its registers
+    // are what the steps of `compute` need
+    const int R = P.ring_mask + 1;
+    for (int s = 0; s < (MODE == 1 ? 3 : 2) * R; ++s) ring[(size_t)s * 64 + lane] = 0.0;
+    for (int u = ubeg; u < uend; ++u) {
+      const Unit qa = load_unit(P, u);
+      Regs ra;
+      load_regs(P, G, qa, lane, sc.active, ra);
+      compute(P, G, qa, ra, sc, j0, j1, lane, ring, stage, xbl, xpl, out);
+    }
+#else
     Unit qa = load_unit(P, ubeg), qb = qa;
     Regs ra, rb;
-    load_regs(P, G, qa, lane, ra);
+    load_regs(P, G, qa, lane, sc.active, ra);
 #pragma unroll
     for (int l = 0; l < NLP; ++l) { lane_pin(xbl[l]); if (MODE == 1) lane_pin(xpl[l]); }
     lane_pin(sc.tau); lane_pin(sc.sig); lane_pin(sc.oml);
@@ -320,12 +378,13 @@ struct LaneTile {
     const int R = P.ring_mask + 1;
     for (int s = 0; s < (MODE == 1 ? 3 : 2) * R; ++s) ring[(size_t)s * 64 + lane] = 0.0;
     for (int u = ubeg; u < uend; u += 2) {
-      if (u + 1 < uend) { qb = load_unit(P, u + 1); load_regs(P, G, qb, lane, rb); }
+      if (u + 1 < uend) { qb = load_unit(P, u + 1); load_regs(P, G, qb, lane, sc.active, rb); }
       compute(P, G, qa, ra, sc, j0, j1, lane, ring, stage, xbl, xpl, out);
       if (u + 1 >= uend) break;
-      if (u + 2 < uend) { qa = load_unit(P, u + 2); load_regs(P, G, qa, lane, ra); }
+      if (u + 2 < uend) { qa = load_unit(P, u + 2); load_regs(P, G, qa, lane, sc.active, ra); }
       compute(P, G, qb, rb, sc, j0, j1, lane, ring, stage, xbl, xpl, out);
     }
+#endif
   }
 };
 

@@ -1541,6 +1541,7 @@ static hipError_t stream_solve_locked(StreamSolver *S, const dsp_batch &batch, c
       const int nt = std::max(S->P.n, S->P.m) > 2048 ? 1024 : (std::max(S->P.n, S->P.m) > 512 ? 512 : 256);
       hipError_t be = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_block_solve), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (be != hipSuccess) return be;
+      S->last_form = DSP_STREAM_FORM_BLOCK;
       hipLaunchKernelGGL(k_block_solve, dim3(B), dim3(nt), lds, st, a);
       hipLaunchKernelGGL(k_finalize, dim3(a.nblk, B), dim3(kTB), 0, st, a);
       *periods_run = -1;
@@ -1552,6 +1553,7 @@ static hipError_t stream_solve_locked(StreamSolver *S, const dsp_batch &batch, c
     bool used = false;
     if ((e = lane_run(S, a, st, periods_run, &used)) != hipSuccess) return e;
     if (used) {
+      S->last_form = DSP_STREAM_FORM_LANE;
       hipLaunchKernelGGL(k_finalize, dim3(a.nblk, B), dim3(kTB), 0, st, a);
       return hipGetLastError();
     }
@@ -1565,6 +1567,7 @@ static hipError_t stream_solve_locked(StreamSolver *S, const dsp_batch &batch, c
   static const int sg_env = getenv("DSP_STREAM_SG") ? atoi(getenv("DSP_STREAM_SG")) : 0;     // development override
   if (sg_env == 1 || sg_env == 2 || sg_env == 4 || sg_env == 8) sg = sg_env;
   S->last_bytes_per_iteration = (size_t)8 * (8 * (size_t)S->P.n + 6 * (size_t)S->P.m);
+  S->last_form = S->P.F.ntile > 0 ? DSP_STREAM_FORM_TILE : DSP_STREAM_FORM_TWO_LAUNCH;
   if (S->P.F.ntile > 0) {
     // banded matrix: one launch per plain iteration.  Bounds that are the same template for every scenario of the batch
     // (stride 0: the price-taker families differ in the objective only) are read once per workgroup from scenario 0's copy.

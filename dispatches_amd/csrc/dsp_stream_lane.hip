@@ -31,7 +31,16 @@ namespace dsp {
 namespace {
 
 constexpr int kLaneWaves = 4;           // waves (= tiles) per workgroup
-constexpr int kLaneCH = 4;              // rows / columns per unit of a tile's walk
+// rows / columns per unit of a tile's walk: DSP_LANE_CH where a unit's records still fit one 16-byte-per-lane load, else 4
+#ifndef DSP_LANE_CH
+#define DSP_LANE_CH 4
+#endif
+#ifndef DSP_LANE_MINWAVES
+#define DSP_LANE_MINWAVES 1
+#endif
+constexpr int lane_ch(int wc, int wr, int nlp) {
+  return (DSP_LANE_CH * lane_crec(wc) <= 1024 && DSP_LANE_CH * lane_rrec(wr, nlp) <= 1024) ? DSP_LANE_CH : 4;
+}
 constexpr int kLaneNQ = 16;             // check-sum slots per (group, workgroup)
 
 struct LaneTiling {                     // device copy of one tiling (dsp_lane_plan.hpp: HostLaneTiles)
@@ -173,7 +182,7 @@ __global__ void k_lane_setup(LaneArgs a, const double *__restrict__ lbW, const d
 
 // ---- the tile kernel ----------------------------------------------------------------------------------------------------------------
 template <int WC, int WR, int NLP, bool SHARED, bool QP, int MODE>
-__global__ void __launch_bounds__(kLaneWaves * 64) k_lane(LaneArgs a) {
+__global__ void __launch_bounds__(kLaneWaves * 64, DSP_LANE_MINWAVES) k_lane(LaneArgs a) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -199,14 +208,17 @@ __global__ void __launch_bounds__(kLaneWaves * 64) k_lane(LaneArgs a) {
   sc.oml = 1.0 / (double)(kk + a.kofs + 3);
   asm volatile("" ::: "memory");               // the per-lane scalars are requested before the tile's first rows
   LaneOut<NLP> out;
-  const bool idle = __builtin_amdgcn_readfirstlane(__all(sc.done ? 1 : 0)) != 0;     // every scenario of the group has finished
-  if (tile < a.P.ntile && !idle) LaneTile<WC, WR, NLP, kLaneCH, SHARED, QP, MODE>::run(a.P, G, tile, lane, sc, ring, stage, out);
-  else {
 #pragma unroll
-    for (int l = 0; l < NLP; ++l) out.lp[l] = 0.0;
+  for (int l = 0; l < NLP; ++l) out.lp[l] = 0.0;
 #pragma unroll
-    for (int q = 0; q < 13; ++q) out.v[q] = 0.0;
-  }
+  for (int q = 0; q < 13; ++q) out.v[q] = 0.0;
+  // Lanes without work - beyond the batch, or whose scenario has finished - sit the walk out: the EXEC mask keeps their loads and
+  // stores off the memory system - they only help to fetch and park the unit's records (first version: every lane of every wave walked, a batch of 1 moved the bytes of a batch of 64 -
+  // 48 us per iteration for 1, 16 or 64 scenarios alike, profiles/r40g_lane_pmc_summary_B16.csv - and a solve paid for its finished
+  // scenarios until the last one was through).  Their sums stay zero; a group with no live lane skips the walk altogether.
+  sc.active = !sc.done;
+  const bool any = __builtin_amdgcn_readfirstlane(__any(sc.active ? 1 : 0)) != 0;
+  if (tile < a.P.ntile && any) LaneTile<WC, WR, NLP, lane_ch(WC, WR, NLP), SHARED, QP, MODE>::run(a.P, G, tile, lane, sc, ring, stage, out);
   // the workgroup's waves add their partial sums in wave order (the one barrier of the launch; the rings are free by then)
   __syncthreads();
   double *red = lds;
@@ -246,18 +258,20 @@ __global__ void __launch_bounds__(kLaneWaves * 64) k_lane(LaneArgs a) {
 // LM 0: plain iteration (xbar for the rows, x averaged into the other buffer); LM 1: check iteration (x+, xbar, the column's terms of
 // the residual sums); LM 2: the column's reduced cost at y+ (the partial sums k_lane<.., 1> left are those of A^T y+)
 constexpr int kLongWaves = 16;         // waves of a k_lane_long / k_lane_sum workgroup: each adds every 16th partial sum
-// sum over the workgroups' partial sums p[w * stride] (w = 0 .. count), fixed order: wave v takes w = v, v + 16, ..., eight loads in
-// flight at a time (one dependent load per addition was 0.5 us each: 60 us per launch at 470 workgroups), then the waves' sums in
-// wave order.  Every thread of the workgroup must call it; the result is valid in wave 0.
+// sum over the workgroups' partial sums p[w * stride] (w = 0 .. count), fixed order: wave v takes w = v, v + 16, ..., sixteen loads in
+// flight at a time (one dependent load per addition was a memory round trip each - the partial sums were written by other XCDs a
+// moment ago: 60 us per launch at 470 workgroups), then the waves' sums in wave order.  Every thread of the workgroup must call it;
+// the result is valid in wave 0.
 __device__ __forceinline__ double lane_sum_partials(const double *p, size_t stride, int count, double (*red)[64]) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  constexpr int U = 16;
   double t = 0.0;
-  for (int w = wv; w < count; w += 8 * kLongWaves) {
-    double v[8];
+  for (int w = wv; w < count; w += U * kLongWaves) {
+    double v[U];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) { const int ww = w + k * kLongWaves; v[k] = p[(size_t)min(ww, count - 1) * stride + lane]; }
+    for (int k = 0; k < U; ++k) { const int ww = w + k * kLongWaves; v[k] = p[(size_t)min(ww, count - 1) * stride + lane]; }
 #pragma unroll
-    for (int k = 0; k < 8; ++k) t += (w + k * kLongWaves < count) ? v[k] : 0.0;
+    for (int k = 0; k < U; ++k) t += (w + k * kLongWaves < count) ? v[k] : 0.0;
   }
   red[wv][lane] = t;
   __syncthreads();
@@ -274,15 +288,22 @@ __global__ void __launch_bounds__(kLongWaves * 64) k_lane_long(LaneArgs a) {
   __shared__ double red[kLongWaves][64];
   const int l = blockIdx.x, g = blockIdx.y, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int NLP = a.NLP;
-  const double aty = lane_sum_partials(a.lpart + ((size_t)g * a.nwg * NLP + l) * 64, (size_t)NLP * 64, a.nwg, red);
-  if (wv != 0) return;
   const int j = a.long_id[l];
   const size_t at = ((size_t)g * (a.P.n + 1) + j) * 64 + lane, al = ((size_t)g * NLP + l) * 64 + lane, as = (size_t)g * 64 + lane;
-  const double lb = a.lbl[al], ub = a.ubl[al], cj = a.c[at];
-  const bool done = a.done[as] != 0;
+  // the column's own data is requested ahead of the partial sums (wave 0 uses it)
+  double lb = 0.0, ub = 0.0, cj = 0.0, x = 0.0, x0 = 0.0, tau = 0.0, xpv = 0.0;
+  int kk = 0;
+  bool done = true;
+  if (wv == 0) {
+    lb = a.lbl[al]; ub = a.ubl[al]; cj = a.c[at]; done = a.done[as] != 0;
+    if (LM == 2) xpv = a.xp[at];
+    else { x = a.x_in[at]; x0 = a.x0[at]; tau = a.tau[as]; kk = a.k[as]; }
+  }
+  const double aty = lane_sum_partials(a.lpart + ((size_t)g * a.nwg * NLP + l) * 64, (size_t)NLP * 64, a.nwg, red);
+  if (wv != 0) return;
   double *slot = a.partial + (((size_t)g * a.nslot + a.nwg + l) * kLaneNQ) * 64 + lane;
   if (LM == 2) {
-    const double xp = a.xp[at];
+    const double xp = xpv;
     const double rc = cj - aty;
     const double lp = lane_finite(lb) ? fmax(rc, 0.0) : 0.0;
     const double lm = lane_finite(ub) ? fmax(-rc, 0.0) : 0.0;
@@ -294,12 +315,11 @@ __global__ void __launch_bounds__(kLongWaves * 64) k_lane_long(LaneArgs a) {
     slot[12 * 64] = fabs(rc - lp + lm) * fabs(xp);
     return;
   }
-  const double x = a.x_in[at], x0 = a.x0[at], tau = a.tau[as];
   const double xp = lane_clamp(fma(-tau, cj - aty, x), lb, ub);
   const double tt = 2.0 * xp - x;
   a.xbl[al] = tt;
   if (LM == 0) {
-    const double oml = 1.0 / (double)(a.k[as] + a.kofs + 3);
+    const double oml = 1.0 / (double)(kk + a.kofs + 3);
     a.x_out[at] = fma(oml, x0 - tt, tt);
   } else {
     a.xpl[al] = xp;
@@ -349,7 +369,7 @@ __global__ void __launch_bounds__(kLaneWaves * 64) k_lane_apply(LaneArgs a) {
   double lp[NLP];
 #pragma unroll
   for (int l = 0; l < NLP; ++l) lp[l] = 0.0;
-  if (tile < a.P.ntile) {
+  if (tile < a.P.ntile && !done) {                   // (lanes whose scenario has finished: no loads, no stores, zero sums)
     const LaneVecI<8> tp = ldu(reinterpret_cast<const LaneVecI<8> *>(a.P.tiles) + tile);
     const int i0 = tp.v[0], i1 = tp.v[1], j0 = tp.v[2], j1 = tp.v[3];
     constexpr int U = 8;
@@ -438,7 +458,7 @@ hipError_t lane_create(const HostCSR &A_scaled, const HostCSR &AT_scaled, Stream
   L->plan = build_lane_plan(A_scaled, AT_scaled, std::max(4096, A_scaled.m / 4));
   const HostLanePlan &H = L->plan;
   // applicable when some tiling of a few dozen rows schedules within the ring budget (a matrix that is not banded does not)
-  if (!H.ok || !build_lane_tiles(H, 64, kLaneCH).ok) { delete L; return hipSuccess; }
+  if (!H.ok || !build_lane_tiles(H, 64, lane_ch(H.WC, H.WR, H.NLP)).ok) { delete L; return hipSuccess; }
   hipError_t e;
   L->P.n = H.n; L->P.m = H.m; L->P.nl = H.nl;
   std::vector<uint8_t> is_long(H.n, 0);
@@ -472,10 +492,11 @@ void lane_destroy(StreamSolver *S) {
 static hipError_t lane_tiling(LaneState *L, int rows_per_tile, LaneTiling **out) {
   // DSP_LANE_RING_MAX (development): largest ring the planner may use (8: less LDS per wave, more resident waves, emptier units)
   const int ring_max = getenv("DSP_LANE_RING_MAX") ? atoi(getenv("DSP_LANE_RING_MAX")) : kLaneMaxRing;
-  const int key = rows_per_tile * 256 + std::min(ring_max, 255);
+  const int ring_min = getenv("DSP_LANE_RING_MIN") ? atoi(getenv("DSP_LANE_RING_MIN")) : 8;
+  const int key = rows_per_tile * 4096 + std::min(ring_max, 63) * 64 + std::min(ring_min, 63);
   auto it = L->tilings.find(key);
   if (it == L->tilings.end()) {
-    const HostLaneTiles T = build_lane_tiles(L->plan, rows_per_tile, kLaneCH, 8, ring_max);
+    const HostLaneTiles T = build_lane_tiles(L->plan, rows_per_tile, lane_ch(L->plan.WC, L->plan.WR, L->plan.NLP), ring_min, ring_max);
     LaneTiling D;
     if (T.ok) {
       hipError_t e;
@@ -532,6 +553,12 @@ hipError_t lane_run(StreamSolver *S, StreamArgs &a, hipStream_t st, int *periods
   LaneState *L = S->lane;
   if (!L) return hipSuccess;
   const int B = a.b.B, n = L->P.n, m = L->P.m, NLP = L->plan.NLP, G = (B + 63) / 64;
+  // Small batches stay with the workgroup-per-tile form of round 3 (dsp_stream.hip: k_fused_pre): a lane's walk through its tile is one
+  // in-order chain of ~10 units of ~3 us each whatever the batch - 42 us per iteration for 1 .. 32 scenarios, against 10 us (1 scenario)
+  // and 32 us (16) there; from 32 scenarios on the lane form is ahead (64: 48 vs 90 us, 256: 165 vs 407 us; profiles/r40h_lane_rates.log).
+  // DSP_LANE_MIN_B: the threshold (development).
+  const int min_b = getenv("DSP_LANE_MIN_B") ? atoi(getenv("DSP_LANE_MIN_B")) : 32;
+  if (B < min_b) return hipSuccess;
   const bool qp = a.b.row_compliance != nullptr;
   hipError_t e;
   // tiles: enough waves to fill the chip (8 per CU), at least a few units each.  DSP_LANE_ROWS: rows per tile (development)
@@ -539,8 +566,9 @@ hipError_t lane_run(StreamSolver *S, StreamArgs &a, hipStream_t st, int *periods
   const int waves_env = getenv("DSP_LANE_WAVES") ? atoi(getenv("DSP_LANE_WAVES")) : 0;
   const int want_waves = waves_env > 0 ? waves_env : 2048;
   int rows = rows_env > 0 ? rows_env : (int)(((int64_t)m * G + want_waves - 1) / want_waves);
-  rows = std::max(rows, 3 * kLaneCH);
-  rows = (rows + kLaneCH - 1) / kLaneCH * kLaneCH;
+  const int ch = lane_ch(L->plan.WC, L->plan.WR, NLP);
+  rows = std::max(rows, 3 * ch);
+  rows = (rows + ch - 1) / ch * ch;
   LaneTiling *T = nullptr;
   if ((e = lane_tiling(L, rows, &T)) != hipSuccess) return e;
   if (T->ntile == 0) return hipSuccess;

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define DSP_VERSION 6
+#define DSP_VERSION 7
 
 /* return codes (0 = ok, < 0 = API misuse / HIP error; text via dsp_strerror) */
 #define DSP_OK                 0
@@ -225,8 +225,15 @@ typedef struct dsp_stats {
   int32_t quadratic;              /* 1 = soft rows present (QP variant of the kernel ran)                */
   int32_t precision;              /* precision the iterates were held in (dsp_options::precision)        */
   int32_t rtc;                    /* 1 = the kernel that ran was compiled at run time for this LP's shape (dsp_options::no_rtc) */
-  int32_t reserved1;
+  int32_t stream_form;            /* streaming path, which form of the iteration ran (ABI 7; was reserved): DSP_STREAM_FORM_* */
 } dsp_stats;
+
+/* dsp_stats::stream_form */
+#define DSP_STREAM_FORM_NONE       0   /* not the streaming path */
+#define DSP_STREAM_FORM_TWO_LAUNCH 1   /* k_primal + k_dual_halpern per iteration: 8 n + 6 m doubles per scenario-iteration */
+#define DSP_STREAM_FORM_TILE       2   /* round 3: one launch per iteration, a workgroup per tile of rows x 2 scenarios (k_fused_pre / k_fused) */
+#define DSP_STREAM_FORM_LANE       3   /* round 4: scenario-minor storage, a lane per scenario walks a tile (k_lane; batches of 32 scenarios and more) */
+#define DSP_STREAM_FORM_BLOCK      4   /* mid-size LPs: the whole solve in one launch, one workgroup per scenario, state in LDS (k_block_solve) */
 
 void dsp_default_options(dsp_options *opt);
 

@@ -124,7 +124,7 @@ static int run_all(Problem &Q) {
         LaneGroup G{};
         G.x_in = Q.x.data(); G.y_in = Q.y.data(); G.x0 = Q.x0.data(); G.c = Q.c.data(); G.y0 = Q.y0.data();
         G.x_out = x_out.data(); G.y_out = y_out.data(); G.xbl = xbl.data(); G.xpl = xpl.data(); G.xp = xp_out.data(); G.yp = yp_out.data();
-        LaneScalars sc{Q.tau[s], Q.sig[s], Q.oml[s], false};
+        LaneScalars sc{Q.tau[s], Q.sig[s], Q.oml[s], false, true};
         LaneOut<NLP> out;
         if (mode == 0) LaneTile<WC, WR, NLP, 4, true, false, 0>::run(P, G, t, s, sc, ring.data(), nullptr, out);
         else if (mode == 1) LaneTile<WC, WR, NLP, 4, true, false, 1>::run(P, G, t, s, sc, ring.data(), nullptr, out);

@@ -55,10 +55,12 @@ def test_one_launch_forms_reproduce_the_two_launch_form(monkeypatch):
         P, _ = orc.wind_battery_price_taker(T, cf, lmp * lm, batt_cap_factor=bf)
         ref.append(P.solve(tight=True)[1])
     ref = np.array(ref)
-    keys = ("DSP_STREAM_NO_LANE", "DSP_STREAM_NO_FUSED", "DSP_FUSED_V", "DSP_FUSED_XCD", "DSP_FUSED_RB", "DSP_FUSED_DEFER", "DSP_LANE_ROWS")
+    keys = ("DSP_STREAM_NO_LANE", "DSP_STREAM_NO_FUSED", "DSP_FUSED_V", "DSP_FUSED_XCD", "DSP_FUSED_RB", "DSP_FUSED_DEFER", "DSP_LANE_ROWS", "DSP_LANE_MIN_B")
     for thr in ("chain", "two_level"):
         out = {}
-        for form, extra in (("lane", {}), ("lane_small_tiles", {"DSP_LANE_ROWS": "12"}), ("lane_large_tiles", {"DSP_LANE_ROWS": "400"}),
+        # (DSP_LANE_MIN_B: batches below 32 scenarios run the round-3 form by default)
+        for form, extra in (("lane", {"DSP_LANE_MIN_B": "1"}), ("lane_small_tiles", {"DSP_LANE_MIN_B": "1", "DSP_LANE_ROWS": "12"}),
+                            ("lane_large_tiles", {"DSP_LANE_MIN_B": "1", "DSP_LANE_ROWS": "400"}),
                             ("fused", {"DSP_STREAM_NO_LANE": "1"}), ("fused_staged", {"DSP_STREAM_NO_LANE": "1", "DSP_FUSED_V": "1"}),
                             ("fused_small_tiles", {"DSP_STREAM_NO_LANE": "1", "DSP_FUSED_RB": "64"}),
                             ("two_launch", {"DSP_STREAM_NO_LANE": "1", "DSP_STREAM_NO_FUSED": "1"})):
@@ -89,29 +91,35 @@ def test_one_launch_forms_reproduce_the_two_launch_form(monkeypatch):
 
 
 @gpu
-@pytest.mark.parametrize("throughput", ["chain", "two_level"])
-def test_year_long_price_taker_lps_converge(throughput):
+@pytest.mark.parametrize("throughput,B", [("chain", 8), ("two_level", 16), ("two_level", 64)])
+def test_year_long_price_taker_lps_converge(throughput, B):
     """The reference's own horizon (wind_battery_LMP.py: 8736 hourly periods, n = m = 52 419) for the first 8 members of the family
     against the oracle fixture (HiGHS on the un-reduced LP, tools/make_price_taker_fixtures.py).  Round 2 never converged here:
     the step size rested on a 500-iteration power-iteration estimate of ||A||, 1 % short for this near-Toeplitz matrix.
     `two_level`: the same LPs with the battery's accumulated throughput as 3 node values + local deviations (an exact change of
     variables, flowsheets/price_taker.py): same optima on the same kernels in a fifth of the iterations (the 16 scenarios of the
-    fixture: 404 k -> 75 k on average, slowest 770 k -> 139 k; profiles/r30_two_level_probe_B16.log)."""
+    fixture: 404 k -> 75 k on average, slowest 770 k -> 139 k; profiles/r30_two_level_probe_B16.log).  16 members: the whole fixture
+    on the workgroup-per-tile form of round 3 (small batches); 64 members (the family four times over): the lane-per-scenario form
+    of round 4 (csrc/dsp_stream_lane.hip), whose lanes drop out of the walk as their scenarios finish."""
     from dispatches_amd import scenarios
     from dispatches_amd.hip_solver import HipPdlpSolver
     fx = np.load(os.path.join(GOLD, "oracle_price_taker.npz"))
-    T, B = 8736, 8
+    T = 8736
     solver = HipPdlpSolver(device=0, check_every=64, max_iter=2_000_000)
     handles, model = scenarios.price_taker_batch(T, B, solver, throughput=throughput)
     solver.solve(model, tee=True)
     assert (model.status == 0).all(), (model.status, model.iterations)
     if throughput == "two_level":
         assert solver.last_stats.streaming == 1 and model.iterations.max() < 250_000, model.iterations
-    ref = fx["T8736/obj"][:B]
+    member = np.arange(B) % len(scenarios.PRICE_TAKER_FAMILY)
+    ref = fx["T8736/obj"][member]
     err = np.abs(model.objective - ref) / np.maximum(1.0, np.abs(ref))
     assert err.max() < 1e-6, (err, model.iterations)
     batt = model.x[:, handles["battery_system_capacity"].index] * 1e-3
-    np.testing.assert_allclose(batt, fx["T8736/batt_mw"][:B], rtol=2e-3, atol=1.0)
+    np.testing.assert_allclose(batt, fx["T8736/batt_mw"][member], rtol=2e-3, atol=1.0)
+    if B >= 32:
+        n, m = model.lp.n, model.lp.m
+        assert solver.last_stats.stream_bytes_per_iteration == 8 * (4 * n + 3 * m)
 
 
 @gpu
