@@ -296,15 +296,18 @@ __global__ void __launch_bounds__(64) simplex_kernel(SimplexArgs a) {
     wave_lds_fence();
     double xs[CQ];
     double po = 0.0;
-    bool okv = true, okb = true;
+    bool okv = true, okb = true, okr = true;
+    double viol = 0.0;                                        // largest bound violation of the vertex, relative to its variable's scale
 #pragma unroll
     for (int q = 0; q < CQ; ++q) {
       const int j = lane + 64 * q;
       xs[q] = (j < N) ? xval[j] : 0.0;
       if (j < N) {
         // same scale as the simplex' own feasibility tolerance (tol_p (1 + the variable's larger finite bound)), 10x looser
-        const double tol = 1e-9 * (1.0 + fmax(fabs(xs[q]), fmax(fabs(finite_or_zero(lo[q])), fabs(finite_or_zero(hi[q])))));
+        const double scl = 1.0 + fmax(fabs(xs[q]), fmax(fabs(finite_or_zero(lo[q])), fabs(finite_or_zero(hi[q]))));
+        const double tol = 1e-9 * scl;
         if (xs[q] < lo[q] - tol || xs[q] > hi[q] + tol || !(xs[q] == xs[q])) { okv = false; okb = false; }
+        viol = fmax(viol, fmax(lo[q] - xs[q], xs[q] - hi[q]) / scl);
       }
       if (j < n) po = fma(cost[q], xs[q], po);
     }
@@ -323,7 +326,7 @@ __global__ void __launch_bounds__(64) simplex_kernel(SimplexArgs a) {
         }
       }
       const double gmag = wave_max(mag);
-      if (lane < m && !(fabs(res) <= 1e-9 * (1.0 + gmag))) okv = false;
+      if (lane < m && !(fabs(res) <= 1e-9 * (1.0 + gmag))) { okv = false; okr = false; }
     }
     const bool certified = __ballot(!okv) == 0ull;
     const unsigned long long bad_bounds = __ballot(!okb), bad_any = __ballot(!okv);
@@ -333,6 +336,24 @@ __global__ void __launch_bounds__(64) simplex_kernel(SimplexArgs a) {
     // degenerate hourly LP either stop can be a tolerance artefact (no |d_j| above 1e-9, every ratio below the pivot tolerance).
     // Not reported as infeasible / unbounded: the PDLP pass takes the scenario (a genuinely infeasible LP ends there at the
     // iteration limit - dispatch LPs carry slack columns, so that is an input error, not a regular outcome).
+    // ... EXCEPT a phase-1 optimum whose vertex is clearly outside its bounds (> 1e-6 of the variable's scale, a thousand times the
+    // feasibility tolerance) on an intact tableau (row residuals certified): that is a proof of infeasibility, reported as such -
+    // a caller that hands over an infeasible hourly LP gets status 2 like from the reference's CBC, not an iteration limit.
+    const bool clearly_infeasible = status == DSP_STATUS_PRIMAL_INFEASIBLE && __ballot(!okr) == 0ull && wave_max(viol) > 1e-6;
+    if (clearly_infeasible) {
+#pragma unroll
+      for (int q = 0; q < CQ; ++q) { const int j = lane + 64 * q; if (j < n) b.x[(size_t)s * n + j] = NAN; }
+      if (lane < m) b.y[(size_t)s * m + lane] = NAN;
+      if (lane == 0) {
+        b.obj[s] = NAN;
+        b.status[s] = DSP_STATUS_PRIMAL_INFEASIBLE;
+        if (b.iters) b.iters[s] = pivots;
+        if (b.jumps) b.jumps[s] = 0;
+        if (b.flags) b.flags[s] = 0;
+      }
+      wave_lds_fence();
+      continue;
+    }
     if (status == DSP_STATUS_PRIMAL_INFEASIBLE || status == DSP_STATUS_DUAL_INFEASIBLE) { status = -1; reason = 3; }
     if (status == -1) {
       if (lane == 0) {
@@ -644,14 +665,17 @@ __global__ void __launch_bounds__(64, 2) simplex_reg_kernel(SimplexArgs a) {
     wave_lds_fence();
     double xs[CQ];
     double po = 0.0;
-    bool okv = true, okb = true;
+    bool okv = true, okb = true, okr = true;
+    double viol = 0.0;                                        // largest bound violation of the vertex, relative to its variable's scale
 #pragma unroll
     for (int q = 0; q < CQ; ++q) {
       const int j = lane + 64 * q;
       xs[q] = (j < N) ? xval[j] : 0.0;
       if (j < N) {
-        const double tol = 1e-9 * (1.0 + fmax(fabs(xs[q]), fmax(fabs(finite_or_zero(lo[q])), fabs(finite_or_zero(hi[q])))));
+        const double scl = 1.0 + fmax(fabs(xs[q]), fmax(fabs(finite_or_zero(lo[q])), fabs(finite_or_zero(hi[q]))));
+        const double tol = 1e-9 * scl;
         if (xs[q] < lo[q] - tol || xs[q] > hi[q] + tol || !(xs[q] == xs[q])) { okv = false; okb = false; }
+        viol = fmax(viol, fmax(lo[q] - xs[q], xs[q] - hi[q]) / scl);
       }
       if (j < n) po = fma(cost[q], xs[q], po);
     }
@@ -679,13 +703,29 @@ __global__ void __launch_bounds__(64, 2) simplex_reg_kernel(SimplexArgs a) {
           if (lane == i0 + u) { res = part[2 * u] - xval[n + lane]; mag = part[2 * u + 1] + fabs(xval[n + lane]); }
       }
       const double gmag = wave_max(mag);
-      if (lane < m && !(fabs(res) <= 1e-9 * (1.0 + gmag))) okv = false;
+      if (lane < m && !(fabs(res) <= 1e-9 * (1.0 + gmag))) { okv = false; okr = false; }
     }
     const bool certified = __ballot(!okv) == 0ull;
     const unsigned long long bad_bounds = __ballot(!okb), bad_any = __ballot(!okv);
     int reason = status == -1 ? 1 : 0;
     if (status == DSP_STATUS_OPTIMAL && !certified) { status = -1; reason = 2; }
-    if (status == DSP_STATUS_PRIMAL_INFEASIBLE || status == DSP_STATUS_DUAL_INFEASIBLE) { status = -1; reason = 3; }   // see the LDS-tableau kernel
+    // (a phase-1 optimum clearly outside its bounds on an intact tableau is reported infeasible: see the LDS-tableau kernel)
+    const bool clearly_infeasible = status == DSP_STATUS_PRIMAL_INFEASIBLE && __ballot(!okr) == 0ull && wave_max(viol) > 1e-6;
+    if (clearly_infeasible) {
+#pragma unroll
+      for (int q = 0; q < CQ; ++q) { const int j = lane + 64 * q; if (j < n) b.x[(size_t)s * n + j] = NAN; }
+      if (lane < m) b.y[(size_t)s * m + lane] = NAN;
+      if (lane == 0) {
+        b.obj[s] = NAN;
+        b.status[s] = DSP_STATUS_PRIMAL_INFEASIBLE;
+        if (b.iters) b.iters[s] = pivots;
+        if (b.jumps) b.jumps[s] = 0;
+        if (b.flags) b.flags[s] = 0;
+      }
+      wave_lds_fence();
+      continue;
+    }
+    if (status == DSP_STATUS_PRIMAL_INFEASIBLE || status == DSP_STATUS_DUAL_INFEASIBLE) { status = -1; reason = 3; }
     if (status == -1) {
       if (lane == 0) {
         if (a.debug_keep) {

@@ -130,9 +130,8 @@ def solve_sharded(model, solver, group=None, gather_solution: bool = False):
         out = None
     buffers = make_gather_buffers(world, per, dev, width)
     if world > 1:
-        if out is None:                                     # empty shard: still takes part in the collective
-            dist.all_gather_into_tensor(buffers["all"], buffers["local"], group=group)
-            everything = buffers["all"].view(world, per, width)
+        if out is None:                                     # empty shard: still takes part in the collective, through the SAME
+            everything = gather_device_results({}, buffers, per, group, ())     # path as the others (host staging under the rehearsal)
         else:
             everything = gather_device_results(out, buffers, per, group, columns)   # the ONE collective of the solve
         everything = everything.cpu().numpy()

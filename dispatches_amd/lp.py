@@ -245,8 +245,6 @@ def implied_column_ranges(lp: "StandardFormLP", lb=None, ub=None, passes: int = 
 
 
 class LinearBlock:
-    presolve_sequential_limit = 256      # candidates confirmed one at a time up to this many, in one batch beyond (flatten)
-
     """The block a model object's ``populate_model(b, horizon)`` fills (stand-in for a Pyomo Block).
 
     Columns, rows and named expression families are appended in call order.  ``flatten()`` produces the
@@ -254,6 +252,8 @@ class LinearBlock:
     1e8 battery ramp rows of wind_battery_LMP.py:139-142).  Bounds / row bounds stay mutable afterwards and
     are re-read through ``current_bounds()`` at every solve.
     """
+
+    presolve_sequential_limit = 256      # candidates confirmed one at a time up to this many, in one batch beyond (flatten)
 
     def __init__(self, name: str = "fs"):
         self.name = name

@@ -60,7 +60,8 @@ class _DeviceModel:
         self.soc_init, self.thr_init = fam["soc_init"].index, fam["thr_init"].index
         # (period 0's throughput is a column in the reference's form of the accumulator; in the two-level form it is an expression and
         #  this model cannot hand the realised state over - the loop takes it from the tracking model, whose horizon keeps the chain)
-        self.soc0, self.thr0 = per[0]["state_of_charge"].index, getattr(per[0]["energy_throughput"], "index", -1)
+        # -> thr0 = None, never -1: an index of -1 reads the LAST column on the host and runs off the array in the fused update kernel
+        self.soc0, self.thr0 = per[0]["state_of_charge"].index, getattr(per[0]["energy_throughput"], "index", None)
         self.wind_kw = float(fam["wind_kw"])
         # P_T[t] = 1e-3 (grid_elec[t] + elec_out[t]): the two columns of every hour
         self.pt_cols = idx([[p["grid_elec"].index, p["elec_out"].index] for p in per])       # [T, 2]
@@ -86,6 +87,9 @@ class _DeviceModel:
         w.c, w.lb, w.ub, w.rlo, w.rhi = (t.data_ptr() for t in (self.c, self.lb, self.ub, self.rlo, self.rhi))
         w.base_c, w.x = self.base_c.data_ptr(), self.out["x"].data_ptr()
         w.n, w.m, w.T = self.lp.n, self.lp.m, self.T
+        if self.thr0 is None:
+            raise ValueError("this model holds period 0's throughput as an expression (two-level accumulator): it cannot hand the "
+                             "realised state to the fused rolling-update kernel")
         w.soc_init, w.thr_init, w.soc0, w.thr0 = self.soc_init, self.thr_init, self.soc0, self.thr0
         wc, pt = self.wind_cols.cpu().tolist(), self.pt_cols.cpu().tolist()
         pda = self.pda_cols.cpu().tolist() if hasattr(self, "pda_cols") else []
@@ -151,6 +155,8 @@ class BatchedWindBatteryDoubleLoop:
         self.da = _DeviceModel(da_model, B, dev, device, hints=getattr(da_model, "solver_hints", None), lp_backend=lp_backend)
         self.rt = _DeviceModel(rt_model, B, dev, device, hints=getattr(rt_model, "solver_hints", None), lp_backend=lp_backend)
         self.tr = _DeviceModel(tr_model, B, dev, device, hints=getattr(tr_model, "solver_hints", None), lp_backend=lp_backend)
+        if self.tr.thr0 is None:
+            raise ValueError("the tracking model must carry period 0's throughput as a column: the loop reads the realised state from it")
         idx = lambda cols: torch.as_tensor(np.asarray(cols, np.int64), device=dev)
         self.da.pda_cols, self.rt.pda_cols = idx(da_model.pda_cols), idx(rt_model.pda_cols)
         # column handles of the hourly models' periods (tests map device solutions into the oracle's variables through these)

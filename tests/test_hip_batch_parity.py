@@ -118,6 +118,28 @@ def test_tracking_lps_full_batch(case):
 
 
 @gpu
+def test_infeasible_hourly_lp_is_reported_infeasible():
+    """A 4-h tracking LP whose fixed initial state of charge is ten times the battery's energy capacity (bounds not crossed: the
+    infeasibility only shows through the rows).  The in-wave simplex stops in phase 1 with a vertex far outside its bounds on an
+    intact tableau: status 2 (primal infeasible), as the reference's solvers report it - round 3 handed every phase-1 stop to the
+    PDLP pass, where such an LP came back as an iteration limit (round-3 advisor finding).  The neighbours are unaffected."""
+    from dispatches_amd import scenarios
+    fx = np.load(os.path.join(GOLD, "oracle_hourly.npz"))
+    case, B = "wind_battery_track4", 8
+    inp = {k.split("/", 1)[1]: fx[k][:B] for k in fx.files if k.startswith(case + "/")}
+    inp["soc0"] = inp["soc0"].copy()
+    inp["soc0"][3] = 10.0 * 4 * 25.0e3 * 40                         # kWh: far beyond any battery of the fixture family
+    solver = _solver()
+    tracker, model = scenarios.hourly_tracking_batch(case, inp, solver)
+    solver.solve(model)
+    assert solver.last_stats.simplex == 1
+    assert model.status.tolist() == [0, 0, 0, 2, 0, 0, 0, 0], model.status
+    assert np.isnan(model.objective[3])
+    keep = [0, 1, 2, 4, 5, 6, 7]
+    _check_objective(model.objective[keep], inp["obj"][keep], case)
+
+
+@gpu
 def test_simplex_certificate_regression():
     """Three 4-h real-time LPs met in the rolling double loop (day_ahead_power fixed to un-rounded offers, SOC ~45 MWh):
     the in-wave simplex found the right vertex (objective = HiGHS to 14 digits) but an over-strict certificate (row

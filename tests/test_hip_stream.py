@@ -123,6 +123,32 @@ def test_year_long_price_taker_lps_converge(throughput, B):
 
 
 @gpu
+@pytest.mark.parametrize("B", [8, 32])
+def test_year_long_pem_price_taker_lps_converge(B):
+    """LP #5 (reference wind_battery_pem_optimize, wind_battery_PEM_LMP.py:180-298) at the horizon the reference's sweeps run it at
+    (run_pricetaker_wind_PEM.py:54-56: every hour of the year, 8736 periods; n = 61 156): the members of the hydrogen-price x PEM-
+    capital-cost family against the oracle fixture (HiGHS on the un-reduced LP, 27 s per member: tools/make_price_taker_fixtures.py
+    --pem) - objectives to 1e-6, the PEM's size within the reference test's own tolerance (test_RE_flowsheet.py:139-164: +- 1 MW on
+    487 MW), no battery.  8 members: the small-batch form; 32 (the family twice over): the lane-per-scenario form."""
+    from dispatches_amd import scenarios
+    from dispatches_amd.hip_solver import HipPdlpSolver
+    fx = np.load(os.path.join(GOLD, "oracle_price_taker.npz"))
+    T = 8736
+    solver = HipPdlpSolver(device=0, check_every=64, max_iter=2_000_000)
+    handles, model = scenarios.pem_price_taker_batch(T, B, solver, inputs="rts303")
+    solver.solve(model, tee=True)
+    assert solver.last_stats.streaming == 1 and (model.status == 0).all(), (model.status, model.iterations)
+    member = np.arange(B) % len(scenarios.PEM_PRICE_TAKER_FAMILY)
+    ref = fx["pem_T8736/obj"][member]
+    err = np.abs(model.objective - ref) / np.maximum(1.0, np.abs(ref))
+    assert err.max() < 1e-6, (err, model.iterations)
+    pem = model.x[:, handles["pem_system_capacity"].index] * 1e-3
+    np.testing.assert_allclose(pem, fx["pem_T8736/pem_mw"][member], rtol=2e-3, atol=1.0)
+    batt = model.x[:, handles["battery_system_capacity"].index] * 1e-3
+    np.testing.assert_allclose(batt, fx["pem_T8736/batt_mw"][member], rtol=2e-3, atol=1.0)
+
+
+@gpu
 def test_reference_price_taker_goldens_on_the_gpu(golden):
     """The reference's own price-taker tests (renewables_case/tests/test_RE_flowsheet.py:123-161) through the HIP path: LP #4 (wind +
     battery, one week) and LP #5 (wind + battery + PEM, six days, hydrogen at 2.5 $/kg) on the reference's inputs - SRW wind speeds
@@ -186,6 +212,11 @@ def test_nuclear_price_taker_enumeration_on_the_gpu():
     closed = np.array([-1e-6 * orc.nuclear_price_taker_closed_form(model.lmp, hp, pc * 400.0) for hp, pc in model.family])
     err = np.abs(model.objective - closed) / np.maximum(1.0, np.abs(closed))
     assert err.max() < 1e-6, (err.max(), model.iterations)
+    # ... and, at this full horizon, against HiGHS on the oracle's LP for four points of the grid (committed fixture:
+    # tools/make_price_taker_fixtures.py --nuclear; HiGHS' presolve decouples the hours, under a second per point) - the closed form lives in the oracle module itself
+    fx = np.load(os.path.join(GOLD, "oracle_price_taker.npz"))
+    for k, ref in zip(fx["nuclear_T8784/k"], fx["nuclear_T8784/obj"]):
+        assert abs(model.objective[k] - ref) <= 1e-6 * max(1.0, abs(ref)), (k, model.objective[k], ref)
     # n (incl. 3 design columns) and the algorithmic bytes: the members differ in the bounds of ONE design column (a long column, whose
     # bounds the lane form keeps per scenario in any case), so the batch shares every other bound: 4 n + 3 m doubles (the round-3
     # form read all bounds per scenario: 6 n + 5 m)

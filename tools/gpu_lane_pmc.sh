@@ -20,6 +20,6 @@ with open(sys.argv[1], "w") as o:
     w = csv.writer(o); w.writerow(["counter", "kernel", "dispatches", "mean_counter_value"])
     for (c, k), (n, s) in acc.items():
         if "k_lane" in k:
-            w.writerow([c, k.split("(")[0][-60:], n, round(s / n, 1)])
+            w.writerow([c, k.replace("(anonymous namespace)::", "").split("(")[0][-70:], n, round(s / n, 1)])
 print("\n".join(l for l in open(sys.argv[1]).read().splitlines() if "false, 0>" in l or "k_lane_long<0>" in l))
 PY

@@ -29,9 +29,75 @@ def one(args):
     return k, obj, P.value(info["npv"], x), x[info["Pb"]] * 1e-3, time.time() - t
 
 
+def one_pem(args):
+    """LP #5 (reference wind_battery_pem_optimize, wind_battery_PEM_LMP.py:180-298) for member k of scenarios.PEM_PRICE_TAKER_FAMILY on
+    the bus-303 series (the inputs of scenarios.pem_price_taker_batch(..., inputs="rts303"))."""
+    T, k = args
+    from dispatches_amd import scenarios
+    from oracle import dispatch_lp_oracle as orc
+    cf, lmp = scenarios.price_taker_inputs(T)
+    h2, pf = scenarios.PEM_PRICE_TAKER_FAMILY[k]
+    t = time.time()
+    P, info = orc.wind_battery_pem_price_taker(T, cf, lmp, h2, True)
+    c = P.c.copy()
+    c[info["Cp"]] += 1e-5 * (pf - 1.0) * orc.PEM_CAP_COST                  # the family's PEM capital-cost factor
+    x, obj = P.solve(c=c, tight=True)
+    return k, obj, x[info["Cp"]] * 1e-3, x[info["Pb"]] * 1e-3, time.time() - t
+
+
+def pem_fixtures(T, members):
+    """python tools/make_price_taker_fixtures.py --pem [T] [members]: adds pem_T<T>/{obj, pem_mw, batt_mw} for the first `members`
+    members of the wind + battery + PEM family (round 4: the year-long horizon the reference's sweeps run LP #5 at)."""
+    import multiprocessing as mp
+    path = os.path.join(os.path.dirname(__file__), "..", "tests", "golden", "oracle_price_taker.npz")
+    out = dict(np.load(path)) if os.path.exists(path) else {}
+    with mp.get_context("spawn").Pool(min(os.cpu_count() or 1, members)) as pool:
+        res = sorted(pool.map(one_pem, [(T, k) for k in range(members)]))
+    out[f"pem_T{T}/obj"] = np.array([r[1] for r in res])
+    out[f"pem_T{T}/pem_mw"] = np.array([r[2] for r in res])
+    out[f"pem_T{T}/batt_mw"] = np.array([r[3] for r in res])
+    print(f"PEM T={T}: HiGHS {np.mean([r[4] for r in res]):.1f} s per member; obj {out[f'pem_T{T}/obj']} PEM MW {out[f'pem_T{T}/pem_mw']} batt MW {out[f'pem_T{T}/batt_mw']}", flush=True)
+    np.savez(path, **out)
+
+
+def one_nuclear(args):
+    """LP #6 (nuclear + PEM + tank price-taker, price_taker_analysis.py:116-222) for point k of the 6 x 10 (hydrogen price x PEM
+    capacity) grid of scenarios.nuclear_price_taker_batch, at the reference's own horizon."""
+    T, k = args
+    from dispatches_amd import scenarios
+    from dispatches_amd.flowsheets.price_taker import NUCLEAR_H2_PRICES, NUCLEAR_PEM_FRACTIONS, NP_CAPACITY_MW
+    from oracle import dispatch_lp_oracle as orc
+    lmp = scenarios.load_series("nuclear_price_taker_lmps.npz")["rt_lmp"][:T]
+    grid = [(hp, pc) for hp in NUCLEAR_H2_PRICES for pc in NUCLEAR_PEM_FRACTIONS]
+    hp, pc = grid[k]
+    t = time.time()
+    obj = orc.nuclear_price_taker(T, lmp, hp, pc * NP_CAPACITY_MW)[0].solve(tight=True)[1]
+    return k, obj, time.time() - t
+
+
+def nuclear_fixtures(T, points):
+    """python tools/make_price_taker_fixtures.py --nuclear [T] [k ...]: adds nuclear_T<T>/{k, obj}: HiGHS objectives of the given grid
+    points (round 4: the full-horizon enumeration was checked against the oracle's closed form only)."""
+    import multiprocessing as mp
+    path = os.path.join(os.path.dirname(__file__), "..", "tests", "golden", "oracle_price_taker.npz")
+    out = dict(np.load(path)) if os.path.exists(path) else {}
+    with mp.get_context("spawn").Pool(min(os.cpu_count() or 1, len(points))) as pool:
+        res = sorted(pool.map(one_nuclear, [(T, k) for k in points]))
+    out[f"nuclear_T{T}/k"] = np.array([r[0] for r in res])
+    out[f"nuclear_T{T}/obj"] = np.array([r[1] for r in res])
+    print(f"nuclear T={T}: HiGHS {np.mean([r[2] for r in res]):.1f} s per point; k {out[f'nuclear_T{T}/k']} obj {out[f'nuclear_T{T}/obj']}", flush=True)
+    np.savez(path, **out)
+
+
 if __name__ == "__main__":
     import multiprocessing as mp
     from dispatches_amd import scenarios
+    if len(sys.argv) > 1 and sys.argv[1] == "--nuclear":
+        nuclear_fixtures(int(sys.argv[2]) if len(sys.argv) > 2 else 8784, [int(a) for a in sys.argv[3:]] or [0, 17, 34, 59])
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "--pem":
+        pem_fixtures(int(sys.argv[2]) if len(sys.argv) > 2 else 8736, int(sys.argv[3]) if len(sys.argv) > 3 else 8)
+        sys.exit(0)
     horizons = [int(a) for a in sys.argv[1:]] or [168, 8736]
     path = os.path.join(os.path.dirname(__file__), "..", "tests", "golden", "oracle_price_taker.npz")
     out = dict(np.load(path)) if os.path.exists(path) else {}
