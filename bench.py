@@ -33,7 +33,7 @@ PEAK_CLOCK_HZ = 2.4e9     # max shader clock (MI355X_MICROARCH.md)
 FP64_VECTOR_PEAK_TFLOPS = 78.6   # 1/2 of the 157.3 TF FP32 vector peak
 
 
-def _profiled_counters(kernel):
+def _profiled_counters(kernel, batch=None):
     """Mean per-launch PMC counters of `kernel` from the NEWEST committed rocprofv3 summary that holds that kernel
     (profiles/rNN*_pmc_summary.csv: separate --pmc passes of this same bench command, tools/gpu_profile.sh).  `kernel` is a
     substring of the demangled name - the solve kernel is looked up WITH its template arguments ("pdlp_solve_kernel<4, 2,"), so
@@ -43,6 +43,10 @@ def _profiled_counters(kernel):
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.csv")), key=os.path.getmtime)
     # (mtime is the checkout time in a fresh clone, so ties are broken by name: later round tags sort later)
     files = sorted(files, key=lambda f: os.path.basename(f))
+    # a summary collected at THIS batch size (tools/gpu_profile_configs.sh: r4xp_<workload>_B<batch>_pmc_summary.csv) wins over one
+    # of the same kernel at another batch (FETCH_SIZE / WRITE_SIZE are per launch: they do not scale like the SQ counters)
+    if batch is not None:
+        files = [f for f in files if f"_B{batch}_" not in os.path.basename(f)] + [f for f in files if f"_B{batch}_" in os.path.basename(f)]
     for f in reversed(files):
         out = {}
         for row in csv.DictReader(open(f)):
@@ -53,10 +57,10 @@ def _profiled_counters(kernel):
     return {}, None
 
 
-def _profiled_traffic(kernel):
+def _profiled_traffic(kernel, batch=None):
     """HBM bytes per launch of `kernel` from that summary: FETCH_SIZE doubled per the gfx950 correction of
     MI355X_MICROARCH.md (both counters are in KB).  None if no profile is committed."""
-    c, _ = _profiled_counters(kernel)
+    c, _ = _profiled_counters(kernel, batch)
     if "FETCH_SIZE" not in c or "WRITE_SIZE" not in c:
         return None
     return (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0
@@ -724,8 +728,8 @@ def main():
         true_io = (sum(t.numel() for t in (c_d, lb_d, ub_d, rlo_d, rhi_d) if t.dim() == 2) * w
                    + B * w * (lp.n + lp.m + 1) + B * 12)
         solve_kernel = f"pdlp_solve_kernel<{int(st.cols_per_lane)}, {int(st.rows_per_lane)}," if geometry[3] else "pdlp_solve_kernel"
-        pmc, pmc_file = _profiled_counters(solve_kernel)
-        traffic = _profiled_traffic(solve_kernel)
+        pmc, pmc_file = _profiled_counters(solve_kernel, B)
+        traffic = _profiled_traffic(solve_kernel, B)
         # The SQ counters of a launch are proportional to the scenario-iterations it runs (hot loop + checks; the per-scenario
         # prologue is < 1 %).  A profile records the iterations of its launch (profiles/<tag>_pmc_iterations.json); when the
         # shipped options / model hints have changed the iteration count since (e.g. the column scaling of DESIGN 5a-4, adopted
