@@ -34,6 +34,10 @@
 #define DSP_LANE_HD inline
 #endif
 
+#ifndef DSP_LANE_IL
+#define DSP_LANE_IL 4
+#endif
+
 namespace dsp {
 
 template <int N> struct LaneVecD { double v[N]; };
@@ -62,12 +66,26 @@ DSP_LANE_HD T ldu(const T *p) {
 // element (e, lane) of a group's block [elements][64] through a 32-bit byte offset on the block's wave-uniform base:
 // global_load v, v_off, s[base] - one 32-bit add per access (e * 512 is scalar), no 64-bit vector address arithmetic.  A group's
 // block of one vector is 512 bytes per element: 4 GiB = 8 M elements (checked by the host).
+#if defined(__HIP_DEVICE_COMPILE__) && defined(DSP_LANE_NT)
+// (experiment) non-temporal: every iterate is read once and written once per launch
+DSP_LANE_HD double lane_ld(const double *base, int e, uint32_t lane8) {
+  return __builtin_nontemporal_load(reinterpret_cast<const double *>(reinterpret_cast<const char *>(base) + ((uint32_t)e * 512u + lane8)));
+}
+struct LaneStoreNT {
+  double *p;
+  DSP_LANE_HD void operator=(double v) const { __builtin_nontemporal_store(v, p); }
+};
+DSP_LANE_HD LaneStoreNT lane_st(double *base, int e, uint32_t lane8) {
+  return LaneStoreNT{reinterpret_cast<double *>(reinterpret_cast<char *>(base) + ((uint32_t)e * 512u + lane8))};
+}
+#else
 DSP_LANE_HD const double &lane_ld(const double *base, int e, uint32_t lane8) {
   return *reinterpret_cast<const double *>(reinterpret_cast<const char *>(base) + ((uint32_t)e * 512u + lane8));
 }
 DSP_LANE_HD double &lane_st(double *base, int e, uint32_t lane8) {
   return *reinterpret_cast<double *>(reinterpret_cast<char *>(base) + ((uint32_t)e * 512u + lane8));
 }
+#endif
 
 // (device) the value must be in its register HERE: the wait for its load is placed at this point of straight-line code, with an
 // exact count, instead of inside the unit loop - where the merge over the back edge makes it s_waitcnt vmcnt(0), i.e. a wait for
@@ -111,6 +129,10 @@ template <int NLP> struct LaneOut { double lp[NLP]; double v[13]; };
 template <int WC, int WR, int NLP, int CH, bool SHARED, bool QP, int MODE>
 struct LaneTile {
   static constexpr int CREC = lane_crec(WC), RREC = lane_rrec(WR, NLP);
+  // slots of a unit whose chains are interleaved (the steps of `compute`): CH = all of them - most overlap, most registers (129
+  // VGPRs on the 4 / 4 / 4 shape: 3 waves per SIMD) - or 2 (DSP_LANE_IL: two pairs one after the other)
+  static constexpr int IL = DSP_LANE_IL < CH ? DSP_LANE_IL : CH;
+  static_assert(CH % IL == 0, "CH must be a multiple of the interleave");
   static_assert(CH * CREC <= 1024 && CH * RREC <= 1024, "a unit's records must fit one 16-byte-per-lane load");
   struct Unit { int ys0, nys, cx0, ncx, rd0, nrd; };
   struct Regs {
@@ -198,32 +220,36 @@ struct LaneTile {
       for (int k = 0; k < CH; ++k) yr[(size_t)((q.ys0 + (k < q.nys ? k : 0)) & M) * 64] = r.ys[k];
     }
     if (q.ncx > 0) {
-      LaneVecD<WC> av[CH];
-      LaneVecI<WC> ix[CH];
-      LaneVecD<2> bd[CH];
-      double cs[CH], gy[CH][WC];
 #pragma unroll
-      for (int k = 0; k < CH; ++k) {                                 // step 1: the records
+     for (int k0 = 0; k0 < CH; k0 += IL) {                          // IL slots at a time (registers: see DSP_LANE_IL)
+      LaneVecD<WC> av[IL];
+      LaneVecI<WC> ix[IL];
+      LaneVecD<2> bd[IL];
+      double cs[IL], gy[IL][WC];
+#pragma unroll
+      for (int kk = 0; kk < IL; ++kk) {                               // step 1: the records
+        const int k = k0 + kk;
         const char *cr = cbase + (k < q.ncx ? k : 0) * CREC;
-        av[k] = rec<LaneVecD<WC>>(cr, 0);
-        ix[k] = rec<LaneVecI<WC>>(cr, WC * 8);
-        if (SHARED) bd[k] = rec<LaneVecD<2>>(cr, WC * 12);
-        else { bd[k].v[0] = r.lb[k]; bd[k].v[1] = r.ub[k]; }
-        cs[k] = MODE == 2 ? rec<double>(cr, WC * 12 + 16) : 1.0;
+        av[kk] = rec<LaneVecD<WC>>(cr, 0);
+        ix[kk] = rec<LaneVecI<WC>>(cr, WC * 8);
+        if (SHARED) bd[kk] = rec<LaneVecD<2>>(cr, WC * 12);
+        else { bd[kk].v[0] = r.lb[k]; bd[kk].v[1] = r.ub[k]; }
+        cs[kk] = MODE == 2 ? rec<double>(cr, WC * 12 + 16) : 1.0;
       }
 #pragma unroll
-      for (int k = 0; k < CH; ++k)                                    // step 2: the gathers of y
+      for (int kk = 0; kk < IL; ++kk)                                  // step 2: the gathers of y
 #pragma unroll
-        for (int e = 0; e < WC; ++e) gy[k][e] = slot(ywin, (uint32_t)ix[k].v[e], M9, l8);
+        for (int e = 0; e < WC; ++e) gy[kk][e] = slot(ywin, (uint32_t)ix[kk].v[e], M9, l8);
 #pragma unroll
-      for (int k = 0; k < CH; ++k) {                                 // step 3: the arithmetic
+      for (int kk = 0; kk < IL; ++kk) {                               // step 3: the arithmetic
+        const int k = k0 + kk;
         const bool live = k < q.ncx;
         const int j = q.cx0 + (live ? k : 0);
-        const bool own = j >= j0 && j < j1 && ix[k].v[0] >= 0;         // sign bit of the first index: long column
+        const bool own = j >= j0 && j < j1 && ix[kk].v[0] >= 0;         // sign bit of the first index: long column
         double aty = 0.0;
 #pragma unroll
-        for (int e = 0; e < WC; ++e) aty = fma(av[k].v[e], gy[k][e], aty);
-        const double lbv = bd[k].v[0], ubv = bd[k].v[1];
+        for (int e = 0; e < WC; ++e) aty = fma(av[kk].v[e], gy[kk][e], aty);
+        const double lbv = bd[kk].v[0], ubv = bd[kk].v[1];
         if (MODE == 2) {
           // reduced cost at y+ (kkt_col_terms of dsp_stream.hip); only the own columns count
           const double w = (own && live) ? 1.0 : 0.0;
@@ -231,7 +257,7 @@ struct LaneTile {
           const double rc = cj - aty;
           const double lp = lane_finite(lbv) ? fmax(rc, 0.0) : 0.0;
           const double lm = lane_finite(ubv) ? fmax(-rc, 0.0) : 0.0;
-          const double dr = (rc - lp + lm) / cs[k];
+          const double dr = (rc - lp + lm) / cs[kk];
           out.v[8] = fma(w, dr * dr, out.v[8]);
           out.v[9] = fma(w, cj * xp, out.v[9]);
           out.v[10] = fma(w, lp * lane_fin0(lbv) - lm * lane_fin0(ubv), out.v[10]);
@@ -254,50 +280,55 @@ struct LaneTile {
           }
         }
       }
+     }
     }
     if (MODE == 2 || q.nrd <= 0) return;
-    {
-      LaneVecD<WR> av[CH];
-      LaneVecI<WR> ix[CH];
-      LaneVecD<2> bd[CH];
-      LaneVecD<NLP> al[CH];
-      double rs[CH], gx[CH][WR], gxp[CH][MODE == 1 ? WR : 1], yv[CH];
 #pragma unroll
-      for (int k = 0; k < CH; ++k) {                                 // step 1: the records
+    for (int k0 = 0; k0 < CH; k0 += IL) {
+      LaneVecD<WR> av[IL];
+      LaneVecI<WR> ix[IL];
+      LaneVecD<2> bd[IL];
+      LaneVecD<NLP> al[IL];
+      double rs[IL], gx[IL][WR], gxp[IL][MODE == 1 ? WR : 1], yv[IL];
+#pragma unroll
+      for (int kk = 0; kk < IL; ++kk) {                               // step 1: the records
+        const int k = k0 + kk;
         const char *rr = rbase + (k < q.nrd ? k : 0) * RREC;
-        av[k] = rec<LaneVecD<WR>>(rr, 0);
-        ix[k] = rec<LaneVecI<WR>>(rr, WR * 8);
-        if (SHARED) bd[k] = rec<LaneVecD<2>>(rr, WR * 12);
-        else { bd[k].v[0] = r.rlo[k]; bd[k].v[1] = r.rhi[k]; }
-        al[k] = rec<LaneVecD<NLP>>(rr, WR * 12 + 16);
-        rs[k] = MODE == 1 ? rec<double>(rr, WR * 12 + 16 + NLP * 8) : 1.0;
+        av[kk] = rec<LaneVecD<WR>>(rr, 0);
+        ix[kk] = rec<LaneVecI<WR>>(rr, WR * 8);
+        if (SHARED) bd[kk] = rec<LaneVecD<2>>(rr, WR * 12);
+        else { bd[kk].v[0] = r.rlo[k]; bd[kk].v[1] = r.rhi[k]; }
+        al[kk] = rec<LaneVecD<NLP>>(rr, WR * 12 + 16);
+        rs[kk] = MODE == 1 ? rec<double>(rr, WR * 12 + 16 + NLP * 8) : 1.0;
       }
 #pragma unroll
-      for (int k = 0; k < CH; ++k) {                                 // step 2: the gathers of xbar (and x+), the row's own y
+      for (int kk = 0; kk < IL; ++kk) {                               // step 2: the gathers of xbar (and x+), the row's own y
+        const int k = k0 + kk;
 #pragma unroll
         for (int e = 0; e < WR; ++e) {
-          gx[k][e] = slot(xwin, (uint32_t)ix[k].v[e], M9, l8);
-          if (MODE == 1) gxp[k][e] = slot(xpwin, (uint32_t)ix[k].v[e], M9, l8);
+          gx[kk][e] = slot(xwin, (uint32_t)ix[kk].v[e], M9, l8);
+          if (MODE == 1) gxp[kk][e] = slot(xpwin, (uint32_t)ix[kk].v[e], M9, l8);
         }
-        yv[k] = yr[(size_t)((q.rd0 + (k < q.nrd ? k : 0)) & M) * 64];
+        yv[kk] = yr[(size_t)((q.rd0 + (k < q.nrd ? k : 0)) & M) * 64];
       }
 #pragma unroll
-      for (int k = 0; k < CH; ++k) {                                 // step 3: the arithmetic
+      for (int kk = 0; kk < IL; ++kk) {                               // step 3: the arithmetic
+        const int k = k0 + kk;
         const bool live = k < q.nrd;
         const int i = q.rd0 + (live ? k : 0);
         double ax = 0.0, axp = 0.0;
 #pragma unroll
         for (int e = 0; e < WR; ++e) {
-          ax = fma(av[k].v[e], gx[k][e], ax);
-          if (MODE == 1) axp = fma(av[k].v[e], gxp[k][e], axp);
+          ax = fma(av[kk].v[e], gx[kk][e], ax);
+          if (MODE == 1) axp = fma(av[kk].v[e], gxp[kk][e], axp);
         }
 #pragma unroll
         for (int l = 0; l < NLP; ++l) {
-          ax = fma(al[k].v[l], xbl[l], ax);
-          if (MODE == 1) axp = fma(al[k].v[l], xpl[l], axp);
+          ax = fma(al[kk].v[l], xbl[l], ax);
+          if (MODE == 1) axp = fma(al[kk].v[l], xpl[l], axp);
         }
-        const double rlo = bd[k].v[0], rhi = bd[k].v[1];
-        const double y = yv[k];
+        const double rlo = bd[kk].v[0], rhi = bd[kk].v[1];
+        const double y = yv[kk];
         const double gyy = fma(-sc.sig, ax, y);
         double yp = gyy - lane_clamp(gyy, -sc.sig * rhi, -sc.sig * rlo);
         const double kp = QP ? r.kap[k] : 0.0;
@@ -308,13 +339,13 @@ struct LaneTile {
           lane_st(G.y_out, i, l8) = yn;
           const double yw = live ? yn : 0.0;
 #pragma unroll
-          for (int l = 0; l < NLP; ++l) out.lp[l] = fma(al[k].v[l], yw, out.lp[l]);
+          for (int l = 0; l < NLP; ++l) out.lp[l] = fma(al[kk].v[l], yw, out.lp[l]);
         } else {
           lane_st(G.yp, sc.done ? P.m : i, l8) = yp;                  // (a finished scenario keeps the x+, y+ it finished with)
           const double w = live ? 1.0 : 0.0;
           const double yw = live ? yp : 0.0;
 #pragma unroll
-          for (int l = 0; l < NLP; ++l) out.lp[l] = fma(al[k].v[l], yw, out.lp[l]);
+          for (int l = 0; l < NLP; ++l) out.lp[l] = fma(al[kk].v[l], yw, out.lp[l]);
           const double dy = yp - y;
           const double nsadx = -sc.sig * (ax - axp);                 // -sig A (x+ - x)   (xbar - x+ = x+ - x)
           out.v[1] = fma(w, dy * fma(2.0, nsadx, dy), out.v[1]);
@@ -329,7 +360,7 @@ struct LaneTile {
           }
           out.v[7] = fma(w, soft, out.v[7]);
           out.v[4] = fma(w, dobj, out.v[4]);
-          const double viol = viol_s / rs[k];
+          const double viol = viol_s / rs[kk];
           out.v[2] = fma(w, viol * viol, out.v[2]);
           out.v[3] = fma(w, fabs(yp) * viol_s, out.v[3]);
           const double d0 = yp - r.y0[k];
