@@ -862,7 +862,7 @@ def main():
                             traffic=None, kernel_ms=ms, algorithmic_bytes_per_launch=bsp, timing=how)
 
             result["spmv_step"] = time_spmv(dlp, lp, B, 200)
-            result["spmv_step"]["traffic"] = _profiled_traffic("spmv_stream_kernel") or _profiled_traffic("spmv_step_kernel")
+            result["spmv_step"]["traffic"] = _profiled_traffic("spmv_step_kernel")
             result["spmv_step"]["note"] = ("one A x + one A^T y for every scenario of the batch with vectors streamed "
                                            "from/to HBM, results through non-temporal stores (matrix staged in LDS per 8-wave "
                                            "block, one scenario per wave, everything in flight at once); a 20 MB launch "

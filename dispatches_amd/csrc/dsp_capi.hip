@@ -608,25 +608,9 @@ int dsp_spmv_step(dsp_handle *h, int32_t B, const double *X, const double *Y, do
   HIP_TRY(hipSetDevice(h->device));
   SpmvArgs a{};
   a.P = h->P; a.B = B; a.X = X; a.Y = Y; a.AX = AX; a.ATY = ATY;
-  // Two forms of the streaming step exist.  Default: the matrix is staged once per 8-wave block in LDS (shared by its
-  // waves).  DSP_SPMV_REG=1 selects the register-resident-matrix form (one scenario per wave, no block barrier, every
-  // load in flight at once), measured SLOWER at every batch size on MI355X (r02e: 7.1-7.6 vs 6.7 us at 4096 x 24 h,
-  // 14.8-16.0 vs 11.3 us at 4096 x 48 h): each wave pulls its own 16-28 matrix entries through the vector memory path,
-  // 7x the bytes of the vectors it streams.  DSP_SPMV_WAVES_PER_CU caps its resident waves, DSP_SPMV_WPB the block
-  // size of the default form.
-  static const bool use_reg = getenv("DSP_SPMV_REG") && atoi(getenv("DSP_SPMV_REG")) != 0;
-  static const int waves_cap = getenv("DSP_SPMV_WAVES_PER_CU") ? atoi(getenv("DSP_SPMV_WAVES_PER_CU")) : 32;
+  // The matrix is staged once per 8-wave block in LDS (shared by its waves).  (A register-resident-matrix form - one scenario per
+  // wave, no block barrier - was measured slower at every batch size in round 2 and is gone.)  DSP_SPMV_WPB: waves per block.
   static const int wpb_env = getenv("DSP_SPMV_WPB") ? atoi(getenv("DSP_SPMV_WPB")) : 0;
-  if (h->matreg && use_reg) {
-    a.waves_per_block = 4;
-    const size_t lds = ((size_t)h->P.mr_tailc_entries + h->P.mr_tailr_entries) * sizeof(Entry) +
-                       (size_t)a.waves_per_block * (h->P.n_pad + h->P.m_pad) * 8;
-    if (lds > (size_t)h->lds_limit) return DSP_ERR_TOO_LARGE;
-    const int per_cu = std::max<int>(1, std::min<int>((int)(h->lds_limit / lds), std::max(1, waves_cap / a.waves_per_block)));
-    const int grid = std::min((B + a.waves_per_block - 1) / a.waves_per_block, h->num_cus * per_cu);
-    HIP_TRY(launch_spmv_stream(h->cpl, h->rpl, a, dim3(grid), dim3(64 * a.waves_per_block), lds, (hipStream_t)hipStream));
-    return DSP_OK;
-  }
   // generic form (matrix staged in LDS per block): 8-wave blocks, as many as LDS admits per CU
   constexpr int kSpmvMaxWaves = 16;                 // spmv_step_kernel is compiled with __launch_bounds__(1024)
   a.waves_per_block = wpb_env > 0 ? std::min(wpb_env, kSpmvMaxWaves) : kMaxWavesPerBlock;
@@ -635,7 +619,9 @@ int dsp_spmv_step(dsp_handle *h, int32_t B, const double *X, const double *Y, do
   if (lds > (size_t)h->lds_limit) return DSP_ERR_TOO_LARGE;
   int blocks_per_cu = std::max<int>(1, std::min<int>((int)(h->lds_limit / lds), 32 / a.waves_per_block));
   int grid = std::min((B + a.waves_per_block - 1) / a.waves_per_block, h->num_cus * blocks_per_cu);
-  HIP_TRY(launch_spmv(h->cpl, h->rpl, a, dim3(grid), dim3(64 * a.waves_per_block), lds, (hipStream_t)hipStream));
+  const hipError_t se = launch_spmv(h->cpl, h->rpl, a, dim3(grid), dim3(64 * a.waves_per_block), lds, (hipStream_t)hipStream);
+  if (se == hipErrorInvalidValue) return DSP_ERR_INVALID;          // a measurement kernel: benchmark shapes only (dsp_kernels.hip)
+  HIP_TRY(se);
   return DSP_OK;
 }
 

@@ -1000,85 +1000,6 @@ __global__ void __launch_bounds__(1024) spmv_step_kernel(SpmvArgs a) {
   }
 }
 
-// ---- streaming SpMV step, register-resident matrix ---------------------------------------------------------
-// Same contract as spmv_step_kernel (AX = A X, ATY = A^T Y, vectors in HBM, 2*8*(n+m) algorithmic bytes per scenario)
-// for the LP shapes that have a register-resident specialisation.  A 20-40 MB launch is bound by ONE memory round
-// trip plus the launch ramp, so everything a wave needs is put in flight at once: one scenario per wave, no block-level
-// staging or barrier (the wave's 16-byte matrix entries come straight from L2 into VGPRs next to its x / y loads), the
-// exchange goes through the wave's own LDS slots, results are stored to the owned rows / columns of the scenario.
-// Waves beyond the first pass of the grid prefetch their next scenario before they compute the current one.
-template <int CPL, int RPL, bool LONG, unsigned WC, unsigned WR>
-__global__ void __launch_bounds__(256) spmv_stream_kernel(SpmvArgs a) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const DeviceProblem &P = a.P;
-  const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
-  const int n = P.n, m = P.m;
-  const int waves_total = gridDim.x * a.waves_per_block;
-  int s = blockIdx.x * a.waves_per_block + wave;
-  Entry *tailc = reinterpret_cast<Entry *>(smem);
-  Entry *tailr = tailc + P.mr_tailc_entries;
-  char *wave_buf = reinterpret_cast<char *>(tailr + P.mr_tailr_entries);
-  char *xb = wave_buf + (size_t)wave * (P.n_pad + P.m_pad) * 8;
-  char *yb = xb + (size_t)P.n_pad * 8;
-  using lds_cptr = const __attribute__((address_space(3))) char *;
-  const uint32_t xb_lds = (uint32_t)(uintptr_t)(lds_cptr)xb, yb_lds = (uint32_t)(uintptr_t)(lds_cptr)yb;
-  // first scenario's vectors (natural order: lane-consecutive, coalesced) in flight before anything else
-  double xr[CPL], yr[RPL];
-  if (s < a.B) {
-#pragma unroll
-    for (int q = 0; q < CPL; ++q) { const int j = lane + 64 * q; xr[q] = (j < n) ? a.X[(size_t)s * n + j] : 0.0; }
-#pragma unroll
-    for (int q = 0; q < RPL; ++q) { const int i = lane + 64 * q; yr[q] = (i < m) ? a.Y[(size_t)s * m + i] : 0.0; }
-  }
-  RegEll<CPL, WC> mreg_c;      // A^T, gathers y
-  RegEll<RPL, WR> mreg_r;      // A,   gathers x
-  mreg_c.load(P.mr_ellc_unscaled, lane, yb_lds, 1.0);
-  mreg_r.load(P.mr_ellr_unscaled, lane, xb_lds, 1.0);
-  // LDS slot of each NATURAL element this lane loads, and the column / row each owned slot produces
-  uint32_t xw[CPL], yw[RPL];
-  int colat[CPL], rowat[RPL];
-#pragma unroll
-  for (int q = 0; q < CPL; ++q) { xw[q] = xb_lds + (uint32_t)P.mr_nat_slot_x[lane + 64 * q]; colat[q] = P.mr_colat[lane + 64 * q]; }
-#pragma unroll
-  for (int q = 0; q < RPL; ++q) { yw[q] = yb_lds + (uint32_t)P.mr_nat_slot_y[lane + 64 * q]; rowat[q] = P.mr_rowat[lane + 64 * q]; }
-  if (LONG) {
-    stage_entries(tailc, P.mr_tailc_unscaled, P.mr_tailc_entries);
-    stage_entries(tailr, P.mr_tailr_unscaled, P.mr_tailr_entries);
-    __syncthreads();
-  }
-  // padding slots are never stored to but may be gathered (times a zero coefficient): they must not hold NaN bits
-  for (int t = lane; t < P.n_pad + P.m_pad; t += 64) reinterpret_cast<double *>(xb)[t] = 0.0;
-  wave_lds_fence();
-  const double zero_c[CPL] = {}, zero_r[RPL] = {};
-  for (; s < a.B; s += waves_total) {
-#pragma unroll
-    for (int q = 0; q < CPL; ++q) if (lane + 64 * q < n) lds_store_f64(xw[q], xr[q]);
-#pragma unroll
-    for (int q = 0; q < RPL; ++q) if (lane + 64 * q < m) lds_store_f64(yw[q], yr[q]);
-    wave_lds_fence();
-    const int sn = s + waves_total;
-    if (sn < a.B) {
-#pragma unroll
-      for (int q = 0; q < CPL; ++q) { const int j = lane + 64 * q; xr[q] = (j < n) ? a.X[(size_t)sn * n + j] : 0.0; }
-#pragma unroll
-      for (int q = 0; q < RPL; ++q) { const int i = lane + 64 * q; yr[q] = (i < m) ? a.Y[(size_t)sn * m + i] : 0.0; }
-    }
-    double axv[RPL], atyv[CPL];
-    mreg_r.product(axv, zero_r);
-    mreg_c.product(atyv, zero_c);
-    if (LONG) {
-      long_product<RPL>(axv, xb, lane, P.mr_long_r, tailr, 1.0);
-      long_product<CPL>(atyv, yb, lane, P.mr_long_c, tailc, 1.0);
-    }
-#pragma unroll
-    for (int q = 0; q < RPL; ++q) if (rowat[q] >= 0) a.AX[(size_t)s * m + rowat[q]] = axv[q];
-#pragma unroll
-    for (int q = 0; q < CPL; ++q) if (colat[q] >= 0) a.ATY[(size_t)s * n + colat[q]] = atyv[q];
-    wave_lds_fence();
-  }
-}
-
 #ifdef __HIPCC_RTC__      /* run-time compiled code objects carry the layout token they were compiled with (dsp_device.hpp) */
 }  // namespace dsp
 extern "C" __device__ __attribute__((used)) const unsigned long long dsp_rtc_layout_token = dsp::kSolveArgsToken;
@@ -1237,27 +1158,16 @@ hipError_t occupancy_solve(int cpl, int rpl, const SolveArgs &a0, int block_thre
   hipStream_t st = nullptr;
   DSP_FOR_CPL(occupancy_solve_t)
 }
+// The streaming SpMV step is a MEASUREMENT kernel (the HBM roofline of one A x + one A^T y with the vectors in HBM; no
+// solve calls it): instantiated for the shapes of the benchmark workloads only (scenarios.WORKLOADS: wind + battery 24 / 48 h, nuclear
+// 24 / 48 h, wind + PEM 48 h and its shared capacity column), hipErrorInvalidValue for any other LP.
 hipError_t launch_spmv(int cpl, int rpl, const SpmvArgs &a, dim3 grid, dim3 block, size_t lds, hipStream_t st) {
-  DSP_FOR_CPL(launch_spmv_t)
-}
-
-// register-resident-matrix form of the streaming step (same shapes as the solve kernel's specialisations)
-hipError_t launch_spmv_stream(int cpl, int rpl, const SpmvArgs &a, dim3 grid, dim3 block, size_t lds, hipStream_t st) {
-  const bool lng = a.P.mr_long_c.count > 0 || a.P.mr_long_r.count > 0;
-  const void *fn = nullptr;
-#ifndef DSP_NO_MATREG
-#define DSP_X(C, R, WC_, WR_, L)                                                                  \
-  if (cpl == C && rpl == R && a.P.mr_wc_pack == WC_ && a.P.mr_wr_pack == WR_ && lng == L)        \
-    fn = reinterpret_cast<const void *>(&spmv_stream_kernel<C, R, L, WC_, WR_>);
-  DSP_MATREG_SHAPES(DSP_X)
-#undef DSP_X
-#endif
-  if (!fn) return hipErrorInvalidValue;
-  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if (e != hipSuccess) return e;
-  SpmvArgs args = a;
-  void *params[] = {&args};
-  return hipLaunchKernel(fn, grid, block, params, lds, st);
+  if (cpl == 4 && rpl == 2) return launch_spmv_t<4, 2>(a, grid, block, lds, st);
+  if (cpl == 7 && rpl == 4) return launch_spmv_t<7, 4>(a, grid, block, lds, st);
+  if (cpl == 3 && rpl == 2) return launch_spmv_t<3, 2>(a, grid, block, lds, st);
+  if (cpl == 5 && rpl == 3) return launch_spmv_t<5, 3>(a, grid, block, lds, st);
+  if (cpl == 4 && rpl == 3) return launch_spmv_t<4, 3>(a, grid, block, lds, st);
+  return hipErrorInvalidValue;
 }
 
 #endif   // __HIPCC_RTC__

@@ -1443,27 +1443,25 @@ static hipError_t run_fused(StreamSolver *S, StreamArgs &a, hipStream_t st, int 
   const int K_own = (F.own_max + kTB - 1) / kTB;
   // (+ the thread-private slots of k_fused_pre's deferred form: y0, x0, and the row bounds when they differ per scenario)
   const size_t lds = ((size_t)SG * (F.ny_max + F.nxb_max) + (1 + kTB / 64) * kFusedMaxLong * SG + (size_t)K_own * SG * (shared ? 2 : 4) * kTB) * sizeof(double);
-  // k_fused_pre (all loads up front) where a thread can own its K <= 4 rows and columns and the halo columns fit one pass;
-  // k_fused (staged phases) otherwise.  DSP_FUSED_V=1 forces the staged form (development).
+  // k_fused_pre (every HBM load of the workgroup ahead of the first barrier, matrix entries requested after the barriers) where a
+  // thread owns ONE row and ONE column of the tile (250-row tiles: always) and the halo columns fit one pass; k_fused (staged
+  // phases) otherwise.  DSP_FUSED_V=1 forces the staged form (development).  Since round 4 this form serves batches below 32
+  // scenarios only (larger ones run the lane form, dsp_stream_lane.hip): the instantiations of round 3 for 2 - 3 rows per thread,
+  // 4 scenarios per workgroup and loads-up-front are gone (144 -> 16 + 8).
   const void *fn = nullptr;
   const int v_env = getenv("DSP_FUSED_V") ? atoi(getenv("DSP_FUSED_V")) : 0;      // (read per solve: tests switch forms)
   const int K = (F.own_max + kTB - 1) / kTB;
   const int mw = std::max(P.C.W, P.R.W);
-  const bool pre = v_env != 1 && K >= 1 && K <= 3 && mw <= 8 && F.halo_max <= kTB;
   // the deferred form addresses with 32-bit byte offsets: every array it touches must stay below 4 GiB
   const bool narrow_ok = (uint64_t)std::max(B, mw) * (uint64_t)std::max(P.n, P.m) * 8ull < (1ull << 32);
-  const int defer_env = (getenv("DSP_FUSED_DEFER") ? atoi(getenv("DSP_FUSED_DEFER")) : 1) && narrow_ok;   // default: deferred form (0: all loads up front)
-#define DSP_PICK3(KK, MM, DD)                                                                                                        \
-  (shared ? (qp ? reinterpret_cast<const void *>(&k_fused_pre<SG, KK, MM, true, true, DD>) : reinterpret_cast<const void *>(&k_fused_pre<SG, KK, MM, true, false, DD>)) \
-          : (qp ? reinterpret_cast<const void *>(&k_fused_pre<SG, KK, MM, false, true, DD>) : reinterpret_cast<const void *>(&k_fused_pre<SG, KK, MM, false, false, DD>)))
-#define DSP_PICK2(KK, MM) (defer_env ? DSP_PICK3(KK, MM, 1) : DSP_PICK3(KK, MM, 0))
-#define DSP_PICK(KK) (mw <= 4 ? DSP_PICK2(KK, 4) : DSP_PICK2(KK, 8))
-  if (pre) fn = K == 1 ? DSP_PICK(1) : K == 2 ? DSP_PICK(2) : DSP_PICK(3);
+  const bool pre = v_env != 1 && K == 1 && mw <= 8 && F.halo_max <= kTB && narrow_ok;
+#define DSP_PICK(MM)                                                                                                                 \
+  (shared ? (qp ? reinterpret_cast<const void *>(&k_fused_pre<SG, 1, MM, true, true, 1>) : reinterpret_cast<const void *>(&k_fused_pre<SG, 1, MM, true, false, 1>)) \
+          : (qp ? reinterpret_cast<const void *>(&k_fused_pre<SG, 1, MM, false, true, 1>) : reinterpret_cast<const void *>(&k_fused_pre<SG, 1, MM, false, false, 1>)))
+  if (pre) fn = mw <= 4 ? DSP_PICK(4) : DSP_PICK(8);
   else fn = shared ? (qp ? reinterpret_cast<const void *>(&k_fused<SG, true, true>) : reinterpret_cast<const void *>(&k_fused<SG, true, false>))
                    : (qp ? reinterpret_cast<const void *>(&k_fused<SG, false, true>) : reinterpret_cast<const void *>(&k_fused<SG, false, false>));
 #undef DSP_PICK
-#undef DSP_PICK2
-#undef DSP_PICK3
   hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
   const int xcd_env = getenv("DSP_FUSED_XCD") ? atoi(getenv("DSP_FUSED_XCD")) : 1;   // default on (DSP_FUSED_XCD=0: grid order)
@@ -1577,7 +1575,7 @@ static hipError_t stream_solve_locked(StreamSolver *S, const dsp_batch &batch, c
     int fsg = 2;                       // scenarios per workgroup (matrix entries are loaded once per workgroup): 2 measured best with
     if ((long)S->P.F.ntile * ((B + 1) / 2) < 1024) fsg = 1;      // 250-row tiles (81 vs 89-91 us at 4, 102 at 1: profiles/r30j_fused_scan.log)
     static const int fsg_env = getenv("DSP_FUSED_SG") ? atoi(getenv("DSP_FUSED_SG")) : 0;
-    if (fsg_env == 1 || fsg_env == 2 || fsg_env == 4) fsg = fsg_env;
+    if (fsg_env == 1 || fsg_env == 2) fsg = fsg_env;
     // the workgroup's LDS (staged y + xbar per scenario, the deferred form's thread-private slots) must fit a CU's 160 KB: plans
     // with wide hulls (the host admits up to 40 KB per scenario) run with fewer scenarios per workgroup
     {
@@ -1590,8 +1588,7 @@ static hipError_t stream_solve_locked(StreamSolver *S, const dsp_batch &batch, c
     }
     S->last_bytes_per_iteration = (size_t)8 * (shared ? 4 * (size_t)S->P.n + 3 * (size_t)S->P.m : 6 * (size_t)S->P.n + 5 * (size_t)S->P.m)
                                   + (qp ? 8 * (size_t)S->P.m : 0);
-    if (fsg == 4) e = run_fused<4>(S, a, st, periods_run, shared, qp);
-    else if (fsg == 2) e = run_fused<2>(S, a, st, periods_run, shared, qp);
+    if (fsg == 2) e = run_fused<2>(S, a, st, periods_run, shared, qp);
     else e = run_fused<1>(S, a, st, periods_run, shared, qp);
   } else
   if (sg == 8) e = run<8>(S, a, st, periods_run);

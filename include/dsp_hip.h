@@ -256,7 +256,9 @@ int dsp_solve(dsp_handle *h, const dsp_batch *batch, const dsp_options *opt, dsp
 
 /* The PDLP SpMV step in streaming form (vectors in HBM): AX[B][m] = A X[b],  ATY[B][n] = A^T Y[b] with the
  * UNSCALED A.  This is the kernel the HBM roofline of SURVEY.md 8(d) is quoted on
- * (bytes = B*2*8*(n+m) + shared CSR), and the building block for LPs too large for the LDS-resident solve. */
+ * (bytes = B*2*8*(n+m) + shared CSR).  A MEASUREMENT entry point - no solve calls it - compiled for the LP shapes of the benchmark
+ * workloads (wind + battery 24 / 48 h, nuclear 24 / 48 h, wind + PEM 48 h); DSP_ERR_INVALID for any other LP, DSP_ERR_TOO_LARGE for
+ * an LP of the streaming path (whose iteration kernels are its own: csrc/dsp_stream*.hip). */
 int dsp_spmv_step(dsp_handle *h, int32_t B, const double *X, const double *Y, double *AX, double *ATY,
                   void *hipStream);
 
