@@ -30,7 +30,10 @@ namespace dsp {
 
 namespace {
 
-constexpr int kLaneWaves = 4;           // waves (= tiles) per workgroup
+#ifndef DSP_LANE_WAVES_PER_WG
+#define DSP_LANE_WAVES_PER_WG 4
+#endif
+constexpr int kLaneWaves = DSP_LANE_WAVES_PER_WG;   // waves (= tiles) per workgroup
 // rows / columns per unit of a tile's walk: DSP_LANE_CH where a unit's records still fit one 16-byte-per-lane load, else 4
 #ifndef DSP_LANE_CH
 #define DSP_LANE_CH 4

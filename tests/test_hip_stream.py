@@ -91,6 +91,61 @@ def test_one_launch_forms_reproduce_the_two_launch_form(monkeypatch):
 
 
 @gpu
+def test_lane_form_with_per_scenario_bounds_and_with_soft_rows(monkeypatch):
+    """The two instantiation families of the lane form the price-taker families do not reach on their own: (a) bounds that differ
+    per scenario on SHORT columns (a grid-connection limit per member: every bound is then read per lane, 6 n + 5 m doubles per
+    scenario-iteration; the family's own batches share theirs) and (b) soft rows (convex QP: a compliance on every 5th balance
+    row) - each against the two-launch form of the same solve: same termination, same objectives, the lane form forced onto the
+    small batch with DSP_LANE_MIN_B."""
+    from dispatches_amd import scenarios
+    from dispatches_amd.hip_solver import HipPdlpSolver
+    T, B = 336, 6
+    keys = ("DSP_STREAM_NO_LANE", "DSP_STREAM_NO_FUSED", "DSP_LANE_MIN_B")
+
+    def solve(form, mutate):
+        for k in keys:
+            monkeypatch.delenv(k, raising=False)
+        for k, v in ({"DSP_LANE_MIN_B": "1"} if form == "lane" else {"DSP_STREAM_NO_LANE": "1", "DSP_STREAM_NO_FUSED": "1"}).items():
+            monkeypatch.setenv(k, v)
+        solver = HipPdlpSolver(device=0, check_every=64, max_iter=400_000)
+        handles, model = scenarios.price_taker_batch(T, B, solver)
+        mutate(model)
+        solver.solve(model, tee=True)
+        st = solver.last_stats
+        assert st.streaming == 1 and (model.status == 0).all(), (form, model.status, model.iterations)
+        return model.objective.copy(), model.iterations.copy(), int(st.stream_bytes_per_iteration), int(st.stream_form), int(st.quadratic), model
+
+    def grid_limits(model):
+        lb, ub, _, _ = model.block.current_bounds()
+        model.lb, model.ub = np.tile(lb, (B, 1)), np.tile(ub, (B, 1))
+        cols = [j for j, name in enumerate(model.lp.col_names) if name.startswith("splitter.grid_elec[")]
+        for k in range(B):
+            model.ub[k, cols] = 847.0e3 * (0.55 + 0.08 * k)             # kW: binding for the smaller ones
+
+    def soft_rows(model):
+        lp = model.lp
+        kappa = np.zeros(lp.m)
+        eq = np.flatnonzero((lp.rlo == lp.rhi) & np.isfinite(lp.rlo))
+        kappa[eq[::5]] = 1e-4
+        lp.row_compliance = kappa
+
+    try:
+        for what, mutate, per_iter, qp in (("bounds", grid_limits, lambda n, m: 8 * (6 * n + 5 * m), 0), ("soft rows", soft_rows, lambda n, m: 8 * (4 * n + 3 * m) + 8 * m, 1)):
+            lane = solve("lane", mutate)
+            two = solve("two_launch", mutate)
+            n, m = lane[5].lp.n, lane[5].lp.m
+            assert lane[3] == 3 and two[3] == 1, (what, lane[3], two[3])          # DSP_STREAM_FORM_LANE / _TWO_LAUNCH
+            assert lane[2] == per_iter(n, m) and lane[4] == qp == two[4], (what, lane[2], lane[4])
+            assert np.allclose(lane[0], two[0], rtol=1e-6, atol=1e-6), (what, lane[0], two[0])
+            assert (np.abs(lane[1] - two[1]) <= 0.05 * two[1] + 128).all(), (what, lane[1], two[1])
+            if what == "bounds":
+                assert len(set(np.round(lane[0], 6))) == B               # the limits bind differently: six different optima
+    finally:
+        for k in keys:
+            monkeypatch.delenv(k, raising=False)
+
+
+@gpu
 @pytest.mark.parametrize("throughput,B", [("chain", 8), ("two_level", 16), ("two_level", 64)])
 def test_year_long_price_taker_lps_converge(throughput, B):
     """The reference's own horizon (wind_battery_LMP.py: 8736 hourly periods, n = m = 52 419) for the first 8 members of the family
