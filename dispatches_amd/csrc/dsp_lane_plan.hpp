@@ -74,6 +74,7 @@ inline HostLanePlan build_lane_plan(const HostCSR &A, const HostCSR &AT, int spa
   }
   if (wc > 8 || wr > 8) return P;                       // a long ROW (or a dense short part): not this form
   P.WC = wc <= 4 ? 4 : 8; P.WR = wr <= 4 ? 4 : 8;
+  if (P.WC == 8) P.WR = 8;                              // the kernels exist for (4, 4), (4, 8), (8, 8): wide columns take the wide row record too
   P.cval.assign((size_t)n * P.WC, 0.0); P.cidx.assign((size_t)n * P.WC, 0);
   P.rval.assign((size_t)m * P.WR, 0.0); P.ridx.assign((size_t)m * P.WR, 0);
   P.ral.assign((size_t)m * P.NLP, 0.0);

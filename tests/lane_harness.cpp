@@ -148,16 +148,16 @@ static int run_all(Problem &Q) {
   }
   // ---- compare ----------------------------------------------------------------------------------------------------------------------------
   double ex = 0, ey = 0, exp_ = 0, eyp = 0, elp = 0, ev = 0;
-  int missing = 0;
+  int missing = 0, first_missing_col = -1, first_missing_row = -1;
   for (int s = 0; s < S; ++s) {
     for (int j = 0; j < n; ++j) {
       const size_t at = (size_t)j * 64 + s;
-      if (std::isnan(x_out[at]) || std::isnan(xp_out[at])) { missing++; continue; }
+      if (std::isnan(x_out[at]) || std::isnan(xp_out[at])) { missing++; if (first_missing_col < 0) first_missing_col = j; continue; }
       ex = std::fmax(ex, std::fabs(x_out[at] - xn_ref[at])); exp_ = std::fmax(exp_, std::fabs(xp_out[at] - xp_ref[at]));
     }
     for (int i = 0; i < m; ++i) {
       const size_t at = (size_t)i * 64 + s;
-      if (std::isnan(y_out[at]) || std::isnan(yp_out[at])) { missing++; continue; }
+      if (std::isnan(y_out[at]) || std::isnan(yp_out[at])) { missing++; if (first_missing_row < 0) first_missing_row = i; continue; }
       ey = std::fmax(ey, std::fabs(y_out[at] - yn_ref[at])); eyp = std::fmax(eyp, std::fabs(yp_out[at] - yp_ref[at]));
     }
     for (int l = 0; l < nl; ++l) {
@@ -175,8 +175,8 @@ static int run_all(Problem &Q) {
   // lanes that are not in use and the sink rows aside, nothing else was touched: count the finite entries per array
   printf("{\"ok\": true, \"ntile\": %d, \"nunit\": %d, \"max_units\": %d, \"ring\": %d, \"wc\": %d, \"wr\": %d, \"nlp\": %d, \"long_cols\": %d, "
          "\"halo\": %.4f, \"err_x\": %.3e, \"err_y\": %.3e, \"err_xp\": %.3e, \"err_yp\": %.3e, \"err_lp\": %.3e, \"err_sums\": %.3e, "
-         "\"missing\": %d, \"nan_partials\": %d}\n",
-         T.ntile, T.nunit, T.max_units, T.ring, WC, WR, NLP, nl, T.halo_rows, ex, ey, exp_, eyp, elp, ev, missing, bad_ring);
+         "\"missing\": %d, \"first_missing_col\": %d, \"first_missing_row\": %d, \"nan_partials\": %d}\n",
+         T.ntile, T.nunit, T.max_units, T.ring, WC, WR, NLP, nl, T.halo_rows, ex, ey, exp_, eyp, elp, ev, missing, first_missing_col, first_missing_row, bad_ring);
   return 0;
 }
 

@@ -229,6 +229,52 @@ def test_lane_form_of_the_streaming_iteration(lane_harness, tmp_path, family, T,
     assert res["nunit"] <= 2.5 * -(-lp.m // 4)                     # the walks keep their units reasonably full (12-row tiles, ring of 8: 2.3 x)
 
 
+@pytest.mark.parametrize("seed", range(12))
+def test_lane_form_on_random_banded_matrices(lane_harness, tmp_path, seed):
+    """Property test of plan + walk: random banded matrices - n != m, 1 .. 4 (or .. 7) short entries per row inside a band around
+    the diagonal, empty rows and empty columns, 0 .. 6 long columns of random density, tiles of 8 .. 96 rows - through the harness:
+    whenever the planner accepts the matrix, one iteration / check / reduced-cost pass of the per-lane routine reproduces the plain
+    formulas on the CSR and writes every row and column; a matrix it cannot schedule is refused, never mis-computed."""
+    rng = np.random.default_rng(1000 + seed)
+    m = int(rng.integers(120, 420))
+    n = int(m * rng.uniform(0.7, 1.5))
+    band = int(rng.integers(2, 10))
+    wmax = 7 if seed % 4 == 3 else 4
+    rows, cols, vals = [], [], []
+    for i in range(m):
+        if rng.uniform() < 0.05:
+            continue                                            # an empty row
+        centre = i * n / m
+        k = int(rng.integers(1, wmax + 1))
+        cand = np.unique(np.clip(np.round(centre + rng.integers(-band, band + 1, size=k)), 0, n - 1).astype(int))
+        for j in cand:
+            rows.append(i); cols.append(int(j)); vals.append(float(rng.uniform(0.2, 2.0) * rng.choice([-1.0, 1.0])))
+    A = sp.csr_matrix((vals, (rows, cols)), shape=(m, n)).tolil()
+    dead = rng.choice(n, size=max(1, n // 25), replace=False)     # a few empty columns
+    A[:, dead] = 0.0
+    nlong = int(rng.integers(0, 7))
+    for j in rng.choice(np.setdiff1d(np.arange(n), dead), size=nlong, replace=False):
+        hit = rng.uniform(size=m) < rng.uniform(0.3, 1.0)
+        hit[:12] = True                                           # more than 8 entries: a long column whatever the draw
+        A[np.flatnonzero(hit), j] = rng.uniform(0.1, 1.0, size=int(hit.sum()))
+    A = sp.csr_matrix(A)
+    A.eliminate_zeros()
+    A.sort_indices()
+    # columns other than the planted ones may have collected more than 8 entries (dense bands): they become long columns too
+    path = str(tmp_path / "a.bin")
+    _write_csr(A, path)
+    rows_per_tile = int(rng.choice([8, 12, 20, 40, 96]))
+    res = json.loads(subprocess.run([lane_harness, path, str(rows_per_tile)], check=True, capture_output=True, text=True).stdout)
+    if not res["ok"]:
+        assert res["why"] in ("plan", "tiles")
+        collen = np.diff(sp.csc_matrix(A).indptr)
+        assert res["why"] == "tiles" or (collen > 8).sum() > 8 or wmax > 4, (res, int((collen > 8).sum()))
+        return
+    assert res["missing"] == 0 and res["nan_partials"] == 0, res
+    assert max(res["err_x"], res["err_y"], res["err_xp"], res["err_yp"]) < 1e-11 and res["err_sums"] < 1e-11, res
+    assert res["err_lp"] < 1e-9, res
+
+
 def test_lane_plan_refuses_matrices_that_are_not_banded(lane_harness, tmp_path):
     """The parallel-prefix form of the accumulator reaches across the whole horizon: no walk fits the ring budget, the handle keeps
     the two-launch form."""
