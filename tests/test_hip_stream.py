@@ -146,6 +146,55 @@ def test_lane_form_with_per_scenario_bounds_and_with_soft_rows(monkeypatch):
 
 
 @gpu
+def test_lane_form_wide_records_and_eight_long_columns(monkeypatch):
+    """The wide instantiations of the lane form on the device.  (a) WC = WR = 8: the two-week design LP with every row written
+    TWICE (rows 2 i and 2 i + 1: the same feasible set and optimum; every column then has up to 8 short entries) through the plain
+    C-ABI wrapper, against the original LP's solve.  (b) NLP = 8: the wind + battery + PEM design LP with the throughput accumulator
+    on 3 nodes (6 long columns: nodes, battery power, PEM size, the periodic state of charge) against its chain form."""
+    import dataclasses
+    import torch
+    from dispatches_amd import scenarios
+    from dispatches_amd.hip_solver import DeviceLP, HipPdlpSolver, default_options
+    monkeypatch.setenv("DSP_LANE_MIN_B", "1")
+    try:
+        # ---- (a) ---------------------------------------------------------------------------------------------------------------
+        T, B = 336, 6
+        solver = HipPdlpSolver(device=0, check_every=64, max_iter=400_000)
+        handles, model = scenarios.price_taker_batch(T, B, solver)
+        solver.solve(model)
+        assert (model.status == 0).all() and solver.last_stats.stream_form == 3
+        lp = model.lp
+        A = lp.csr()
+        rep = np.repeat(np.arange(lp.m), 2)
+        A2 = A[rep].tocsr()
+        A2.sort_indices()
+        lp2 = dataclasses.replace(lp, m=2 * lp.m, indptr=A2.indptr.astype(np.int32), indices=A2.indices.astype(np.int32), data=A2.data.astype(np.float64),
+                                  rlo=lp.rlo[rep], rhi=lp.rhi[rep], row_names=[lp.row_names[i] for i in rep] if lp.row_names else [])
+        dev = torch.device("cuda", 0)
+        up = lambda a: torch.as_tensor(np.ascontiguousarray(a, np.float64)).to(dev)
+        lb, ub, _, _ = model.scenario_bounds()
+        dlp = DeviceLP(lp2, 0, default_options(check_every=64, max_iter=400_000))
+        out = dlp.solve(B, up(model.c), up(lb), up(ub), up(lp2.rlo), up(lp2.rhi), obj_offset=up(model.c0))
+        st = dlp.last_stats
+        assert st.streaming == 1 and st.stream_form == 3 and st.n_optimal == B, (st.stream_form, st.n_optimal)
+        obj2 = out["obj"].cpu().numpy() + model.c0
+        assert np.allclose(obj2, model.objective, rtol=1e-6, atol=1e-6), (obj2, model.objective)
+        dlp.close()
+        # ---- (b) ---------------------------------------------------------------------------------------------------------------
+        T, B = 1000, 4
+        res = {}
+        for thr, nodes in (("chain", 1), ("two_level", 3)):
+            solver = HipPdlpSolver(device=0, check_every=64, max_iter=1_000_000)
+            handles, m2 = scenarios.pem_price_taker_batch(T, B, solver, inputs="rts303", throughput=thr, coarse_nodes=nodes)
+            solver.solve(m2, tee=True)
+            assert (m2.status == 0).all() and solver.last_stats.stream_form == 3, (thr, m2.status, solver.last_stats.stream_form)
+            res[thr] = m2.objective.copy()
+        assert np.allclose(res["chain"], res["two_level"], rtol=1e-6, atol=1e-6), res
+    finally:
+        monkeypatch.delenv("DSP_LANE_MIN_B", raising=False)
+
+
+@gpu
 @pytest.mark.parametrize("throughput,B", [("chain", 8), ("two_level", 16), ("two_level", 64)])
 def test_year_long_price_taker_lps_converge(throughput, B):
     """The reference's own horizon (wind_battery_LMP.py: 8736 hourly periods, n = m = 52 419) for the first 8 members of the family
