@@ -220,8 +220,9 @@ typedef struct dsp_stats {
                                      scenarios it solved)                                           */
   int32_t streaming;              /* 1 = LP beyond the register/LDS-resident kernels (n > 640 or m > 384): the HBM-resident
                                      PDLP ran (state streamed from HBM every iteration: dsp_stream.hip)    */
-  int64_t stream_bytes_per_iteration;  /* streaming path: algorithmic HBM bytes per scenario and plain iteration
-                                          (8 n + 6 m doubles)                                          */
+  int64_t stream_bytes_per_iteration;  /* streaming path: algorithmic HBM bytes per scenario and plain iteration OF THE FORM THAT RAN
+                                          (stream_form): 8 (4 n + 3 m) one-launch forms with shared bounds, 8 (6 n + 5 m) with
+                                          per-scenario bounds, 8 (8 n + 6 m) two-launch form (+ 8 m with soft rows)             */
   int32_t quadratic;              /* 1 = soft rows present (QP variant of the kernel ran)                */
   int32_t precision;              /* precision the iterates were held in (dsp_options::precision)        */
   int32_t rtc;                    /* 1 = the kernel that ran was compiled at run time for this LP's shape (dsp_options::no_rtc) */
