@@ -113,19 +113,21 @@ inline HostLanePlan build_lane_plan(const HostCSR &A, const HostCSR &AT, int spa
   return P;
 }
 
-// The records as the kernels read them (dsp_lane_tile.hpp: layout, lane_crec / lane_rrec), bounds infinite and scale factors 1
-// until someone writes them (device: k_lane_fill_records per solve; tests: set_lane_record_bounds), 1 KiB of slack behind each
+// The records as the kernels read them (dsp_lane_tile.hpp: layout, lane_crec / lane_rrec) for a ring of `ring` slots - an index is
+// stored as the byte offset of its ring slot, (index & (ring - 1)) << 9: one add per gather on the device -, bounds infinite and
+// scale factors 1 until someone writes them (device: k_lane_fill_records per solve; tests: set_lane_record_bounds), 1 KiB of slack behind each
 // array (a unit's records are fetched as one 16-byte-per-lane block that may run past the last record).
-inline void pack_lane_records(const HostLanePlan &P, std::vector<char> &crec, std::vector<char> &rrec) {
+inline void pack_lane_records(const HostLanePlan &P, int ring, std::vector<char> &crec, std::vector<char> &rrec) {
+  const uint32_t M = (uint32_t)ring - 1u;
   const int CREC = P.WC * 12 + 32, RREC = P.WR * 12 + 32 + P.NLP * 8;
   crec.assign((size_t)P.n * CREC + 1024, 0); rrec.assign((size_t)P.m * RREC + 1024, 0);
   const double inf = INFINITY, one = 1.0;
   for (int j = 0; j < P.n; ++j) {
     char *r = &crec[(size_t)j * CREC];
     std::memcpy(r, &P.cval[(size_t)j * P.WC], (size_t)P.WC * 8);
-    for (int e = 0; e < P.WC; ++e) {                       // index << 9, long flag (bit 30 of the plan's index) -> sign bit
+    for (int e = 0; e < P.WC; ++e) {                       // ring slot << 9, long flag (bit 30 of the plan's index) -> sign bit
       const int32_t v = P.cidx[(size_t)j * P.WC + e];
-      const uint32_t enc = ((uint32_t)(v & 0x3fffffff) << 9) | ((v >> 30) & 1 ? 0x80000000u : 0u);
+      const uint32_t enc = (((uint32_t)(v & 0x3fffffff) & M) << 9) | ((v >> 30) & 1 ? 0x80000000u : 0u);
       std::memcpy(r + P.WC * 8 + e * 4, &enc, 4);
     }
     const double lo = -inf;
@@ -134,7 +136,7 @@ inline void pack_lane_records(const HostLanePlan &P, std::vector<char> &crec, st
   for (int i = 0; i < P.m; ++i) {
     char *r = &rrec[(size_t)i * RREC];
     std::memcpy(r, &P.rval[(size_t)i * P.WR], (size_t)P.WR * 8);
-    for (int e = 0; e < P.WR; ++e) { const uint32_t enc = (uint32_t)P.ridx[(size_t)i * P.WR + e] << 9; std::memcpy(r + P.WR * 8 + e * 4, &enc, 4); }
+    for (int e = 0; e < P.WR; ++e) { const uint32_t enc = ((uint32_t)P.ridx[(size_t)i * P.WR + e] & M) << 9; std::memcpy(r + P.WR * 8 + e * 4, &enc, 4); }
     const double lo = -inf;
     std::memcpy(r + P.WR * 12, &lo, 8); std::memcpy(r + P.WR * 12 + 8, &inf, 8);
     std::memcpy(r + P.WR * 12 + 16, &P.ral[(size_t)i * P.NLP], (size_t)P.NLP * 8);

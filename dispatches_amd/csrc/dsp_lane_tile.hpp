@@ -40,6 +40,16 @@
 
 namespace dsp {
 
+// DSP_LANE_PROBE (measurement build only; tools/gpu_lane_probe.sh): every wave of the plain-iteration kernel leaves time stamps of
+// its walk - start, per unit (before its loads are requested, after its arithmetic), before and after the workgroup's barrier - in a
+// device array the host writes to $DSP_LANE_PROBE_OUT after the solve.  1: stamps only; 2: + a full wait after each unit's loads
+// (splits a unit into "waiting for memory" and "arithmetic + LDS").
+#if defined(DSP_LANE_PROBE) && defined(__HIPCC__)
+constexpr int kProbeWaves = 16384, kProbeSlots = 128;     // per wave: [0] wall clock at start, [1] clock at start, [2] units, [3] hw id,
+                                                          // [4] end of walk, [5] after barrier, [6] end, [7] wall clock at end, [8 + 3 u ..] per unit
+__device__ unsigned long long g_lane_probe[(size_t)kProbeWaves * kProbeSlots];
+#endif
+
 template <int N> struct LaneVecD { double v[N]; };
 template <int N> struct LaneVecI { int32_t v[N]; };
 #if defined(__HIPCC__)
@@ -152,42 +162,50 @@ struct LaneTile {
 
   // every global load of a unit, unconditionally, to clamped addresses (no data-dependent control flow between the loads)
   static DSP_LANE_HD void load_regs(const LaneProblem &P, const LaneGroup &G, const Unit &q, int lane, bool active, Regs &r) {
-    const uint32_t l8 = (uint32_t)lane * 8u;
 #if defined(__HIP_DEVICE_COMPILE__)
     r.cq = *reinterpret_cast<const LaneQuad *>(P.crec + ((uint32_t)q.cx0 * (uint32_t)CREC + (uint32_t)lane * 16u));
     if (MODE != 2) r.rq = *reinterpret_cast<const LaneQuad *>(P.rrec + ((uint32_t)q.rd0 * (uint32_t)RREC + (uint32_t)lane * 16u));
+    // An idle lane's loads all go to element 0 of lane 0 - ONE line per instruction next to the active lanes' - instead of sitting
+    // behind a branch on EXEC: with the branch the number of loads in flight depends on the path, and the compiler's wait before the
+    // first use of this unit's registers becomes a wait for every load issued so far (vmcnt(1) on the merge; r40u), i.e. also for
+    // the rows of the NEXT unit that were requested to overlap with this one's arithmetic.
+    const uint32_t am = active ? 0xffffffffu : 0u, l8 = active ? (uint32_t)lane * 8u : 0u;
 #else
     (void)P;
-#endif
     if (!active) return;
+    const uint32_t am = 0xffffffffu, l8 = (uint32_t)lane * 8u;
+#endif
+    auto ld = [&](const double *base, int e) -> double {
+      return *reinterpret_cast<const double *>(reinterpret_cast<const char *>(base) + ((((uint32_t)e * 512u) & am) | l8));
+    };
 #pragma unroll
-    for (int k = 0; k < CH; ++k) r.ys[k] = lane_ld(MODE == 2 ? G.yp : G.y_in, q.ys0 + (k < q.nys ? k : 0), l8);
+    for (int k = 0; k < CH; ++k) r.ys[k] = ld(MODE == 2 ? G.yp : G.y_in, q.ys0 + (k < q.nys ? k : 0));
 #pragma unroll
     for (int k = 0; k < CH; ++k) {
       const int j = q.cx0 + (k < q.ncx ? k : 0);
-      r.c[k] = lane_ld(G.c, j, l8);
-      if (MODE == 2) r.xp[k] = lane_ld(G.xp, j, l8);
-      else { r.x[k] = lane_ld(G.x_in, j, l8); r.x0[k] = lane_ld(G.x0, j, l8); }
-      if (!SHARED) { r.lb[k] = lane_ld(G.lb, j, l8); r.ub[k] = lane_ld(G.ub, j, l8); }
+      r.c[k] = ld(G.c, j);
+      if (MODE == 2) r.xp[k] = ld(G.xp, j);
+      else { r.x[k] = ld(G.x_in, j); r.x0[k] = ld(G.x0, j); }
+      if (!SHARED) { r.lb[k] = ld(G.lb, j); r.ub[k] = ld(G.ub, j); }
     }
     if (MODE != 2) {
 #pragma unroll
       for (int k = 0; k < CH; ++k) {
         const int i = q.rd0 + (k < q.nrd ? k : 0);
-        r.y0[k] = lane_ld(G.y0, i, l8);
-        if (!SHARED) { r.rlo[k] = lane_ld(G.rlo, i, l8); r.rhi[k] = lane_ld(G.rhi, i, l8); }
-        if (QP) r.kap[k] = lane_ld(G.kap, i, l8);
+        r.y0[k] = ld(G.y0, i);
+        if (!SHARED) { r.rlo[k] = ld(G.rlo, i); r.rhi[k] = ld(G.rhi, i); }
+        if (QP) r.kap[k] = ld(G.kap, i);
       }
     }
   }
 
   template <class T>
   static DSP_LANE_HD T rec(const char *base, int off) { return *reinterpret_cast<const T *>(base + off); }
-  // ring slot of a record index (stored as index << 9 = byte offset of its slot in an unbounded window; bit 31 of a column's first
-  // index flags a long column): (idx9 & mask9) | (lane * 8) - one v_and_or_b32 per gather
-  static DSP_LANE_HD const double &slot(const char *win, uint32_t idx9, uint32_t mask9, uint32_t l8) {
-    return *reinterpret_cast<const double *>(win + ((idx9 & mask9) | l8));
-  }
+  // ring slot of a record index: the records hold (index & ring mask) << 9 = the byte offset of the slot (dsp_lane_plan.hpp:
+  // pack_lane_records; the ring is the tiling's, the records are packed for it) - one add per gather; bit 31 of a column's first
+  // index flags a long column
+  // (`winl` = the window's base + 8 * lane)
+  static DSP_LANE_HD const double &slot(const char *winl, uint32_t off9) { return *reinterpret_cast<const double *>(winl + off9); }
 
   // ring layout: [0, R) y window, [R, 2R) xbar window, [2R, 3R) x+ window (MODE 1); `stage`: the wave's record stage (device).
   // Each phase (stage, primal, dual) is BRANCH-FREE over its CH slots - a slot beyond the unit's count repeats the unit's first
@@ -201,10 +219,9 @@ struct LaneTile {
                                   int j0, int j1, int lane, double *ring, char *stage, const double (&xbl)[NLP], const double (&xpl)[NLP],
                                   LaneOut<NLP> &out) {
     const int M = P.ring_mask, R = M + 1;
-    const uint32_t l8 = (uint32_t)lane * 8u, M9 = (uint32_t)M << 9;
+    const uint32_t l8 = (uint32_t)lane * 8u;
     double *yr = ring + lane, *xr = ring + (size_t)R * 64 + lane, *xpr = ring + (size_t)2 * R * 64 + lane;
-    const char *ywin = reinterpret_cast<const char *>(ring), *xwin = reinterpret_cast<const char *>(ring + (size_t)R * 64),
-               *xpwin = reinterpret_cast<const char *>(ring + (size_t)2 * R * 64);
+    const char *ywin = reinterpret_cast<const char *>(yr), *xwin = reinterpret_cast<const char *>(xr), *xpwin = reinterpret_cast<const char *>(xpr);
 #if defined(__HIP_DEVICE_COMPILE__)
     // park the unit's records: lane L's 16 bytes at byte 16 L of each half of the stage; the LDS serves one wave's accesses in order
     *reinterpret_cast<LaneQuad *>(stage + lane * 16) = r.cq;
@@ -239,7 +256,7 @@ struct LaneTile {
 #pragma unroll
       for (int kk = 0; kk < IL; ++kk)                                  // step 2: the gathers of y
 #pragma unroll
-        for (int e = 0; e < WC; ++e) gy[kk][e] = slot(ywin, (uint32_t)ix[kk].v[e], M9, l8);
+        for (int e = 0; e < WC; ++e) gy[kk][e] = slot(ywin, (uint32_t)ix[kk].v[e] & (e == 0 ? 0x7fffffffu : 0xffffffffu));
 #pragma unroll
       for (int kk = 0; kk < IL; ++kk) {                               // step 3: the arithmetic
         const int k = k0 + kk;
@@ -306,8 +323,8 @@ struct LaneTile {
         const int k = k0 + kk;
 #pragma unroll
         for (int e = 0; e < WR; ++e) {
-          gx[kk][e] = slot(xwin, (uint32_t)ix[kk].v[e], M9, l8);
-          if (MODE == 1) gxp[kk][e] = slot(xpwin, (uint32_t)ix[kk].v[e], M9, l8);
+          gx[kk][e] = slot(xwin, (uint32_t)ix[kk].v[e]);
+          if (MODE == 1) gxp[kk][e] = slot(xpwin, (uint32_t)ix[kk].v[e]);
         }
         yv[kk] = yr[(size_t)((q.rd0 + (k < q.nrd ? k : 0)) & M) * 64];
       }
@@ -387,19 +404,33 @@ struct LaneTile {
     }
 #pragma unroll
     for (int q = 0; q < 13; ++q) out.v[q] = 0.0;
-#ifndef DSP_LANE_PREFETCH
-    // one register set: a second one, loaded a unit ahead, measured no faster (profiles/r40e_lane_variants.log) and its registers
-    // are what the steps of `compute` need
+#if defined(DSP_LANE_NO_PREFETCH) || defined(DSP_LANE_PROBE)
+    // one register set, a unit's rows requested right before its arithmetic (measurement variant; the probe build)
     const int R = P.ring_mask + 1;
     for (int s = 0; s < (MODE == 1 ? 3 : 2) * R; ++s) ring[(size_t)s * 64 + lane] = 0.0;
     for (int u = ubeg; u < uend; ++u) {
+#if defined(DSP_LANE_PROBE) && defined(__HIP_DEVICE_COMPILE__)
+      unsigned long long *pw = g_lane_probe + (size_t)((blockIdx.y * gridDim.x + blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6)) * kProbeSlots;
+      const bool pon = MODE == 0 && lane == 0 && (size_t)(pw - g_lane_probe) < (size_t)(kProbeWaves - 1) * kProbeSlots && 8 + 3 * (u - ubeg) + 2 < kProbeSlots;
+      if (pon) pw[8 + 3 * (u - ubeg)] = clock64();
+#endif
       const Unit qa = load_unit(P, u);
       Regs ra;
       load_regs(P, G, qa, lane, sc.active, ra);
+#if defined(DSP_LANE_PROBE) && defined(__HIP_DEVICE_COMPILE__)
+      if (DSP_LANE_PROBE >= 2) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); if (pon) pw[8 + 3 * (u - ubeg) + 1] = clock64(); }
+#endif
       compute(P, G, qa, ra, sc, j0, j1, lane, ring, stage, xbl, xpl, out);
+#if defined(DSP_LANE_PROBE) && defined(__HIP_DEVICE_COMPILE__)
+      if (pon) { pw[8 + 3 * (u - ubeg) + 2] = clock64(); pw[2] = (unsigned long long)(u - ubeg + 1); }
+#endif
     }
 #else
-    Unit qa = load_unit(P, ubeg), qb = qa;
+    // Two register sets: the rows of unit u + 1 are requested before the arithmetic of unit u (its descriptor a unit earlier still),
+    // the loop unrolled by two so that no register moves between the sets.  This pays only since the loads are unconditional
+    // (load_regs: an idle lane's go to one line): behind a branch on EXEC the wait before unit u's first use was a wait for u + 1's
+    // rows as well.  B = 64: 47.3 -> 43.2 us, B = 16: 45.2 -> 37.3 us per iteration (profiles/r41a_lane_variants.log).
+    Unit qa = load_unit(P, ubeg), qb = load_unit(P, ubeg + 1 < uend ? ubeg + 1 : ubeg), qn = qa;
     Regs ra, rb;
     load_regs(P, G, qa, lane, sc.active, ra);
 #pragma unroll
@@ -409,11 +440,15 @@ struct LaneTile {
     const int R = P.ring_mask + 1;
     for (int s = 0; s < (MODE == 1 ? 3 : 2) * R; ++s) ring[(size_t)s * 64 + lane] = 0.0;
     for (int u = ubeg; u < uend; u += 2) {
-      if (u + 1 < uend) { qb = load_unit(P, u + 1); load_regs(P, G, qb, lane, sc.active, rb); }
+      qn = load_unit(P, u + 2 < uend ? u + 2 : u);                // descriptors two units ahead, rows one unit ahead
+      if (u + 1 < uend) load_regs(P, G, qb, lane, sc.active, rb);
       compute(P, G, qa, ra, sc, j0, j1, lane, ring, stage, xbl, xpl, out);
       if (u + 1 >= uend) break;
-      if (u + 2 < uend) { qa = load_unit(P, u + 2); load_regs(P, G, qa, lane, sc.active, ra); }
+      qa = qn;
+      qn = load_unit(P, u + 3 < uend ? u + 3 : u);
+      if (u + 2 < uend) load_regs(P, G, qa, lane, sc.active, ra);
       compute(P, G, qb, rb, sc, j0, j1, lane, ring, stage, xbl, xpl, out);
+      qb = qn;
     }
 #endif
   }

@@ -72,6 +72,7 @@ struct LaneState {
   HostLanePlan plan;
   LaneProblem P{};                      // device pointers of the records (tiles / units filled per solve)
   char *crec = nullptr, *rrec = nullptr;   // the records (mutable: shared bounds are written into them per solve)
+  int rec_ring = 0;                     // the ring the records' indices are packed for (dsp_lane_plan.hpp: pack_lane_records)
   const int32_t *long_id = nullptr;
   const uint8_t *is_long = nullptr;     // [n]
   std::vector<void *> allocs;
@@ -221,9 +222,20 @@ __global__ void __launch_bounds__(kLaneWaves * 64, DSP_LANE_MINWAVES) k_lane(Lan
   // scenarios until the last one was through).  Their sums stay zero; a group with no live lane skips the walk altogether.
   sc.active = !sc.done;
   const bool any = __builtin_amdgcn_readfirstlane(__any(sc.active ? 1 : 0)) != 0;
+#ifdef DSP_LANE_PROBE
+  unsigned long long *pw = g_lane_probe + (size_t)((blockIdx.y * gridDim.x + blockIdx.x) * kLaneWaves + wv) * kProbeSlots;
+  const bool pon = MODE == 0 && lane == 0 && (size_t)(pw - g_lane_probe) < (size_t)(kProbeWaves - 1) * kProbeSlots;
+  if (pon) { pw[0] = wall_clock64(); pw[1] = clock64(); pw[2] = 0; unsigned hw; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw)); unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc)); pw[3] = ((unsigned long long)xcc << 32) | hw; }
+#endif
   if (tile < a.P.ntile && any) LaneTile<WC, WR, NLP, lane_ch(WC, WR, NLP), SHARED, QP, MODE>::run(a.P, G, tile, lane, sc, ring, stage, out);
+#ifdef DSP_LANE_PROBE
+  if (pon) pw[4] = clock64();
+#endif
   // the workgroup's waves add their partial sums in wave order (the one barrier of the launch; the rings are free by then)
   __syncthreads();
+#ifdef DSP_LANE_PROBE
+  if (pon) pw[5] = clock64();
+#endif
   double *red = lds;
   if (MODE != 2) {
 #pragma unroll
@@ -255,6 +267,9 @@ __global__ void __launch_bounds__(kLaneWaves * 64, DSP_LANE_MINWAVES) k_lane(Lan
       }
     }
   }
+#ifdef DSP_LANE_PROBE
+  if (pon) { pw[6] = clock64(); pw[7] = wall_clock64(); }
+#endif
 }
 
 // ---- the long columns: A^T y from the workgroups' partial sums (fixed order), then the column's own step ------------------------------
@@ -467,7 +482,8 @@ hipError_t lane_create(const HostCSR &A_scaled, const HostCSR &AT_scaled, Stream
   std::vector<uint8_t> is_long(H.n, 0);
   for (int j : H.long_id) is_long[j] = 1;
   std::vector<char> crec, rrec;
-  pack_lane_records(H, crec, rrec);
+  L->rec_ring = 16;                                       // the usual ring; a tiling with another one repacks (lane_records_for)
+  pack_lane_records(H, L->rec_ring, crec, rrec);
   const char *cdev = nullptr, *rdev = nullptr;
   if ((e = lane_up(L->allocs, crec, &cdev)) != hipSuccess || (e = lane_up(L->allocs, rrec, &rdev)) != hipSuccess ||
       (e = lane_up(L->allocs, H.long_id, &L->long_id)) != hipSuccess || (e = lane_up(L->allocs, is_long, &L->is_long)) != hipSuccess) {
@@ -492,10 +508,23 @@ void lane_destroy(StreamSolver *S) {
   S->lane = nullptr;
 }
 
+// the records' gather indices are ring offsets: packed again when a tiling uses another ring than the last one did
+static hipError_t lane_records_for(LaneState *L, int ring) {
+  if (ring == L->rec_ring) return hipSuccess;
+  std::vector<char> crec, rrec;
+  pack_lane_records(L->plan, ring, crec, rrec);
+  hipError_t e;
+  if ((e = hipMemcpy(L->crec, crec.data(), crec.size(), hipMemcpyHostToDevice)) != hipSuccess) return e;
+  if ((e = hipMemcpy(L->rrec, rrec.data(), rrec.size(), hipMemcpyHostToDevice)) != hipSuccess) return e;
+  L->rec_ring = ring;
+  return hipSuccess;
+}
+
 static hipError_t lane_tiling(LaneState *L, int rows_per_tile, LaneTiling **out) {
   // DSP_LANE_RING_MAX (development): largest ring the planner may use (8: less LDS per wave, more resident waves, emptier units)
   const int ring_max = getenv("DSP_LANE_RING_MAX") ? atoi(getenv("DSP_LANE_RING_MAX")) : kLaneMaxRing;
-  const int ring_min = getenv("DSP_LANE_RING_MIN") ? atoi(getenv("DSP_LANE_RING_MIN")) : 8;
+  // from 16 slots: with 8 the units of these matrices are 60 % full, with 16 80 - 90 % (17 - 40 % fewer units; r40x_lane_variants.log)
+  const int ring_min = getenv("DSP_LANE_RING_MIN") ? atoi(getenv("DSP_LANE_RING_MIN")) : 16;
   const int key = rows_per_tile * 4096 + std::min(ring_max, 63) * 64 + std::min(ring_min, 63);
   auto it = L->tilings.find(key);
   if (it == L->tilings.end()) {
@@ -567,7 +596,9 @@ hipError_t lane_run(StreamSolver *S, StreamArgs &a, hipStream_t st, int *periods
   // tiles: enough waves to fill the chip (8 per CU), at least a few units each.  DSP_LANE_ROWS: rows per tile (development)
   const int rows_env = getenv("DSP_LANE_ROWS") ? atoi(getenv("DSP_LANE_ROWS")) : 0;          // (read per solve: tests switch tilings)
   const int waves_env = getenv("DSP_LANE_WAVES") ? atoi(getenv("DSP_LANE_WAVES")) : 0;
-  const int want_waves = waves_env > 0 ? waves_env : 2048;
+  // one wave per SIMD (1024) from 64 scenarios on - larger tiles, fewer halo rows; the next unit's rows in flight hide the latency a
+  // second wave would -, two per SIMD below and for many groups (profiles/r40y_, r40z_, r41a_lane_variants.log)
+  const int want_waves = waves_env > 0 ? waves_env : ((B >= 64 && G <= 4) ? 1024 : 2048);
   int rows = rows_env > 0 ? rows_env : (int)(((int64_t)m * G + want_waves - 1) / want_waves);
   const int ch = lane_ch(L->plan.WC, L->plan.WR, NLP);
   rows = std::max(rows, 3 * ch);
@@ -575,6 +606,7 @@ hipError_t lane_run(StreamSolver *S, StreamArgs &a, hipStream_t st, int *periods
   LaneTiling *T = nullptr;
   if ((e = lane_tiling(L, rows, &T)) != hipSuccess) return e;
   if (T->ntile == 0) return hipSuccess;
+  if ((e = lane_records_for(L, T->ring)) != hipSuccess) return e;
   // bounds: one template for the whole batch (stride 0), or equal apart from the long columns' (checked on the device)
   bool shared = (!a.b.var_lb || a.b.var_lb_stride == 0) && (!a.b.var_ub || a.b.var_ub_stride == 0) &&
                 (!a.b.row_lb || a.b.row_lb_stride == 0) && (!a.b.row_ub || a.b.row_ub_stride == 0);
@@ -702,6 +734,20 @@ hipError_t lane_run(StreamSolver *S, StreamArgs &a, hipStream_t st, int *periods
   }
   if (e != hipSuccess) return e;
   *periods_run = period;
+#ifdef DSP_LANE_PROBE
+  if (const char *path = getenv("DSP_LANE_PROBE_OUT")) {
+    std::vector<unsigned long long> h((size_t)kProbeWaves * kProbeSlots);
+    (void)hipStreamSynchronize(ls);
+    if (hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(g_lane_probe), h.size() * sizeof(unsigned long long)) == hipSuccess) {
+      if (FILE *f = fopen(path, "wb")) {
+        const int nwg = (T->ntile + kLaneWaves - 1) / kLaneWaves;
+        const int hdr[4] = {T->ntile, G, kLaneWaves, kProbeSlots};
+        const size_t rows = std::min<size_t>((size_t)kProbeWaves, (size_t)nwg * kLaneWaves * G);
+        fwrite(hdr, sizeof(int), 4, f); fwrite(h.data(), sizeof(unsigned long long), rows * kProbeSlots, f); fclose(f);
+      }
+    }
+  }
+#endif
   // ---- out: x+, y+ of the last check back to the scenario-major workspace (k_finalize unscales them) -----------------------------------
   hipLaunchKernelGGL(k_lane_out, gcol, tb, 0, st, (const double *)W.xp, n, B, a.W.xp);
   hipLaunchKernelGGL(k_lane_out, grow, tb, 0, st, (const double *)W.yp, m, B, a.W.yp);

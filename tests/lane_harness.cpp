@@ -39,7 +39,7 @@ static int run_all(Problem &Q) {
   LaneProblem P{};
   P.n = n; P.m = m; P.nl = nl;
   std::vector<char> crec, rrec;
-  pack_lane_records(H, crec, rrec);
+  pack_lane_records(H, R, crec, rrec);
   set_lane_record_bounds(H, crec, rrec, Q.lb.data(), Q.ub.data(), Q.rlo.data(), Q.rhi.data(), Q.col_scale.data(), Q.row_scale.data());
   P.crec = crec.data(); P.rrec = rrec.data();
   P.tiles = T.tiles.data(); P.units = T.units.data(); P.ntile = T.ntile; P.ring_mask = R - 1;

@@ -190,6 +190,21 @@ def lane_harness(tmp_path_factory):
     return exe
 
 
+def test_lane_walk_with_one_register_set(tmp_path):
+    """The measurement variant of the walk (DSP_LANE_NO_PREFETCH: a unit's rows requested right before its arithmetic; the probe build
+    of tools/gpu_lane_probe.sh uses it) computes the same iteration."""
+    exe = str(tmp_path / "lane_harness_np")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-DDSP_LANE_NO_PREFETCH", "-o", exe, os.path.join(ROOT, "tests", "lane_harness.cpp")], check=True)
+    lp = _lane_case("wind_battery_two_level", 336).lp
+    A = sp.csr_matrix((lp.data, lp.indices, lp.indptr), shape=(lp.m, lp.n))
+    A.sort_indices()
+    path = str(tmp_path / "a.bin")
+    _write_csr(A, path)
+    res = json.loads(subprocess.run([exe, path, "24", "16"], check=True, capture_output=True, text=True).stdout)
+    assert res["ok"] and res["missing"] == 0 and res["nan_partials"] == 0
+    assert max(res["err_x"], res["err_y"], res["err_xp"], res["err_yp"]) < 1e-11 and res["err_sums"] < 1e-11
+
+
 def _lane_case(name, T):
     from dispatches_amd import scenarios
     if name == "wind_battery_chain":
@@ -264,7 +279,8 @@ def test_lane_form_on_random_banded_matrices(lane_harness, tmp_path, seed):
     path = str(tmp_path / "a.bin")
     _write_csr(A, path)
     rows_per_tile = int(rng.choice([8, 12, 20, 40, 96]))
-    res = json.loads(subprocess.run([lane_harness, path, str(rows_per_tile)], check=True, capture_output=True, text=True).stdout)
+    ring_min = (8, 16, 32)[seed % 3]                            # (the device starts from 16; the records are packed for the tiling's ring)
+    res = json.loads(subprocess.run([lane_harness, path, str(rows_per_tile), str(ring_min)], check=True, capture_output=True, text=True).stdout)
     if not res["ok"]:
         assert res["why"] in ("plan", "tiles")
         collen = np.diff(sp.csc_matrix(A).indptr)
