@@ -34,10 +34,6 @@
 #define DSP_LANE_HD inline
 #endif
 
-#ifndef DSP_LANE_IL
-#define DSP_LANE_IL 4
-#endif
-
 namespace dsp {
 
 // DSP_LANE_PROBE (measurement build only; tools/gpu_lane_probe.sh): every wave of the plain-iteration kernel leaves time stamps of
@@ -76,26 +72,12 @@ DSP_LANE_HD T ldu(const T *p) {
 // element (e, lane) of a group's block [elements][64] through a 32-bit byte offset on the block's wave-uniform base:
 // global_load v, v_off, s[base] - one 32-bit add per access (e * 512 is scalar), no 64-bit vector address arithmetic.  A group's
 // block of one vector is 512 bytes per element: 4 GiB = 8 M elements (checked by the host).
-#if defined(__HIP_DEVICE_COMPILE__) && defined(DSP_LANE_NT)
-// (experiment) non-temporal: every iterate is read once and written once per launch
-DSP_LANE_HD double lane_ld(const double *base, int e, uint32_t lane8) {
-  return __builtin_nontemporal_load(reinterpret_cast<const double *>(reinterpret_cast<const char *>(base) + ((uint32_t)e * 512u + lane8)));
-}
-struct LaneStoreNT {
-  double *p;
-  DSP_LANE_HD void operator=(double v) const { __builtin_nontemporal_store(v, p); }
-};
-DSP_LANE_HD LaneStoreNT lane_st(double *base, int e, uint32_t lane8) {
-  return LaneStoreNT{reinterpret_cast<double *>(reinterpret_cast<char *>(base) + ((uint32_t)e * 512u + lane8))};
-}
-#else
 DSP_LANE_HD const double &lane_ld(const double *base, int e, uint32_t lane8) {
   return *reinterpret_cast<const double *>(reinterpret_cast<const char *>(base) + ((uint32_t)e * 512u + lane8));
 }
 DSP_LANE_HD double &lane_st(double *base, int e, uint32_t lane8) {
   return *reinterpret_cast<double *>(reinterpret_cast<char *>(base) + ((uint32_t)e * 512u + lane8));
 }
-#endif
 
 // (device) the value must be in its register HERE: the wait for its load is placed at this point of straight-line code, with an
 // exact count, instead of inside the unit loop - where the merge over the back edge makes it s_waitcnt vmcnt(0), i.e. a wait for
@@ -139,10 +121,9 @@ template <int NLP> struct LaneOut { double lp[NLP]; double v[13]; };
 template <int WC, int WR, int NLP, int CH, bool SHARED, bool QP, int MODE>
 struct LaneTile {
   static constexpr int CREC = lane_crec(WC), RREC = lane_rrec(WR, NLP);
-  // slots of a unit whose chains are interleaved (the steps of `compute`): CH = all of them - most overlap, most registers (129
-  // VGPRs on the 4 / 4 / 4 shape: 3 waves per SIMD) - or 2 (DSP_LANE_IL: two pairs one after the other)
-  static constexpr int IL = DSP_LANE_IL < CH ? DSP_LANE_IL : CH;
-  static_assert(CH % IL == 0, "CH must be a multiple of the interleave");
+  // the chains of a unit's CH slots are interleaved (the steps of `compute`): most overlap, most registers; two pairs one after
+  // the other (128 VGPRs, 4 waves per SIMD) measured no faster (profiles/r40j_lane_variants.log)
+  static constexpr int IL = CH;
   static_assert(CH * CREC <= 1024 && CH * RREC <= 1024, "a unit's records must fit one 16-byte-per-lane load");
   struct Unit { int ys0, nys, cx0, ncx, rd0, nrd; };
   struct Regs {
@@ -238,7 +219,7 @@ struct LaneTile {
     }
     if (q.ncx > 0) {
 #pragma unroll
-     for (int k0 = 0; k0 < CH; k0 += IL) {                          // IL slots at a time (registers: see DSP_LANE_IL)
+     for (int k0 = 0; k0 < CH; k0 += IL) {
       LaneVecD<WC> av[IL];
       LaneVecI<WC> ix[IL];
       LaneVecD<2> bd[IL];

@@ -30,20 +30,10 @@ namespace dsp {
 
 namespace {
 
-#ifndef DSP_LANE_WAVES_PER_WG
-#define DSP_LANE_WAVES_PER_WG 4
-#endif
-constexpr int kLaneWaves = DSP_LANE_WAVES_PER_WG;   // waves (= tiles) per workgroup
-// rows / columns per unit of a tile's walk: DSP_LANE_CH where a unit's records still fit one 16-byte-per-lane load, else 4
-#ifndef DSP_LANE_CH
-#define DSP_LANE_CH 4
-#endif
-#ifndef DSP_LANE_MINWAVES
-#define DSP_LANE_MINWAVES 1
-#endif
-constexpr int lane_ch(int wc, int wr, int nlp) {
-  return (DSP_LANE_CH * lane_crec(wc) <= 1024 && DSP_LANE_CH * lane_rrec(wr, nlp) <= 1024) ? DSP_LANE_CH : 4;
-}
+constexpr int kLaneWaves = 4;           // waves (= tiles) per workgroup (8 measured no better: profiles/r40j_lane_variants.log)
+// rows / columns per unit of a tile's walk (8 - where a unit's records would still fit one 16-byte-per-lane load - measured no better
+// with one or two register sets: profiles/r40e_, r41a_lane_variants.log)
+constexpr int lane_ch(int, int, int) { return 4; }
 constexpr int kLaneNQ = 16;             // check-sum slots per (group, workgroup)
 
 struct LaneTiling {                     // device copy of one tiling (dsp_lane_plan.hpp: HostLaneTiles)
@@ -186,7 +176,7 @@ __global__ void k_lane_setup(LaneArgs a, const double *__restrict__ lbW, const d
 
 // ---- the tile kernel ----------------------------------------------------------------------------------------------------------------
 template <int WC, int WR, int NLP, bool SHARED, bool QP, int MODE>
-__global__ void __launch_bounds__(kLaneWaves * 64, DSP_LANE_MINWAVES) k_lane(LaneArgs a) {
+__global__ void __launch_bounds__(kLaneWaves * 64) k_lane(LaneArgs a) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
