@@ -29,7 +29,10 @@
 namespace dsp {
 
 constexpr int kLaneMaxLong = 8;          // long columns the lane form carries
-constexpr int kLaneMaxRing = 64;         // largest ring (slots per orientation) the planner tries
+// largest ring (slots per window) the planner tries: the check kernel keeps THREE windows per wave, four waves per workgroup -
+// 3 x 16 x 512 B x 4 + the record stages = 104 KB of a CU's 160 KB of LDS; 32 slots (200 KB) would not launch.  A band that needs
+// more is not scheduled: the handle keeps the other forms.
+constexpr int kLaneMaxRing = 16;
 
 struct HostLanePlan {
   bool ok = false;
@@ -214,11 +217,10 @@ inline HostLaneTiles build_lane_tiles_ring(const HostLanePlan &P, int rows_per_t
   return T;
 }
 
-// The smallest ring (8 .. kLaneMaxRing slots per window; LDS per wave = 2 or 3 windows x ring x 512 bytes) that holds the band.  A
-// ring that only just holds it leaves the three streams of a walk (stage, primal, dual) waiting for each other - 20 % more, emptier
-// units on the wind + battery LPs at 8 slots than at 16 - but halves the LDS of a wave: twice the resident waves were worth more
-// than the fuller units (year-long batch of 256: 157 vs 176 us per iteration, profiles/r40d_lane_rates.log).  `slack` > 1 prefers
-// the smallest ring within that factor of the fewest units any ring needs instead.
+// The smallest ring (ring_min .. kLaneMaxRing slots per window; LDS per wave = 2 or 3 windows x ring x 512 bytes) that holds the
+// band.  A ring that only just holds it leaves the three streams of a walk (stage, primal, dual) waiting for each other: 17 - 40 %
+// more, emptier units on the year-long LPs at 8 slots than at 16 (profiles/r40x_ .. r41a_lane_variants.log; the device asks for 16).
+// `slack` > 1 prefers the smallest ring within that factor of the fewest units any ring needs instead.
 inline HostLaneTiles build_lane_tiles(const HostLanePlan &P, int rows_per_tile, int CH, int ring_min = 8, int ring_max = kLaneMaxRing, double slack = 0.0) {
   HostLaneTiles best;
   if (!P.ok) return best;

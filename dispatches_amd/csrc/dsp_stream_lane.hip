@@ -596,6 +596,8 @@ hipError_t lane_run(StreamSolver *S, StreamArgs &a, hipStream_t st, int *periods
   LaneTiling *T = nullptr;
   if ((e = lane_tiling(L, rows, &T)) != hipSuccess) return e;
   if (T->ntile == 0) return hipSuccess;
+  // the check kernel's three windows + record stages of four waves must fit a CU's LDS (kLaneMaxRing keeps them below: defensive)
+  if ((size_t)kLaneWaves * (3 * (size_t)T->ring * 64 * sizeof(double) + kLaneStageBytes) > 160u * 1024u) return hipSuccess;
   if ((e = lane_records_for(L, T->ring)) != hipSuccess) return e;
   // bounds: one template for the whole batch (stride 0), or equal apart from the long columns' (checked on the device)
   bool shared = (!a.b.var_lb || a.b.var_lb_stride == 0) && (!a.b.var_ub || a.b.var_ub_stride == 0) &&
