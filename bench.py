@@ -303,9 +303,10 @@ def bench_price_taker(args, rank, local_rank, world, dev):
         traffic = src = None
         kname = {3: "k_lane<", 2: "k_fused"}.get(form)
         if kname:
-            pats = [f"r4*_pmc_summary*{args.workload}*.csv"] + (["r4*_lane_pmc_summary_B*.csv", "r4*_stream_pmc_summary*.csv"] if args.workload == "price_taker" else [])
+            pats = [f"r4*_pmc_summary_{args.workload}_B*.csv"] + (["r4*_lane_pmc_summary_B*.csv", "r4*_stream_pmc_summary*.csv"] if args.workload == "price_taker" else [])
             files = [f for pat in pats for f in glob.glob(os.path.join(ROOT, "profiles", pat))]
-            for f in sorted(set(files), key=os.path.basename, reverse=True):
+            # the newest summary collected at this line's batch, else the newest of the round
+            for f in sorted(set(files), key=lambda f: (f"_B{B}." in os.path.basename(f), os.path.basename(f)), reverse=True):
                 c = {}
                 for row in csv.DictReader(open(f)):
                     if kname in row["kernel"] and ("0>" in row["kernel"] or form == 2):

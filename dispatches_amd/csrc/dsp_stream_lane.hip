@@ -575,10 +575,10 @@ hipError_t lane_run(StreamSolver *S, StreamArgs &a, hipStream_t st, int *periods
   LaneState *L = S->lane;
   if (!L) return hipSuccess;
   const int B = a.b.B, n = L->P.n, m = L->P.m, NLP = L->plan.NLP, G = (B + 63) / 64;
-  // Small batches stay with the workgroup-per-tile form of round 3 (dsp_stream.hip: k_fused_pre): a lane's walk through its tile is one
-  // in-order chain of ~10 units of ~3 us each whatever the batch - 42 us per iteration for 1 .. 32 scenarios, against 10 us (1 scenario)
-  // and 32 us (16) there; from 32 scenarios on the lane form is ahead (64: 48 vs 90 us, 256: 165 vs 407 us; profiles/r40h_lane_rates.log).
-  // DSP_LANE_MIN_B: the threshold (development).
+  // Small batches stay with the workgroup-per-tile form of round 3 (dsp_stream.hip: k_fused_pre): a lane's walk through its tile costs
+  // the same instruction stream whatever the batch - 36 us per iteration for 1 .. 32 scenarios, against 10 us (1 scenario) and
+  // 28 - 32 us (16) there; from 32 scenarios on the lane form is ahead (64: 42 vs 90 us, 256: 165 vs 407 us; profiles/r40h_lane_rates.log,
+  // r41a_lane_variants.log).  DSP_LANE_MIN_B: the threshold (development).
   const int min_b = getenv("DSP_LANE_MIN_B") ? atoi(getenv("DSP_LANE_MIN_B")) : 32;
   if (B < min_b) return hipSuccess;
   const bool qp = a.b.row_compliance != nullptr;

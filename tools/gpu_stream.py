@@ -1,5 +1,5 @@
 """GPU dev tool: streaming PDLP on the price-taker family.  python tools/gpu_stream.py T B [max_iter] [check_every]
-(STREAM_FAMILY=pem: the wind + battery + PEM family, chain accumulator)"""
+(STREAM_FAMILY=pem: the wind + battery + PEM family, chain accumulator; nuclear: the nuclear enumeration, B design points)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -11,6 +11,8 @@ solver = HipPdlpSolver(device=0, check_every=ce, max_iter=mi)
 t = time.time()
 if os.environ.get("STREAM_FAMILY") == "pem":
     handles, model = scenarios.pem_price_taker_batch(T, B, solver, inputs="rts303", throughput=os.environ.get('STREAM_THROUGHPUT', 'chain'))
+elif os.environ.get("STREAM_FAMILY") == "nuclear":
+    handles, model = scenarios.nuclear_price_taker_batch(T, B, solver)
 else:
     handles, model = scenarios.price_taker_batch(T, B, solver, throughput=os.environ.get('STREAM_THROUGHPUT', 'two_level'))
 tb = time.time() - t
