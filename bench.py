@@ -323,7 +323,8 @@ def bench_price_taker(args, rank, local_rank, world, dev):
             "config": {"workload": f"{args.workload}: {B} scenarios/GPU sharing one constraint matrix, T = {T} h, streaming PDLP "
                                    + ("solved to optimality" if args.solve else f"capped at {args.steps} check periods of {ce} iterations")
                                    + ("" if thr == "chain" else f", throughput accumulator in its {thr} form"),
-                       "throughput_form": thr, "stream_form": STREAM_FORMS.get(form, str(form)), "solved_to_optimality": int((model.status == 0).sum()),
+                       "throughput_form": thr, "stream_form": STREAM_FORMS.get(form, str(form)), "stream_phases": int(getattr(st, "stream_phases", 0)),
+                       "solved_to_optimality": int((model.status == 0).sum()),
                        "iterations_per_scenario": float(model.iterations.mean()), "max_iterations": int(model.iterations.max()),
                        "status_counts": np.bincount(model.status, minlength=5).tolist(),
                        "finished_before_the_cap": int((model.status == 0).sum()) if not args.solve else None,

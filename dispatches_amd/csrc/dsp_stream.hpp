@@ -150,6 +150,7 @@ struct StreamSolver {
   int *ndone_host = nullptr;
   LaneState *lane = nullptr;
   int last_form = 0;                     // DSP_STREAM_FORM_* of the last solve
+  int last_phases = 0;                   // lane form: phases of the last solve (dsp_stats::stream_phases)
   size_t last_bytes_per_iteration = 0;   // algorithmic HBM bytes per scenario and plain iteration of the form the last solve ran
   std::mutex mu;          // one solve at a time per handle: the workspace above is per handle, not per call (stream_solve)
   size_t lds_limit = 160 * 1024 - 2048;   // dynamic LDS available to the block-resident form (static __shared__ on top)

@@ -69,6 +69,8 @@ struct LaneState {
   std::map<int, LaneTiling> tilings;    // by rows per tile
   LaneWork W;
   int *flag_host = nullptr;
+  int *sid = nullptr;                   // [sid_cap] slot -> scenario map of a compacted phase
+  int sid_cap = 0;
   hipStream_t stream = nullptr;         // the iteration loop's own stream (graph replays)
 };
 
@@ -76,7 +78,9 @@ namespace {
 
 struct LaneArgs {
   LaneProblem P;
-  int NLP, nwg, nslot, B, kofs, iters, rrec_stride, ral_off;
+  int NLP, nwg, nslot, B, kofs, iters, rrec_stride, ral_off;   // B: lane slots in use (scenarios of this phase of the solve)
+  int sums_only;                        // k_lane_apply: leave the iterate alone, only the long columns' partial sums of A^T y
+  const int *sid;                       // slot -> scenario of the batch (nullptr: identity): after finished scenarios were dropped
   const int32_t *long_id;
   const double *x_in, *y_in, *x0, *c, *y0;
   double *x_out, *y_out;
@@ -110,12 +114,15 @@ hipError_t lane_up(std::vector<void *> &allocs, const std::vector<T> &v, const T
 // ---- layout changes ---------------------------------------------------------------------------------------------------------------
 // scenario-major [B][len] (stride `stride`, 0 = one template for every scenario) -> lane layout [G][len + 1][64]; lanes beyond the
 // batch get `fill`.  64 x 64 tiles through LDS: both sides coalesced.
-__global__ void __launch_bounds__(256) k_lane_in(const double *__restrict__ src, size_t stride, int len, int B, double fill, double *__restrict__ dst) {
+// `sid`: slot -> scenario (nullptr: identity), B = slots in use.
+__global__ void __launch_bounds__(256) k_lane_in(const double *__restrict__ src, size_t stride, int len, int B, const int *__restrict__ sid, double fill,
+                                                 double *__restrict__ dst) {
   __shared__ double tile[64][65];
   const int g = blockIdx.y, e0 = blockIdx.x * 64, tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   for (int r = ty; r < 64; r += 4) {
-    const int s = g * 64 + r, e = e0 + tx;
-    tile[r][tx] = (s < B && e < len) ? src[(size_t)s * stride + e] : fill;
+    const int slot = g * 64 + r, e = e0 + tx;
+    const int s = (slot < B && sid) ? sid[slot] : slot;
+    tile[r][tx] = (slot < B && e < len) ? src[(size_t)s * stride + e] : fill;
   }
   __syncthreads();
   for (int r = ty; r < 64; r += 4) {
@@ -124,7 +131,7 @@ __global__ void __launch_bounds__(256) k_lane_in(const double *__restrict__ src,
   }
 }
 
-__global__ void __launch_bounds__(256) k_lane_out(const double *__restrict__ src, int len, int B, double *__restrict__ dst) {
+__global__ void __launch_bounds__(256) k_lane_out(const double *__restrict__ src, int len, int B, const int *__restrict__ sid, double *__restrict__ dst) {
   __shared__ double tile[64][65];
   const int g = blockIdx.y, e0 = blockIdx.x * 64, tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   for (int r = ty; r < 64; r += 4) {
@@ -133,8 +140,9 @@ __global__ void __launch_bounds__(256) k_lane_out(const double *__restrict__ src
   }
   __syncthreads();
   for (int r = ty; r < 64; r += 4) {
-    const int s = g * 64 + r, e = e0 + tx;
-    if (s < B && e < len) dst[(size_t)s * len + e] = tile[tx][r];
+    const int slot = g * 64 + r, e = e0 + tx;
+    const int s = (slot < B && sid) ? sid[slot] : slot;
+    if (slot < B && e < len) dst[(size_t)s * len + e] = tile[tx][r];
   }
 }
 
@@ -159,8 +167,9 @@ __global__ void k_lane_bounds_differ(const double *__restrict__ lo, const double
 
 // per-scenario bounds of the long columns; control blocks -> per-lane arrays
 __global__ void k_lane_setup(LaneArgs a, const double *__restrict__ lbW, const double *__restrict__ ubW) {
-  const int g = blockIdx.x, lane = threadIdx.x, s = g * 64 + lane;
-  const bool in = s < a.B;
+  const int g = blockIdx.x, lane = threadIdx.x, slot = g * 64 + lane;
+  const bool in = slot < a.B;
+  const int s = (in && a.sid) ? a.sid[slot] : slot;
   for (int l = 0; l < a.NLP; ++l) {
     double lo = 0.0, hi = 0.0;
     if (in && l < a.P.nl) { const int j = a.long_id[l]; lo = lbW[(size_t)s * a.P.n + j]; hi = ubW[(size_t)s * a.P.n + j]; }
@@ -347,9 +356,10 @@ __global__ void __launch_bounds__(kLongWaves * 64) k_lane_sum(LaneArgs a) {
 }
 
 __global__ void __launch_bounds__(64) k_lane_decide(LaneArgs a) {
-  const int g = blockIdx.x, lane = threadIdx.x, s = g * 64 + lane;
+  const int g = blockIdx.x, lane = threadIdx.x, slot = g * 64 + lane;
   const size_t at = (size_t)g * 64 + lane;
-  if (s >= a.B || a.done[at]) return;
+  if (slot >= a.B || a.done[at]) return;
+  const int s = a.sid ? a.sid[slot] : slot;
   double acc[kLaneNQ];
 #pragma unroll
   for (int q = 0; q < 13; ++q) acc[q] = a.acc[((size_t)g * kLaneNQ + q) * 64 + lane];
@@ -373,6 +383,7 @@ __global__ void __launch_bounds__(kLaneWaves * 64) k_lane_apply(LaneArgs a) {
   const uint32_t l8 = (uint32_t)lane * 8u;
   const bool done = a.done[as] != 0;
   const bool restart = a.mode[as] == 1;
+  const bool keep = a.sums_only != 0;                 // (entering a solve or a compacted phase: the iterate stays, only the sums are wanted)
   const double oml = 1.0 / (double)(a.k[as] + 2);
   double lp[NLP];
 #pragma unroll
@@ -381,7 +392,7 @@ __global__ void __launch_bounds__(kLaneWaves * 64) k_lane_apply(LaneArgs a) {
     const LaneVecI<8> tp = ldu(reinterpret_cast<const LaneVecI<8> *>(a.P.tiles) + tile);
     const int i0 = tp.v[0], i1 = tp.v[1], j0 = tp.v[2], j1 = tp.v[3];
     constexpr int U = 8;
-    for (int b = j0; b < j1; b += U) {
+    for (int b = j0; b < j1 && !keep; b += U) {
       double xp[U], x[U], x0[U];
 #pragma unroll
       for (int k = 0; k < U; ++k) {
@@ -406,11 +417,11 @@ __global__ void __launch_bounds__(kLaneWaves * 64) k_lane_apply(LaneArgs a) {
 #pragma unroll
       for (int k = 0; k < U; ++k) {
         const bool live = b + k < i1;
-        const int i = (live && !done) ? b + k : a.P.m;
+        const int i = (live && !done && !keep) ? b + k : a.P.m;
         const double tt = 2.0 * yp[k] - y[k];
-        const double yn = restart ? yp[k] : fma(oml, y0[k] - tt, tt);
+        const double yn = keep ? y[k] : (restart ? yp[k] : fma(oml, y0[k] - tt, tt));
         lane_st(a.ya + gm, i, l8) = yn;
-        lane_st(a.y0w + gm, (restart && live && !done) ? b + k : a.P.m, l8) = yp[k];
+        lane_st(a.y0w + gm, (restart && live && !done && !keep) ? b + k : a.P.m, l8) = yp[k];
         const LaneVecD<NLP> al = ldu(reinterpret_cast<const LaneVecD<NLP> *>(a.P.rrec + (size_t)min(b + k, i1 - 1) * a.rrec_stride + a.ral_off));
         const double yw = live ? yn : 0.0;
 #pragma unroll
@@ -493,6 +504,7 @@ void lane_destroy(StreamSolver *S) {
   for (void *p : L->allocs) (void)hipFree(p);
   for (void *p : L->W.allocs) (void)hipFree(p);
   if (L->flag_host) (void)hipHostFree(L->flag_host);
+  if (L->sid) (void)hipFree(L->sid);
   if (L->stream) (void)hipStreamDestroy(L->stream);
   delete L;
   S->lane = nullptr;
@@ -574,7 +586,7 @@ hipError_t lane_run(StreamSolver *S, StreamArgs &a, hipStream_t st, int *periods
   *used = false;
   LaneState *L = S->lane;
   if (!L) return hipSuccess;
-  const int B = a.b.B, n = L->P.n, m = L->P.m, NLP = L->plan.NLP, G = (B + 63) / 64;
+  const int B = a.b.B, n = L->P.n, m = L->P.m, NLP = L->plan.NLP;
   // Small batches stay with the workgroup-per-tile form of round 3 (dsp_stream.hip: k_fused_pre): a lane's walk through its tile costs
   // the same instruction stream whatever the batch - 36 us per iteration for 1 .. 32 scenarios, against 10 us (1 scenario) and
   // 28 - 32 us (16) there; from 32 scenarios on the lane form is ahead (64: 42 vs 90 us, 256: 165 vs 407 us; profiles/r40h_lane_rates.log,
@@ -583,166 +595,217 @@ hipError_t lane_run(StreamSolver *S, StreamArgs &a, hipStream_t st, int *periods
   if (B < min_b) return hipSuccess;
   const bool qp = a.b.row_compliance != nullptr;
   hipError_t e;
-  // tiles: enough waves to fill the chip (8 per CU), at least a few units each.  DSP_LANE_ROWS: rows per tile (development)
-  const int rows_env = getenv("DSP_LANE_ROWS") ? atoi(getenv("DSP_LANE_ROWS")) : 0;          // (read per solve: tests switch tilings)
+  const int rows_env = getenv("DSP_LANE_ROWS") ? atoi(getenv("DSP_LANE_ROWS")) : 0;          // rows per tile (development; read per solve)
   const int waves_env = getenv("DSP_LANE_WAVES") ? atoi(getenv("DSP_LANE_WAVES")) : 0;
-  // one wave per SIMD (1024) from 64 scenarios on - larger tiles, fewer halo rows; the next unit's rows in flight hide the latency a
-  // second wave would -, two per SIMD below and for many groups (profiles/r40y_, r40z_, r41a_lane_variants.log)
-  const int want_waves = waves_env > 0 ? waves_env : ((B >= 64 && G <= 4) ? 1024 : 2048);
-  int rows = rows_env > 0 ? rows_env : (int)(((int64_t)m * G + want_waves - 1) / want_waves);
+  const int graph_env = getenv("DSP_LANE_GRAPH") ? atoi(getenv("DSP_LANE_GRAPH")) : 1;
+  // DSP_LANE_COMPACT=0: keep every scenario's lane to the end of the solve (measurement)
+  const bool compact = !(getenv("DSP_LANE_COMPACT") && atoi(getenv("DSP_LANE_COMPACT")) == 0);
   const int ch = lane_ch(L->plan.WC, L->plan.WR, NLP);
-  rows = std::max(rows, 3 * ch);
-  rows = (rows + ch - 1) / ch * ch;
-  LaneTiling *T = nullptr;
-  if ((e = lane_tiling(L, rows, &T)) != hipSuccess) return e;
-  if (T->ntile == 0) return hipSuccess;
-  // the check kernel's three windows + record stages of four waves must fit a CU's LDS (kLaneMaxRing keeps them below: defensive)
-  if ((size_t)kLaneWaves * (3 * (size_t)T->ring * 64 * sizeof(double) + kLaneStageBytes) > 160u * 1024u) return hipSuccess;
-  if ((e = lane_records_for(L, T->ring)) != hipSuccess) return e;
-  // bounds: one template for the whole batch (stride 0), or equal apart from the long columns' (checked on the device)
-  bool shared = (!a.b.var_lb || a.b.var_lb_stride == 0) && (!a.b.var_ub || a.b.var_ub_stride == 0) &&
-                (!a.b.row_lb || a.b.row_lb_stride == 0) && (!a.b.row_ub || a.b.row_ub_stride == 0);
-  if ((e = lane_workspace(L, B, T->nwg, /*per_scenario_bounds: decided below*/ false, qp)) != hipSuccess) return e;
-  LaneWork &W = L->W;
-  if (!shared && B > 1) {
-    if ((e = hipMemsetAsync(W.flag, 0, sizeof(int), st)) != hipSuccess) return e;
-    hipLaunchKernelGGL(k_lane_bounds_differ, dim3((n + 255) / 256, B - 1), dim3(256), 0, st, a.W.lb, a.W.ub, n, B, L->is_long, W.flag);
-    hipLaunchKernelGGL(k_lane_bounds_differ, dim3((m + 255) / 256, B - 1), dim3(256), 0, st, a.W.rlo, a.W.rhi, m, B, (const uint8_t *)nullptr, W.flag);
-    if ((e = hipMemcpyAsync(L->flag_host, W.flag, sizeof(int), hipMemcpyDeviceToHost, st)) != hipSuccess) return e;
-    if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;
-    shared = *L->flag_host == 0;
-  } else shared = true;
-  if (!shared) {
-    if (qp) return hipSuccess;                                     // (no instantiation: the two-launch form takes it)
-    if ((e = lane_workspace(L, B, T->nwg, true, qp)) != hipSuccess) return e;
-  }
-  LaneKernel kern[3];
-  for (int mode = 0; mode < 3; ++mode) if (!(kern[mode] = lane_pick(L->plan.WC, L->plan.WR, NLP, shared, qp, mode))) return hipSuccess;
-  *used = true;
-  S->last_bytes_per_iteration = (size_t)8 * (shared ? 4 * (size_t)n + 3 * (size_t)m : 6 * (size_t)n + 5 * (size_t)m) + (qp ? 8 * (size_t)m : 0);
-
-  LaneArgs la{};
-  la.P = L->P; la.P.tiles = T->tiles; la.P.units = T->units; la.P.ntile = T->ntile; la.P.ring_mask = T->ring - 1;
-  la.NLP = NLP; la.nwg = T->nwg; la.nslot = T->nwg + NLP; la.B = B; la.kofs = 0;
-  la.long_id = L->long_id;
-  la.x0 = W.x0; la.c = W.c; la.y0 = W.y0; la.lb = W.lb; la.ub = W.ub; la.rlo = W.rlo; la.rhi = W.rhi; la.kap = W.kap;
-  la.xbl = W.xbl; la.xpl = W.xpl; la.lbl = W.lbl; la.ubl = W.ubl; la.xp = W.xp; la.yp = W.yp;
-  la.lpart = W.lpart; la.partial = W.partial; la.acc = W.acc; la.tau = W.tau; la.sig = W.sig; la.k = W.k; la.done = W.done; la.mode = W.mode;
-  la.x0w = W.x0; la.y0w = W.y0; la.xa = W.xA; la.ya = W.yA;
-  la.ctrl = a.W.ctrl; la.ndone = a.W.ndone; la.opt = a.opt; la.eta = a.eta; la.col_scale = S->P.col_scale;
   const int CREC = lane_crec(L->plan.WC), RREC = lane_rrec(L->plan.WR, NLP);
-  la.rrec_stride = RREC; la.ral_off = L->plan.WR * 12 + 16;
   const int C = a.opt.check_every > 0 ? a.opt.check_every : 64;
-  la.iters = C;
-
-  // ---- in: scenario-major workspace -> lane layout ---------------------------------------------------------------------------------
-  const dim3 tb(256), gcol((n + 63) / 64, G), grow((m + 63) / 64, G);
-  auto in = [&](const double *src, size_t stride, int len, double *dst) {
-    hipLaunchKernelGGL(k_lane_in, len == n ? gcol : grow, tb, 0, st, src, stride, len, B, 0.0, dst);
-  };
-  in(a.W.x, (size_t)n, n, W.xA); in(a.W.x, (size_t)n, n, W.x0); in(a.W.c, (size_t)n, n, W.c); in(a.W.xp, (size_t)n, n, W.xp);
-  in(a.W.y, (size_t)m, m, W.yA); in(a.W.y, (size_t)m, m, W.y0); in(a.W.yp, (size_t)m, m, W.yp);
-  if (!shared) { in(a.W.lb, (size_t)n, n, W.lb); in(a.W.ub, (size_t)n, n, W.ub); in(a.W.rlo, (size_t)m, m, W.rlo); in(a.W.rhi, (size_t)m, m, W.rhi); }
-  if (qp) in(a.W.kap, (size_t)m, m, W.kap);
-  hipLaunchKernelGGL(k_lane_fill_records, dim3((n + 255) / 256), tb, 0, st, L->crec, CREC, L->plan.WC * 12, L->plan.WC * 12 + 16,
-                     (const double *)a.W.lb, (const double *)a.W.ub, S->P.col_scale, n);
-  hipLaunchKernelGGL(k_lane_fill_records, dim3((m + 255) / 256), tb, 0, st, L->rrec, RREC, L->plan.WR * 12, L->plan.WR * 12 + 16 + NLP * 8,
-                     (const double *)a.W.rlo, (const double *)a.W.rhi, S->P.row_scale, m);
-  if ((e = hipMemsetAsync(W.partial, 0, (size_t)G * la.nslot * kLaneNQ * 64 * sizeof(double), st)) != hipSuccess) return e;
-  hipLaunchKernelGGL(k_lane_setup, dim3(G), dim3(64), 0, st, la, (const double *)a.W.lb, (const double *)a.W.ub);
-
-  const dim3 g_tile(T->nwg, G), b_tile(kLaneWaves * 64);
-  const size_t lds_ring = (size_t)kLaneWaves * T->ring * 64 * sizeof(double);
-  const size_t lds_red = (size_t)kLaneWaves * std::max(NLP, 8) * 64 * sizeof(double);
-  const size_t lds_stage = (size_t)kLaneWaves * kLaneStageBytes;
-  const size_t lds[3] = {std::max(2 * lds_ring + lds_stage, lds_red), std::max(3 * lds_ring + lds_stage, lds_red), std::max(2 * lds_ring + lds_stage, lds_red)};
-  for (int mode = 0; mode < 3; ++mode)
-    if ((e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern[mode]), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds[mode])) != hipSuccess) return e;
-  auto apply = [&](const double *xcur, const double *ycur) {
-    LaneArgs q = la; q.x_in = xcur; q.y_in = ycur;
-    if (NLP == 4) hipLaunchKernelGGL(k_lane_apply<4>, g_tile, b_tile, 0, st, q);
-    else hipLaunchKernelGGL(k_lane_apply<8>, g_tile, b_tile, 0, st, q);
-  };
-  // the long columns' partial sums of the starting y: an "apply" that leaves the iterate where it is (every lane in Halpern mode with
-  // xp = x, x0 = x: tt = x, x_new = x; the anchors are not written) - k_init left xp = x, yp = y
-  apply(W.xA, W.yA);
-
   const int max_periods = (a.opt.max_iter + C - 1) / C;
   const int poll = 4;
-  const dim3 g_long(std::max(1, L->P.nl), G), tl(kLongWaves * 64);
-  // One check period = 2 (C - 1) + 7 launches with the same arguments every time (a period starts in buffer A and k_lane_apply
-  // leaves the iterate there): captured once into a hipGraph and replayed - a year-long solve is 10^3 .. 10^4 periods, and below
-  // ~30 us per iteration the host cannot enqueue two launches per iteration fast enough.  The legacy default stream cannot be
-  // captured: the loop then runs on the handle's own stream between two host synchronisations (the call is blocking anyway).
-  auto enqueue_period = [&](hipStream_t s) {
-    double *xcur = W.xA, *ycur = W.yA, *xalt = W.xB, *yalt = W.yB;
-    for (int u = 0; u < C - 1; ++u) {
-      LaneArgs q = la; q.kofs = u; q.x_in = xcur; q.y_in = ycur; q.x_out = xalt; q.y_out = yalt;
-      if (L->P.nl) hipLaunchKernelGGL(k_lane_long<0>, g_long, tl, 0, s, q);
-      hipLaunchKernelGGL(kern[0], g_tile, b_tile, lds[0], s, q);
-      std::swap(xcur, xalt); std::swap(ycur, yalt);
-    }
-    LaneArgs q = la; q.kofs = 0; q.x_in = xcur; q.y_in = ycur; q.x_out = xalt; q.y_out = yalt;
-    if (L->P.nl) hipLaunchKernelGGL(k_lane_long<1>, g_long, tl, 0, s, q);
-    hipLaunchKernelGGL(kern[1], g_tile, b_tile, lds[1], s, q);
-    hipLaunchKernelGGL(kern[2], g_tile, b_tile, lds[2], s, q);
-    if (L->P.nl) hipLaunchKernelGGL(k_lane_long<2>, g_long, tl, 0, s, q);
-    hipLaunchKernelGGL(k_lane_sum, dim3(13, G), tl, 0, s, q);
-    hipLaunchKernelGGL(k_lane_decide, dim3(G), dim3(64), 0, s, q);
-    LaneArgs r = la; r.x_in = xcur; r.y_in = ycur;
-    if (NLP == 4) hipLaunchKernelGGL(k_lane_apply<4>, g_tile, b_tile, 0, s, r);
-    else hipLaunchKernelGGL(k_lane_apply<8>, g_tile, b_tile, 0, s, r);
-  };
-  const int graph_env = getenv("DSP_LANE_GRAPH") ? atoi(getenv("DSP_LANE_GRAPH")) : 1;
-  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-  if (st) (void)hipStreamIsCapturing(st, &cap);
-  const bool use_graph = graph_env && max_periods > 2 && cap == hipStreamCaptureStatusNone;
-  hipStream_t ls = st;
-  hipGraph_t graph = nullptr;
-  hipGraphExec_t exec = nullptr;
-  if (use_graph) {
-    if (!L->stream && (e = hipStreamCreateWithFlags(&L->stream, hipStreamNonBlocking)) != hipSuccess) return e;
-    ls = L->stream;
-    if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;                    // everything enqueued so far precedes the loop
-    if ((e = hipStreamBeginCapture(ls, hipStreamCaptureModeThreadLocal)) != hipSuccess) return e;
-    enqueue_period(ls);
-    if ((e = hipStreamEndCapture(ls, &graph)) != hipSuccess) return e;
-    if ((e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0)) != hipSuccess) { (void)hipGraphDestroy(graph); return e; }
-  }
-  int period = 0;
-  for (; period < max_periods; ++period) {
-    if (use_graph) { if ((e = hipGraphLaunch(exec, ls)) != hipSuccess) break; }
-    else enqueue_period(ls);
-    if ((period + 1) % poll == 0 || period + 1 == max_periods) {
-      if ((e = hipMemcpyAsync(S->ndone_host, a.W.ndone, sizeof(int), hipMemcpyDeviceToHost, ls)) != hipSuccess) break;
-      if ((e = hipStreamSynchronize(ls)) != hipSuccess) break;
-      if (*S->ndone_host >= B) { ++period; break; }
-    }
-  }
-  if (use_graph) {
-    const hipError_t es = hipStreamSynchronize(ls);
-    (void)hipGraphExecDestroy(exec); (void)hipGraphDestroy(graph);
-    if (e == hipSuccess) e = es;
-  }
-  if (e != hipSuccess) return e;
-  *periods_run = period;
-#ifdef DSP_LANE_PROBE
-  if (const char *path = getenv("DSP_LANE_PROBE_OUT")) {
-    std::vector<unsigned long long> h((size_t)kProbeWaves * kProbeSlots);
-    (void)hipStreamSynchronize(ls);
-    if (hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(g_lane_probe), h.size() * sizeof(unsigned long long)) == hipSuccess) {
-      if (FILE *f = fopen(path, "wb")) {
-        const int nwg = (T->ntile + kLaneWaves - 1) / kLaneWaves;
-        const int hdr[4] = {T->ntile, G, kLaneWaves, kProbeSlots};
-        const size_t rows = std::min<size_t>((size_t)kProbeWaves, (size_t)nwg * kLaneWaves * G);
-        fwrite(hdr, sizeof(int), 4, f); fwrite(h.data(), sizeof(unsigned long long), rows * kProbeSlots, f); fclose(f);
+  const dim3 tb(256);
+
+  // A solve runs in PHASES.  The first one gives every scenario of the batch a lane; whenever enough scenarios have finished to
+  // free a quarter of the groups (at least one), the iterate goes back to the scenario-major workspace and the scenarios still
+  // iterating are packed into fewer groups - a new tiling, a new graph: a launch costs what its groups cost, and a batch of year-long
+  // LPs finishes over a 4 x range of iteration counts (35 k .. 139 k on the wind + battery family).  `ids`: slot -> scenario of the
+  // current phase (empty: identity).
+  std::vector<int> ids;
+  int nact = B, period = 0;
+  S->last_phases = 0;
+  bool shared = true, first = true;
+  for (;;) {
+    const int G = (nact + 63) / 64;
+    // tiles: one wave per SIMD (1024) from 64 scenarios on - larger tiles, fewer halo rows; the next unit's rows in flight hide the
+    // latency a second wave would -, two per SIMD below and for many groups (profiles/r40y_, r40z_, r41a_lane_variants.log)
+    const int want_waves = waves_env > 0 ? waves_env : ((nact >= 64 && G <= 4) ? 1024 : 2048);
+    int rows = rows_env > 0 ? rows_env : (int)(((int64_t)m * G + want_waves - 1) / want_waves);
+    rows = std::max(rows, 3 * ch);
+    rows = (rows + ch - 1) / ch * ch;
+    LaneTiling *T = nullptr;
+    if ((e = lane_tiling(L, rows, &T)) != hipSuccess) return e;
+    // (not applicable: nothing has been touched in the first phase; later phases use a ring that scheduled before)
+    if (T->ntile == 0) return first ? hipSuccess : hipErrorUnknown;
+    // the check kernel's three windows + record stages of four waves must fit a CU's LDS (kLaneMaxRing keeps them below: defensive)
+    if ((size_t)kLaneWaves * (3 * (size_t)T->ring * 64 * sizeof(double) + kLaneStageBytes) > 160u * 1024u) return first ? hipSuccess : hipErrorUnknown;
+    if ((e = lane_records_for(L, T->ring)) != hipSuccess) return e;
+    if ((e = lane_workspace(L, nact, T->nwg, !shared, qp)) != hipSuccess) return e;
+    if (first) {
+      // bounds: one template for the whole batch (stride 0), or equal apart from the long columns' (checked on the device)
+      shared = (!a.b.var_lb || a.b.var_lb_stride == 0) && (!a.b.var_ub || a.b.var_ub_stride == 0) &&
+               (!a.b.row_lb || a.b.row_lb_stride == 0) && (!a.b.row_ub || a.b.row_ub_stride == 0);
+      if (!shared && B > 1) {
+        if ((e = hipMemsetAsync(L->W.flag, 0, sizeof(int), st)) != hipSuccess) return e;
+        hipLaunchKernelGGL(k_lane_bounds_differ, dim3((n + 255) / 256, B - 1), dim3(256), 0, st, a.W.lb, a.W.ub, n, B, L->is_long, L->W.flag);
+        hipLaunchKernelGGL(k_lane_bounds_differ, dim3((m + 255) / 256, B - 1), dim3(256), 0, st, a.W.rlo, a.W.rhi, m, B, (const uint8_t *)nullptr, L->W.flag);
+        if ((e = hipMemcpyAsync(L->flag_host, L->W.flag, sizeof(int), hipMemcpyDeviceToHost, st)) != hipSuccess) return e;
+        if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;
+        shared = *L->flag_host == 0;
+      } else shared = true;
+      if (!shared) {
+        if (qp) return hipSuccess;                                     // (no instantiation: the two-launch form takes it)
+        if ((e = lane_workspace(L, nact, T->nwg, true, qp)) != hipSuccess) return e;
       }
     }
-  }
+    LaneWork &W = L->W;
+    LaneKernel kern[3];
+    for (int mode = 0; mode < 3; ++mode) if (!(kern[mode] = lane_pick(L->plan.WC, L->plan.WR, NLP, shared, qp, mode))) return first ? hipSuccess : hipErrorUnknown;
+    *used = true;
+    ++S->last_phases;
+    S->last_bytes_per_iteration = (size_t)8 * (shared ? 4 * (size_t)n + 3 * (size_t)m : 6 * (size_t)n + 5 * (size_t)m) + (qp ? 8 * (size_t)m : 0);
+    const int *sid = nullptr;
+    if (!ids.empty()) {
+      if (L->sid_cap < B) {
+        if (L->sid) (void)hipFree(L->sid);
+        L->sid = nullptr; L->sid_cap = 0;
+        if ((e = hipMalloc((void **)&L->sid, (size_t)B * sizeof(int))) != hipSuccess) return e;
+        L->sid_cap = B;
+      }
+      if ((e = hipMemcpyAsync(L->sid, ids.data(), ids.size() * sizeof(int), hipMemcpyHostToDevice, st)) != hipSuccess) return e;
+      if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;           // (`ids` is pageable and changes below)
+      sid = L->sid;
+    }
+
+    LaneArgs la{};
+    la.P = L->P; la.P.tiles = T->tiles; la.P.units = T->units; la.P.ntile = T->ntile; la.P.ring_mask = T->ring - 1;
+    la.NLP = NLP; la.nwg = T->nwg; la.nslot = T->nwg + NLP; la.B = nact; la.kofs = 0; la.sums_only = 0; la.sid = sid;
+    la.long_id = L->long_id;
+    la.x0 = W.x0; la.c = W.c; la.y0 = W.y0; la.lb = W.lb; la.ub = W.ub; la.rlo = W.rlo; la.rhi = W.rhi; la.kap = W.kap;
+    la.xbl = W.xbl; la.xpl = W.xpl; la.lbl = W.lbl; la.ubl = W.ubl; la.xp = W.xp; la.yp = W.yp;
+    la.lpart = W.lpart; la.partial = W.partial; la.acc = W.acc; la.tau = W.tau; la.sig = W.sig; la.k = W.k; la.done = W.done; la.mode = W.mode;
+    la.x0w = W.x0; la.y0w = W.y0; la.xa = W.xA; la.ya = W.yA;
+    la.ctrl = a.W.ctrl; la.ndone = a.W.ndone; la.opt = a.opt; la.eta = a.eta; la.col_scale = S->P.col_scale;
+    la.rrec_stride = RREC; la.ral_off = L->plan.WR * 12 + 16;
+    la.iters = C;
+
+    // ---- in: scenario-major workspace -> lane layout (iterate, anchors, x+ / y+ of the last check, objective, bounds) ----------------
+    const dim3 gcol((n + 63) / 64, G), grow((m + 63) / 64, G);
+    auto in = [&](const double *src, int len, double *dst) {
+      hipLaunchKernelGGL(k_lane_in, len == n ? gcol : grow, tb, 0, st, src, (size_t)len, len, nact, sid, 0.0, dst);
+    };
+    in(a.W.x, n, W.xA); in(a.W.x0, n, W.x0); in(a.W.c, n, W.c); in(a.W.xp, n, W.xp);
+    in(a.W.y, m, W.yA); in(a.W.y0, m, W.y0); in(a.W.yp, m, W.yp);
+    if (!shared) { in(a.W.lb, n, W.lb); in(a.W.ub, n, W.ub); in(a.W.rlo, m, W.rlo); in(a.W.rhi, m, W.rhi); }
+    if (qp) in(a.W.kap, m, W.kap);
+    if (first) {
+      hipLaunchKernelGGL(k_lane_fill_records, dim3((n + 255) / 256), tb, 0, st, L->crec, CREC, L->plan.WC * 12, L->plan.WC * 12 + 16,
+                         (const double *)a.W.lb, (const double *)a.W.ub, S->P.col_scale, n);
+      hipLaunchKernelGGL(k_lane_fill_records, dim3((m + 255) / 256), tb, 0, st, L->rrec, RREC, L->plan.WR * 12, L->plan.WR * 12 + 16 + NLP * 8,
+                         (const double *)a.W.rlo, (const double *)a.W.rhi, S->P.row_scale, m);
+    }
+    if ((e = hipMemsetAsync(W.partial, 0, (size_t)G * la.nslot * kLaneNQ * 64 * sizeof(double), st)) != hipSuccess) return e;
+    hipLaunchKernelGGL(k_lane_setup, dim3(G), dim3(64), 0, st, la, (const double *)a.W.lb, (const double *)a.W.ub);
+
+    const dim3 g_tile(T->nwg, G), b_tile(kLaneWaves * 64);
+    const size_t lds_ring = (size_t)kLaneWaves * T->ring * 64 * sizeof(double);
+    const size_t lds_red = (size_t)kLaneWaves * std::max(NLP, 8) * 64 * sizeof(double);
+    const size_t lds_stage = (size_t)kLaneWaves * kLaneStageBytes;
+    const size_t lds[3] = {std::max(2 * lds_ring + lds_stage, lds_red), std::max(3 * lds_ring + lds_stage, lds_red), std::max(2 * lds_ring + lds_stage, lds_red)};
+    for (int mode = 0; mode < 3; ++mode)
+      if ((e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern[mode]), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds[mode])) != hipSuccess) return e;
+    // the long columns' partial sums of the y the phase starts from (the iterate itself stays where it is)
+    {
+      LaneArgs q = la; q.x_in = W.xA; q.y_in = W.yA; q.sums_only = 1;
+      if (NLP == 4) hipLaunchKernelGGL(k_lane_apply<4>, g_tile, b_tile, 0, st, q);
+      else hipLaunchKernelGGL(k_lane_apply<8>, g_tile, b_tile, 0, st, q);
+    }
+
+    const dim3 g_long(std::max(1, L->P.nl), G), tl(kLongWaves * 64);
+    // One check period = 2 (C - 1) + 7 launches with the same arguments every time (a period starts in buffer A and k_lane_apply
+    // leaves the iterate there): captured once into a hipGraph and replayed - a year-long solve is 10^3 .. 10^4 periods, and below
+    // ~30 us per iteration the host cannot enqueue two launches per iteration fast enough.  The legacy default stream cannot be
+    // captured: the loop then runs on the handle's own stream between two host synchronisations (the call is blocking anyway).
+    auto enqueue_period = [&](hipStream_t s) {
+      double *xcur = W.xA, *ycur = W.yA, *xalt = W.xB, *yalt = W.yB;
+      for (int u = 0; u < C - 1; ++u) {
+        LaneArgs q = la; q.kofs = u; q.x_in = xcur; q.y_in = ycur; q.x_out = xalt; q.y_out = yalt;
+        if (L->P.nl) hipLaunchKernelGGL(k_lane_long<0>, g_long, tl, 0, s, q);
+        hipLaunchKernelGGL(kern[0], g_tile, b_tile, lds[0], s, q);
+        std::swap(xcur, xalt); std::swap(ycur, yalt);
+      }
+      LaneArgs q = la; q.kofs = 0; q.x_in = xcur; q.y_in = ycur; q.x_out = xalt; q.y_out = yalt;
+      if (L->P.nl) hipLaunchKernelGGL(k_lane_long<1>, g_long, tl, 0, s, q);
+      hipLaunchKernelGGL(kern[1], g_tile, b_tile, lds[1], s, q);
+      hipLaunchKernelGGL(kern[2], g_tile, b_tile, lds[2], s, q);
+      if (L->P.nl) hipLaunchKernelGGL(k_lane_long<2>, g_long, tl, 0, s, q);
+      hipLaunchKernelGGL(k_lane_sum, dim3(13, G), tl, 0, s, q);
+      hipLaunchKernelGGL(k_lane_decide, dim3(G), dim3(64), 0, s, q);
+      LaneArgs r = la; r.x_in = xcur; r.y_in = ycur;
+      if (NLP == 4) hipLaunchKernelGGL(k_lane_apply<4>, g_tile, b_tile, 0, s, r);
+      else hipLaunchKernelGGL(k_lane_apply<8>, g_tile, b_tile, 0, s, r);
+    };
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (st) (void)hipStreamIsCapturing(st, &cap);
+    const bool use_graph = graph_env && max_periods - period > 2 && cap == hipStreamCaptureStatusNone;
+    hipStream_t ls = st;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    if (use_graph) {
+      if (!L->stream && (e = hipStreamCreateWithFlags(&L->stream, hipStreamNonBlocking)) != hipSuccess) return e;
+      ls = L->stream;
+      if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;                    // everything enqueued so far precedes the loop
+      if ((e = hipStreamBeginCapture(ls, hipStreamCaptureModeThreadLocal)) != hipSuccess) return e;
+      enqueue_period(ls);
+      if ((e = hipStreamEndCapture(ls, &graph)) != hipSuccess) return e;
+      if ((e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0)) != hipSuccess) { (void)hipGraphDestroy(graph); return e; }
+    }
+    // scenarios still iterating below which the phase ends: they fit G - max(1, G / 4) groups
+    const int shrink_at = (compact && G > 1) ? 64 * (G - std::max(1, G / 4)) : -1;
+    bool finished = false, shrink = false;
+    for (; period < max_periods;) {
+      if (use_graph) { if ((e = hipGraphLaunch(exec, ls)) != hipSuccess) break; }
+      else enqueue_period(ls);
+      ++period;
+      if (period % poll == 0 || period == max_periods) {
+        if ((e = hipMemcpyAsync(S->ndone_host, a.W.ndone, sizeof(int), hipMemcpyDeviceToHost, ls)) != hipSuccess) break;
+        if ((e = hipStreamSynchronize(ls)) != hipSuccess) break;
+        if (*S->ndone_host >= B) { finished = true; break; }
+        if (B - *S->ndone_host <= shrink_at && period < max_periods) { shrink = true; break; }
+      }
+    }
+    if (use_graph) {
+      const hipError_t es = hipStreamSynchronize(ls);
+      (void)hipGraphExecDestroy(exec); (void)hipGraphDestroy(graph);
+      if (e == hipSuccess) e = es;
+    }
+    if (e != hipSuccess) return e;
+#ifdef DSP_LANE_PROBE
+    if (const char *path = getenv("DSP_LANE_PROBE_OUT")) {
+      std::vector<unsigned long long> h((size_t)kProbeWaves * kProbeSlots);
+      (void)hipStreamSynchronize(ls);
+      if (hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(g_lane_probe), h.size() * sizeof(unsigned long long)) == hipSuccess) {
+        if (FILE *f = fopen(path, "wb")) {
+          const int nwg = (T->ntile + kLaneWaves - 1) / kLaneWaves;
+          const int hdr[4] = {T->ntile, G, kLaneWaves, kProbeSlots};
+          const size_t prow = std::min<size_t>((size_t)kProbeWaves, (size_t)nwg * kLaneWaves * G);
+          fwrite(hdr, sizeof(int), 4, f); fwrite(h.data(), sizeof(unsigned long long), prow * kProbeSlots, f); fclose(f);
+        }
+      }
+    }
 #endif
-  // ---- out: x+, y+ of the last check back to the scenario-major workspace (k_finalize unscales them) -----------------------------------
-  hipLaunchKernelGGL(k_lane_out, gcol, tb, 0, st, (const double *)W.xp, n, B, a.W.xp);
-  hipLaunchKernelGGL(k_lane_out, grow, tb, 0, st, (const double *)W.yp, m, B, a.W.yp);
+    // ---- out: x+, y+ of the last check back to the scenario-major workspace (k_finalize unscales them); between two phases also the
+    //      iterate and its anchors (buffer A: where k_lane_apply left them) -----------------------------------------------------------
+    auto out = [&](const double *src, int len, double *dst) {
+      hipLaunchKernelGGL(k_lane_out, len == n ? gcol : grow, tb, 0, st, src, len, nact, sid, dst);
+    };
+    out(W.xp, n, a.W.xp); out(W.yp, m, a.W.yp);
+    if (!shrink) break;
+    (void)finished;
+    out(W.xA, n, a.W.x); out(W.x0, n, a.W.x0); out(W.yA, m, a.W.y); out(W.y0, m, a.W.y0);
+    // the scenarios that go on, in their order
+    std::vector<int> done_h((size_t)G * 64);
+    if ((e = hipMemcpyAsync(done_h.data(), W.done, done_h.size() * sizeof(int), hipMemcpyDeviceToHost, st)) != hipSuccess) return e;
+    if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;
+    std::vector<int> next;
+    for (int slot = 0; slot < nact; ++slot) if (!done_h[slot]) next.push_back(ids.empty() ? slot : ids[slot]);
+    if (next.empty()) break;
+    ids.swap(next);
+    nact = (int)ids.size();
+    first = false;
+  }
+  *periods_run = period;
   return hipGetLastError();
 }
 

@@ -52,7 +52,7 @@ class DspStats(C.Structure):
                 ("cols_per_lane", C.c_int32), ("rows_per_lane", C.c_int32), ("kernel_ms", C.c_float),
                 ("matreg", C.c_int32), ("lds_conflicts_identity", C.c_int32), ("lds_conflicts_chosen", C.c_int32),
                 ("simplex", C.c_int32), ("streaming", C.c_int32), ("stream_bytes_per_iteration", C.c_int64),
-                ("quadratic", C.c_int32), ("precision", C.c_int32), ("rtc", C.c_int32), ("stream_form", C.c_int32)]
+                ("quadratic", C.c_int32), ("precision", C.c_int32), ("rtc", C.c_int32), ("stream_form", C.c_int32), ("stream_phases", C.c_int32)]
 
 
 class DspLpDesc(C.Structure):
@@ -84,7 +84,7 @@ EXPORTED_SYMBOLS = ("dsp_default_options", "dsp_create", "dsp_solve", "dsp_spmv_
                     "dsp_rtc_compile_check", "dsp_rtc_message", "dsp_wb_rolling_update")
 
 
-ABI_VERSION = 7          # DSP_VERSION of the include/dsp_hip.h these structures mirror
+ABI_VERSION = 8          # DSP_VERSION of the include/dsp_hip.h these structures mirror
 
 
 def load_library(path: Optional[str] = None):

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define DSP_VERSION 7
+#define DSP_VERSION 8
 
 /* return codes (0 = ok, < 0 = API misuse / HIP error; text via dsp_strerror) */
 #define DSP_OK                 0
@@ -227,6 +227,8 @@ typedef struct dsp_stats {
   int32_t precision;              /* precision the iterates were held in (dsp_options::precision)        */
   int32_t rtc;                    /* 1 = the kernel that ran was compiled at run time for this LP's shape (dsp_options::no_rtc) */
   int32_t stream_form;            /* streaming path, which form of the iteration ran (ABI 7; was reserved): DSP_STREAM_FORM_* */
+  int32_t stream_phases;          /* streaming path, lane form (ABI 8): phases the solve ran in = 1 + the number of times the scenarios
+                                     still iterating were packed into fewer groups of 64 lanes after others had finished; 0 otherwise */
 } dsp_stats;
 
 /* dsp_stats::stream_form */

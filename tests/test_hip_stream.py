@@ -146,6 +146,38 @@ def test_lane_form_with_per_scenario_bounds_and_with_soft_rows(monkeypatch):
 
 
 @gpu
+def test_lane_form_packs_the_scenarios_still_iterating_into_fewer_groups(monkeypatch):
+    """A lane-form solve of more than 64 scenarios runs in phases (dsp_stream_lane.hip: lane_run): when a quarter of its groups of 64
+    lanes could be freed, the iterate goes back to the scenario-major workspace and the scenarios still iterating are packed into
+    fewer groups (dsp_stats::stream_phases).  200 two-week design LPs (4 groups -> 3 -> 2 -> 1) against the same solve with every
+    scenario keeping its lane to the end (DSP_LANE_COMPACT=0): same terminations, same optima; a scenario's iteration count may
+    differ by a check period or two (the long columns' partial sums are added over another tiling)."""
+    from dispatches_amd import scenarios
+    from dispatches_amd.hip_solver import HipPdlpSolver
+    T, B = 336, 200
+    res = {}
+    try:
+        for packed in (True, False):
+            monkeypatch.delenv("DSP_LANE_COMPACT", raising=False)
+            if not packed:
+                monkeypatch.setenv("DSP_LANE_COMPACT", "0")
+            solver = HipPdlpSolver(device=0, check_every=64, max_iter=400_000)
+            handles, model = scenarios.price_taker_batch(T, B, solver)
+            solver.solve(model)
+            st = solver.last_stats
+            assert st.streaming == 1 and st.stream_form == 3 and (model.status == 0).all(), (packed, st.stream_form, np.bincount(model.status))
+            res[packed] = (model.objective.copy(), model.iterations.copy(), int(st.stream_phases), model.x[:, handles["battery_system_capacity"].index].copy())
+    finally:
+        monkeypatch.delenv("DSP_LANE_COMPACT", raising=False)
+    (obj_p, it_p, ph_p, cap_p), (obj_k, it_k, ph_k, cap_k) = res[True], res[False]
+    assert ph_k == 1 and 2 <= ph_p <= 4, (ph_p, ph_k)
+    assert it_p.max() > 1.5 * it_p.min()                                  # (the scenarios do finish at different times)
+    assert np.allclose(obj_p, obj_k, rtol=1e-6, atol=1e-6), np.abs(obj_p - obj_k).max()
+    assert np.allclose(cap_p, cap_k, rtol=1e-4, atol=1.0), np.abs(cap_p - cap_k).max()
+    assert (np.abs(it_p - it_k) <= 0.1 * it_k + 256).all(), (it_p, it_k)
+
+
+@gpu
 def test_lane_form_wide_records_and_eight_long_columns(monkeypatch):
     """The wide instantiations of the lane form on the device.  (a) WC = WR = 8: the two-week design LP with every row written
     TWICE (rows 2 i and 2 i + 1: the same feasible set and optimum; every column then has up to 8 short entries) through the plain
