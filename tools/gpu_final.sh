@@ -14,6 +14,7 @@ timeout 200 python bench.py --workload pem_price_taker --batch 256 --steps 50 --
 timeout 200 python bench.py --workload nuclear_price_taker --steps 12 --warmup 2 2>/dev/null | tail -1
 timeout 200 python bench.py --workload nuclear_price_taker --batch 240 --steps 12 --warmup 2 2>/dev/null | tail -1
 timeout 400 python bench.py --workload price_taker --batch 64 --solve --warmup 1 2>/dev/null | tail -1
+timeout 400 python bench.py --workload price_taker --batch 256 --solve --warmup 1 2>/dev/null | tail -1
 } > "$out/${tag}_stream_bench.jsonl"
 python - "$out/${tag}_stream_bench.jsonl" <<'PY'
 import json, sys
