@@ -972,6 +972,14 @@ __global__ void __launch_bounds__(kTB, fused_pre_waves(SG, K, MW, SHARED, QP, DE
     act[u] = b0 + u < a.b.B && !c.done;
     tau[u] = c.tau; sig[u] = c.sig; oml[u] = 1.0 / (double)(c.k + kofs + 3);
   }
+  // every scenario of the workgroup has finished: nothing to load, compute or store (uniform over the workgroup, ahead of its first
+  // barrier).  A full solve then stops paying for a scenario pair the moment both have terminated (16 year-long LPs: r41g).
+  {
+    bool any = false;
+#pragma unroll
+    for (int u = 0; u < SG; ++u) any = any || act[u];
+    if (!any) return;
+  }
   // ---- phase A: every global load of the workgroup -----------------------------------------------------------------------------
   int ik[K], jk[K];
   double yr[K][SG], y0r[K][SG], xr[K][SG], cr[K][SG], x0r[K][SG], lbr[K][SHARED ? 1 : SG], ubr[K][SHARED ? 1 : SG],
