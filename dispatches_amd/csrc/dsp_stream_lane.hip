@@ -66,7 +66,7 @@ struct LaneState {
   const int32_t *long_id = nullptr;
   const uint8_t *is_long = nullptr;     // [n]
   std::vector<void *> allocs;
-  std::map<int, LaneTiling> tilings;    // by rows per tile
+  std::map<long long, LaneTiling> tilings;   // by rows per tile (+ the ring limits of the planner)
   LaneWork W;
   int *flag_host = nullptr;
   int *sid = nullptr;                   // [sid_cap] slot -> scenario map of a compacted phase
@@ -527,7 +527,7 @@ static hipError_t lane_tiling(LaneState *L, int rows_per_tile, LaneTiling **out)
   const int ring_max = getenv("DSP_LANE_RING_MAX") ? atoi(getenv("DSP_LANE_RING_MAX")) : kLaneMaxRing;
   // from 16 slots: with 8 the units of these matrices are 60 % full, with 16 80 - 90 % (17 - 40 % fewer units; r40x_lane_variants.log)
   const int ring_min = getenv("DSP_LANE_RING_MIN") ? atoi(getenv("DSP_LANE_RING_MIN")) : 16;
-  const int key = rows_per_tile * 4096 + std::min(ring_max, 63) * 64 + std::min(ring_min, 63);
+  const long long key = (long long)rows_per_tile * 4096 + std::min(ring_max, 63) * 64 + std::min(ring_min, 63);
   auto it = L->tilings.find(key);
   if (it == L->tilings.end()) {
     const HostLaneTiles T = build_lane_tiles(L->plan, rows_per_tile, lane_ch(L->plan.WC, L->plan.WR, L->plan.NLP), ring_min, ring_max);
