@@ -146,18 +146,18 @@ struct LaneTile {
 #if defined(__HIP_DEVICE_COMPILE__)
     r.cq = *reinterpret_cast<const LaneQuad *>(P.crec + ((uint32_t)q.cx0 * (uint32_t)CREC + (uint32_t)lane * 16u));
     if (MODE != 2) r.rq = *reinterpret_cast<const LaneQuad *>(P.rrec + ((uint32_t)q.rd0 * (uint32_t)RREC + (uint32_t)lane * 16u));
-    // An idle lane's loads all go to element 0 of lane 0 - ONE line per instruction next to the active lanes' - instead of sitting
-    // behind a branch on EXEC: with the branch the number of loads in flight depends on the path, and the compiler's wait before the
-    // first use of this unit's registers becomes a wait for every load issued so far (vmcnt(1) on the merge; r40u), i.e. also for
-    // the rows of the NEXT unit that were requested to overlap with this one's arithmetic.
-    const uint32_t am = active ? 0xffffffffu : 0u, l8 = active ? (uint32_t)lane * 8u : 0u;
+    // An idle lane loads what lane 0 loads - the same 8 bytes of the same row, already part of the active lanes' line: no traffic of
+    // its own - instead of sitting behind a branch on EXEC: with the branch the number of loads in flight depends on the path, and
+    // the compiler's wait before the first use of this unit's registers becomes a wait for every load issued so far (vmcnt(1) on the
+    // merge; r40u), i.e. also for the rows of the NEXT unit that were requested to overlap with this one's arithmetic.
+    const uint32_t l8 = active ? (uint32_t)lane * 8u : 0u;
 #else
     (void)P;
     if (!active) return;
-    const uint32_t am = 0xffffffffu, l8 = (uint32_t)lane * 8u;
+    const uint32_t l8 = (uint32_t)lane * 8u;
 #endif
     auto ld = [&](const double *base, int e) -> double {
-      return *reinterpret_cast<const double *>(reinterpret_cast<const char *>(base) + ((((uint32_t)e * 512u) & am) | l8));
+      return *reinterpret_cast<const double *>(reinterpret_cast<const char *>(base) + (((uint32_t)e * 512u) | l8));
     };
 #pragma unroll
     for (int k = 0; k < CH; ++k) r.ys[k] = ld(MODE == 2 ? G.yp : G.y_in, q.ys0 + (k < q.nys ? k : 0));
