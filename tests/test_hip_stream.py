@@ -146,15 +146,17 @@ def test_lane_form_with_per_scenario_bounds_and_with_soft_rows(monkeypatch):
 
 
 @gpu
-def test_lane_form_packs_the_scenarios_still_iterating_into_fewer_groups(monkeypatch):
+@pytest.mark.parametrize("B,bounds", [(200, "shared"), (130, "per_scenario")])
+def test_lane_form_packs_the_scenarios_still_iterating_into_fewer_groups(monkeypatch, B, bounds):
     """A lane-form solve of more than 64 scenarios runs in phases (dsp_stream_lane.hip: lane_run): when a quarter of its groups of 64
     lanes could be freed, the iterate goes back to the scenario-major workspace and the scenarios still iterating are packed into
-    fewer groups (dsp_stats::stream_phases).  200 two-week design LPs (4 groups -> 3 -> 2 -> 1) against the same solve with every
-    scenario keeping its lane to the end (DSP_LANE_COMPACT=0): same terminations, same optima; a scenario's iteration count may
-    differ by a check period or two (the long columns' partial sums are added over another tiling)."""
+    fewer groups (dsp_stats::stream_phases).  200 two-week design LPs (4 groups -> 3 -> 2 -> 1), and 130 (a last group of 2 lanes)
+    with a grid-connection limit per member (bounds read per lane: they move with their scenario), against the same solve with
+    every scenario keeping its lane to the end (DSP_LANE_COMPACT=0): same terminations, same optima; a scenario's iteration count
+    may differ by a check period or two (the long columns' partial sums are added over another tiling)."""
     from dispatches_amd import scenarios
     from dispatches_amd.hip_solver import HipPdlpSolver
-    T, B = 336, 200
+    T = 336
     res = {}
     try:
         for packed in (True, False):
@@ -163,9 +165,17 @@ def test_lane_form_packs_the_scenarios_still_iterating_into_fewer_groups(monkeyp
                 monkeypatch.setenv("DSP_LANE_COMPACT", "0")
             solver = HipPdlpSolver(device=0, check_every=64, max_iter=400_000)
             handles, model = scenarios.price_taker_batch(T, B, solver)
+            if bounds == "per_scenario":
+                lb, ub, _, _ = model.block.current_bounds()
+                model.lb, model.ub = np.tile(lb, (B, 1)), np.tile(ub, (B, 1))
+                cols = [j for j, name in enumerate(model.lp.col_names) if name.startswith("splitter.grid_elec[")]
+                for k in range(B):
+                    model.ub[k, cols] = 847.0e3 * (0.55 + 0.4 * ((37 * k) % B) / B)      # kW: binding for the smaller ones
             solver.solve(model)
             st = solver.last_stats
             assert st.streaming == 1 and st.stream_form == 3 and (model.status == 0).all(), (packed, st.stream_form, np.bincount(model.status))
+            n, m = model.lp.n, model.lp.m
+            assert st.stream_bytes_per_iteration == (8 * (4 * n + 3 * m) if bounds == "shared" else 8 * (6 * n + 5 * m))
             res[packed] = (model.objective.copy(), model.iterations.copy(), int(st.stream_phases), model.x[:, handles["battery_system_capacity"].index].copy())
     finally:
         monkeypatch.delenv("DSP_LANE_COMPACT", raising=False)
@@ -175,6 +185,8 @@ def test_lane_form_packs_the_scenarios_still_iterating_into_fewer_groups(monkeyp
     assert np.allclose(obj_p, obj_k, rtol=1e-6, atol=1e-6), np.abs(obj_p - obj_k).max()
     assert np.allclose(cap_p, cap_k, rtol=1e-4, atol=1.0), np.abs(cap_p - cap_k).max()
     assert (np.abs(it_p - it_k) <= 0.1 * it_k + 256).all(), (it_p, it_k)
+    if bounds == "per_scenario":
+        assert len(set(np.round(obj_p, 4))) > B // 2                      # the limits bind differently
 
 
 @gpu
