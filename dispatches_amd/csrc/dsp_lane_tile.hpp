@@ -9,8 +9,9 @@
 // RECORDS.  What depends on the element only - matrix entries, their indices, shared bounds, scale factors - is one record per
 // column (CREC bytes) and one per row (RREC bytes), contiguous in element order:
 //     column  val[WC] | idx[WC] | lb, ub | col_scale, -            row  val[WR] | idx[WR] | rlo, rhi | al[NLP] | row_scale, -
-// (idx: row / column indices of the SHORT entries, stored as index << 9 = the byte offset of the index's ring slot before masking;
-// padding entries repeat the first one with value 0; the sign bit of a column's idx[0] marks a long column; al: the row's coefficients on the long columns.)  A unit's records are one contiguous block per kind, so
+// (idx: row / column indices of the SHORT entries, stored as the byte offset of the index's ring slot, (index & ring mask) << 9 - the
+// records are packed for the ring of the tiling in use; padding entries repeat the first one with value 0; the sign bit of a column's
+// idx[0] marks a long column; al: the row's coefficients on the long columns.)  A unit's records are one contiguous block per kind, so
 // the wave fetches them with ONE 16-byte-per-lane load each, together with the unit's rows of x, c, y ... one unit ahead, parks them
 // in its LDS stage when the unit's turn comes, and every lane reads the same 16 bytes back (broadcast ds_read_b128).  The first
 // version read the records through the scalar unit: each record was a scalar-cache miss (~0.25 us) behind an s_waitcnt lgkmcnt(0)
@@ -112,7 +113,7 @@ struct LaneGroup {                   // one scenario group's block of every arra
 };
 
 // active: the lane has a scenario that is still iterating.  Lanes without one take part in fetching and parking the unit's records
-// (a wave's 16-byte-per-lane block) and in nothing else: none of their loads or stores reaches the memory system.
+// (a wave's 16-byte-per-lane block), load what lane 0 loads (load_regs) and store nothing.
 struct LaneScalars { double tau, sig, oml; bool done, active; };
 
 // per-lane result of a tile: lp[l] = the tile's part of (A^T y)_long_l; v[0 .. 12] the check sums (MODE 1: 0 .. 7, MODE 2: 8 .. 12)
