@@ -3,8 +3,8 @@
 // Same algorithm, same check sums, same restart / termination decision (control_decide, dsp_stream.hpp) as dsp_stream.hip; what
 // changes is who does what.  The batch lives scenario-minor - group g, element e, lane s at ((g (len + 1) + e) 64 + s) - and lane
 // s of a wave owns scenario s of its group: it walks through a tile of consecutive rows and columns alone (dsp_lane_tile.hpp), the
-// matrix, the shared bounds and every index come through the scalar unit, both products gather from lane-private ring buffers in
-// LDS, and no lane ever needs another lane's value.  A workgroup is 4 waves = 4 neighbouring tiles that meet once, at the end, to
+// matrix, the shared bounds and every index come as per-element RECORDS (one 16-byte-per-lane load per unit, parked in LDS and read
+// back as broadcasts), both products gather from lane-private ring buffers in LDS, and no lane ever needs another lane's value.  A workgroup is 4 waves = 4 neighbouring tiles that meet once, at the end, to
 // add their partial sums (of A^T y for the long columns; of the check sums at a check).  Plan and applicability: dsp_lane_plan.hpp.
 //
 // Per plain iteration, two launches:
@@ -13,7 +13,8 @@
 // Per check (every `check_every` iterations): k_lane_long<1>, k_lane<.., 1> (x+, y+, residual and row sums), k_lane<.., 2>
 // (reduced costs), k_lane_long<2>, k_lane_sum, k_lane_decide, k_lane_apply - all on the device; the host enqueues and polls the
 // finished-counter every few periods, exactly as before.  Initialisation and results go through the scenario-major workspace of
-// dsp_stream.hip (k_init, k_init_control, k_finalize) and two transposing kernels.
+// dsp_stream.hip (k_init, k_init_control, k_finalize) and two transposing kernels.  A solve of more than 64 scenarios runs in
+// PHASES (lane_run): when enough scenarios have finished, the rest goes through the scenario-major workspace into fewer groups.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
