@@ -619,9 +619,12 @@ hipError_t lane_run(StreamSolver *S, StreamArgs &a, hipStream_t st, int *periods
   bool shared = true, first = true;
   for (;;) {
     const int G = (nact + 63) / 64;
-    // tiles: one wave per SIMD (1024) from 64 scenarios on - larger tiles, fewer halo rows; the next unit's rows in flight hide the
-    // latency a second wave would -, two per SIMD below and for many groups (profiles/r40y_, r40z_, r41a_lane_variants.log)
-    const int want_waves = waves_env > 0 ? waves_env : ((nact >= 64 && G <= 4) ? 1024 : 2048);
+    // tiles: one wave per SIMD (1024 tiles) for a single group of 40 scenarios and more (~50 rows per wave), two waves per SIMD (2048
+    // tiles) otherwise - fewer scenarios (less to fetch per unit: the second wave hides more than the extra halo rows cost), 2 - 3
+    // groups (7 % / 2 % ahead), 8 and more (3 - 4 %).  Four groups: a tie in time (172 vs 172 us, 164 vs 156 - 172 across boxes), and
+    // 1024 tiles move 1.01 x the algorithmic bytes against 1.12 x: 1024.  (profiles/r40y_, r40z_, r41a_lane_variants.log,
+    // r41l_large_batches.log, r41m_mid_batches.log, r41n_*)
+    const int want_waves = waves_env > 0 ? waves_env : (((G == 1 && nact >= 40) || G == 4) ? 1024 : 2048);
     int rows = rows_env > 0 ? rows_env : (int)(((int64_t)m * G + want_waves - 1) / want_waves);
     rows = std::max(rows, 3 * ch);
     rows = (rows + ch - 1) / ch * ch;
