@@ -1,5 +1,5 @@
 #!/bin/bash
-# Time stamps of the lane kernel's waves:  bash tools/gpu_lane_probe.sh <tag>   (needs libdsp_probe1.so / libdsp_probe2.so:
+# Time stamps of the lane kernel's waves:  bash tools/build_lane_probe.sh (here), then gpurun -- bash tools/gpu_lane_probe.sh <tag>
 #   hipcc ... -DDSP_LANE_PROBE=1|2 -c csrc/dsp_stream_lane.hip, linked with the other objects of _build/)
 tag=${1:-probe}
 repo="$(cd "$(dirname "$0")/.." && pwd)"; out="$repo/gpurun_out"; mkdir -p "$out"; cd "$repo"
