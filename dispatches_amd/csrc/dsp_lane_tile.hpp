@@ -40,11 +40,30 @@ namespace dsp {
 // DSP_LANE_PROBE (measurement build only; tools/gpu_lane_probe.sh): every wave of the plain-iteration kernel leaves time stamps of
 // its walk - start, per unit (before its loads are requested, after its arithmetic), before and after the workgroup's barrier - in a
 // device array the host writes to $DSP_LANE_PROBE_OUT after the solve.  1: stamps only; 2: + a full wait after each unit's loads
-// (splits a unit into "waiting for memory" and "arithmetic + LDS").
+// (splits a unit into "waiting for memory" and "arithmetic + LDS"); 1 and 2 walk with one register set, 3: stamps in the product's
+// two-register-set walk.
 #if defined(DSP_LANE_PROBE) && defined(__HIPCC__)
 constexpr int kProbeWaves = 16384, kProbeSlots = 128;     // per wave: [0] wall clock at start, [1] clock at start, [2] units, [3] hw id,
                                                           // [4] end of walk, [5] after barrier, [6] end, [7] wall clock at end, [8 + 3 u ..] per unit
 __device__ unsigned long long g_lane_probe[(size_t)kProbeWaves * kProbeSlots];
+#endif
+
+// (probe 3: stamps in the two-register-set walk - [8 + 3 u] before the next unit's rows are requested, [8 + 3 u + 2] after the unit's
+//  arithmetic)
+#if defined(DSP_LANE_PROBE) && defined(__HIP_DEVICE_COMPILE__)
+#define DSP_LANE_STAMP(U, Q)                                                                                                              \
+  do {                                                                                                                                    \
+    if (DSP_LANE_PROBE >= 3 && MODE == 0 && lane == 0) {                                                                                  \
+      const size_t pw_ = (size_t)((blockIdx.y * gridDim.x + blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6));                        \
+      const int ps_ = 8 + 3 * ((U) - ubeg) + (Q);                                                                                         \
+      if (pw_ < (size_t)kProbeWaves - 1 && ps_ < kProbeSlots) {                                                                           \
+        g_lane_probe[pw_ * kProbeSlots + ps_] = clock64();                                                                                \
+        if ((Q) == 2) g_lane_probe[pw_ * kProbeSlots + 2] = (unsigned long long)((U) - ubeg + 1);                                         \
+      }                                                                                                                                   \
+    }                                                                                                                                     \
+  } while (0)
+#else
+#define DSP_LANE_STAMP(U, Q) do { } while (0)
 #endif
 
 template <int N> struct LaneVecD { double v[N]; };
@@ -386,7 +405,7 @@ struct LaneTile {
     }
 #pragma unroll
     for (int q = 0; q < 13; ++q) out.v[q] = 0.0;
-#if defined(DSP_LANE_NO_PREFETCH) || defined(DSP_LANE_PROBE)
+#if defined(DSP_LANE_NO_PREFETCH) || (defined(DSP_LANE_PROBE) && DSP_LANE_PROBE < 3)
     // one register set, a unit's rows requested right before its arithmetic (measurement variant; the probe build)
     const int R = P.ring_mask + 1;
     for (int s = 0; s < (MODE == 1 ? 3 : 2) * R; ++s) ring[(size_t)s * 64 + lane] = 0.0;
@@ -423,13 +442,17 @@ struct LaneTile {
     for (int s = 0; s < (MODE == 1 ? 3 : 2) * R; ++s) ring[(size_t)s * 64 + lane] = 0.0;
     for (int u = ubeg; u < uend; u += 2) {
       qn = load_unit(P, u + 2 < uend ? u + 2 : u);                // descriptors two units ahead, rows one unit ahead
+      DSP_LANE_STAMP(u, 0);
       if (u + 1 < uend) load_regs(P, G, qb, lane, sc.active, rb);
       compute(P, G, qa, ra, sc, j0, j1, lane, ring, stage, xbl, xpl, out);
+      DSP_LANE_STAMP(u, 2);
       if (u + 1 >= uend) break;
       qa = qn;
       qn = load_unit(P, u + 3 < uend ? u + 3 : u);
+      DSP_LANE_STAMP(u + 1, 0);
       if (u + 2 < uend) load_regs(P, G, qa, lane, sc.active, ra);
       compute(P, G, qb, rb, sc, j0, j1, lane, ring, stage, xbl, xpl, out);
+      DSP_LANE_STAMP(u + 1, 2);
       qb = qn;
     }
 #endif
