@@ -29,6 +29,7 @@
 namespace dsp {
 
 constexpr int kLaneMaxLong = 8;          // long columns the lane form carries
+constexpr int kLaneTileInts = 16;        // ints per entry of the tile table (dsp_lane_tile.hpp reads an entry as ONE 64-byte scalar load)
 // largest ring (slots per window) the planner tries: the check kernel keeps THREE windows per wave, four waves per workgroup -
 // 3 x 16 x 512 B x 4 + the record stages = 104 KB of a CU's 160 KB of LDS; 32 slots (200 KB) would not launch.  A band that needs
 // more is not scheduled: the handle keeps the other forms.
@@ -159,7 +160,8 @@ inline void set_lane_record_bounds(const HostLanePlan &P, std::vector<char> &cre
   }
 }
 
-// Tiles + their walks.  tiles[8 t ..]: i0, i1 (own rows), j0, j1 (own columns), first unit, one past the last unit, c_lo, r_lo.
+// Tiles + their walks.  tiles[16 t ..]: i0, i1 (own rows), j0, j1 (own columns), first unit, one past the last unit, c_lo, r_lo, then
+// the first unit's six numbers (a copy) and two spare ints.
 // units[8 u ..]: ys0, nys (rows whose y is staged into the ring), cx0, ncx (columns whose primal step is computed: own ones are
 // written, halo ones only feed the window), rd0, nrd (own rows whose dual step is computed); counts <= CH; a start with count 0
 // is still a valid index (the kernel's loads are unconditional, to clamped addresses).
@@ -176,7 +178,7 @@ inline HostLaneTiles build_lane_tiles_ring(const HostLanePlan &P, int rows_per_t
   const int n = P.n, m = P.m;
   const int RB = std::max(1, rows_per_tile);
   const int ntile = (m + RB - 1) / RB;
-  std::vector<int32_t> tiles((size_t)ntile * 8), units;
+  std::vector<int32_t> tiles((size_t)ntile * kLaneTileInts, 0), units;
   int max_units = 0;
   int64_t halo = 0;
   for (int t = 0; t < ntile; ++t) {
@@ -208,8 +210,10 @@ inline HostLaneTiles build_lane_tiles_ring(const HostLanePlan &P, int rows_per_t
     const int uend = (int)(units.size() / 8);
     max_units = std::max(max_units, uend - ubeg);
     halo += (r_hi - r_lo) - (i1 - i0) + 2 * ((c_hi - c_lo) - (j1 - j0));
-    int32_t *tp = &tiles[(size_t)t * 8];
+    int32_t *tp = &tiles[(size_t)t * kLaneTileInts];
     tp[0] = i0; tp[1] = i1; tp[2] = j0; tp[3] = j1; tp[4] = ubeg; tp[5] = uend; tp[6] = c_lo; tp[7] = r_lo;
+    // the walk's first unit rides along: the wave has it with the tile's entry instead of after a second, dependent scalar load
+    for (int q = 0; q < 6; ++q) tp[8 + q] = uend > ubeg ? units[(size_t)ubeg * 8 + q] : 0;
   }
   T.ok = true; T.ntile = ntile; T.rows_per_tile = RB; T.CH = CH; T.ring = R; T.nunit = (int)(units.size() / 8);
   T.max_units = max_units; T.halo_rows = (double)halo / (7.0 * std::max(1, m));

@@ -117,7 +117,7 @@ DSP_LANE_HD bool lane_finite(double v) { return fabs(v) < INFINITY; }
 struct LaneProblem {                 // per handle (+ the shared bounds of the solve, written into the records)
   int n, m, nl;
   const char *crec, *rrec;                       // [n] column records, [m] row records (+ 1 KiB of slack behind each)
-  const int32_t *tiles, *units;                  // [ntile][8], [nunit][8]
+  const int32_t *tiles, *units;                  // [ntile][16] (dsp_lane_plan.hpp: kLaneTileInts), [nunit][8]
   int ntile, ring_mask;
 };
 
@@ -393,8 +393,15 @@ struct LaneTile {
   static DSP_LANE_HD void run(const LaneProblem &P, const LaneGroup &G, int tile, int lane, const LaneScalars &sc_in, double *ring, char *stage,
                               LaneOut<NLP> &out) {
     LaneScalars sc = sc_in;
-    const LaneVecI<8> tp = ldu(reinterpret_cast<const LaneVecI<8> *>(P.tiles) + tile);
+    // the rings start from zeros: a padding entry of an empty vector multiplies whatever its slot holds by 0 (first thing: nothing
+    // here waits for a load)
+    const int R = P.ring_mask + 1;
+    for (int s = 0; s < (MODE == 1 ? 3 : 2) * R; ++s) ring[(size_t)s * 64 + lane] = 0.0;
+    // the tile's entry brings the walk's first unit with it (one 64-byte scalar load)
+    const LaneVecI<16> tp = ldu(reinterpret_cast<const LaneVecI<16> *>(P.tiles) + tile);
     const int j0 = tp.v[2], j1 = tp.v[3], ubeg = tp.v[4], uend = tp.v[5];
+    Unit first;
+    first.ys0 = tp.v[8]; first.nys = tp.v[9]; first.cx0 = tp.v[10]; first.ncx = tp.v[11]; first.rd0 = tp.v[12]; first.nrd = tp.v[13];
     const uint32_t l8 = (uint32_t)lane * 8u;
     double xbl[NLP], xpl[NLP];
 #pragma unroll
@@ -407,15 +414,13 @@ struct LaneTile {
     for (int q = 0; q < 13; ++q) out.v[q] = 0.0;
 #if defined(DSP_LANE_NO_PREFETCH) || (defined(DSP_LANE_PROBE) && DSP_LANE_PROBE < 3)
     // one register set, a unit's rows requested right before its arithmetic (measurement variant; the probe build)
-    const int R = P.ring_mask + 1;
-    for (int s = 0; s < (MODE == 1 ? 3 : 2) * R; ++s) ring[(size_t)s * 64 + lane] = 0.0;
     for (int u = ubeg; u < uend; ++u) {
 #if defined(DSP_LANE_PROBE) && defined(__HIP_DEVICE_COMPILE__)
       unsigned long long *pw = g_lane_probe + (size_t)((blockIdx.y * gridDim.x + blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6)) * kProbeSlots;
       const bool pon = MODE == 0 && lane == 0 && (size_t)(pw - g_lane_probe) < (size_t)(kProbeWaves - 1) * kProbeSlots && 8 + 3 * (u - ubeg) + 2 < kProbeSlots;
       if (pon) pw[8 + 3 * (u - ubeg)] = clock64();
 #endif
-      const Unit qa = load_unit(P, u);
+      const Unit qa = u == ubeg ? first : load_unit(P, u);
       Regs ra;
       load_regs(P, G, qa, lane, sc.active, ra);
 #if defined(DSP_LANE_PROBE) && defined(__HIP_DEVICE_COMPILE__)
@@ -431,15 +436,12 @@ struct LaneTile {
     // the loop unrolled by two so that no register moves between the sets.  This pays only since the loads are unconditional
     // (load_regs: an idle lane's go to one line): behind a branch on EXEC the wait before unit u's first use was a wait for u + 1's
     // rows as well.  B = 64: 47.3 -> 43.2 us, B = 16: 45.2 -> 37.3 us per iteration (profiles/r41a_lane_variants.log).
-    Unit qa = load_unit(P, ubeg), qb = load_unit(P, ubeg + 1 < uend ? ubeg + 1 : ubeg), qn = qa;
+    Unit qa = first, qb = load_unit(P, ubeg + 1 < uend ? ubeg + 1 : ubeg), qn = qa;
     Regs ra, rb;
     load_regs(P, G, qa, lane, sc.active, ra);
 #pragma unroll
     for (int l = 0; l < NLP; ++l) { lane_pin(xbl[l]); if (MODE == 1) lane_pin(xpl[l]); }
     lane_pin(sc.tau); lane_pin(sc.sig); lane_pin(sc.oml);
-    // the rings start from zeros: a padding entry of an empty vector multiplies whatever its slot holds by 0
-    const int R = P.ring_mask + 1;
-    for (int s = 0; s < (MODE == 1 ? 3 : 2) * R; ++s) ring[(size_t)s * 64 + lane] = 0.0;
     for (int u = ubeg; u < uend; u += 2) {
       qn = load_unit(P, u + 2 < uend ? u + 2 : u);                // descriptors two units ahead, rows one unit ahead
       DSP_LANE_STAMP(u, 0);

@@ -36,6 +36,7 @@ constexpr int kLaneWaves = 4;           // waves (= tiles) per workgroup (8 meas
 // with one or two register sets: profiles/r40e_, r41a_lane_variants.log)
 constexpr int lane_ch(int, int, int) { return 4; }
 constexpr int kLaneNQ = 16;             // check-sum slots per (group, workgroup)
+static_assert(kLaneTileInts == 16, "LaneTile::run reads a tile's entry as LaneVecI<16>");
 
 struct LaneTiling {                     // device copy of one tiling (dsp_lane_plan.hpp: HostLaneTiles)
   int ntile = 0, nwg = 0, ring = 0, rows_per_tile = 0;
@@ -390,7 +391,7 @@ __global__ void __launch_bounds__(kLaneWaves * 64) k_lane_apply(LaneArgs a) {
 #pragma unroll
   for (int l = 0; l < NLP; ++l) lp[l] = 0.0;
   if (tile < a.P.ntile && !done) {                   // (lanes whose scenario has finished: no loads, no stores, zero sums)
-    const LaneVecI<8> tp = ldu(reinterpret_cast<const LaneVecI<8> *>(a.P.tiles) + tile);
+    const LaneVecI<8> tp = ldu(reinterpret_cast<const LaneVecI<8> *>(a.P.tiles + (size_t)tile * kLaneTileInts));
     const int i0 = tp.v[0], i1 = tp.v[1], j0 = tp.v[2], j1 = tp.v[3];
     constexpr int U = 8;
     for (int b = j0; b < j1 && !keep; b += U) {

@@ -100,7 +100,7 @@ static int run_all(Problem &Q) {
       double aty = 0.0;                                    // sum over the tiles of their rows' terms, tile by tile
       for (int t = 0; t < T.ntile; ++t) {
         double part = 0.0;
-        for (int i = T.tiles[8 * t]; i < T.tiles[8 * t + 1]; ++i) part = std::fma(H.ral[(size_t)i * NLP + l], X(Q.y, i, s), part);
+        for (int i = T.tiles[kLaneTileInts * t]; i < T.tiles[kLaneTileInts * t + 1]; ++i) part = std::fma(H.ral[(size_t)i * NLP + l], X(Q.y, i, s), part);
         aty += part;
       }
       const double x = X(Q.x, j, s);
