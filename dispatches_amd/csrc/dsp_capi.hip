@@ -261,9 +261,16 @@ void dsp_default_options(dsp_options *o) {
   o->precision = 0;
   o->polish_patience = 1024;
   o->no_rtc = 0;
+  o->eps_infeasible = 1e-6;
 }
 
 int dsp_version(void) { return DSP_VERSION; }
+#ifndef DSP_SOURCE_HASH
+#define DSP_SOURCE_HASH "unknown"
+#endif
+// (tagged, so that a build script can read it from the file without loading the library: __graft_entry__._stale)
+static const char kSourceHashTag[] = "dsp_source_hash=" DSP_SOURCE_HASH;
+const char *dsp_source_hash(void) { return kSourceHashTag + 16; }
 int dsp_last_hip_error(void) { return g_last_hip_error; }
 
 const char *dsp_strerror(int code) {
@@ -443,7 +450,7 @@ int dsp_solve(dsp_handle *h, const dsp_batch *batch, const dsp_options *opt, dsp
   SolveArgs a{};
   a.P = h->P; a.b = *batch;
   a.opt = opt ? *opt : h->opt;
-  if (a.opt.max_iter < 1 || a.opt.check_every < 0 || a.opt.kkt_every < 0 || !(a.opt.kkt_gate >= 0) || a.opt.stall_rescue < 0 || a.opt.polish_patience < 0 || !(a.opt.jump_rel >= 0) || !(a.opt.eps_rel > 0) || !(a.opt.eps_obj >= 0) ||
+  if (a.opt.max_iter < 1 || a.opt.check_every < 0 || a.opt.kkt_every < 0 || !(a.opt.kkt_gate >= 0) || a.opt.stall_rescue < 0 || a.opt.polish_patience < 0 || !(a.opt.jump_rel >= 0) || !(a.opt.eps_rel > 0) || !(a.opt.eps_obj >= 0) || !(a.opt.eps_infeasible >= 0) ||
       !(a.opt.pid_kp >= 0) || !(a.opt.restart_artificial >= 0) || !(a.opt.step_scale > 0))
     return DSP_ERR_INVALID;
   a.eta = a.opt.step_scale * h->eta_unit;

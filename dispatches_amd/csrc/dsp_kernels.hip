@@ -494,6 +494,7 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
     int stalls = 0;                  // restarts forced after >= stall_rescue iterations without decay
     bool waive_obj = false;          // stalled twice: terminate on the eps_rel tests alone
     bool lastjump = false;           // the last restart of the anchor was a ray jump
+    bool suspect = false;            // the last KKT test found the objectives drifting apart: certificates at every 4th check
     pol_best.set(INFINITY);          // polish phase (eps_rel tests hold, eps_obj tests missing): best worst-ratio seen,
     int pol_it = 0, nboost = 0;      //   the iteration it was seen at, guard tightenings so far
     bool pol_tried = false;          //   the guard test of this stagnation period has been made
@@ -606,9 +607,9 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
         // ---- KKT test at (x+, y+) in the ORIGINAL (unscaled) space: 7 reductions + two SpMVs, so it is scheduled from
         // r, which the restart test has anyway (see dsp_options::kkt_gate); kkt_gate = 0: every kkt_every-th check
         ++ncheck;
-        const bool kkt_now = a.opt.kkt_gate > 0.0
-                                 ? (ncheck - last_kkt >= (last_kkt ? kkt_every : min(4, kkt_every)) || r <= gate2)
-                                 : (ncheck % kkt_every) == 0;
+        const bool kkt_now = (a.opt.kkt_gate > 0.0
+                                  ? (ncheck - last_kkt >= (last_kkt ? kkt_every : min(4, kkt_every)) || r <= gate2)
+                                  : (ncheck % kkt_every) == 0) || (suspect && (ncheck & 3) == 0);
         DSP_PROF_ADD(1)
         if (kkt_now) {
 #pragma unroll
@@ -670,6 +671,63 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
           const double rd = sqrt(red[1]) / (1.0 + cn.get());
           const double gap = fabs(po - dobj);
           const double rg = gap / (1.0 + fabs(po) + fabs(dobj));
+          // ---- infeasibility / unboundedness certificates (dsp_options::eps_infeasible) ---------------------------------------
+          // An LP without a solution has no fixed point: T(z) - z tends to a ray (dx, dy), one of the objectives runs away and the
+          // relative gap goes to 1.  On the bidding LPs of every workload the gap is below 1/2 by the 8th check (lab:
+          // tools/infeas_lab.py, no test at all on 4 x 64 feasible scenarios), so feasible batches pay one comparison per KKT
+          // test.  dy, with the signs its rows cannot take removed, is tested as a FARKAS RAY (reduced costs -A'dy absorbed by
+          // finite column bounds, bound value > 0); dx, clipped to the recession cone of the column bounds, as a direction of
+          // UNBOUNDED descent (c.dx < 0, A dx in the recession cone of the rows).  Both are proofs up to the tolerance whatever
+          // the iterate; scaled space (diagonal scalings map the cones onto themselves).  Soft rows (QP) admit no multiplier ray
+          // and count as equalities for the recession cone.  Lab: a 24-h bidding LP with 10 x the battery as initial charge is
+          // certified at iteration 192, unbounded variants at 0.8 - 2.5 k (five of six; the rest of the LP keeps converging
+          // underneath the ray, and its movement counts as violation until it has).
+          suspect = a.opt.eps_infeasible > 0.0 && rg >= 0.5 && ncheck >= 8;
+          if (suspect) {
+            double rr[6] = {0, 0, 0, 0, 0, 0};   // 0 |dual residual of the ray|^2, 1 its bound value, 2 |bounds|^2, 3 |recession violation|^2, 4 c.d, 5 |c|^2
+#pragma unroll
+            for (int q = 0; q < RPL; ++q) {
+              const double dy = yp[q] - y[q];
+              const double rlo_q = rlo[q].get(), rhi_q = rhi[q].get();
+              double yc = (is_finite(rlo_q) ? fmax(dy, 0.0) : 0.0) - (is_finite(rhi_q) ? fmax(-dy, 0.0) : 0.0);
+              if constexpr (QP) { if (kap[q] > 0.0) yc = 0.0; }
+              lds_store_f64(yw[q], yc);
+              rr[1] += fmax(yc, 0.0) * finite_or_zero(rlo_q) - fmax(-yc, 0.0) * finite_or_zero(rhi_q);
+              const double big = fmax(fabs(finite_or_zero(rlo_q)), fabs(finite_or_zero(rhi_q)));
+              rr[2] = fma(big, big, rr[2]);
+            }
+            wave_lds_fence();
+            col_step(atyp, zero_c, tau);                   // tau A^T (cleaned dy)
+#pragma unroll
+            for (int q = 0; q < CPL; ++q) {
+              const double lbq = lb[q], ubq = ub[q];
+              const bool fl = is_finite(lbq), fu = is_finite(ubq);
+              const double rc = -(itau * atyp[q]);
+              const double lp = fl ? fmax(rc, 0.0) : 0.0, lm = fu ? fmax(-rc, 0.0) : 0.0;
+              const double res = rc - lp + lm;
+              rr[0] = fma(res, res, rr[0]);
+              rr[1] += lp * finite_or_zero(lbq) - lm * finite_or_zero(ubq);
+              const double lf = finite_or_zero(lbq), uf = finite_or_zero(ubq);
+              rr[2] += lf * lf + uf * uf;
+              const double dx = xp[q] - x[q];
+              const double d = (fl && fu) ? 0.0 : fl ? fmax(dx, 0.0) : fu ? fmin(dx, 0.0) : dx;
+              lds_store_f64(xw[q], d);
+              rr[4] = fma(c[q], d, rr[4]);
+              rr[5] = fma(c[q], c[q], rr[5]);
+            }
+            wave_lds_fence();
+            row_step(axp, zero_r, -sig);                   // -sig A (clipped dx)
+#pragma unroll
+            for (int q = 0; q < RPL; ++q) {
+              const double ad = nisig * axp[q];
+              const double rv = (is_finite(rlo[q].get()) ? fmax(-ad, 0.0) : 0.0) + (is_finite(rhi[q].get()) ? fmax(ad, 0.0) : 0.0);
+              rr[3] = fma(rv, rv, rr[3]);
+            }
+            wave_sums<6>(rr);
+            const double ei = a.opt.eps_infeasible;
+            if (rr[1] > 0.0 && sqrt(rr[0]) * (1.0 + sqrt(rr[2])) <= ei * rr[1]) { status = DSP_STATUS_PRIMAL_INFEASIBLE; ++it; break; }
+            if (rr[4] < 0.0 && sqrt(rr[3]) * (1.0 + sqrt(rr[5])) <= ei * -rr[4]) { status = DSP_STATUS_DUAL_INFEASIBLE; ++it; break; }
+          }
           // Termination.  eps_obj > 0 (default): both feasibility tests AND a bound on the objective error of x+,
           //     err = |gap| + sum |y_i| viol_i + sum |dual residual_j| |x_j|  <=  eps_obj (1 + |c.x + c0|)
           // (the infeasibility-weighted sums are what the remaining infeasibilities can move the objective by).  The

@@ -131,6 +131,7 @@ __global__ void __launch_bounds__(64) simplex_kernel(SimplexArgs a) {
       blo = l * d; bhi = u * d;
     }
     int status = -1, pivots = 0;
+    bool p1_priced_out = false;        // phase 1 ended because no column prices in (the only phase-1 stop that proves infeasibility)
     bool phase1 = false;
 
     for (int it = 0;; ++it) {
@@ -176,7 +177,7 @@ __global__ void __launch_bounds__(64) simplex_kernel(SimplexArgs a) {
         best = fmax(best, score[q]);
       }
       best = wave_max(best);
-      if (best < 0.0) { status = phase1 ? DSP_STATUS_PRIMAL_INFEASIBLE : DSP_STATUS_OPTIMAL; break; }
+      if (best < 0.0) { status = phase1 ? DSP_STATUS_PRIMAL_INFEASIBLE : DSP_STATUS_OPTIMAL; p1_priced_out = phase1; break; }
       if (it >= a.max_pivots) { status = -1; break; }
       // entering column: the smallest index among the maxima (as numpy's argmax in the prototype)
       int jin = -1;
@@ -339,7 +340,9 @@ __global__ void __launch_bounds__(64) simplex_kernel(SimplexArgs a) {
     // ... EXCEPT a phase-1 optimum whose vertex is clearly outside its bounds (> 1e-6 of the variable's scale, a thousand times the
     // feasibility tolerance) on an intact tableau (row residuals certified): that is a proof of infeasibility, reported as such -
     // a caller that hands over an infeasible hourly LP gets status 2 like from the reference's CBC, not an iteration limit.
-    const bool clearly_infeasible = status == DSP_STATUS_PRIMAL_INFEASIBLE && __ballot(!okr) == 0ull && wave_max(viol) > 1e-6;
+    // Only a phase 1 that ended because NO column prices in (all reduced costs of the infeasibility sum within tolerance: its
+    // dual feasibility) counts; an empty ratio test in phase 1 is an artefact and goes to the PDLP pass, which has certificates of its own.
+    const bool clearly_infeasible = status == DSP_STATUS_PRIMAL_INFEASIBLE && p1_priced_out && __ballot(!okr) == 0ull && wave_max(viol) > 1e-6;
     if (clearly_infeasible) {
 #pragma unroll
       for (int q = 0; q < CQ; ++q) { const int j = lane + 64 * q; if (j < n) b.x[(size_t)s * n + j] = NAN; }
@@ -523,6 +526,7 @@ __global__ void __launch_bounds__(64, 2) simplex_reg_kernel(SimplexArgs a) {
       beta = 0.0;
     }
     int status = -1, pivots = 0;
+    bool p1_priced_out = false;        // phase 1 ended because no column prices in (the only phase-1 stop that proves infeasibility)
     bool phase1 = false;
 
     for (int it = 0;; ++it) {
@@ -553,7 +557,7 @@ __global__ void __launch_bounds__(64, 2) simplex_reg_kernel(SimplexArgs a) {
         best = fmax(best, score[q]);
       }
       best = wave_max(best);
-      if (best < 0.0) { status = phase1 ? DSP_STATUS_PRIMAL_INFEASIBLE : DSP_STATUS_OPTIMAL; break; }
+      if (best < 0.0) { status = phase1 ? DSP_STATUS_PRIMAL_INFEASIBLE : DSP_STATUS_OPTIMAL; p1_priced_out = phase1; break; }
       if (it >= a.max_pivots) { status = -1; break; }
       int jin = -1;
 #pragma unroll
@@ -710,7 +714,7 @@ __global__ void __launch_bounds__(64, 2) simplex_reg_kernel(SimplexArgs a) {
     int reason = status == -1 ? 1 : 0;
     if (status == DSP_STATUS_OPTIMAL && !certified) { status = -1; reason = 2; }
     // (a phase-1 optimum clearly outside its bounds on an intact tableau is reported infeasible: see the LDS-tableau kernel)
-    const bool clearly_infeasible = status == DSP_STATUS_PRIMAL_INFEASIBLE && __ballot(!okr) == 0ull && wave_max(viol) > 1e-6;
+    const bool clearly_infeasible = status == DSP_STATUS_PRIMAL_INFEASIBLE && p1_priced_out && __ballot(!okr) == 0ull && wave_max(viol) > 1e-6;
     if (clearly_infeasible) {
 #pragma unroll
       for (int q = 0; q < CQ; ++q) { const int j = lane + 64 * q; if (j < n) b.x[(size_t)s * n + j] = NAN; }

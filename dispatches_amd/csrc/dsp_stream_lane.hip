@@ -513,8 +513,11 @@ void lane_destroy(StreamSolver *S) {
 }
 
 // the records' gather indices are ring offsets: packed again when a tiling uses another ring than the last one did
-static hipError_t lane_records_for(LaneState *L, int ring) {
+// (*repacked: the records are fresh from the host plan - shared bounds +-inf, scale factors 1 - and need k_lane_fill_records again)
+static hipError_t lane_records_for(LaneState *L, int ring, bool *repacked) {
+  *repacked = false;
   if (ring == L->rec_ring) return hipSuccess;
+  *repacked = true;
   std::vector<char> crec, rrec;
   pack_lane_records(L->plan, ring, crec, rrec);
   hipError_t e;
@@ -618,6 +621,7 @@ hipError_t lane_run(StreamSolver *S, StreamArgs &a, hipStream_t st, int *periods
   int nact = B, period = 0;
   S->last_phases = 0;
   bool shared = true, first = true;
+  LaneTiling *Tprev = nullptr;            // the tiling the previous phase ran on
   for (;;) {
     const int G = (nact + 63) / 64;
     // tiles: one wave per SIMD (1024 tiles) for a single group of 40 scenarios and more (~50 rows per wave), two waves per SIMD (2048
@@ -631,11 +635,17 @@ hipError_t lane_run(StreamSolver *S, StreamArgs &a, hipStream_t st, int *periods
     rows = (rows + ch - 1) / ch * ch;
     LaneTiling *T = nullptr;
     if ((e = lane_tiling(L, rows, &T)) != hipSuccess) return e;
-    // (not applicable: nothing has been touched in the first phase; later phases use a ring that scheduled before)
-    if (T->ntile == 0) return first ? hipSuccess : hipErrorUnknown;
-    // the check kernel's three windows + record stages of four waves must fit a CU's LDS (kLaneMaxRing keeps them below: defensive)
-    if ((size_t)kLaneWaves * (3 * (size_t)T->ring * 64 * sizeof(double) + kLaneStageBytes) > 160u * 1024u) return first ? hipSuccess : hipErrorUnknown;
-    if ((e = lane_records_for(L, T->ring)) != hipSuccess) return e;
+    // Not applicable (no schedule for this tile size, or the check kernel's three windows + record stages of four waves beyond a CU's
+    // LDS - kLaneMaxRing keeps them below: defensive): in the first phase nothing has been touched and the caller's other forms take
+    // the batch; a LATER phase - its tile size differs with the number of groups - keeps the tiling the previous phase ran on (the
+    // scenario-major workspace holds a consistent iterate; the packed groups run on somewhat larger tiles than they would have got).
+    if (T->ntile == 0 || (size_t)kLaneWaves * (3 * (size_t)T->ring * 64 * sizeof(double) + kLaneStageBytes) > 160u * 1024u) {
+      if (first) return hipSuccess;
+      T = Tprev;
+    }
+    Tprev = T;
+    bool repacked = false;
+    if ((e = lane_records_for(L, T->ring, &repacked)) != hipSuccess) return e;
     if ((e = lane_workspace(L, nact, T->nwg, !shared, qp)) != hipSuccess) return e;
     if (first) {
       // bounds: one template for the whole batch (stride 0), or equal apart from the long columns' (checked on the device)
@@ -694,7 +704,7 @@ hipError_t lane_run(StreamSolver *S, StreamArgs &a, hipStream_t st, int *periods
     in(a.W.y, m, W.yA); in(a.W.y0, m, W.y0); in(a.W.yp, m, W.yp);
     if (!shared) { in(a.W.lb, n, W.lb); in(a.W.ub, n, W.ub); in(a.W.rlo, m, W.rlo); in(a.W.rhi, m, W.rhi); }
     if (qp) in(a.W.kap, m, W.kap);
-    if (first) {
+    if (first || repacked) {      // (a.W.lb .. a.W.rhi: scenario 0's scaled bounds in the scenario-major workspace, valid for the whole solve)
       hipLaunchKernelGGL(k_lane_fill_records, dim3((n + 255) / 256), tb, 0, st, L->crec, CREC, L->plan.WC * 12, L->plan.WC * 12 + 16,
                          (const double *)a.W.lb, (const double *)a.W.ub, S->P.col_scale, n);
       hipLaunchKernelGGL(k_lane_fill_records, dim3((m + 255) / 256), tb, 0, st, L->rrec, RREC, L->plan.WR * 12, L->plan.WR * 12 + 16 + NLP * 8,

@@ -28,7 +28,8 @@ class DspOptions(C.Structure):
                 ("jump_min", C.c_double), ("ray_jumps", C.c_int32), ("ruiz_iters", C.c_int32),
                 ("waves_per_block", C.c_int32), ("kkt_every", C.c_int32), ("no_matreg", C.c_int32), ("geo_iters", C.c_int32),
                 ("kkt_gate", C.c_double), ("stall_rescue", C.c_int32), ("no_simplex", C.c_int32),
-                ("jump_rel", C.c_double), ("precision", C.c_int32), ("polish_patience", C.c_int32), ("no_rtc", C.c_int32), ("reserved1", C.c_int32)]
+                ("jump_rel", C.c_double), ("precision", C.c_int32), ("polish_patience", C.c_int32), ("no_rtc", C.c_int32), ("reserved1", C.c_int32),
+                ("eps_infeasible", C.c_double)]
 
 
 class DspBatch(C.Structure):
@@ -81,10 +82,30 @@ class DspWbState(C.Structure):
 
 EXPORTED_SYMBOLS = ("dsp_default_options", "dsp_create", "dsp_solve", "dsp_spmv_step", "dsp_get_dims",
                     "dsp_get_scaling", "dsp_destroy", "dsp_strerror", "dsp_last_hip_error", "dsp_version",
-                    "dsp_rtc_compile_check", "dsp_rtc_message", "dsp_wb_rolling_update")
+                    "dsp_rtc_compile_check", "dsp_rtc_message", "dsp_wb_rolling_update", "dsp_source_hash")
 
 
-ABI_VERSION = 8          # DSP_VERSION of the include/dsp_hip.h these structures mirror
+ABI_VERSION = 9          # DSP_VERSION of the include/dsp_hip.h these structures mirror
+
+
+def source_hash(root: Optional[str] = None) -> Optional[str]:
+    """What dsp_source_hash() of a library built from the sources in this tree returns: the first 16 hex digits of the SHA-256 over
+    csrc/*.hip, csrc/*.hpp and include/dsp_hip.h (name order, each preceded by its base name).  None when the sources are not
+    next to the package (an installed binary: nothing to compare with)."""
+    import glob
+    import hashlib
+    root = root or os.path.dirname(_HERE)
+    csrc = os.path.join(root, "dispatches_amd", "csrc")
+    files = sorted(glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.hpp")), key=os.path.basename)
+    hdr = os.path.join(root, "include", "dsp_hip.h")
+    if not files or not os.path.exists(hdr):
+        return None
+    h = hashlib.sha256()
+    for f in files + [hdr]:
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
 
 
 def load_library(path: Optional[str] = None):
@@ -125,10 +146,19 @@ def load_library(path: Optional[str] = None):
     lib.dsp_wb_rolling_update.restype = C.c_int
     lib.dsp_last_hip_error.restype = C.c_int
     lib.dsp_version.restype = C.c_int
+    if not hasattr(lib, "dsp_source_hash"):
+        raise RuntimeError(f"{path} predates ABI 9 (no dsp_source_hash): rebuild (python -c 'import __graft_entry__ as g; g.build(force=True)')")
+    lib.dsp_source_hash.restype = C.c_char_p
     if lib.dsp_version() != ABI_VERSION:
         # the ctypes structures below mirror ONE header version; a stale library would read them with another layout
         raise RuntimeError(f"{path} has ABI version {lib.dsp_version()}, this binding mirrors include/dsp_hip.h version "
                            f"{ABI_VERSION}: rebuild (python -c 'import __graft_entry__ as g; g.build(force=True)')")
+    # a binary that travelled with the tree (gpurun ships built .so files) must be the build of THESE sources: the driver's bench once
+    # timed a prebuilt library that no hash tied to the code next to it.  DSP_LIB builds (development variants) are exempt.
+    want, have = source_hash(), lib.dsp_source_hash().decode()
+    if want is not None and have != want and "DSP_LIB" not in os.environ and os.environ.get("DSP_ALLOW_STALE_LIB") != "1":
+        raise RuntimeError(f"{path} was built from other sources (library {have}, tree {want}): rebuild "
+                           f"(python -c 'import __graft_entry__ as g; g.build()')")
     if path == _LIB_PATH:
         _lib = lib
     return lib
@@ -300,6 +330,7 @@ def period_shift_maps(lp, shift: int):
 
 
 FLAG_OBJ_WAIVED = 1          # DSP_FLAG_OBJ_WAIVED of include/dsp_hip.h
+STATUS_PRIMAL_INFEASIBLE, STATUS_DUAL_INFEASIBLE = 2, 3      # DSP_STATUS_* of include/dsp_hip.h
 STATUS_UNCERTIFIED = 5       # host-side report code (Bidder.failed_scenarios, Tracker): the kernel said OPTIMAL with
                              # DSP_FLAG_OBJ_WAIVED set and no re-solve certified the objective accuracy either
 
@@ -477,5 +508,9 @@ class HipPdlpSolver:
                   f"grid={st.grid_blocks}x{st.block_threads} lds={st.lds_bytes}B matreg={st.matreg} simplex={st.simplex} streaming={st.streaming} "
                   f"recertified={self.last_recertified} uncertified={int(model.uncertified.sum())}")
         all_ok = bool((status == 0).all())
-        return SolveResults("ok" if all_ok else "warning", "optimal" if all_ok else "maxIterations",
+        # termination condition in Pyomo's vocabulary, the worst scenario deciding (what the reference's callers branch on:
+        # case_studies/renewables_case/solar_battery_hydrogen.py:451-458): statuses 2 / 3 come with a certificate (include/dsp_hip.h)
+        term = ("optimal" if all_ok else "infeasible" if (status == STATUS_PRIMAL_INFEASIBLE).any() else
+                "unbounded" if (status == STATUS_DUAL_INFEASIBLE).any() else "maxIterations")
+        return SolveResults("ok" if all_ok else "warning", term,
                             iterations=int(st.total_iterations), kernel_ms=float(st.kernel_ms))

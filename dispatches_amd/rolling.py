@@ -80,17 +80,21 @@ class _DeviceModel:
         if lp_backend is not None:
             self.out = None
 
-    def wb_struct(self):
-        """dsp_wb_model of this LP (include/dsp_hip.h) for the fused rolling-update kernel."""
+    def wb_struct(self, needs_state=True):
+        """dsp_wb_model of this LP (include/dsp_hip.h) for the fused rolling-update kernel.  needs_state: the kernel reads the
+        realised state (soc0 / thr0) from THIS model's solution - true for the tracking model only; the real-time bidding model
+        hands over thr_init alone and may hold period 0's throughput as an expression."""
         from .hip_solver import DspWbModel
         w = DspWbModel()
         w.c, w.lb, w.ub, w.rlo, w.rhi = (t.data_ptr() for t in (self.c, self.lb, self.ub, self.rlo, self.rhi))
         w.base_c, w.x = self.base_c.data_ptr(), self.out["x"].data_ptr()
         w.n, w.m, w.T = self.lp.n, self.lp.m, self.T
-        if self.thr0 is None:
+        if self.thr0 is None and needs_state:
             raise ValueError("this model holds period 0's throughput as an expression (two-level accumulator): it cannot hand the "
                              "realised state to the fused rolling-update kernel")
-        w.soc_init, w.thr_init, w.soc0, w.thr0 = self.soc_init, self.thr_init, self.soc0, self.thr0
+        # thr0 of a model the kernel never reads the state from: its own thr_init column (a valid index; never -1, which would
+        # run off the array if the field were ever read)
+        w.soc_init, w.thr_init, w.soc0, w.thr0 = self.soc_init, self.thr_init, self.soc0, (self.thr_init if self.thr0 is None else self.thr0)
         wc, pt = self.wind_cols.cpu().tolist(), self.pt_cols.cpu().tolist()
         pda = self.pda_cols.cpu().tolist() if hasattr(self, "pda_cols") else []
         trk = self.track_rows.cpu().tolist() if hasattr(self, "track_rows") else []
@@ -207,7 +211,7 @@ class BatchedWindBatteryDoubleLoop:
             st.soc, st.thr = self.soc.data_ptr(), self.thr.data_ptr()
             st.da_offer, st.da_prices = self.da_offer.data_ptr(), self.da_prices.data_ptr()
             st.delivered, st.revenue, st.energy_mwh = self.delivered.data_ptr(), self.revenue.data_ptr(), self.energy_mwh.data_ptr()
-            self._wb_state, self._wb_rt, self._wb_tr = st, self.rt.wb_struct(), self.tr.wb_struct()
+            self._wb_state, self._wb_rt, self._wb_tr = st, self.rt.wb_struct(needs_state=False), self.tr.wb_struct()
         self._graphs = {}                                                  # "da" / hour of day -> captured hipGraph
 
     # -- windows -----------------------------------------------------------------------------------------------------------

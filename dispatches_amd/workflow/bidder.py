@@ -302,7 +302,7 @@ class StochasticProgramBidder(AbstractBidder):
         bad = np.nonzero(~ok)[0]
         self.failed_scenarios[(str(date), hour, market)] = {int(i): int(status[i]) for i in bad}
         msg = (f"{market} bidding problem of {self.generator} ({date}, hour {hour}): {len(bad)} of {len(status)} scenarios "
-               f"did not reach optimality (scenario: status; 1 iteration limit, 5 objective accuracy not certified) {dict(list(self.failed_scenarios[(str(date), hour, market)].items())[:8])}")
+               f"did not reach optimality (scenario: status; 1 iteration limit, 2 infeasible, 3 unbounded, 5 objective accuracy not certified) {dict(list(self.failed_scenarios[(str(date), hour, market)].items())[:8])}")
         if self.strict or not ok.any():
             raise RuntimeError(msg)
         import warnings

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define DSP_VERSION 8
+#define DSP_VERSION 9
 
 /* return codes (0 = ok, < 0 = API misuse / HIP error; text via dsp_strerror) */
 #define DSP_OK                 0
@@ -43,11 +43,18 @@ extern "C" {
 /* per-scenario termination status written to status[B] */
 #define DSP_STATUS_OPTIMAL            0
 #define DSP_STATUS_ITERATION_LIMIT    1
-#define DSP_STATUS_PRIMAL_INFEASIBLE  2   /* crossed bounds (var_lb > var_ub or row_lb > row_ub) in the input; infeasibility
-                                             that needs a Farkas ray is NOT detected (dispatch LPs carry slack columns) */
-#define DSP_STATUS_DUAL_INFEASIBLE    3   /* reserved: never reported (the in-wave simplex certifies OPTIMAL vertices only; a phase-1
-                                             stop or an unbounded ray it meets is handed to the PDLP pass, which ends at
-                                             ITERATION_LIMIT on a genuinely infeasible / unbounded LP)                */
+#define DSP_STATUS_PRIMAL_INFEASIBLE  2   /* no point satisfies rows and bounds.  Reported (i) for crossed bounds in the input (var_lb > var_ub or
+                                             row_lb > row_ub: before any iteration, x / y / obj = NaN), (ii) by the in-wave simplex when its
+                                             phase 1 ends at a certified optimum clearly outside the bounds (x / y / obj = NaN), (iii) by the
+                                             PDLP kernels - fused and HBM-resident - when the displacement T(z) - z of the iteration is a
+                                             FARKAS RAY to dsp_options::eps_infeasible: a row multiplier dy (signs admitted by the finite row
+                                             bounds) whose reduced costs -A'dy are absorbed by finite column bounds and whose bound value
+                                             dy+.row_lb - dy-.row_ub + rc+.var_lb - rc-.var_ub is positive (x / y hold the last iterate)       */
+#define DSP_STATUS_DUAL_INFEASIBLE    3   /* the objective is unbounded below along a recession direction of the feasible set (or the dual is
+                                             infeasible): reported by the PDLP kernels when the primal part dx of the displacement, clipped to
+                                             the recession cone of the column bounds, has c.dx < 0 and A dx inside the recession cone of the
+                                             rows to dsp_options::eps_infeasible (x / y hold the last iterate).  An LP that is infeasible or
+                                             unbounded by a margin below that tolerance still ends at ITERATION_LIMIT                          */
 #define DSP_STATUS_NUMERICAL          4   /* NaN in the input or NaN / Inf met in the iteration                */
 
 /* per-scenario flag bits written to flags[B] */
@@ -163,6 +170,17 @@ typedef struct dsp_options {
                                 the kernel sources ($DSP_KERNEL_SRC or csrc/ next to the library) at run time; without them
                                 the padded / LDS-matrix ahead-of-time kernels are used (dsp_rtc_message says why)  default 0 */
   int32_t reserved1;
+  double  eps_infeasible;    /* > 0: infeasibility / unboundedness certificates (DSP_STATUS_PRIMAL_INFEASIBLE / DUAL_INFEASIBLE, ABI 9).  On
+                                an LP without a solution the PDHG operator has no fixed point and T(z) - z tends to a ray.  Whenever a
+                                KKT test finds the relative gap |c.x - dual objective| / (1 + |c.x| + |dual objective|) >= 1/2 after
+                                the 8th check (the objectives drifting apart: never seen on a feasible bidding LP at that stage, so the
+                                test costs feasible batches one comparison), the two certificates are evaluated on the displacement
+                                (two products + one reduction), the KKT test is then repeated every 4th check, and the scenario ends when
+                                    |dual residual of the ray| (1 + |bounds|) <= eps_infeasible * (bound value of the ray)        or
+                                    |recession violation of A dx| (1 + |c|) <= eps_infeasible * (-c.dx)
+                                (scaled space; both are proofs up to the tolerance, whatever the iterate).  Reference behaviour: the
+                                solver's termination condition, on which the callers act (case_studies/renewables_case/
+                                solar_battery_hydrogen.py:451-458).  0 = off                                     default 1e-6 */
 } dsp_options;
 
 /* The per-call data of B scenarios.  c is required; every other input may be NULL (= no bound: -inf / +inf,
@@ -312,6 +330,10 @@ int dsp_destroy(dsp_handle *h);
 const char *dsp_strerror(int code);
 int dsp_last_hip_error(void);
 int dsp_version(void);
+/* The first 16 hex digits of the SHA-256 over the library's sources (csrc/ *.hip, *.hpp and this header, in name order, each preceded
+ * by its base name) as they were when it was compiled ("unknown" for a build that did not pass -DDSP_SOURCE_HASH).  A binding that sits next to the sources compares it with the files it sees and refuses a stale binary
+ * (dispatches_amd/hip_solver.py::load_library); bench.py prints it, so that a measured number names the code that produced it. */
+const char *dsp_source_hash(void);
 
 #ifdef __cplusplus
 }

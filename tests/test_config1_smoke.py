@@ -1,0 +1,70 @@
+"""BASELINE.json configs[0] as a named smoke: the reference's own CPU-runnable case is the fossil case study's 24-h MultiPeriodModel
+with ONE price scenario - the 24 LMPs of `_get_lmp`
+(dispatches/case_studies/fossil_case/ultra_supercritical_plant/storage/pricetaker_with_multiperiod_integrated_storage_usc.py:41-66).
+The USC flowsheet is an NLP (out of scope); what the config exercises on this path is the PLUMBING: model object ->
+populate_model -> forecaster -> Bidder / SelfScheduler -> solver.solve -> bids, on LP #1 (wind + battery) at a 24-h horizon with
+that price list as day-ahead and real-time forecast.  CPU tier: the boundary classes with the test-only HiGHS solver against the
+oracle's independent statement of the same LP.  GPU tier: the same call through HipPdlpSolver."""
+import numpy as np
+import pytest
+
+from dispatches_amd.flowsheets import MultiPeriodWindBattery
+from dispatches_amd.workflow import Backcaster, Bidder, RenewableGeneratorModelData, SelfScheduler, ThermalGeneratorModelData
+
+gpu = pytest.mark.gpu
+BUS = "Carter"
+
+
+def _model_object(rts309, thermal):
+    if thermal:
+        md = ThermalGeneratorModelData(gen_name="309_WIND_1", bus=BUS, p_min=0, p_max=200, min_down_time=0, min_up_time=0,
+                                       ramp_up_60min=225, ramp_down_60min=225, shutdown_capacity=225, startup_capacity=0,
+                                       initial_status=1, initial_p_output=0, production_cost_bid_pairs=[(0, 0), (200, 0)],
+                                       include_default_p_cost=False, startup_cost_pairs=[(0, 0)], fixed_commitment=None)
+    else:
+        md = RenewableGeneratorModelData(gen_name="309_WIND_1", bus=BUS, p_min=0, p_max=200, p_cost=0, fixed_commitment=None)
+    return MultiPeriodWindBattery(model_data=md, wind_capacity_factors=rts309["rt_cf"], wind_pmax_mw=200, battery_pmax_mw=25,
+                                  battery_energy_capacity_mwh=100)
+
+
+def _oracle_objective(rts309, lmp):
+    from oracle import dispatch_lp_oracle as orc
+    P, *_ = orc.wind_battery_da(24, rts309["rt_cf"][:24], np.asarray(lmp, float), np.asarray(lmp, float))
+    return P.solve(tight=True)[1]
+
+
+def _run(solver, golden, rts309, cls, thermal):
+    lmp = golden["G13_usc_pricetaker_lmp_24h"]["lmp"]
+    assert len(lmp) == 24
+    bidder = cls(bidding_model_object=_model_object(rts309, thermal), day_ahead_horizon=24, real_time_horizon=4, n_scenario=1,
+                 solver=solver, forecaster=Backcaster({BUS: list(lmp)}, {BUS: list(lmp)}))
+    bids = bidder.compute_day_ahead_bids(date="2020-01-02")
+    model = bidder.day_ahead_model
+    assert len(bids) == 24 and len(model.fs.index_set()) == 1 and len(model.fs[0].windBattery["periods"]) == 24
+    assert model.lp.n == 8 * 24 + 2 and model.lp.m == 5 * 24
+    return bidder, bids, model, _oracle_objective(rts309, lmp)
+
+
+@pytest.mark.parametrize("cls,thermal", [(SelfScheduler, False), (Bidder, True)])
+def test_config1_plumbing_on_the_cpu(golden, rts309, cls, thermal):
+    from tests._highs_solver import HighsTestSolver
+    bidder, bids, model, ref = _run(HighsTestSolver(), golden, rts309, cls, thermal)
+    assert abs(model.objective[0] - ref) <= 1e-9 * max(1.0, abs(ref)), (model.objective[0], ref)
+    # day-ahead = real-time forecast: the offer is indifferent, the delivered power is not - it follows the price list
+    pt = model.expression_values("P_T")[0]
+    lmp = np.asarray(golden["G13_usc_pricetaker_lmp_24h"]["lmp"])
+    assert pt[lmp == 200].min() >= pt[lmp == 0].max() - 1e-6          # the battery discharges into the 200 $/MWh hours
+
+
+@gpu
+@pytest.mark.parametrize("cls,thermal", [(SelfScheduler, False), (Bidder, True)])
+def test_config1_plumbing_through_the_hip_solver(golden, rts309, cls, thermal):
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("GPU test selected but no GPU visible")
+    from dispatches_amd.hip_solver import HipPdlpSolver
+    solver = HipPdlpSolver(device=0)
+    bidder, bids, model, ref = _run(solver, golden, rts309, cls, thermal)
+    assert (model.status == 0).all() and not model.uncertified.any()
+    assert abs(model.objective[0] - ref) <= 1e-6 * max(1.0, abs(ref)), (model.objective[0], ref)
+    assert solver.last_stats.matreg == 1 and solver.last_stats.streaming == 0           # the 24-h register-resident kernel ran

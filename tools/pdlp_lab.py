@@ -114,7 +114,7 @@ def solve(P, eps=1e-9, max_iter=60000, check=32, wrule="pid", kp=0.7, maxdl=np.l
                     solve.boosts = getattr(solve, "boosts", 0) + int(boosted.sum())
             if getattr(solve, "hook", None) is not None:       # development hook (tools/polish_lab.py)
                 solve.hook(it + 1, dict(xp=xp, yp=yp, gx=x - tau * (c - y @ As), gy=wv, lb=lb, ub=ub, rlo=rlo, rhi=rhi,
-                                        sig=sig, tau=tau, As=As, c=c, done=done, dc=dc, dr=dr, w=w))
+                                        sig=sig, tau=tau, As=As, c=c, done=done, dc=dc, dr=dr, w=w, x=x, y=y, k=k, x0=x0, y0=y0))
             conv = (rp <= eps) & (rd <= eps) & (rg <= eps) & ~done
             if getattr(solve, "trace", None) is not None:      # (iteration, r, rho = worst criterion / its limit, done)
                 rho = np.maximum(np.maximum(rp, rd), rg) / eps
@@ -156,6 +156,14 @@ def solve(P, eps=1e-9, max_iter=60000, check=32, wrule="pid", kp=0.7, maxdl=np.l
                     ax_ = ratio(gx1, dgx, lb, ub).min(1); ay_ = ratio(g, dgy, lo_, hi_).min(1)
                     alpha = np.minimum(ax_, ay_)
                     dojump = trans & (alpha >= jmin) & (alpha >= jrel * k) & (alpha < 1e200)
+                    if getattr(solve, "jump_hook", None) is not None:      # development hook (tools/infeas_lab.py)
+                        stop = solve.jump_hook(it + 1, dict(alpha=alpha, trans=trans, x=x, y=y, xp=xp, yp=yp, x2=x2, y2=y2, lb=lb, ub=ub, rlo=rlo, rhi=rhi,
+                                                            As=As, c=c, k=k, w=w, done=done))
+                        if stop is not None:
+                            newly = stop & ~done
+                            iters[newly] = it + 1; done |= newly
+                            if done.all():
+                                break
                     if dojump.any():
                         a = np.where(dojump, np.maximum(np.floor(alpha) + jland, 0.0), 0.0)[:, None]
                         xn = np.clip(x2 + a * v2x, lb, ub); yn = y2 + a * v2y
