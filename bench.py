@@ -177,9 +177,10 @@ def bench_double_loop(args, rank, local_rank, world, dev):
     assert int(unc.item()) == 0, f"{int(unc.item())} uncertified solves entered the realised state of the rolling loop"
     rank_devices, dist_world = _rank_devices(world, dev)
     elapsed = float(t.item())
+    line = None
     if rank == 0:
         days = args.steps
-        print(json.dumps({
+        line = ({
             "metric": f"plant-days simulated/sec, RTS-GMLC rolling double loop (config 4), {total} plants", "value": total * days / elapsed,
             "unit": "plant-days/s", "n_gpus": world, "steps": days, "warmup": max(1, args.warmup), "ms_per_step": 1e3 * elapsed / days,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
@@ -194,9 +195,8 @@ def bench_double_loop(args, rank, local_rank, world, dev):
                        "day_ahead_iterations_last_day": {"mean": float(loop.da.out["iters"].float().mean().item()),
                                                          "max": int(loop.da.out["iters"].max().item())},
                        "seconds_per_simulated_year": 366 * elapsed / days,
-                       "mean_revenue_per_plant_day": float(res["obj"].mean().item()) / (days + max(1, args.warmup))}}))
-    if world > 1:
-        dist.destroy_process_group()
+                       "mean_revenue_per_plant_day": float(res["obj"].mean().item()) / (days + max(1, args.warmup))}})
+    return line
 
 
 def _rank_devices(world, dev):
@@ -303,7 +303,7 @@ def bench_price_taker(args, rank, local_rank, world, dev):
         traffic = src = None
         kname = {3: "k_lane<", 2: "k_fused"}.get(form)
         if kname:
-            pats = [f"r4*_pmc_summary_{args.workload}_B*.csv"] + (["r4*_lane_pmc_summary_B*.csv", "r4*_stream_pmc_summary*.csv"] if args.workload == "price_taker" else [])
+            pats = [f"r[45]*_pmc_summary_{args.workload}_B*.csv"] + (["r[45]*_lane_pmc_summary_B*.csv", "r[45]*_stream_pmc_summary*.csv"] if args.workload == "price_taker" else [])
             files = [f for pat in pats for f in glob.glob(os.path.join(ROOT, "profiles", pat))]
             # the newest summary collected at this line's batch, else the newest of the round
             for f in sorted(set(files), key=lambda f: (f"_B{B}." in os.path.basename(f), os.path.basename(f)), reverse=True):
@@ -354,20 +354,85 @@ def bench_price_taker(args, rank, local_rank, world, dev):
                     ref = fx[f"T{T}/obj"][np.arange(B) % len(scenarios.PRICE_TAKER_FAMILY)]
                     line["config"]["max_rel_objective_error_vs_oracle_fixture"] = float((np.abs(model.objective - ref) / np.maximum(1.0, np.abs(ref))).max())
             if args.workload == "price_taker" and args.cpu_sample != 0:
+                # The WHOLE host beside the GPU: one HiGHS process per hardware thread (the reference's own sweep runs its members as
+                # a process pool: renewables_case/run_pricetaker_wind_PEM.py:106-107), each solving one member of the family - as many
+                # members as the GPU batch holds, at most one per thread, and no more processes than the free memory holds at ~0.5 GB
+                # each (a member's HiGHS solve peaks at 0.37 GB).  --cpu-sample N caps the processes.
                 import multiprocessing as mp
-                nsample = max(1, min(B, len(scenarios.PRICE_TAKER_FAMILY), (os.cpu_count() or 1), args.cpu_sample if args.cpu_sample > 0 else 16))
+                import psutil
+                mem_cap = max(1, int(psutil.virtual_memory().available / (0.6 * 2 ** 30)))
+                nsample = max(1, min(B, (os.cpu_count() or 1), mem_cap, args.cpu_sample if args.cpu_sample > 0 else 1 << 30))
                 t1 = time.perf_counter()
                 with mp.get_context("spawn").Pool(nsample) as pool:
-                    res = pool.map(_price_taker_cpu_worker, [(T, k) for k in range(nsample)])
+                    res = pool.map(_price_taker_cpu_worker, [(T, k) for k in range(nsample)], chunksize=1)
                 wall = time.perf_counter() - t1
                 err = max(abs(model.objective[k] - obj) / max(1.0, abs(obj)) for k, obj, _ in res)
-                line["cpu_baseline"] = {"value": nsample / wall, "unit": "LPs/s", "cores": nsample, "kind": "port",
-                                        "sample": f"{nsample} members of the same family, one HiGHS process each (oracle/dispatch_lp_oracle.py: the un-reduced LP, "
-                                                  f"feasibility tolerances 1e-9), wall {wall:.1f} s, {np.mean([r[2] for r in res]):.1f} s per member",
+                line["cpu_baseline"] = {"value": nsample / wall, "unit": "LPs/s", "cores": nsample, "kind": "port", "host_threads": os.cpu_count(),
+                                        "sample": f"{nsample} members of the same batch (the {len(scenarios.PRICE_TAKER_FAMILY)}-member family repeated), one HiGHS process "
+                                                  f"each on {os.cpu_count()} hardware threads (oracle/dispatch_lp_oracle.py: the un-reduced LP, feasibility tolerances "
+                                                  f"1e-9), wall {wall:.1f} s incl. process start, {np.mean([r[2] for r in res]):.1f} s per member (max {max(r[2] for r in res):.1f} s)",
                                         "max_rel_objective_difference_gpu_vs_these": float(err)}
-        print(json.dumps(line))
-    if world > 1:
-        dist.destroy_process_group()
+                line["config"]["gpu_over_full_host"] = line["value"] / line["cpu_baseline"]["value"]
+        return line
+    return None
+
+
+def bench_bidder_api(args, rank, local_rank, world, dev):
+    """The number a DISPATCHES user sees: wall time of the reference-level call `Bidder.compute_day_ahead_bids` (forecast -> objective
+    vectors -> solve -> bid curves -> records) for --batch price scenarios x 24 h of the wind + battery plant on one GPU, host arrays in,
+    the reference's bid dictionaries out (upstream idaes Bidder.compute_day_ahead_bids; driver call sites
+    dispatches/case_studies/renewables_case/run_double_loop_battery.py:222-285).  One step = one call; value = scenarios / s through
+    the plugin API.  The same day is also assembled by the numpy path (solution downloaded in full) and the two bid dictionaries
+    are compared bit for bit."""
+    import torch
+    from dispatches_amd import scenarios
+    from dispatches_amd.hip_solver import HipPdlpSolver
+    B, T = args.batch, 24
+    solver = HipPdlpSolver(device=local_rank)
+    bidder, model = scenarios.wind_battery_batch(B, T, solver)
+    inner = []
+    orig = solver.solve
+
+    def timed(*a, **k):
+        t0 = time.perf_counter()
+        r = orig(*a, **k)
+        inner.append((time.perf_counter() - t0, float(solver.last_stats.kernel_ms)))
+        return r
+    solver.solve = timed
+    days = [f"2020-01-{d:02d}" for d in range(2, 30)]
+    for d in days[:max(2, args.warmup)]:
+        bidder.compute_day_ahead_bids(d, 0)
+    inner.clear()
+    calls = []
+    for k in range(args.steps):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        bids = bidder.compute_day_ahead_bids(days[k % len(days)], 0)
+        calls.append(time.perf_counter() - t0)
+    n_opt = int((model.status == 0).sum())
+    # the same day through the numpy path (eager download): identical dictionaries
+    ref_solver = HipPdlpSolver(device=local_rank, lazy_solution=False)
+    ref_bidder, ref_model = scenarios.wind_battery_batch(B, T, ref_solver)
+    day = days[(args.steps - 1) % len(days)]
+    ref_bids = ref_bidder.compute_day_ahead_bids(day, 0)
+    t0 = time.perf_counter()
+    ref_bids = ref_bidder.compute_day_ahead_bids(day, 0)
+    ref_ms = 1e3 * (time.perf_counter() - t0)
+    same = bids == ref_bids
+    med = float(np.median(calls))
+    k_med = int(np.argsort(calls)[len(calls) // 2])
+    points = [len(v[bidder.generator]["p_cost"]) for v in bids.values()]
+    return {"metric": f"LP scenarios/sec through Bidder.compute_day_ahead_bids, wind + battery 24 h, batch={B}", "value": B / med, "unit": "scenarios/s",
+            "n_gpus": 1, "steps": args.steps, "warmup": max(2, args.warmup), "ms_per_step": 1e3 * med, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"bidder_api: {B} price scenarios x {T} h, Bidder (thermal generator data) + MultiPeriodWindBattery + HipPdlpSolver, host arrays in, bid dictionaries out",
+                       "call_ms": {"min": 1e3 * min(calls), "median": 1e3 * med, "max": 1e3 * max(calls)},
+                       "solver_solve_ms": 1e3 * inner[k_med][0], "kernel_ms": inner[k_med][1], "host_rest_ms": 1e3 * (calls[k_med] - inner[k_med][0]),
+                       "optimal": n_opt, "curve_points_per_hour": {"mean": float(np.mean(points)), "max": int(max(points))},
+                       "bids_identical_to_numpy_path": bool(same), "numpy_path_call_ms": ref_ms,
+                       "path": "objective vectors formed on the device from the uploaded price windows (PriceObjective), x / y left on the device "
+                               "(DeviceSolution), roundings + per-hour sorts of the bid assembly as tensor operations (workflow/bid_curves.py), "
+                               "p_cost lists, records and the first 16 scenarios' detail rows on the host"}}
 
 
 def _qp_oracle_worker(args):
@@ -429,7 +494,7 @@ def bench_qp_sweep(args, rank, local_rank, world, dev):
                     obj_err_max=float(e.max()), obj_err_median_of_terminated=(float(np.median(e[stat[:len(e)] == 0])) if (stat[:len(e)] == 0).any() else None),
                     scenarios_per_s_lone_batch=B / (1e-3 * float(st.kernel_ms)))
     sweep = []
-    if rank == 0:
+    if rank == 0 and not getattr(args, "no_sweep", False):
         for prec in (0, 1):
             for eps in (1e-3, 1e-4, 1e-5, 1e-6, 1e-7, 1e-8, 1e-9):
                 o = default_options(**{**hints, "precision": prec, "eps_rel": eps, "eps_obj": 0.0, "max_iter": args.sweep_max_iter})
@@ -483,7 +548,7 @@ def bench_qp_sweep(args, rank, local_rank, world, dev):
             cpu = dict(value=sample / wall, unit="scenarios/s", cores=procs, kind="port",
                        sample=f"the first {sample} scenarios of the same batch, Kelley cutting planes on HiGHS LPs to a certified 1e-9 "
                               f"bracket (oracle/qp_cutting_plane.py; no QP solver in the image reaches the bar), {procs} processes, wall {wall:.2f} s")
-        print(json.dumps({
+        return ({
             "metric": f"QP scenarios solved/sec, RTS-GMLC 24h day-ahead bidding + quadratic ramp cost (config 5), batch={B}",
             "value": world * B * args.steps / elapsed, "unit": "scenarios/s", "n_gpus": world, "steps": args.steps, "warmup": max(args.warmup, depth),
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
@@ -491,10 +556,195 @@ def bench_qp_sweep(args, rank, local_rank, world, dev):
             "config": {"workload": f"{wl}: {B} scenarios/GPU x 24 h day-ahead bidding QP (n={lp.n}, m={lp.m}, nnz={lp.nnz}, "
                                    f"{int(np.count_nonzero(lp.row_compliance))} soft rows, rho={kw['ramp_cost']})",
                        "eps_rel": args.eps, "streams": depth, "lone_batch": first, "optimal": first["terminated"],
-                       "max_rel_obj_err_vs_oracle_bracket": float(e.max()), "scenarios_beyond_1e-6": int((e >= 1e-6).sum())},
-            "sweep": sweep, "cpu_baseline": cpu}))
-    if world > 1:
-        dist.destroy_process_group()
+                       "max_rel_obj_err_vs_oracle_bracket": float(e.max()), "scenarios_beyond_1e-6": int((e >= 1e-6).sum()),
+                       "flagged": int(((outs[0]["flags"] & 1) != 0).sum().item()) if "flags" in outs[0] else None},
+            "sweep": sweep, "cpu_baseline": cpu})
+    return None
+
+
+def _source_hash():
+    """dsp_source_hash() of the library this process loaded (include/dsp_hip.h): names the code that produced the numbers."""
+    from dispatches_amd import hip_solver
+    return hip_solver.load_library().dsp_source_hash().decode()
+
+
+def _valu_lds_fractions(solve_kernel, B, sum_iters, step_s):
+    """VALU / LDS busy fractions of a fused solve kernel from the newest committed SQ counters of that kernel at this batch
+    (profiles/r*_<workload>_B<batch>_pmc_summary.csv; instruction counts per launch are deterministic for a build + batch and are
+    scaled by the iteration ratio when the recorded launch ran a different total) and the sustained step time measured HERE.
+    Returns (valu_frac, lds_frac, valu_rate, counters_file, scaled_by, traffic)."""
+    pmc, pmc_file = _profiled_counters(solve_kernel, B)
+    traffic = _profiled_traffic(solve_kernel, B)
+    scaled = 1.0
+    if pmc_file:
+        rec_path = os.path.join(ROOT, "profiles", pmc_file.replace("_pmc_summary.csv", "_pmc_iterations.json"))
+        if os.path.exists(rec_path):
+            rec = json.load(open(rec_path))
+            per_launch = next((v for k, v in rec.items() if k in solve_kernel or solve_kernel in k), None)
+            if per_launch:
+                scaled = float(sum_iters) / float(per_launch)
+                pmc = {k: (v * scaled if k.startswith("SQ_") else v) for k, v in pmc.items()}
+    valu_frac = lds_frac = valu_rate = None
+    if "SQ_INSTS_VALU" in pmc:
+        valu_rate = pmc["SQ_INSTS_VALU"] / step_s
+        valu_frac = pmc["SQ_INSTS_VALU"] * 4.0 / (SIMDS * step_s * PEAK_CLOCK_HZ)
+    if "SQ_LDS_IDX_ACTIVE" in pmc:
+        lds_frac = pmc["SQ_LDS_IDX_ACTIVE"] / (256 * step_s * PEAK_CLOCK_HZ)
+    return valu_frac, lds_frac, valu_rate, pmc_file, scaled, traffic
+
+
+def _fused_config_entry(tag, workload, B, local_rank, dev, steps, depth=8):
+    """One BASELINE config of the fused one-wave kernels as an entry of the default line's `configs` array: the same measurement as
+    the headline (lone batch + `steps` steps pipelined over `depth` HIP streams between synchronisations, inputs resident in HBM),
+    parity of the timed batch against the committed oracle fixture, flags, and the VALU / LDS fractions from the committed
+    counters of this kernel at this batch."""
+    import torch
+    from dispatches_amd import scenarios
+    from dispatches_amd.hip_solver import DeviceLP, HipPdlpSolver, default_options
+    solver = HipPdlpSolver(device=local_rank)
+    fn, kw = scenarios.WORKLOADS[workload]
+    bidder, model = fn(B=B, solver=solver, **kw)
+    scenarios.load_prices(bidder, model)
+    lp = model.lp
+    lb, ub, rlo, rhi = model.scenario_bounds()
+    up = lambda a: torch.as_tensor(np.ascontiguousarray(a, np.float64)).to(dev)
+    c_d, lb_d, ub_d, rlo_d, rhi_d, c0_d = up(model.c), up(lb), up(ub), up(rlo), up(rhi), up(np.ascontiguousarray(model.c0))
+    opts = default_options(**(getattr(model, "solver_hints", None) or {}))
+    dlp = DeviceLP(lp, local_rank, opts)
+    solve = lambda out, sync: dlp.solve(B, c_d, lb_d, ub_d, rlo_d, rhi_d, options=opts, out=out, sync_stats=sync, obj_offset=c0_d)
+    out = solve(None, True)
+    out = solve(out, True)
+    st = dlp.last_stats
+    lone_ms, sum_iters, max_iters = float(st.kernel_ms), int(st.total_iterations), int(st.max_iterations)
+    streams = [torch.cuda.Stream(device=dev) for _ in range(depth)]
+    outs = [None] * depth
+
+    def burst(n):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(n):
+            with torch.cuda.stream(streams[i % depth]):
+                outs[i % depth] = solve(outs[i % depth], False)
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0
+    burst(depth)                                           # every stream launches once (hardware queues, output buffers)
+    times = [burst(steps) for _ in range(3)]
+    elapsed = float(np.median(times))
+    step_s = elapsed / steps
+    status = out["status"].cpu().numpy()
+    flags = out["flags"].cpu().numpy()
+    entry = {"config": tag, "workload": workload, "batch": B, "horizon_h": len(model.HOUR), "n": lp.n, "m": lp.m,
+             "value": B * steps / elapsed, "unit": "scenarios/s", "steps": steps, "streams": depth, "ms_per_step": 1e3 * step_s,
+             "lone_batch_ms": lone_ms, "lone_batch_scenarios_per_s": B / (1e-3 * lone_ms),
+             "mean_iterations": sum_iters / B, "max_iterations": max_iters,
+             "optimal": int((status == 0).sum()), "flagged": int(((flags & 1) != 0).sum())}
+    fx_path = os.path.join(ROOT, "tests", "golden", "oracle_objectives.npz")
+    if os.path.exists(fx_path):
+        fx = np.load(fx_path)
+        if workload in fx.files and len(fx[workload]) >= B:
+            ref = fx[workload][:B]
+            mine = out["obj"].cpu().numpy() + model.c0
+            entry["max_rel_obj_err_vs_oracle_fixture"] = float(np.max(np.abs(mine - ref) / np.maximum(1.0, np.abs(ref))))
+    kernel = f"pdlp_solve_kernel<{int(st.cols_per_lane)}, {int(st.rows_per_lane)}," if int(st.matreg) else "pdlp_solve_kernel"
+    vf, lf, vr, cfile, scaled, traffic = _valu_lds_fractions(kernel, B, sum_iters, step_s)
+    w = 8
+    true_io = (sum(t.numel() for t in (c_d, lb_d, ub_d, rlo_d, rhi_d) if t.dim() == 2) * w + B * w * (lp.n + lp.m + 1) + B * 12)
+    entry["roofline"] = {"bound": "valu+lds", "kernel": kernel, "frac": vf, "frac_lds": lf, "achieved": (vr / 1e9) if vr else None,
+                         "peak": SIMDS * PEAK_CLOCK_HZ / 4.0 / 1e9, "unit": "G FP64-wave-instr/s", "counters_from": cfile,
+                         "counters_scaled_by": scaled, "traffic": traffic, "true_io_bytes_per_launch": true_io,
+                         "traffic_over_true_io": (traffic / true_io) if traffic else None}
+    dlp.close()
+    return entry
+
+
+def _condense(tag, line, keys=()):
+    """A full bench line of another workload as an entry of `configs`: headline fields, its roofline, the parity / certification fields."""
+    cfg = line.get("config", {})
+    e = {"config": tag, "metric": line["metric"], "value": line["value"], "unit": line["unit"], "steps": line["steps"],
+         "ms_per_step": line["ms_per_step"], "workload": cfg.get("workload")}
+    for k in keys:
+        if k in cfg:
+            e[k] = cfg[k]
+    if "roofline" in line:
+        r = line["roofline"]
+        e["roofline"] = {k: r.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_from",
+                                                "algorithmic_bytes_per_scenario_iteration") if k in r}
+    return e
+
+
+def baseline_configs(args, local_rank, dev, budget_s=360.0, depth=8):
+    """Every BASELINE.json config beside the metric one, measured in THIS run (1 GPU), as the `configs` array of the default line:
+        1  the reference's own CPU-runnable case as plumbing: boundary classes on LP #1 with the 24 _get_lmp prices, one scenario
+        2  nuclear 24 h, 256 scenarios                        3  wind + PEM 48 h, 4096 scenarios
+        4  wind + battery 48 h, 4096 (the day-ahead shape) AND the rolling double loop itself at its stated size, 8192 plants
+        5  24-h bidding QP (quadratic ramp cost), 4096 scenarios, contract setting (the fp64 / fp32 ladder: --workload qp_sweep)
+        +  the plugin API itself (Bidder.compute_day_ahead_bids, 4096 x 24 h, host arrays in, bid dictionaries out)
+        +  the HBM-bound streaming path: year-long price-taker design LPs, 256 scenarios, iteration rate over 50 check periods
+    Entries are skipped (and say so) once `budget_s` seconds have gone, so that the whole command stays within a few minutes."""
+    import copy
+    t_start = time.perf_counter()
+    out = []
+
+    def leg(tag, fn):
+        if time.perf_counter() - t_start > budget_s:
+            out.append({"config": tag, "skipped": f"time budget of {budget_s:.0f} s for the configs array spent"})
+            return
+        t0 = time.perf_counter()
+        try:
+            e = fn()
+        except Exception as exc:                           # noqa: BLE001 - one broken leg must not lose the headline line
+            e = {"config": tag, "error": f"{type(exc).__name__}: {exc}"[:300]}
+        e["wall_s"] = time.perf_counter() - t0
+        out.append(e)
+
+    def config1():
+        from dispatches_amd import scenarios
+        from dispatches_amd.flowsheets import MultiPeriodWindBattery
+        from dispatches_amd.hip_solver import HipPdlpSolver
+        from dispatches_amd.workflow import Backcaster, RenewableGeneratorModelData, SelfScheduler
+        from oracle import dispatch_lp_oracle as orc
+        lmp = json.load(open(os.path.join(ROOT, "tests", "golden", "reference_vectors.json")))["G13_usc_pricetaker_lmp_24h"]["lmp"]
+        s = scenarios.load_series("rts_gmlc_309.npz")
+        md = RenewableGeneratorModelData(gen_name="309_WIND_1", bus="Carter", p_min=0, p_max=200, p_cost=0, fixed_commitment=None)
+        mp = MultiPeriodWindBattery(model_data=md, wind_capacity_factors=s["rt_cf"], wind_pmax_mw=200, battery_pmax_mw=25,
+                                    battery_energy_capacity_mwh=100)
+        solver = HipPdlpSolver(device=local_rank)
+        bidder = SelfScheduler(bidding_model_object=mp, day_ahead_horizon=24, real_time_horizon=4, n_scenario=1, solver=solver,
+                               forecaster=Backcaster({"Carter": list(lmp)}, {"Carter": list(lmp)}))
+        bidder.compute_day_ahead_bids(date="2020-01-02")            # first call: handle creation, code-object load
+        t0 = time.perf_counter()
+        bidder.compute_day_ahead_bids(date="2020-01-02")
+        call_ms = 1e3 * (time.perf_counter() - t0)
+        m = bidder.day_ahead_model
+        ref = orc.wind_battery_da(24, s["rt_cf"][:24], np.asarray(lmp, float), np.asarray(lmp, float))[0].solve(tight=True)[1]
+        return {"config": "1", "workload": "plumbing: SelfScheduler + MultiPeriodWindBattery, 24 h, 1 price scenario = the 24 LMPs of the fossil case "
+                                           "study's _get_lmp (tests/golden/reference_vectors.json G13), through HipPdlpSolver",
+                "value": 1e3 / call_ms, "unit": "compute_day_ahead_bids calls/s", "call_ms": call_ms, "kernel_ms": float(solver.last_stats.kernel_ms),
+                "iterations": int(m.iterations[0]), "optimal": int((m.status == 0).sum()), "flagged": int(m.uncertified.sum()),
+                "rel_obj_err_vs_oracle": float(abs(m.objective[0] - ref) / max(1.0, abs(ref)))}
+    leg("1", config1)
+    # (steps = a multiple of the stream depth the headline chose in its warm-up: every stream gets the same number of launches)
+    leg("2", lambda: _fused_config_entry("2", "nuclear_24h", 256, local_rank, dev, steps=4 * depth, depth=depth))
+    leg("3", lambda: _fused_config_entry("3", "wind_pem_48h", 4096, local_rank, dev, steps=2 * depth, depth=depth))
+    leg("4-day-ahead", lambda: _fused_config_entry("4-day-ahead", "wind_battery_48h", 4096, local_rank, dev, steps=depth, depth=depth))
+
+    def sub(**kw):
+        a = copy.copy(args)
+        for k, v in kw.items():
+            setattr(a, k, v)
+        return a
+    leg("4", lambda: _condense("4", bench_double_loop(sub(workload="double_loop", total=8192, steps=2, warmup=1), 0, local_rank, 1, dev),
+                               ("lp_solves_per_s", "all_optimal", "uncertified_solves", "day_ahead_iterations_last_day", "seconds_per_simulated_year")))
+    leg("5", lambda: _condense("5", bench_qp_sweep(sub(workload="qp_sweep", batch=4096, steps=12, warmup=3, no_sweep=True, cpu_sample=0, eps=None, streams=0),
+                                                   0, local_rank, 1, dev),
+                               ("eps_rel", "optimal", "flagged", "max_rel_obj_err_vs_oracle_bracket", "scenarios_beyond_1e-6", "lone_batch")))
+    leg("bidder_api", lambda: _condense("bidder_api", bench_bidder_api(sub(workload="bidder_api", batch=4096, steps=12, warmup=2), 0, local_rank, 1, dev),
+                                        ("call_ms", "solver_solve_ms", "kernel_ms", "host_rest_ms", "optimal", "curve_points_per_hour",
+                                         "bids_identical_to_numpy_path", "numpy_path_call_ms")))
+    leg("streaming", lambda: _condense("streaming", bench_price_taker(sub(workload="price_taker", batch=256, steps=50, warmup=1, solve=False, horizon=8736,
+                                                                           throughput=None, cpu_sample=0), 0, local_rank, 1, dev),
+                                       ("stream_form", "stream_phases", "iterations_per_scenario", "finished_before_the_cap", "us_per_batch_iteration")))
+    return out
 
 
 def main():
@@ -526,6 +776,8 @@ def main():
                          "with --steps large enough the batch runs to optimality and config.solved_to_optimality / iterations_per_scenario tell")
     ap.add_argument("--warm-start", type=int, default=-1,
                     help="--workload double_loop: 1 / 0 = rolling warm start of the day-ahead LP on / off (-1 = the loop's default)")
+    ap.add_argument("--no-configs", action="store_true", help="default line only: skip the `configs` array (the other BASELINE configs measured in the same run)")
+    ap.add_argument("--no-sweep", action="store_true", help="--workload qp_sweep: the contract entry only, without the fp64 / fp32 tolerance ladder")
     ap.add_argument("--no-spmv", action="store_true", help="skip the streaming SpMV-step roofline measurement")
     ap.add_argument("--spmv-large-mult", type=int, default=32,
                     help="also time spmv_step on a batch this many times larger (0 = skip; the PMC passes skip it so "
@@ -566,12 +818,16 @@ def main():
     from dispatches_amd.hip_solver import DeviceLP, HipPdlpSolver, default_options
 
     from dispatches_amd.distributed import shard_bounds
-    if args.workload == "double_loop":
-        return bench_double_loop(args, rank, local_rank, world, dev)
-    if args.workload in ("price_taker", "pem_price_taker", "nuclear_price_taker"):
-        return bench_price_taker(args, rank, local_rank, world, dev)
-    if args.workload == "qp_sweep":
-        return bench_qp_sweep(args, rank, local_rank, world, dev)
+    other = {"double_loop": bench_double_loop, "price_taker": bench_price_taker, "pem_price_taker": bench_price_taker,
+             "nuclear_price_taker": bench_price_taker, "qp_sweep": bench_qp_sweep, "bidder_api": bench_bidder_api}.get(args.workload)
+    if other is not None:
+        line = other(args, rank, local_rank, world, dev)
+        if rank == 0:
+            line["source_hash"] = _source_hash()
+            print(json.dumps(line))
+        if world > 1:
+            dist.destroy_process_group()
+        return
     solver = HipPdlpSolver(device=local_rank, **({} if args.eps is None else {"eps_rel": args.eps}))
     fn, kw = scenarios.WORKLOADS[args.workload]
     if args.total > 0:
@@ -605,7 +861,8 @@ def main():
                     obj=torch.empty(B, dtype=torch.float64, device=dev),
                     status=torch.empty(B, dtype=torch.int32, device=dev),
                     iters=torch.empty(B, dtype=torch.int32, device=dev),
-                    jumps=torch.empty(B, dtype=torch.int32, device=dev))
+                    jumps=torch.empty(B, dtype=torch.int32, device=dev),
+                    flags=torch.zeros(B, dtype=torch.int32, device=dev))
 
     c0_d = up(np.ascontiguousarray(c0))
     # Pipeline: consecutive steps (independent batches) are issued round-robin on `--streams` HIP streams, each with
@@ -702,6 +959,9 @@ def main():
     sum_iters = [sum_iters_one]
 
     n_opt = torch.tensor([min(int((o["status"] == 0).sum().item()) for o in outs)], device=dev)
+    # scenarios the kernel accepted without certifying the objective accuracy (DSP_FLAG_OBJ_WAIVED): status 0, but HipPdlpSolver
+    # would re-solve them and the Bidder would not bid them - counted here because the timed region calls DeviceLP.solve directly
+    n_flag = torch.tensor([max(int(((o["flags"] & 1) != 0).sum().item()) for o in outs)], device=dev)
     if world > 1:
         dist.all_reduce(n_opt)
     rank_devices, dist_world = _rank_devices(world, dev)
@@ -730,28 +990,11 @@ def main():
         true_io = (sum(t.numel() for t in (c_d, lb_d, ub_d, rlo_d, rhi_d) if t.dim() == 2) * w
                    + B * w * (lp.n + lp.m + 1) + B * 12)
         solve_kernel = f"pdlp_solve_kernel<{int(st.cols_per_lane)}, {int(st.rows_per_lane)}," if geometry[3] else "pdlp_solve_kernel"
-        pmc, pmc_file = _profiled_counters(solve_kernel, B)
-        traffic = _profiled_traffic(solve_kernel, B)
         # The SQ counters of a launch are proportional to the scenario-iterations it runs (hot loop + checks; the per-scenario
         # prologue is < 1 %).  A profile records the iterations of its launch (profiles/<tag>_pmc_iterations.json); when the
-        # shipped options / model hints have changed the iteration count since (e.g. the column scaling of DESIGN 5a-4, adopted
-        # after the last PMC passes of round 2), the counters are scaled by the ratio so that instructions and time belong to the
-        # same work.  `counters_scaled_by` = 1 when nothing changed or no record exists.
-        counters_scaled_by = 1.0
-        if pmc_file:
-            rec_path = os.path.join(ROOT, "profiles", pmc_file.replace("_pmc_summary.csv", "_pmc_iterations.json"))
-            if os.path.exists(rec_path):
-                rec = json.load(open(rec_path))
-                per_launch = next((v for k, v in rec.items() if k in solve_kernel or solve_kernel in k), None)
-                if per_launch:
-                    counters_scaled_by = float(np.mean(sum_iters)) / float(per_launch)
-                    pmc = {k: (v * counters_scaled_by if k.startswith("SQ_") else v) for k, v in pmc.items()}
-        valu_frac = lds_frac = valu_rate = None
-        if "SQ_INSTS_VALU" in pmc:
-            valu_rate = pmc["SQ_INSTS_VALU"] / step_s                         # wave-instructions / s, sustained
-            valu_frac = pmc["SQ_INSTS_VALU"] * 4.0 / (SIMDS * step_s * PEAK_CLOCK_HZ)
-        if "SQ_LDS_IDX_ACTIVE" in pmc:
-            lds_frac = pmc["SQ_LDS_IDX_ACTIVE"] / (256 * step_s * PEAK_CLOCK_HZ)
+        # shipped options / model hints have changed the iteration count since, the counters are scaled by the ratio so that
+        # instructions and time belong to the same work.  `counters_scaled_by` = 1 when nothing changed or no record exists.
+        valu_frac, lds_frac, valu_rate, pmc_file, counters_scaled_by, traffic = _valu_lds_fractions(solve_kernel, B, float(np.mean(sum_iters)), step_s)
         flops = 4.0 * lp.nnz * float(np.mean(sum_iters)) / step_s / 1e12      # SURVEY 8(d) flop unit: 4 nnz per scenario-iteration
         roofline = dict(
             bound="valu+lds", kernel="pdlp_solve_kernel",
@@ -797,7 +1040,7 @@ def main():
                                           "the oracle's 1e-7-optimal face range +- 1e-6 * max(|setpoint|, generator p_max) - a NAMEPLATE tolerance: the optima are "
                                           "degenerate (repeated / zero prices), a setpoint is a range, not a number (tests/test_hip_batch_parity.py, DESIGN 2)",
                        "mean_iterations": float(np.mean(sum_iters)) / B, "max_iterations": max_iters_one,
-                       "optimal": int(n_opt.item()), "scenarios": n_total,
+                       "optimal": int(n_opt.item()), "flagged": int(n_flag.item()), "scenarios": n_total,
                        "grid": geometry[:2], "lds_bytes": geometry[2], "register_resident_matrix": bool(geometry[3]),
                        "simulated_lds_gather_conflict_cycles_per_iteration": {"identity_layout": lds_conflicts[0],
                                                                               "slot_permutation": lds_conflicts[1]},
@@ -807,6 +1050,7 @@ def main():
                                    "a lone batch takes single_batch_latency_ms, dominated by its slowest scenario: "
                                    "lone_batch_scenarios_per_s); value = median over `bursts` bursts of --steps steps each"},
             "roofline": roofline,
+            "source_hash": _source_hash(),
         }
         # ---- streaming SpMV step (vectors in HBM): the kernel SURVEY 8(d) quotes the HBM roofline on -------
         if not args.no_spmv:
@@ -927,6 +1171,9 @@ def main():
                 mine = out["obj"].cpu().numpy() + c0
                 result["config"]["max_rel_obj_err_vs_oracle_fixture"] = float(
                     np.max(np.abs(mine - ref) / np.maximum(1.0, np.abs(ref))))
+        # ---- every other BASELINE config, same run (default command only) ----------------------------------------------
+        if world == 1 and args.workload == "wind_battery_24h" and args.total == 0 and not args.no_configs:
+            result["configs"] = baseline_configs(args, local_rank, dev, depth=depth)
         print(json.dumps(result))
     if world > 1:
         dist.destroy_process_group()

@@ -97,12 +97,12 @@ class MultiPeriodNuclear:
             "Date": date,
             "Hour": hour,
             "Horizon [hr]": np.arange(T, dtype=int),
-            "Power to Grid [MW]": np.round([blk.value(blk.P_T[t]) for t in range(T)], 2),
+            "Power to Grid [MW]": np.round(blk.family_values("P_T")[:T], 2),
             "Power to PEM [MW]": np.round(col("pem_elec") * 1e-3, 2),
             "Initial holdup [kg]": np.round(col("holdup_prev") * prm.mw_h2, 2),
             "Final holdup [kg]": np.round(col("tank_holdup") * prm.mw_h2, 2),
             "Hydrogen Market [kg/hr]": np.round(col("outlet_to_pipeline") * prm.mw_h2 * 3600, 2),
-            "Total Cost [$]": np.round([blk.value(blk.tot_cost[t]) for t in range(T)], 2),
+            "Total Cost [$]": np.round(blk.family_values("tot_cost")[:T], 2),
             **kwargs,                     # e.g. Scenario=, Market= (appended as the last columns, as the reference does)
         }
         self.result_list.append(rec)

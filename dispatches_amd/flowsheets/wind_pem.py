@@ -114,12 +114,12 @@ class MultiPeriodWindPEM:
             "Hour": hour,
             "Horizon [hr]": np.arange(T, dtype=int),
             "Total Wind Generation [MW]": np.round(col("wind") * 1e-3, 2),
-            "Total Power Output [MW]": np.round([b.value(b.P_T[t]) for t in range(T)], 2),
+            "Total Power Output [MW]": np.round(b.family_values("P_T")[:T], 2),
             "Wind Power Output [MW]": np.round(col("grid_elec") * 1e-3, 2),
             "Wind to PEM [MW]": np.round(col("pem_elec") * 1e-3, 2),
             "Wind Curtailment [MW]": round(b.value(b.wind_waste[0]), 2),
             "Hydrogen Sales [kg]": np.round(self._h2_kg_per_hr(col("pem_elec")), 2),
-            "Total Cost [$]": np.round([b.value(b.tot_cost[t]) for t in range(T)], 2),
+            "Total Cost [$]": np.round(b.family_values("tot_cost")[:T], 2),
             **kwargs,                     # e.g. Scenario=, Market= (appended as the last columns, as the reference does)
         }
         self.result_list.append(rec)

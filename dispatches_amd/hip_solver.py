@@ -343,6 +343,31 @@ def uncertified(status, flags):
     return (status == 0) & ((np.asarray(flags) & FLAG_OBJ_WAIVED) != 0)
 
 
+class DeviceSolution:
+    """x / y of a solve, still on the device (ScenarioBatchModel.store_solution(lazy=...)): a Bidder reads T of n columns, the rolling
+    loop nothing at all - downloading 4096 x (n + m) doubles per call was a third of the host time of compute_day_ahead_bids."""
+
+    def __init__(self, out, m, device):
+        self.x, self.y, self.m, self.device = out["x"], out["y"], m, device
+
+    def fetch(self):
+        import torch
+        hx = torch.empty(self.x.shape, dtype=self.x.dtype, pin_memory=True)
+        hy = torch.empty(self.y.shape, dtype=self.y.dtype, pin_memory=True)
+        hx.copy_(self.x, non_blocking=True)
+        hy.copy_(self.y, non_blocking=True)
+        torch.cuda.current_stream(self.device).synchronize()
+        return hx.numpy(), hy.numpy()[:, :self.m]
+
+    def columns(self, cols):
+        import torch
+        idx = torch.as_tensor(np.ascontiguousarray(cols, np.int64), device=self.x.device)
+        return self.x.index_select(1, idx).cpu().numpy()
+
+    def rows(self, lo, hi):
+        return self.x[lo:hi].cpu().numpy()
+
+
 class HipPdlpSolver:
     """Solver object for Bidder / SelfScheduler / Tracker: `solver.solve(model, tee=False)`.
 
@@ -360,8 +385,10 @@ class HipPdlpSolver:
     RECERTIFY_VARIANTS = (dict(pid_kp=0.45, restart_artificial=0.3), dict(pid_kp=0.8, restart_artificial=0.15),
                           dict(pid_kp=0.3, restart_artificial=0.5, check_every=12))
 
-    def __init__(self, device: int = 0, recertify: int = 3, **options):
+    def __init__(self, device: int = 0, recertify: int = 3, lazy_solution: bool = True, **options):
         self.device = device
+        # lazy_solution: models that support it (ScenarioBatchModel) get x / y on first access instead of with every solve
+        self.lazy_solution = bool(lazy_solution)
         self.recertify = max(0, min(int(recertify), len(self.RECERTIFY_VARIANTS)))
         self._option_overrides = options
         self.options = None
@@ -420,8 +447,9 @@ class HipPdlpSolver:
             if good.any():
                 at = todo[good]
                 gsel = torch.as_tensor(np.nonzero(good)[0], dtype=torch.int64, device=dev)
-                host["x"].numpy()[at] = sub["x"].index_select(0, gsel).cpu().numpy()
-                host["y"].numpy()[at] = sub["y"].index_select(0, gsel).cpu().numpy()
+                if "x" in host:                                                    # (lazy solutions are read from `out` later)
+                    host["x"].numpy()[at] = sub["x"].index_select(0, gsel).cpu().numpy()
+                    host["y"].numpy()[at] = sub["y"].index_select(0, gsel).cpu().numpy()
                 host["obj"].numpy()[at] = sub["obj"].index_select(0, gsel).cpu().numpy()
                 host["jumps"].numpy()[at] = sub["jumps"].index_select(0, gsel).cpu().numpy()
                 host["flags"].numpy()[at] = fl[good]
@@ -460,7 +488,7 @@ class HipPdlpSolver:
             return buf[1]
         x0 = y0 = None
         pw = torch.zeros(B, dtype=torch.float64, device=dev)          # in: 0 = automatic; out: final primal weights
-        if warm_start and model.x is not None and model.y is not None and model.x.shape == (B, model.lp.n):
+        if warm_start and getattr(model, "has_solution", model.x is not None) and model.x is not None and model.y is not None and model.x.shape == (B, model.lp.n):
             xs, ys = model.x, model.y
             if shift:
                 cmap, rmap = period_shift_maps(model.lp, int(shift))
@@ -469,7 +497,11 @@ class HipPdlpSolver:
             prev = getattr(model, "primal_weight", None)
             if prev is not None and len(prev) == B:
                 pw = up("primal_weight", prev)
-        out = dlp.solve(B, up("c", model.c), up("lb", lb), up("ub", ub), up("rlo", rlo) if model.lp.m else None,
+        # objective vectors: a recipe (Bidder: base vector + price windows, formed on the device) or a dense [B, n] array
+        recipe = getattr(model, "c_recipe", None)
+        c_dev = recipe.device(torch, dev, up, dlp.__dict__.setdefault("_recipe_cache", {})) if recipe is not None and getattr(model, "_c", 0) is None \
+            else up("c", model.c)
+        out = dlp.solve(B, c_dev, up("lb", lb), up("ub", ub), up("rlo", rlo) if model.lp.m else None,
                         up("rhi", rhi) if model.lp.m else None, x0=x0, y0=y0, options=dlp.options,
                         obj_offset=up("c0", np.broadcast_to(np.asarray(model.c0, np.float64), (B,))), primal_weight=pw,
                         row_compliance=(up("kappa", kappa) if kappa is not None and np.any(kappa) else None))
@@ -485,19 +517,24 @@ class HipPdlpSolver:
             h.copy_(t, non_blocking=True)
             return h
 
-        host = {k: down(out[k]) for k in ("x", "y", "obj", "status", "iters", "jumps", "flags")}
+        lazy = self.lazy_solution and getattr(model, "supports_lazy_solution", False)
+        host = {k: down(out[k]) for k in ("obj", "status", "iters", "jumps", "flags") + (() if lazy else ("x", "y"))}
         host["pw"] = down(pw)
         torch.cuda.current_stream(dev).synchronize()
         status = host["status"].numpy()
         self.last_recertified = 0
         waived = np.nonzero((status == 0) & ((host["flags"].numpy() & FLAG_OBJ_WAIVED) != 0))[0]
         if len(waived) and self.recertify:
-            inputs = dict(c=stage["c"][1], lb=stage["lb"][1], ub=stage["ub"][1],
+            inputs = dict(c=c_dev, lb=stage["lb"][1], ub=stage["ub"][1],
                           rlo=stage["rlo"][1] if model.lp.m else None, rhi=stage["rhi"][1] if model.lp.m else None,
                           c0=stage["c0"][1], kappa=(stage["kappa"][1] if kappa is not None and np.any(kappa) else None))
             self.last_recertified = self._recertify(dlp, inputs, out, host, waived)
-        model.store_solution(host["x"].numpy(), host["y"].numpy()[:, :model.lp.m],
-                             host["obj"].numpy() + model.c0, status, host["iters"].numpy())
+        if lazy:
+            model.store_solution(None, None, host["obj"].numpy() + model.c0, status, host["iters"].numpy(),
+                                 lazy=DeviceSolution(out, model.lp.m, dev))
+        else:
+            model.store_solution(host["x"].numpy(), host["y"].numpy()[:, :model.lp.m],
+                                 host["obj"].numpy() + model.c0, status, host["iters"].numpy())
         model.jumps = host["jumps"].numpy()
         model.flags = host["flags"].numpy()      # DSP_FLAG_* bits AFTER the re-solves (bit 1 left = objective accuracy not certified)
         model.uncertified = uncertified(status, model.flags)

@@ -26,7 +26,7 @@ class _ScenarioIndexer:
         m = self._model
         if not 0 <= i < m.n_scenario:
             raise KeyError(i)
-        m.block.solution = None if m.x is None else m.x[i]
+        m.block.solution = m.row(i)
         return m.block
 
     def index_set(self):
@@ -62,16 +62,81 @@ class ScenarioBatchModel:
         self.c = None
         self.c0 = None
         self.lb = self.ub = self.rlo = self.rhi = None
-        # results
-        self.x = self.y = self.objective = self.status = self.iterations = None
+        # results (x / y may be held by the solver on the device and fetched on first access: store_solution(lazy=...))
+        self._x = self._y = self._lazy = None
+        self._row_cache = {}
+        self.objective = self.status = self.iterations = None
         self.solve_handle = None      # solver-owned cache (device copy of A, scaling, workspace)
+        # the objective vectors may be a RECIPE instead of a [B, n] array (Bidder._pass_price_forecasts): base vector + price windows,
+        # which a solver with device-side pricing turns into c on the device; `c` materialises it on the host on first access
+        self._c = None
+        self.c_recipe = None
+
+    supports_lazy_solution = True     # HipPdlpSolver leaves x / y on the device until somebody reads them
+
+    # -- lazily materialised arrays ------------------------------------------------------------------------------------
+    @property
+    def x(self):
+        if self._x is None and self._lazy is not None:
+            self._x, self._y = self._lazy.fetch()
+        return self._x
+
+    @x.setter
+    def x(self, v):
+        self._x = v
+        if v is None:
+            self._lazy = None
+
+    @property
+    def y(self):
+        if self._y is None and self._lazy is not None:
+            self._x, self._y = self._lazy.fetch()
+        return self._y
+
+    @y.setter
+    def y(self, v):
+        self._y = v
+
+    @property
+    def has_solution(self):
+        return self._x is not None or self._lazy is not None
+
+    def row(self, i):
+        """x[i] (None before the first solve); with the solution still on the device, rows are fetched sixteen at a time - record_bids
+        walks the first `detail_scenarios` scenarios one by one."""
+        if self._x is None and self._lazy is not None:
+            blk = i // 16
+            hit = self._row_cache.get(blk)
+            if hit is None:
+                hit = self._row_cache[blk] = self._lazy.rows(16 * blk, min(16 * blk + 16, self.n_scenario))
+            return hit[i - 16 * blk]
+        return None if self._x is None else self._x[i]
+
+    def columns(self, cols):
+        """x[:, cols] without fetching the whole solution when it still sits on the device."""
+        cols = np.asarray(cols)
+        if self._x is None and self._lazy is not None:
+            flat = self._lazy.columns(cols.reshape(-1))
+            return flat.reshape((flat.shape[0],) + cols.shape)
+        return self.x[:, cols]
+
+    @property
+    def c(self):
+        if self._c is None and self.c_recipe is not None:
+            self._c = self.c_recipe.dense()
+        return self._c
+
+    @c.setter
+    def c(self, v):
+        self._c = v
+        self.c_recipe = None
 
     # model.fs[i] (bidder) or model.fs (tracker: a single block)
     @property
     def fs(self):
         if self._indexed:
             return _ScenarioIndexer(self)
-        self.block.solution = None if self.x is None else self.x[0]
+        self.block.solution = self.row(0)
         return self.block
 
     def finalize(self, objective: LinExpr):
@@ -87,11 +152,19 @@ class ScenarioBatchModel:
         pick = lambda a, t: t if a is None else a
         return pick(self.lb, tlb), pick(self.ub, tub), pick(self.rlo, trlo), pick(self.rhi, trhi)
 
-    def store_solution(self, x, y, objective, status, iterations=None):
-        self.x, self.y = np.asarray(x), np.asarray(y)
+    def store_solution(self, x, y, objective, status, iterations=None, lazy=None):
+        """lazy: an object with fetch() -> (x, y) and columns(cols) -> x[:, cols] (hip_solver.DeviceSolution): the solution stays
+        where the solver left it until `x` / `y` are read; `fs[i]` positions the block on scenario i as before."""
+        self._row_cache = {}
+        if lazy is not None:
+            self._x = self._y = None
+            self._lazy = lazy
+        else:
+            self._lazy = None
+            self._x, self._y = np.asarray(x), np.asarray(y)
         self.objective, self.status = np.asarray(objective), np.asarray(status)
         self.iterations = None if iterations is None else np.asarray(iterations)
-        self.block.solution = self.x[0]
+        self.block.solution = None if lazy is not None else self._x[0]
 
     def expression_values(self, family: str) -> np.ndarray:
         """[B, T] values of an expression family (e.g. 'P_T') for every scenario at once.  The expressions have two or
@@ -106,4 +179,4 @@ class ScenarioBatchModel:
             for e, (j, v) in enumerate(fam[t].coef.items()):
                 cols[t, e], vals[t, e] = j, v
             k[t] = fam[t].const
-        return (self.x[:, cols] * vals).sum(axis=2) + k
+        return (self.columns(cols) * vals).sum(axis=2) + k

@@ -206,20 +206,16 @@ class StochasticProgramBidder(AbstractBidder):
         return a[:, :horizon]
 
     def _pass_price_forecasts(self, model, da, rt):
-        """Objective vectors for all scenarios at once:  c = base - RT (x) dP_T/dx - (DA-RT) on pda."""
-        c = np.empty((self.n_scenario, len(model.base_c)))
-        c[:] = model.base_c
+        """Objective vectors for all scenarios at once:  c = base - RT (x) dP_T/dx - (DA-RT) on pda.
+        Handed to the model as a RECIPE (PriceObjective): a solver with device-side pricing (HipPdlpSolver) uploads the two [B, T]
+        price windows and forms the [B, n] objective on the device - bit-identical to the host form below, which `model.c`
+        still materialises for everybody else (tests, the HiGHS test solver, the coupled problem)."""
         pt = getattr(model, "_pt_nonzeros", None)
         if pt is None:                                           # P_T[t] touches 1-2 columns per hour
             rows, cols = np.nonzero(model.PT_matrix)
             pt = model._pt_nonzeros = (rows, cols, model.PT_matrix[rows, cols], len(np.unique(cols)) == len(cols))
-        rows, cols, vals, distinct = pt
-        if distinct:                                             # every column belongs to one hour: plain fancy indexing
-            c[:, cols] -= rt[:, rows] * vals
-        else:
-            np.subtract.at(c, (slice(None), cols), rt[:, rows] * vals)
-        c[:, model.pda_cols] -= da - rt
-        model.c = c
+        model.c = None
+        model.c_recipe = PriceObjective(model.base_c, pt, model.pda_cols, da, rt)
         model.c0 = model.base_c0 - rt @ model.PT_const
         if getattr(model, "c0_shift", None) is not None:      # per-scenario objective constants (scenarios.py)
             model.c0 = model.c0 + model.c0_shift
@@ -344,6 +340,50 @@ class StochasticProgramBidder(AbstractBidder):
         self._generator = name
 
 
+class PriceObjective:
+    """c[s] = base - rt[s, t] * dP_T[t]/dx - (da - rt)[s, t] on day_ahead_power[t]: the objective vectors of a batch as a recipe.
+    dense(): the host form (numpy).  device(torch, dev, upload): the same arithmetic - one multiply, one subtract per touched entry,
+    in the same order - on device tensors from the uploaded price windows."""
+
+    def __init__(self, base_c, pt, pda_cols, da, rt):
+        self.base_c, self.pt, self.pda_cols = base_c, pt, np.asarray(pda_cols)
+        self.da, self.rt = np.ascontiguousarray(da, float), np.ascontiguousarray(rt, float)
+
+    @property
+    def shape(self):
+        return (self.da.shape[0], len(self.base_c))
+
+    def dense(self):
+        rows, cols, vals, distinct = self.pt
+        c = np.empty(self.shape)
+        c[:] = self.base_c
+        if distinct:                                             # every column belongs to one hour: plain fancy indexing
+            c[:, cols] -= self.rt[:, rows] * vals
+        else:
+            np.subtract.at(c, (slice(None), cols), self.rt[:, rows] * vals)
+        c[:, self.pda_cols] -= self.da - self.rt
+        return c
+
+    def device(self, torch, dev, upload, cache):
+        """[B, n] objective on `dev`; `upload(key, array)` returns the device copy of a host array; `cache`: a dict that lives with the
+        solver's handle (index tensors and the base vector are uploaded once)."""
+        rows, cols, vals, distinct = self.pt
+        if not distinct or len(np.intersect1d(cols, self.pda_cols)):
+            return upload("c", self.dense())                     # (scatter with repeated columns: keep the host order of operations)
+        key = (id(self.pt[1]), len(self.base_c))
+        st = cache.get("price_objective")
+        if st is None or st[0] != key:
+            i64 = lambda a: torch.as_tensor(np.ascontiguousarray(a, np.int64), device=dev)
+            st = cache["price_objective"] = (key, i64(rows), i64(cols), torch.as_tensor(np.ascontiguousarray(vals, np.float64), device=dev), i64(self.pda_cols))
+        _, rows_d, cols_d, vals_d, pda_d = st
+        base_d = upload("base_c", np.ascontiguousarray(self.base_c, np.float64))
+        da_d, rt_d = upload("da", self.da), upload("rt", self.rt)
+        c = base_d.unsqueeze(0).expand(self.shape[0], -1).contiguous()
+        c[:, cols_d] = c[:, cols_d] - rt_d[:, rows_d] * vals_d
+        c[:, pda_d] = c[:, pda_d] - (da_d - rt_d)
+        return c
+
+
 def round_decimal(a, ndigits):
     """Python's round(x, ndigits) - correctly rounded decimal, ties to even - for a whole array.
 
@@ -361,27 +401,79 @@ def round_decimal(a, ndigits):
     return out
 
 
+def _distinct_max(pw, pr):
+    """Sorted distinct values of `pw` and the largest `pr` at each: ONE sort, then a segmented maximum over the runs of equal
+    powers (np.unique + np.maximum.at did the same with a second pass and a scattered update)."""
+    if not len(pw):
+        return np.zeros(0), np.zeros(0)
+    order = np.argsort(pw)
+    ps, cs = pw[order], pr[order]
+    starts = np.flatnonzero(np.concatenate([[True], ps[1:] != ps[:-1]]))
+    return ps[starts] + 0.0, np.maximum.reduceat(cs, starts)          # (+ 0.0: no negative zeros in the curves)
+
+
 class Bidder(StochasticProgramBidder):
     """Bid-curve bidder: per hour the (power, price) pairs of all scenarios, rounded to 2 dp, sorted and
     integrated to a cost curve (pinned by SURVEY.md A.7 G2)."""
+
+    def _scenario_points(self, model, energy_prices, market):
+        """Per hour: (distinct powers offered by the scenarios, the highest marginal price at each), both rounded to 2 dp exactly
+        as Python's round() does (the reference's bid assembly calls it per pair), powers below p_min and failed scenarios
+        dropped.  Where the solution still sits on the device (HipPdlpSolver, lazy) the 98 k roundings and the 24 sorts of a
+        4096 x 24 h batch run there as tensor operations (workflow/bid_curves.py) and only the sorted integer pairs come back;
+        otherwise numpy, one pass per hour.  Both give the same arrays bit for bit (tests/test_bid_curves_cpu.py)."""
+        md = self.bidding_model_object.model_data
+        T = len(model.HOUR)
+        ok = getattr(model, "ok", None)
+        if ok is not None and ok.all():
+            ok = None
+        lazy = getattr(model, "_lazy", None) if getattr(model, "_x", 0) is None else None
+        fam = model.block.expressions[self.bidding_model_object.power_output]
+        if lazy is not None and hasattr(lazy, "x") and (market != "Real-time" or max(len(fam[t].coef) for t in range(T)) <= 2):
+            import torch
+            from . import bid_curves as bc
+            xd = lazy.x
+            dev = xd.device
+            i64 = lambda a: torch.as_tensor(np.ascontiguousarray(a, np.int64), device=dev)
+            f64 = lambda a: torch.as_tensor(np.ascontiguousarray(a, np.float64), device=dev)
+            if market == "Real-time":
+                # P_T[t] = sum_k vals[t, k] x[cols[t, k]] + const[t], at most two terms: the same products and the same single addition
+                # as ScenarioBatchModel.expression_values
+                K = max(1, max(len(fam[t].coef) for t in range(T)))
+                cols, vals, k0 = np.zeros((T, K), np.int64), np.zeros((T, K)), np.zeros(T)
+                for t in range(T):
+                    for e, (j, v) in enumerate(fam[t].coef.items()):
+                        cols[t, e], vals[t, e] = j, v
+                    k0[t] = fam[t].const
+                terms = xd[:, i64(cols.reshape(-1))].reshape(xd.shape[0], T, K) * f64(vals)
+                power = (terms[:, :, 0] if K == 1 else terms[:, :, 0] + terms[:, :, 1]) + f64(k0)
+            else:
+                power = xd[:, i64(model.pda_cols)]
+            price = f64(np.asarray(energy_prices, float)[:, :T])
+            okd = None if ok is None else torch.as_tensor(np.ascontiguousarray(ok), device=dev)
+            ps, cs, first = bc.sorted_pairs(torch, power[:, :T], price, md.p_min, okd)
+            return bc.hour_points(*bc.compact(torch, ps, cs, first))                                   # one download
+        power = model.expression_values(self.bidding_model_object.power_output) if market == "Real-time" \
+            else model.columns(model.pda_cols)
+        B = model.n_scenario
+        energy_prices = np.asarray(energy_prices, float)
+        if ok is not None:                                 # scenarios that failed to solve offer nothing
+            power = np.asarray(power, float)[ok]
+            energy_prices = energy_prices[ok]
+            B = int(ok.sum())
+        p2 = round_decimal(np.asarray(power[:, :T], float), 2).reshape(B, T)
+        c2 = round_decimal(energy_prices[:, :T], 2).reshape(B, T)
+        out = []
+        for t in range(T):
+            keep = p2[:, t] >= md.p_min
+            out.append(_distinct_max(p2[keep, t], c2[keep, t]))
+        return out
 
     def _assemble_bids(self, model, energy_prices, hour, market):
         md = self.bidding_model_object.model_data
         gen = self.generator
         is_thermal = md.generator_type == "thermal"
-        power = model.expression_values(self.bidding_model_object.power_output) if market == "Real-time" \
-            else model.x[:, model.pda_cols]
-        # all (scenario, hour) pairs rounded to 2 dp exactly as Python's round() does (the reference's bid assembly calls it
-        # per pair), then grouped per hour with numpy: one pass over B*T numbers instead of B*T dict updates
-        T = len(model.HOUR)
-        B = model.n_scenario
-        ok = getattr(model, "ok", None)
-        if ok is not None and not ok.all():                # scenarios that failed to solve offer nothing
-            power = np.asarray(power, float)[ok]
-            energy_prices = np.asarray(energy_prices, float)[ok]
-            B = int(ok.sum())
-        p2 = round_decimal(np.asarray(power[:, :T], float), 2).reshape(B, T)
-        c2 = round_decimal(np.asarray(energy_prices[:, :T], float), 2).reshape(B, T)
+        points = self._scenario_points(model, energy_prices, market)
         default = [(round(p, 2), float(mc)) for p, mc in md.p_cost] \
             if (is_thermal and getattr(md, "include_default_p_cost", False)) else []
         pmin2 = round(md.p_min, 2)
@@ -391,19 +483,9 @@ class Bidder(StochasticProgramBidder):
         dflt_c = np.array([d[1] for d in default], float)
         for t_idx in model.HOUR:
             t = t_idx + hour
-            keep = p2[:, t_idx] >= md.p_min
-            pw = np.concatenate([dflt_p, p2[keep, t_idx]])
-            pr = np.concatenate([dflt_c, c2[keep, t_idx]])
-            if len(pw):
-                # sorted distinct powers and the highest price offered at each: ONE sort by power, then a segmented maximum over
-                # the runs of equal powers (np.unique + np.maximum.at did the same with a second pass and a scattered update)
-                order = np.argsort(pw)
-                ps, cs = pw[order], pr[order]
-                starts = np.flatnonzero(np.concatenate([[True], ps[1:] != ps[:-1]]))
-                up = ps[starts] + 0.0                                           # (+ 0.0: no negative zeros in the curves)
-                mc = np.maximum.reduceat(cs, starts)
-            else:
-                up, mc = np.zeros(0), np.zeros(0)
+            up, mc = points[t_idx]
+            if len(dflt_p):                                # the generator's default cost-curve points join the scenarios' (a few numbers)
+                up, mc = _distinct_max(np.concatenate([dflt_p, up]), np.concatenate([dflt_c, mc]))
             if not (len(up) and (up == md.p_min).any()):
                 # the reference adds the p_min point at the lowest marginal price seen (0 if there is none)
                 lowest = float(mc.min()) if len(mc) else 0.0
@@ -465,7 +547,7 @@ class SelfScheduler(StochasticProgramBidder):
         if market == "Real-time":
             power = model.expression_values(self.bidding_model_object.power_output)[0]
         else:
-            power = model.x[0, model.pda_cols]
+            power = model.columns(model.pda_cols)[0]
         bids = {}
         for t_idx in model.HOUR:
             t = t_idx + hour

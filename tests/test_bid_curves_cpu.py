@@ -1,0 +1,103 @@
+"""The tensor form of the Bidder's bid assembly (workflow/bid_curves.py: exact decimal rounding + one batched sort, run on the device the
+solution lives on) against the numpy path it replaces, BIT FOR BIT, on CPU tensors: the same torch operations run on the GPU
+(tests/test_hip_bidder_api.py repeats the comparison there on a 4096-scenario solve).
+Reference behaviour: upstream `Bidder._assemble_bids` rounds every (power, price) pair with Python's round(x, 2)
+(golden G2: renewables_case/tests/test_multiperiod_wind_battery_doubleloop.py:245-250)."""
+import numpy as np
+import pytest
+import torch
+
+from dispatches_amd import scenarios
+from dispatches_amd.workflow import bid_curves as bc
+from dispatches_amd.workflow.batch_model import SolveResults
+from dispatches_amd.workflow.bidder import round_decimal
+
+
+def test_cents_is_pythons_round():
+    rng = np.random.default_rng(7)
+    vals = np.concatenate([
+        rng.uniform(-300, 300, 20000), rng.uniform(0, 1e5, 20000), rng.uniform(-1e-3, 1e-3, 2000),
+        np.round(rng.uniform(-500, 500, 20000), 3),                       # three decimals ending in 5: as close to a tie as doubles get
+        np.arange(-2000, 2000) / 8.0,                                     # EXACT ties (k + 1/2) / 100 representable: .125, .375, ...
+        np.arange(-4000, 4000) * 0.005, np.arange(0, 4000) * 0.015 + 0.005,
+        np.array([0.0, -0.0, 1.115, 2.675, 1.005, 0.125, -0.125, 0.375, 1e-300, -1e-300, 123456.785, 99999.995, 0.285, 0.295, 200.0])])
+    got = bc.cents(torch, torch.as_tensor(vals)).numpy()
+    want = np.array([int(round(round(float(v), 2) * 100)) for v in vals])
+    bad = np.nonzero(got != want)[0]
+    assert not len(bad), [(vals[i], got[i], want[i]) for i in bad[:10]]
+    # and the float the curve finally holds, cents / 100, is Python's round(v, 2) itself - also where round_decimal takes its slow path
+    np.testing.assert_array_equal(got / 100.0 + 0.0, np.array([round(float(v), 2) for v in vals]) + 0.0)
+    np.testing.assert_array_equal(got / 100.0 + 0.0, round_decimal(vals, 2) + 0.0)
+
+
+class _CpuLazy:
+    """What hip_solver.DeviceSolution is to the Bidder, on CPU tensors."""
+
+    def __init__(self, x, y):
+        self.x, self.y = torch.as_tensor(x), torch.as_tensor(y)
+
+    def fetch(self):
+        return self.x.numpy(), self.y.numpy()
+
+    def columns(self, cols):
+        return self.x.numpy()[:, np.asarray(cols)]
+
+    def rows(self, lo, hi):
+        return self.x.numpy()[lo:hi]
+
+
+class _PlantedSolver:
+    """Stores a planted solution - lazily (the tensor path) or eagerly (the numpy path)."""
+
+    def __init__(self, lazy, seed, fail=()):
+        self.lazy, self.seed, self.fail = lazy, seed, fail
+
+    def solve(self, model, tee=False):
+        B, n, m = model.n_scenario, model.lp.n, model.lp.m
+        rng = np.random.default_rng(self.seed)
+        x = rng.uniform(0, 220, (B, n))
+        dec = 10.0 ** rng.integers(0, 4, (B, len(model.pda_cols)))
+        x[:, model.pda_cols] = np.round(x[:, model.pda_cols] * dec) / dec                     # many duplicates and near-ties
+        x[rng.random((B, n)) < 0.2] = 0.0
+        x[::7, model.pda_cols[1]] = 12.345                                 # a power every seventh scenario shares
+        x[::5, model.pda_cols[2]] = 0.125                                  # an exact tie
+        y = np.zeros((B, m))
+        status = np.zeros(B, np.int32)
+        status[list(self.fail)] = 1
+        x[list(self.fail)] = np.nan
+        obj = np.zeros(B)
+        if self.lazy:
+            model.store_solution(None, None, obj, status, np.zeros(B, np.int32), lazy=_CpuLazy(x, y))
+        else:
+            model.store_solution(x, y, obj, status, np.zeros(B, np.int32))
+        model.flags = np.zeros(B, np.int32)
+        return SolveResults("ok", "optimal")
+
+
+@pytest.mark.parametrize("workload,thermal", [("wind_battery", True), ("wind_battery", False), ("nuclear", True)])
+@pytest.mark.parametrize("fail", [(), (3, 17)])
+def test_tensor_bid_assembly_reproduces_the_numpy_path(workload, thermal, fail):
+    import warnings
+    B, T = 257, 24
+    out = []
+    for lazy in (False, True):
+        solver = _PlantedSolver(lazy, seed=11, fail=fail)
+        if workload == "wind_battery":
+            bidder, model = scenarios.wind_battery_batch(B, T, solver)
+        else:
+            bidder, model = scenarios.nuclear_batch(B, T, solver)
+        md = bidder.bidding_model_object.model_data
+        if thermal and hasattr(md, "include_default_p_cost"):
+            md.include_default_p_cost = True
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            da = bidder.compute_day_ahead_bids("2020-01-02", 0)
+            rt = bidder.compute_real_time_bids("2020-01-02", 3, realized_day_ahead_prices=None, realized_day_ahead_dispatches=None)
+        assert (model._x is None) == lazy                           # the tensor path never fetched the whole solution
+        out.append((da, rt))
+    (da0, rt0), (da1, rt1) = out
+    for a, b in ((da0, da1), (rt0, rt1)):
+        assert a.keys() == b.keys()
+        for t in a:
+            for gen in a[t]:
+                assert a[t][gen] == b[t][gen], (t, a[t][gen]["p_cost"][:4], b[t][gen]["p_cost"][:4])   # floats compared exactly

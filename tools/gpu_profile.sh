@@ -14,16 +14,16 @@ bench="python $repo/bench.py"
 [ -n "$wl" ] && bench="python $repo/bench.py --workload $wl --no-spmv"
 $bench > "$out/${tag}_bench.json" 2> "$out/${tag}_bench.err"
 tail -c 600 "$out/${tag}_bench.json"; echo
-rm -rf /tmp/prof_trace; timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_trace -- $bench --cpu-sample 0 > /dev/null 2>&1
+rm -rf /tmp/prof_trace; timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_trace -- $bench --cpu-sample 0 --no-configs > /dev/null 2>&1
 f=$(find /tmp/prof_trace -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp "$f" "$out/${tag}_kernel_stats.csv" && head -4 "$f" | cut -c1-200
-rm -rf /tmp/prof_trace1; timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_trace1 -- $bench --cpu-sample 0 --streams 1 --no-spmv --min-time 0.2 > "$out/${tag}_bench_1stream.json" 2>/dev/null
+rm -rf /tmp/prof_trace1; timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_trace1 -- $bench --cpu-sample 0 --no-configs --streams 1 --no-spmv --min-time 0.2 > "$out/${tag}_bench_1stream.json" 2>/dev/null
 f=$(find /tmp/prof_trace1 -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp "$f" "$out/${tag}_kernel_stats_1stream.csv" && head -3 "$f" | cut -c1-200
 i=0
 for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY" \
            "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY" "SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_WAVES"; do
   i=$((i+1)); rm -rf /tmp/prof_pmc$i
   extra="--no-spmv"; [ $i -le 2 ] && extra="--spmv-large-mult 0"
-  timeout 300 rocprofv3 --pmc $set --output-format csv -d /tmp/prof_pmc$i -- $bench --cpu-sample 0 --steps 8 --warmup 1 --streams 8 --min-time 0 $extra > /dev/null 2>&1
+  timeout 300 rocprofv3 --pmc $set --output-format csv -d /tmp/prof_pmc$i -- $bench --cpu-sample 0 --no-configs --steps 8 --warmup 1 --streams 8 --min-time 0 $extra > /dev/null 2>&1
 done
 python - "$out/${tag}_pmc_summary.csv" <<'PY'
 import csv, glob, sys, collections

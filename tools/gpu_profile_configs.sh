@@ -9,7 +9,7 @@ export TMPDIR=/tmp; cd /tmp
 configs="wind_battery_24h:4096 wind_pem_48h:4096 nuclear_24h:256 nuclear_24h:4096 wind_battery_48h:4096"
 for cfg in $configs; do
   wl=${cfg%%:*}; B=${cfg##*:}
-  bench="python $repo/bench.py --workload $wl --batch $B --cpu-sample 0 --no-spmv --no-eps4"
+  bench="python $repo/bench.py --workload $wl --batch $B --cpu-sample 0 --no-spmv --no-eps4 --no-configs"
   i=0
   for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAVES"; do
     i=$((i+1)); rm -rf /tmp/pc_$i
@@ -47,7 +47,7 @@ rm -f "$out/${tag}_configs.jsonl"
 for cfg in $configs; do
   wl=${cfg%%:*}; B=${cfg##*:}
   [ "$cfg" = "wind_battery_24h:4096" ] && continue
-  timeout 200 python $repo/bench.py --workload $wl --batch $B --cpu-sample 0 --no-spmv 2>/dev/null | tail -1 >> "$out/${tag}_configs.jsonl"
+  timeout 200 python $repo/bench.py --workload $wl --batch $B --cpu-sample 0 --no-spmv --no-configs 2>/dev/null | tail -1 >> "$out/${tag}_configs.jsonl"
 done
 python - "$out/${tag}_configs.jsonl" <<'PY'
 import json, sys
