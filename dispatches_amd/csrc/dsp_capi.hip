@@ -539,7 +539,8 @@ int dsp_solve(dsp_handle *h, const dsp_batch *batch, const dsp_options *opt, dsp
   a.queue = h->queue + (size_t)slot * kQueueStride;
   a.queue_base = 0u;
   a.unsolved = a.queue + 1;
-  HIP_TRY(hipMemsetAsync(a.queue, 0, 2 * sizeof(int), st));
+  a.suspects = a.queue + 2;                          // (+ 3: the work-queue head of the certificate pass)
+  HIP_TRY(hipMemsetAsync(a.queue, 0, 4 * sizeof(int), st));
   a.matreg = qp ? h->matreg_qp : h->matreg;
   a.qp = qp;
 #ifdef DSP_KKT_TRACE
@@ -574,6 +575,27 @@ int dsp_solve(dsp_handle *h, const dsp_batch *batch, const dsp_options *opt, dsp
     HIP_TRY(hipModuleLaunchKernel(h->rtc[qp].fn, grid, 1, 1, 64 * a.waves_per_block, 1, 1, (unsigned)lds, st, nullptr, config));
   } else {
     HIP_TRY(launch_solve(h->cpl, h->rpl, a, dim3(grid), dim3(64 * a.waves_per_block), lds, st));
+  }
+  if (a.matreg && a.opt.eps_infeasible > 0.0) {
+    // Certificate pass: the register-resident kernels only WATCH for scenarios whose objectives keep drifting apart and leave them
+    // DSP_STATUS_SUSPECT; the generic kernel - which evaluates the infeasibility / unboundedness certificates at its restarts -
+    // continues those from their iterate (x0 / y0 = the outputs of the first pass).  One more launch per solve that returns at
+    // its first line when the device-side count of suspects is 0: every feasible batch.
+    SolveArgs c = a;
+    c.matreg = 0;
+    c.skip_solved = 2;
+    c.queue = a.queue + 3;
+    c.b.x0 = a.b.x; c.b.y0 = a.b.y;
+    c.waves_per_block = 1;
+    size_t lds2 = lds_bytes(h->P, 1, 0, h->cpl, h->rpl);
+    for (int wpb = 2; wpb <= 4; ++wpb) {              // a few waves per block share the LDS matrix; the pass is rare, not tuned
+      const size_t l = lds_bytes(h->P, wpb, 0, h->cpl, h->rpl);
+      if (l <= (size_t)h->lds_limit) { c.waves_per_block = wpb; lds2 = l; }
+    }
+    if (lds2 <= (size_t)h->lds_limit) {
+      const int grid2 = std::min((B + c.waves_per_block - 1) / c.waves_per_block, h->num_cus);
+      HIP_TRY(launch_solve(h->cpl, h->rpl, c, dim3(grid2), dim3(64 * c.waves_per_block), lds2, st));
+    }
   }
   if (timed) HIP_TRY(hipEventRecord(h->ev1, st));
 #ifdef DSP_KKT_TRACE

@@ -67,11 +67,15 @@ struct DeviceProblem {
 
 // internal status written by the simplex kernel for scenarios it leaves to the PDLP kernel (never reaches the caller)
 #define DSP_STATUS_UNSOLVED 99
+// internal status of a register-resident solve kernel for a scenario whose objectives keep drifting apart (an LP without a solution is
+// suspected): the certificate pass - the generic kernel, which evaluates the certificates - takes it from there (never reaches the caller)
+#define DSP_STATUS_SUSPECT 98
 
 struct SolveArgs {
   DeviceProblem P;
   dsp_batch b;
-  int skip_solved;             // 1 = only scenarios whose status is DSP_STATUS_UNSOLVED are solved (after the simplex pass)
+  int skip_solved;             // 1 = only scenarios whose status is DSP_STATUS_UNSOLVED are solved (after the simplex pass);
+                               // 2 = only DSP_STATUS_SUSPECT ones, continued from the iterate in b.x / b.y (certificate pass)
   int waves_per_block;
   double eta;
   dsp_options opt;
@@ -82,6 +86,7 @@ struct SolveArgs {
   int qp;                      // 1 = soft rows present (b.row_compliance): QP instantiation
   double *trace;               // development (-DDSP_KKT_TRACE, DSP_TRACE_SCENARIO): [4096][12] KKT history of one scenario
   int trace_scenario;
+  int *suspects;               // scenarios the register-resident kernel left DSP_STATUS_SUSPECT (0 = the certificate pass has nothing to do)
 };
 
 // Layout token of the kernarg buffer: a run-time compiled kernel (dsp_rtc.hpp) receives SolveArgs as raw bytes and is compiled

@@ -211,7 +211,16 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
   constexpr bool MATREG = WC != 0;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // after a simplex pass that certified every scenario there is nothing to do (one scalar load per wave)
-  if (a.skip_solved && __builtin_amdgcn_readfirstlane(*a.unsolved) == 0) return;
+  if (a.skip_solved == 1 && __builtin_amdgcn_readfirstlane(*a.unsolved) == 0) return;
+  // certificate pass (below: CERT) after a register-resident kernel that left no suspect: nothing to do either
+  if (a.skip_solved == 2 && __builtin_amdgcn_readfirstlane(*a.suspects) == 0) return;
+  // Infeasibility / unboundedness certificates (dsp_options::eps_infeasible).  The generic kernels evaluate them themselves, at
+  // restarts.  The register-resident kernels do NOT carry that code: on the 48-h shape - 246 of 256 VGPRs are live state - the two
+  // extra products in a rare block made the allocator spill on the common paths (-10 % on the whole batch, -2 % on the 24-h
+  // metric kernel, wherever the block was put: profiles/r50p_*, tools/kernel_resources.sh).  They only WATCH the relative gap (one
+  // comparison per KKT test) and hand a scenario whose objectives keep drifting apart over three tests to a second launch of the
+  // generic kernel (skip_solved = 2), which continues from its iterate.  Feasible batches: that launch returns at the line above.
+  constexpr bool CERT = !MATREG;
   const DeviceProblem &P = a.P;
   const dsp_batch &b = a.b;
   const int lane = threadIdx.x & 63;
@@ -374,7 +383,11 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
 #endif
     DSP_TRACE("[trace] scenario %d\n", s);
     if ((unsigned)s >= (unsigned)b.B) break;
-    if (a.skip_solved && __builtin_amdgcn_readfirstlane(b.status[s]) != DSP_STATUS_UNSOLVED) continue;
+    if (a.skip_solved == 1 && __builtin_amdgcn_readfirstlane(b.status[s]) != DSP_STATUS_UNSOLVED) continue;
+    if (a.skip_solved == 2 && __builtin_amdgcn_readfirstlane(b.status[s]) != DSP_STATUS_SUSPECT) continue;
+    // (certificate pass: the iterations the first pass spent on the scenario count; the limit covers both passes)
+    const int it_base = (a.skip_solved == 2 && b.iters) ? __builtin_amdgcn_readfirstlane(b.iters[s]) : 0;
+    const int max_it = max(a.opt.max_iter - it_base, 1);
 
     // ---- load + scale this scenario's vectors (coalesced: lane-consecutive addresses) -----------------------
     double x[CPL], x0[CPL], c[CPL], lb[CPL], ub[CPL];
@@ -494,7 +507,8 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
     int stalls = 0;                  // restarts forced after >= stall_rescue iterations without decay
     bool waive_obj = false;          // stalled twice: terminate on the eps_rel tests alone
     bool lastjump = false;           // the last restart of the anchor was a ray jump
-    bool suspect = false;            // the last KKT test found the objectives drifting apart: certificates at every 4th check
+    bool suspect = false;            // the last KKT test found the objectives drifting apart: KKT tests at every 4th check from then on
+    int nsus = 0;                    // consecutive KKT tests that did (register-resident kernels: three of them end the first pass)
     pol_best.set(INFINITY);          // polish phase (eps_rel tests hold, eps_obj tests missing): best worst-ratio seen,
     int pol_it = 0, nboost = 0;      //   the iteration it was seen at, guard tightenings so far
     bool pol_tried = false;          //   the guard test of this stagnation period has been made
@@ -566,7 +580,7 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
     DSP_TRACE("[trace] enter loop\n");
     for (it = 0;;) {
       // ---- plain iterations up to the next check: two SpMVs + elementwise work, no reduction, no branch --------
-      const int plain = min(check_every - 1, a.opt.max_iter - it);
+      const int plain = min(check_every - 1, max_it - it);
       DSP_PROF_MARK()
       for (int u = 0; u < plain; ++u) {
         DSP_PDHG_STEP()
@@ -576,7 +590,7 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
       DSP_PROF_ADD(0)
       it += plain;
       DSP_TRACE("[trace] it=%d k=%d\n", it, k);
-      if (it >= a.opt.max_iter) break;
+      if (it >= max_it) break;
       // ---- check iteration ----------------------------------------------------------------------------------
       DSP_PDHG_STEP()
       ++k;
@@ -671,63 +685,6 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
           const double rd = sqrt(red[1]) / (1.0 + cn.get());
           const double gap = fabs(po - dobj);
           const double rg = gap / (1.0 + fabs(po) + fabs(dobj));
-          // ---- infeasibility / unboundedness certificates (dsp_options::eps_infeasible) ---------------------------------------
-          // An LP without a solution has no fixed point: T(z) - z tends to a ray (dx, dy), one of the objectives runs away and the
-          // relative gap goes to 1.  On the bidding LPs of every workload the gap is below 1/2 by the 8th check (lab:
-          // tools/infeas_lab.py, no test at all on 4 x 64 feasible scenarios), so feasible batches pay one comparison per KKT
-          // test.  dy, with the signs its rows cannot take removed, is tested as a FARKAS RAY (reduced costs -A'dy absorbed by
-          // finite column bounds, bound value > 0); dx, clipped to the recession cone of the column bounds, as a direction of
-          // UNBOUNDED descent (c.dx < 0, A dx in the recession cone of the rows).  Both are proofs up to the tolerance whatever
-          // the iterate; scaled space (diagonal scalings map the cones onto themselves).  Soft rows (QP) admit no multiplier ray
-          // and count as equalities for the recession cone.  Lab: a 24-h bidding LP with 10 x the battery as initial charge is
-          // certified at iteration 192, unbounded variants at 0.8 - 2.5 k (five of six; the rest of the LP keeps converging
-          // underneath the ray, and its movement counts as violation until it has).
-          suspect = a.opt.eps_infeasible > 0.0 && rg >= 0.5 && ncheck >= 8;
-          if (suspect) {
-            double rr[6] = {0, 0, 0, 0, 0, 0};   // 0 |dual residual of the ray|^2, 1 its bound value, 2 |bounds|^2, 3 |recession violation|^2, 4 c.d, 5 |c|^2
-#pragma unroll
-            for (int q = 0; q < RPL; ++q) {
-              const double dy = yp[q] - y[q];
-              const double rlo_q = rlo[q].get(), rhi_q = rhi[q].get();
-              double yc = (is_finite(rlo_q) ? fmax(dy, 0.0) : 0.0) - (is_finite(rhi_q) ? fmax(-dy, 0.0) : 0.0);
-              if constexpr (QP) { if (kap[q] > 0.0) yc = 0.0; }
-              lds_store_f64(yw[q], yc);
-              rr[1] += fmax(yc, 0.0) * finite_or_zero(rlo_q) - fmax(-yc, 0.0) * finite_or_zero(rhi_q);
-              const double big = fmax(fabs(finite_or_zero(rlo_q)), fabs(finite_or_zero(rhi_q)));
-              rr[2] = fma(big, big, rr[2]);
-            }
-            wave_lds_fence();
-            col_step(atyp, zero_c, tau);                   // tau A^T (cleaned dy)
-#pragma unroll
-            for (int q = 0; q < CPL; ++q) {
-              const double lbq = lb[q], ubq = ub[q];
-              const bool fl = is_finite(lbq), fu = is_finite(ubq);
-              const double rc = -(itau * atyp[q]);
-              const double lp = fl ? fmax(rc, 0.0) : 0.0, lm = fu ? fmax(-rc, 0.0) : 0.0;
-              const double res = rc - lp + lm;
-              rr[0] = fma(res, res, rr[0]);
-              rr[1] += lp * finite_or_zero(lbq) - lm * finite_or_zero(ubq);
-              const double lf = finite_or_zero(lbq), uf = finite_or_zero(ubq);
-              rr[2] += lf * lf + uf * uf;
-              const double dx = xp[q] - x[q];
-              const double d = (fl && fu) ? 0.0 : fl ? fmax(dx, 0.0) : fu ? fmin(dx, 0.0) : dx;
-              lds_store_f64(xw[q], d);
-              rr[4] = fma(c[q], d, rr[4]);
-              rr[5] = fma(c[q], c[q], rr[5]);
-            }
-            wave_lds_fence();
-            row_step(axp, zero_r, -sig);                   // -sig A (clipped dx)
-#pragma unroll
-            for (int q = 0; q < RPL; ++q) {
-              const double ad = nisig * axp[q];
-              const double rv = (is_finite(rlo[q].get()) ? fmax(-ad, 0.0) : 0.0) + (is_finite(rhi[q].get()) ? fmax(ad, 0.0) : 0.0);
-              rr[3] = fma(rv, rv, rr[3]);
-            }
-            wave_sums<6>(rr);
-            const double ei = a.opt.eps_infeasible;
-            if (rr[1] > 0.0 && sqrt(rr[0]) * (1.0 + sqrt(rr[2])) <= ei * rr[1]) { status = DSP_STATUS_PRIMAL_INFEASIBLE; ++it; break; }
-            if (rr[4] < 0.0 && sqrt(rr[3]) * (1.0 + sqrt(rr[5])) <= ei * -rr[4]) { status = DSP_STATUS_DUAL_INFEASIBLE; ++it; break; }
-          }
           // Termination.  eps_obj > 0 (default): both feasibility tests AND a bound on the objective error of x+,
           //     err = |gap| + sum |y_i| viol_i + sum |dual residual_j| |x_j|  <=  eps_obj (1 + |c.x + c0|)
           // (the infeasibility-weighted sums are what the remaining infeasibilities can move the objective by).  The
@@ -798,6 +755,13 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
             }
           }
           if (done) { status = DSP_STATUS_OPTIMAL; ++it; break; }
+          // the objectives drifting apart after the 8th check: an LP without a solution is suspected, the certificates are
+          // evaluated at the restarts from here on (see the restart block)
+          suspect = a.opt.eps_infeasible > 0.0 && rg >= 0.5 && ncheck >= 8;
+          if constexpr (!CERT) {
+            nsus = suspect ? nsus + 1 : 0;
+            if (nsus >= 3) { status = DSP_STATUS_SUSPECT; ++it; break; }
+          }
           const double gf = fmin(1.0, a.opt.kkt_gate / rho);
           gate2 = r * gf * gf;
           last_kkt = ncheck;
@@ -852,6 +816,67 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
           lastjump = false;
           moved = true;
           DSP_PROF_ADD(3)
+          // ---- infeasibility / unboundedness certificates (dsp_options::eps_infeasible) ---------------------------------------
+          // An LP without a solution has no fixed point: T(z) - z tends to a ray (dx, dy), one of the objectives runs away and the
+          // relative gap goes to 1.  On the bidding LPs of every workload the gap is below 1/2 by the 8th check (lab:
+          // tools/infeas_lab.py, no test at all on 4 x 64 feasible scenarios), so feasible batches pay one comparison per KKT
+          // test.  dy, with the signs its rows cannot take removed, is tested as a FARKAS RAY (reduced costs -A'dy absorbed by
+          // finite column bounds, bound value > 0); dx, clipped to the recession cone of the column bounds, as a direction of
+          // UNBOUNDED descent (c.dx < 0, A dx in the recession cone of the rows).  Both are proofs up to the tolerance whatever
+          // the iterate; scaled space (diagonal scalings map the cones onto themselves).  Soft rows (QP) admit no multiplier ray
+          // and count as equalities for the recession cone.  Lab: a 24-h bidding LP with 10 x the battery as initial charge is
+          // certified at iteration 192, unbounded variants at 0.8 - 2.5 k (five of six; the rest of the LP keeps converging
+          // underneath the ray, and its movement counts as violation until it has).
+          // Evaluated HERE, right after a restart: anchor and iterate coincide, so a third of the per-scenario state is dead and the
+          // two extra products fit without new spills on the common paths (in the KKT block they cost the 48-h kernel 10 %).
+          if constexpr (CERT) if (suspect) {
+            DSP_PDHG_STEP()                                // (x+, y+) = T(x, y) from the restart point: the displacement the certificates use
+            const double itau = w * ieta, nisig = -(iw * ieta);
+            double atyp[CPL], axp[RPL];
+            double rr[6] = {0, 0, 0, 0, 0, 0};   // 0 |dual residual of the ray|^2, 1 its bound value, 2 |bounds|^2, 3 |recession violation|^2, 4 c.d, 5 |c|^2
+#pragma unroll
+            for (int q = 0; q < RPL; ++q) {
+              const double dy = yp[q] - y[q];
+              const double rlo_q = rlo[q].get(), rhi_q = rhi[q].get();
+              double yc = (is_finite(rlo_q) ? fmax(dy, 0.0) : 0.0) - (is_finite(rhi_q) ? fmax(-dy, 0.0) : 0.0);
+              if constexpr (QP) { if (kap[q] > 0.0) yc = 0.0; }
+              lds_store_f64(yw[q], yc);
+              rr[1] += fmax(yc, 0.0) * finite_or_zero(rlo_q) - fmax(-yc, 0.0) * finite_or_zero(rhi_q);
+              const double big = fmax(fabs(finite_or_zero(rlo_q)), fabs(finite_or_zero(rhi_q)));
+              rr[2] = fma(big, big, rr[2]);
+            }
+            wave_lds_fence();
+            col_step(atyp, zero_c, tau);                   // tau A^T (cleaned dy)
+#pragma unroll
+            for (int q = 0; q < CPL; ++q) {
+              const double lbq = lb[q], ubq = ub[q];
+              const bool fl = is_finite(lbq), fu = is_finite(ubq);
+              const double rc = -(itau * atyp[q]);
+              const double lp = fl ? fmax(rc, 0.0) : 0.0, lm = fu ? fmax(-rc, 0.0) : 0.0;
+              const double res = rc - lp + lm;
+              rr[0] = fma(res, res, rr[0]);
+              rr[1] += lp * finite_or_zero(lbq) - lm * finite_or_zero(ubq);
+              const double lf = finite_or_zero(lbq), uf = finite_or_zero(ubq);
+              rr[2] += lf * lf + uf * uf;
+              const double dx = xp[q] - x[q];
+              const double d = (fl && fu) ? 0.0 : fl ? fmax(dx, 0.0) : fu ? fmin(dx, 0.0) : dx;
+              lds_store_f64(xw[q], d);
+              rr[4] = fma(c[q], d, rr[4]);
+              rr[5] = fma(c[q], c[q], rr[5]);
+            }
+            wave_lds_fence();
+            row_step(axp, zero_r, -sig);                   // -sig A (clipped dx)
+#pragma unroll
+            for (int q = 0; q < RPL; ++q) {
+              const double ad = nisig * axp[q];
+              const double rv = (is_finite(rlo[q].get()) ? fmax(-ad, 0.0) : 0.0) + (is_finite(rhi[q].get()) ? fmax(ad, 0.0) : 0.0);
+              rr[3] = fma(rv, rv, rr[3]);
+            }
+            wave_sums<6>(rr);
+            const double ei = a.opt.eps_infeasible;
+            if (rr[1] > 0.0 && sqrt(rr[0]) * (1.0 + sqrt(rr[2])) <= ei * rr[1]) { status = DSP_STATUS_PRIMAL_INFEASIBLE; ++it; break; }
+            if (rr[4] < 0.0 && sqrt(rr[3]) * (1.0 + sqrt(rr[5])) <= ei * -rr[4]) { status = DSP_STATUS_DUAL_INFEASIBLE; ++it; break; }
+          }
         } else if (steady) {
           // ---- ray jump: second application of T from (x+, y+), translation test, ratio test ------------------
           double x2[CPL], y2[RPL];
@@ -970,7 +995,8 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
     if (lane == 0) {
       b.obj[s] = pobj.get();
       b.status[s] = status;
-      if (b.iters) b.iters[s] = it;
+      if (b.iters) b.iters[s] = it + it_base;
+      if (status == DSP_STATUS_SUSPECT) atomicAdd(a.suspects, 1);
 #ifdef DSP_CLOCKS
       iters_done += it;
 #endif
@@ -1064,7 +1090,7 @@ extern "C" __device__ __attribute__((used)) const unsigned long long dsp_rtc_lay
 namespace dsp {
 #endif
 
-#ifndef __HIPCC_RTC__     /* everything below is host code */
+#if !defined(__HIPCC_RTC__) && !defined(DSP_KERNELS_ONLY)     /* everything below is host code (DSP_KERNELS_ONLY: development TUs that instantiate single kernels, tools/kernel_resources.sh) */
 // ---- launch tables ------------------------------------------------------------------------------------------
 // Register-resident-matrix specialisations exist for the shapes of the reference's flowsheets at the benchmark
 // horizons (cols/lane, rows/lane, ELL width of A^T, ELL width of A, long vectors): everything else runs the generic

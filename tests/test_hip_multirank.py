@@ -67,10 +67,10 @@ def test_sharded_solve_two_ranks_on_one_gpu():
         assert (status == 0).all() and (flags & 1 == 0).all() and not xnan
 
 
-def _run_bench(extra, timeout=600):
+def _run_bench(extra, timeout=600, nproc=2):
     env = dict(os.environ, DSP_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2"] + extra
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(nproc)] + extra
     out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=timeout)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
@@ -92,3 +92,26 @@ def test_bench_launch_contract_with_two_ranks():
     assert d["config"]["optimal"] == 1025
     d = _run_bench(["--workload", "double_loop", "--total", "65", "--steps", "1", "--warmup", "1"])
     assert d["n_gpus"] == 2 and d["config"]["all_optimal"] is True and d["value"] > 0 and d["rehearsal"] is True
+
+
+@gpu
+def test_bench_launch_contract_with_eight_ranks():
+    """The launch the scaling bench makes on an 8-GPU node, rehearsed with eight ranks on this box's one GPU (gloo on host copies):
+    the metric workload with the stream depth chosen in the warm-up (eight ranks x up to 24 streams, every step an all-gather on
+    the one communicator), BASELINE config 4's 8192 scenarios minus one as a ragged strong-scaling split, and config 4 itself -
+    the rolling double loop of 8192 plants, 1024 per rank.  Not scaling numbers (`rehearsal`); what is pinned is that the
+    first real 8-rank launch cannot fail on plumbing, and that the line proves how many ranks and distinct GPUs took part."""
+    import time
+    t0 = time.time()
+    d = _run_bench(["--steps", "4", "--warmup", "1", "--no-spmv", "--cpu-sample", "0", "--min-time", "0.05", "--batch", "512"], timeout=900, nproc=8)
+    assert d["n_gpus"] == 8 and d["world_size"] == 8 and d["dist_world_size"] == 8 and d["rehearsal"] is True and d["scaling"] == "weak"
+    assert len(d["rank_devices"]) == 8 and sorted(r["rank"] for r in d["rank_devices"]) == list(range(8)) and d["distinct_gpus"] == 1
+    assert d["config"]["scenarios"] == 4096 and d["config"]["optimal"] == 4096 and d["config"]["flagged"] == 0 and d["value"] > 0
+    d = _run_bench(["--steps", "2", "--warmup", "1", "--no-spmv", "--cpu-sample", "0", "--min-time", "0", "--streams", "8",
+                    "--workload", "wind_battery_48h", "--total", "8191"], timeout=900, nproc=8)
+    assert d["scaling"] == "strong" and d["config"]["scenarios"] == 8191 and d["config"]["batch_per_gpu"] == 1024
+    assert d["config"]["optimal"] == 8191 and d["dist_world_size"] == 8
+    d = _run_bench(["--workload", "double_loop", "--total", "8192", "--steps", "1", "--warmup", "1"], timeout=900, nproc=8)
+    assert d["n_gpus"] == 8 and d["config"]["all_optimal"] is True and d["config"]["uncertified_solves"] == 0 and d["dist_world_size"] == 8
+    assert "8192 wind+battery plants (1024 per GPU)" in d["config"]["workload"]
+    assert time.time() - t0 < 1800
