@@ -506,6 +506,7 @@ __global__ void k_control(StreamArgs a, int iters_this_period) {
   if (threadIdx.x != 0) return;
   control_decide(acc, c, a.opt, a.eta, iters_this_period);
   if (c.done) atomicAdd(a.W.ndone, 1);
+  else if (c.suspect) a.W.ndone[1] = 1;
 }
 
 // ---- apply: Halpern step or restart after a check ---------------------------------------------------------------------------
@@ -534,6 +535,172 @@ __global__ void k_apply(StreamArgs a) {
       else { const double y = a.W.y[at]; const double tt = 2.0 * yp - y; a.W.y[at] = fma(oml, a.W.y0[at] - tt, tt); }
     }
   }
+}
+
+// ---- infeasibility / unboundedness certificates (dsp_options::eps_infeasible) on the scenario-major workspace ------------------------
+// Same certificates as the fused kernels (dsp_kernels.hip): the dual part dy of the displacement T(z) - z, with the signs its rows
+// cannot take removed, as a FARKAS RAY; the primal part dx, clipped to the recession cone of the column bounds, as a direction of
+// unbounded descent.  Run by the host for the scenarios control_decide marked suspect (StreamCtrl::suspect), after k_primal<.., true>
+// and k_check_rows have put T(z) into xp / yp:
+//   k_ray_prep   d -> xbar, cleaned dy -> ray                    (element-wise)
+//   k_ray_rows   A d (ELL rows + long rows), the rows' share of the ray's bound value        -> partial slots 1 .. 3
+//   k_ray_cols   A^T dy (ELL columns; long columns: chunk partials + k_ray_long_finish)       -> partial slots 4 .. 8
+//   k_ray_decide sums, the two tests, status 2 / 3
+template <int SG>
+__global__ void k_ray_prep(StreamArgs a) {
+  const StreamProblem &P = a.P;
+  const int b0 = blockIdx.y * SG;
+  const int t = blockIdx.x * kTB + threadIdx.x;
+  for (int u = 0; u < SG; ++u) {
+    const int s = b0 + u;
+    if (s >= a.b.B) break;
+    const StreamCtrl &c = a.W.ctrl[s];
+    if (c.done || !c.suspect) continue;
+    if (t < P.n) {
+      const size_t at = (size_t)s * P.n + t;
+      const double dx = a.W.xp[at] - a.W.x[at];
+      const bool fl = finite_d(a.W.lb[at]), fu = finite_d(a.W.ub[at]);
+      a.W.xbar[at] = (fl && fu) ? 0.0 : fl ? fmax(dx, 0.0) : fu ? fmin(dx, 0.0) : dx;
+    }
+    if (t < P.m) {
+      const size_t at = (size_t)s * P.m + t;
+      const double dy = a.W.yp[at] - a.W.y[at];
+      double yc = (finite_d(a.W.rlo[at]) ? fmax(dy, 0.0) : 0.0) - (finite_d(a.W.rhi[at]) ? fmax(-dy, 0.0) : 0.0);
+      if (a.b.row_compliance && a.W.kap[at] > 0.0) yc = 0.0;           // soft rows admit no multiplier ray
+      a.W.ray[at] = yc;
+    }
+  }
+}
+
+// grid: (row blocks + one block per long row, scenario groups)
+template <int SG>
+__global__ void k_ray_rows(StreamArgs a) {
+  const StreamProblem &P = a.P;
+  const int b0 = blockIdx.y * SG;
+  const int t = blockIdx.x * kTB + threadIdx.x;
+  const bool is_long_block = (int)blockIdx.x >= a.nblk;
+  const bool row = !is_long_block && t < P.m && !P.R.is_long[t < P.m ? t : 0];
+  for (int u = 0; u < SG; ++u) {
+    const int s = b0 + u;
+    if (s >= a.b.B) break;
+    const StreamCtrl &c = a.W.ctrl[s];
+    double v[3] = {0, 0, 0};                       // 1 bound value of the ray (rows), 2 |bounds|^2 (rows), 3 |recession violation of A d|^2
+    if (!c.done && c.suspect) {
+      const double *__restrict__ d = a.W.xbar + (size_t)s * P.n;
+      int i = -1;
+      double ad = 0.0;
+      if (is_long_block) {
+        const int l = blockIdx.x - a.nblk;
+        const double t1 = long_dot_all(P.R, l, d);
+        if (threadIdx.x == 0) { i = P.R.long_id[l]; ad = t1; }
+      } else if (row) {
+        i = t;
+        ad = ell_dot(P.R, t, d);
+      }
+      if (i >= 0) {
+        const size_t at = (size_t)s * P.m + i;
+        const double yc = a.W.ray[at], rlo = a.W.rlo[at], rhi = a.W.rhi[at];
+        v[0] = fmax(yc, 0.0) * fin0(rlo) - fmax(-yc, 0.0) * fin0(rhi);
+        const double big = fmax(fabs(fin0(rlo)), fabs(fin0(rhi)));
+        v[1] = big * big;
+        const double rv = (finite_d(rlo) ? fmax(-ad, 0.0) : 0.0) + (finite_d(rhi) ? fmax(ad, 0.0) : 0.0);
+        v[2] = rv * rv;
+      }
+    }
+    block_partials<3>(v, a.W.partial + ((size_t)s * a.nblk_tot + blockIdx.x) * kNQ + 1);
+  }
+}
+
+// the five column quantities (slots 4 .. 8): c.d, |c|^2, bound value of the ray (columns), |bounds|^2 (columns), |dual residual of the ray|^2
+__device__ __forceinline__ void ray_col_terms(const StreamArgs &a, int s, int j, double aty, double (&v)[5]) {
+  const size_t at = (size_t)s * a.P.n + j;
+  const double cj = a.W.c[at], lb = a.W.lb[at], ub = a.W.ub[at], d = a.W.xbar[at];
+  const double rc = -aty;
+  const double lp = finite_d(lb) ? fmax(rc, 0.0) : 0.0;
+  const double lm = finite_d(ub) ? fmax(-rc, 0.0) : 0.0;
+  const double res = rc - lp + lm;
+  v[0] = cj * d;
+  v[1] = cj * cj;
+  v[2] = lp * fin0(lb) - lm * fin0(ub);
+  v[3] = fin0(lb) * fin0(lb) + fin0(ub) * fin0(ub);
+  v[4] = res * res;
+}
+
+// grid: (column blocks + one block per CHUNK of a long column, scenario groups), as k_kkt_cols
+template <int SG>
+__global__ void k_ray_cols(StreamArgs a) {
+  const StreamProblem &P = a.P;
+  const int b0 = blockIdx.y * SG;
+  if ((int)blockIdx.x >= a.nblk_n) {
+    const int ch = blockIdx.x - a.nblk_n;
+    for (int u = 0; u < SG; ++u) {
+      const int s = b0 + u;
+      if (s >= a.b.B) break;
+      if (a.W.ctrl[s].done || !a.W.ctrl[s].suspect) continue;
+      const double part = long_dot(P.C, ch, a.W.ray + (size_t)s * P.m);
+      if (threadIdx.x == 0) a.W.long_partial[(size_t)s * a.nchunk_max + ch] = part;
+    }
+    return;
+  }
+  const int t = blockIdx.x * kTB + threadIdx.x;
+  const bool col = t < P.n && !P.C.is_long[t < P.n ? t : 0];
+  for (int u = 0; u < SG; ++u) {
+    const int s = b0 + u;
+    if (s >= a.b.B) break;
+    const StreamCtrl &c = a.W.ctrl[s];
+    double v[5] = {0, 0, 0, 0, 0};
+    if (!c.done && c.suspect && col) ray_col_terms(a, s, t, ell_dot(P.C, t, a.W.ray + (size_t)s * P.m), v);
+    block_partials<5>(v, a.W.partial + ((size_t)s * a.nblk_tot + blockIdx.x) * kNQ + 4);
+  }
+}
+
+__global__ void k_ray_long_finish(StreamArgs a) {
+  const StreamProblem &P = a.P;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= P.C.nlong * a.b.B) return;
+  const int l = t % P.C.nlong, s = t / P.C.nlong;
+  double v[5] = {0, 0, 0, 0, 0};
+  if (!a.W.ctrl[s].done && a.W.ctrl[s].suspect) {
+    double aty = 0.0;
+    for (int ch = P.C.long_chunk_ptr[l]; ch < P.C.long_chunk_ptr[l + 1]; ++ch) aty += a.W.long_partial[(size_t)s * a.nchunk_max + ch];
+    ray_col_terms(a, s, P.C.long_id[l], aty, v);
+  }
+  double *out = a.W.partial + ((size_t)s * a.nblk_tot + a.nblk_n + l) * kNQ + 4;
+#pragma unroll
+  for (int q = 0; q < 5; ++q) out[q] = v[q];
+}
+
+// the two tests on the sums (slot q of `acc`: see the kernels above); returns the status (0 = no certificate)
+__device__ inline int ray_verdict(const double *acc, double eps_infeasible) {
+  const double bound_value = acc[1] + acc[6], bounds2 = acc[2] + acc[7];
+  if (bound_value > 0.0 && sqrt(acc[8]) * (1.0 + sqrt(bounds2)) <= eps_infeasible * bound_value) return DSP_STATUS_PRIMAL_INFEASIBLE;
+  if (acc[4] < 0.0 && sqrt(acc[3]) * (1.0 + sqrt(acc[5])) <= eps_infeasible * -acc[4]) return DSP_STATUS_DUAL_INFEASIBLE;
+  return 0;
+}
+
+__global__ void k_ray_decide(StreamArgs a) {
+  const int s = blockIdx.x;
+  StreamCtrl &c = a.W.ctrl[s];
+  if (c.done || !c.suspect) return;
+  __shared__ double strand[16][kNQ];
+  __shared__ double acc[kNQ];
+  {
+    const int q = threadIdx.x & (kNQ - 1), p = threadIdx.x >> 4;
+    double t = 0.0;
+    if (q >= 1 && q <= 8) for (int blk = p; blk < a.nblk_tot; blk += 16) t += a.W.partial[((size_t)s * a.nblk_tot + blk) * kNQ + q];
+    strand[p][q] = t;
+  }
+  __syncthreads();
+  if (threadIdx.x < kNQ) {
+    double t = 0.0;
+#pragma unroll
+    for (int p = 0; p < 16; ++p) t += strand[p][threadIdx.x];
+    acc[threadIdx.x] = t;
+  }
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  const int verdict = ray_verdict(acc, a.opt.eps_infeasible);
+  if (verdict) { c.status = verdict; c.done = 1; atomicAdd(a.W.ndone, 1); }
 }
 
 // ---- block-resident solve for MID-SIZE LPs: one workgroup per scenario, the whole state in LDS --------------------------------
@@ -705,6 +872,56 @@ __global__ void __launch_bounds__(1024) k_block_solve(StreamArgs a) {
       if (t0 == 0) mode_s = control_decide(acc, c, a.opt, a.eta, C);
       __syncthreads();
       if (c.done) break;
+      if (c.suspect) {
+        // certificates on the displacement (x+ - x, y+ - y) of this check: the same sums as k_ray_rows / k_ray_cols, state in LDS
+        // (xb <- clipped dx, axp <- cleaned dy: both are scratch between two iterations)
+        for (int j = t0; j < n; j += NT) {
+          const double dx = xp[j] - x[j];
+          const bool fl = finite_d(lb[j]), fu = finite_d(ub[j]);
+          xb[j] = (fl && fu) ? 0.0 : fl ? fmax(dx, 0.0) : fu ? fmin(dx, 0.0) : dx;
+        }
+        for (int i = t0; i < m; i += NT) {
+          const double dy = yp[i] - y[i];
+          double yc = (finite_d(rlo[i]) ? fmax(dy, 0.0) : 0.0) - (finite_d(rhi[i]) ? fmax(-dy, 0.0) : 0.0);
+          if (kapg && kapg[i] > 0.0) yc = 0.0;
+          axp[i] = yc;
+        }
+        __syncthreads();
+        double rv[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        for (int i = t0; i < m; i += NT) {             // (no long rows in this form)
+          double ad = 0.0;
+          for (int e = 0; e < P.R.W; ++e) ad = fma(P.R.val[(size_t)e * m + i], xb[P.R.idx[(size_t)e * m + i]], ad);
+          rv[1] += fmax(axp[i], 0.0) * fin0(rlo[i]) - fmax(-axp[i], 0.0) * fin0(rhi[i]);
+          const double big = fmax(fabs(fin0(rlo[i])), fabs(fin0(rhi[i])));
+          rv[2] += big * big;
+          const double r_ = (finite_d(rlo[i]) ? fmax(-ad, 0.0) : 0.0) + (finite_d(rhi[i]) ? fmax(ad, 0.0) : 0.0);
+          rv[3] += r_ * r_;
+        }
+        auto col_terms = [&](int j, double aty) {
+          const double rc = -aty;
+          const double lp = finite_d(lb[j]) ? fmax(rc, 0.0) : 0.0, lm = finite_d(ub[j]) ? fmax(-rc, 0.0) : 0.0;
+          const double res = rc - lp + lm;
+          rv[4] += cc[j] * xb[j]; rv[5] += cc[j] * cc[j]; rv[6] += lp * fin0(lb[j]) - lm * fin0(ub[j]);
+          rv[7] += fin0(lb[j]) * fin0(lb[j]) + fin0(ub[j]) * fin0(ub[j]); rv[8] += res * res;
+        };
+        for (int j = t0; j < n; j += NT) {
+          if (P.C.is_long[j]) continue;
+          double aty = 0.0;
+          for (int e = 0; e < P.C.W; ++e) aty = fma(P.C.val[(size_t)e * n + j], axp[P.C.idx[(size_t)e * n + j]], aty);
+          col_terms(j, aty);
+        }
+        for (int l = 0; l < P.C.nlong; ++l) {
+          const double aty = block_long_dot(P.C, l, axp, red, acc);
+          if (t0 == 0) col_terms(P.C.long_id[l], aty);
+        }
+        block_sum(rv, 9, red, acc);
+        if (t0 == 0) {
+          const int verdict = ray_verdict(acc, a.opt.eps_infeasible);
+          if (verdict) { c.status = verdict; c.done = 1; atomicAdd(a.W.ndone, 1); }
+        }
+        __syncthreads();
+        if (c.done) break;
+      }
       const double om2 = 1.0 / (double)(c.k + 2);
       if (mode_s == 1) {
         for (int j = t0; j < n; j += NT) { x[j] = xp[j]; x0[j] = xp[j]; }
@@ -1375,8 +1592,9 @@ static hipError_t ensure_workspace(StreamSolver *S, int B) {
     const size_t lp = (size_t)B * std::max(1, S->P.C.nlong) * S->P.F.ntile * sizeof(double);
     for (int q = 0; q < 2; ++q) if ((e = alloc(lp, (void **)&W.lpart[q])) != hipSuccess) return e;
   }
-  if ((e = alloc(sizeof(int), (void **)&W.ndone)) != hipSuccess) return e;
-  if (!S->ndone_host && (e = hipHostMalloc((void **)&S->ndone_host, sizeof(int))) != hipSuccess) return e;
+  if ((e = alloc((size_t)B * m * sizeof(double), (void **)&W.ray)) != hipSuccess) return e;
+  if ((e = alloc(2 * sizeof(int), (void **)&W.ndone)) != hipSuccess) return e;
+  if (!S->ndone_host && (e = hipHostMalloc((void **)&S->ndone_host, 2 * sizeof(int))) != hipSuccess) return e;
   S->work_B = B;
   return hipSuccess;
 }
@@ -1385,6 +1603,33 @@ size_t stream_bytes_per_iteration(const StreamSolver *S) {
   // per scenario and plain iteration of the form the last solve ran: two launches 8 n + 6 m doubles (see the file header); fused
   // banded form 4 n + 3 m with shared bounds, 6 n + 5 m with per-scenario bounds (k_fused); before any solve: the two-launch figure
   return S->last_bytes_per_iteration ? S->last_bytes_per_iteration : (size_t)8 * (8 * (size_t)S->P.n + 6 * (size_t)S->P.m);
+}
+
+// The certificate sequence for the scenarios control_decide marked suspect, on the scenario-major workspace: a.W.x / a.W.y must be
+// the current iterate (every form's check sequence leaves it there; the lane form brings it back first).  xp / yp are overwritten
+// with T(z) of that iterate - what the next check would write anyway -, xbar and ray are scratch; certified scenarios get
+// status 2 / 3, done = 1 and count as finished.  The partial-sum buffer is left zeroed as after k_init.
+hipError_t stream_certify(StreamSolver *S, StreamArgs &a, hipStream_t st) {
+  const StreamProblem &P = a.P;
+  const int B = a.b.B;
+  const dim3 blk(kTB);
+  const dim3 g_primal(a.nblk_n + P.C.nchunk, B), g_rows(a.nblk + P.R.nlong, B), g_cols(a.nblk_n + P.C.nchunk, B), g_elem(a.nblk, B);
+  const int fin_c = (P.C.nlong * B + 63) / 64;
+  const size_t pbytes = (size_t)B * a.nblk_tot * kNQ * sizeof(double);
+  hipError_t e;
+  hipLaunchKernelGGL((k_primal<1, true>), g_primal, blk, 0, st, a);
+  if (P.C.nlong) hipLaunchKernelGGL(k_primal_long_finish, dim3(fin_c), dim3(64), 0, st, a, 1);
+  hipLaunchKernelGGL((k_check_rows<1>), g_rows, blk, 0, st, a);
+  if ((e = hipMemsetAsync(a.W.partial, 0, pbytes, st)) != hipSuccess) return e;
+  hipLaunchKernelGGL((k_ray_prep<1>), g_elem, blk, 0, st, a);
+  hipLaunchKernelGGL((k_ray_rows<1>), g_rows, blk, 0, st, a);
+  hipLaunchKernelGGL((k_ray_cols<1>), g_cols, blk, 0, st, a);
+  if (P.C.nlong) hipLaunchKernelGGL(k_ray_long_finish, dim3(fin_c), dim3(64), 0, st, a);
+  hipLaunchKernelGGL(k_ray_decide, dim3(B), dim3(256), 0, st, a);
+  if ((e = hipMemsetAsync(a.W.partial, 0, pbytes, st)) != hipSuccess) return e;
+  if ((e = hipMemsetAsync(a.W.ndone + 1, 0, sizeof(int), st)) != hipSuccess) return e;
+  (void)S;
+  return hipGetLastError();
 }
 
 template <int SG>
@@ -1420,9 +1665,13 @@ static hipError_t run(StreamSolver *S, StreamArgs &a, hipStream_t st, int *perio
     hipLaunchKernelGGL(k_control, dim3(B), dim3(256), 0, st, a, C);
     hipLaunchKernelGGL((k_apply<SG>), g_elem, blk, 0, st, a);
     if ((period + 1) % poll == 0 || period + 1 == max_periods) {
-      if ((e = hipMemcpyAsync(S->ndone_host, a.W.ndone, sizeof(int), hipMemcpyDeviceToHost, st)) != hipSuccess) return e;
+      if ((e = hipMemcpyAsync(S->ndone_host, a.W.ndone, 2 * sizeof(int), hipMemcpyDeviceToHost, st)) != hipSuccess) return e;
       if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;
-      if (*S->ndone_host >= B) { ++period; break; }
+      if (S->ndone_host[0] >= B) { ++period; break; }
+      // suspects (relative gap >= 1/2 after 2048 iterations): the certificate sequence, at most every 16 check periods
+      if (S->ndone_host[1] && (period + 1) % 16 == 0) {
+        if ((e = stream_certify(S, a, st)) != hipSuccess) return e;
+      }
     }
   }
   *periods_run = period;
@@ -1504,9 +1753,14 @@ static hipError_t run_fused(StreamSolver *S, StreamArgs &a, hipStream_t st, int 
     hipLaunchKernelGGL((k_apply<SG>), g_elem, blk, 0, st, ac);
     partials();
     if ((period + 1) % poll == 0 || period + 1 == max_periods) {
-      if ((e = hipMemcpyAsync(S->ndone_host, a.W.ndone, sizeof(int), hipMemcpyDeviceToHost, st)) != hipSuccess) return e;
+      if ((e = hipMemcpyAsync(S->ndone_host, a.W.ndone, 2 * sizeof(int), hipMemcpyDeviceToHost, st)) != hipSuccess) return e;
       if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;
-      if (*S->ndone_host >= B) { ++period; break; }
+      if (S->ndone_host[0] >= B) { ++period; break; }
+      if (S->ndone_host[1] && (period + 1) % 16 == 0) {          // certificate sequence on the buffers that are current
+        StreamArgs ar = a;
+        ar.W.x = xcur; ar.W.y = ycur;
+        if ((e = stream_certify(S, ar, st)) != hipSuccess) return e;
+      }
     }
   }
   *periods_run = period;
@@ -1532,7 +1786,7 @@ static hipError_t stream_solve_locked(StreamSolver *S, const dsp_batch &batch, c
   a.nblk = (std::max(S->P.n, S->P.m) + kTB - 1) / kTB;
   a.nblk_tot = a.nblk + std::max(S->P.R.nlong, S->P.C.nlong);
   a.nchunk_max = std::max(1, std::max(S->P.R.nchunk, S->P.C.nchunk));
-  if ((e = hipMemsetAsync(a.W.ndone, 0, sizeof(int), st)) != hipSuccess) return e;
+  if ((e = hipMemsetAsync(a.W.ndone, 0, 2 * sizeof(int), st)) != hipSuccess) return e;
   if ((e = hipMemsetAsync(a.W.partial, 0, (size_t)B * a.nblk_tot * kNQ * sizeof(double), st)) != hipSuccess) return e;
   hipLaunchKernelGGL(k_init, dim3(a.nblk, B), dim3(kTB), 0, st, a);
   hipLaunchKernelGGL(k_init_control, dim3(B), dim3(64), 0, st, a);

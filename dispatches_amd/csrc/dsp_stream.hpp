@@ -60,6 +60,7 @@ struct StreamCtrl {
   double qn, cn, c0, pobj;
   double last_rp, last_rd, last_rg;
   int k, it, status, done, mode, nrestart;
+  int suspect;                // the objectives are drifting apart (relative gap >= 1/2 after 2048 iterations): certificate sequence wanted
 };
 
 #if defined(__HIPCC__)
@@ -87,6 +88,10 @@ __device__ inline int control_decide(const double *acc, StreamCtrl &c, const dsp
       fin = rp <= o.eps_rel && rd <= o.eps_rel && rg <= o.eps_rel;
     }
     c.last_rp = rp; c.last_rd = rd; c.last_rg = rg;
+    // An LP without a solution: no fixed point, one of the objectives runs away, the relative gap tends to 1.  A feasible year-long
+    // LP passes 1/2 within its first 1.3 - 1.5 k iterations (lab, T = 672 / 1344); a scenario still above it after 2048 is SUSPECT:
+    // the host runs the certificate sequence (stream_certify, dsp_stream.hip) on the displacement T(z) - z, at most every 16 checks.
+    c.suspect = (o.eps_infeasible > 0.0 && rg >= 0.5 && c.it >= 2048) ? 1 : 0;
     if (fin) { c.status = DSP_STATUS_OPTIMAL; c.done = 1; }
     else if (c.it >= o.max_iter) { c.status = DSP_STATUS_ITERATION_LIMIT; c.done = 1; }
     else {
@@ -125,7 +130,8 @@ struct StreamWork {
   StreamCtrl *ctrl;                             // [B]
   double *partial;                              // [B][nblk_tot][16] ordered block partial sums
   double *long_partial;                         // [B][nchunk_max] chunk partials of the long vectors
-  int *ndone;                                   // scenarios finished
+  int *ndone;                                   // [2]: scenarios finished; flag "some scenario is suspect" (set by the decision kernels)
+  double *ray;                                  // [B][m] scratch of the certificate sequence (the cleaned dual displacement)
 };
 
 struct StreamArgs {
@@ -167,5 +173,7 @@ size_t stream_bytes_per_iteration(const StreamSolver *S);
 hipError_t lane_create(const HostCSR &A_scaled, const HostCSR &AT_scaled, StreamSolver *S);
 void lane_destroy(StreamSolver *S);
 hipError_t lane_run(StreamSolver *S, StreamArgs &a, hipStream_t st, int *periods_run, bool *used);
+// certificate sequence on the scenario-major workspace (x, y = the current iterate): dsp_stream.hip
+hipError_t stream_certify(StreamSolver *S, StreamArgs &a, hipStream_t st);
 
 }  // namespace dsp

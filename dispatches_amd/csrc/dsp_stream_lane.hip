@@ -370,6 +370,7 @@ __global__ void __launch_bounds__(64) k_lane_decide(LaneArgs a) {
   a.ctrl[s] = c;
   a.tau[at] = c.tau; a.sig[at] = c.sig; a.k[at] = c.k; a.done[at] = c.done; a.mode[at] = mode;
   if (c.done) atomicAdd(a.ndone, 1);
+  else if (c.suspect) a.ndone[1] = 1;               // the host runs the certificate sequence (stream_certify) at its next look
 }
 
 // Halpern step or restart after a check, tile by tile like k_lane; leaves the iterate in buffer A (xa, ya; may be the buffer it reads:
@@ -622,6 +623,7 @@ hipError_t lane_run(StreamSolver *S, StreamArgs &a, hipStream_t st, int *periods
   S->last_phases = 0;
   bool shared = true, first = true;
   LaneTiling *Tprev = nullptr;            // the tiling the previous phase ran on
+  bool count_phase = true;
   for (;;) {
     const int G = (nact + 63) / 64;
     // tiles: one wave per SIMD (1024 tiles) for a single group of 40 scenarios and more (~50 rows per wave), two waves per SIMD (2048
@@ -668,7 +670,8 @@ hipError_t lane_run(StreamSolver *S, StreamArgs &a, hipStream_t st, int *periods
     LaneKernel kern[3];
     for (int mode = 0; mode < 3; ++mode) if (!(kern[mode] = lane_pick(L->plan.WC, L->plan.WR, NLP, shared, qp, mode))) return first ? hipSuccess : hipErrorUnknown;
     *used = true;
-    ++S->last_phases;
+    if (count_phase) ++S->last_phases;           // (a phase that only follows a certificate sequence is not a packing: not counted)
+    count_phase = true;
     S->last_bytes_per_iteration = (size_t)8 * (shared ? 4 * (size_t)n + 3 * (size_t)m : 6 * (size_t)n + 5 * (size_t)m) + (qp ? 8 * (size_t)m : 0);
     const int *sid = nullptr;
     if (!ids.empty()) {
@@ -768,16 +771,20 @@ hipError_t lane_run(StreamSolver *S, StreamArgs &a, hipStream_t st, int *periods
     }
     // scenarios still iterating below which the phase ends: they fit G - max(1, G / 4) groups
     const int shrink_at = (compact && G > 1) ? 64 * (G - std::max(1, G / 4)) : -1;
-    bool finished = false, shrink = false;
+    bool finished = false, shrink = false, certify = false;
     for (; period < max_periods;) {
       if (use_graph) { if ((e = hipGraphLaunch(exec, ls)) != hipSuccess) break; }
       else enqueue_period(ls);
       ++period;
       if (period % poll == 0 || period == max_periods) {
-        if ((e = hipMemcpyAsync(S->ndone_host, a.W.ndone, sizeof(int), hipMemcpyDeviceToHost, ls)) != hipSuccess) break;
+        if ((e = hipMemcpyAsync(S->ndone_host, a.W.ndone, 2 * sizeof(int), hipMemcpyDeviceToHost, ls)) != hipSuccess) break;
         if ((e = hipStreamSynchronize(ls)) != hipSuccess) break;
-        if (*S->ndone_host >= B) { finished = true; break; }
-        if (B - *S->ndone_host <= shrink_at && period < max_periods) { shrink = true; break; }
+        if (S->ndone_host[0] >= B) { finished = true; break; }
+        if (B - S->ndone_host[0] <= shrink_at && period < max_periods) { shrink = true; break; }
+        // Suspects (relative gap >= 1/2 after 2048 iterations: control_decide): the infeasibility / unboundedness certificates are
+        // evaluated on the scenario-major workspace (stream_certify, dsp_stream.hip), so the phase ends here, the iterate goes back
+        // there, and the scenarios that are not certified go on in a new phase - at most every 16 check periods.
+        if (S->ndone_host[1] && period % 16 == 0 && period < max_periods) { shrink = true; certify = true; break; }
       }
     }
     if (use_graph) {
@@ -809,6 +816,10 @@ hipError_t lane_run(StreamSolver *S, StreamArgs &a, hipStream_t st, int *periods
     if (!shrink) break;
     (void)finished;
     out(W.xA, n, a.W.x); out(W.x0, n, a.W.x0); out(W.yA, m, a.W.y); out(W.y0, m, a.W.y0);
+    if (certify) {
+      if ((e = stream_certify(S, a, st)) != hipSuccess) return e;
+      count_phase = false;
+    }
     // the scenarios that go on, in their order
     std::vector<int> done_h((size_t)G * 64);
     if ((e = hipMemcpyAsync(done_h.data(), W.done, done_h.size() * sizeof(int), hipMemcpyDeviceToHost, st)) != hipSuccess) return e;

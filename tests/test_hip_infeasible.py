@@ -109,3 +109,63 @@ def test_certificates_off_means_iteration_limit():
 
 # (no feasible scenario is ever called infeasible: tests/test_hip_parity.py::test_full_batch_objective_parity_vs_oracle_fixture and
 #  tests/test_hip_batch_parity.py assert status 0 for all 4096 scenarios of every bench workload with the certificates on)
+
+
+STREAM_ENV = ("DSP_STREAM_NO_LANE", "DSP_STREAM_NO_FUSED", "DSP_STREAM_NO_BLOCK", "DSP_LANE_MIN_B")
+
+
+@gpu
+@pytest.mark.parametrize("form,T,B,env,stream_form", [
+    ("lane", 336, 40, {}, 3),                                                        # lane per scenario (batches of 32 and more)
+    ("tile", 336, 6, {"DSP_STREAM_NO_LANE": "1"}, 2),                                 # workgroup per tile
+    ("two_launch", 336, 6, {"DSP_STREAM_NO_LANE": "1", "DSP_STREAM_NO_FUSED": "1"}, 1),
+    ("block", 96, 5, {}, 4)])                                                         # the whole solve in one launch, state in LDS
+def test_streaming_forms_certify_an_infeasible_member(monkeypatch, form, T, B, env, stream_form):
+    """HBM-resident path (dsp_stream.hip / dsp_stream_lane.hip): one member of a price-taker design batch gets an impossible power
+    balance (a period whose splitter row asks for 1e9 kW more than the wind plant can ever deliver) - every form of the streaming
+    iteration reports it primal infeasible (status 2) within 5 k iterations through the certificate sequence (stream_certify /
+    the block form's in-kernel evaluation) while the other members reach their optima as without the edit."""
+    from dispatches_amd import scenarios
+    for k in STREAM_ENV:
+        monkeypatch.delenv(k, raising=False)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    solver = _solver(check_every=64)
+    handles, model = scenarios.price_taker_batch(T, B, solver)
+    solver.solve(model)
+    st = solver.last_stats
+    assert st.streaming == 1 and st.stream_form == stream_form and (model.status == 0).all(), (form, st.stream_form, model.status)
+    ref = model.objective.copy()
+    _own_bounds(model)
+    i = model.lp.row_names.index("splitter.sum_split[5]")
+    bad = 3
+    model.rlo[bad, i] = model.rhi[bad, i] = 1.0e9
+    res = solver.solve(model)
+    want = np.zeros(B, int); want[bad] = 2
+    assert solver.last_stats.stream_form == stream_form
+    assert model.status.tolist() == want.tolist(), (form, model.status, model.iterations)
+    assert model.iterations[bad] <= 5000, model.iterations
+    assert res.solver.termination_condition == "infeasible"
+    keep = [k for k in range(B) if k != bad]
+    np.testing.assert_allclose(model.objective[keep], ref[keep], rtol=1e-6, atol=1e-6)
+    assert _highs_status(model, bad) == 2
+
+
+@gpu
+def test_streaming_path_certifies_an_unbounded_member():
+    """The same batch with one member's power balance of period 5 switched off (a free row): its grid sale G_5 is paid and nothing
+    limits it any more - unbounded.  Status 3 from the recession-direction test of the certificate sequence."""
+    from dispatches_amd import scenarios
+    solver = _solver(check_every=64, max_iter=60_000)
+    handles, model = scenarios.price_taker_batch(336, 40, solver)
+    _own_bounds(model)
+    i = model.lp.row_names.index("splitter.sum_split[5]")
+    j = model.lp.col_names.index("splitter.grid_elec[5]")
+    bad = 11
+    assert model.c[bad, j] < 0                                       # selling at a positive price: the direction pays
+    model.rlo[bad, i], model.rhi[bad, i] = -np.inf, np.inf
+    res = solver.solve(model)
+    assert model.status[bad] == 3, (model.status, model.iterations)
+    assert (np.delete(model.status, bad) == 0).all()
+    assert res.solver.termination_condition == "unbounded"
+    assert _highs_status(model, bad) in (2, 3)

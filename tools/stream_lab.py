@@ -67,7 +67,7 @@ def physical_scales(P, T, thr_duty=0.25, e_mult=1.0):
 
 
 def solve(P, eps=1e-9, eps_obj=5e-7, max_iter=2_000_000, check=64, kp=0.7, beta=(0.2, 0.8, 0.36), colscale=None, n_ruiz=10,
-          verbose=0, maxdl=np.log(30.0), x0=None, y0=None, w0=None, log_every=0, norm_iters=4000, beta3=None, beta1=None):
+          verbose=0, maxdl=np.log(30.0), x0=None, y0=None, w0=None, log_every=0, norm_iters=4000, beta3=None, beta1=None, post_boost=None):
     if beta3 is not None or beta1 is not None:
         beta = (beta[0] if beta1 is None else beta1, beta[1], beta[2] if beta3 is None else beta3)
     A0 = sp.csr_matrix(P["A"])
@@ -77,6 +77,11 @@ def solve(P, eps=1e-9, eps_obj=5e-7, max_iter=2_000_000, check=64, kp=0.7, beta=
     As, dr, dc = pp.ruiz_pc_scaling(A0, n_ruiz=int(n_ruiz))
     if colscale is not None:
         dc = dc * colscale
+    if post_boost:                      # {column: factor}: extra column scale AFTER Ruiz / Pock-Chambolle (round 5: design columns)
+        f = np.ones(n)
+        for j, v in post_boost.items():
+            f[j] = v
+        As = sp.csr_matrix(As @ sp.diags(f)); dc = dc * f
     AsT = sp.csr_matrix(As.T)
     c = P["c"] * dc; lb, ub = P["lb"] / dc, P["ub"] / dc; rlo, rhi = P["rlo"] * dr, P["rhi"] * dr
     nrm = pp.spectral_norm(As, iters=int(norm_iters))
