@@ -1119,9 +1119,11 @@ def main():
                                            "block, one scenario per wave, everything in flight at once); a 20 MB launch "
                                            "is bound by one memory round trip + the dispatch ramp - the BASELINE.md "
                                            "section 3 configuration (T = 48, 41 MB) is spmv_step_T48_B4096")
-            # the same kernel on a batch large enough to be bandwidth bound (0.67 GB per launch, beyond L2 + MALL)
+            # the same kernel on a batch large enough to be bandwidth bound (0.67 GB per launch, beyond L2 + MALL), and on twice the
+            # metric batch - where the 20 MB launch's round trip + dispatch ramp stop dominating
             if args.spmv_large_mult > 0:
                 result["spmv_step_large_batch"] = time_spmv(dlp, lp, args.spmv_large_mult * B, 20)
+                result["spmv_step_2x_batch"] = time_spmv(dlp, lp, 2 * B, 100)
             # BASELINE.md section 3 quotes the contract figure at T = 48, B = 4096 (40.9 MB, <= 10.2 us <=> >= 50 %)
             if args.workload == "wind_battery_24h":
                 _, m48 = scenarios.WORKLOADS["wind_battery_48h"][0](B=2, solver=solver, T=48)
@@ -1129,6 +1131,13 @@ def main():
                 result["spmv_step_T48_B4096"] = time_spmv(d48, m48.lp, 4096, 200)
                 result["spmv_step_T48_B4096"]["note"] = "BASELINE.md section 3 configuration: wind+battery 48 h, 4096 scenarios"
                 d48.close()
+            # north_star: ">= 50 % of the HBM roofline on the PDLP SpMV step" - said plainly, per measured batch
+            fr = {k: result[k]["frac"] for k in ("spmv_step", "spmv_step_2x_batch", "spmv_step_T48_B4096", "spmv_step_large_batch") if k in result}
+            result["spmv_step_target"] = {"target_frac": 0.5, "measured": fr, "met_at": [k for k, v in fr.items() if v >= 0.5],
+                                          "not_met_at": [k for k, v in fr.items() if v < 0.5],
+                                          "statement": "the 0.5 target is met at BASELINE.md section 3's configuration (T = 48, 4096 scenarios, 41 MB) and from "
+                                                       "about twice the metric batch on; NOT at the 20 MB metric batch itself, whose launch is one memory round "
+                                                       "trip + the dispatch ramp (latency bound)"}
         # ---- the same batch at PDLP's default tolerance ("also report eps = 1e-4") --------------------------------
         # relative primal / dual residual and relative gap <= 1e-4, the objective-error bound of the contract setting off
         if world == 1 and not args.no_eps4:
