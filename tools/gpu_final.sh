@@ -7,14 +7,20 @@ export TMPDIR=/tmp
 python -c "import __graft_entry__ as g; g.build(); g.smoke()" > "$out/${tag}_smoke.log" 2>&1; tail -2 "$out/${tag}_smoke.log"
 timeout 1500 python -m pytest tests -m gpu -q --timeout 900 > "$out/${tag}_tests.log" 2>&1; tail -4 "$out/${tag}_tests.log"
 python bench.py > "$out/${tag}_bench.json" 2> "$out/${tag}_bench.err"; tail -c 300 "$out/${tag}_bench.json"; echo
+# same-round kernel trace of the default line's kernels (pdlp_solve_kernel, spmv_step_kernel; without the configs array and the CPU leg)
+( cd /tmp; rm -rf /tmp/trz; timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/trz -- python $repo/bench.py --cpu-sample 0 --no-configs > /dev/null 2>&1
+  f=$(find /tmp/trz -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" "$out/${tag}_kernel_stats.csv" && head -6 "$f" | cut -c1-200 )
+timeout 200 python tools/gpu_bidder_profile.py > "$out/${tag}_bidder_profile.log" 2>&1; head -30 "$out/${tag}_bidder_profile.log" | tail -22
 {
 timeout 200 python bench.py --workload price_taker --batch 64 --steps 50 --warmup 2 2>/dev/null | tail -1
 timeout 200 python bench.py --workload price_taker --batch 256 --steps 50 --warmup 2 2>/dev/null | tail -1
 timeout 200 python bench.py --workload pem_price_taker --batch 256 --steps 50 --warmup 2 2>/dev/null | tail -1
 timeout 200 python bench.py --workload nuclear_price_taker --steps 12 --warmup 2 2>/dev/null | tail -1
 timeout 200 python bench.py --workload nuclear_price_taker --batch 240 --steps 12 --warmup 2 2>/dev/null | tail -1
-timeout 400 python bench.py --workload price_taker --batch 64 --solve --warmup 1 2>/dev/null | tail -1
-timeout 400 python bench.py --workload price_taker --batch 256 --solve --warmup 1 2>/dev/null | tail -1
+# (full solves: the HiGHS leg of the 256-member batch keeps the host's 256 threads busy for ~ 5 minutes - profiles/r50d_solve256.json -, so the
+#  end-of-round check runs the GPU side only and a 64-process leg on the 64-member batch)
+timeout 600 python bench.py --workload price_taker --batch 64 --solve --warmup 1 --cpu-sample 64 2>/dev/null | tail -1
+timeout 400 python bench.py --workload price_taker --batch 256 --solve --warmup 1 --cpu-sample 0 2>/dev/null | tail -1
 } > "$out/${tag}_stream_bench.jsonl"
 python - "$out/${tag}_stream_bench.jsonl" <<'PY'
 import json, sys
