@@ -141,40 +141,23 @@ def bench_double_loop(args, rank, local_rank, world, dev):
     import torch
     import torch.distributed as dist
     from dispatches_amd.distributed import gather_device_results, make_gather_buffers, shard_bounds
-    from dispatches_amd.rolling import BatchedWindBatteryDoubleLoop
+    from dispatches_amd.rolling import PipelinedDoubleLoops
     total = args.total if args.total > 0 else 8192
     lo, hi = shard_bounds(total, world, rank)
     B = hi - lo
     per = max(shard_bounds(total, world, r)[1] - shard_bounds(total, world, r)[0] for r in range(world))
     kw = {} if args.warm_start < 0 else {"warm_start": bool(args.warm_start)}
-    # --groups G: the rank's plants as G independent loops on G HIP streams.  A simulated day of ONE loop is a chain of lone batches -
-    # the day-ahead solve ends with its slowest plant (up to 12 x the mean iteration count) while the chip idles - and plants are
-    # independent of each other, so the groups' days overlap: one group's day-ahead tail runs beside the others' hourly steps.
-    # Measured on one MI355X, 8192 plants (profiles/r50f_double_loop_groups.log): 1 group 44.2 ms per simulated day, 2 groups 35.4, 4 groups
-    # 53.4, 8 groups 57.0 (smaller batches per launch, 25 graph replays per group and day).  0 = automatic: 2 from 4096 plants per rank on.
-    G = int(getattr(args, "groups", 0) or 0)
-    G = (2 if B >= 4096 else 1) if G <= 0 else G
-    G = max(1, min(G, max(B, 1)))
-    cuts = [shard_bounds(B, G, g) for g in range(G)]
-    loops = [BatchedWindBatteryDoubleLoop(b1 - b0, device=local_rank, first_scenario=lo + b0, **kw) for b0, b1 in cuts]
-    lstreams = [torch.cuda.Stream(device=dev) for _ in range(G)] if G > 1 else [None]
-    loop = loops[0]
+    # --groups G: the rank's plants as G independent loops on G HIP streams whose simulated days overlap (rolling.PipelinedDoubleLoops:
+    # 8192 plants on one MI355X 44.2 -> 35.4 ms per simulated day with two groups; 0 = automatic: two from 1024 plants per rank on)
+    loop = PipelinedDoubleLoops(B, device=local_rank, first_scenario=lo, groups=int(getattr(args, "groups", 0) or 0), **kw)
+    G = loop.groups
     buffers = make_gather_buffers(world, per, dev, width=2) if world > 1 else None
     status_ok = torch.zeros(B, dtype=torch.float64, device=dev)
 
     def step():
-        if G == 1:
-            loop.run_day()
-        else:
-            for lp_, s_ in zip(loops, lstreams):
-                s_.wait_stream(torch.cuda.current_stream(dev))
-                with torch.cuda.stream(s_):
-                    lp_.run_day()
-            for s_ in lstreams:
-                torch.cuda.current_stream(dev).wait_stream(s_)
+        loop.run_day()
         if world > 1:
-            rev = loop.revenue if G == 1 else torch.cat([l.revenue for l in loops])
-            gather_device_results(dict(obj=rev, status=status_ok), buffers, per)
+            gather_device_results(dict(obj=loop.revenue, status=status_ok), buffers, per)
     for _ in range(max(1, args.warmup)):
         step()
     torch.cuda.synchronize()
@@ -188,14 +171,12 @@ def bench_double_loop(args, rank, local_rank, world, dev):
         dist.barrier()
     elapsed = time.perf_counter() - t0
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    results = [l.results() for l in loops]
-    res = {"obj": torch.cat([r[0]["obj"] for r in results])}
-    ok = all(r[1] for r in results)
+    res, ok = loop.results()
     okt = torch.tensor([1 if ok else 0], device=dev)
     # solves the loop accepted with DSP_FLAG_OBJ_WAIVED (the objective bound of the returned point was waived after a stall): the loop
     # counts them on the device and carries their solutions on - the line is only valid while there are none
-    unc = sum(l.uncertified.to(torch.int64) for l in loops).reshape(1).clone()
-    da_iters = torch.cat([l.da.out["iters"] for l in loops]).float()
+    unc = loop.uncertified.to(torch.int64).reshape(1).clone()
+    da_iters = loop.day_ahead_iterations().float()
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(okt, op=dist.ReduceOp.MIN)
@@ -804,7 +785,7 @@ def main():
                     help="--workload double_loop: 1 / 0 = rolling warm start of the day-ahead LP on / off (-1 = the loop's default)")
     ap.add_argument("--groups", type=int, default=0,
                     help="--workload double_loop: the rank's plants as this many independent loops on as many HIP streams (their days overlap); "
-                         "0 = automatic (2 from 4096 plants per rank on)")
+                         "0 = automatic (2 from 1024 plants per rank on)")
     ap.add_argument("--no-configs", action="store_true", help="default line only: skip the `configs` array (the other BASELINE configs measured in the same run)")
     ap.add_argument("--no-sweep", action="store_true", help="--workload qp_sweep: the contract entry only, without the fp64 / fp32 tolerance ladder")
     ap.add_argument("--no-spmv", action="store_true", help="skip the streaming SpMV-step roofline measurement")

@@ -136,3 +136,26 @@ def test_day_ahead_warm_start_solves_the_same_lps_in_fewer_iterations(graphs):
     assert it_w.mean() < 0.85 * it_c.mean(), (it_w.mean(), it_c.mean())
     res, ok = loop.results()
     assert ok and int(loop.uncertified.item()) == 0
+
+
+@gpu
+def test_pipelined_groups_reproduce_the_single_loop():
+    """rolling.PipelinedDoubleLoops: the same plants as two independent loops on two HIP streams (their simulated days overlap) end
+    with exactly the per-plant revenues, states and energies of one loop - plants do not interact and a scenario's solve does not
+    depend on its batch."""
+    import torch
+    from dispatches_amd.rolling import BatchedWindBatteryDoubleLoop, PipelinedDoubleLoops
+    n, days = 96, 3
+    one = BatchedWindBatteryDoubleLoop(n, device=0, first_scenario=5)
+    two = PipelinedDoubleLoops(n, device=0, first_scenario=5, groups=2)
+    assert two.groups == 2 and PipelinedDoubleLoops(8, device=0, groups=0).groups == 1
+    for _ in range(days):
+        one.run_day()
+        two.run_day()
+    torch.cuda.synchronize()
+    r1, ok1 = one.results()
+    r2, ok2 = two.results()
+    assert ok1 and ok2
+    for k in ("obj", "energy_mwh", "soc", "throughput"):
+        assert torch.equal(r1[k], r2[k]), k
+    assert int(two.uncertified) == int(one.uncertified) == 0
