@@ -101,3 +101,30 @@ def test_tensor_bid_assembly_reproduces_the_numpy_path(workload, thermal, fail):
         for t in a:
             for gen in a[t]:
                 assert a[t][gen] == b[t][gen], (t, a[t][gen]["p_cost"][:4], b[t][gen]["p_cost"][:4])   # floats compared exactly
+
+
+@pytest.mark.parametrize("builder", ["wind_battery_batch", "nuclear_batch", "wind_pem_batch"])
+def test_price_objective_on_tensors_is_the_dense_objective(builder):
+    """Bidder._pass_price_forecasts hands the objective vectors over as a recipe (PriceObjective: base vector + the two [B, T] price
+    windows); HipPdlpSolver forms c on the device from the uploaded windows.  The tensor form - run here on CPU tensors - gives the
+    host's dense array bit for bit for every flowsheet, and `model.c` still materialises it for everybody else."""
+    class NoSolver:
+        def solve(self, *a, **k):
+            raise RuntimeError
+    B, T = 33, 24
+    bidder, model = getattr(scenarios, builder)(B, T, NoSolver())
+    rng = np.random.default_rng(3)
+    da, rt = rng.uniform(0, 300, (B, T)), rng.uniform(0, 300, (B, T))
+    rt[:, 3] = 0.0
+    da[5] = rt[5]
+    bidder._pass_price_forecasts(model, da, rt)
+    recipe = model.c_recipe
+    assert recipe is not None and model._c is None
+    cache = {}
+    dev = recipe.device(torch, torch.device("cpu"), lambda key, a: torch.as_tensor(np.ascontiguousarray(a)), cache).numpy()
+    dense = recipe.dense()
+    np.testing.assert_array_equal(dev, dense)
+    np.testing.assert_array_equal(model.c, dense)                 # the property materialises the same array
+    # a caller that edits model.c afterwards is honoured (the solver then uploads the dense array, not the recipe)
+    model.c[0, 0] += 1.0
+    assert model._c is not None and model._c[0, 0] == dense[0, 0] + 1.0
