@@ -553,6 +553,18 @@ int dsp_solve(dsp_handle *h, const dsp_batch *batch, const dsp_options *opt, dsp
   }
 #endif
   int grid = std::min((B + geo.wpb - 1) / geo.wpb, h->num_cus * geo.blocks_per_cu);
+  // geometry of the certificate pass (below), fixed BEFORE the first pass runs: a register-resident kernel may only leave scenarios
+  // DSP_STATUS_SUSPECT if the generic kernel that takes them over can be launched (it always can for an LP of the fused path - it is
+  // the fallback of every shape -; if not, the first pass keeps every scenario and the certificates are off for this call)
+  int cert_wpb = 0;
+  size_t cert_lds = 0;
+  if (a.matreg && a.opt.eps_infeasible > 0.0) {
+    for (int wpb = 1; wpb <= 4; ++wpb) {              // a few waves per block share the LDS matrix; the pass is rare, not tuned
+      const size_t l = lds_bytes(h->P, wpb, 0, h->cpl, h->rpl);
+      if (l <= (size_t)h->lds_limit) { cert_wpb = wpb; cert_lds = l; }
+    }
+    if (!cert_wpb) a.opt.eps_infeasible = 0.0;
+  }
   const bool timed = stats && sync_stats;
   if (timed) HIP_TRY(hipEventRecord(h->ev0, st));
   if (h->simplex && !qp) {
@@ -586,16 +598,9 @@ int dsp_solve(dsp_handle *h, const dsp_batch *batch, const dsp_options *opt, dsp
     c.skip_solved = 2;
     c.queue = a.queue + 3;
     c.b.x0 = a.b.x; c.b.y0 = a.b.y;
-    c.waves_per_block = 1;
-    size_t lds2 = lds_bytes(h->P, 1, 0, h->cpl, h->rpl);
-    for (int wpb = 2; wpb <= 4; ++wpb) {              // a few waves per block share the LDS matrix; the pass is rare, not tuned
-      const size_t l = lds_bytes(h->P, wpb, 0, h->cpl, h->rpl);
-      if (l <= (size_t)h->lds_limit) { c.waves_per_block = wpb; lds2 = l; }
-    }
-    if (lds2 <= (size_t)h->lds_limit) {
-      const int grid2 = std::min((B + c.waves_per_block - 1) / c.waves_per_block, h->num_cus);
-      HIP_TRY(launch_solve(h->cpl, h->rpl, c, dim3(grid2), dim3(64 * c.waves_per_block), lds2, st));
-    }
+    c.waves_per_block = cert_wpb;
+    const int grid2 = std::min((B + cert_wpb - 1) / cert_wpb, h->num_cus);
+    HIP_TRY(launch_solve(h->cpl, h->rpl, c, dim3(grid2), dim3(64 * cert_wpb), cert_lds, st));
   }
   if (timed) HIP_TRY(hipEventRecord(h->ev1, st));
 #ifdef DSP_KKT_TRACE
