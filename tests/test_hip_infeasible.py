@@ -169,3 +169,43 @@ def test_streaming_path_certifies_an_unbounded_member():
     assert (np.delete(model.status, bad) == 0).all()
     assert res.solver.termination_condition == "unbounded"
     assert _highs_status(model, bad) in (2, 3)
+
+
+@gpu
+def test_infeasible_qp_scenario_and_the_bidder_around_it():
+    """The ramp-cost QP instantiation (soft rows: no multiplier ray on them) certifies the same impossible initial charge, and the
+    Bidder built on top never turns such a scenario into a bid: it is listed under its status in `failed_scenarios`, the hourly curves
+    come from the other scenarios (exactly the curves of a batch without it), and `strict=True` raises instead."""
+    import warnings
+    from dispatches_amd import scenarios
+    solver = _solver()
+    bidder, model = scenarios.make_batch("wind_battery_24h_qp01", 6, solver)
+    solver.solve(model)
+    assert (model.status == 0).all() and solver.last_stats.quadratic == 1
+    ref = model.objective.copy()
+    _own_bounds(model)
+    j = model.lp.col_names.index("battery.initial_state_of_charge")
+    model.lb[2, j] = model.ub[2, j] = 1.0e6
+    solver.solve(model)
+    assert model.status.tolist() == [0, 0, 2, 0, 0, 0] and model.iterations[2] <= 5000, (model.status, model.iterations)
+    np.testing.assert_allclose(np.delete(model.objective, 2), np.delete(ref, 2), rtol=1e-9)
+    # the Bidder: one infeasible price scenario among eight
+    bidder, model = scenarios.wind_battery_batch(8, 24, solver)
+    full = bidder.compute_day_ahead_bids("2020-01-02", 0)
+    lb, ub, rlo, rhi = model.scenario_bounds()
+    model.lb, model.ub = np.broadcast_to(lb, (8, model.lp.n)).copy(), np.broadcast_to(ub, (8, model.lp.n)).copy()
+    j = model.lp.col_names.index("battery.initial_state_of_charge")
+    model.lb[5, j] = model.ub[5, j] = 1.0e6
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        bids = bidder.compute_day_ahead_bids("2020-01-02", 0)
+    assert any("did not reach optimality" in str(x.message) for x in w)
+    assert bidder.failed_scenarios[("2020-01-02", 0, "Day-ahead")] == {5: 2}
+    assert model.status[5] == 2 and (np.delete(model.status, 5) == 0).all()
+    gen = bidder.generator
+    for t in bids:                                               # every point of every curve is offered by a feasible scenario
+        pts = {p for p, _ in bids[t][gen]["p_cost"]}
+        assert pts <= {p for p, _ in full[t][gen]["p_cost"]} | {0.0}, t
+    bidder.strict = True
+    with pytest.raises(RuntimeError):
+        bidder.compute_day_ahead_bids("2020-01-02", 0)

@@ -67,7 +67,8 @@ def physical_scales(P, T, thr_duty=0.25, e_mult=1.0):
 
 
 def solve(P, eps=1e-9, eps_obj=5e-7, max_iter=2_000_000, check=64, kp=0.7, beta=(0.2, 0.8, 0.36), colscale=None, n_ruiz=10,
-          verbose=0, maxdl=np.log(30.0), x0=None, y0=None, w0=None, log_every=0, norm_iters=4000, beta3=None, beta1=None, post_boost=None):
+          verbose=0, maxdl=np.log(30.0), x0=None, y0=None, w0=None, log_every=0, norm_iters=4000, beta3=None, beta1=None, post_boost=None,
+          aitken=None, aitken_gain=1.0):
     if beta3 is not None or beta1 is not None:
         beta = (beta[0] if beta1 is None else beta1, beta[1], beta[2] if beta3 is None else beta3)
     A0 = sp.csr_matrix(P["A"])
@@ -100,6 +101,8 @@ def solve(P, eps=1e-9, eps_obj=5e-7, max_iter=2_000_000, check=64, kp=0.7, beta=
     cn = np.linalg.norm(P["c"])
     A = P["A"]; AT = sp.csr_matrix(A.T)
     hist = []
+    hist_p, naitken = [], [0]
+    solve.naitken = naitken
     t0 = time.time()
     for it in range(int(max_iter)):
         tau, sig = eta / w, eta * w
@@ -140,6 +143,21 @@ def solve(P, eps=1e-9, eps_obj=5e-7, max_iter=2_000_000, check=64, kp=0.7, beta=
                     e = np.log(w) + np.log(ddx) - np.log(ddy)
                     w = w * np.exp(np.clip(-kp * e, -maxdl, maxdl))
                 x, y, xa, ya = xp.copy(), yp.copy(), xp.copy(), yp.copy()
+                if aitken is not None:
+                    # round 5 experiment: Aitken extrapolation of the DESIGN columns (indices `aitken`) over their values at the last
+                    # three restarts - their slow 1-D dynamics (step ~ 1 / T) is what the free-design solve waits for
+                    hist_p.append(x[aitken].copy())
+                    if len(hist_p) >= 3:
+                        p0, p1, p2 = hist_p[-3], hist_p[-2], hist_p[-1]
+                        d1, d2 = p1 - p0, p2 - p1
+                        den = d2 - d1
+                        ok = (np.abs(d2) < np.abs(d1)) & (d1 * d2 > 0) & (np.abs(den) > 1e-300)
+                        ext = np.where(ok, p2 - aitken_gain * d2 * d2 / np.where(ok, den, 1.0), p2)
+                        ext = np.clip(ext, lb[aitken], ub[aitken])
+                        if ok.any():
+                            x[aitken] = ext; xa[aitken] = ext
+                            hist_p.clear()
+                            naitken[0] += 1
                 k = 0; r0 = np.inf; rprev = np.inf; nrs += 1
                 continue
         lam = (k + 1) / (k + 2)
