@@ -709,8 +709,8 @@ def baseline_configs(args, local_rank, dev, budget_s=360.0, depth=8):
         from dispatches_amd.flowsheets import MultiPeriodWindBattery
         from dispatches_amd.hip_solver import HipPdlpSolver
         from dispatches_amd.workflow import Backcaster, RenewableGeneratorModelData, SelfScheduler
-        from oracle import dispatch_lp_oracle as orc
-        lmp = json.load(open(os.path.join(ROOT, "tests", "golden", "reference_vectors.json")))["G13_usc_pricetaker_lmp_24h"]["lmp"]
+        g13 = json.load(open(os.path.join(ROOT, "tests", "golden", "reference_vectors.json")))["G13_usc_pricetaker_lmp_24h"]
+        lmp = g13["lmp"]
         s = scenarios.load_series("rts_gmlc_309.npz")
         md = RenewableGeneratorModelData(gen_name="309_WIND_1", bus="Carter", p_min=0, p_max=200, p_cost=0, fixed_commitment=None)
         mp = MultiPeriodWindBattery(model_data=md, wind_capacity_factors=s["rt_cf"], wind_pmax_mw=200, battery_pmax_mw=25,
@@ -723,12 +723,12 @@ def baseline_configs(args, local_rank, dev, budget_s=360.0, depth=8):
         bidder.compute_day_ahead_bids(date="2020-01-02")
         call_ms = 1e3 * (time.perf_counter() - t0)
         m = bidder.day_ahead_model
-        ref = orc.wind_battery_da(24, s["rt_cf"][:24], np.asarray(lmp, float), np.asarray(lmp, float))[0].solve(tight=True)[1]
+        ref = g13["oracle_objective_lp1_24h"]["value"]            # committed fixture of the oracle's objective for this LP (tests/golden)
         return {"config": "1", "workload": "plumbing: SelfScheduler + MultiPeriodWindBattery, 24 h, 1 price scenario = the 24 LMPs of the fossil case "
                                            "study's _get_lmp (tests/golden/reference_vectors.json G13), through HipPdlpSolver",
                 "value": 1e3 / call_ms, "unit": "compute_day_ahead_bids calls/s", "call_ms": call_ms, "kernel_ms": float(solver.last_stats.kernel_ms),
                 "iterations": int(m.iterations[0]), "optimal": int((m.status == 0).sum()), "flagged": int(m.uncertified.sum()),
-                "rel_obj_err_vs_oracle": float(abs(m.objective[0] - ref) / max(1.0, abs(ref)))}
+                "rel_obj_err_vs_oracle_fixture": float(abs(m.objective[0] - ref) / max(1.0, abs(ref)))}
     leg("1", config1)
     # (steps = a multiple of the stream depth the headline chose in its warm-up: every stream gets the same number of launches)
     leg("2", lambda: _fused_config_entry("2", "nuclear_24h", 256, local_rank, dev, steps=4 * depth, depth=depth))

@@ -50,6 +50,9 @@ def test_config1_plumbing_on_the_cpu(golden, rts309, cls, thermal):
     from tests._highs_solver import HighsTestSolver
     bidder, bids, model, ref = _run(HighsTestSolver(), golden, rts309, cls, thermal)
     assert abs(model.objective[0] - ref) <= 1e-9 * max(1.0, abs(ref)), (model.objective[0], ref)
+    # the committed fixture bench.py's configs entry 1 reads IS the oracle's objective
+    fx = golden["G13_usc_pricetaker_lmp_24h"]["oracle_objective_lp1_24h"]["value"]
+    assert abs(fx - ref) <= 1e-12 * max(1.0, abs(ref))
     # day-ahead = real-time forecast: the offer is indifferent, the delivered power is not - it follows the price list
     pt = model.expression_values("P_T")[0]
     lmp = np.asarray(golden["G13_usc_pricetaker_lmp_24h"]["lmp"])
