@@ -55,6 +55,28 @@ def test_default_options(lib):
     assert lib.dsp_strerror(0) == b"ok" and b"invalid" in lib.dsp_strerror(-1)
 
 
+def test_library_names_the_sources_it_was_built_from(lib, tmp_path):
+    """dsp_source_hash() (ABI 9) is the SHA-256 prefix of csrc/*.hip, *.hpp and include/dsp_hip.h as they were at build time: the binding
+    compares it with the tree next to it (a prebuilt .so that travelled with the tree must be the build of THESE sources - the driver's
+    bench once timed a binary no hash tied to the code), build() rebuilds on a mismatch, the bench line prints it."""
+    import shutil
+    import __graft_entry__ as g
+    from dispatches_amd import hip_solver
+    have = lib.dsp_source_hash().decode()
+    assert len(have) == 16 and have == hip_solver.source_hash() and not g._stale()
+    assert hip_solver.default_options().eps_infeasible == 1e-6
+    # a tree whose kernels differ by one byte has another hash; a tree without sources has none (nothing to compare with)
+    root = tmp_path / "copy"
+    shutil.copytree(os.path.join(ROOT, "dispatches_amd", "csrc"), root / "dispatches_amd" / "csrc", ignore=shutil.ignore_patterns(".*"))
+    os.makedirs(root / "include")
+    shutil.copy(os.path.join(ROOT, "include", "dsp_hip.h"), root / "include" / "dsp_hip.h")
+    assert hip_solver.source_hash(str(root)) == have
+    with open(root / "dispatches_amd" / "csrc" / "dsp_wave.hpp", "a") as fh:
+        fh.write("\n")
+    assert hip_solver.source_hash(str(root)) != have
+    assert hip_solver.source_hash(str(tmp_path / "nowhere")) is None
+
+
 def test_create_rejects_bad_input_without_gpu(lib):
     from dispatches_amd.hip_solver import DspLpDesc
     h = C.c_void_p()
