@@ -171,16 +171,22 @@ typedef struct dsp_options {
                                 the padded / LDS-matrix ahead-of-time kernels are used (dsp_rtc_message says why)  default 0 */
   int32_t reserved1;
   double  eps_infeasible;    /* > 0: infeasibility / unboundedness certificates (DSP_STATUS_PRIMAL_INFEASIBLE / DUAL_INFEASIBLE, ABI 9).  On
-                                an LP without a solution the PDHG operator has no fixed point and T(z) - z tends to a ray.  Whenever a
-                                KKT test finds the relative gap |c.x - dual objective| / (1 + |c.x| + |dual objective|) >= 1/2 after
-                                the 8th check (the objectives drifting apart: never seen on a feasible bidding LP at that stage, so the
-                                test costs feasible batches one comparison), the two certificates are evaluated on the displacement
-                                (two products + one reduction), the KKT test is then repeated every 4th check, and the scenario ends when
+                                an LP without a solution the PDHG operator has no fixed point, T(z) - z tends to a ray, one of the
+                                objectives runs away and the relative gap |c.x - dual objective| / (1 + |c.x| + |dual objective|) tends
+                                to 1.  A KKT test that finds the gap >= 1/2 after the 8th check (HBM-resident path: after 2048
+                                iterations) marks the scenario SUSPECT - no feasible scenario of the reference's bidding LPs is there at
+                                that stage, so feasible batches pay one comparison per KKT test.  For suspects the two certificates are
+                                evaluated on the displacement (dy as a Farkas ray, dx clipped to the recession cone of the bounds as a
+                                direction of unbounded descent: two products + one reduction) and the scenario ends when
                                     |dual residual of the ray| (1 + |bounds|) <= eps_infeasible * (bound value of the ray)        or
                                     |recession violation of A dx| (1 + |c|) <= eps_infeasible * (-c.dx)
-                                (scaled space; both are proofs up to the tolerance, whatever the iterate).  Reference behaviour: the
-                                solver's termination condition, on which the callers act (case_studies/renewables_case/
-                                solar_battery_hydrogen.py:451-458).  0 = off                                     default 1e-6 */
+                                (scaled space; both are proofs up to the tolerance, whatever the iterate).  Where: the generic (LDS-
+                                matrix) kernels at their restarts; the register-resident kernels only watch the gap and hand a scenario
+                                that stays suspect over three KKT tests to a second launch of the generic kernel, which continues from
+                                its iterate (that launch returns at once when there is no suspect); the HBM-resident path in a
+                                certificate sequence the host enqueues at most every 16 check periods while suspects exist.  Reference
+                                behaviour: the solver's termination condition, on which the callers act (case_studies/renewables_case/
+                                solar_battery_hydrogen.py:451-458).  0 = off                                        default 1e-6 */
 } dsp_options;
 
 /* The per-call data of B scenarios.  c is required; every other input may be NULL (= no bound: -inf / +inf,
