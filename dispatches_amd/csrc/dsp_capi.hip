@@ -599,8 +599,22 @@ int dsp_solve(dsp_handle *h, const dsp_batch *batch, const dsp_options *opt, dsp
     c.queue = a.queue + 3;
     c.b.x0 = a.b.x; c.b.y0 = a.b.y;
     c.waves_per_block = cert_wpb;
-    const int grid2 = std::min((B + cert_wpb - 1) / cert_wpb, h->num_cus);
-    HIP_TRY(launch_solve(h->cpl, h->rpl, c, dim3(grid2), dim3(64 * cert_wpb), cert_lds, st));
+    // How many blocks: a caller that waits for the statistics anyway (sync_stats) lets the host read the count of suspects after the
+    // first pass - no launch at all on a feasible batch, one block per suspect otherwise.  Asynchronous callers (pipelined batches,
+    // the rolling loop's graphs) get a launch of 8 blocks that returns at its first line when there is no suspect: with one block
+    // per CU it cost the pipelined metric batch 1.2 % (every block needs a free 256-VGPR wave slot before it can even return), with
+    // 8 blocks 0.5 %, without the pass 0 (profiles/r51d_cert_pass_cost.log); 32 waves are plenty for the rare suspect.
+    static const int cert_grid_env = getenv("DSP_CERT_GRID") ? atoi(getenv("DSP_CERT_GRID")) : 0;      // development: blocks of the pass
+    int nsus = -1;
+    if (stats && sync_stats) {
+      HIP_TRY(hipMemcpyAsync(&nsus, a.suspects, sizeof(int), hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipStreamSynchronize(st));
+    }
+    if (nsus != 0) {
+      const int want = nsus > 0 ? (nsus + cert_wpb - 1) / cert_wpb : (cert_grid_env > 0 ? cert_grid_env : 8);
+      const int grid2 = std::max(1, std::min(std::min((B + cert_wpb - 1) / cert_wpb, want), 2 * h->num_cus));
+      HIP_TRY(launch_solve(h->cpl, h->rpl, c, dim3(grid2), dim3(64 * cert_wpb), cert_lds, st));
+    }
   }
   if (timed) HIP_TRY(hipEventRecord(h->ev1, st));
 #ifdef DSP_KKT_TRACE
