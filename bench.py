@@ -438,8 +438,11 @@ def bench_bidder_api(args, rank, local_rank, world, dev):
                        "optimal": n_opt, "curve_points_per_hour": {"mean": float(np.mean(points)), "max": int(max(points))},
                        "bids_identical_to_numpy_path": bool(same), "numpy_path_call_ms": ref_ms,
                        "path": "objective vectors formed on the device from the uploaded price windows (PriceObjective), x / y left on the device "
-                               "(DeviceSolution), roundings + per-hour sorts of the bid assembly as tensor operations (workflow/bid_curves.py), "
-                               "p_cost lists, records and the first 16 scenarios' detail rows on the host"}}
+                               "(DeviceSolution), exact roundings + per-hour sorts + distinct points of the bid assembly in ONE kernel launch "
+                               "(dsp_bid_points, csrc/dsp_bids.hip), p_min point / running maximum / cost integration for all hours at once on the "
+                               "host (workflow/bid_curves.py::curves), p_cost tuple lists (31 k tuples: ~0.8 ms of CPython), records and the "
+                               "first 16 scenarios' detail rows (one set of numpy operations) on the host; floor of this call: the lone-batch "
+                               "kernel latency (its slowest scenario) + the tuple lists"}}
 
 
 def _qp_oracle_worker(args):

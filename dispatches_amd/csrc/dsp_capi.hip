@@ -233,6 +233,18 @@ int dsp_wb_rolling_update(const dsp_wb_state *st, const dsp_wb_model *rt, const 
   return DSP_OK;
 }
 
+int dsp_bid_points(const dsp_bid_request *rq, void *hipStream) {
+  if (!rq || rq->B < 0 || rq->T < 0 || rq->terms < 0 || rq->terms > 2 || rq->ldx < 1 || rq->ldp < rq->T) return DSP_ERR_INVALID;
+  if (rq->B > DSP_BID_MAX_SCENARIOS || rq->T > DSP_BID_MAX_HOURS) return DSP_ERR_TOO_LARGE;
+  if (rq->T == 0) return DSP_OK;
+  if (!rq->out || (rq->B > 0 && (!rq->x || !rq->price))) return DSP_ERR_INVALID;
+  for (int t = 0; t < rq->T; ++t)
+    for (int e = 0; e < (rq->terms == 2 ? 2 : 1); ++e)
+      if (rq->col[t][e] < 0 || rq->col[t][e] >= rq->ldx) return DSP_ERR_INVALID;
+  HIP_TRY(launch_bid_points(*rq, (hipStream_t)hipStream));
+  return DSP_OK;
+}
+
 void dsp_default_options(dsp_options *o) {
   if (!o) return;
   std::memset(o, 0, sizeof(*o));

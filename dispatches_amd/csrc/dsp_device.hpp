@@ -159,6 +159,8 @@ hipError_t launch_simplex(const SimplexArgs &a, int grid, size_t lds, hipStream_
 // float32-iterate solve (dsp_qp.hip); returns the launch geometry it chose
 hipError_t launch_solve_f32(int cpl, int rpl, const SolveArgs &a, int num_cus, size_t lds_limit, hipStream_t st, int *grid,
                             int *threads, size_t *lds);
+// bid-curve points of a solved batch (dsp_bids.hip)
+hipError_t launch_bid_points(const dsp_bid_request &rq, hipStream_t st);
 hipError_t launch_spmv(int cpl, int rpl, const SpmvArgs &a, dim3 grid, dim3 block, size_t lds, hipStream_t st);
 
 #endif

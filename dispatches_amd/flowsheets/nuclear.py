@@ -46,7 +46,7 @@ def create_multiperiod_nuclear_model(b, n_time_points=4, h2_demand=0.35, demand_
     return dict(periods=periods, holdup_init=holdup_init)
 
 
-class MultiPeriodNuclear:
+class MultiPeriodNuclear(units.ResultRecords):
     # preconditioner hint for the HIP solver (include/dsp_hip.h geo_iters): the hydrogen-tank rows mix 3600 s/h,
     # mol/s and kW coefficients; geometric pre-equilibration halves the PDLP iteration count of this flowsheet
     solver_hints = {"geo_iters": 8}
@@ -86,29 +86,21 @@ class MultiPeriodNuclear:
         return {"implemented_tank_holdup": deque(
             [per[t]["tank_holdup"].value for t in range(last_implemented_time_step + 1)])}
 
-    def record_results(self, blk, date=None, hour=None, **kwargs):
+    record_generator = False
+
+    def _result_columns(self, blk):
         per = blk.nuclear["periods"]
         T = len(per)
-        x = blk.solution
-        col = lambda key: np.array([x[p[key].index] for p in per])
-        # kept as a plain dict; the frames are built once in write_results (one pandas constructor per recorded
-        # scenario and call was most of the host time of an hourly real-time bid)
-        rec = {
-            "Date": date,
-            "Hour": hour,
-            "Horizon [hr]": np.arange(T, dtype=int),
-            "Power to Grid [MW]": np.round(blk.family_values("P_T")[:T], 2),
+        x = np.asarray(blk.solution)
+        col = lambda key: x[..., [p[key].index for p in per]]
+        return T, {
+            "Power to Grid [MW]": np.round(blk.family_values("P_T")[..., :T], 2),
             "Power to PEM [MW]": np.round(col("pem_elec") * 1e-3, 2),
             "Initial holdup [kg]": np.round(col("holdup_prev") * prm.mw_h2, 2),
             "Final holdup [kg]": np.round(col("tank_holdup") * prm.mw_h2, 2),
             "Hydrogen Market [kg/hr]": np.round(col("outlet_to_pipeline") * prm.mw_h2 * 3600, 2),
-            "Total Cost [$]": np.round(blk.family_values("tot_cost")[:T], 2),
-            **kwargs,                     # e.g. Scenario=, Market= (appended as the last columns, as the reference does)
+            "Total Cost [$]": np.round(blk.family_values("tot_cost")[..., :T], 2),
         }
-        self.result_list.append(rec)
-
-    def write_results(self, path):
-        pd.concat([pd.DataFrame(r) for r in self.result_list]).to_csv(path, index=False)
 
     @property
     def power_output(self):

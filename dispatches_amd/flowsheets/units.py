@@ -5,6 +5,8 @@ Every function appends columns/rows for ONE time period `t` and returns the hand
 """
 from __future__ import annotations
 
+import numpy as np
+
 from ..lp import INF, LinearBlock
 
 
@@ -110,3 +112,41 @@ def hydrogen_tank(b: LinearBlock, t: int, holdup_prev, inlet_mol_per_s, dt_s=360
     out = b.var(f"h2_tank.outlet_to_pipeline.flow_mol[{t}]", 0.0, demand_ub_mol_s)
     b.equality(f"h2_tank.tank_material_balance[{t}]", holdup - holdup_prev - dt_s * inlet_mol_per_s + dt_s * out, 0.0)
     return dict(tank_holdup=holdup, outlet_to_pipeline=out)
+
+
+class ResultRecords:
+    """record_results / write_results of the three multi-period model objects (reference: `record_results` of
+    wind_battery_double_loop.py:276-335, wind_PEM_double_loop.py, nuclear multiperiod model: one row per horizon hour, the
+    reference's column names).  A model object states its columns ONCE, shape-agnostically (`_result_columns(b)`: from a block
+    whose solution is one scenario [n] or several [S, n]); `record_results` is the reference's per-block call, and
+    `record_results_many` records S scenarios of a batch with the same dozen numpy operations instead of S times a dozen -
+    the Bidder's per-scenario detail rows were 0.9 ms of a 6-ms compute_day_ahead_bids."""
+
+    record_generator = True           # "Generator" is the first column (the nuclear model object has none)
+
+    def _record_head(self, date, hour, T):
+        head = {"Generator": self.model_data.gen_name} if self.record_generator else {}
+        head.update({"Date": date, "Hour": hour, "Horizon [hr]": np.arange(T, dtype=int)})
+        return head
+
+    @staticmethod
+    def _round_scalar(v):
+        """round(value, 2) as Python does it, for one scenario (a float) or several (a list of floats)"""
+        return round(float(v), 2) if np.ndim(v) == 0 else [round(float(w), 2) for w in v]
+
+    def record_results(self, b, date=None, hour=None, **kwargs):
+        T, cols = self._result_columns(b)
+        # kept as a plain dict; the frames are built once in write_results (one pandas constructor per recorded
+        # scenario and call was most of the host time of an hourly real-time bid)
+        self.result_list.append({**self._record_head(date, hour, T), **cols, **kwargs})     # kwargs: e.g. Scenario=, Market= (last columns)
+
+    def record_results_many(self, b, scenarios, date=None, hour=None, **kwargs):
+        """b.solution: [len(scenarios), n].  The records record_results would append scenario by scenario with Scenario=i."""
+        T, cols = self._result_columns(b)
+        head = self._record_head(date, hour, T)
+        for r, i in enumerate(scenarios):
+            self.result_list.append({**head, **{k: v[r] for k, v in cols.items()}, "Scenario": i, **kwargs})
+
+    def write_results(self, path):
+        import pandas as pd
+        pd.concat([pd.DataFrame(r) for r in self.result_list]).to_csv(path, index=False)

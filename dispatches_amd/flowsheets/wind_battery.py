@@ -49,7 +49,7 @@ def create_multiperiod_wind_battery_model(b, n_time_points, wind_cfs, input_para
                 batt_kw=batt_kw, batt_kwh=batt_kwh)
 
 
-class MultiPeriodWindBattery:
+class MultiPeriodWindBattery(units.ResultRecords):
     # scaling hint for the HIP solver: column ranges implied by the bounds (lp.implied_column_ranges) - this LP mixes kW, MW and
     # (wind + battery) kWh of accumulated throughput; the reference sets IDAES scaling factors on the same variables
     column_scaling = "implied_ranges"
@@ -127,35 +127,23 @@ class MultiPeriodWindBattery:
                 for t in range(last_implemented_time_step + 1)),
         }
 
-    def record_results(self, b, date=None, hour=None, **kwargs):
-        """One row per horizon hour, same column names as the reference (:276-335), built column-wise."""
+    def _result_columns(self, b):
+        """One row per horizon hour, same column names as the reference (:276-335), built column-wise (units.ResultRecords)."""
         per = b.windBattery["periods"]
         T = len(per)
-        x = b.solution
-        col = lambda key: np.array([x[p[key].index] for p in per])
-        # the reference reports wind_waste[0] in every row (:312); kept for CSV compatibility
-        waste0 = b.value(b.wind_waste[0])
-        # kept as a plain dict; the frames are built once in write_results (one pandas constructor per recorded
-        # scenario and call was most of the host time of an hourly real-time bid)
-        rec = {
-            "Generator": self.model_data.gen_name,
-            "Date": date,
-            "Hour": hour,
-            "Horizon [hr]": np.arange(T, dtype=int),
+        x = np.asarray(b.solution)
+        col = lambda key: x[..., [p[key].index for p in per]]
+        return T, {
             "Total Wind Generation [MW]": np.round(col("wind") * 1e-3, 2),
-            "Total Power Output [MW]": np.round(b.family_values("P_T")[:T], 2),
+            "Total Power Output [MW]": np.round(b.family_values("P_T")[..., :T], 2),
             "Wind Power Output [MW]": np.round(col("grid_elec") * 1e-3, 2),
-            "Wind Curtailment [MW]": round(waste0, 2),
+            # the reference reports wind_waste[0] in every row (:312); kept for CSV compatibility
+            "Wind Curtailment [MW]": self._round_scalar(b.family_values("wind_waste")[..., 0]),
             "Battery Power Output [MW]": np.round(col("elec_out") * 1e-3, 2),
             "Wind Power to Battery [MW]": np.round(col("elec_in") * 1e-3, 2),
             "State of Charge [MWh]": np.round(col("state_of_charge") * 1e-3, 2),
-            "Total Cost [$]": np.round(b.family_values("tot_cost")[:T], 2),
-            **kwargs,                     # e.g. Scenario=, Market= (appended as the last columns, as the reference does)
+            "Total Cost [$]": np.round(b.family_values("tot_cost")[..., :T], 2),
         }
-        self.result_list.append(rec)
-
-    def write_results(self, path):
-        pd.concat([pd.DataFrame(r) for r in self.result_list]).to_csv(path, index=False)
 
     @property
     def power_output(self):

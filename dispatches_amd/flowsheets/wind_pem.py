@@ -29,7 +29,7 @@ def create_multiperiod_wind_pem_model(b, n_time_points, wind_cfs, input_params):
     return dict(periods=periods, pem_system_capacity=cap, wind_kw=wind_kw)
 
 
-class MultiPeriodWindPEM:
+class MultiPeriodWindPEM(units.ResultRecords):
     # scaling hint for the HIP solver: column ranges implied by the bounds (lp.implied_column_ranges) - this LP mixes kW, MW and
     # (wind + battery) kWh of accumulated throughput; the reference sets IDAES scaling factors on the same variables
     column_scaling = "implied_ranges"
@@ -101,31 +101,20 @@ class MultiPeriodWindPEM:
         return {"realized_h2_sales": deque(
             MultiPeriodWindPEM._h2_kg_per_hr(per[t]["pem_elec"].value) for t in range(last_implemented_time_step + 1))}
 
-    def record_results(self, b, date=None, hour=None, **kwargs):
+    def _result_columns(self, b):
         per = b.windPEM["periods"]
         T = len(per)
-        x = b.solution
-        col = lambda key: np.array([x[p[key].index] for p in per])
-        # kept as a plain dict; the frames are built once in write_results (one pandas constructor per recorded
-        # scenario and call was most of the host time of an hourly real-time bid)
-        rec = {
-            "Generator": self.model_data.gen_name,
-            "Date": date,
-            "Hour": hour,
-            "Horizon [hr]": np.arange(T, dtype=int),
+        x = np.asarray(b.solution)
+        col = lambda key: x[..., [p[key].index for p in per]]
+        return T, {
             "Total Wind Generation [MW]": np.round(col("wind") * 1e-3, 2),
-            "Total Power Output [MW]": np.round(b.family_values("P_T")[:T], 2),
+            "Total Power Output [MW]": np.round(b.family_values("P_T")[..., :T], 2),
             "Wind Power Output [MW]": np.round(col("grid_elec") * 1e-3, 2),
             "Wind to PEM [MW]": np.round(col("pem_elec") * 1e-3, 2),
-            "Wind Curtailment [MW]": round(b.value(b.wind_waste[0]), 2),
+            "Wind Curtailment [MW]": self._round_scalar(b.family_values("wind_waste")[..., 0]),
             "Hydrogen Sales [kg]": np.round(self._h2_kg_per_hr(col("pem_elec")), 2),
-            "Total Cost [$]": np.round(b.family_values("tot_cost")[:T], 2),
-            **kwargs,                     # e.g. Scenario=, Market= (appended as the last columns, as the reference does)
+            "Total Cost [$]": np.round(b.family_values("tot_cost")[..., :T], 2),
         }
-        self.result_list.append(rec)
-
-    def write_results(self, path):
-        pd.concat([pd.DataFrame(r) for r in self.result_list]).to_csv(path, index=False)
 
     @property
     def power_output(self):

@@ -85,7 +85,17 @@ EXPORTED_SYMBOLS = ("dsp_default_options", "dsp_create", "dsp_solve", "dsp_spmv_
                     "dsp_rtc_compile_check", "dsp_rtc_message", "dsp_wb_rolling_update", "dsp_source_hash")
 
 
-ABI_VERSION = 9          # DSP_VERSION of the include/dsp_hip.h these structures mirror
+ABI_VERSION = 10         # DSP_VERSION of the include/dsp_hip.h these structures mirror
+
+
+BID_MAX_HOURS, BID_MAX_SCENARIOS = 64, 16384
+
+
+class DspBidRequest(C.Structure):
+    """include/dsp_hip.h: dsp_bid_request (ABI 10)"""
+    _fields_ = [("B", C.c_int32), ("T", C.c_int32), ("ldx", C.c_int32), ("ldp", C.c_int32), ("terms", C.c_int32), ("reserved", C.c_int32),
+                ("x", C.c_void_p), ("price", C.c_void_p), ("ok", C.c_void_p), ("out", C.c_void_p), ("p_min", C.c_double),
+                ("col", (C.c_int32 * 2) * BID_MAX_HOURS), ("val", (C.c_double * 2) * BID_MAX_HOURS), ("constant", C.c_double * BID_MAX_HOURS)]
 
 
 def source_hash(root: Optional[str] = None) -> Optional[str]:
@@ -144,6 +154,8 @@ def load_library(path: Optional[str] = None):
     lib.dsp_rtc_message.restype = C.c_char_p
     lib.dsp_wb_rolling_update.argtypes = [C.POINTER(DspWbState), C.POINTER(DspWbModel), C.POINTER(DspWbModel), i32, i32, vp]
     lib.dsp_wb_rolling_update.restype = C.c_int
+    lib.dsp_bid_points.argtypes = [C.POINTER(DspBidRequest), vp]
+    lib.dsp_bid_points.restype = C.c_int
     lib.dsp_last_hip_error.restype = C.c_int
     lib.dsp_version.restype = C.c_int
     if not hasattr(lib, "dsp_source_hash"):
@@ -347,8 +359,9 @@ class DeviceSolution:
     """x / y of a solve, still on the device (ScenarioBatchModel.store_solution(lazy=...)): a Bidder reads T of n columns, the rolling
     loop nothing at all - downloading 4096 x (n + m) doubles per call was a third of the host time of compute_day_ahead_bids."""
 
-    def __init__(self, out, m, device):
+    def __init__(self, out, m, device, price_windows=()):
         self.x, self.y, self.m, self.device = out["x"], out["y"], m, device
+        self.price_windows = price_windows            # ((host array, device tensor), ...) of the solve's objective recipe
 
     def fetch(self):
         import torch
@@ -366,6 +379,43 @@ class DeviceSolution:
 
     def rows(self, lo, hi):
         return self.x[lo:hi].cpu().numpy()
+
+    def device_prices(self, prices):
+        """Device copy of a [B, T] price array: the very window the solve uploaded for its objective when it is that array."""
+        import torch
+        for host, dev in self.price_windows:
+            if host is prices:
+                return dev
+        return torch.as_tensor(np.ascontiguousarray(prices, np.float64), device=self.x.device)
+
+    def bid_points(self, cols, vals, const, terms, prices, p_min, ok=None):
+        """dsp_bid_points (csrc/dsp_bids.hip) on the solution where it lies: per hour the distinct offered powers with the highest price
+        at each, in integer cents.  cols / vals: [T, 2]; const: [T]; prices: [B, >= T] host array (or device tensor).
+        Returns (counts [T], power_cents [T, W], price_cents [T, W]) as numpy arrays (W = B), or None when the batch is beyond the
+        kernel's limits (the caller keeps its tensor path)."""
+        import torch
+        B, T = self.x.shape[0], len(const)
+        if B > BID_MAX_SCENARIOS or T > BID_MAX_HOURS or B < 1 or T < 1:
+            return None
+        lib = load_library()
+        dev = self.x.device
+        pd = prices if isinstance(prices, torch.Tensor) else self.device_prices(prices)
+        okd = None if ok is None else torch.as_tensor(np.ascontiguousarray(ok, np.uint8), device=dev)
+        out = torch.empty((T, B + 1), dtype=torch.int64, device=dev)
+        rq = DspBidRequest()
+        rq.B, rq.T, rq.ldx, rq.ldp, rq.terms = B, T, self.x.stride(0), pd.stride(0), int(terms)
+        rq.x, rq.price, rq.ok, rq.out, rq.p_min = self.x.data_ptr(), pd.data_ptr(), (okd.data_ptr() if okd is not None else None), out.data_ptr(), float(p_min)
+        C.memmove(rq.col, np.ascontiguousarray(cols, np.int32).ctypes.data, 8 * T)
+        C.memmove(rq.val, np.ascontiguousarray(vals, np.float64).ctypes.data, 16 * T)
+        C.memmove(rq.constant, np.ascontiguousarray(const, np.float64).ctypes.data, 8 * T)
+        stream = torch.cuda.current_stream(dev)
+        _check(lib, lib.dsp_bid_points(C.byref(rq), C.c_void_p(stream.cuda_stream)), "dsp_bid_points")
+        host = torch.empty((T, B + 1), dtype=torch.int64, pin_memory=True)
+        host.copy_(out, non_blocking=True)
+        stream.synchronize()
+        keys = host.numpy()
+        halves = keys[:, 1:].view(np.int32)                      # little endian: price cents, power cents, price cents, ...
+        return keys[:, 0].astype(np.int64), halves[:, 1::2], halves[:, 0::2]
 
 
 class HipPdlpSolver:
@@ -531,7 +581,7 @@ class HipPdlpSolver:
             self.last_recertified = self._recertify(dlp, inputs, out, host, waived)
         if lazy:
             model.store_solution(None, None, host["obj"].numpy() + model.c0, status, host["iters"].numpy(),
-                                 lazy=DeviceSolution(out, model.lp.m, dev))
+                                 lazy=DeviceSolution(out, model.lp.m, dev, getattr(recipe, "device_windows", None) or ()))
         else:
             model.store_solution(host["x"].numpy(), host["y"].numpy()[:, :model.lp.m],
                                  host["obj"].numpy() + model.c0, status, host["iters"].numpy())

@@ -364,10 +364,10 @@ class LinearBlock:
                     cols[r, e], vals[r, e] = j, v
             hit = cache[family] = (cols, vals, np.array([fam[t].const for t in keys]), K)
         cols, vals, const, K = hit
-        terms = vals * np.asarray(self.solution)[cols]
-        acc = terms[:, 0].copy()
+        terms = vals * np.asarray(self.solution)[..., cols]     # (solution [n], or [S, n]: S scenarios at once -> [S, members])
+        acc = terms[..., 0].copy()
         for e in range(1, K):                      # left to right, like the Python sum of LinExpr.value
-            acc += terms[:, e]
+            acc += terms[..., e]
         return const + acc
 
     def __getattr__(self, item):

@@ -32,8 +32,14 @@ class WindowForecaster(AbstractPrescientPriceForecaster):
         self.start_hours = np.asarray(start_hours, int)
 
     def windows(self, series, hour, horizon, n_samples):
-        idx = (self.start_hours[:n_samples, None] + int(hour) + np.arange(horizon)[None, :]) % len(series)
-        return series[idx]
+        # rows of a sliding-window view over the series continued by its own start (the windows wrap around the year): one gather of
+        # n_samples rows instead of an [n_samples, horizon] index array, a modulo and an element-wise gather
+        cache = self.__dict__.setdefault("_views", {})
+        view = cache.get((id(series), horizon))
+        if view is None:
+            ext = np.concatenate([series, series[:horizon - 1]]) if horizon > 1 else series
+            view = cache[(id(series), horizon)] = np.lib.stride_tricks.sliding_window_view(ext, horizon)
+        return view[(self.start_hours[:n_samples] + int(hour)) % len(series)]
 
     def forecast_day_ahead_and_real_time_prices(self, date, hour, bus, horizon, n_samples):
         return self.windows(self.da, hour, horizon, n_samples), self.windows(self.rt, hour, horizon, n_samples)

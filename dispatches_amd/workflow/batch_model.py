@@ -112,6 +112,12 @@ class ScenarioBatchModel:
             return hit[i - 16 * blk]
         return None if self._x is None else self._x[i]
 
+    def block_of(self, scenarios):
+        """The block with the solutions of SEVERAL scenarios at once (block.solution = x[scenarios], [S, n]): what a model object's
+        record_results_many reads - the per-scenario `model.fs[i]` walk evaluates the same expressions S times."""
+        self.block.solution = np.stack([self.row(i) for i in scenarios])
+        return self.block
+
     def columns(self, cols):
         """x[:, cols] without fetching the whole solution when it still sits on the device."""
         cols = np.asarray(cols)

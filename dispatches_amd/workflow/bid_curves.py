@@ -20,7 +20,7 @@ from __future__ import annotations
 import numpy as np
 
 _SPLIT = 134217729.0          # 2^27 + 1 (Veltkamp split of a double into two 26-bit halves)
-_KEY_OFF = 1 << 31            # cents are shifted into [0, 2^32) inside the composite key
+_KEY_OFF = 1 << 31            # price cents are reflected into [0, 2^32) in the low half of the composite key
 _DROP = (1 << 63) - 1         # key of a pair that takes no part (sorted to the end)
 
 
@@ -56,11 +56,13 @@ def sorted_pairs(torch, power, price, p_min, ok=None):
     if ok is not None:
         keep = keep & ok.reshape(-1, 1)
     keep = keep & torch.isfinite(power) & torch.isfinite(price)
-    key = ((pc + _KEY_OFF) << 32) | ((_KEY_OFF - 1) - cc)          # power ascending, then price DESCENDING
+    # signed power cents in the high half, the reflected price in [0, 2^32) below it: power ascending, then price DESCENDING
+    # (the same key as csrc/dsp_bids.hip)
+    key = pc * (1 << 32) + ((_KEY_OFF - 1) - cc)
     key = torch.where(keep, key, torch.full_like(key, _DROP))
     key, _ = torch.sort(key, dim=0)
     live = key != _DROP
-    ps = (key >> 32) - _KEY_OFF
+    ps = key >> 32                                                  # arithmetic shift = floor: the low half is non-negative
     cs = (_KEY_OFF - 1) - (key & 0xFFFFFFFF)
     first = live.clone()
     first[1:] &= ps[1:] != ps[:-1]
@@ -80,3 +82,45 @@ def hour_points(packed, counts):
     vals = packed / 100.0
     ends = np.cumsum(counts)
     return [(vals[e - n:e, 0], vals[e - n:e, 1]) for n, e in zip(counts.tolist(), ends.tolist())]
+
+
+def padded(points, width=None):
+    """hour_points() / numpy-path lists -> (counts [T], powers [T, W], prices [T, W]) with one spare column (curves() may insert a point)."""
+    counts = np.array([len(p) for p, _ in points], np.int64)
+    W = max(int(counts.max()) if len(counts) else 0, width or 0) + 1
+    U, M = np.zeros((len(points), W)), np.zeros((len(points), W))
+    for t, (p, c) in enumerate(points):
+        U[t, :len(p)], M[t, :len(p)] = p, c
+    return counts, U, M
+
+
+def curves(counts, U, M, p_min, pmin2):
+    """The host half of the bid assembly for ALL hours at once (numpy).  counts [T]; U, M [T, W]: per hour the distinct offered powers
+    (ascending) and the highest marginal price at each, W > max(counts).  Per hour, exactly what the reference does to its sorted
+    pairs: an hour without a point AT p_min gets (round(p_min, 2), lowest price seen or 0) inserted in order; marginal prices made
+    non-decreasing; integrated to costs, cost[0] = power[0] * price[0], cost[k] = cost[0] + (d_1 + ... + d_k) with
+    d_i = (power[i] - power[i-1]) * price[i] summed left to right (np.cumsum along the hour: the order of the per-hour loop this
+    replaces, so the floats are the same - tests/test_bid_curves_cpu.py compares them bit for bit).
+    Returns (counts, powers, costs)."""
+    T, W = U.shape
+    n = np.asarray(counts, np.int64)
+    idx = np.arange(W)[None, :]
+    valid = idx < n[:, None]
+    ins = ~((U == p_min) & valid).any(axis=1)
+    if ins.any():
+        lowest = np.where(valid, M, np.inf).min(axis=1)
+        lowest[n == 0] = 0.0
+        k = (valid & (U < pmin2)).sum(axis=1)                       # np.searchsorted(up, pmin2) of the sorted powers
+        shift = ins[:, None] & (idx > k[:, None])
+        U, M = np.take_along_axis(U, idx - shift, 1), np.take_along_axis(M, idx - shift, 1)
+        at = ins[:, None] & (idx == k[:, None])
+        U, M = np.where(at, pmin2, U), np.where(at, lowest[:, None], M)
+        n = n + ins
+        valid = idx < n[:, None]
+    M = np.maximum.accumulate(np.where(valid, M, -np.inf), axis=1)   # (every hour has a point now: finite from column 0 on)
+    U = np.where(valid, U, U[np.arange(T), n - 1][:, None])          # padding repeats the last power: zero increments behind it
+    cost = np.empty_like(U)
+    cost[:, 0] = U[:, 0] * M[:, 0]
+    if W > 1:
+        cost[:, 1:] = cost[:, :1] + np.cumsum(np.diff(U, axis=1) * M[:, 1:], axis=1)
+    return n, U, cost

@@ -321,7 +321,12 @@ class StochasticProgramBidder(AbstractBidder):
         # per-scenario detail rows (reference parametrized_bidder.py:146-149); for very large batches only the
         # first `detail_scenarios` scenarios are expanded (row-by-row pandas would dominate).
         limit = getattr(self, "detail_scenarios", 16)
-        for i in list(model.SCENARIOS)[:limit]:
+        ids = list(model.SCENARIOS)[:limit]
+        many = getattr(self.bidding_model_object, "record_results_many", None)
+        if many is not None and len(ids) > 1 and hasattr(model, "block_of"):
+            many(model.block_of(ids), ids, date=date, hour=hour, Market=market)        # the same records, their columns formed once
+            return
+        for i in ids:
             self.bidding_model_object.record_results(model.fs[i], date=date, hour=hour, Scenario=i, Market=market)
 
     def write_results(self, path):
@@ -368,6 +373,7 @@ class PriceObjective:
         """[B, n] objective on `dev`; `upload(key, array)` returns the device copy of a host array; `cache`: a dict that lives with the
         solver's handle (index tensors and the base vector are uploaded once)."""
         rows, cols, vals, distinct = self.pt
+        self.device_windows = None
         if not distinct or len(np.intersect1d(cols, self.pda_cols)):
             return upload("c", self.dense())                     # (scatter with repeated columns: keep the host order of operations)
         key = (id(self.pt[1]), len(self.base_c))
@@ -378,6 +384,8 @@ class PriceObjective:
         _, rows_d, cols_d, vals_d, pda_d = st
         base_d = upload("base_c", np.ascontiguousarray(self.base_c, np.float64))
         da_d, rt_d = upload("da", self.da), upload("rt", self.rt)
+        # (host array, device copy) of both windows: the bid assembly that follows the solve reads its prices from these
+        self.device_windows = ((self.da, da_d), (self.rt, rt_d))
         c = base_d.unsqueeze(0).expand(self.shape[0], -1).contiguous()
         c[:, cols_d] = c[:, cols_d] - rt_d[:, rows_d] * vals_d
         c[:, pda_d] = c[:, pda_d] - (da_d - rt_d)
@@ -429,7 +437,27 @@ class Bidder(StochasticProgramBidder):
             ok = None
         lazy = getattr(model, "_lazy", None) if getattr(model, "_x", 0) is None else None
         fam = model.block.expressions[self.bidding_model_object.power_output]
-        if lazy is not None and hasattr(lazy, "x") and (market != "Real-time" or max(len(fam[t].coef) for t in range(T)) <= 2):
+        two_terms = market != "Real-time" or max(len(fam[t].coef) for t in range(T)) <= 2
+        if lazy is not None and hasattr(lazy, "bid_points") and two_terms:
+            # ONE kernel launch on the solution where it lies (csrc/dsp_bids.hip), one download of the distinct points
+            if market == "Real-time":
+                K = max(1, max(len(fam[t].coef) for t in range(T)))
+                cols, vals, k0 = np.zeros((T, 2), np.int32), np.zeros((T, 2)), np.zeros(T)
+                for t in range(T):
+                    for e, (j, v) in enumerate(fam[t].coef.items()):
+                        cols[t, e], vals[t, e] = j, v
+                    k0[t] = fam[t].const
+            else:
+                K, cols, vals, k0 = 0, np.zeros((T, 2), np.int32), np.zeros((T, 2)), np.zeros(T)
+                cols[:, 0] = np.asarray(model.pda_cols)[:T]
+            got = lazy.bid_points(cols, vals, k0, K, energy_prices, md.p_min, ok)
+            if got is not None:
+                counts, pc, cc = got
+                w = int(counts.max()) if len(counts) else 0
+                U, M = np.zeros((T, w + 1)), np.zeros((T, w + 1))
+                U[:, :w], M[:, :w] = pc[:, :w] / 100.0, cc[:, :w] / 100.0
+                return counts, U, M
+        if lazy is not None and hasattr(lazy, "x") and two_terms:
             import torch
             from . import bid_curves as bc
             xd = lazy.x
@@ -452,7 +480,7 @@ class Bidder(StochasticProgramBidder):
             price = f64(np.asarray(energy_prices, float)[:, :T])
             okd = None if ok is None else torch.as_tensor(np.ascontiguousarray(ok), device=dev)
             ps, cs, first = bc.sorted_pairs(torch, power[:, :T], price, md.p_min, okd)
-            return bc.hour_points(*bc.compact(torch, ps, cs, first))                                   # one download
+            return bc.padded(bc.hour_points(*bc.compact(torch, ps, cs, first)))                       # one download
         power = model.expression_values(self.bidding_model_object.power_output) if market == "Real-time" \
             else model.columns(model.pda_cols)
         B = model.n_scenario
@@ -467,36 +495,51 @@ class Bidder(StochasticProgramBidder):
         for t in range(T):
             keep = p2[:, t] >= md.p_min
             out.append(_distinct_max(p2[keep, t], c2[keep, t]))
-        return out
+        from . import bid_curves as bc
+        return bc.padded(out)
+
+    @staticmethod
+    def _hour_curve(up, mc, p_min, pmin2):
+        """One hour, the reference's steps one after the other (the statement bid_curves.curves() is tested against, and the path of
+        generators whose default cost-curve points join the scenarios')."""
+        if not (len(up) and (up == p_min).any()):
+            # the reference adds the p_min point at the lowest marginal price seen (0 if there is none)
+            lowest = float(mc.min()) if len(mc) else 0.0
+            k = int(np.searchsorted(up, pmin2))
+            up = np.insert(up, k, pmin2)
+            mc = np.insert(mc, k, lowest)
+        mc = np.maximum.accumulate(mc)                                 # non-decreasing marginal prices
+        cost = np.empty(len(up))
+        cost[0] = up[0] * mc[0]
+        if len(up) > 1:
+            cost[1:] = cost[0] + np.cumsum(np.diff(up) * mc[1:])       # convert_marginal_costs_to_actual_costs
+        return up, cost
 
     def _assemble_bids(self, model, energy_prices, hour, market):
+        from . import bid_curves as bc
         md = self.bidding_model_object.model_data
         gen = self.generator
         is_thermal = md.generator_type == "thermal"
-        points = self._scenario_points(model, energy_prices, market)
+        counts, U, M = self._scenario_points(model, energy_prices, market)
         default = [(round(p, 2), float(mc)) for p, mc in md.p_cost] \
             if (is_thermal and getattr(md, "include_default_p_cost", False)) else []
         pmin2 = round(md.p_min, 2)
         bids = {}
         pairs = {}                # (power, cost) arrays of every curve: record_bids re-uses them instead of re-parsing the tuple lists
-        dflt_p = np.array([d[0] for d in default], float)
-        dflt_c = np.array([d[1] for d in default], float)
+        if default:                                        # the generator's default cost-curve points join the scenarios' (a few numbers)
+            dflt_p = np.array([d[0] for d in default], float)
+            dflt_c = np.array([d[1] for d in default], float)
+            hours = []
+            for t_idx in model.HOUR:
+                n = int(counts[t_idx])
+                up, mc = _distinct_max(np.concatenate([dflt_p, U[t_idx, :n]]), np.concatenate([dflt_c, M[t_idx, :n]]))
+                hours.append(self._hour_curve(up, mc, md.p_min, pmin2))
+        else:                                              # all hours at once: p_min point, running maximum, cost integration
+            n, P, Cst = bc.curves(counts, U, M, md.p_min, pmin2)
+            hours = [(P[t_idx, :k], Cst[t_idx, :k]) for t_idx, k in zip(model.HOUR, n.tolist())]
         for t_idx in model.HOUR:
             t = t_idx + hour
-            up, mc = points[t_idx]
-            if len(dflt_p):                                # the generator's default cost-curve points join the scenarios' (a few numbers)
-                up, mc = _distinct_max(np.concatenate([dflt_p, up]), np.concatenate([dflt_c, mc]))
-            if not (len(up) and (up == md.p_min).any()):
-                # the reference adds the p_min point at the lowest marginal price seen (0 if there is none)
-                lowest = float(mc.min()) if len(mc) else 0.0
-                k = int(np.searchsorted(up, pmin2))
-                up = np.insert(up, k, pmin2)
-                mc = np.insert(mc, k, lowest)
-            mc = np.maximum.accumulate(mc)                                 # non-decreasing marginal prices
-            cost = np.empty(len(up))
-            cost[0] = up[0] * mc[0]
-            if len(up) > 1:
-                cost[1:] = cost[0] + np.cumsum(np.diff(up) * mc[1:])       # convert_marginal_costs_to_actual_costs
+            up, cost = hours[t_idx]
             p_cost = list(zip(up.tolist(), cost.tolist()))
             p_max = float(up[-1])
             bids[t] = {gen: {"p_cost": p_cost, "p_min": md.p_min, "p_max": p_max,

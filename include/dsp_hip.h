@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define DSP_VERSION 9
+#define DSP_VERSION 10
 
 /* return codes (0 = ok, < 0 = API misuse / HIP error; text via dsp_strerror) */
 #define DSP_OK                 0
@@ -323,6 +323,35 @@ typedef struct dsp_wb_state {
  * phase 2: after the tracking solve: delivered power, realised state rounded to 2 dp, revenue, energy, clock + 1. */
 int dsp_wb_rolling_update(const dsp_wb_state *st, const dsp_wb_model *rt, const dsp_wb_model *tr, int32_t phase, int32_t k,
                           void *hipStream);
+
+/* The scenario half of the Bidder's bid assembly ON THE DEVICE (reference: idaes Bidder._assemble_bids as DISPATCHES drives it -
+ * dispatches/workflow/coordinator.py hands its bids to Prescient; golden values
+ * dispatches/case_studies/renewables_case/tests/test_multiperiod_wind_battery_doubleloop.py:245-250): per hour t the pairs
+ * (power[s][t], price[s][t]) of all scenarios, both numbers rounded to cents exactly as Python's round(v, 2) rounds them, pairs with
+ * rounded power < p_min, non-finite numbers or ok[s] == 0 dropped, the highest price kept per distinct power, sorted by power.
+ * One launch (one workgroup per hour: exact rounding, an LDS bitonic sort, an ordered compaction), no synchronisation.
+ * power[s][t] = x[s][col[t][0]]                                                  (terms 0: the day-ahead power columns)
+ *             = x[s][col[t][0]] * val[t][0] + constant[t]                        (terms 1)
+ *             = (x[s][col[t][0]] * val[t][0] + x[s][col[t][1]] * val[t][1]) + constant[t]   (terms 2: P_T of the real-time models)
+ * out[t][0] = number k of distinct powers of hour t, out[t][1 .. k] = the points: high 32 bits power cents, low 32 bits price cents
+ * (both signed).  DSP_ERR_TOO_LARGE for B > DSP_BID_MAX_SCENARIOS or T > DSP_BID_MAX_HOURS (the caller keeps its own path then). */
+#define DSP_BID_MAX_HOURS 64
+#define DSP_BID_MAX_SCENARIOS 16384
+typedef struct dsp_bid_request {
+  int32_t B, T;                        /* scenarios, hours                                                                     */
+  int32_t ldx, ldp;                    /* doubles per scenario in x / in price                                                 */
+  int32_t terms;                       /* 0, 1 or 2 (above)                                                                    */
+  int32_t reserved;
+  const double *x;                     /* [B][ldx] DEVICE: the solution of the batch (dsp_batch::x of its solve)               */
+  const double *price;                 /* [B][ldp] DEVICE: the energy prices the curve is built on, hour t in column t         */
+  const uint8_t *ok;                   /* [B] DEVICE or NULL: 0 = the scenario offers nothing (not solved to optimality)       */
+  int64_t *out;                        /* [T][B + 1] DEVICE                                                                    */
+  double p_min;
+  int32_t col[DSP_BID_MAX_HOURS][2];
+  double val[DSP_BID_MAX_HOURS][2];
+  double constant[DSP_BID_MAX_HOURS];
+} dsp_bid_request;
+int dsp_bid_points(const dsp_bid_request *rq, void *hipStream);
 
 /* Introspection */
 int dsp_get_dims(const dsp_handle *h, int32_t *n, int32_t *m, int64_t *nnz);

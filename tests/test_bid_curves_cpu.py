@@ -128,3 +128,65 @@ def test_price_objective_on_tensors_is_the_dense_objective(builder):
     # a caller that edits model.c afterwards is honoured (the solver then uploads the dense array, not the recipe)
     model.c[0, 0] += 1.0
     assert model._c is not None and model._c[0, 0] == dense[0, 0] + 1.0
+
+
+@pytest.mark.parametrize("p_min", [0.0, 10.0, 10.126, 3.5])
+def test_all_hours_at_once_is_the_hour_by_hour_loop(p_min):
+    """bid_curves.curves() (p_min point, running maximum, cost integration for all hours in a dozen numpy calls) against the
+    reference's steps taken hour by hour (Bidder._hour_curve), bit for bit: hours without points, hours with and without a point at
+    p_min, p_min that is not a whole number of cents (the inserted point then sits beside an offered one), single points."""
+    from dispatches_amd.workflow.bidder import Bidder
+    rng = np.random.default_rng(5)
+    pmin2 = round(p_min, 2)
+    hours = []
+    for t in range(40):
+        n = int(rng.integers(0, 60)) if t % 7 else (0 if t % 14 == 0 else 1)
+        up = np.unique(np.round(rng.uniform(p_min, p_min + 50, n), 2))
+        up = up[up >= p_min]
+        if t % 3 == 0 and len(up):
+            up[0] = p_min                                        # a point AT p_min (only equal as floats when p_min is whole cents)
+            up = np.unique(up)
+        if t % 5 == 0 and len(up) > 2:
+            up[1] = pmin2                                        # a point at round(p_min, 2)
+            up = np.unique(up)
+        mc = np.round(rng.uniform(-20, 300, len(up)), 2)
+        hours.append((up, mc))
+    counts, U, M = bc.padded(hours)
+    U[np.arange(U.shape[1])[None, :] >= counts[:, None]] = 777.0     # whatever sits behind an hour's points is not looked at
+    n, P, C = bc.curves(counts, U.copy(), M.copy(), p_min, pmin2)
+    for t, (up, mc) in enumerate(hours):
+        want_p, want_c = Bidder._hour_curve(up, mc, p_min, pmin2)
+        assert n[t] == len(want_p)
+        np.testing.assert_array_equal(P[t, :n[t]], want_p)
+        np.testing.assert_array_equal(C[t, :n[t]], want_c)
+
+
+@pytest.mark.parametrize("builder", ["wind_battery_batch", "nuclear_batch", "wind_pem_batch"])
+def test_detail_rows_of_many_scenarios_are_the_per_scenario_records(builder):
+    """record_results_many (units.ResultRecords: the columns of the first 16 scenarios formed by one set of numpy operations) appends
+    exactly the records the reference's per-block record_results call appends scenario by scenario: same keys in the same order,
+    same numbers bit for bit, and the CSV they make is the same text."""
+    import io
+    import warnings
+    import pandas as pd
+    recs = []
+    for many in (True, False):
+        bidder, model = getattr(scenarios, builder)(40, 24, _PlantedSolver(False, seed=4))
+        obj = bidder.bidding_model_object
+        if not many:
+            obj.record_results_many = None                    # the reference's walk over model.fs[i]
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            bidder.compute_day_ahead_bids("2020-01-02", 0)
+        recs.append(obj.result_list)
+    a, b = recs
+    assert len(a) == len(b) == 16
+    for ra, rb in zip(a, b):
+        assert list(ra) == list(rb)
+        for k in ra:
+            np.testing.assert_array_equal(np.asarray(ra[k]), np.asarray(rb[k]), err_msg=k)
+            assert type(ra[k]) is type(rb[k]) or isinstance(ra[k], np.ndarray), k
+    buf_a, buf_b = io.StringIO(), io.StringIO()
+    pd.concat([pd.DataFrame(r) for r in a]).to_csv(buf_a, index=False)
+    pd.concat([pd.DataFrame(r) for r in b]).to_csv(buf_b, index=False)
+    assert buf_a.getvalue() == buf_b.getvalue()
