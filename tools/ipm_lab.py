@@ -1,0 +1,179 @@
+"""Lab (development tool; NOT product, NOT oracle): a primal-dual interior-point method (Mehrotra predictor-corrector) whose Newton
+systems are solved EXACTLY through the time-banded structure of the year-long price-taker LPs: the normal matrix A Theta A' without the
+design column(s) has half-bandwidth 6 in the natural row order (m = 6 T rows), the dense columns come back through Sherman-Morrison-
+Woodbury.  Question: Newton iterations to the parity tolerance, against the 75 k PDHG iterations of the streaming path.
+
+    python tools/ipm_lab.py T=672 member=5
+"""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import numpy as np
+import scipy.linalg as sla
+import scipy.sparse as sp
+
+import pdlp_proto as pp
+import stream_lab as lab
+
+fin = lab.fin
+
+
+def banded_from(N, w):
+    """upper banded storage [w + 1, M] of a symmetric sparse matrix (scipy.linalg.cholesky_banded layout)"""
+    N = sp.coo_matrix(N)
+    M = N.shape[0]
+    ab = np.zeros((w + 1, M))
+    k = N.col - N.row
+    keep = (k >= 0) & (k <= w)
+    np.add.at(ab, (w - k[keep], N.col[keep]), N.data[keep])
+    return ab
+
+
+def solve(P, eps=1e-9, eps_obj=5e-7, max_iter=200, colscale=None, n_ruiz=10, dense_thr=16, verbose=0, reg=1e-12, prox=0.0, frac=0.9995, refine=3, theta_cap=1e30):
+    A0 = sp.csr_matrix(P["A"])
+    m, n = A0.shape
+    if colscale is not None:
+        A0 = sp.csr_matrix(A0 @ sp.diags(colscale))
+    As, dr, dc = pp.ruiz_pc_scaling(A0, n_ruiz=int(n_ruiz))
+    if colscale is not None:
+        dc = dc * colscale
+    c = P["c"] * dc
+    cs = max(np.abs(c).max(), 1e-300); c = c / cs
+    lb, ub, rlo, rhi = P["lb"] / dc, P["ub"] / dc, P["rlo"] * dr, P["rhi"] * dr
+    # fixed columns out, slack columns in
+    fixed = lb == ub
+    xfix = np.where(fixed, lb, 0.0)
+    eq = rlo == rhi
+    ine = np.nonzero(~eq)[0]
+    b = np.where(eq, rhi, 0.0) - As @ xfix
+    cols = np.nonzero(~fixed)[0]
+    E = sp.csr_matrix((np.ones(len(ine)), (ine, np.arange(len(ine)))), shape=(m, len(ine)))
+    Abar = sp.hstack([As[:, cols], -E]).tocsc()
+    N = Abar.shape[1]
+    cbar = np.concatenate([c[cols], np.zeros(len(ine))])
+    l = np.concatenate([lb[cols], rlo[ine]]); u = np.concatenate([ub[cols], rhi[ine]])
+    hl, hu = np.isfinite(l), np.isfinite(u)
+    assert (hl | hu).all(), "free columns: not handled here"
+    # wide columns: rows further apart than the band allows (design columns, periodic conditions) - Woodbury
+    span = np.array([(Abar.indices[Abar.indptr[j]:Abar.indptr[j + 1]].max() - Abar.indices[Abar.indptr[j]:Abar.indptr[j + 1]].min())
+                     if Abar.indptr[j + 1] > Abar.indptr[j] else 0 for j in range(N)])
+    dense = np.nonzero(span > dense_thr)[0]
+    sparse_cols = np.setdiff1d(np.arange(N), dense)
+    Asp, Ad = Abar[:, sparse_cols].tocsr(), Abar[:, dense].toarray()
+    pat = (abs(Asp) @ abs(Asp).T).tocoo()
+    w = int(np.abs(pat.row - pat.col).max())
+    if verbose:
+        print(f"  N={N} M={m} dense columns {len(dense)} half-bandwidth {w}")
+    AspT = Asp.T.tocsr()
+    # starting point: inside the box, duals 1
+    v = np.where(hl & hu, 0.5 * (fin(l) + fin(u)), np.where(hl, fin(l) + 1.0, fin(u) - 1.0))
+    y = np.zeros(m)
+    z = np.where(hl, 1.0, 0.0); f = np.where(hu, 1.0, 0.0)
+    A, AT = P["A"], sp.csr_matrix(P["A"].T)
+    qn = np.sqrt(np.sum(np.maximum(np.abs(fin(P["rlo"])), np.abs(fin(P["rhi"]))) ** 2) + np.sum(fin(P["lb"]) ** 2 + fin(P["ub"]) ** 2))
+    cn = np.linalg.norm(P["c"])
+    nb = hl.sum() + hu.sum()
+    t0 = time.time()
+    for it in range(1, int(max_iter) + 1):
+        wl = np.where(hl, v - fin(l), 1.0); tu = np.where(hu, fin(u) - v, 1.0)
+        rp = b - Abar @ v
+        rd = cbar - Abar.T @ y - z + f
+        mu = (z @ (wl * hl) + f @ (tu * hu)) / nb
+        theta = 1.0 / np.maximum(np.where(hl, z / wl, 0.0) + np.where(hu, f / tu, 0.0), 1e-300)
+        theta = np.minimum(theta, theta_cap)
+        if not (np.isfinite(theta).all() and np.isfinite(rp).all() and mu > 0):
+            return None, None, it, False
+        # factor B = Asp Theta Asp' (banded) ; dense columns through Woodbury
+        th_s, th_d = theta[sparse_cols], theta[dense]
+        Nm = (Asp @ sp.diags(th_s) @ AspT)
+        ab = banded_from(Nm, w)
+        delta = prox * np.median(ab[w])                      # dual proximal term (rank-deficient rows): K = A Theta A' + delta I
+        ab[w] = ab[w] * (1.0 + reg) + delta                  # + relative diagonal regularisation (roundoff of the factorisation)
+        cb = sla.cholesky_banded(ab, lower=False)
+        bsolve = lambda r: sla.cho_solve_banded((cb, False), r)
+        if len(dense):
+            BiAd = bsolve(Ad)
+            S = np.diag(1.0 / th_d) + Ad.T @ BiAd
+            nsolve = lambda r: (lambda q: q - BiAd @ np.linalg.solve(S, Ad.T @ q))(bsolve(r))
+        else:
+            nsolve = bsolve
+
+        def direction(sig_mu, corr_l, corr_u):
+            # complementarity targets: z w + w dz + z dv = sig_mu - corr ; f t + t df - f dv = sig_mu - corr
+            cz = np.where(hl, (sig_mu - corr_l) / wl - z, 0.0)
+            cf = np.where(hu, (sig_mu - corr_u) / tu - f, 0.0)
+            rt = rd - cz + cf
+            rhs = rp + Abar @ (theta * rt)
+            dy = nsolve(rhs)
+            for _ in range(int(refine)):                     # iterative refinement on the full normal equations
+                res = rhs - Abar @ (theta * (Abar.T @ dy)) - delta * dy
+                dy = dy + nsolve(res)
+            dv = theta * (Abar.T @ dy - rt)
+            dz = np.where(hl, cz - z / wl * dv, 0.0)
+            df = np.where(hu, cf + f / tu * dv, 0.0)
+            return dv, dy, dz, df
+
+        def steps(dv, dz, df):
+            ap = 1.0
+            neg = hl & (dv < 0)
+            if neg.any():
+                ap = min(ap, np.min(-wl[neg] / dv[neg]))
+            pos = hu & (dv > 0)
+            if pos.any():
+                ap = min(ap, np.min(tu[pos] / dv[pos]))
+            ad = 1.0
+            nz = hl & (dz < 0)
+            if nz.any():
+                ad = min(ad, np.min(-z[nz] / dz[nz]))
+            nf = hu & (df < 0)
+            if nf.any():
+                ad = min(ad, np.min(-f[nf] / df[nf]))
+            return ap, ad
+        dva, dya, dza, dfa = direction(0.0, 0.0, 0.0)
+        apa, ada = steps(dva, dza, dfa)
+        mu_aff = ((z + ada * dza) @ ((wl + apa * dva) * hl) + (f + ada * dfa) @ ((tu - apa * dva) * hu)) / nb
+        sigma = (mu_aff / mu) ** 3
+        dv, dy, dz, df = direction(sigma * mu, dva * dza, -dva * dfa)
+        ap, ad = steps(dv, dz, df)
+        ap, ad = min(1.0, frac * ap), min(1.0, frac * ad)
+        v = v + ap * dv; y = y + ad * dy; z = z + ad * dz; f = f + ad * df
+        # termination on the unscaled problem, the streaming path's test
+        xs = xfix.copy(); xs[cols] = v[:len(cols)]
+        Xu = xs * dc
+        Yu = y * dr * cs                    # row multipliers: c - A' y = reduced costs
+        AX = A @ Xu
+        viol = np.maximum(P["rlo"] - AX, 0) + np.maximum(AX - P["rhi"], 0)
+        rc = P["c"] - AT @ Yu
+        lp_ = np.where(np.isfinite(P["lb"]), np.maximum(rc, 0), 0.0); lm_ = np.where(np.isfinite(P["ub"]), np.maximum(-rc, 0), 0.0)
+        dres = rc - lp_ + lm_
+        po = P["c"] @ Xu
+        do = np.sum(np.maximum(Yu, 0) * fin(P["rlo"]) - np.maximum(-Yu, 0) * fin(P["rhi"])) + np.sum(lp_ * fin(P["lb"]) - lm_ * fin(P["ub"]))
+        rpn, rdn = np.linalg.norm(viol) / (1 + qn), np.linalg.norm(dres) / (1 + cn)
+        bound = abs(po - do) + np.sum(np.abs(Yu) * viol) + np.sum(np.abs(dres) * np.abs(Xu))
+        lim = max(eps_obj * (1 + abs(po + P["c0"])), 1e-12 * np.sum(np.abs(P["c"] * Xu)))
+        if verbose:
+            print(f"  it {it} mu {mu:.2e} sigma {sigma:.1e} ap {ap:.3f} ad {ad:.3f} rp {rpn:.2e} rd {rdn:.2e} bound/lim {bound/lim:.2e} obj {po + P['c0']:.10e} "
+                  f"theta {theta.min():.1e}..{theta.max():.1e} t {time.time()-t0:.1f}s", flush=True)
+        if rpn <= eps and rdn <= eps and bound <= lim:
+            return Xu, Yu, it, True
+    return Xu, Yu, int(max_iter), False
+
+
+if __name__ == "__main__":
+    kw = dict(a.split("=") for a in sys.argv[1:])
+    T = int(kw.pop("T", 672)); members = [int(k) for k in kw.pop("member", "5").split(",")]
+    cs = kw.pop("colscale", "phys")
+    opts = {k: float(v) for k, v in kw.items()}
+    for member in members:
+        P = lab.build(T, member, None, "chain")
+        ref, xr, th = lab.highs(P)
+        print(f"T={T} member={member} n={P['lp'].n} m={P['lp'].m} nnz={P['lp'].nnz} HiGHS {ref:.10e} ({th:.1f}s)", flush=True)
+        if cs == "phys":
+            opts["colscale"] = lab.physical_scales(P, T)
+        t = time.time()
+        X, Y, it, done = solve(P, **opts)
+        obj = P["c"] @ X + P["c0"]
+        print(f"done={done} newton_iterations={it} obj={obj:.10e} relerr={abs(obj-ref)/max(1,abs(ref)):.2e} t={time.time()-t:.1f}s", flush=True)
