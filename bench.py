@@ -232,8 +232,9 @@ def _rank_devices(world, dev):
     return devs, ws
 
 
-STREAM_FORMS = {0: "none", 1: "two_launch", 2: "tile", 3: "lane", 4: "block"}
-STREAM_KERNELS = {1: "k_primal + k_dual_halpern", 2: "k_fused_pre / k_fused", 3: "k_lane<.., 0> (+ k_lane_long<0>)", 4: "k_block_solve"}
+STREAM_FORMS = {0: "none", 1: "two_launch", 2: "tile", 3: "lane", 4: "block", 5: "interior_point"}
+STREAM_KERNELS = {1: "k_primal + k_dual_halpern", 2: "k_fused_pre / k_fused", 3: "k_lane<.., 0> (+ k_lane_long<0>)", 4: "k_block_solve",
+                  5: "k_seq<FactorBody / ForwardBody / BackwardBody> (banded LDL' and substitutions, csrc/dsp_ipm.hip)"}
 
 
 def _price_taker_cpu_worker(args):
@@ -275,13 +276,17 @@ def bench_price_taker(args, rank, local_rank, world, dev):
     B, ce = (args.batch if args.batch != 4096 else (60 if args.workload == "nuclear_price_taker" else 64)), 64
     # form of the throughput accumulator (flowsheets/price_taker.py): "two_level" is the wind + battery family's default since round 4
     # (scenarios.price_taker_batch), the PEM family keeps the reference's chain (the electrolyzer takes the energy a battery would cycle)
-    thr = args.throughput or ("two_level" if args.workload == "price_taker" else "chain")
+    # interior-point form (round 5, csrc/dsp_ipm.hip): the --solve lines use it unless --pdhg; it wants the reference's own chain form of the
+    # accumulator (the two_level change of variables has free columns: a first-order device).  The capped iteration-throughput lines measure
+    # the PDHG kernels and switch it off.
+    ipm = bool(args.solve) and not getattr(args, "pdhg", False)
+    thr = args.throughput or ("two_level" if args.workload == "price_taker" and not ipm else "chain")
     build = {"price_taker": lambda s: scenarios.price_taker_batch(T, B, s, throughput=thr)[1],
              "pem_price_taker": lambda s: scenarios.pem_price_taker_batch(T, B, s, inputs="rts303", throughput=thr)[1],
              "nuclear_price_taker": lambda s: scenarios.nuclear_price_taker_batch(T, B, s)[1]}[args.workload]
 
     def run(periods):
-        solver = HipPdlpSolver(device=local_rank, check_every=ce, max_iter=periods * ce, recertify=0)
+        solver = HipPdlpSolver(device=local_rank, check_every=ce, max_iter=periods * ce, recertify=0, no_interior_point=0 if (ipm and periods > 1000) else 1)
         if not hasattr(run, "model"):
             run.model = build(solver)
         run.model.solve_handle = None          # the handle carries its options (max_iter): a fresh one per run
@@ -347,6 +352,19 @@ def bench_price_taker(args, rank, local_rank, world, dev):
                                  "scenario for the long columns only); xbar and both products' gathers stay in LDS; time = HIP events around the whole "
                                  "solve on its stream (includes the long-column launches and the check sequences; with --solve also the iterations "
                                  "finished scenarios no longer take part in: frac then understates the kernel)"}}
+        if args.solve and form == 5:
+            # interior point: `iterations` are Newton iterations; the time is the sequential chain of the banded factorisation and
+            # substitutions (m dependent steps per pass, ~100 ns each), not a bandwidth
+            line["config"]["workload"] = (f"{args.workload}: {B} scenarios/GPU sharing one constraint matrix, T = {T} h, interior point with banded LDL' "
+                                          f"factorisations, one lane per scenario (csrc/dsp_ipm.hip), solved to optimality")
+            line["config"]["newton_iterations_per_scenario"] = line["config"].pop("iterations_per_scenario")
+            line["config"]["max_newton_iterations"] = line["config"].pop("max_iterations")
+            line["config"]["ms_per_newton_iteration_of_the_batch"] = 1e3 * k_s / max(1, int(model.iterations.max()))
+            line["config"].pop("us_per_batch_iteration", None)
+            line["roofline"] = {"bound": "latency", "kernel": STREAM_KERNELS[5], "achieved": None, "peak": None, "unit": None, "frac": None, "traffic": None,
+                                "sequential_steps_per_newton_iteration": "m per pass; passes: 1 factorisation + 2 per substitution pair x (K wide columns + predictor + corrector + refinement steps)",
+                                "note": "not a bandwidth- or FLOP-bound kernel: one wave per 64 scenarios walks m dependent rows out of LDS (measured 88 - 117 ns "
+                                        "per row and pass, 58 - 69 ns with the data already in LDS); the batch's time is independent of its size up to one wave per SIMD"}
         if args.solve:
             line["metric"] = f"year-long design LPs solved/sec, {args.workload}, T={T} (n={n}, m={m}), batch={B}"
             line["value"] = world * int((model.status == 0).sum()) / k_s
@@ -751,6 +769,10 @@ def baseline_configs(args, local_rank, dev, budget_s=360.0, depth=8):
     leg("bidder_api", lambda: _condense("bidder_api", bench_bidder_api(sub(workload="bidder_api", batch=4096, steps=12, warmup=2), 0, local_rank, 1, dev),
                                         ("call_ms", "solver_solve_ms", "kernel_ms", "host_rest_ms", "optimal", "curve_points_per_hour",
                                          "bids_identical_to_numpy_path", "numpy_path_call_ms")))
+    leg("price_taker_solve", lambda: _condense("price_taker_solve", bench_price_taker(sub(workload="price_taker", batch=256, steps=1, warmup=1, solve=True, horizon=8736,
+                                                                                           throughput=None, cpu_sample=0, pdhg=False), 0, local_rank, 1, dev),
+                                               ("stream_form", "solved_to_optimality", "newton_iterations_per_scenario", "max_newton_iterations", "seconds_per_batch",
+                                                "ms_per_newton_iteration_of_the_batch", "max_rel_objective_error_vs_oracle_fixture", "throughput_form")))
     leg("streaming", lambda: _condense("streaming", bench_price_taker(sub(workload="price_taker", batch=256, steps=50, warmup=1, solve=False, horizon=8736,
                                                                            throughput=None, cpu_sample=0), 0, local_rank, 1, dev),
                                        ("stream_form", "stream_phases", "iterations_per_scenario", "finished_before_the_cap", "us_per_batch_iteration")))
@@ -780,6 +802,7 @@ def main():
                     help="the burst of --steps steps is repeated until the timed bursts cover this many seconds; the median burst is reported")
     ap.add_argument("--max-bursts", type=int, default=500)
     ap.add_argument("--no-eps4", action="store_true", help="skip the extra eps_rel = 1e-4 (PDLP default tolerance) leg of the LP metric line")
+    ap.add_argument("--pdhg", action="store_true", help="--solve lines: the PDHG forms instead of the interior-point form (dsp_options::no_interior_point)")
     ap.add_argument("--solve", action="store_true", help="--workload price_taker / pem_price_taker / nuclear_price_taker: solve the batch to optimality (full-solve line)")
     ap.add_argument("--throughput", default=None, choices=["chain", "two_level", "hier"],
                     help="--workload price_taker / pem_price_taker: form of the battery's throughput accumulator (flowsheets/price_taker.py); "

@@ -273,6 +273,7 @@ void dsp_default_options(dsp_options *o) {
   o->precision = 0;
   o->polish_patience = 1024;
   o->no_rtc = 0;
+  o->no_interior_point = 0;
   o->eps_infeasible = 1e-6;
 }
 

@@ -1,0 +1,1257 @@
+// dsp_ipm.hip — interior-point form of the HBM-resident path for TIME-BANDED LPs, gfx950 only.
+//
+// The year-long price-taker LPs (reference: dispatches/case_studies/renewables_case/wind_battery_LMP.py:172-269 and its sweeps,
+// run_pricetaker_wind_PEM.py:106-107) cost the restarted PDHG of dsp_stream*.hip 75 k iterations on average (139 k at worst): the
+// state-of-charge / throughput chains are integrators and the design column couples all T periods, and a diagonally preconditioned
+// first-order method sees the horizon one period per iteration.  Their structure is what a DIRECT method wants: in the
+// natural (period-major) row order the normal matrix  A Theta A'  of all columns but the design column(s) has half-bandwidth 6 - 8 with
+// m = 6 T rows.  This file is a primal-dual interior-point method (Mehrotra predictor-corrector; lab: tools/ipm_lab.py - 40 - 144
+// Newton iterations on the 16-member year-long fixture, objectives to 2e-7) whose Newton systems are solved exactly:
+//     [A | -I] (x, r) = 0,  lb <= x <= ub,  rlo <= r <= rhi        (one slack per row: the structure does not depend on the batch's bounds;
+//                                                                     fixed columns / equality rows simply carry Theta = 0)
+//     (A_s Theta_s A_s' + Theta_r) dy = rhs    banded LDL' (no pivoting; relative diagonal regularisation 1e-12), half-bandwidth W <= 8
+//     wide columns (span > 16 rows: design variables, periodic conditions; K <= 4) through Sherman-Morrison-Woodbury, K x K per scenario
+//     iterative refinement on the full normal equations (1 step, 3 in the end game where Theta spans 30 decades)
+// ONE LANE PER SCENARIO: every array is scenario-minor ([index][scenario], 64 scenarios = one 512-byte line per index), all lanes walk the
+// same rows, and the structure (CSR / CSC of the scaled matrix, the band's product lists) is read through uniform addresses.  The two
+// sequential kernels (factorisation, triangular solves: m dependent steps) run one wave per 64 scenarios out of LDS: the workgroup's
+// four waves stream chunks of rows HBM -> registers -> LDS -> HBM around the computing wave (k_seq), so that the chain never waits
+// for memory: 9 loads + 36 fused multiply-adds per row for the factorisation, 8 per row and direction for a solve.  Everything else
+// (residuals, Theta, assembly of the band, directions, step lengths, KKT test) is elementwise over (chunk of indices) x (64 scenarios).
+// Cost per Newton iteration and 64 scenarios: ~20 m sequential steps, independent of the batch size up to one wave per SIMD x 64.
+//
+// Termination is the HBM-resident path's own test (control_decide, dsp_stream.hpp) evaluated on the unscaled problem; a scenario the
+// method does not finish (breakdown, 250 Newton iterations, free columns) is left to the PDHG forms, which start as if this file did
+// not exist.  dsp_options::no_interior_point = 1 switches it off; dsp_stats::stream_form = DSP_STREAM_FORM_IPM when it solved the batch.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <map>
+#include <vector>
+
+#include "dsp_stream.hpp"
+
+namespace dsp {
+
+constexpr int kIpmMaxW = 8, kIpmMaxK = 4, kIpmSpan = 16, kIpmMaxNewton = 250;
+constexpr int kIpmNQ = 16;                 // partial-sum slots (the Woodbury matrix needs K * K)
+
+struct IpmPlan {                            // shared by all scenarios (device)
+  int n, m, W, K, Mp;                       // Mp = m + W rows of the band arrays
+  // the scaled matrix as two ELLs (fixed widths: the address of an entry follows from the index alone - with CSR every product waits
+  // for its pointer, then its index, then its operand: three memory round trips in a row); padding: index 0, value 0
+  int rw, cw, bw;                           // entries per row (all columns), per NARROW column, products per band entry
+  const int32_t *rcol; const double *rval;  // [m][rw]
+  const int32_t *crow; const double *cval;  // [n][cw]   (wide columns: empty here)
+  const uint8_t *wide;                      // [n] 0 = narrow, k + 1 = wide column k
+  int32_t wide_col[kIpmMaxK];
+  const int32_t *wptr, *wrow; const double *wval;      // the wide columns' entries: CSR over k
+  const int32_t *bcol; const double *bval;  // [m][W + 1][bw]: B(t, t - k) = sum bval * theta[bcol] (narrow columns)
+  const double *col_scale, *row_scale;
+};
+
+// per-lane scalars
+enum { SC_MU = 0, SC_SIGMU, SC_AP, SC_AD, SC_CS, SC_NB, SC_APA, SC_ADA, SC_POBJ, SC_COUNT };
+
+struct IpmWork {
+  size_t Bp;                                // lanes (batch rounded up to 64)
+  int B, nch;                               // scenarios, chunks of the elementwise kernels
+  double *v, *z, *f, *l, *u, *cb, *th, *rd, *dv, *dz, *df, *rt, *corl, *coru, *tn;      // [n + m][Bp]
+  double *y, *dy, *rp, *rhs, *q, *res;      // [m][Bp]
+  double *biad;                             // [K][m][Bp]
+  double *band;                             // [W + 1][Mp][Bp]
+  double *sc;                               // [SC_COUNT][Bp]
+  double *part;                             // [kIpmNQ][nch][Bp]
+  double *sinv, *tk;                        // [K * K][Bp], [K][Bp]
+  double *wat;                              // [K][Bp] (Abar' vec) of the wide columns (k_ipm_wide_aty)
+  int *state;                               // [Bp] 0 = iterating, 1 = solved, 2 = given up
+  int *iters;                               // [Bp]
+  int *stall;                               // [Bp] consecutive Newton iterations with a step below 1e-4
+  int *counts;                              // [4]: finished (solved or given up), solved, lanes in the end game
+};
+
+struct IpmArgs {
+  IpmPlan P;
+  IpmWork w;
+  StreamWork sw;                            // scenario-major scaled inputs (k_init) and outputs (k_finalize reads xp / yp / ctrl)
+  dsp_options opt;
+  int it;                                   // Newton iteration (1-based)
+  int max_it;                               // give up after this many (kIpmMaxNewton; development: DSP_IPM_MAXIT)
+};
+
+struct IpmState {
+  IpmPlan P{};
+  IpmWork w{};
+  std::vector<void *> allocs, work_allocs;
+  int work_B = 0;
+  int *counts_host = nullptr;
+};
+
+__device__ __forceinline__ bool ipm_fin(double v) { return fabs(v) < INFINITY; }
+__device__ __forceinline__ double ipm_fin0(double v) { return fabs(v) < INFINITY ? v : 0.0; }
+
+#define IPM_LANE()                                                        \
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;             \
+  const size_t Bp = a.w.Bp;                                               \
+  const size_t s = (size_t)blockIdx.y * 64 + lane;                        \
+  const int cid = blockIdx.x * 4 + wv;                                    \
+  (void)cid;                                                              \
+  if (a.w.state[s] != 0) return
+
+// chunk [i0, i1) of `count` indices for this wave
+__device__ __forceinline__ void ipm_chunk(int count, int nch, int cid, int &i0, int &i1) {
+  const int per = (count + nch - 1) / nch;
+  i0 = min(cid * per, count); i1 = min(i0 + per, count);
+}
+
+// sum (or minimum / maximum) over the chunks' partials part[q][chunk][lane], q < NQ, by a workgroup of 256 threads = 4 waves x the 64
+// scenarios of the group: every wave takes a quarter of the chunks with four independent accumulators (the loads of a plain loop queue
+// up one memory latency each: a 512-chunk sum took 0.95 ms), LDS combines.  Every thread returns the result.
+template <int NQ, int OP>                  // OP 0: sum, 1: min, 2: max
+__device__ __forceinline__ void ipm_finish(const double *part, int nch, size_t Bp, size_t s, double (&out)[NQ]) {
+  __shared__ double red[4][NQ][64];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  auto op = [](double x, double y) { return OP == 0 ? x + y : OP == 1 ? fmin(x, y) : fmax(x, y); };
+  const double e0 = OP == 0 ? 0.0 : OP == 1 ? 1e300 : -1e300;
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    double acc[4] = {e0, e0, e0, e0};
+    int c = wv;
+    for (; c + 12 < nch; c += 16) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) acc[u] = op(acc[u], part[((size_t)q * nch + c + 4 * u) * Bp + s]);
+    }
+    for (; c < nch; c += 4) acc[0] = op(acc[0], part[((size_t)q * nch + c) * Bp + s]);
+    red[wv][q][lane] = op(op(acc[0], acc[1]), op(acc[2], acc[3]));
+  }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) out[q] = op(op(red[0][q][lane], red[1][q][lane]), op(red[2][q][lane], red[3][q][lane]));
+}
+
+// ---- setup -------------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_ipm_cmax(IpmArgs a) {
+  IPM_LANE();
+  int j0, j1; ipm_chunk(a.P.n, a.w.nch, cid, j0, j1);
+  double mx = 0.0;
+  const double *c = a.sw.c + s * a.P.n;
+  for (int j = j0; j < j1; ++j) mx = fmax(mx, fabs(c[j]));
+  a.w.part[(size_t)cid * Bp + s] = mx;
+}
+
+__global__ __launch_bounds__(256) void k_ipm_cmax_finish(IpmArgs a) {
+  const size_t s = (size_t)blockIdx.x * 64 + (threadIdx.x & 63), Bp = a.w.Bp;
+  double mx[1];
+  ipm_finish<1, 2>(a.w.part, a.w.nch, Bp, s, mx);
+  if (threadIdx.x < 64 && a.w.state[s] == 0) a.w.sc[SC_CS * Bp + s] = mx[0] > 1e-300 ? mx[0] : 1.0;
+}
+
+__global__ __launch_bounds__(256) void k_ipm_setup(IpmArgs a) {
+  IPM_LANE();
+  const int n = a.P.n, m = a.P.m, N = n + m;
+  int j0, j1; ipm_chunk(N, a.w.nch, cid, j0, j1);
+  const double ics = 1.0 / a.w.sc[SC_CS * Bp + s];
+  bool bad = false;
+  for (int j = j0; j < j1; ++j) {
+    double l, u, c;
+    if (j < n) { l = a.sw.lb[s * n + j]; u = a.sw.ub[s * n + j]; c = a.sw.c[s * n + j] * ics; }
+    else { l = a.sw.rlo[s * m + (j - n)]; u = a.sw.rhi[s * m + (j - n)]; c = 0.0; }
+    const bool hl = ipm_fin(l), hu = ipm_fin(u);
+    double v, z = 0.0, f = 0.0;
+    if (hl && hu && l == u) v = l;                                     // fixed: takes no part (Theta = 0)
+    else if (hl && hu) { v = 0.5 * (l + u); z = 1.0; f = 1.0; }
+    else if (hl) { v = l + 1.0; z = 1.0; }
+    else if (hu) { v = u - 1.0; f = 1.0; }
+    else { v = 0.0; if (j < n) bad = true; }                           // free column: not this method's LP (a free ROW: slack with a huge Theta)
+    const size_t at = (size_t)j * Bp + s;
+    a.w.l[at] = l; a.w.u[at] = u; a.w.cb[at] = c; a.w.v[at] = v; a.w.z[at] = z; a.w.f[at] = f;
+  }
+  int i0, i1; ipm_chunk(m, a.w.nch, cid, i0, i1);
+  for (int i = i0; i < i1; ++i) a.w.y[(size_t)i * Bp + s] = 0.0;
+  if (bad) a.w.state[s] = 3;                                           // (3: marked here, counted by k_ipm_begin)
+}
+
+// ---- residuals, Theta, mu ----------------------------------------------------------------------------------------------------------
+// (Abar' y)_j : narrow structural column j -> sum_i a_ij y_i ; wide column k -> wat[k] (k_ipm_wide_aty ran on y) ; slack of row i -> -y_i
+__device__ __forceinline__ double ipm_aty(const IpmPlan &P, const double *y, const double *wat, int j, size_t Bp, size_t s) {
+  if (j >= P.n) return -y[(size_t)(j - P.n) * Bp + s];
+  const int wk = P.wide[j];
+  if (wk) return wat[(size_t)(wk - 1) * Bp + s];
+  double t = 0.0;
+  const int32_t *ci = P.crow + (size_t)j * P.cw;
+  const double *cv = P.cval + (size_t)j * P.cw;
+  for (int e = 0; e < P.cw; ++e) t = fma(cv[e], y[(size_t)ci[e] * Bp + s], t);
+  return t;
+}
+// (Abar u)_i = sum_j a_ij u_j - u_{n+i}
+__device__ __forceinline__ double ipm_au(const IpmPlan &P, const double *u, int i, size_t Bp, size_t s) {
+  double t = -u[(size_t)(P.n + i) * Bp + s];
+  const int32_t *ri = P.rcol + (size_t)i * P.rw;
+  const double *rv = P.rval + (size_t)i * P.rw;
+  for (int e = 0; e < P.rw; ++e) t = fma(rv[e], u[(size_t)ri[e] * Bp + s], t);
+  return t;
+}
+
+// (Abar' vec)_j of the wide columns: partial sums over slices of their entries, finished per scenario into wat[k]
+__global__ __launch_bounds__(256) void k_ipm_wide_aty(IpmArgs a, const double *vec) {
+  IPM_LANE();
+  for (int k = 0; k < a.P.K; ++k) {
+    int p0, p1; ipm_chunk(a.P.wptr[k + 1] - a.P.wptr[k], a.w.nch, cid, p0, p1);
+    p0 += a.P.wptr[k]; p1 += a.P.wptr[k];
+    double t = 0.0;
+#pragma unroll 4
+    for (int p = p0; p < p1; ++p) t = fma(a.P.wval[p], vec[(size_t)a.P.wrow[p] * Bp + s], t);
+    a.w.part[((size_t)k * a.w.nch + cid) * Bp + s] = t;
+  }
+}
+__global__ __launch_bounds__(256) void k_ipm_wide_aty_finish(IpmArgs a) {
+  const size_t s = (size_t)blockIdx.x * 64 + (threadIdx.x & 63), Bp = a.w.Bp;
+  double t[kIpmMaxK];
+  ipm_finish<kIpmMaxK, 0>(a.w.part, a.w.nch, Bp, s, t);
+  if (threadIdx.x >= 64 || a.w.state[s] != 0) return;
+#pragma unroll
+  for (int k = 0; k < kIpmMaxK; ++k) if (k < a.P.K) a.w.wat[(size_t)k * Bp + s] = t[k];
+}
+
+__global__ __launch_bounds__(256) void k_ipm_resid(IpmArgs a) {
+  IPM_LANE();
+  const int n = a.P.n, m = a.P.m, N = n + m;
+  int j0, j1; ipm_chunk(N, a.w.nch, cid, j0, j1);
+  double comp = 0.0, cnt = 0.0;
+#pragma unroll 2
+  for (int j = j0; j < j1; ++j) {
+    const size_t at = (size_t)j * Bp + s;
+    const double l = a.w.l[at], u = a.w.u[at], v = a.w.v[at], z = a.w.z[at], f = a.w.f[at];
+    const bool hl = ipm_fin(l), hu = ipm_fin(u), fixed = hl && hu && l == u;
+    a.w.rd[at] = a.w.cb[at] - ipm_aty(a.P, a.w.y, a.w.wat, j, Bp, s) - z + f;
+    double th = 0.0;
+    if (!fixed) {
+      double den = 0.0;
+      if (hl) { const double wl = v - l; den += z / wl; comp += z * wl; cnt += 1.0; }
+      if (hu) { const double tu = u - v; den += f / tu; comp += f * tu; cnt += 1.0; }
+      th = (hl || hu) ? 1.0 / fmax(den, 1e-300) : 1e20;               // (free slack = free row: dropped by a huge Theta)
+      th = fmin(th, 1e30);
+    }
+    a.w.th[at] = th;
+  }
+  a.w.part[((size_t)0 * a.w.nch + cid) * Bp + s] = comp;
+  a.w.part[((size_t)1 * a.w.nch + cid) * Bp + s] = cnt;
+  int i0, i1; ipm_chunk(m, a.w.nch, cid, i0, i1);
+  for (int i = i0; i < i1; ++i) a.w.rp[(size_t)i * Bp + s] = -ipm_au(a.P, a.w.v, i, Bp, s);
+}
+
+__global__ __launch_bounds__(256) void k_ipm_mu(IpmArgs a) {
+  const size_t s = (size_t)blockIdx.x * 64 + (threadIdx.x & 63), Bp = a.w.Bp;
+  double t[2];
+  ipm_finish<2, 0>(a.w.part, a.w.nch, Bp, s, t);
+  if (threadIdx.x < 64 && a.w.state[s] == 0) {
+    a.w.sc[SC_MU * Bp + s] = t[0] / fmax(t[1], 1.0);
+    a.w.sc[SC_NB * Bp + s] = t[1];
+  }
+}
+
+// ---- band assembly -----------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_ipm_assemble(IpmArgs a) {
+  IPM_LANE();
+  const int W1 = a.P.W + 1, m = a.P.m, Mp = a.P.Mp;
+  int t0, t1; ipm_chunk(Mp, a.w.nch, cid, t0, t1);
+  for (int t = t0; t < t1; ++t)
+    for (int k = 0; k < W1; ++k) {
+      double val = 0.0;
+      if (t < m) {
+        const size_t e0 = ((size_t)t * W1 + k) * a.P.bw;
+        for (int p = 0; p < a.P.bw; ++p) val = fma(a.P.bval[e0 + p], a.w.th[(size_t)a.P.bcol[e0 + p] * Bp + s], val);
+        if (k == 0) { val += a.w.th[(size_t)(a.P.n + t) * Bp + s]; val *= 1.0 + 1e-12; if (!(val > 0.0)) val = 1.0; }
+      } else if (k == 0) val = 1.0;
+      a.w.band[((size_t)k * Mp + t) * Bp + s] = val;
+    }
+}
+
+// ---- the sequential kernels ----------------------------------------------------------------------------------------------------------
+// NS streams of `rows` rows each ([row][lane], `Bp` doubles between rows) are walked in order (or in reverse) by wave 0 of the workgroup,
+// R rows at a time out of LDS; all four waves move the next chunk HBM -> registers while it computes, then registers -> LDS and the
+// finished chunk's output streams LDS -> HBM.  Body::step(state, row, lr): row[q * 64] is stream q of the current row for this lane.
+template <int NS>
+struct SeqArgs {
+  double *band;                            // streams 0 .. nband-1: band + q * stride  (no pointer table: a table indexed per thread is a load
+  size_t stride;                           //  from the kernel-argument segment in front of every data load, and serialises them)
+  int nband;
+  double *x;                               // stream nband (the one vector of a solve), when NS > nband
+  int rows, reverse;
+  size_t Bp;
+  unsigned outmask;
+  const int *state;                        // groups whose 64 lanes have all finished are skipped
+  int dev_mode;                            // development (DSP_IPM_SEQ_MODE): 1 = no compute, 2 = no data movement after the first chunk
+};
+
+// wave 0 computes; the other WAVES - 1 waves move, as ONE set (every mover serves every chunk) or as TWO (the lower half serves the even
+// chunks, the upper half the odd ones).  While chunk c is computed in one LDS buffer, the set whose turn it is (1) reads chunk c - 1's
+// results out of the other buffer into registers, (2) refills that buffer with chunk c + 1, which it requested one turn earlier - the
+// ONLY vector-memory operations those waves have outstanding at that point, so the wait the compiler places there is exact (the
+// counters are per wave) -, (3) stores chunk c - 1 and (4) requests the chunk of its next turn.  One barrier per chunk.  With one
+// set a load has one chunk's compute time to arrive, with two sets two: HBM answers in ~2.7 us, a chunk of a triangular solve is
+// computed in 1.3 us (measured, m = 4034: compute alone 58 / 69 / 158 ns per row forward / backward / factor; one set 137 / 137 /
+// 161).  Two sets need 15 movers to keep a thread's share of a chunk in registers - 16 waves, 128 VGPRs per thread: enough for
+// the solves, not for the factorisation's 7 x 7 window, which keeps 8 waves and one set (its chunk takes 3 us to compute anyway).
+template <int NS, int R, class Body, int WAVES, int SETS>
+__global__ __launch_bounds__(64 * WAVES) void k_seq(SeqArgs<NS> a, Body body) {
+  extern __shared__ double lds[];          // [2][R][NS][64]
+  const int t = threadIdx.x, lane = t & 63, w4 = t >> 6;
+  const size_t g0 = (size_t)blockIdx.x * 64 + lane;
+  {
+    __shared__ int any;
+    if (t == 0) any = 0;
+    __syncthreads();
+    if (t < 64 && a.state[g0] == 0) any = 1;
+    __syncthreads();
+    if (!any) return;
+  }
+  constexpr int MOV = WAVES - 1, N0 = SETS == 1 ? MOV : MOV / 2, N1 = MOV - N0;
+  constexpr int CH = R * NS, RP = (R + N0 - 1) / N0, E = RP * NS;        // a mover serves the rows r = mi, mi + nset, ... of a chunk, all streams
+  const int nch = (a.rows + R - 1) / R;
+  const int mv = w4 - 1;                   // mover index (wave 0: -1)
+  const int sx = (SETS == 2 && mv >= N0) ? 1 : 0, nset = SETS == 1 ? MOV : (sx ? N1 : N0), mi = sx ? mv - N0 : mv;
+  auto phys = [&](int lr) { return a.reverse ? a.rows - 1 - lr : lr; };
+  auto addr = [&](int q, int lr) { return (q < a.nband ? a.band + (size_t)q * a.stride : a.x) + (size_t)phys(lr) * a.Bp + g0; };
+#define SEQ_LOAD(c)                                                                                                    \
+  _Pragma("unroll") for (int rr = 0; rr < RP; ++rr) {                                                                  \
+    const int r = min(mi + nset * rr, R - 1), lr = min((c) * R + r, a.rows - 1);                                       \
+    const size_t off = (size_t)phys(lr) * a.Bp + g0;                                                                   \
+    _Pragma("unroll") for (int q = 0; q < NS; ++q) reg[rr * NS + q] = (q < a.nband ? a.band + (size_t)q * a.stride : a.x)[off]; \
+  }
+#define SEQ_PUT(buf)                                                                                                   \
+  _Pragma("unroll") for (int rr = 0; rr < RP; ++rr) {                                                                  \
+    const int r = mi + nset * rr;            /* (no clipped duplicates here: another wave may still be reading that row's results) */ \
+    if (r < R) {                                                                                                       \
+      _Pragma("unroll") for (int q = 0; q < NS; ++q) lds[((size_t)(buf) * CH + r * NS + q) * 64 + lane] = reg[rr * NS + q]; \
+    }                                                                                                                  \
+  }
+#define SEQ_STORE(c, buf, SRC)                                                                                         \
+  _Pragma("unroll") for (int rr = 0; rr < RP; ++rr) {                                                                  \
+    const int r = mi + nset * rr, lr = (c) * R + r;                                                                    \
+    if (r < R && lr < a.rows) {                                                                                        \
+      const size_t off = (size_t)phys(lr) * a.Bp + g0;                                                                 \
+      _Pragma("unroll") for (int q = 0; q < NS; ++q)                                                                   \
+        if ((a.outmask >> q) & 1u) (q < a.nband ? a.band + (size_t)q * a.stride : a.x)[off] = SRC;                     \
+    }                                                                                                                  \
+  }
+  if (mv >= 0) {
+    double reg[E];
+    if (sx == 0) {
+      SEQ_LOAD(0)
+      SEQ_PUT(0)
+      if (SETS < nch) { SEQ_LOAD(SETS) }                          // one set: chunk 1; two sets: chunk 2 (the odd set requests chunk 1)
+    } else if (nch > 1) { SEQ_LOAD(1) }
+    __syncthreads();
+    for (int c = 0; c < nch; ++c) {
+      const int buf = c & 1;
+      if (a.dev_mode != 2 && (SETS == 1 || ((c + 1) & 1) == sx)) {
+        if (SETS == 1) {                     // one set: results through registers (the stores must not sit in front of the wait for the loads)
+          double fl[E];
+          if (c >= 1) {
+#pragma unroll
+            for (int rr = 0; rr < RP; ++rr)
+#pragma unroll
+              for (int q = 0; q < NS; ++q) fl[rr * NS + q] = lds[((size_t)(buf ^ 1) * CH + min(mi + nset * rr, R - 1) * NS + q) * 64 + lane];
+          }
+          if (c + 1 < nch) { SEQ_PUT(buf ^ 1) }
+          if (c >= 1) { SEQ_STORE(c - 1, buf ^ 1, fl[rr * NS + q]) }
+        } else {                             // two sets: a set has two chunks' time per turn - the stores may complete first (no second register array)
+          if (c >= 1) { SEQ_STORE(c - 1, buf ^ 1, (lds[((size_t)(buf ^ 1) * CH + r * NS + q) * 64 + lane])) }
+          if (c + 1 < nch) { SEQ_PUT(buf ^ 1) }
+        }
+        if (c + 1 + SETS < nch) { SEQ_LOAD(c + 1 + SETS) }
+      }
+      __syncthreads();
+    }
+    if (a.dev_mode != 2 && sx == 0) {
+      const int c = nch - 1, buf = c & 1;
+      SEQ_STORE(c, buf, (lds[((size_t)buf * CH + r * NS + q) * 64 + lane]))
+    }
+  } else {
+    __syncthreads();
+    typename Body::State st;
+    Body::init(st);
+    for (int c = 0; c < nch; ++c) {
+      if (a.dev_mode != 1) {
+        double *base = lds + (size_t)(c & 1) * CH * 64 + lane;
+        const int rmax = min(R, a.rows - c * R);
+        int r = 0;
+        for (; r + 2 <= rmax; r += 2) {
+          body.step(st, base + (size_t)r * NS * 64, c * R + r);
+          body.step(st, base + (size_t)(r + 1) * NS * 64, c * R + r + 1);
+        }
+        for (; r < rmax; ++r) body.step(st, base + (size_t)r * NS * 64, c * R + r);
+      }
+      __syncthreads();
+    }
+  }
+#undef SEQ_LOAD
+#undef SEQ_PUT
+#undef SEQ_STORE
+}
+
+// banded LDL': streams q = 0 .. W hold B(t, t - q) on the way in; on the way out row t holds column t - W of the factor:
+// stream 0 = 1 / d, stream q = L(t - W + q, t - W)
+template <int W>
+struct FactorBody {
+  struct State { double S[W + 1][W + 1]; };
+  __device__ __forceinline__ static void init(State &st) {
+#pragma unroll
+    for (int a = 0; a <= W; ++a)
+#pragma unroll
+      for (int b = 0; b <= W; ++b) st.S[a][b] = a == b ? 1.0 : 0.0;
+  }
+  __device__ __forceinline__ void step(State &st, double *row, int) const {
+#pragma unroll
+    for (int b = 0; b <= W; ++b) st.S[W][b] = row[(size_t)(W - b) * 64];
+    double d = st.S[0][0];
+    if (!(d > 1e-200)) d = 1e64;                      // a dependent row: dropped
+    const double inv = 1.0 / d;
+    double l[W + 1], c0[W + 1];                        // c0: column 0 of the window (the update below overwrites it in place)
+#pragma unroll
+    for (int a = 1; a <= W; ++a) { c0[a] = st.S[a][0]; l[a] = c0[a] * inv; }
+    row[0] = inv;
+#pragma unroll
+    for (int a = 1; a <= W; ++a) row[(size_t)a * 64] = l[a];
+#pragma unroll
+    for (int a = 1; a <= W; ++a)
+#pragma unroll
+      for (int b = 1; b <= a; ++b) st.S[a - 1][b - 1] = fma(-l[a], c0[b], st.S[a][b]);
+  }
+};
+
+// forward substitution L z = r: streams 0 .. W-1 = L(i + q + 1, i) (factor row i + W), stream W = r / z
+template <int W>
+struct ForwardBody {
+  struct State { double acc[W]; };
+  __device__ __forceinline__ static void init(State &st) {
+#pragma unroll
+    for (int k = 0; k < W; ++k) st.acc[k] = 0.0;
+  }
+  __device__ __forceinline__ void step(State &st, double *row, int) const {
+    const double x = row[(size_t)W * 64] + st.acc[0];
+    row[(size_t)W * 64] = x;
+#pragma unroll
+    for (int k = 1; k <= W; ++k) st.acc[k - 1] = fma(-row[(size_t)(k - 1) * 64], x, k < W ? st.acc[k] : 0.0);
+  }
+};
+
+// D^-1 and backward substitution L' x = z (rows in reverse): stream 0 = 1 / d, streams 1 .. W = L(i + q, i), stream W + 1 = z / x
+template <int W>
+struct BackwardBody {
+  struct State { double xw[W]; };
+  __device__ __forceinline__ static void init(State &st) {
+#pragma unroll
+    for (int k = 0; k < W; ++k) st.xw[k] = 0.0;
+  }
+  __device__ __forceinline__ void step(State &st, double *row, int) const {
+    double x = row[(size_t)(W + 1) * 64] * row[0];
+#pragma unroll
+    for (int k = 0; k < W; ++k) x = fma(-row[(size_t)(k + 1) * 64], st.xw[k], x);
+    row[(size_t)(W + 1) * 64] = x;
+#pragma unroll
+    for (int k = W - 1; k > 0; --k) st.xw[k] = st.xw[k - 1];
+    st.xw[0] = x;
+  }
+};
+
+// ---- Woodbury ------------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_ipm_wide_rhs(IpmArgs a, int k) {        // q = column `wide_col[k]` of the scaled matrix
+  IPM_LANE();
+  int i0, i1; ipm_chunk(a.P.m, a.w.nch, cid, i0, i1);
+  for (int i = i0; i < i1; ++i) a.w.q[(size_t)i * Bp + s] = 0.0;
+  for (int p = a.P.wptr[k]; p < a.P.wptr[k + 1]; ++p) {              // (the entries are sorted by row: a binary search would do; K <= 4 calls per factorisation)
+    const int i = a.P.wrow[p];
+    if (i >= i0 && i < i1) a.w.q[(size_t)i * Bp + s] = a.P.wval[p];
+  }
+}
+
+__global__ __launch_bounds__(256) void k_ipm_copy_m(IpmArgs a, const double *src, double *dst) {
+  IPM_LANE();
+  int i0, i1; ipm_chunk(a.P.m, a.w.nch, cid, i0, i1);
+  for (int i = i0; i < i1; ++i) dst[(size_t)i * Bp + s] = src[(size_t)i * Bp + s];
+}
+
+// Woodbury: S = diag(1 / theta_d) + Ad' B^-1 Ad (K <= 4) and t = Ad' q are sums over the wide columns' entries: partials per wave
+// over slices of the entries (one wave walking a year-long design column alone took 0.5 ms at T = 672), finished per scenario
+__global__ __launch_bounds__(256) void k_ipm_wood_part(IpmArgs a, int what) {       // what 0: S (K * K slots), 1: t (K slots)
+  IPM_LANE();
+  const int K = a.P.K, m = a.P.m;
+  for (int k1 = 0; k1 < K; ++k1) {
+    int p0, p1; ipm_chunk(a.P.wptr[k1 + 1] - a.P.wptr[k1], a.w.nch, cid, p0, p1);
+    p0 += a.P.wptr[k1]; p1 += a.P.wptr[k1];
+    if (what == 0) {
+      for (int k2 = 0; k2 < K; ++k2) {
+        double t = 0.0;
+#pragma unroll 4
+        for (int p = p0; p < p1; ++p) t = fma(a.P.wval[p], a.w.biad[((size_t)k2 * m + a.P.wrow[p]) * Bp + s], t);
+        a.w.part[((size_t)(k1 * K + k2) * a.w.nch + cid) * Bp + s] = t;
+      }
+    } else {
+      double t = 0.0;
+#pragma unroll 4
+      for (int p = p0; p < p1; ++p) t = fma(a.P.wval[p], a.w.q[(size_t)a.P.wrow[p] * Bp + s], t);
+      a.w.part[((size_t)k1 * a.w.nch + cid) * Bp + s] = t;
+    }
+  }
+}
+
+// S inverted; a wide column that is fixed in this scenario (theta = 0) drops out
+__global__ __launch_bounds__(256) void k_ipm_wood_s(IpmArgs a) {
+  const size_t s = (size_t)blockIdx.x * 64 + (threadIdx.x & 63), Bp = a.w.Bp;
+  const int K = a.P.K;
+  double sums[kIpmMaxK * kIpmMaxK];
+  ipm_finish<kIpmMaxK * kIpmMaxK, 0>(a.w.part, a.w.nch, Bp, s, sums);       // (slots beyond K * K: stale sums, not looked at)
+  if (threadIdx.x >= 64 || a.w.state[s] != 0) return;
+  double S[kIpmMaxK][kIpmMaxK], I[kIpmMaxK][kIpmMaxK];
+  bool dead[kIpmMaxK];
+#pragma unroll
+  for (int k1 = 0; k1 < kIpmMaxK; ++k1) {
+    dead[k1] = true;
+#pragma unroll
+    for (int k2 = 0; k2 < kIpmMaxK; ++k2) { S[k1][k2] = k1 == k2 ? 1.0 : 0.0; I[k1][k2] = k1 == k2 ? 1.0 : 0.0; }
+  }
+#pragma unroll
+  for (int k1 = 0; k1 < kIpmMaxK; ++k1) {
+    if (k1 >= K) continue;
+    const double th = a.w.th[(size_t)a.P.wide_col[k1] * Bp + s];
+    dead[k1] = !(th > 0.0);
+    if (dead[k1]) continue;
+#pragma unroll
+    for (int k2 = 0; k2 < kIpmMaxK; ++k2) {
+      if (k2 >= K) continue;
+      double t = 0.0;
+#pragma unroll
+      for (int e = 0; e < kIpmMaxK * kIpmMaxK; ++e) if (e == k1 * K + k2) t = sums[e];
+      S[k1][k2] = t + (k1 == k2 ? 1.0 / th : 0.0);
+    }
+  }
+#pragma unroll
+  for (int k1 = 0; k1 < kIpmMaxK; ++k1)
+    if (dead[k1]) {
+#pragma unroll
+      for (int k2 = 0; k2 < kIpmMaxK; ++k2) { S[k1][k2] = k1 == k2 ? 1.0 : 0.0; S[k2][k1] = k1 == k2 ? 1.0 : 0.0; }
+    }
+  // Gauss-Jordan (S is symmetric positive definite)
+#pragma unroll
+  for (int c = 0; c < kIpmMaxK; ++c) {
+    const double inv = 1.0 / S[c][c];
+#pragma unroll
+    for (int k = 0; k < kIpmMaxK; ++k) { S[c][k] *= inv; I[c][k] *= inv; }
+#pragma unroll
+    for (int r = 0; r < kIpmMaxK; ++r) {
+      if (r == c) continue;
+      const double g = S[r][c];
+#pragma unroll
+      for (int k = 0; k < kIpmMaxK; ++k) { S[r][k] = fma(-g, S[c][k], S[r][k]); I[r][k] = fma(-g, I[c][k], I[r][k]); }
+    }
+  }
+#pragma unroll
+  for (int k1 = 0; k1 < kIpmMaxK; ++k1)
+#pragma unroll
+    for (int k2 = 0; k2 < kIpmMaxK; ++k2)
+      if (k1 < K && k2 < K) a.w.sinv[((size_t)k1 * K + k2) * Bp + s] = (dead[k1] || dead[k2]) ? 0.0 : I[k1][k2];
+}
+
+// g = Sinv (Ad' q)
+__global__ __launch_bounds__(256) void k_ipm_wood_g(IpmArgs a) {
+  const size_t s = (size_t)blockIdx.x * 64 + (threadIdx.x & 63), Bp = a.w.Bp;
+  const int K = a.P.K;
+  double t[kIpmMaxK];
+  ipm_finish<kIpmMaxK, 0>(a.w.part, a.w.nch, Bp, s, t);
+  if (threadIdx.x >= 64 || a.w.state[s] != 0) return;
+#pragma unroll
+  for (int k1 = 0; k1 < kIpmMaxK; ++k1) {
+    if (k1 >= K) continue;
+    double g = 0.0;
+#pragma unroll
+    for (int k2 = 0; k2 < kIpmMaxK; ++k2) if (k2 < K) g = fma(a.w.sinv[((size_t)k1 * K + k2) * Bp + s], t[k2], g);
+    a.w.tk[(size_t)k1 * Bp + s] = g;
+  }
+}
+
+// dy (+)= q - BiAd g
+__global__ __launch_bounds__(256) void k_ipm_wood_axpy(IpmArgs a, int accumulate) {
+  IPM_LANE();
+  const int K = a.P.K, m = a.P.m;
+  double g[kIpmMaxK];
+#pragma unroll
+  for (int k = 0; k < kIpmMaxK; ++k) g[k] = k < K ? a.w.tk[(size_t)k * Bp + s] : 0.0;
+  int i0, i1; ipm_chunk(m, a.w.nch, cid, i0, i1);
+  for (int i = i0; i < i1; ++i) {
+    double x = a.w.q[(size_t)i * Bp + s];
+#pragma unroll
+    for (int k = 0; k < kIpmMaxK; ++k) if (k < K) x = fma(-g[k], a.w.biad[((size_t)k * m + i) * Bp + s], x);
+    const size_t at = (size_t)i * Bp + s;
+    a.w.dy[at] = accumulate ? a.w.dy[at] + x : x;
+  }
+}
+
+// ---- directions ----------------------------------------------------------------------------------------------------------------------
+// complementarity targets of one column: cz, cf (mode 0: predictor; 1: corrector with sigma mu and the second-order terms)
+__device__ __forceinline__ void ipm_targets(const IpmArgs &a, size_t at, size_t s, int mode, bool hl, bool hu, double wl, double tu, double z, double f,
+                                            double &cz, double &cf) {
+  const double sm = mode ? a.w.sc[SC_SIGMU * a.w.Bp + s] : 0.0;
+  cz = hl ? (sm - (mode ? a.w.corl[at] : 0.0)) / wl - z : 0.0;
+  cf = hu ? (sm - (mode ? a.w.coru[at] : 0.0)) / tu - f : 0.0;
+}
+
+// rt = rd - cz + cf ; tn = theta rt
+__global__ __launch_bounds__(256) void k_ipm_rt(IpmArgs a, int mode) {
+  IPM_LANE();
+  const int N = a.P.n + a.P.m;
+  int j0, j1; ipm_chunk(N, a.w.nch, cid, j0, j1);
+#pragma unroll 2
+  for (int j = j0; j < j1; ++j) {
+    const size_t at = (size_t)j * Bp + s;
+    const double l = a.w.l[at], u = a.w.u[at], v = a.w.v[at], th = a.w.th[at];
+    const bool hl = ipm_fin(l) && th > 0.0, hu = ipm_fin(u) && th > 0.0;
+    double cz, cf;
+    ipm_targets(a, at, s, mode, hl, hu, v - l, u - v, a.w.z[at], a.w.f[at], cz, cf);
+    const double rt = a.w.rd[at] - cz + cf;
+    a.w.rt[at] = rt;
+    a.w.tn[at] = th * rt;
+  }
+}
+
+// rhs = rp + Abar tn
+__global__ __launch_bounds__(256) void k_ipm_rhs(IpmArgs a) {
+  IPM_LANE();
+  int i0, i1; ipm_chunk(a.P.m, a.w.nch, cid, i0, i1);
+#pragma unroll 2
+  for (int i = i0; i < i1; ++i) {
+    const size_t at = (size_t)i * Bp + s;
+    const double r = a.w.rp[at] + ipm_au(a.P, a.w.tn, i, Bp, s);
+    a.w.rhs[at] = r;
+    a.w.q[at] = r;
+  }
+}
+
+// refinement: tn = theta (Abar' dy) ; q = res = rhs - Abar tn
+__global__ __launch_bounds__(256) void k_ipm_ref_cols(IpmArgs a) {
+  IPM_LANE();
+  const int N = a.P.n + a.P.m;
+  int j0, j1; ipm_chunk(N, a.w.nch, cid, j0, j1);
+#pragma unroll 2
+  for (int j = j0; j < j1; ++j) {
+    const size_t at = (size_t)j * Bp + s;
+    a.w.tn[at] = a.w.th[at] * ipm_aty(a.P, a.w.dy, a.w.wat, j, Bp, s);
+  }
+}
+__global__ __launch_bounds__(256) void k_ipm_ref_rows(IpmArgs a) {
+  IPM_LANE();
+  int i0, i1; ipm_chunk(a.P.m, a.w.nch, cid, i0, i1);
+#pragma unroll 2
+  for (int i = i0; i < i1; ++i) {
+    const size_t at = (size_t)i * Bp + s;
+    a.w.q[at] = a.w.rhs[at] - ipm_au(a.P, a.w.tn, i, Bp, s);
+  }
+}
+
+// how well the Newton system is solved: max |rhs - N dy| against max |rhs| per scenario; a scenario beyond the tolerance asks for a
+// (further) step of iterative refinement - of the whole batch: the sequential kernels cost the same for one lane as for 64
+__global__ __launch_bounds__(256) void k_ipm_resnorm(IpmArgs a) {
+  IPM_LANE();
+  int i0, i1; ipm_chunk(a.P.m, a.w.nch, cid, i0, i1);
+  double mq = 0.0, mr = 0.0;
+#pragma unroll 4
+  for (int i = i0; i < i1; ++i) { mq = fmax(mq, fabs(a.w.q[(size_t)i * Bp + s])); mr = fmax(mr, fabs(a.w.rhs[(size_t)i * Bp + s])); }
+  a.w.part[((size_t)0 * a.w.nch + cid) * Bp + s] = mq;
+  a.w.part[((size_t)1 * a.w.nch + cid) * Bp + s] = mr;
+}
+__global__ __launch_bounds__(256) void k_ipm_resflag(IpmArgs a, double tol) {
+  const size_t s = (size_t)blockIdx.x * 64 + (threadIdx.x & 63), Bp = a.w.Bp;
+  double t[2];
+  ipm_finish<2, 2>(a.w.part, a.w.nch, Bp, s, t);
+  if (threadIdx.x >= 64 || a.w.state[s] != 0) return;
+  if (!(t[0] <= tol * t[1])) atomicAdd(a.w.counts + 3, 1);
+}
+
+// dv, dz, df from dy; partial minima of the step lengths
+__global__ __launch_bounds__(256) void k_ipm_dir(IpmArgs a, int mode) {
+  IPM_LANE();
+  const int N = a.P.n + a.P.m;
+  int j0, j1; ipm_chunk(N, a.w.nch, cid, j0, j1);
+  double ap = 1e300, ad = 1e300;
+#pragma unroll 2
+  for (int j = j0; j < j1; ++j) {
+    const size_t at = (size_t)j * Bp + s;
+    const double l = a.w.l[at], u = a.w.u[at], v = a.w.v[at], th = a.w.th[at], z = a.w.z[at], f = a.w.f[at];
+    const bool hl = ipm_fin(l) && th > 0.0, hu = ipm_fin(u) && th > 0.0;
+    const double wl = v - l, tu = u - v;
+    double cz, cf;
+    ipm_targets(a, at, s, mode, hl, hu, wl, tu, z, f, cz, cf);
+    const double dv = th * (ipm_aty(a.P, a.w.dy, a.w.wat, j, Bp, s) - a.w.rt[at]);
+    const double dz = hl ? cz - z / wl * dv : 0.0;
+    const double df = hu ? cf + f / tu * dv : 0.0;
+    a.w.dv[at] = dv; a.w.dz[at] = dz; a.w.df[at] = df;
+    if (hl && dv < 0.0) ap = fmin(ap, -wl / dv);
+    if (hu && dv > 0.0) ap = fmin(ap, tu / dv);
+    if (hl && dz < 0.0) ad = fmin(ad, -z / dz);
+    if (hu && df < 0.0) ad = fmin(ad, -f / df);
+  }
+  a.w.part[((size_t)0 * a.w.nch + cid) * Bp + s] = ap;
+  a.w.part[((size_t)1 * a.w.nch + cid) * Bp + s] = ad;
+}
+
+__global__ __launch_bounds__(256) void k_ipm_steps(IpmArgs a, int mode) {
+  const size_t s = (size_t)blockIdx.x * 64 + (threadIdx.x & 63), Bp = a.w.Bp;
+  double t[2];
+  ipm_finish<2, 1>(a.w.part, a.w.nch, Bp, s, t);
+  if (threadIdx.x >= 64 || a.w.state[s] != 0) return;
+  if (mode == 0) { a.w.sc[SC_APA * Bp + s] = fmin(t[0], 1.0); a.w.sc[SC_ADA * Bp + s] = fmin(t[1], 1.0); }
+  else { a.w.sc[SC_AP * Bp + s] = fmin(1.0, 0.9995 * t[0]); a.w.sc[SC_AD * Bp + s] = fmin(1.0, 0.9995 * t[1]); }
+}
+
+// mu of the affine step; the second-order terms of the corrector
+__global__ __launch_bounds__(256) void k_ipm_muaff(IpmArgs a) {
+  IPM_LANE();
+  const int N = a.P.n + a.P.m;
+  int j0, j1; ipm_chunk(N, a.w.nch, cid, j0, j1);
+  const double apa = a.w.sc[SC_APA * Bp + s], ada = a.w.sc[SC_ADA * Bp + s];
+  double comp = 0.0;
+#pragma unroll 2
+  for (int j = j0; j < j1; ++j) {
+    const size_t at = (size_t)j * Bp + s;
+    const double l = a.w.l[at], u = a.w.u[at], v = a.w.v[at], th = a.w.th[at];
+    const bool hl = ipm_fin(l) && th > 0.0, hu = ipm_fin(u) && th > 0.0;
+    const double dv = a.w.dv[at], dz = a.w.dz[at], df = a.w.df[at];
+    if (hl) comp += (a.w.z[at] + ada * dz) * (v - l + apa * dv);
+    if (hu) comp += (a.w.f[at] + ada * df) * (u - v - apa * dv);
+    a.w.corl[at] = dv * dz;
+    a.w.coru[at] = -dv * df;
+  }
+  a.w.part[((size_t)0 * a.w.nch + cid) * Bp + s] = comp;
+}
+
+__global__ __launch_bounds__(256) void k_ipm_sigma(IpmArgs a) {
+  const size_t s = (size_t)blockIdx.x * 64 + (threadIdx.x & 63), Bp = a.w.Bp;
+  double t[1];
+  ipm_finish<1, 0>(a.w.part, a.w.nch, Bp, s, t);
+  if (threadIdx.x >= 64 || a.w.state[s] != 0) return;
+  const double mu = a.w.sc[SC_MU * Bp + s], mu_aff = t[0] / fmax(a.w.sc[SC_NB * Bp + s], 1.0);
+  const double r = mu > 0.0 ? mu_aff / mu : 1.0;
+  a.w.sc[SC_SIGMU * Bp + s] = fmin(fmax(r * r * r, 0.0), 1.0) * mu;
+}
+
+__global__ __launch_bounds__(256) void k_ipm_update(IpmArgs a) {
+  IPM_LANE();
+  const int N = a.P.n + a.P.m;
+  const double ap = a.w.sc[SC_AP * Bp + s], ad = a.w.sc[SC_AD * Bp + s];
+  int j0, j1; ipm_chunk(N, a.w.nch, cid, j0, j1);
+#pragma unroll 2
+  for (int j = j0; j < j1; ++j) {
+    const size_t at = (size_t)j * Bp + s;
+    if (!(a.w.th[at] > 0.0)) continue;
+    a.w.v[at] += ap * a.w.dv[at];
+    a.w.z[at] += ad * a.w.dz[at];
+    a.w.f[at] += ad * a.w.df[at];
+  }
+  int i0, i1; ipm_chunk(a.P.m, a.w.nch, cid, i0, i1);
+  for (int i = i0; i < i1; ++i) a.w.y[(size_t)i * Bp + s] += ad * a.w.dy[(size_t)i * Bp + s];
+}
+
+// ---- termination: the HBM-resident path's KKT test on the unscaled problem (control_decide, dsp_stream.hpp) ------------------------------
+__global__ __launch_bounds__(256) void k_ipm_check(IpmArgs a) {
+  IPM_LANE();
+  const int n = a.P.n, m = a.P.m;
+  double q[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  int i0, i1; ipm_chunk(m, a.w.nch, cid, i0, i1);
+  for (int i = i0; i < i1; ++i) {
+    const size_t ar = (size_t)(n + i) * Bp + s;
+    const double rlo = a.w.l[ar], rhi = a.w.u[ar], y = a.w.y[(size_t)i * Bp + s];
+    const double ax = ipm_au(a.P, a.w.v, i, Bp, s) + a.w.v[ar];                  // (A_s x)_i
+    const double viol = fmax(rlo - ax, 0.0) + fmax(ax - rhi, 0.0);
+    const double vu = viol / a.P.row_scale[i];
+    q[0] += vu * vu;                                                              // ||row violation||^2, unscaled
+    q[1] += fabs(y) * viol;                                                       // |y| . violation       (x cs)
+    q[2] += fmax(y, 0.0) * ipm_fin0(rlo) - fmax(-y, 0.0) * ipm_fin0(rhi);          // dual objective, rows  (x cs)
+  }
+  int j0, j1; ipm_chunk(n, a.w.nch, cid, j0, j1);
+  const double cs = a.w.sc[SC_CS * Bp + s];
+#pragma unroll 2
+  for (int j = j0; j < j1; ++j) {
+    const size_t at = (size_t)j * Bp + s;
+    const double l = a.w.l[at], u = a.w.u[at], v = a.w.v[at], cb = a.w.cb[at];
+    const double rc = cb - ipm_aty(a.P, a.w.y, a.w.wat, j, Bp, s);
+    const double lp = ipm_fin(l) ? fmax(rc, 0.0) : 0.0, lm = ipm_fin(u) ? fmax(-rc, 0.0) : 0.0;
+    const double dres = rc - lp + lm;
+    const double du = dres * cs / a.P.col_scale[j];
+    q[3] += du * du;                                                              // ||dual residual||^2, unscaled
+    q[4] += fabs(dres) * fabs(v);                                                 // (x cs)
+    q[5] += cb * v;                                                               // primal objective      (x cs)
+    q[6] += fabs(cb * v);
+    q[7] += lp * ipm_fin0(l) - lm * ipm_fin0(u);                                  // dual objective, bounds (x cs)
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) a.w.part[((size_t)k * a.w.nch + cid) * Bp + s] = q[k];
+}
+
+__global__ __launch_bounds__(256) void k_ipm_decide(IpmArgs a) {
+  const size_t s = (size_t)blockIdx.x * 64 + (threadIdx.x & 63), Bp = a.w.Bp;
+  double q[8];
+  ipm_finish<8, 0>(a.w.part, a.w.nch, Bp, s, q);
+  if (threadIdx.x >= 64 || a.w.state[s] != 0) return;
+  StreamCtrl &c = a.sw.ctrl[s];
+  const dsp_options &o = a.opt;
+  const double cs = a.w.sc[SC_CS * Bp + s];
+  const double po = cs * q[5], dobj = cs * (q[2] + q[7]);
+  const double rp = sqrt(q[0]) / (1.0 + c.qn), rd = sqrt(q[3]) / (1.0 + c.cn);
+  const double gap = fabs(po - dobj);
+  bool fin;
+  if (o.eps_obj > 0.0) {
+    const double lim = fmax(o.eps_obj * (1.0 + fabs(po + c.c0)), 1e-12 * cs * q[6]);
+    fin = rp <= o.eps_rel && rd <= o.eps_rel && gap + cs * (q[1] + q[4]) <= lim;
+  } else {
+    fin = rp <= o.eps_rel && rd <= o.eps_rel && gap / (1.0 + fabs(po) + fabs(dobj)) <= o.eps_rel;
+  }
+  const double mu = a.w.sc[SC_MU * Bp + s];
+  a.w.iters[s] = a.it;
+  c.last_rp = rp; c.last_rd = rd; c.last_rg = gap / (1.0 + fabs(po) + fabs(dobj));
+  if (fin) {
+    a.w.sc[SC_POBJ * Bp + s] = po;
+    a.w.state[s] = 1;
+    atomicAdd(a.w.counts + 0, 1); atomicAdd(a.w.counts + 1, 1);
+  } else if (!(po == po) || !(mu == mu) || !(mu > 0.0) || a.it >= a.max_it ||
+             (a.w.stall[s] = (fmin(a.w.sc[SC_AP * Bp + s], a.w.sc[SC_AD * Bp + s]) < 1e-4 ? a.w.stall[s] + 1 : 0)) >= 12) {
+    // (steps that stay below 1e-4: an LP without a solution, or a breakdown - not this method's scenario)
+    a.w.state[s] = 2;                                                             // given up: the PDHG forms take the scenario
+    atomicAdd(a.w.counts + 0, 1);
+  } else if (gap + cs * (q[1] + q[4]) <= 1e4 * fmax(o.eps_obj * (1.0 + fabs(po + c.c0)), 1e-300)) {
+    atomicAdd(a.w.counts + 2, 1);                                                 // end game: three refinement steps from here on
+  } else if (gap + cs * (q[1] + q[4]) <= 1e7 * fmax(o.eps_obj * (1.0 + fabs(po + c.c0)), 1e-300)) {
+    atomicAdd(a.w.counts + 3, 1);                                                 // one refinement step (none while the iterate is far out)
+  }
+}
+
+// lanes beyond the batch, invalid scenarios (k_init_control), scenarios with free columns (k_ipm_setup)
+__global__ void k_ipm_begin(IpmArgs a, int phase) {
+  const size_t s = (size_t)blockIdx.x * 64 + threadIdx.x;
+  if (phase == 0) {
+    int st = 0;
+    if (s >= (size_t)a.w.B) st = 2;
+    else if (a.sw.ctrl[s].done) st = 2;
+    a.w.state[s] = st;
+    a.w.iters[s] = 0;
+    a.w.stall[s] = 0;
+    if (st) atomicAdd(a.w.counts + 0, 1);
+  } else if (a.w.state[s] == 3) {
+    a.w.state[s] = 2;
+    atomicAdd(a.w.counts + 0, 1);
+  }
+}
+
+// solved scenarios: x+ / y+ of the scenario-major workspace (k_finalize unscales them)
+__global__ __launch_bounds__(256) void k_ipm_export(IpmArgs a) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const size_t Bp = a.w.Bp, s = (size_t)blockIdx.y * 64 + lane;
+  const int cid = blockIdx.x * 4 + wv;
+  if (a.w.state[s] != 1) return;
+  const int n = a.P.n, m = a.P.m;
+  const double cs = a.w.sc[SC_CS * Bp + s];
+  if (cid == 0) {
+    StreamCtrl &c = a.sw.ctrl[s];
+    c.pobj = a.w.sc[SC_POBJ * Bp + s]; c.status = DSP_STATUS_OPTIMAL; c.done = 1; c.it = a.w.iters[s];
+    atomicAdd(a.sw.ndone, 1);
+  }
+  int j0, j1; ipm_chunk(n, a.w.nch, cid, j0, j1);
+  for (int j = j0; j < j1; ++j) { const double v = a.w.v[(size_t)j * Bp + s]; a.sw.xp[s * n + j] = v; a.sw.x[s * n + j] = v; }
+  int i0, i1; ipm_chunk(m, a.w.nch, cid, i0, i1);
+  for (int i = i0; i < i1; ++i) { const double y = a.w.y[(size_t)i * Bp + s] * cs; a.sw.yp[s * m + i] = y; a.sw.y[s * m + i] = y; }
+}
+
+// ---- host --------------------------------------------------------------------------------------------------------------------------------
+template <class T>
+static hipError_t ipm_up(std::vector<void *> &allocs, const std::vector<T> &v, const T **out) {
+  void *d = nullptr;
+  hipError_t e = hipMalloc(&d, std::max<size_t>(v.size(), 1) * sizeof(T));
+  if (e != hipSuccess) return e;
+  allocs.push_back(d);
+  if (!v.empty() && (e = hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice)) != hipSuccess) return e;
+  *out = reinterpret_cast<const T *>(d);
+  return hipSuccess;
+}
+
+// The plan: wide columns by their row span, the band of the rest, the product lists of its entries.  No plan (S->ipm stays null) when
+// the matrix is not banded enough - the PDHG forms are the general path.
+hipError_t ipm_create(const HostCSR &A, const HostCSR &AT, StreamSolver *S) {
+  S->ipm = nullptr;
+  const int off = getenv("DSP_NO_IPM") ? atoi(getenv("DSP_NO_IPM")) : 0;          // (read at every create: tests build handles of every form)
+  if (off) return hipSuccess;
+  const int n = A.n, m = A.m;
+  if (m < 64) return hipSuccess;
+  std::vector<uint8_t> wide(n, 0);
+  std::vector<int32_t> wide_col;
+  for (int j = 0; j < n; ++j) {
+    if (AT.ptr[j + 1] == AT.ptr[j]) continue;
+    int lo = m, hi = -1;
+    for (int p = AT.ptr[j]; p < AT.ptr[j + 1]; ++p) { lo = std::min(lo, (int)AT.idx[p]); hi = std::max(hi, (int)AT.idx[p]); }
+    if (hi - lo > kIpmSpan) { wide[j] = 1; wide_col.push_back(j); }
+  }
+  if ((int)wide_col.size() > kIpmMaxK) return hipSuccess;
+  int W = 0;
+  for (int j = 0; j < n; ++j)
+    if (!wide[j] && AT.ptr[j + 1] > AT.ptr[j]) {
+      int lo = m, hi = -1;
+      for (int p = AT.ptr[j]; p < AT.ptr[j + 1]; ++p) { lo = std::min(lo, (int)AT.idx[p]); hi = std::max(hi, (int)AT.idx[p]); }
+      W = std::max(W, hi - lo);
+    }
+  if (W > kIpmMaxW) return hipSuccess;
+  W = W <= 6 ? 6 : 8;
+  const int W1 = W + 1;
+  // B(t, t - k) = sum over the narrow columns j of rows t and t - k: a_tj a_(t-k)j theta_j
+  std::vector<std::vector<std::pair<int32_t, double>>> prod((size_t)m * W1);
+  int bw = 1;
+  for (int t = 0; t < m; ++t)
+    for (int k = 0; k < W1; ++k) {
+      const int r2 = t - k;
+      if (r2 < 0) continue;
+      auto &pl = prod[(size_t)t * W1 + k];
+      for (int p = A.ptr[t]; p < A.ptr[t + 1]; ++p) {
+        const int j = A.idx[p];
+        if (wide[j]) continue;
+        for (int p2 = A.ptr[r2]; p2 < A.ptr[r2 + 1]; ++p2)
+          if (A.idx[p2] == j) pl.push_back({j, A.val[p] * A.val[p2]});
+      }
+      bw = std::max(bw, (int)pl.size());
+    }
+  std::vector<int32_t> bcol((size_t)m * W1 * bw, 0);
+  std::vector<double> bval((size_t)m * W1 * bw, 0.0);
+  for (size_t e = 0; e < prod.size(); ++e)
+    for (size_t q = 0; q < prod[e].size(); ++q) { bcol[e * bw + q] = prod[e][q].first; bval[e * bw + q] = prod[e][q].second; }
+  // ELL of the rows (all columns) and of the narrow columns; CSR of the wide columns
+  int rw = 1, cw = 1;
+  for (int i = 0; i < m; ++i) rw = std::max(rw, A.ptr[i + 1] - A.ptr[i]);
+  for (int j = 0; j < n; ++j) if (!wide[j]) cw = std::max(cw, AT.ptr[j + 1] - AT.ptr[j]);
+  if (rw > 16 || cw > 16 || bw > 16) return hipSuccess;              // not the sparse time-banded kind after all
+  std::vector<int32_t> rcol((size_t)m * rw, 0), crow((size_t)n * cw, 0), wptr(1, 0), wrow;
+  std::vector<double> rval((size_t)m * rw, 0.0), cval((size_t)n * cw, 0.0), wval;
+  for (int i = 0; i < m; ++i)
+    for (int p = A.ptr[i], q = 0; p < A.ptr[i + 1]; ++p, ++q) { rcol[(size_t)i * rw + q] = A.idx[p]; rval[(size_t)i * rw + q] = A.val[p]; }
+  for (int j = 0; j < n; ++j)
+    if (!wide[j])
+      for (int p = AT.ptr[j], q = 0; p < AT.ptr[j + 1]; ++p, ++q) { crow[(size_t)j * cw + q] = AT.idx[p]; cval[(size_t)j * cw + q] = AT.val[p]; }
+  for (size_t k = 0; k < wide_col.size(); ++k) {
+    const int j = wide_col[k];
+    wide[j] = (uint8_t)(k + 1);
+    for (int p = AT.ptr[j]; p < AT.ptr[j + 1]; ++p) { wrow.push_back(AT.idx[p]); wval.push_back(AT.val[p]); }
+    wptr.push_back((int32_t)wrow.size());
+  }
+  IpmState *I = new IpmState();
+  IpmPlan &P = I->P;
+  P.n = n; P.m = m; P.W = W; P.K = (int)wide_col.size(); P.Mp = m + W;
+  P.rw = rw; P.cw = cw; P.bw = bw;
+  for (int k = 0; k < kIpmMaxK; ++k) P.wide_col[k] = k < P.K ? wide_col[k] : 0;
+  P.col_scale = S->P.col_scale; P.row_scale = S->P.row_scale;
+  hipError_t e;
+  if ((e = ipm_up(I->allocs, rcol, &P.rcol)) != hipSuccess || (e = ipm_up(I->allocs, rval, &P.rval)) != hipSuccess ||
+      (e = ipm_up(I->allocs, crow, &P.crow)) != hipSuccess || (e = ipm_up(I->allocs, cval, &P.cval)) != hipSuccess ||
+      (e = ipm_up(I->allocs, wide, &P.wide)) != hipSuccess || (e = ipm_up(I->allocs, wptr, &P.wptr)) != hipSuccess ||
+      (e = ipm_up(I->allocs, wrow, &P.wrow)) != hipSuccess || (e = ipm_up(I->allocs, wval, &P.wval)) != hipSuccess ||
+      (e = ipm_up(I->allocs, bcol, &P.bcol)) != hipSuccess || (e = ipm_up(I->allocs, bval, &P.bval)) != hipSuccess) {
+    for (void *p : I->allocs) (void)hipFree(p);
+    delete I;
+    return e;
+  }
+  if ((e = hipHostMalloc((void **)&I->counts_host, 4 * sizeof(int))) != hipSuccess) { for (void *p : I->allocs) (void)hipFree(p); delete I; return e; }
+  S->ipm = I;
+  return hipSuccess;
+}
+
+void ipm_destroy(StreamSolver *S) {
+  IpmState *I = S->ipm;
+  if (!I) return;
+  for (void *p : I->allocs) (void)hipFree(p);
+  for (void *p : I->work_allocs) (void)hipFree(p);
+  if (I->counts_host) (void)hipHostFree(I->counts_host);
+  delete I;
+  S->ipm = nullptr;
+}
+
+static hipError_t ipm_workspace(IpmState *I, int B) {
+  if (B <= I->work_B) { I->w.B = B; return hipSuccess; }
+  for (void *p : I->work_allocs) (void)hipFree(p);
+  I->work_allocs.clear();
+  I->work_B = 0;
+  IpmWork &w = I->w;
+  const IpmPlan &P = I->P;
+  w.Bp = (size_t)((B + 63) / 64) * 64;
+  w.B = B;
+  const int G = (int)(w.Bp / 64);
+  int nblk = std::max(16, std::min(256, 2048 / std::max(G, 1)));
+  w.nch = 4 * nblk;
+  const size_t N = (size_t)P.n + P.m, M = P.m;
+  hipError_t e;
+  auto alloc = [&](size_t doubles, double **out) {
+    e = hipMalloc((void **)out, std::max<size_t>(doubles, 1) * sizeof(double));
+    if (e == hipSuccess) I->work_allocs.push_back(*out);
+    return e;
+  };
+  double **nv[] = {&w.v, &w.z, &w.f, &w.l, &w.u, &w.cb, &w.th, &w.rd, &w.dv, &w.dz, &w.df, &w.rt, &w.corl, &w.coru, &w.tn};
+  double **mv[] = {&w.y, &w.dy, &w.rp, &w.rhs, &w.q, &w.res};
+  for (double **p : nv) if (alloc(N * w.Bp, p) != hipSuccess) return e;
+  for (double **p : mv) if (alloc(M * w.Bp, p) != hipSuccess) return e;
+  if (alloc((size_t)std::max(P.K, 1) * M * w.Bp, &w.biad) != hipSuccess) return e;
+  if (alloc((size_t)(P.W + 1) * P.Mp * w.Bp, &w.band) != hipSuccess) return e;
+  if (alloc((size_t)SC_COUNT * w.Bp, &w.sc) != hipSuccess) return e;
+  if (alloc((size_t)kIpmNQ * w.nch * w.Bp, &w.part) != hipSuccess) return e;
+  if (alloc((size_t)kIpmMaxK * kIpmMaxK * w.Bp, &w.sinv) != hipSuccess) return e;
+  if (alloc((size_t)kIpmMaxK * w.Bp, &w.tk) != hipSuccess) return e;
+  if (alloc((size_t)kIpmMaxK * w.Bp, &w.wat) != hipSuccess) return e;
+  if ((e = hipMalloc((void **)&w.state, w.Bp * sizeof(int))) != hipSuccess) return e;
+  I->work_allocs.push_back(w.state);
+  if ((e = hipMalloc((void **)&w.iters, w.Bp * sizeof(int))) != hipSuccess) return e;
+  I->work_allocs.push_back(w.iters);
+  if ((e = hipMalloc((void **)&w.stall, w.Bp * sizeof(int))) != hipSuccess) return e;
+  I->work_allocs.push_back(w.stall);
+  if ((e = hipMalloc((void **)&w.counts, 4 * sizeof(int))) != hipSuccess) return e;
+  I->work_allocs.push_back(w.counts);
+  I->work_B = B;
+  return hipSuccess;
+}
+
+template <int W>
+static hipError_t ipm_factor(const IpmArgs &a, hipStream_t st) {
+  constexpr int NS = W + 1, R = (72 * 1024) / (NS * 512);
+  SeqArgs<NS> q{};
+  q.band = a.w.band; q.stride = (size_t)a.P.Mp * a.w.Bp; q.nband = NS; q.x = nullptr;
+  q.rows = a.P.Mp; q.reverse = 0; q.Bp = a.w.Bp; q.outmask = (1u << NS) - 1u; q.state = a.w.state; q.dev_mode = getenv("DSP_IPM_SEQ_MODE") ? atoi(getenv("DSP_IPM_SEQ_MODE")) : 0;
+  const size_t lds = (size_t)2 * R * NS * 64 * sizeof(double);
+  constexpr int WV = 8;
+  auto fn = k_seq<NS, R, FactorBody<W>, WV, 1>;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(fn, dim3((unsigned)(a.w.Bp / 64)), dim3(64 * WV), lds, st, q, FactorBody<W>{});
+  return hipGetLastError();
+}
+
+// x := B^-1 x for the [m][Bp] vector `x` (in place)
+template <int W>
+static hipError_t ipm_bsolve(const IpmArgs &a, double *x, hipStream_t st) {
+  hipError_t e;
+  {
+    constexpr int NS = W + 1, R = (72 * 1024) / (NS * 512);
+    SeqArgs<NS> q{};
+    q.band = a.w.band + ((size_t)a.P.Mp + W) * a.w.Bp; q.stride = (size_t)a.P.Mp * a.w.Bp; q.nband = W; q.x = x;     // L(i + k + 1, i): factor row i + W
+    q.rows = a.P.m; q.reverse = 0; q.Bp = a.w.Bp; q.outmask = 1u << W; q.state = a.w.state; q.dev_mode = getenv("DSP_IPM_SEQ_MODE") ? atoi(getenv("DSP_IPM_SEQ_MODE")) : 0;
+    const size_t lds = (size_t)2 * R * NS * 64 * sizeof(double);
+    static const int one_set = getenv("DSP_IPM_SEQ_SETS") ? atoi(getenv("DSP_IPM_SEQ_SETS")) == 1 : 0;      // development
+    if (one_set) {
+      auto fn = k_seq<NS, R, ForwardBody<W>, 8, 1>;
+      if ((e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return e;
+      hipLaunchKernelGGL(fn, dim3((unsigned)(a.w.Bp / 64)), dim3(64 * 8), lds, st, q, ForwardBody<W>{});
+    } else {
+      auto fn = k_seq<NS, R, ForwardBody<W>, 16, 2>;
+      if ((e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return e;
+      hipLaunchKernelGGL(fn, dim3((unsigned)(a.w.Bp / 64)), dim3(64 * 16), lds, st, q, ForwardBody<W>{});
+    }
+  }
+  {
+    constexpr int NS = W + 2, R = (72 * 1024) / (NS * 512);
+    SeqArgs<NS> q{};
+    q.band = a.w.band + (size_t)W * a.w.Bp; q.stride = (size_t)a.P.Mp * a.w.Bp; q.nband = W + 1; q.x = x;               // 1 / d_i, then L(i + k, i): factor row i + W
+    q.rows = a.P.m; q.reverse = 1; q.Bp = a.w.Bp; q.outmask = 1u << (W + 1); q.state = a.w.state; q.dev_mode = getenv("DSP_IPM_SEQ_MODE") ? atoi(getenv("DSP_IPM_SEQ_MODE")) : 0;
+    const size_t lds = (size_t)2 * R * NS * 64 * sizeof(double);
+    static const int one_set = getenv("DSP_IPM_SEQ_SETS") ? atoi(getenv("DSP_IPM_SEQ_SETS")) == 1 : 0;      // development
+    if (one_set) {
+      auto fn = k_seq<NS, R, BackwardBody<W>, 8, 1>;
+      if ((e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return e;
+      hipLaunchKernelGGL(fn, dim3((unsigned)(a.w.Bp / 64)), dim3(64 * 8), lds, st, q, BackwardBody<W>{});
+    } else {
+      auto fn = k_seq<NS, R, BackwardBody<W>, 16, 2>;
+      if ((e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return e;
+      hipLaunchKernelGGL(fn, dim3((unsigned)(a.w.Bp / 64)), dim3(64 * 16), lds, st, q, BackwardBody<W>{});
+    }
+  }
+  return hipGetLastError();
+}
+
+// dy = (A Theta A')^-1 rhs (a.w.q holds the right-hand side on entry and is overwritten); iterative refinement on the full normal
+// equations while some scenario's residual is above 1e-8 of its right-hand side (max norms) (at most 3 steps); returns the steps taken
+template <int W>
+static hipError_t ipm_nsolve(StreamSolver *S, const IpmArgs &a, hipStream_t st, int *steps) {
+  const dim3 blk(256), grid((unsigned)(a.w.nch / 4), (unsigned)(a.w.Bp / 64)), lanes((unsigned)(a.w.Bp / 64));
+  hipError_t e;
+  *steps = 0;
+  for (int r = 0; r <= 3; ++r) {
+    if (r > 0) {
+      if (a.P.K > 0) { hipLaunchKernelGGL(k_ipm_wide_aty, grid, blk, 0, st, a, (const double *)a.w.dy); hipLaunchKernelGGL(k_ipm_wide_aty_finish, lanes, blk, 0, st, a); }
+      hipLaunchKernelGGL(k_ipm_ref_cols, grid, blk, 0, st, a);
+      hipLaunchKernelGGL(k_ipm_ref_rows, grid, blk, 0, st, a);
+      if ((e = hipMemsetAsync(a.w.counts + 3, 0, sizeof(int), st)) != hipSuccess) return e;
+      hipLaunchKernelGGL(k_ipm_resnorm, grid, blk, 0, st, a);
+      hipLaunchKernelGGL(k_ipm_resflag, lanes, blk, 0, st, a, 1e-8);
+      if ((e = hipMemcpyAsync(S->ipm->counts_host + 3, a.w.counts + 3, sizeof(int), hipMemcpyDeviceToHost, st)) != hipSuccess) return e;
+      if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;
+      if (S->ipm->counts_host[3] == 0) break;
+      *steps = r;
+    }
+    if ((e = ipm_bsolve<W>(a, a.w.q, st)) != hipSuccess) return e;
+    if (a.P.K > 0) {
+      hipLaunchKernelGGL(k_ipm_wood_part, grid, blk, 0, st, a, 1);
+      hipLaunchKernelGGL(k_ipm_wood_g, lanes, blk, 0, st, a);
+    }
+    else if ((e = hipMemsetAsync(a.w.tk, 0, kIpmMaxK * a.w.Bp * sizeof(double), st)) != hipSuccess) return e;
+    hipLaunchKernelGGL(k_ipm_wood_axpy, grid, blk, 0, st, a, r > 0 ? 1 : 0);
+  }
+  return hipGetLastError();
+}
+
+static int g_ipm_debug = 0;
+// development: one lane of a scenario-minor array as raw doubles under $DSP_IPM_DUMP/
+static void ipm_dump(const char *name, const double *dev, size_t rows, size_t Bp, int lane, hipStream_t st) {
+  const char *dir = getenv("DSP_IPM_DUMP");
+  if (!dir) return;
+  (void)hipStreamSynchronize(st);
+  std::vector<double> h(rows);
+  (void)hipMemcpy2D(h.data(), 8, dev + lane, Bp * 8, 8, rows, hipMemcpyDeviceToHost);
+  char path[512];
+  snprintf(path, sizeof(path), "%s/ipm_%s.bin", dir, name);
+  FILE *f = fopen(path, "wb");
+  if (f) { fwrite(h.data(), 8, rows, f); fclose(f); }
+}
+#define IPM_DBG(what)                                                                                                   \
+  do {                                                                                                                  \
+    if (g_ipm_debug) {                                                                                                  \
+      hipError_t de = hipStreamSynchronize(st);                                                                         \
+      if (de != hipSuccess) { fprintf(stderr, "[ipm] %s: %s\n", what, hipGetErrorString(de)); return de; }             \
+      if (g_ipm_debug > 1) fprintf(stderr, "[ipm] %s ok\n", what);                                                     \
+    }                                                                                                                   \
+  } while (0)
+
+template <int W>
+static hipError_t ipm_loop(StreamSolver *S, IpmArgs &a, hipStream_t st, bool *all_solved, int *newton) {
+  IpmState *I = S->ipm;
+  const dim3 blk(256), grid((unsigned)(a.w.nch / 4), (unsigned)(a.w.Bp / 64)), lanes((unsigned)(a.w.Bp / 64));
+  static const int trace = getenv("DSP_IPM_TRACE") ? atoi(getenv("DSP_IPM_TRACE")) : 0;
+  g_ipm_debug = getenv("DSP_IPM_DEBUG") ? atoi(getenv("DSP_IPM_DEBUG")) : 0;
+  hipError_t e;
+  if ((e = hipMemsetAsync(a.w.counts, 0, 4 * sizeof(int), st)) != hipSuccess) return e;
+  hipLaunchKernelGGL(k_ipm_begin, lanes, dim3(64), 0, st, a, 0);
+  hipLaunchKernelGGL(k_ipm_cmax, grid, blk, 0, st, a);
+  hipLaunchKernelGGL(k_ipm_cmax_finish, lanes, blk, 0, st, a);
+  hipLaunchKernelGGL(k_ipm_setup, grid, blk, 0, st, a);
+  hipLaunchKernelGGL(k_ipm_begin, lanes, dim3(64), 0, st, a, 1);
+  IPM_DBG("setup");
+  int refine = 0, it = 0;
+  const int lanes_total = (int)a.w.Bp;
+  for (it = 1; it <= a.max_it; ++it) {
+    a.it = it;
+    if (a.P.K > 0) { hipLaunchKernelGGL(k_ipm_wide_aty, grid, blk, 0, st, a, (const double *)a.w.y); hipLaunchKernelGGL(k_ipm_wide_aty_finish, lanes, blk, 0, st, a); }
+    hipLaunchKernelGGL(k_ipm_resid, grid, blk, 0, st, a);
+    hipLaunchKernelGGL(k_ipm_mu, lanes, blk, 0, st, a);
+    IPM_DBG("resid");
+    hipLaunchKernelGGL(k_ipm_assemble, grid, blk, 0, st, a);
+    IPM_DBG("assemble");
+    if (it == 1 && trace) {
+      const size_t N = (size_t)a.P.n + a.P.m;
+      ipm_dump("th", a.w.th, N, a.w.Bp, trace - 1, st); ipm_dump("band_in", a.w.band, (size_t)(W + 1) * a.P.Mp, a.w.Bp, trace - 1, st);
+      ipm_dump("rp", a.w.rp, a.P.m, a.w.Bp, trace - 1, st); ipm_dump("rd", a.w.rd, N, a.w.Bp, trace - 1, st);
+      ipm_dump("v", a.w.v, N, a.w.Bp, trace - 1, st); ipm_dump("l", a.w.l, N, a.w.Bp, trace - 1, st); ipm_dump("u", a.w.u, N, a.w.Bp, trace - 1, st);
+      ipm_dump("cb", a.w.cb, N, a.w.Bp, trace - 1, st);
+    }
+    if ((e = ipm_factor<W>(a, st)) != hipSuccess) return e;
+    IPM_DBG("factor");
+    for (int k = 0; k < a.P.K; ++k) {
+      hipLaunchKernelGGL(k_ipm_wide_rhs, grid, blk, 0, st, a, k);
+      if ((e = ipm_bsolve<W>(a, a.w.q, st)) != hipSuccess) return e;
+      hipLaunchKernelGGL(k_ipm_copy_m, grid, blk, 0, st, a, (const double *)a.w.q, a.w.biad + (size_t)k * a.P.m * a.w.Bp);
+    }
+    if (a.P.K > 0) {
+      hipLaunchKernelGGL(k_ipm_wood_part, grid, blk, 0, st, a, 0);
+      hipLaunchKernelGGL(k_ipm_wood_s, lanes, blk, 0, st, a);
+    }
+    IPM_DBG("woodbury");
+    if (it == 1 && trace) {
+      ipm_dump("band_out", a.w.band, (size_t)(W + 1) * a.P.Mp, a.w.Bp, trace - 1, st);
+      ipm_dump("biad", a.w.biad, (size_t)std::max(a.P.K, 1) * a.P.m, a.w.Bp, trace - 1, st);
+      ipm_dump("sinv", a.w.sinv, (size_t)kIpmMaxK * kIpmMaxK, a.w.Bp, trace - 1, st);
+    }
+    for (int mode = 0; mode < 2; ++mode) {
+      hipLaunchKernelGGL(k_ipm_rt, grid, blk, 0, st, a, mode);
+      hipLaunchKernelGGL(k_ipm_rhs, grid, blk, 0, st, a);
+      IPM_DBG("rhs");
+      { int steps = 0; if ((e = ipm_nsolve<W>(S, a, st, &steps)) != hipSuccess) return e; refine = std::max(refine, steps); }
+      IPM_DBG("nsolve");
+      if (it == 1 && trace && mode == 0) {
+        ipm_dump("rhs", a.w.rhs, a.P.m, a.w.Bp, trace - 1, st); ipm_dump("dy", a.w.dy, a.P.m, a.w.Bp, trace - 1, st);
+        ipm_dump("rt", a.w.rt, (size_t)a.P.n + a.P.m, a.w.Bp, trace - 1, st);
+      }
+      if (trace && g_ipm_debug) {                       // development: relative residual of the Newton system for the traced lane
+        if (a.P.K > 0) { hipLaunchKernelGGL(k_ipm_wide_aty, grid, blk, 0, st, a, (const double *)a.w.dy); hipLaunchKernelGGL(k_ipm_wide_aty_finish, lanes, blk, 0, st, a); }
+        hipLaunchKernelGGL(k_ipm_ref_cols, grid, blk, 0, st, a);
+        hipLaunchKernelGGL(k_ipm_ref_rows, grid, blk, 0, st, a);
+        std::vector<double> hq(a.P.m), hr(a.P.m), hd(a.P.m);
+        (void)hipStreamSynchronize(st);
+        (void)hipMemcpy2D(hq.data(), 8, a.w.q + (trace - 1), a.w.Bp * 8, 8, a.P.m, hipMemcpyDeviceToHost);
+        (void)hipMemcpy2D(hr.data(), 8, a.w.rhs + (trace - 1), a.w.Bp * 8, 8, a.P.m, hipMemcpyDeviceToHost);
+        (void)hipMemcpy2D(hd.data(), 8, a.w.dy + (trace - 1), a.w.Bp * 8, 8, a.P.m, hipMemcpyDeviceToHost);
+        double nq = 0, nr = 0, nd = 0;
+        for (int i = 0; i < a.P.m; ++i) { nq += hq[i] * hq[i]; nr += hr[i] * hr[i]; nd += hd[i] * hd[i]; }
+        fprintf(stderr, "[ipm]   mode %d: |rhs| %.3e |dy| %.3e |rhs - N dy| / |rhs| %.3e\n", mode, sqrt(nr), sqrt(nd), sqrt(nq) / fmax(sqrt(nr), 1e-300));
+      }
+      if (a.P.K > 0) { hipLaunchKernelGGL(k_ipm_wide_aty, grid, blk, 0, st, a, (const double *)a.w.dy); hipLaunchKernelGGL(k_ipm_wide_aty_finish, lanes, blk, 0, st, a); }
+      hipLaunchKernelGGL(k_ipm_dir, grid, blk, 0, st, a, mode);
+      hipLaunchKernelGGL(k_ipm_steps, lanes, blk, 0, st, a, mode);
+      if (mode == 0) {
+        hipLaunchKernelGGL(k_ipm_muaff, grid, blk, 0, st, a);
+        hipLaunchKernelGGL(k_ipm_sigma, lanes, blk, 0, st, a);
+      }
+    }
+    IPM_DBG("direction");
+    hipLaunchKernelGGL(k_ipm_update, grid, blk, 0, st, a);
+    IPM_DBG("update");
+    if ((e = hipMemsetAsync(a.w.counts + 2, 0, 2 * sizeof(int), st)) != hipSuccess) return e;
+    if (a.P.K > 0) { hipLaunchKernelGGL(k_ipm_wide_aty, grid, blk, 0, st, a, (const double *)a.w.y); hipLaunchKernelGGL(k_ipm_wide_aty_finish, lanes, blk, 0, st, a); }
+    hipLaunchKernelGGL(k_ipm_check, grid, blk, 0, st, a);
+    IPM_DBG("check");
+    hipLaunchKernelGGL(k_ipm_decide, lanes, blk, 0, st, a);
+    IPM_DBG("decide");
+    if ((e = hipMemcpyAsync(I->counts_host, a.w.counts, 4 * sizeof(int), hipMemcpyDeviceToHost, st)) != hipSuccess) return e;
+    if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;
+    if (trace) {
+      double sc[SC_COUNT];
+      for (int q = 0; q < SC_COUNT; ++q) (void)hipMemcpy(&sc[q], a.w.sc + (size_t)q * a.w.Bp + (trace - 1), sizeof(double), hipMemcpyDeviceToHost);
+      StreamCtrl c0{};
+      (void)hipMemcpy(&c0, a.sw.ctrl + (trace - 1), sizeof(StreamCtrl), hipMemcpyDeviceToHost);
+      fprintf(stderr, "[ipm] it %d lane %d: mu %.3e sigma*mu %.3e ap %.3f ad %.3f rp %.2e rd %.2e rg %.2e | finished %d solved %d endgame %d refine %d\n", it, trace - 1,
+              sc[SC_MU], sc[SC_SIGMU], sc[SC_AP], sc[SC_AD], c0.last_rp, c0.last_rd, c0.last_rg, I->counts_host[0], I->counts_host[1], I->counts_host[2], refine);
+    }
+    if (I->counts_host[0] >= lanes_total) break;
+    refine = 0;
+  }
+  *newton = std::min(it, a.max_it);
+  IPM_DBG("loop");
+  if (trace) {
+    std::vector<int> hs(a.w.Bp), hi(a.w.Bp);
+    (void)hipMemcpy(hs.data(), a.w.state, a.w.Bp * sizeof(int), hipMemcpyDeviceToHost);
+    (void)hipMemcpy(hi.data(), a.w.iters, a.w.Bp * sizeof(int), hipMemcpyDeviceToHost);
+    fprintf(stderr, "[ipm] lanes (state:newton iterations):");
+    for (int q = 0; q < a.w.B; ++q) fprintf(stderr, " %d:%d", hs[q], hi[q]);
+    fprintf(stderr, "\n");
+  }
+  // all or nothing: a batch with a scenario this method did not finish runs the PDHG forms as a whole, from their own start (they
+  // carry the certificates; nothing of this file's state reaches them)
+  *all_solved = I->counts_host[1] >= a.w.B;
+  if (*all_solved) hipLaunchKernelGGL(k_ipm_export, grid, blk, 0, st, a);
+  IPM_DBG("export");
+  return hipGetLastError();
+}
+
+hipError_t ipm_run(StreamSolver *S, StreamArgs &sa, hipStream_t st, bool *all_solved, int *newton) {
+  *all_solved = false; *newton = 0;
+  IpmState *I = S->ipm;
+  if (!I) return hipSuccess;
+  hipError_t e = ipm_workspace(I, sa.b.B);
+  if (e != hipSuccess) { (void)hipGetLastError(); return hipSuccess; }      // no memory for this form: the PDHG forms run
+  IpmArgs a{};
+  a.P = I->P; a.w = I->w; a.sw = sa.W; a.opt = sa.opt; a.it = 0;
+  a.max_it = getenv("DSP_IPM_MAXIT") ? std::max(1, std::min(atoi(getenv("DSP_IPM_MAXIT")), kIpmMaxNewton)) : kIpmMaxNewton;
+  return I->P.W == 6 ? ipm_loop<6>(S, a, st, all_solved, newton) : ipm_loop<8>(S, a, st, all_solved, newton);
+}
+
+}  // namespace dsp

@@ -1551,12 +1551,15 @@ hipError_t stream_create(const HostCSR &A_scaled, const HostCSR &AT_scaled, cons
       S->P.F.own_max = H.own_max; S->P.F.halo_max = H.halo_max;
     }
   }
+  // interior-point form (round 5): time-banded matrices with at most 4 wide columns
+  if ((e = ipm_create(A_scaled, AT_scaled, S)) != hipSuccess) return e;
   // lane-per-scenario form (round 4): banded matrices with at most 8 long columns
   return lane_create(A_scaled, AT_scaled, S);
 }
 
 void stream_destroy(StreamSolver *S) {
   lane_destroy(S);
+  ipm_destroy(S);
   for (void *p : S->allocs) (void)hipFree(p);
   for (void *p : S->work_allocs) (void)hipFree(p);
   S->allocs.clear(); S->work_allocs.clear();
@@ -1792,6 +1795,19 @@ static hipError_t stream_solve_locked(StreamSolver *S, const dsp_batch &batch, c
   hipLaunchKernelGGL(k_init_control, dim3(B), dim3(64), 0, st, a);
   // k_init wrote its partials with stride nblk; the check kernels use nblk_tot: clear again before the first check
   if ((e = hipMemsetAsync(a.W.partial, 0, (size_t)B * a.nblk_tot * kNQ * sizeof(double), st)) != hipSuccess) return e;
+  // time-banded LPs: interior point with exact banded solves first (dsp_ipm.hip); what it does not finish continues below as before
+  S->last_newton = 0;
+  if (S->ipm && !opt.no_interior_point && !batch.row_compliance) {
+    bool all = false;
+    if ((e = ipm_run(S, a, st, &all, &S->last_newton)) != hipSuccess) return e;
+    if (all) {
+      S->last_form = DSP_STREAM_FORM_IPM;
+      S->last_bytes_per_iteration = 0;
+      hipLaunchKernelGGL(k_finalize, dim3(a.nblk, B), dim3(kTB), 0, st, a);
+      *periods_run = -1;
+      return hipGetLastError();
+    }
+  }
   // mid-size LPs: the whole solve in ONE launch, one workgroup per scenario with its state in LDS
   {
     const size_t lds = ((size_t)7 * S->P.n + 7 * S->P.m + (1024 / 64) * kNQ + kNQ) * sizeof(double);

@@ -147,6 +147,7 @@ struct StreamArgs {
 };
 
 struct LaneState;                      // lane-per-scenario form (dsp_stream_lane.hip); nullptr = not applicable to this matrix
+struct IpmState;                       // interior-point form for time-banded LPs (dsp_ipm.hip); nullptr = not applicable
 
 struct StreamSolver {
   StreamProblem P{};
@@ -155,6 +156,8 @@ struct StreamSolver {
   std::vector<void *> allocs, work_allocs;
   int *ndone_host = nullptr;
   LaneState *lane = nullptr;
+  IpmState *ipm = nullptr;
+  int last_newton = 0;                   // interior-point form: Newton iterations of the last solve
   int last_form = 0;                     // DSP_STREAM_FORM_* of the last solve
   int last_phases = 0;                   // lane form: phases of the last solve (dsp_stats::stream_phases)
   size_t last_bytes_per_iteration = 0;   // algorithmic HBM bytes per scenario and plain iteration of the form the last solve ran
@@ -173,6 +176,10 @@ size_t stream_bytes_per_iteration(const StreamSolver *S);
 hipError_t lane_create(const HostCSR &A_scaled, const HostCSR &AT_scaled, StreamSolver *S);
 void lane_destroy(StreamSolver *S);
 hipError_t lane_run(StreamSolver *S, StreamArgs &a, hipStream_t st, int *periods_run, bool *used);
+// dsp_ipm.hip: scenarios it solves get ctrl.done = 1 / status 0 and their x+ / y+ in the scenario-major workspace; the others are untouched
+hipError_t ipm_create(const HostCSR &A_scaled, const HostCSR &AT_scaled, StreamSolver *S);
+void ipm_destroy(StreamSolver *S);
+hipError_t ipm_run(StreamSolver *S, StreamArgs &a, hipStream_t st, bool *all_solved, int *newton);
 // certificate sequence on the scenario-major workspace (x, y = the current iterate): dsp_stream.hip
 hipError_t stream_certify(StreamSolver *S, StreamArgs &a, hipStream_t st);
 

@@ -169,7 +169,13 @@ typedef struct dsp_options {
                                 ~/.cache/dsp_hip, keyed by shape and a hash of the kernel sources).  Needs libhiprtc.so and
                                 the kernel sources ($DSP_KERNEL_SRC or csrc/ next to the library) at run time; without them
                                 the padded / LDS-matrix ahead-of-time kernels are used (dsp_rtc_message says why)  default 0 */
-  int32_t reserved1;
+  int32_t no_interior_point; /* 1 = never use the interior-point form of the HBM-resident path.  LPs of that path whose normal matrix is
+                                TIME-BANDED (half-bandwidth <= 8 in the given row order once at most 4 wide columns - design variables,
+                                periodic conditions - are set aside: the year-long price-taker LPs) are solved by a primal-dual
+                                interior-point method with exact banded factorisations, one lane per scenario (csrc/dsp_ipm.hip): ~100
+                                Newton iterations instead of ~75 k first-order iterations.  Scenarios it does not finish (free columns,
+                                numerical breakdown, 250 iterations) and batches with soft rows run the PDHG forms as before; statuses
+                                2 / 3 come from those.  `iters` counts Newton iterations for scenarios it solved       default 0 */
   double  eps_infeasible;    /* > 0: infeasibility / unboundedness certificates (DSP_STATUS_PRIMAL_INFEASIBLE / DUAL_INFEASIBLE, ABI 9).  On
                                 an LP without a solution the PDHG operator has no fixed point, T(z) - z tends to a ray, one of the
                                 objectives runs away and the relative gap |c.x - dual objective| / (1 + |c.x| + |dual objective|) tends
@@ -261,6 +267,7 @@ typedef struct dsp_stats {
 #define DSP_STREAM_FORM_TILE       2   /* round 3: one launch per iteration, a workgroup per tile of rows x 2 scenarios (k_fused_pre / k_fused) */
 #define DSP_STREAM_FORM_LANE       3   /* round 4: scenario-minor storage, a lane per scenario walks a tile (k_lane; batches of 32 scenarios and more) */
 #define DSP_STREAM_FORM_BLOCK      4   /* mid-size LPs: the whole solve in one launch, one workgroup per scenario, state in LDS (k_block_solve) */
+#define DSP_STREAM_FORM_IPM        5   /* round 5: interior point with banded LDL' factorisations, one lane per scenario (csrc/dsp_ipm.hip) */
 
 void dsp_default_options(dsp_options *opt);
 

@@ -1,0 +1,127 @@
+"""GPU tests of the interior-point form of the HBM-resident path (csrc/dsp_ipm.hip, round 5): time-banded LPs - the reference's
+year-long price-taker design problems (wind_battery_LMP.py:172-269; the sweeps of run_pricetaker_wind_PEM.py:106-107) - solved by a
+primal-dual interior-point method with exact banded LDL' factorisations, one lane per scenario, instead of ~75 k PDHG iterations.
+Same oracle fixture, same 1e-6 objective contract and the same termination test as the PDHG forms (tests/test_hip_stream.py pins
+those with the interior-point form switched off)."""
+import os
+
+import numpy as np
+import pytest
+
+gpu = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+FORM_IPM = 5                     # DSP_STREAM_FORM_IPM (include/dsp_hip.h)
+
+
+def _need_gpu():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("GPU test selected but no GPU visible")
+
+
+@gpu
+def test_one_week_family_by_interior_point_matches_oracle_and_the_pdhg_forms(monkeypatch):
+    """T = 168 (n = 1011, m = 1010): all 16 members against the oracle fixture and against the PDHG forms on the same model; Newton
+    iterations in the dozens; `no_interior_point` and DSP_NO_IPM switch the form off."""
+    _need_gpu()
+    from dispatches_amd import scenarios
+    from dispatches_amd.hip_solver import HipPdlpSolver
+    fx = np.load(os.path.join(GOLD, "oracle_price_taker.npz"))
+    T, B = 168, 16
+    solver = HipPdlpSolver(device=0, check_every=64, max_iter=1_000_000)
+    handles, model = scenarios.price_taker_batch(T, B, solver, throughput="chain")
+    solver.solve(model)
+    st = solver.last_stats
+    assert st.streaming == 1 and st.stream_form == FORM_IPM and (model.status == 0).all(), (st.stream_form, model.status)
+    assert model.iterations.max() <= 100, model.iterations                       # Newton iterations
+    ref = fx[f"T{T}/obj"][:B]
+    err = np.abs(model.objective - ref) / np.maximum(1.0, np.abs(ref))
+    assert err.max() < 1e-6, err
+    lb, ub, rlo, rhi = model.scenario_bounds()
+    x = model.x
+    scale = np.maximum(1.0, np.abs(x).max())
+    assert np.isfinite(x).all() and (x >= lb - 1e-9 * scale).all() and (x <= ub + 1e-9 * scale).all()
+    ax = (model.lp.csr() @ x.T).T
+    row_scale = np.maximum(1.0, np.abs(ax).max())
+    assert (ax >= rlo - 1e-7 * row_scale).all() and (ax <= rhi + 1e-7 * row_scale).all()
+    obj_ipm = model.objective.copy()
+    # the option switches the form off; the PDHG forms agree with it
+    solver2 = HipPdlpSolver(device=0, check_every=64, max_iter=1_000_000, no_interior_point=1)
+    handles2, model2 = scenarios.price_taker_batch(T, B, solver2, throughput="chain")
+    solver2.solve(model2)
+    assert solver2.last_stats.stream_form != FORM_IPM and (model2.status == 0).all()
+    assert np.abs(obj_ipm - model2.objective).max() <= 2e-6 * np.maximum(1.0, np.abs(model2.objective)).max()
+    assert model2.iterations.max() > 1000                                          # PDHG iterations
+    monkeypatch.setenv("DSP_NO_IPM", "1")
+    solver3 = HipPdlpSolver(device=0, check_every=64, max_iter=1_000_000)
+    handles3, model3 = scenarios.price_taker_batch(T, B, solver3, throughput="chain")
+    solver3.solve(model3)
+    assert solver3.last_stats.stream_form != FORM_IPM and (model3.status == 0).all()
+
+
+@gpu
+@pytest.mark.parametrize("B", [16, 80])
+def test_year_long_price_taker_lps_by_interior_point(B):
+    """The reference's own horizon (8736 hourly periods, n = 52 419, m = 52 418): the 16-member fixture (B = 80: five times over, two
+    groups of lanes, the second one ragged) to 1e-6 in at most 250 Newton iterations per member - the PDHG forms need 75 k iterations
+    on average for the same LPs in their two_level form (404 k in this chain form)."""
+    _need_gpu()
+    from dispatches_amd import scenarios
+    from dispatches_amd.hip_solver import HipPdlpSolver
+    fx = np.load(os.path.join(GOLD, "oracle_price_taker.npz"))
+    T = 8736
+    solver = HipPdlpSolver(device=0, check_every=64, max_iter=2_000_000)
+    handles, model = scenarios.price_taker_batch(T, B, solver, throughput="chain")
+    solver.solve(model, tee=True)
+    st = solver.last_stats
+    assert st.streaming == 1 and st.stream_form == FORM_IPM and (model.status == 0).all(), (st.stream_form, np.bincount(model.status), model.iterations)
+    assert model.iterations.max() <= 250, model.iterations
+    member = np.arange(B) % len(scenarios.PRICE_TAKER_FAMILY)
+    ref = fx["T8736/obj"][member]
+    err = np.abs(model.objective - ref) / np.maximum(1.0, np.abs(ref))
+    assert err.max() < 1e-6, (err, model.iterations)
+    batt = model.x[:, handles["battery_system_capacity"].index] * 1e-3
+    np.testing.assert_allclose(batt, fx["T8736/batt_mw"][member], rtol=2e-3, atol=1.0)
+    # repeated members of the family: the same lanes' arithmetic, the same numbers
+    if B > 16:
+        np.testing.assert_array_equal(model.objective[:16], model.objective[16:32])
+
+
+@gpu
+def test_nuclear_price_taker_enumeration_by_interior_point():
+    """LP #6 (nuclear + PEM + tank + turbine, design fixed per member: no wide column at all, half-bandwidth 8) at four weeks: the
+    members against the PDHG forms' objectives."""
+    _need_gpu()
+    from dispatches_amd import scenarios
+    from dispatches_amd.hip_solver import HipPdlpSolver
+    T, B = 672, 12
+    out = []
+    for off in (0, 1):
+        solver = HipPdlpSolver(device=0, check_every=64, max_iter=1_000_000, no_interior_point=off)
+        handles, model = scenarios.nuclear_price_taker_batch(T, B, solver)
+        solver.solve(model)
+        assert (model.status == 0).all(), (off, model.status, model.iterations)
+        assert (solver.last_stats.stream_form == FORM_IPM) == (off == 0), (off, solver.last_stats.stream_form)
+        out.append(model.objective.copy())
+    assert np.abs(out[0] - out[1]).max() <= 2e-6 * np.maximum(1.0, np.abs(out[1])).max(), out
+
+
+@gpu
+def test_a_batch_with_an_infeasible_member_goes_to_the_pdhg_forms():
+    """The interior-point form solves or gives up; it does not certify.  A member with an impossible power balance makes it give up
+    (steps that stay below 1e-4), the batch then runs the PDHG forms as a whole: status 2 with its certificate for that member, the
+    others optimal."""
+    _need_gpu()
+    from dispatches_amd import scenarios
+    from dispatches_amd.hip_solver import HipPdlpSolver
+    T, B = 168, 6
+    solver = HipPdlpSolver(device=0, check_every=64, max_iter=400_000)
+    handles, model = scenarios.price_taker_batch(T, B, solver, throughput="chain")
+    lb, ub, rlo, rhi = model.scenario_bounds()
+    model.rlo, model.rhi = np.tile(rlo, (B, 1)), np.tile(rhi, (B, 1))
+    row = next(i for i, nm in enumerate(model.lp.row_names) if nm.startswith("splitter.sum_split[5]"))
+    model.rlo[3, row] = model.rhi[3, row] = 1e9                                    # wind = grid + battery + 1e9 kW: impossible
+    solver.solve(model)
+    st = solver.last_stats
+    assert st.stream_form != FORM_IPM
+    assert model.status[3] == 2 and (np.delete(model.status, 3) == 0).all(), model.status
