@@ -360,6 +360,7 @@ def bench_price_taker(args, rank, local_rank, world, dev):
             line["config"]["newton_iterations_per_scenario"] = line["config"].pop("iterations_per_scenario")
             line["config"]["max_newton_iterations"] = line["config"].pop("max_iterations")
             line["config"]["ms_per_newton_iteration_of_the_batch"] = 1e3 * k_s / max(1, int(model.iterations.max()))
+            line["config"]["time_partitions"] = line["config"].pop("stream_phases")      # of the banded factorisations / solves (1: sequential walks)
             line["config"].pop("us_per_batch_iteration", None)
             line["roofline"] = {"bound": "latency", "kernel": STREAM_KERNELS[5], "achieved": None, "peak": None, "unit": None, "frac": None, "traffic": None,
                                 "sequential_steps_per_newton_iteration": "m per pass; passes: 1 factorisation + 2 per substitution pair x (K wide columns + predictor + corrector + refinement steps)",
@@ -771,7 +772,7 @@ def baseline_configs(args, local_rank, dev, budget_s=360.0, depth=8):
                                          "bids_identical_to_numpy_path", "numpy_path_call_ms")))
     leg("price_taker_solve", lambda: _condense("price_taker_solve", bench_price_taker(sub(workload="price_taker", batch=256, steps=1, warmup=1, solve=True, horizon=8736,
                                                                                            throughput=None, cpu_sample=0, pdhg=False), 0, local_rank, 1, dev),
-                                               ("stream_form", "solved_to_optimality", "newton_iterations_per_scenario", "max_newton_iterations", "seconds_per_batch",
+                                               ("stream_form", "time_partitions", "solved_to_optimality", "newton_iterations_per_scenario", "max_newton_iterations", "seconds_per_batch",
                                                 "ms_per_newton_iteration_of_the_batch", "max_rel_objective_error_vs_oracle_fixture", "throughput_form")))
     leg("streaming", lambda: _condense("streaming", bench_price_taker(sub(workload="price_taker", batch=256, steps=50, warmup=1, solve=False, horizon=8736,
                                                                            throughput=None, cpu_sample=0), 0, local_rank, 1, dev),

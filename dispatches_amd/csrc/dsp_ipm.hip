@@ -32,6 +32,7 @@
 #include <map>
 #include <vector>
 
+#include "dsp_ipm_seq.hpp"
 #include "dsp_stream.hpp"
 
 namespace dsp {
@@ -51,6 +52,7 @@ struct IpmPlan {                            // shared by all scenarios (device)
   const int32_t *wptr, *wrow; const double *wval;      // the wide columns' entries: CSR over k
   const int32_t *bcol; const double *bval;  // [m][W + 1][bw]: B(t, t - k) = sum bval * theta[bcol] (narrow columns)
   const double *col_scale, *row_scale;
+  IpmParts parts;                           // the time-parallel form's geometry (P = 1: sequential walks; dsp_ipm_seq.hpp)
 };
 
 // per-lane scalars
@@ -63,6 +65,10 @@ struct IpmWork {
   double *y, *dy, *rp, *rhs, *q, *res;      // [m][Bp]
   double *biad;                             // [K][m][Bp]
   double *band;                             // [W + 1][Mp][Bp]
+  double *gs;                               // [W][Mp][Bp]  spikes (time-parallel form)
+  double *sfin, *cfin;                      // [P][W (W + 1) / 2][Bp]  final windows / Schur updates of the partitions
+  double *redf;                             // [P][W W + W (W + 1) / 2][Bp]  the reduced system's block factor
+  double *bd;                               // [P][W][Bp]  border sums of a solve
   double *sc;                               // [SC_COUNT][Bp]
   double *part;                             // [kIpmNQ][nch][Bp]
   double *sinv, *tk;                        // [K * K][Bp], [K][Bp]
@@ -257,6 +263,8 @@ __global__ __launch_bounds__(256) void k_ipm_mu(IpmArgs a) {
 __global__ __launch_bounds__(256) void k_ipm_assemble(IpmArgs a) {
   IPM_LANE();
   const int W1 = a.P.W + 1, m = a.P.m, Mp = a.P.Mp;
+  const IpmParts g = a.P.parts;
+  const bool par = g.P > 1;
   int t0, t1; ipm_chunk(Mp, a.w.nch, cid, t0, t1);
   for (int t = t0; t < t1; ++t)
     for (int k = 0; k < W1; ++k) {
@@ -265,8 +273,19 @@ __global__ __launch_bounds__(256) void k_ipm_assemble(IpmArgs a) {
         const size_t e0 = ((size_t)t * W1 + k) * a.P.bw;
         for (int p = 0; p < a.P.bw; ++p) val = fma(a.P.bval[e0 + p], a.w.th[(size_t)a.P.bcol[e0 + p] * Bp + s], val);
         if (k == 0) { val += a.w.th[(size_t)(a.P.n + t) * Bp + s]; val *= 1.0 + 1e-12; if (!(val > 0.0)) val = 1.0; }
+        else if (par && ipm_diverted(g, t, k)) {      // the column lies before this row's partition: a spike's entry (dsp_ipm_seq.hpp)
+          const int j = t - k - (g.start(g.part_of(t)) - g.W);
+          a.w.gs[((size_t)j * Mp + t) * Bp + s] = val;
+          val = 0.0;
+        }
       } else if (k == 0) val = 1.0;
       a.w.band[((size_t)k * Mp + t) * Bp + s] = val;
+    }
+  if (par)                                             // the spikes a head row has no band entry for
+    for (int t = t0; t < min(t1, m); ++t) {
+      const int p = g.part_of(t), i = t - g.start(p);
+      if (p < 1 || i >= g.W) continue;
+      for (int j = 0; j < i; ++j) a.w.gs[((size_t)j * Mp + t) * Bp + s] = 0.0;
     }
 }
 
@@ -279,8 +298,11 @@ struct SeqArgs {
   double *band;                            // streams 0 .. nband-1: band + q * stride  (no pointer table: a table indexed per thread is a load
   size_t stride;                           //  from the kernel-argument segment in front of every data load, and serialises them)
   int nband;
-  double *x;                               // stream nband (the one vector of a solve), when NS > nband
-  int rows, reverse;
+  double *x;                               // streams nband .. NS-1: x + (q - nband) * xstride (the one vector of a solve; the spikes)
+  size_t xstride;
+  int rows, last_rows;                     // rows of a partition's walk: every partition but the last / the last one
+  int nparts, part0;                       // partitions of the walk (1: the sequential form); this workgroup's = blockIdx.y + part0,
+  int reverse;                             //  its first row = partition * rows
   size_t Bp;
   unsigned outmask;
   const int *state;                        // groups whose 64 lanes have all finished are skipped
@@ -296,6 +318,7 @@ struct SeqArgs {
 // computed in 1.3 us (measured, m = 4034: compute alone 58 / 69 / 158 ns per row forward / backward / factor; one set 137 / 137 /
 // 161).  Two sets need 15 movers to keep a thread's share of a chunk in registers - 16 waves, 128 VGPRs per thread: enough for
 // the solves, not for the factorisation's 7 x 7 window, which keeps 8 waves and one set (its chunk takes 3 us to compute anyway).
+// Time-parallel form: grid.y = the partitions of the walk, each a walk of its own over its rows (fresh Body state, Body::finish at its end).
 template <int NS, int R, class Body, int WAVES, int SETS>
 __global__ __launch_bounds__(64 * WAVES) void k_seq(SeqArgs<NS> a, Body body) {
   extern __shared__ double lds[];          // [2][R][NS][64]
@@ -309,18 +332,21 @@ __global__ __launch_bounds__(64 * WAVES) void k_seq(SeqArgs<NS> a, Body body) {
     __syncthreads();
     if (!any) return;
   }
+  const int part = (int)blockIdx.y + a.part0;
+  const int rows = part == a.nparts - 1 ? a.last_rows : a.rows;
+  const size_t row0 = (size_t)part * a.rows;
   constexpr int MOV = WAVES - 1, N0 = SETS == 1 ? MOV : MOV / 2, N1 = MOV - N0;
   constexpr int CH = R * NS, RP = (R + N0 - 1) / N0, E = RP * NS;        // a mover serves the rows r = mi, mi + nset, ... of a chunk, all streams
-  const int nch = (a.rows + R - 1) / R;
+  const int nch = (rows + R - 1) / R;
   const int mv = w4 - 1;                   // mover index (wave 0: -1)
   const int sx = (SETS == 2 && mv >= N0) ? 1 : 0, nset = SETS == 1 ? MOV : (sx ? N1 : N0), mi = sx ? mv - N0 : mv;
-  auto phys = [&](int lr) { return a.reverse ? a.rows - 1 - lr : lr; };
-  auto addr = [&](int q, int lr) { return (q < a.nband ? a.band + (size_t)q * a.stride : a.x) + (size_t)phys(lr) * a.Bp + g0; };
+  auto phys = [&](int lr) { return row0 + (size_t)(a.reverse ? rows - 1 - lr : lr); };
+#define SEQ_PTR(q) ((q) < a.nband ? a.band + (size_t)(q) * a.stride : a.x + (size_t)((q) - a.nband) * a.xstride)
 #define SEQ_LOAD(c)                                                                                                    \
   _Pragma("unroll") for (int rr = 0; rr < RP; ++rr) {                                                                  \
-    const int r = min(mi + nset * rr, R - 1), lr = min((c) * R + r, a.rows - 1);                                       \
-    const size_t off = (size_t)phys(lr) * a.Bp + g0;                                                                   \
-    _Pragma("unroll") for (int q = 0; q < NS; ++q) reg[rr * NS + q] = (q < a.nband ? a.band + (size_t)q * a.stride : a.x)[off]; \
+    const int r = min(mi + nset * rr, R - 1), lr = min((c) * R + r, rows - 1);                                         \
+    const size_t off = phys(lr) * a.Bp + g0;                                                                           \
+    _Pragma("unroll") for (int q = 0; q < NS; ++q) reg[rr * NS + q] = SEQ_PTR(q)[off];                                 \
   }
 #define SEQ_PUT(buf)                                                                                                   \
   _Pragma("unroll") for (int rr = 0; rr < RP; ++rr) {                                                                  \
@@ -332,10 +358,10 @@ __global__ __launch_bounds__(64 * WAVES) void k_seq(SeqArgs<NS> a, Body body) {
 #define SEQ_STORE(c, buf, SRC)                                                                                         \
   _Pragma("unroll") for (int rr = 0; rr < RP; ++rr) {                                                                  \
     const int r = mi + nset * rr, lr = (c) * R + r;                                                                    \
-    if (r < R && lr < a.rows) {                                                                                        \
-      const size_t off = (size_t)phys(lr) * a.Bp + g0;                                                                 \
+    if (r < R && lr < rows) {                                                                                          \
+      const size_t off = phys(lr) * a.Bp + g0;                                                                         \
       _Pragma("unroll") for (int q = 0; q < NS; ++q)                                                                   \
-        if ((a.outmask >> q) & 1u) (q < a.nband ? a.band + (size_t)q * a.stride : a.x)[off] = SRC;                     \
+        if ((a.outmask >> q) & 1u) SEQ_PTR(q)[off] = SRC;                                                              \
     }                                                                                                                  \
   }
   if (mv >= 0) {
@@ -374,11 +400,11 @@ __global__ __launch_bounds__(64 * WAVES) void k_seq(SeqArgs<NS> a, Body body) {
   } else {
     __syncthreads();
     typename Body::State st;
-    Body::init(st);
+    body.init(st, part);
     for (int c = 0; c < nch; ++c) {
       if (a.dev_mode != 1) {
         double *base = lds + (size_t)(c & 1) * CH * 64 + lane;
-        const int rmax = min(R, a.rows - c * R);
+        const int rmax = min(R, rows - c * R);
         int r = 0;
         for (; r + 2 <= rmax; r += 2) {
           body.step(st, base + (size_t)r * NS * 64, c * R + r);
@@ -388,85 +414,74 @@ __global__ __launch_bounds__(64 * WAVES) void k_seq(SeqArgs<NS> a, Body body) {
       }
       __syncthreads();
     }
+    body.finish(st, part, g0);
   }
+#undef SEQ_PTR
 #undef SEQ_LOAD
 #undef SEQ_PUT
 #undef SEQ_STORE
 }
 
-// banded LDL': streams q = 0 .. W hold B(t, t - q) on the way in; on the way out row t holds column t - W of the factor:
-// stream 0 = 1 / d, stream q = L(t - W + q, t - W)
-template <int W>
-struct FactorBody {
-  struct State { double S[W + 1][W + 1]; };
-  __device__ __forceinline__ static void init(State &st) {
-#pragma unroll
-    for (int a = 0; a <= W; ++a)
-#pragma unroll
-      for (int b = 0; b <= W; ++b) st.S[a][b] = a == b ? 1.0 : 0.0;
-  }
-  __device__ __forceinline__ void step(State &st, double *row, int) const {
-#pragma unroll
-    for (int b = 0; b <= W; ++b) st.S[W][b] = row[(size_t)(W - b) * 64];
-    double d = st.S[0][0];
-    if (!(d > 1e-200)) d = 1e64;                      // a dependent row: dropped
-    const double inv = 1.0 / d;
-    double l[W + 1], c0[W + 1];                        // c0: column 0 of the window (the update below overwrites it in place)
-#pragma unroll
-    for (int a = 1; a <= W; ++a) { c0[a] = st.S[a][0]; l[a] = c0[a] * inv; }
-    row[0] = inv;
-#pragma unroll
-    for (int a = 1; a <= W; ++a) row[(size_t)a * 64] = l[a];
-#pragma unroll
-    for (int a = 1; a <= W; ++a)
-#pragma unroll
-      for (int b = 1; b <= a; ++b) st.S[a - 1][b - 1] = fma(-l[a], c0[b], st.S[a][b]);
-  }
-};
+// (the bodies - FactorBody, ForwardBody, BackwardBody, SpikeBody - and the reduced system's per-lane arithmetic: dsp_ipm_seq.hpp)
 
-// forward substitution L z = r: streams 0 .. W-1 = L(i + q + 1, i) (factor row i + W), stream W = r / z
+// ---- the time-parallel form's kernels between the walks (dsp_ipm_seq.hpp) -------------------------------------------------------------
 template <int W>
-struct ForwardBody {
-  struct State { double acc[W]; };
-  __device__ __forceinline__ static void init(State &st) {
-#pragma unroll
-    for (int k = 0; k < W; ++k) st.acc[k] = 0.0;
-  }
-  __device__ __forceinline__ void step(State &st, double *row, int) const {
-    const double x = row[(size_t)W * 64] + st.acc[0];
-    row[(size_t)W * 64] = x;
-#pragma unroll
-    for (int k = 1; k <= W; ++k) st.acc[k - 1] = fma(-row[(size_t)(k - 1) * 64], x, k < W ? st.acc[k] : 0.0);
-  }
-};
-
-// D^-1 and backward substitution L' x = z (rows in reverse): stream 0 = 1 / d, streams 1 .. W = L(i + q, i), stream W + 1 = z / x
+__global__ __launch_bounds__(64) void k_ipm_red_factor(IpmArgs a) {
+  const size_t s = (size_t)blockIdx.x * 64 + threadIdx.x;
+  if (a.w.state[s] != 0) return;
+  ipm_red_factor_lane<W>(a.P.parts, a.w.sfin, a.w.cfin, a.w.gs, (size_t)a.P.Mp * a.w.Bp, a.w.redf, a.w.Bp, s);
+}
 template <int W>
-struct BackwardBody {
-  struct State { double xw[W]; };
-  __device__ __forceinline__ static void init(State &st) {
+__global__ __launch_bounds__(64) void k_ipm_red_solve(IpmArgs a, double *x) {
+  const size_t s = (size_t)blockIdx.x * 64 + threadIdx.x;
+  if (a.w.state[s] != 0) return;
+  ipm_red_solve_lane<W>(a.P.parts, a.w.redf, a.w.bd, x, a.w.Bp, s);
+}
+constexpr int kIpmBorderWaves = 8;
+// border sums of partition blockIdx.x + 1: eight waves take every eighth interior row, LDS combines
+template <int W>
+__global__ __launch_bounds__(64 * kIpmBorderWaves) void k_ipm_border_dot(IpmArgs a, const double *z) {
+  __shared__ double red[kIpmBorderWaves][W][64];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, p = (int)blockIdx.x + 1;
+  const size_t s = (size_t)blockIdx.y * 64 + lane;
+  double acc[W];
+  ipm_border_dot_lane<W>(a.P.parts, p, wv, kIpmBorderWaves, a.w.gs, (size_t)a.P.Mp * a.w.Bp, z, a.w.Bp, s, acc);
 #pragma unroll
-    for (int k = 0; k < W; ++k) st.xw[k] = 0.0;
+  for (int j = 0; j < W; ++j) red[wv][j][lane] = acc[j];
+  __syncthreads();
+  if (wv == 0) {
+#pragma unroll
+    for (int j = 0; j < W; ++j) {
+      double t = 0.0;
+#pragma unroll
+      for (int v = 0; v < kIpmBorderWaves; ++v) t += red[v][j][lane];
+      a.w.bd[((size_t)p * W + j) * a.w.Bp + s] = t;
+    }
   }
-  __device__ __forceinline__ void step(State &st, double *row, int) const {
-    double x = row[(size_t)(W + 1) * 64] * row[0];
-#pragma unroll
-    for (int k = 0; k < W; ++k) x = fma(-row[(size_t)(k + 1) * 64], st.xw[k], x);
-    row[(size_t)(W + 1) * 64] = x;
-#pragma unroll
-    for (int k = W - 1; k > 0; --k) st.xw[k] = st.xw[k - 1];
-    st.xw[0] = x;
-  }
-};
+}
+template <int W>
+__global__ __launch_bounds__(64 * kIpmBorderWaves) void k_ipm_border_apply(IpmArgs a, double *x) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, p = (int)blockIdx.x + 1;
+  const size_t s = (size_t)blockIdx.y * 64 + lane;
+  if (a.w.state[s] != 0) return;
+  ipm_border_apply_lane<W>(a.P.parts, p, wv, kIpmBorderWaves, a.w.gs, (size_t)a.P.Mp * a.w.Bp, a.w.band, x, a.w.Bp, s);
+}
 
 // ---- Woodbury ------------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_ipm_wide_rhs(IpmArgs a, int k) {        // q = column `wide_col[k]` of the scaled matrix
   IPM_LANE();
   int i0, i1; ipm_chunk(a.P.m, a.w.nch, cid, i0, i1);
   for (int i = i0; i < i1; ++i) a.w.q[(size_t)i * Bp + s] = 0.0;
-  for (int p = a.P.wptr[k]; p < a.P.wptr[k + 1]; ++p) {              // (the entries are sorted by row: a binary search would do; K <= 4 calls per factorisation)
+  int lo = a.P.wptr[k], hi = a.P.wptr[k + 1];
+  const int end = hi;
+  while (lo < hi) {                                                     // the entries are sorted by row: the first one at or after i0
+    const int mid = (lo + hi) >> 1;                                   // (every wave walking all 8736 entries of a design column: 1.9 ms)
+    if (a.P.wrow[mid] < i0) lo = mid + 1; else hi = mid;
+  }
+  for (int p = lo; p < end; ++p) {
     const int i = a.P.wrow[p];
-    if (i >= i0 && i < i1) a.w.q[(size_t)i * Bp + s] = a.P.wval[p];
+    if (i >= i1) break;
+    a.w.q[(size_t)i * Bp + s] = a.P.wval[p];
   }
 }
 
@@ -938,7 +953,10 @@ hipError_t ipm_create(const HostCSR &A, const HostCSR &AT, StreamSolver *S) {
   for (size_t k = 0; k < wide_col.size(); ++k) {
     const int j = wide_col[k];
     wide[j] = (uint8_t)(k + 1);
-    for (int p = AT.ptr[j]; p < AT.ptr[j + 1]; ++p) { wrow.push_back(AT.idx[p]); wval.push_back(AT.val[p]); }
+    std::vector<std::pair<int32_t, double>> ent;
+    for (int p = AT.ptr[j]; p < AT.ptr[j + 1]; ++p) ent.push_back({(int32_t)AT.idx[p], AT.val[p]});
+    std::sort(ent.begin(), ent.end());                                   // k_ipm_wide_rhs searches them by row
+    for (const auto &en : ent) { wrow.push_back(en.first); wval.push_back(en.second); }
     wptr.push_back((int32_t)wrow.size());
   }
   IpmState *I = new IpmState();
@@ -947,6 +965,21 @@ hipError_t ipm_create(const HostCSR &A, const HostCSR &AT, StreamSolver *S) {
   P.rw = rw; P.cw = cw; P.bw = bw;
   for (int k = 0; k < kIpmMaxK; ++k) P.wide_col[k] = k < P.K ? wide_col[k] : 0;
   P.col_scale = S->P.col_scale; P.row_scale = S->P.row_scale;
+  {
+    // time-parallel form: partitions of >= 256 rows, 64 at most (the reduced system's 63 sequential blocks then weigh about as much as
+    // a partition's 820 rows at T = 8736); DSP_IPM_PARTS = 1: the sequential walks (development, tests: any count the rows allow)
+    int want = std::min(64, m / 256);
+    if (getenv("DSP_IPM_PARTS")) want = std::max(1, atoi(getenv("DSP_IPM_PARTS")));
+    IpmParts g{};
+    g.m = m; g.W = W; g.P = 1; g.Lp = m;
+    if (want >= 2) {
+      const int Lp = std::max((m + want - 1) / want, 4 * W);
+      int parts = (m + Lp - 1) / Lp;
+      if (parts > 1 && m - (parts - 1) * Lp < 2 * W + 1) parts -= 1;       // a short tail joins the partition before it
+      if (parts >= 2) { g.P = parts; g.Lp = Lp; }
+    }
+    P.parts = g;
+  }
   hipError_t e;
   if ((e = ipm_up(I->allocs, rcol, &P.rcol)) != hipSuccess || (e = ipm_up(I->allocs, rval, &P.rval)) != hipSuccess ||
       (e = ipm_up(I->allocs, crow, &P.crow)) != hipSuccess || (e = ipm_up(I->allocs, cval, &P.cval)) != hipSuccess ||
@@ -961,6 +994,8 @@ hipError_t ipm_create(const HostCSR &A, const HostCSR &AT, StreamSolver *S) {
   S->ipm = I;
   return hipSuccess;
 }
+
+int ipm_partitions(const StreamSolver *S) { return S->ipm ? S->ipm->P.parts.P : 0; }
 
 void ipm_destroy(StreamSolver *S) {
   IpmState *I = S->ipm;
@@ -997,6 +1032,15 @@ static hipError_t ipm_workspace(IpmState *I, int B) {
   for (double **p : mv) if (alloc(M * w.Bp, p) != hipSuccess) return e;
   if (alloc((size_t)std::max(P.K, 1) * M * w.Bp, &w.biad) != hipSuccess) return e;
   if (alloc((size_t)(P.W + 1) * P.Mp * w.Bp, &w.band) != hipSuccess) return e;
+  w.gs = w.sfin = w.cfin = w.redf = w.bd = nullptr;
+  if (P.parts.P > 1) {
+    const size_t NT = (size_t)P.W * (P.W + 1) / 2, NR = (size_t)P.W * P.W + NT;
+    if (alloc((size_t)P.W * P.Mp * w.Bp, &w.gs) != hipSuccess) return e;
+    if (alloc((size_t)P.parts.P * NT * w.Bp, &w.sfin) != hipSuccess) return e;
+    if (alloc((size_t)P.parts.P * NT * w.Bp, &w.cfin) != hipSuccess) return e;
+    if (alloc((size_t)P.parts.P * NR * w.Bp, &w.redf) != hipSuccess) return e;
+    if (alloc((size_t)P.parts.P * P.W * w.Bp, &w.bd) != hipSuccess) return e;
+  }
   if (alloc((size_t)SC_COUNT * w.Bp, &w.sc) != hipSuccess) return e;
   if (alloc((size_t)kIpmNQ * w.nch * w.Bp, &w.part) != hipSuccess) return e;
   if (alloc((size_t)kIpmMaxK * kIpmMaxK * w.Bp, &w.sinv) != hipSuccess) return e;
@@ -1014,58 +1058,78 @@ static hipError_t ipm_workspace(IpmState *I, int B) {
   return hipSuccess;
 }
 
-template <int W>
-static hipError_t ipm_factor(const IpmArgs &a, hipStream_t st) {
-  constexpr int NS = W + 1, R = (72 * 1024) / (NS * 512);
-  SeqArgs<NS> q{};
-  q.band = a.w.band; q.stride = (size_t)a.P.Mp * a.w.Bp; q.nband = NS; q.x = nullptr;
-  q.rows = a.P.Mp; q.reverse = 0; q.Bp = a.w.Bp; q.outmask = (1u << NS) - 1u; q.state = a.w.state; q.dev_mode = getenv("DSP_IPM_SEQ_MODE") ? atoi(getenv("DSP_IPM_SEQ_MODE")) : 0;
+static int ipm_seq_mode() { static const int v = getenv("DSP_IPM_SEQ_MODE") ? atoi(getenv("DSP_IPM_SEQ_MODE")) : 0; return v; }
+
+// one walk: `parts` partitions starting with partition `part0` (grid.y), `rows` rows each (`last_rows` for the last one of the `nparts`)
+template <int NS, int R, class Body, int WV, int SETS>
+static hipError_t ipm_walk(const IpmArgs &a, SeqArgs<NS> q, const Body &body, int parts, hipStream_t st) {
+  q.Bp = a.w.Bp; q.state = a.w.state; q.dev_mode = ipm_seq_mode();
   const size_t lds = (size_t)2 * R * NS * 64 * sizeof(double);
-  constexpr int WV = 8;
-  auto fn = k_seq<NS, R, FactorBody<W>, WV, 1>;
+  auto fn = k_seq<NS, R, Body, WV, SETS>;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(fn, dim3((unsigned)(a.w.Bp / 64)), dim3(64 * WV), lds, st, q, FactorBody<W>{});
+  hipLaunchKernelGGL(fn, dim3((unsigned)(a.w.Bp / 64), (unsigned)parts), dim3(64 * WV), lds, st, q, body);
+  return hipGetLastError();
+}
+
+// the factorisation of the band in a.w.band (in place).  Time-parallel form (P > 1; dsp_ipm_seq.hpp): the interiors of the P partitions at
+// once, their spikes, then the separators' block-tridiagonal system.
+template <int W>
+static hipError_t ipm_factor(const IpmArgs &a, hipStream_t st) {
+  const IpmParts &g = a.P.parts;
+  const size_t stride = (size_t)a.P.Mp * a.w.Bp;
+  hipError_t e;
+  {
+    constexpr int NS = W + 1, R = (72 * 1024) / (NS * 512);
+    SeqArgs<NS> q{};
+    q.band = a.w.band; q.stride = stride; q.nband = NS; q.x = nullptr; q.xstride = 0;
+    q.rows = g.P > 1 ? g.Lp : a.P.Mp; q.last_rows = a.P.Mp - (g.P - 1) * g.Lp; q.nparts = g.P; q.part0 = 0; q.reverse = 0;
+    q.outmask = (1u << NS) - 1u;
+    if ((e = ipm_walk<NS, R, FactorBody<W>, 8, 1>(a, q, FactorBody<W>{g.P > 1 ? a.w.sfin : nullptr, a.w.Bp, g.P}, g.P, st)) != hipSuccess) return e;
+  }
+  if (g.P <= 1) return hipSuccess;
+  {
+    constexpr int NS = 2 * W + 1, R = (72 * 1024) / (NS * 512), WV = W <= 6 ? 8 : 4;      // (W = 8: 100 doubles of state - one wave per SIMD)
+    SeqArgs<NS> q{};
+    q.band = a.w.band + (size_t)W * a.w.Bp; q.stride = stride; q.nband = W + 1; q.x = a.w.gs; q.xstride = stride;      // 1 / d_c, L(c + k, c): factor row c + W
+    q.rows = g.Lp; q.last_rows = g.cols(g.P - 1); q.nparts = g.P; q.part0 = 1; q.reverse = 0;
+    q.outmask = ((1u << W) - 1u) << (W + 1);
+    if ((e = ipm_walk<NS, R, SpikeBody<W>, WV, 1>(a, q, SpikeBody<W>{a.w.cfin, a.w.Bp, g}, g.P - 1, st)) != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL(k_ipm_red_factor<W>, dim3((unsigned)(a.w.Bp / 64)), dim3(64), 0, st, a);
   return hipGetLastError();
 }
 
 // x := B^-1 x for the [m][Bp] vector `x` (in place)
 template <int W>
 static hipError_t ipm_bsolve(const IpmArgs &a, double *x, hipStream_t st) {
+  const IpmParts &g = a.P.parts;
+  const size_t stride = (size_t)a.P.Mp * a.w.Bp;
+  const dim3 border((unsigned)std::max(g.P - 1, 1), (unsigned)(a.w.Bp / 64));
+  static const int one_set = getenv("DSP_IPM_SEQ_SETS") ? atoi(getenv("DSP_IPM_SEQ_SETS")) == 1 : 0;      // development
   hipError_t e;
   {
     constexpr int NS = W + 1, R = (72 * 1024) / (NS * 512);
     SeqArgs<NS> q{};
-    q.band = a.w.band + ((size_t)a.P.Mp + W) * a.w.Bp; q.stride = (size_t)a.P.Mp * a.w.Bp; q.nband = W; q.x = x;     // L(i + k + 1, i): factor row i + W
-    q.rows = a.P.m; q.reverse = 0; q.Bp = a.w.Bp; q.outmask = 1u << W; q.state = a.w.state; q.dev_mode = getenv("DSP_IPM_SEQ_MODE") ? atoi(getenv("DSP_IPM_SEQ_MODE")) : 0;
-    const size_t lds = (size_t)2 * R * NS * 64 * sizeof(double);
-    static const int one_set = getenv("DSP_IPM_SEQ_SETS") ? atoi(getenv("DSP_IPM_SEQ_SETS")) == 1 : 0;      // development
-    if (one_set) {
-      auto fn = k_seq<NS, R, ForwardBody<W>, 8, 1>;
-      if ((e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return e;
-      hipLaunchKernelGGL(fn, dim3((unsigned)(a.w.Bp / 64)), dim3(64 * 8), lds, st, q, ForwardBody<W>{});
-    } else {
-      auto fn = k_seq<NS, R, ForwardBody<W>, 16, 2>;
-      if ((e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return e;
-      hipLaunchKernelGGL(fn, dim3((unsigned)(a.w.Bp / 64)), dim3(64 * 16), lds, st, q, ForwardBody<W>{});
-    }
+    q.band = a.w.band + ((size_t)a.P.Mp + W) * a.w.Bp; q.stride = stride; q.nband = W; q.x = x; q.xstride = 0;     // L(i + k + 1, i): factor row i + W
+    q.rows = g.P > 1 ? g.Lp : a.P.m; q.last_rows = g.cols(g.P - 1); q.nparts = g.P; q.part0 = 0; q.reverse = 0;
+    q.outmask = 1u << W;
+    e = one_set ? ipm_walk<NS, R, ForwardBody<W>, 8, 1>(a, q, ForwardBody<W>{}, g.P, st) : ipm_walk<NS, R, ForwardBody<W>, 16, 2>(a, q, ForwardBody<W>{}, g.P, st);
+    if (e != hipSuccess) return e;
+  }
+  if (g.P > 1) {
+    hipLaunchKernelGGL(k_ipm_border_dot<W>, border, dim3(64 * kIpmBorderWaves), 0, st, a, (const double *)x);
+    hipLaunchKernelGGL(k_ipm_red_solve<W>, dim3((unsigned)(a.w.Bp / 64)), dim3(64), 0, st, a, x);
+    hipLaunchKernelGGL(k_ipm_border_apply<W>, border, dim3(64 * kIpmBorderWaves), 0, st, a, x);
   }
   {
     constexpr int NS = W + 2, R = (72 * 1024) / (NS * 512);
     SeqArgs<NS> q{};
-    q.band = a.w.band + (size_t)W * a.w.Bp; q.stride = (size_t)a.P.Mp * a.w.Bp; q.nband = W + 1; q.x = x;               // 1 / d_i, then L(i + k, i): factor row i + W
-    q.rows = a.P.m; q.reverse = 1; q.Bp = a.w.Bp; q.outmask = 1u << (W + 1); q.state = a.w.state; q.dev_mode = getenv("DSP_IPM_SEQ_MODE") ? atoi(getenv("DSP_IPM_SEQ_MODE")) : 0;
-    const size_t lds = (size_t)2 * R * NS * 64 * sizeof(double);
-    static const int one_set = getenv("DSP_IPM_SEQ_SETS") ? atoi(getenv("DSP_IPM_SEQ_SETS")) == 1 : 0;      // development
-    if (one_set) {
-      auto fn = k_seq<NS, R, BackwardBody<W>, 8, 1>;
-      if ((e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return e;
-      hipLaunchKernelGGL(fn, dim3((unsigned)(a.w.Bp / 64)), dim3(64 * 8), lds, st, q, BackwardBody<W>{});
-    } else {
-      auto fn = k_seq<NS, R, BackwardBody<W>, 16, 2>;
-      if ((e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return e;
-      hipLaunchKernelGGL(fn, dim3((unsigned)(a.w.Bp / 64)), dim3(64 * 16), lds, st, q, BackwardBody<W>{});
-    }
+    q.band = a.w.band + (size_t)W * a.w.Bp; q.stride = stride; q.nband = W + 1; q.x = x; q.xstride = 0;               // 1 / d_i, then L(i + k, i): factor row i + W
+    q.rows = g.P > 1 ? g.Lp : a.P.m; q.last_rows = g.cols(g.P - 1); q.nparts = g.P; q.part0 = 0; q.reverse = 1;
+    q.outmask = 1u << (W + 1);
+    e = one_set ? ipm_walk<NS, R, BackwardBody<W>, 8, 1>(a, q, BackwardBody<W>{}, g.P, st) : ipm_walk<NS, R, BackwardBody<W>, 16, 2>(a, q, BackwardBody<W>{}, g.P, st);
+    if (e != hipSuccess) return e;
   }
   return hipGetLastError();
 }

@@ -1802,6 +1802,7 @@ static hipError_t stream_solve_locked(StreamSolver *S, const dsp_batch &batch, c
     if ((e = ipm_run(S, a, st, &all, &S->last_newton)) != hipSuccess) return e;
     if (all) {
       S->last_form = DSP_STREAM_FORM_IPM;
+      S->last_phases = ipm_partitions(S);
       S->last_bytes_per_iteration = 0;
       hipLaunchKernelGGL(k_finalize, dim3(a.nblk, B), dim3(kTB), 0, st, a);
       *periods_run = -1;

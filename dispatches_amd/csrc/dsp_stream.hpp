@@ -180,6 +180,7 @@ hipError_t lane_run(StreamSolver *S, StreamArgs &a, hipStream_t st, int *periods
 hipError_t ipm_create(const HostCSR &A_scaled, const HostCSR &AT_scaled, StreamSolver *S);
 void ipm_destroy(StreamSolver *S);
 hipError_t ipm_run(StreamSolver *S, StreamArgs &a, hipStream_t st, bool *all_solved, int *newton);
+int ipm_partitions(const StreamSolver *S);     // time partitions of its banded solves (1: sequential walks; 0: no interior-point plan)
 // certificate sequence on the scenario-major workspace (x, y = the current iterate): dsp_stream.hip
 hipError_t stream_certify(StreamSolver *S, StreamArgs &a, hipStream_t st);
 

@@ -173,7 +173,9 @@ typedef struct dsp_options {
                                 TIME-BANDED (half-bandwidth <= 8 in the given row order once at most 4 wide columns - design variables,
                                 periodic conditions - are set aside: the year-long price-taker LPs) are solved by a primal-dual
                                 interior-point method with exact banded factorisations, one lane per scenario (csrc/dsp_ipm.hip): ~100
-                                Newton iterations instead of ~75 k first-order iterations.  Scenarios it does not finish (free columns,
+                                Newton iterations instead of ~75 k first-order iterations; the factorisations and solves run
+                                TIME-PARALLEL from 512 rows on (up to 64 partitions of the horizon, their separators as a
+                                block-tridiagonal system: csrc/dsp_ipm_seq.hpp; dsp_stats::stream_phases = partitions).  Scenarios it does not finish (free columns,
                                 numerical breakdown, 250 iterations) and batches with soft rows run the PDHG forms as before; statuses
                                 2 / 3 come from those.  `iters` counts Newton iterations for scenarios it solved       default 0 */
   double  eps_infeasible;    /* > 0: infeasibility / unboundedness certificates (DSP_STATUS_PRIMAL_INFEASIBLE / DUAL_INFEASIBLE, ABI 9).  On
@@ -258,7 +260,9 @@ typedef struct dsp_stats {
   int32_t rtc;                    /* 1 = the kernel that ran was compiled at run time for this LP's shape (dsp_options::no_rtc) */
   int32_t stream_form;            /* streaming path, which form of the iteration ran (ABI 7; was reserved): DSP_STREAM_FORM_* */
   int32_t stream_phases;          /* streaming path, lane form (ABI 8): phases the solve ran in = 1 + the number of times the scenarios
-                                     still iterating were packed into fewer groups of 64 lanes after others had finished; 0 otherwise */
+                                     still iterating were packed into fewer groups of 64 lanes after others had finished; interior-point form
+                                     (round 5): the time partitions its banded factorisations and solves ran in (1 = sequential walks);
+                                     0 otherwise */
 } dsp_stats;
 
 /* dsp_stats::stream_form */

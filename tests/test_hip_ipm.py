@@ -60,6 +60,39 @@ def test_one_week_family_by_interior_point_matches_oracle_and_the_pdhg_forms(mon
 
 
 @gpu
+def test_time_parallel_banded_solves_equal_the_sequential_walks(monkeypatch):
+    """The factorisations and solves of a Newton iteration run time-parallel (csrc/dsp_ipm_seq.hpp: partitions of the horizon, their
+    separators as a block-tridiagonal system; dsp_stats::stream_phases = partitions): the same LPs with one partition (the sequential
+    walks), the automatic geometry and a finer one - the same elimination in another order, so the Newton iterations agree to rounding:
+    the same iteration counts (+- 2) and objectives to 1e-9.  Half-bandwidth 6 (wind + battery, one wide column) and 8 (nuclear, none)."""
+    _need_gpu()
+    from dispatches_amd import scenarios
+    from dispatches_amd.hip_solver import HipPdlpSolver
+    for family, T, B, finer in (("wb", 168, 16, "9"), ("nuclear", 672, 12, "31")):
+        runs = {}
+        for parts in ("1", None, finer):
+            if parts is None:
+                monkeypatch.delenv("DSP_IPM_PARTS", raising=False)
+            else:
+                monkeypatch.setenv("DSP_IPM_PARTS", parts)
+            solver = HipPdlpSolver(device=0, check_every=64, max_iter=1_000_000)
+            if family == "wb":
+                handles, model = scenarios.price_taker_batch(T, B, solver, throughput="chain")
+            else:
+                handles, model = scenarios.nuclear_price_taker_batch(T, B, solver)
+            solver.solve(model)
+            st = solver.last_stats
+            assert st.stream_form == FORM_IPM and (model.status == 0).all(), (family, parts, st.stream_form, model.status)
+            runs[parts] = (model.objective.copy(), model.iterations.copy(), int(st.stream_phases), model.lp.m)
+        m = runs["1"][3]
+        assert runs["1"][2] == 1 and runs[finer][2] == int(finer), {k: v[2] for k, v in runs.items()}
+        assert runs[None][2] == (min(64, m // 256) if m >= 512 else 1), (m, runs[None][2])
+        for parts in (None, finer):
+            assert np.abs(runs[parts][0] - runs["1"][0]).max() <= 1e-9 * np.maximum(1.0, np.abs(runs["1"][0])).max(), (family, parts)
+            assert np.abs(runs[parts][1] - runs["1"][1]).max() <= 2, (family, parts, runs[parts][1], runs["1"][1])
+
+
+@gpu
 @pytest.mark.parametrize("B", [16, 80])
 def test_year_long_price_taker_lps_by_interior_point(B):
     """The reference's own horizon (8736 hourly periods, n = 52 419, m = 52 418): the 16-member fixture (B = 80: five times over, two
@@ -75,6 +108,7 @@ def test_year_long_price_taker_lps_by_interior_point(B):
     solver.solve(model, tee=True)
     st = solver.last_stats
     assert st.streaming == 1 and st.stream_form == FORM_IPM and (model.status == 0).all(), (st.stream_form, np.bincount(model.status), model.iterations)
+    assert st.stream_phases == 64, st.stream_phases                              # time partitions of the banded solves (m = 52 418 rows)
     assert model.iterations.max() <= 250, model.iterations
     member = np.arange(B) % len(scenarios.PRICE_TAKER_FAMILY)
     ref = fx["T8736/obj"][member]
