@@ -76,6 +76,7 @@ struct IpmWork {
   int *state;                               // [Bp] 0 = iterating, 1 = solved, 2 = given up
   int *iters;                               // [Bp]
   int *stall;                               // [Bp] consecutive Newton iterations with a step below 1e-4
+  int *endg;                                // [Bp] 1 = the scenario is in its end game (k_ipm_decide): its Newton systems are refined further
   int *counts;                              // [4]: finished (solved or given up), solved, lanes in the end game
 };
 
@@ -86,6 +87,8 @@ struct IpmArgs {
   dsp_options opt;
   int it;                                   // Newton iteration (1-based)
   int max_it;                               // give up after this many (kIpmMaxNewton; development: DSP_IPM_MAXIT)
+  double reftol, reftol_end;                // refinement of the Newton systems: |rhs - N dy| <= tol |rhs| (max norms), far out / in a scenario's end game
+  double reg, step, sigmin;                 // development knobs (ipm_run): primal regularisation of Theta, step to the boundary, floor of sigma
 };
 
 struct IpmState {
@@ -117,7 +120,7 @@ __device__ __forceinline__ void ipm_chunk(int count, int nch, int cid, int &i0, 
 // scenarios of the group: every wave takes a quarter of the chunks with four independent accumulators (the loads of a plain loop queue
 // up one memory latency each: a 512-chunk sum took 0.95 ms), LDS combines.  Every thread returns the result.
 template <int NQ, int OP>                  // OP 0: sum, 1: min, 2: max
-__device__ __forceinline__ void ipm_finish(const double *part, int nch, size_t Bp, size_t s, double (&out)[NQ]) {
+__device__ __forceinline__ void ipm_finish(const double *part, int nch, size_t Bp, size_t s, double (&out)[NQ], int nq = NQ) {
   __shared__ double red[4][NQ][64];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   auto op = [](double x, double y) { return OP == 0 ? x + y : OP == 1 ? fmin(x, y) : fmax(x, y); };
@@ -125,6 +128,7 @@ __device__ __forceinline__ void ipm_finish(const double *part, int nch, size_t B
 #pragma unroll
   for (int q = 0; q < NQ; ++q) {
     double acc[4] = {e0, e0, e0, e0};
+    if (q >= nq) { red[wv][q][lane] = e0; continue; }      // (slots nobody filled: K = 1 uses 1 of the Woodbury matrix's 16)
     int c = wv;
     for (; c + 12 < nch; c += 16) {
 #pragma unroll
@@ -216,7 +220,7 @@ __global__ __launch_bounds__(256) void k_ipm_wide_aty(IpmArgs a, const double *v
 __global__ __launch_bounds__(256) void k_ipm_wide_aty_finish(IpmArgs a) {
   const size_t s = (size_t)blockIdx.x * 64 + (threadIdx.x & 63), Bp = a.w.Bp;
   double t[kIpmMaxK];
-  ipm_finish<kIpmMaxK, 0>(a.w.part, a.w.nch, Bp, s, t);
+  ipm_finish<kIpmMaxK, 0>(a.w.part, a.w.nch, Bp, s, t, a.P.K);
   if (threadIdx.x >= 64 || a.w.state[s] != 0) return;
 #pragma unroll
   for (int k = 0; k < kIpmMaxK; ++k) if (k < a.P.K) a.w.wat[(size_t)k * Bp + s] = t[k];
@@ -238,7 +242,7 @@ __global__ __launch_bounds__(256) void k_ipm_resid(IpmArgs a) {
       double den = 0.0;
       if (hl) { const double wl = v - l; den += z / wl; comp += z * wl; cnt += 1.0; }
       if (hu) { const double tu = u - v; den += f / tu; comp += f * tu; cnt += 1.0; }
-      th = (hl || hu) ? 1.0 / fmax(den, 1e-300) : 1e20;               // (free slack = free row: dropped by a huge Theta)
+      th = (hl || hu) ? 1.0 / fmax(den + a.reg, 1e-300) : 1e20;               // (free slack = free row: dropped by a huge Theta)
       th = fmin(th, 1e30);
     }
     a.w.th[at] = th;
@@ -520,7 +524,7 @@ __global__ __launch_bounds__(256) void k_ipm_wood_s(IpmArgs a) {
   const size_t s = (size_t)blockIdx.x * 64 + (threadIdx.x & 63), Bp = a.w.Bp;
   const int K = a.P.K;
   double sums[kIpmMaxK * kIpmMaxK];
-  ipm_finish<kIpmMaxK * kIpmMaxK, 0>(a.w.part, a.w.nch, Bp, s, sums);       // (slots beyond K * K: stale sums, not looked at)
+  ipm_finish<kIpmMaxK * kIpmMaxK, 0>(a.w.part, a.w.nch, Bp, s, sums, K * K);  // (slots beyond K * K: not summed, not looked at)
   if (threadIdx.x >= 64 || a.w.state[s] != 0) return;
   double S[kIpmMaxK][kIpmMaxK], I[kIpmMaxK][kIpmMaxK];
   bool dead[kIpmMaxK];
@@ -577,7 +581,7 @@ __global__ __launch_bounds__(256) void k_ipm_wood_g(IpmArgs a) {
   const size_t s = (size_t)blockIdx.x * 64 + (threadIdx.x & 63), Bp = a.w.Bp;
   const int K = a.P.K;
   double t[kIpmMaxK];
-  ipm_finish<kIpmMaxK, 0>(a.w.part, a.w.nch, Bp, s, t);
+  ipm_finish<kIpmMaxK, 0>(a.w.part, a.w.nch, Bp, s, t, K);
   if (threadIdx.x >= 64 || a.w.state[s] != 0) return;
 #pragma unroll
   for (int k1 = 0; k1 < kIpmMaxK; ++k1) {
@@ -683,7 +687,7 @@ __global__ __launch_bounds__(256) void k_ipm_resflag(IpmArgs a, double tol) {
   double t[2];
   ipm_finish<2, 2>(a.w.part, a.w.nch, Bp, s, t);
   if (threadIdx.x >= 64 || a.w.state[s] != 0) return;
-  if (!(t[0] <= tol * t[1])) atomicAdd(a.w.counts + 3, 1);
+  if (!(t[0] <= (a.w.endg[s] ? a.reftol_end : tol) * t[1])) atomicAdd(a.w.counts + 3, 1);
 }
 
 // dv, dz, df from dy; partial minima of the step lengths
@@ -719,7 +723,7 @@ __global__ __launch_bounds__(256) void k_ipm_steps(IpmArgs a, int mode) {
   ipm_finish<2, 1>(a.w.part, a.w.nch, Bp, s, t);
   if (threadIdx.x >= 64 || a.w.state[s] != 0) return;
   if (mode == 0) { a.w.sc[SC_APA * Bp + s] = fmin(t[0], 1.0); a.w.sc[SC_ADA * Bp + s] = fmin(t[1], 1.0); }
-  else { a.w.sc[SC_AP * Bp + s] = fmin(1.0, 0.9995 * t[0]); a.w.sc[SC_AD * Bp + s] = fmin(1.0, 0.9995 * t[1]); }
+  else { a.w.sc[SC_AP * Bp + s] = fmin(1.0, a.step * t[0]); a.w.sc[SC_AD * Bp + s] = fmin(1.0, a.step * t[1]); }
 }
 
 // mu of the affine step; the second-order terms of the corrector
@@ -750,7 +754,7 @@ __global__ __launch_bounds__(256) void k_ipm_sigma(IpmArgs a) {
   if (threadIdx.x >= 64 || a.w.state[s] != 0) return;
   const double mu = a.w.sc[SC_MU * Bp + s], mu_aff = t[0] / fmax(a.w.sc[SC_NB * Bp + s], 1.0);
   const double r = mu > 0.0 ? mu_aff / mu : 1.0;
-  a.w.sc[SC_SIGMU * Bp + s] = fmin(fmax(r * r * r, 0.0), 1.0) * mu;
+  a.w.sc[SC_SIGMU * Bp + s] = fmin(fmax(r * r * r, a.sigmin), 1.0) * mu;
 }
 
 __global__ __launch_bounds__(256) void k_ipm_update(IpmArgs a) {
@@ -837,6 +841,7 @@ __global__ __launch_bounds__(256) void k_ipm_decide(IpmArgs a) {
     a.w.state[s] = 2;                                                             // given up: the PDHG forms take the scenario
     atomicAdd(a.w.counts + 0, 1);
   } else if (gap + cs * (q[1] + q[4]) <= 1e4 * fmax(o.eps_obj * (1.0 + fabs(po + c.c0)), 1e-300)) {
+    a.w.endg[s] = 1;
     atomicAdd(a.w.counts + 2, 1);                                                 // end game: three refinement steps from here on
   } else if (gap + cs * (q[1] + q[4]) <= 1e7 * fmax(o.eps_obj * (1.0 + fabs(po + c.c0)), 1e-300)) {
     atomicAdd(a.w.counts + 3, 1);                                                 // one refinement step (none while the iterate is far out)
@@ -853,6 +858,7 @@ __global__ void k_ipm_begin(IpmArgs a, int phase) {
     a.w.state[s] = st;
     a.w.iters[s] = 0;
     a.w.stall[s] = 0;
+    a.w.endg[s] = 0;
     if (st) atomicAdd(a.w.counts + 0, 1);
   } else if (a.w.state[s] == 3) {
     a.w.state[s] = 2;
@@ -1052,6 +1058,8 @@ static hipError_t ipm_workspace(IpmState *I, int B) {
   I->work_allocs.push_back(w.iters);
   if ((e = hipMalloc((void **)&w.stall, w.Bp * sizeof(int))) != hipSuccess) return e;
   I->work_allocs.push_back(w.stall);
+  if ((e = hipMalloc((void **)&w.endg, w.Bp * sizeof(int))) != hipSuccess) return e;
+  I->work_allocs.push_back(w.endg);
   if ((e = hipMalloc((void **)&w.counts, 4 * sizeof(int))) != hipSuccess) return e;
   I->work_allocs.push_back(w.counts);
   I->work_B = B;
@@ -1148,7 +1156,7 @@ static hipError_t ipm_nsolve(StreamSolver *S, const IpmArgs &a, hipStream_t st, 
       hipLaunchKernelGGL(k_ipm_ref_rows, grid, blk, 0, st, a);
       if ((e = hipMemsetAsync(a.w.counts + 3, 0, sizeof(int), st)) != hipSuccess) return e;
       hipLaunchKernelGGL(k_ipm_resnorm, grid, blk, 0, st, a);
-      hipLaunchKernelGGL(k_ipm_resflag, lanes, blk, 0, st, a, 1e-8);
+      hipLaunchKernelGGL(k_ipm_resflag, lanes, blk, 0, st, a, a.reftol);
       if ((e = hipMemcpyAsync(S->ipm->counts_host + 3, a.w.counts + 3, sizeof(int), hipMemcpyDeviceToHost, st)) != hipSuccess) return e;
       if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;
       if (S->ipm->counts_host[3] == 0) break;
@@ -1315,6 +1323,11 @@ hipError_t ipm_run(StreamSolver *S, StreamArgs &sa, hipStream_t st, bool *all_so
   IpmArgs a{};
   a.P = I->P; a.w = I->w; a.sw = sa.W; a.opt = sa.opt; a.it = 0;
   a.max_it = getenv("DSP_IPM_MAXIT") ? std::max(1, std::min(atoi(getenv("DSP_IPM_MAXIT")), kIpmMaxNewton)) : kIpmMaxNewton;
+  a.reg = getenv("DSP_IPM_REG") ? atof(getenv("DSP_IPM_REG")) : 0.0;
+  a.step = getenv("DSP_IPM_STEP") ? atof(getenv("DSP_IPM_STEP")) : 0.99;
+  a.sigmin = getenv("DSP_IPM_SIGMIN") ? atof(getenv("DSP_IPM_SIGMIN")) : 0.0;
+  a.reftol = getenv("DSP_IPM_REFTOL") ? atof(getenv("DSP_IPM_REFTOL")) : 1e-8;
+  a.reftol_end = getenv("DSP_IPM_REFTOL_END") ? atof(getenv("DSP_IPM_REFTOL_END")) : 1e-11;
   return I->P.W == 6 ? ipm_loop<6>(S, a, st, all_solved, newton) : ipm_loop<8>(S, a, st, all_solved, newton);
 }
 

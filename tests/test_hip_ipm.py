@@ -64,7 +64,7 @@ def test_time_parallel_banded_solves_equal_the_sequential_walks(monkeypatch):
     """The factorisations and solves of a Newton iteration run time-parallel (csrc/dsp_ipm_seq.hpp: partitions of the horizon, their
     separators as a block-tridiagonal system; dsp_stats::stream_phases = partitions): the same LPs with one partition (the sequential
     walks), the automatic geometry and a finer one - the same elimination in another order, so the Newton iterations agree to rounding:
-    the same iteration counts (+- 2) and objectives to 1e-9.  Half-bandwidth 6 (wind + battery, one wide column) and 8 (nuclear, none)."""
+    the same iteration counts (+- 2); objectives to 2e-7 (each run stops at its own iterate inside the tolerance).  Half-bandwidth 6 (wind + battery, one wide column) and 8 (nuclear, none)."""
     _need_gpu()
     from dispatches_amd import scenarios
     from dispatches_amd.hip_solver import HipPdlpSolver
@@ -88,7 +88,7 @@ def test_time_parallel_banded_solves_equal_the_sequential_walks(monkeypatch):
         assert runs["1"][2] == 1 and runs[finer][2] == int(finer), {k: v[2] for k, v in runs.items()}
         assert runs[None][2] == (min(64, m // 256) if m >= 512 else 1), (m, runs[None][2])
         for parts in (None, finer):
-            assert np.abs(runs[parts][0] - runs["1"][0]).max() <= 1e-9 * np.maximum(1.0, np.abs(runs["1"][0])).max(), (family, parts)
+            assert (np.abs(runs[parts][0] - runs["1"][0]) <= 2e-7 * np.maximum(1.0, np.abs(runs["1"][0]))).all(), (family, parts)
             assert np.abs(runs[parts][1] - runs["1"][1]).max() <= 2, (family, parts, runs[parts][1], runs["1"][1])
 
 
