@@ -237,6 +237,45 @@ STREAM_KERNELS = {1: "k_primal + k_dual_halpern", 2: "k_fused_pre / k_fused", 3:
                   5: "k_seq<FactorBody / ForwardBody / BackwardBody> (banded LDL' and substitutions, csrc/dsp_ipm.hip)"}
 
 
+def _ipm_roofline(B, m, parts):
+    """Roofline object of an interior-point --solve line.  With the banded factorisations and solves time-parallel (csrc/dsp_ipm_seq.hpp) a
+    Newton iteration is ~30 launches that stream scenario-minor arrays; its largest single item is the banded solve (5.8 per Newton
+    iteration at 256 scenarios: forward walk, border sums, reduced system, border correction, backward walk).  ALGORITHMIC bytes of one
+    solve: 8 Bp m (4 W + 9) - the factor's W streams once per walk, the spikes' W streams for the sums and once more for the correction, the
+    vector read and written by each of the four passes, 1 / d twice.  Its duration is ARCHIVED: the sum of the five kernels' average
+    durations in the newest committed `rocprofv3 --kernel-trace --stats` summary of this form at this batch (profiles/*_ipm_kernel_stats_T8736_B<B>.csv);
+    the bench itself times the whole solve (HIP events), not single kernels."""
+    import csv
+    import glob
+    import re
+    Bp = (B + 63) // 64 * 64
+    out = {"bound": "hbm", "kernel": "one banded solve of the time-parallel form: k_seq<ForwardBody> + k_ipm_border_dot + k_ipm_red_solve + k_ipm_border_apply + "
+                                     "k_seq<BackwardBody> (csrc/dsp_ipm.hip)", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
+           "time_partitions": parts,
+           "note": "ARCHIVED kernel durations (not measured in this run: the line's time is the whole solve); the sequential form (time_partitions = 1) "
+                   "is a latency chain of m dependent rows per walk, 5 - 9 ms each whatever the batch"}
+    if parts <= 1:
+        out.update(bound="latency", peak=None, unit=None)
+        return out
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r5*_ipm_kernel_stats_T8736_B{B}.csv")), reverse=True):
+        dur, W = {}, None
+        for row in csv.DictReader(open(f)):
+            nm = row["Name"]
+            for key in ("ForwardBody", "BackwardBody", "k_ipm_border_dot", "k_ipm_red_solve", "k_ipm_border_apply"):
+                if key in nm:
+                    dur[key] = float(row["AverageNs"])
+                    mm = re.search(r"ForwardBody<(\d+)>", nm)
+                    if mm:
+                        W = int(mm.group(1))
+        if len(dur) == 5 and W:
+            byt = 8.0 * Bp * m * (4 * W + 9)
+            t = sum(dur.values()) * 1e-9
+            out.update(achieved=byt / t / 1e9, frac=byt / t / 1e9 / HBM_PEAK_GBS, algorithmic_bytes_per_solve=int(byt), solve_us=t * 1e6,
+                       kernel_us={k: v * 1e-3 for k, v in dur.items()}, archived_from=os.path.basename(f))
+            break
+    return out
+
+
 def _price_taker_cpu_worker(args):
     """CPU baseline leg of --workload price_taker --solve: one member of the family by the oracle (HiGHS on the un-reduced LP)."""
     T, k = args
@@ -362,10 +401,7 @@ def bench_price_taker(args, rank, local_rank, world, dev):
             line["config"]["ms_per_newton_iteration_of_the_batch"] = 1e3 * k_s / max(1, int(model.iterations.max()))
             line["config"]["time_partitions"] = line["config"].pop("stream_phases")      # of the banded factorisations / solves (1: sequential walks)
             line["config"].pop("us_per_batch_iteration", None)
-            line["roofline"] = {"bound": "latency", "kernel": STREAM_KERNELS[5], "achieved": None, "peak": None, "unit": None, "frac": None, "traffic": None,
-                                "sequential_steps_per_newton_iteration": "m per pass; passes: 1 factorisation + 2 per substitution pair x (K wide columns + predictor + corrector + refinement steps)",
-                                "note": "not a bandwidth- or FLOP-bound kernel: one wave per 64 scenarios walks m dependent rows out of LDS (measured 88 - 117 ns "
-                                        "per row and pass, 58 - 69 ns with the data already in LDS); the batch's time is independent of its size up to one wave per SIMD"}
+            line["roofline"] = _ipm_roofline(B, m, int(line["config"]["time_partitions"]))
         if args.solve:
             line["metric"] = f"year-long design LPs solved/sec, {args.workload}, T={T} (n={n}, m={m}), batch={B}"
             line["value"] = world * int((model.status == 0).sum()) / k_s
@@ -697,7 +733,7 @@ def _condense(tag, line, keys=()):
     if "roofline" in line:
         r = line["roofline"]
         e["roofline"] = {k: r.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_from",
-                                                "algorithmic_bytes_per_scenario_iteration") if k in r}
+                                                "algorithmic_bytes_per_scenario_iteration", "algorithmic_bytes_per_solve", "archived_from") if k in r}
     return e
 
 

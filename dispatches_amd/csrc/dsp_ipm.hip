@@ -193,7 +193,11 @@ __device__ __forceinline__ double ipm_aty(const IpmPlan &P, const double *y, con
   double t = 0.0;
   const int32_t *ci = P.crow + (size_t)j * P.cw;
   const double *cv = P.cval + (size_t)j * P.cw;
-  for (int e = 0; e < P.cw; ++e) t = fma(cv[e], y[(size_t)ci[e] * Bp + s], t);
+  for (int e = 0; e < P.cw; e += 4) {                 // (widths are multiples of 4: four gathers in flight - one at a time, every entry
+    const double y0 = y[(size_t)ci[e] * Bp + s], y1 = y[(size_t)ci[e + 1] * Bp + s];      //  of the ELL cost a round trip to L2)
+    const double y2 = y[(size_t)ci[e + 2] * Bp + s], y3 = y[(size_t)ci[e + 3] * Bp + s];
+    t = fma(cv[e], y0, t); t = fma(cv[e + 1], y1, t); t = fma(cv[e + 2], y2, t); t = fma(cv[e + 3], y3, t);
+  }
   return t;
 }
 // (Abar u)_i = sum_j a_ij u_j - u_{n+i}
@@ -201,7 +205,11 @@ __device__ __forceinline__ double ipm_au(const IpmPlan &P, const double *u, int 
   double t = -u[(size_t)(P.n + i) * Bp + s];
   const int32_t *ri = P.rcol + (size_t)i * P.rw;
   const double *rv = P.rval + (size_t)i * P.rw;
-  for (int e = 0; e < P.rw; ++e) t = fma(rv[e], u[(size_t)ri[e] * Bp + s], t);
+  for (int e = 0; e < P.rw; e += 4) {
+    const double u0 = u[(size_t)ri[e] * Bp + s], u1 = u[(size_t)ri[e + 1] * Bp + s];
+    const double u2 = u[(size_t)ri[e + 2] * Bp + s], u3 = u[(size_t)ri[e + 3] * Bp + s];
+    t = fma(rv[e], u0, t); t = fma(rv[e + 1], u1, t); t = fma(rv[e + 2], u2, t); t = fma(rv[e + 3], u3, t);
+  }
   return t;
 }
 
@@ -275,7 +283,12 @@ __global__ __launch_bounds__(256) void k_ipm_assemble(IpmArgs a) {
       double val = 0.0;
       if (t < m) {
         const size_t e0 = ((size_t)t * W1 + k) * a.P.bw;
-        for (int p = 0; p < a.P.bw; ++p) val = fma(a.P.bval[e0 + p], a.w.th[(size_t)a.P.bcol[e0 + p] * Bp + s], val);
+        for (int p = 0; p < a.P.bw; p += 4) {
+          const double h0 = a.w.th[(size_t)a.P.bcol[e0 + p] * Bp + s], h1 = a.w.th[(size_t)a.P.bcol[e0 + p + 1] * Bp + s];
+          const double h2 = a.w.th[(size_t)a.P.bcol[e0 + p + 2] * Bp + s], h3 = a.w.th[(size_t)a.P.bcol[e0 + p + 3] * Bp + s];
+          val = fma(a.P.bval[e0 + p], h0, val); val = fma(a.P.bval[e0 + p + 1], h1, val);
+          val = fma(a.P.bval[e0 + p + 2], h2, val); val = fma(a.P.bval[e0 + p + 3], h3, val);
+        }
         if (k == 0) { val += a.w.th[(size_t)(a.P.n + t) * Bp + s]; val *= 1.0 + 1e-12; if (!(val > 0.0)) val = 1.0; }
         else if (par && ipm_diverted(g, t, k)) {      // the column lies before this row's partition: a spike's entry (dsp_ipm_seq.hpp)
           const int j = t - k - (g.start(g.part_of(t)) - g.W);
@@ -940,6 +953,7 @@ hipError_t ipm_create(const HostCSR &A, const HostCSR &AT, StreamSolver *S) {
       }
       bw = std::max(bw, (int)pl.size());
     }
+  bw = (bw + 3) / 4 * 4;                                              // (the kernels take the entries four at a time; padding: index 0, value 0)
   std::vector<int32_t> bcol((size_t)m * W1 * bw, 0);
   std::vector<double> bval((size_t)m * W1 * bw, 0.0);
   for (size_t e = 0; e < prod.size(); ++e)
@@ -949,6 +963,7 @@ hipError_t ipm_create(const HostCSR &A, const HostCSR &AT, StreamSolver *S) {
   for (int i = 0; i < m; ++i) rw = std::max(rw, A.ptr[i + 1] - A.ptr[i]);
   for (int j = 0; j < n; ++j) if (!wide[j]) cw = std::max(cw, AT.ptr[j + 1] - AT.ptr[j]);
   if (rw > 16 || cw > 16 || bw > 16) return hipSuccess;              // not the sparse time-banded kind after all
+  rw = (rw + 3) / 4 * 4; cw = (cw + 3) / 4 * 4;
   std::vector<int32_t> rcol((size_t)m * rw, 0), crow((size_t)n * cw, 0), wptr(1, 0), wrow;
   std::vector<double> rval((size_t)m * rw, 0.0), cval((size_t)n * cw, 0.0), wval;
   for (int i = 0; i < m; ++i)
