@@ -122,6 +122,44 @@ def test_year_long_price_taker_lps_by_interior_point(B):
 
 
 @gpu
+def test_year_long_pem_and_nuclear_families_by_interior_point():
+    """The other two year-long families at the reference's own horizons, by the interior-point form in its time-parallel geometry (64
+    partitions), against the fixtures the PDHG forms are pinned to (tests/test_hip_stream.py): LP #5 (wind + battery + PEM, 8736 h,
+    n = 61 156, half-bandwidth 6 + design columns: run_pricetaker_wind_PEM.py:54-56) - objectives to 1e-6, PEM size within the reference
+    test's tolerance -, LP #6 (nuclear + PEM + tank + turbine, 8784 h, n = 70 275, half-bandwidth 8, per-scenario bounds:
+    price_taker_analysis.py:353-419) - all 60 points against the closed form, four against HiGHS."""
+    _need_gpu()
+    from dispatches_amd import scenarios
+    from dispatches_amd.hip_solver import HipPdlpSolver
+    from oracle import dispatch_lp_oracle as orc
+    fx = np.load(os.path.join(GOLD, "oracle_price_taker.npz"))
+    solver = HipPdlpSolver(device=0, check_every=64, max_iter=2_000_000)
+    T, B = 8736, 32
+    handles, model = scenarios.pem_price_taker_batch(T, B, solver, inputs="rts303")
+    solver.solve(model)
+    st = solver.last_stats
+    assert st.stream_form == FORM_IPM and st.stream_phases == 64 and (model.status == 0).all(), (st.stream_form, st.stream_phases, model.status)
+    assert model.iterations.max() <= 100, model.iterations
+    member = np.arange(B) % len(scenarios.PEM_PRICE_TAKER_FAMILY)
+    ref = fx["pem_T8736/obj"][member]
+    err = np.abs(model.objective - ref) / np.maximum(1.0, np.abs(ref))
+    assert err.max() < 1e-6, (err, model.iterations)
+    np.testing.assert_allclose(model.x[:, handles["pem_system_capacity"].index] * 1e-3, fx["pem_T8736/pem_mw"][member], rtol=2e-3, atol=1.0)
+    np.testing.assert_allclose(model.x[:, handles["battery_system_capacity"].index] * 1e-3, fx["pem_T8736/batt_mw"][member], rtol=2e-3, atol=1.0)
+    T, B = 8784, 60
+    handles, model = scenarios.nuclear_price_taker_batch(T, B, solver)
+    solver.solve(model)
+    st = solver.last_stats
+    assert st.stream_form == FORM_IPM and st.stream_phases == 64 and (model.status == 0).all(), (st.stream_form, st.stream_phases, model.status)
+    assert model.iterations.max() <= 100, model.iterations
+    closed = np.array([-1e-6 * orc.nuclear_price_taker_closed_form(model.lmp, hp, pc * 400.0) for hp, pc in model.family])
+    err = np.abs(model.objective - closed) / np.maximum(1.0, np.abs(closed))
+    assert err.max() < 1e-6, (err.max(), model.iterations)
+    for k, ref in zip(fx["nuclear_T8784/k"], fx["nuclear_T8784/obj"]):
+        assert abs(model.objective[k] - ref) <= 1e-6 * max(1.0, abs(ref)), (k, model.objective[k], ref)
+
+
+@gpu
 def test_nuclear_price_taker_enumeration_by_interior_point():
     """LP #6 (nuclear + PEM + tank + turbine, design fixed per member: no wide column at all, half-bandwidth 8) at four weeks: the
     members against the PDHG forms' objectives."""
