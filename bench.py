@@ -273,6 +273,19 @@ def _ipm_roofline(B, m, parts):
             out.update(achieved=byt / t / 1e9, frac=byt / t / 1e9 / HBM_PEAK_GBS, algorithmic_bytes_per_solve=int(byt), solve_us=t * 1e6,
                        kernel_us={k: v * 1e-3 for k, v in dur.items()}, archived_from=os.path.basename(f))
             break
+    # HBM bytes of the same five kernels per solve: FETCH_SIZE x 2 (gfx950: half the bytes of a coalesced streaming read are counted) + WRITE_SIZE,
+    # KB, from the newest committed counter summary of this form at this batch (tools/gpu_ipm_pmc.sh: one --pmc pass per counter)
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r5*_ipm_pmc_summary_B{B}.csv")), reverse=True):
+        tr = {}
+        for row in csv.DictReader(open(f)):
+            for key in ("ForwardBody", "BackwardBody", "k_ipm_border_dot", "k_ipm_red_solve", "k_ipm_border_apply"):
+                if key in row["kernel"] and row["counter"] in ("FETCH_SIZE", "WRITE_SIZE"):
+                    tr[key] = tr.get(key, 0.0) + (2.0 if row["counter"] == "FETCH_SIZE" else 1.0) * float(row["mean_counter_value"]) * 1024.0
+        if len(tr) == 5:
+            out.update(traffic=sum(tr.values()), traffic_from=os.path.basename(f))
+            if out.get("algorithmic_bytes_per_solve"):
+                out["traffic_over_algorithmic"] = out["traffic"] / out["algorithmic_bytes_per_solve"]
+            break
     return out
 
 
@@ -733,7 +746,7 @@ def _condense(tag, line, keys=()):
     if "roofline" in line:
         r = line["roofline"]
         e["roofline"] = {k: r.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_from",
-                                                "algorithmic_bytes_per_scenario_iteration", "algorithmic_bytes_per_solve", "archived_from") if k in r}
+                                                "algorithmic_bytes_per_scenario_iteration", "algorithmic_bytes_per_solve", "archived_from", "traffic_over_algorithmic") if k in r}
     return e
 
 

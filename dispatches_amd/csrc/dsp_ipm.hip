@@ -455,14 +455,15 @@ __global__ __launch_bounds__(64) void k_ipm_red_solve(IpmArgs a, double *x) {
   ipm_red_solve_lane<W>(a.P.parts, a.w.redf, a.w.bd, x, a.w.Bp, s);
 }
 constexpr int kIpmBorderWaves = 8;
-// border sums of partition blockIdx.x + 1: eight waves take every eighth interior row, LDS combines
-template <int W>
-__global__ __launch_bounds__(64 * kIpmBorderWaves) void k_ipm_border_dot(IpmArgs a, const double *z) {
-  __shared__ double red[kIpmBorderWaves][W][64];
+// border sums of partition blockIdx.x + 1: NWV waves take every NWV-th interior row, LDS combines (W = 6: 16 waves - with 8 the kernel ran
+// at 3.1 TB/s next to the correction's 5.4 on the same streams; W = 8: 8, the combine buffer must stay under 64 KB)
+template <int W, int NWV>
+__global__ __launch_bounds__(64 * NWV) void k_ipm_border_dot(IpmArgs a, const double *z) {
+  __shared__ double red[NWV][W][64];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, p = (int)blockIdx.x + 1;
   const size_t s = (size_t)blockIdx.y * 64 + lane;
   double acc[W];
-  ipm_border_dot_lane<W>(a.P.parts, p, wv, kIpmBorderWaves, a.w.gs, (size_t)a.P.Mp * a.w.Bp, z, a.w.Bp, s, acc);
+  ipm_border_dot_lane<W>(a.P.parts, p, wv, NWV, a.w.gs, (size_t)a.P.Mp * a.w.Bp, z, a.w.Bp, s, acc);
 #pragma unroll
   for (int j = 0; j < W; ++j) red[wv][j][lane] = acc[j];
   __syncthreads();
@@ -471,7 +472,7 @@ __global__ __launch_bounds__(64 * kIpmBorderWaves) void k_ipm_border_dot(IpmArgs
     for (int j = 0; j < W; ++j) {
       double t = 0.0;
 #pragma unroll
-      for (int v = 0; v < kIpmBorderWaves; ++v) t += red[v][j][lane];
+      for (int v = 0; v < NWV; ++v) t += red[v][j][lane];
       a.w.bd[((size_t)p * W + j) * a.w.Bp + s] = t;
     }
   }
@@ -668,7 +669,7 @@ __global__ __launch_bounds__(256) void k_ipm_ref_cols(IpmArgs a) {
   IPM_LANE();
   const int N = a.P.n + a.P.m;
   int j0, j1; ipm_chunk(N, a.w.nch, cid, j0, j1);
-#pragma unroll 2
+#pragma unroll 4
   for (int j = j0; j < j1; ++j) {
     const size_t at = (size_t)j * Bp + s;
     a.w.tn[at] = a.w.th[at] * ipm_aty(a.P, a.w.dy, a.w.wat, j, Bp, s);
@@ -677,24 +678,20 @@ __global__ __launch_bounds__(256) void k_ipm_ref_cols(IpmArgs a) {
 __global__ __launch_bounds__(256) void k_ipm_ref_rows(IpmArgs a) {
   IPM_LANE();
   int i0, i1; ipm_chunk(a.P.m, a.w.nch, cid, i0, i1);
+  double mq = 0.0, mr = 0.0;                       // max |rhs - N dy|, max |rhs| of the chunk: what k_ipm_resflag decides on
 #pragma unroll 2
   for (int i = i0; i < i1; ++i) {
     const size_t at = (size_t)i * Bp + s;
-    a.w.q[at] = a.w.rhs[at] - ipm_au(a.P, a.w.tn, i, Bp, s);
+    const double r = a.w.rhs[at], q = r - ipm_au(a.P, a.w.tn, i, Bp, s);
+    a.w.q[at] = q;
+    mq = fmax(mq, fabs(q)); mr = fmax(mr, fabs(r));
   }
-}
-
-// how well the Newton system is solved: max |rhs - N dy| against max |rhs| per scenario; a scenario beyond the tolerance asks for a
-// (further) step of iterative refinement - of the whole batch: the sequential kernels cost the same for one lane as for 64
-__global__ __launch_bounds__(256) void k_ipm_resnorm(IpmArgs a) {
-  IPM_LANE();
-  int i0, i1; ipm_chunk(a.P.m, a.w.nch, cid, i0, i1);
-  double mq = 0.0, mr = 0.0;
-#pragma unroll 4
-  for (int i = i0; i < i1; ++i) { mq = fmax(mq, fabs(a.w.q[(size_t)i * Bp + s])); mr = fmax(mr, fabs(a.w.rhs[(size_t)i * Bp + s])); }
   a.w.part[((size_t)0 * a.w.nch + cid) * Bp + s] = mq;
   a.w.part[((size_t)1 * a.w.nch + cid) * Bp + s] = mr;
 }
+
+// how well the Newton system is solved: max |rhs - N dy| against max |rhs| per scenario (partial maxima: k_ipm_ref_rows); a scenario beyond
+// the tolerance asks for a (further) step of iterative refinement - of the whole batch: the solves cost the same for one lane as for 64
 __global__ __launch_bounds__(256) void k_ipm_resflag(IpmArgs a, double tol) {
   const size_t s = (size_t)blockIdx.x * 64 + (threadIdx.x & 63), Bp = a.w.Bp;
   double t[2];
@@ -1141,7 +1138,8 @@ static hipError_t ipm_bsolve(const IpmArgs &a, double *x, hipStream_t st) {
     if (e != hipSuccess) return e;
   }
   if (g.P > 1) {
-    hipLaunchKernelGGL(k_ipm_border_dot<W>, border, dim3(64 * kIpmBorderWaves), 0, st, a, (const double *)x);
+    constexpr int DW = W <= 6 ? 16 : 8;
+    hipLaunchKernelGGL((k_ipm_border_dot<W, DW>), border, dim3(64 * DW), 0, st, a, (const double *)x);
     hipLaunchKernelGGL(k_ipm_red_solve<W>, dim3((unsigned)(a.w.Bp / 64)), dim3(64), 0, st, a, x);
     hipLaunchKernelGGL(k_ipm_border_apply<W>, border, dim3(64 * kIpmBorderWaves), 0, st, a, x);
   }
@@ -1170,7 +1168,6 @@ static hipError_t ipm_nsolve(StreamSolver *S, const IpmArgs &a, hipStream_t st, 
       hipLaunchKernelGGL(k_ipm_ref_cols, grid, blk, 0, st, a);
       hipLaunchKernelGGL(k_ipm_ref_rows, grid, blk, 0, st, a);
       if ((e = hipMemsetAsync(a.w.counts + 3, 0, sizeof(int), st)) != hipSuccess) return e;
-      hipLaunchKernelGGL(k_ipm_resnorm, grid, blk, 0, st, a);
       hipLaunchKernelGGL(k_ipm_resflag, lanes, blk, 0, st, a, a.reftol);
       if ((e = hipMemcpyAsync(S->ipm->counts_host + 3, a.w.counts + 3, sizeof(int), hipMemcpyDeviceToHost, st)) != hipSuccess) return e;
       if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;
