@@ -1337,7 +1337,7 @@ hipError_t ipm_run(StreamSolver *S, StreamArgs &sa, hipStream_t st, bool *all_so
   a.max_it = getenv("DSP_IPM_MAXIT") ? std::max(1, std::min(atoi(getenv("DSP_IPM_MAXIT")), kIpmMaxNewton)) : kIpmMaxNewton;
   a.reg = getenv("DSP_IPM_REG") ? atof(getenv("DSP_IPM_REG")) : 0.0;
   a.step = getenv("DSP_IPM_STEP") ? atof(getenv("DSP_IPM_STEP")) : 0.99;
-  a.sigmin = getenv("DSP_IPM_SIGMIN") ? atof(getenv("DSP_IPM_SIGMIN")) : 0.0;
+  a.sigmin = getenv("DSP_IPM_SIGMIN") ? atof(getenv("DSP_IPM_SIGMIN")) : 0.05;
   a.reftol = getenv("DSP_IPM_REFTOL") ? atof(getenv("DSP_IPM_REFTOL")) : 1e-8;
   a.reftol_end = getenv("DSP_IPM_REFTOL_END") ? atof(getenv("DSP_IPM_REFTOL_END")) : 1e-11;
   return I->P.W == 6 ? ipm_loop<6>(S, a, st, all_solved, newton) : ipm_loop<8>(S, a, st, all_solved, newton);

@@ -1,7 +1,7 @@
 """GPU development tool: robustness of the interior-point form against the rounding of its linear solves - the year-long family (64 lanes =
 4 x its 16 members) under several counts of time partitions (each count is another elimination order: the same Newton iterations up to
 rounding) and settings of the development knobs (DSP_IPM_REG / STEP / SIGMIN / REFTOL).
-    python tools/gpu_ipm_knobs.py "<parts> <parts> ..." "KEY=VAL,KEY=VAL" ["KEY=VAL,..." ...]"""
+    python tools/gpu_ipm_knobs.py "<parts> <parts> ..." "KEY=VAL,KEY=VAL" ["KEY=VAL,..." ...]        (IPM_T / IPM_B: horizon and batch, default 8736 / 64)"""
 import os
 import re
 import subprocess
@@ -15,7 +15,7 @@ for setting in sys.argv[2:]:
     knobs = dict(kv.split("=") for kv in setting.split(",") if "=" in kv)
     for parts in parts_list:
         env = dict(os.environ, DSP_IPM_PARTS=parts, DSP_IPM_TRACE="1", **knobs)
-        p = subprocess.run([sys.executable, "-c", CHILD, "8736", "64"], env=env, capture_output=True, text=True, timeout=600)
+        p = subprocess.run([sys.executable, "-c", CHILD, os.environ.get("IPM_T", "8736"), os.environ.get("IPM_B", "64")], env=env, capture_output=True, text=True, timeout=600)
         lanes = [l for l in p.stderr.splitlines() if l.startswith("[ipm] lanes")]
         pairs = re.findall(r"(\d+):(\d+)", lanes[-1].split("iterations):")[1])[:16] if lanes else []
         res = re.search(r"form (\d+) .* wall (\S+)", p.stdout)
