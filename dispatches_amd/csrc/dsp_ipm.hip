@@ -11,18 +11,26 @@
 //                                                                     fixed columns / equality rows simply carry Theta = 0)
 //     (A_s Theta_s A_s' + Theta_r) dy = rhs    banded LDL' (no pivoting; relative diagonal regularisation 1e-12), half-bandwidth W <= 8
 //     wide columns (span > 16 rows: design variables, periodic conditions; K <= 4) through Sherman-Morrison-Woodbury, K x K per scenario
-//     iterative refinement on the full normal equations (1 step, 3 in the end game where Theta spans 30 decades)
+//     iterative refinement on the full normal equations: to 1e-8 of the right-hand side (max norms), to 1e-11 once a scenario is in its end
+//     game (within four decades of its objective tolerance), three steps at most
+//     steps 0.99 to the boundary, sigma = max((mu_aff / mu)^3, 0.05): the two settings (with the end-game refinement) under which every
+//     horizon, family and elimination order tried finishes (DESIGN.md 4f "Robustness, measured": mu must not collapse under the solve error)
 // ONE LANE PER SCENARIO: every array is scenario-minor ([index][scenario], 64 scenarios = one 512-byte line per index), all lanes walk the
-// same rows, and the structure (CSR / CSC of the scaled matrix, the band's product lists) is read through uniform addresses.  The two
-// sequential kernels (factorisation, triangular solves: m dependent steps) run one wave per 64 scenarios out of LDS: the workgroup's
-// four waves stream chunks of rows HBM -> registers -> LDS -> HBM around the computing wave (k_seq), so that the chain never waits
-// for memory: 9 loads + 36 fused multiply-adds per row for the factorisation, 8 per row and direction for a solve.  Everything else
-// (residuals, Theta, assembly of the band, directions, step lengths, KKT test) is elementwise over (chunk of indices) x (64 scenarios).
-// Cost per Newton iteration and 64 scenarios: ~20 m sequential steps, independent of the batch size up to one wave per SIMD x 64.
+// same rows, and the structure (ELLs of the scaled matrix, the band's product lists) is read through uniform addresses.
+// The banded factorisation and solves are chains of dependent rows.  SEQUENTIAL form (below 512 rows; DSP_IPM_PARTS=1): one wave per 64
+// scenarios walks all m rows out of LDS while the workgroup's other waves stream chunks of rows HBM -> registers -> LDS -> HBM around it
+// (k_seq), so that the chain never waits for memory: 58 / 69 / 158 ns per row forward / backward / factor - 5 - 9 ms per walk at T = 8736
+// whatever the batch.  TIME-PARALLEL form (default; dsp_ipm_seq.hpp): the rows are cut into up to 64 partitions whose interiors are
+// eliminated at once (k_seq with grid.y = partitions), the W columns coupling an interior to the separator on its left are carried as
+// spikes, the separators form a block-tridiagonal system solved per lane (k_ipm_red_factor / k_ipm_red_solve), border sums and corrections
+// (k_ipm_border_dot / k_ipm_border_apply) connect the two: a solve is then five bandwidth-bound kernels (3.5 GB at 256 scenarios, 0.54 of
+// the HBM peak) instead of two latency chains.  Everything else (residuals, Theta, assembly of the band, directions, step lengths, KKT
+// test) is elementwise over (chunk of indices) x (64 scenarios).  256 year-long scenarios: 13 ms per Newton iteration, ~50 GB of HBM traffic.
 //
 // Termination is the HBM-resident path's own test (control_decide, dsp_stream.hpp) evaluated on the unscaled problem; a scenario the
 // method does not finish (breakdown, 250 Newton iterations, free columns) is left to the PDHG forms, which start as if this file did
-// not exist.  dsp_options::no_interior_point = 1 switches it off; dsp_stats::stream_form = DSP_STREAM_FORM_IPM when it solved the batch.
+// not exist.  dsp_options::no_interior_point = 1 switches it off; dsp_stats::stream_form = DSP_STREAM_FORM_IPM when it solved the batch,
+// dsp_stats::stream_phases = the time partitions.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -88,7 +96,7 @@ struct IpmArgs {
   int it;                                   // Newton iteration (1-based)
   int max_it;                               // give up after this many (kIpmMaxNewton; development: DSP_IPM_MAXIT)
   double reftol, reftol_end;                // refinement of the Newton systems: |rhs - N dy| <= tol |rhs| (max norms), far out / in a scenario's end game
-  double reg, step, sigmin;                 // development knobs (ipm_run): primal regularisation of Theta, step to the boundary, floor of sigma
+  double reg, step, sigmin;                 // primal regularisation of Theta (0: off), step to the boundary (0.99), floor of sigma (0.05); ipm_run
 };
 
 struct IpmState {
