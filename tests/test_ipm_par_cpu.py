@@ -32,3 +32,32 @@ def test_time_parallel_banded_solve_equals_the_sequential_one(harness, m, W, Lp,
     assert res["P"] == parts, res
     assert 0 <= res["err_seq"] < 1e-11, res
     assert 0 <= res["err_par"] < 1e-11, res
+
+
+def test_bench_roofline_object_of_the_interior_point_line():
+    """bench.py's `roofline` object for a --solve line of the interior-point form: the banded solve's algorithmic bytes 8 Bp m (4 W + 9), its
+    duration from the newest committed kernel-trace summary of this round at that batch, the HBM bytes of the same five kernels from the
+    committed counter summary (FETCH_SIZE doubled as the guide prescribes for gfx950).  Without a committed summary for the batch, or with
+    one partition (the sequential walks), the bandwidth fields stay null instead of being guessed."""
+    import importlib.util
+    import sys
+    spec = importlib.util.spec_from_file_location("bench_for_test", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    argv, sys.argv = sys.argv, ["bench.py"]
+    try:
+        spec.loader.exec_module(bench)
+    finally:
+        sys.argv = argv
+    m, W = 52418, 6
+    r = bench._ipm_roofline(256, m, 64)
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == bench.HBM_PEAK_GBS
+    assert r["algorithmic_bytes_per_solve"] == 8 * 256 * m * (4 * W + 9)
+    assert set(r["kernel_us"]) == {"ForwardBody", "BackwardBody", "k_ipm_border_dot", "k_ipm_red_solve", "k_ipm_border_apply"}
+    assert abs(r["achieved"] - r["algorithmic_bytes_per_solve"] / (r["solve_us"] * 1e-6) / 1e9) < 1e-6 * r["achieved"]
+    assert 0.3 < r["frac"] < 0.8 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert r["archived_from"].endswith("_ipm_kernel_stats_T8736_B256.csv") and os.path.exists(os.path.join(ROOT, "profiles", r["archived_from"]))
+    assert 0.9 < r["traffic_over_algorithmic"] < 1.1 and os.path.exists(os.path.join(ROOT, "profiles", r["traffic_from"]))
+    none = bench._ipm_roofline(192, m, 64)                       # no committed summary at this batch
+    assert none["achieved"] is None and none["frac"] is None and none["traffic"] is None
+    seq = bench._ipm_roofline(256, m, 1)
+    assert seq["bound"] == "latency" and seq["frac"] is None
