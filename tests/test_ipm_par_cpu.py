@@ -61,3 +61,28 @@ def test_bench_roofline_object_of_the_interior_point_line():
     assert none["achieved"] is None and none["frac"] is None and none["traffic"] is None
     seq = bench._ipm_roofline(256, m, 1)
     assert seq["bound"] == "latency" and seq["frac"] is None
+
+
+@pytest.mark.parametrize("T", [168, 336])
+def test_numpy_statement_of_the_interior_point_form_against_highs(T):
+    """tools/ipm_lab.py is the numpy statement of the method csrc/dsp_ipm.hip implements (Mehrotra predictor-corrector on [A | -I], banded
+    normal matrix in the natural row order + Sherman-Morrison-Woodbury for the wide columns, refinement on the full normal equations, the
+    streaming path's KKT test on the unscaled problem) with the product's settings (0.99 to the boundary, sigma >= 0.05): all 16 members of
+    the price-taker family (reference wind_battery_LMP.py:172-269 at one and two weeks) to 1e-6 of HiGHS on the un-reduced LP, in at most
+    100 Newton iterations, inside the bounds."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import numpy as np
+    import ipm_lab
+    import stream_lab as lab
+    worst = 0
+    for member in range(16):
+        P = lab.build(T, member, None, "chain")
+        ref = lab.highs(P)[0]
+        X, Y, it, done = ipm_lab.solve(P, colscale=lab.physical_scales(P, T))
+        obj = float(P["c"] @ X + P["c0"])
+        assert done and it <= 100, (member, it)
+        assert abs(obj - ref) <= 1e-6 * max(1.0, abs(ref)), (member, obj, ref)
+        assert (X >= P["lb"] - 1e-7 * np.maximum(1.0, np.abs(P["lb"]))).all() and (X <= P["ub"] + 1e-7 * np.maximum(1.0, np.abs(P["ub"]))).all()
+        worst = max(worst, it)
+    assert worst >= 10                                            # (an interior-point method ran: not a presolve accident)

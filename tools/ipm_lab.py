@@ -32,7 +32,9 @@ def banded_from(N, w):
     return ab
 
 
-def solve(P, eps=1e-9, eps_obj=5e-7, max_iter=200, colscale=None, n_ruiz=10, dense_thr=16, verbose=0, reg=1e-12, prox=0.0, frac=0.9995, refine=3, theta_cap=1e30):
+def solve(P, eps=1e-9, eps_obj=5e-7, max_iter=200, colscale=None, n_ruiz=10, dense_thr=16, verbose=0, reg=1e-12, prox=0.0, frac=0.99, refine=3, theta_cap=1e30, sigmin=0.05):
+    """frac / sigmin: the product's settings since round 5's last commits (csrc/dsp_ipm.hip: 0.99 to the boundary, sigma >= 0.05); the first
+    version ran 0.9995 / 0 (`frac=0.9995 sigmin=0` on the command line)"""
     A0 = sp.csr_matrix(P["A"])
     m, n = A0.shape
     if colscale is not None:
@@ -135,7 +137,7 @@ def solve(P, eps=1e-9, eps_obj=5e-7, max_iter=200, colscale=None, n_ruiz=10, den
         dva, dya, dza, dfa = direction(0.0, 0.0, 0.0)
         apa, ada = steps(dva, dza, dfa)
         mu_aff = ((z + ada * dza) @ ((wl + apa * dva) * hl) + (f + ada * dfa) @ ((tu - apa * dva) * hu)) / nb
-        sigma = (mu_aff / mu) ** 3
+        sigma = max((mu_aff / mu) ** 3, sigmin)
         dv, dy, dz, df = direction(sigma * mu, dva * dza, -dva * dfa)
         ap, ad = steps(dv, dz, df)
         ap, ad = min(1.0, frac * ap), min(1.0, frac * ad)
