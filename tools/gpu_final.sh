@@ -26,7 +26,9 @@ python - "$out/${tag}_stream_bench.jsonl" <<'PY'
 import json, sys
 for l in open(sys.argv[1]):
     d = json.loads(l); c = d["config"]; r = d["roofline"]
-    print(d["metric"][:64], "| %.4g %s | frac %.3f | %s | us/it %.1f | done early %s | traffic %s" % (d["value"], d["unit"], r["frac"], c.get("stream_form"), c["us_per_batch_iteration"], c.get("finished_before_the_cap"), r.get("traffic_from")))
+    fr = "%.3f" % r["frac"] if r.get("frac") is not None else "-"
+    per = "us/it %.1f" % c["us_per_batch_iteration"] if "us_per_batch_iteration" in c else "ms/Newton %.2f (%s partitions)" % (c.get("ms_per_newton_iteration_of_the_batch", float("nan")), c.get("time_partitions"))
+    print(d["metric"][:64], "| %.4g %s | frac %s | %s | %s | done early %s | traffic %s" % (d["value"], d["unit"], fr, c.get("stream_form"), per, c.get("finished_before_the_cap"), r.get("traffic_from")))
 PY
 bash tools/gpu_lane_pmc.sh $tag 256 640 | tail -4
 cd /tmp; rm -rf /tmp/tr; DSP_LANE_GRAPH=0 timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/tr -- python $repo/tools/gpu_stream.py 8736 256 1280 64 > /dev/null 2>&1
