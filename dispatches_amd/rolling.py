@@ -119,7 +119,7 @@ class _DeviceModel:
 class BatchedWindBatteryDoubleLoop:
     def __init__(self, n_scenarios, device=0, first_scenario=0, series="rts_gmlc_309.npz", stride=17,
                  day_ahead_horizon=48, real_time_horizon=4, tracking_horizon=4, wind_mw=200.0, batt_mw=25.0,
-                 price_cap=500.0, warm_start=False, lp_backend=None, use_graphs=True, use_fused=True):
+                 price_cap=500.0, warm_start=False, lp_backend=None, use_graphs=True, use_fused=True, record=None):
         """lp_backend: None = the HIP solver on GPU `device`; tests pass a factory lp -> object with DeviceLP.solve's
         signature working on CPU tensors (tests/_highs_solver.py::HighsTensorLP), which runs the SAME window / objective /
         state-hand-off logic without a GPU.
@@ -129,7 +129,11 @@ class BatchedWindBatteryDoubleLoop:
         reads or writes therefore lives in persistent device tensors that are updated in place, including the clock.
         use_fused: on the GPU, the ~45 element-wise tensor operations of an hour step (price / capacity-factor windows,
         objective and bound rewrites, real-time offer -> dispatch rows, realised state, revenue) are THREE launches of one HIP
-        kernel (dsp_wb_rolling_update, include/dsp_hip.h), bit-identical to the tensor operations they replace."""
+        kernel (dsp_wb_rolling_update, include/dsp_hip.h), bit-identical to the tensor operations they replace.
+        record: (plants, days) - keep, for these plants of the batch (local indices) and up to `days` simulated days, the state every
+        LP was built from and its whole solution, hour by hour, in device buffers (what the reference's record_results keeps per hour,
+        wind_battery_double_loop.py:276-340): `recorded()` returns them.  The writes are indexed by the device clock, so they are part
+        of the captured day like everything else."""
         import torch
         from .workflow import Tracker
         self.B = B = int(n_scenarios)
@@ -165,6 +169,7 @@ class BatchedWindBatteryDoubleLoop:
         self.da.pda_cols, self.rt.pda_cols = idx(da_model.pda_cols), idx(rt_model.pda_cols)
         # column handles of the hourly models' periods (tests map device solutions into the oracle's variables through these)
         self.rt_periods, self.tr_periods = rt_model.block.windBattery["periods"], tr_model.block.windBattery["periods"]
+        self.da_periods = da_model.block.windBattery["periods"]
         # Rolling warm start of the day-ahead LP (warm_start=True): day d + 1's 48-h problem is day d's shifted by 24 h, so period t
         # starts from yesterday's period t + 24 (the last 24 periods keep their own old values); x, y and the primal weight
         # stay on the device (dsp_batch::x0 / y0 / primal_weight) in PERSISTENT buffers that start at zero - which is the cold
@@ -213,6 +218,45 @@ class BatchedWindBatteryDoubleLoop:
             st.delivered, st.revenue, st.energy_mwh = self.delivered.data_ptr(), self.revenue.data_ptr(), self.energy_mwh.data_ptr()
             self._wb_state, self._wb_rt, self._wb_tr = st, self.rt.wb_struct(needs_state=False), self.tr.wb_struct()
         self._graphs = {}                                                  # "da" / hour of day -> captured hipGraph
+        self._rec = None
+        if record is not None:
+            plants, days = record
+            R, H = len(plants), 24 * int(days)
+            buf = lambda *shape: torch.zeros(shape, dtype=torch.float64, device=dev)
+            self._rec = dict(plants=idx(plants), days=int(days),
+                             state=buf(H + 1, R, 2), rt_x=buf(H + 1, R, self.rt.lp.n), tr_x=buf(H + 1, R, self.tr.lp.n),
+                             rt_obj=buf(H + 1, R), tr_obj=buf(H + 1, R),
+                             da_state=buf(int(days) + 1, R, 2), da_x=buf(int(days) + 1, R, self.da.lp.n), da_obj=buf(int(days) + 1, R))
+            self._day_t = torch.zeros((), dtype=torch.int64, device=dev)
+            self._limit_h = torch.full((), H, dtype=torch.int64, device=dev)      # (rows past the recorded span land in the spare last row)
+            self._limit_d = torch.full((), int(days), dtype=torch.int64, device=dev)
+
+    def _record(self, what, value, daily=False):
+        """rec[what][clock] = value[plants]   (clock read on the device: capturable)"""
+        import torch
+        r = self._rec
+        at = torch.minimum(torch.div(self.hour_t, 24, rounding_mode="floor"), self._limit_d) if daily else torch.minimum(self.hour_t, self._limit_h)
+        r[what].index_copy_(0, at.view(1), value.index_select(0, r["plants"]).unsqueeze(0))
+
+    def recorded(self):
+        """-> dict of host arrays [hours or days, plants, ...] of the recorded span (record=... at construction)"""
+        r = self._rec
+        H, D = min(self.hour, 24 * r["days"]), min(self.hour // 24, r["days"])
+        out = {k: r[k][:H].cpu().numpy() for k in ("state", "rt_x", "tr_x", "rt_obj", "tr_obj")}
+        out.update({k: r[k][:D].cpu().numpy() for k in ("da_state", "da_x", "da_obj")})
+        out["plants"] = r["plants"].cpu().numpy()
+        return out
+
+    def reset(self):
+        """Back to hour 0 with an empty battery and zeroed accumulators; handles, buffers and captured graphs are kept (they refer to
+        persistent tensors only), so a warmed-up loop can be timed from the first hour of the year."""
+        for t in (self.soc, self.thr, self.revenue, self.energy_mwh, self.da_energy_mwh, self.da_pw, self.delivered, self.hour_t, self.uncertified,
+                  self.da_offer, self.da_prices):
+            t.zero_()
+        self.bad.zero_()
+        if self.warm_start:
+            self.da_x0.zero_(), self.da_y0.zero_()
+        self.hour = self.solves = 0
 
     # -- windows -----------------------------------------------------------------------------------------------------------
     def _window(self, series, T):
@@ -262,6 +306,10 @@ class BatchedWindBatteryDoubleLoop:
                 self.da_pw.zero_()
             out = m.solve(self.B, primal_weight=self.da_pw)
         self._check(out)
+        if self._rec is not None:
+            self._record("da_state", torch.stack([self.soc, self.thr], 1), daily=True)
+            self._record("da_x", out["x"], daily=True)
+            self._record("da_obj", out["obj"], daily=True)
         self.da_offer.copy_(out["x"][:, m.pda_cols][:, :24])
         self.da_prices.copy_(da[:, :24])
         self.da_energy_mwh += self.da_offer.sum(1)
@@ -278,13 +326,21 @@ class BatchedWindBatteryDoubleLoop:
         """Device work of hour k of the day: real-time bid, stub clearing, tracking, state hand-off, clock (capturable)."""
         import torch
         if self.use_fused:
+            if self._rec is not None:
+                self._record("state", torch.stack([self.soc, self.thr], 1))
             self._fused(0, k)
             self._check(self.rt.solve(self.B))
             self._fused(1, k)
             self._check(self.tr.solve(self.B))
+            if self._rec is not None:
+                for key, m in (("rt", self.rt), ("tr", self.tr)):
+                    self._record(key + "_x", m.out["x"])
+                    self._record(key + "_obj", m.out["obj"])
             self._fused(2, k)
             return
         m = self.rt
+        if self._rec is not None:
+            self._record("state", torch.stack([self.soc, self.thr], 1))
         rt = self._window(self.rt_series, m.T)
         da = self._window(self.da_series, m.T).clone()
         known = min(m.T, 24 - k)                                         # hours of the horizon inside the cleared day
@@ -305,6 +361,10 @@ class BatchedWindBatteryDoubleLoop:
         tr.rhi[:, tr.track_rows] = offer[:, :tr.T]
         out = tr.solve(self.B)
         self._check(out)
+        if self._rec is not None:
+            for key, mm in (("rt", self.rt), ("tr", self.tr)):
+                self._record(key + "_x", mm.out["x"])
+                self._record(key + "_obj", mm.out["obj"])
         x = out["x"]
         self.delivered.copy_(tr.power_output(x)[:, 0])
         # implemented profile -> next hour's initial state, rounded to 2 dp as update_model does
@@ -368,7 +428,7 @@ class PipelinedDoubleLoops:
     batches per launch, 25 graph replays per group and day); two groups against one at 1024 / 2048 / 4096 plants: 12.9 / 17.8 / 24.0 ms
     against 13.5 / 19.9 / 28.1 (r50g).  `groups=0` picks two from 1024 plants on, else one."""
 
-    def __init__(self, n_scenarios, device=0, first_scenario=0, groups=0, **kw):
+    def __init__(self, n_scenarios, device=0, first_scenario=0, groups=0, record=None, **kw):
         import torch
         from .distributed import shard_bounds
         n = int(n_scenarios)
@@ -376,7 +436,10 @@ class PipelinedDoubleLoops:
         self.groups = G = max(1, min(G, max(n, 1)))
         self.dev = torch.device("cuda", device)
         cuts = [shard_bounds(n, G, g) for g in range(G)]
-        self.loops = [BatchedWindBatteryDoubleLoop(b1 - b0, device=device, first_scenario=first_scenario + b0, **kw) for b0, b1 in cuts]
+        # record = (plants of THIS object's batch, days): every group records its own (BatchedWindBatteryDoubleLoop.recorded)
+        rec = lambda b0, b1: None if record is None else ([p - b0 for p in record[0] if b0 <= p < b1], record[1])
+        self.record_order = None if record is None else [p for b0, b1 in cuts for p in record[0] if b0 <= p < b1]
+        self.loops = [BatchedWindBatteryDoubleLoop(b1 - b0, device=device, first_scenario=first_scenario + b0, record=rec(b0, b1), **kw) for b0, b1 in cuts]
         self.streams = [torch.cuda.Stream(device=self.dev) for _ in range(G)] if G > 1 else [None]
 
     def run_day(self):
@@ -390,6 +453,21 @@ class PipelinedDoubleLoops:
                 loop.run_day()
         for s in self.streams:
             cur.wait_stream(s)
+
+    def reset(self):
+        for l in self.loops:
+            l.reset()
+
+    def recorded(self):
+        """recorded arrays of all groups, plants in the order of `record_order` (batch indices of this object)"""
+        parts = [l.recorded() for l in self.loops if l._rec is not None and len(l._rec["plants"])]
+        out = {k: np.concatenate([p[k] for p in parts], axis=1) for k in parts[0] if k != "plants"}
+        out["plants"] = np.asarray(self.record_order)
+        return out
+
+    @property
+    def hour(self):
+        return self.loops[0].hour
 
     @property
     def revenue(self):

@@ -63,3 +63,113 @@ def check_rolling_hours_against_the_oracle(loop, hours, stride):
             check(P, mapped(P, fs, loop.tr_periods, xk, extra), ("track", h, k))
     res, ok = loop.results()
     assert ok
+
+
+# ---- the whole year: teacher-forced check of a RECORDED trajectory (BASELINE config 4) ----------------------------------------------
+_PHYS = (("W", "wind"), ("G", "grid_elec"), ("I", "elec_in"), ("O", "elec_out"), ("S", "state_of_charge"), ("E", "energy_throughput"))
+
+
+def column_maps(loop):
+    """Plain-integer description of where the three LPs of a BatchedWindBatteryDoubleLoop keep their physical columns (picklable:
+    the checks below run in worker processes)."""
+    per = lambda periods: np.array([[p[col].index for _, col in _PHYS] for p in periods], dtype=np.int64)
+    return dict(da=per(loop.da_periods), rt=per(loop.rt_periods), tr=per(loop.tr_periods),
+                da_pda=loop.da.pda_cols.cpu().numpy().astype(np.int64), rt_pda=loop.rt.pda_cols.cpu().numpy().astype(np.int64))
+
+
+def _mapped(P, fs, cols, x, extra):
+    z = np.zeros(len(P.c))
+    for t in range(len(cols)):
+        v = fs["vars"][t]
+        for j, (key, _) in enumerate(_PHYS):
+            z[v[key]] = x[cols[t, j]]
+    for j, val in extra:
+        z[j] = val
+    return z
+
+
+def _feasible_and_optimal(P, z, what, tol=1e-6):
+    """z is feasible for the oracle's rows and bounds and reaches the oracle's optimum (HiGHS) to tol; -> relative objective gap"""
+    f_ref = P.solve(tight=True)[1]
+    Az = P.A @ z
+    scale = 1.0 + np.abs(z).max()
+    assert (Az >= P.lo - 1e-7 * scale).all() and (Az <= P.hi + 1e-7 * scale).all(), (what, "rows")
+    assert (z >= P.lb - 1e-7 * scale).all() and (z <= P.ub + 1e-7 * scale).all(), (what, "bounds")
+    f = float(P.c @ z + P.c0)
+    gap = abs(f - f_ref) / max(1.0, abs(f_ref))
+    assert gap <= tol, (what, f, f_ref)
+    return gap
+
+
+def check_recorded_plant(args, base_hour=0, base_day=0):
+    """Every recorded LP of ONE plant over the hours `hours`, against the oracle's own LPs of the recorded state (oracle/double_loop_oracle.py):
+    the day-ahead LP of every day touched, the real-time bidding LP and the tracking LP of every hour - each solution, mapped into the
+    oracle's variables, must be feasible for the oracle's rows and optimal to 1e-6 - and the state hand-off itself: the state an hour
+    starts from is the previous hour's tracking solution rounded to 2 dp (wind_battery_double_loop.py:194-200), the tracker's dispatch is
+    the real-time offer, the day-ahead position of an hour is that day's offer.
+    args = (plant id k, stride, maps, rec arrays of this plant, hours) -> dict(worst gaps, per-day revenue / delivered / soc).
+    base_hour / base_day: the simulated hour / day the first row of the hourly / daily arrays belongs to (a block of a longer run)."""
+    from oracle import double_loop_oracle as dl
+    k, stride, maps, rec, hours = args
+    year = dl.load_year()
+    da_s, rt_s, cf_s = year
+    N = len(rt_s)
+    start = (stride * k) % N
+    T = maps["rt"].shape[0]
+    Tda = maps["da"].shape[0]
+    pt = lambda cols, x: 1e-3 * (x[cols[:, 1]] + x[cols[:, 3]])
+    worst = dict(da=0.0, rt=0.0, tr=0.0)
+    hours = sorted(int(i) for i in hours)
+    n_days = len(rec["da_obj"])
+    revenue, delivered_mwh, soc_end = np.zeros(n_days), np.zeros(n_days), np.full(n_days, np.nan)
+    checked_days = set()
+    H = lambda i: i - base_hour                    # row of an hourly array
+    for i in hours:
+        d, h = divmod(i, 24)
+        d -= base_day                               # row of a daily array; 24 * (d + base_day) + h = i
+        x_da = rec["da_x"][d]
+        offer = x_da[maps["da_pda"]][:24]
+        prices = dl.window(da_s, start, 24 * (d + base_day), 24)
+        if d not in checked_days:
+            checked_days.add(d)
+            da, rt, cf = (dl.window(s, start, 24 * (d + base_day), Tda) for s in year)
+            soc, thr = rec["da_state"][d]
+            P, fs, pda, u = dl.day_ahead_lp(cf, da, rt, float(soc), float(thr))
+            ptd = pt(maps["da"], x_da)
+            xp = x_da[maps["da_pda"]]
+            extra = [(pda[t], xp[t]) for t in range(Tda)] + [(u[t], max(0.0, xp[t] - ptd[t])) for t in range(Tda)]
+            worst["da"] = max(worst["da"], _feasible_and_optimal(P, _mapped(P, fs, maps["da"], x_da, extra), ("da", k, d + base_day)))
+            # the day starts from the state the loop carried there
+            assert (rec["da_state"][d] == rec["state"][H(24 * (d + base_day))]).all(), ("day-ahead state", k, d + base_day)
+        soc, thr = (float(v) for v in rec["state"][H(i)])
+        if H(i) > 0:
+            prev = rec["tr_x"][H(i) - 1]
+            # the state this hour starts from is a 2-dp value within half a cent of what the tracker realised the hour before
+            # (the device rounds half away from zero on the binary value, Python's round half to even on the decimal one)
+            for got, col in ((soc, 4), (thr, 5)):
+                real = float(prev[maps["tr"][0, col]])
+                assert abs(got - real) <= 0.005 + 1e-9 * max(1.0, abs(real)) and abs(got * 100 - round(got * 100)) <= 1e-6 * max(1.0, abs(got)), ("state hand-off", k, i, got, real)
+        rt, cf, daw = (dl.window(s, start, i, T) for s in (rt_s, cf_s, da_s))
+        known = min(T, 24 - h)
+        daw = daw.copy()
+        daw[:known] = prices[h:h + known]
+        cleared = np.zeros(T)
+        cleared[:known] = offer[h:h + known]
+        x = rec["rt_x"][H(i)]
+        P, fs, u, pda = dl.real_time_lp(cf, rt, daw, cleared, known, soc, thr)
+        ptr = pt(maps["rt"], x)
+        xp = x[maps["rt_pda"]]
+        assert np.abs(xp[:known] - cleared[:known]).max() <= 1e-9 * 225, ("cleared day-ahead position", k, i)
+        pos = np.where(np.arange(T) < known, cleared, xp)
+        extra = [(u[t], max(0.0, pos[t] - ptr[t])) for t in range(T)] + [(pda[t], xp[t]) for t in range(known, T)]
+        worst["rt"] = max(worst["rt"], _feasible_and_optimal(P, _mapped(P, fs, maps["rt"], x, extra), ("rt", k, i)))
+        x = rec["tr_x"][H(i)]
+        P, fs, under, over = dl.tracking_lp(cf, ptr, soc, thr)
+        ptt = pt(maps["tr"], x)
+        extra = [(under[t], max(0.0, ptr[t] - ptt[t])) for t in range(T)] + [(over[t], max(0.0, ptt[t] - ptr[t])) for t in range(T)]
+        worst["tr"] = max(worst["tr"], _feasible_and_optimal(P, _mapped(P, fs, maps["tr"], x, extra), ("tr", k, i)))
+        revenue[d] += ptt[0] * rt[0] + offer[h] * (prices[h] - rt[0])
+        delivered_mwh[d] += ptt[0]
+        if h == 23:
+            soc_end[d] = round(float(x[maps["tr"][0, 4]]), 2)
+    return dict(plant=k, worst=worst, hours=len(hours), revenue=revenue, delivered=delivered_mwh, soc=soc_end)

@@ -159,3 +159,89 @@ def test_pipelined_groups_reproduce_the_single_loop():
     for k in ("obj", "energy_mwh", "soc", "throughput"):
         assert torch.equal(r1[k], r2[k]), k
     assert int(two.uncertified) == int(one.uncertified) == 0
+
+
+@gpu
+def test_full_year_double_loop_8192_plants_against_the_oracle():
+    """BASELINE config 4 as it is written: 8192 plants, 366 simulated days (8784 hand-offs; the data holds 8736 hours, so EVERY plant's
+    windows wrap the data end - parametrized_bidder.py:52-58, wind_battery_double_loop.py:211-228), 147 M LP solves, the two-group
+    pipelined loop replayed from hipGraphs as bench.py runs it.
+
+    16 plants of the batch (tools/make_rolling_year_fixture.py::PLANTS: both groups, the shard edges of an 8-way split, plants that wrap
+    in their first day) are RECORDED hour by hour on the device and checked two ways:
+      1. teacher forced, every hour of the year: each of the 17 934 LPs of a plant is rebuilt by the oracle from the state the loop
+         recorded (oracle/double_loop_oracle.py, un-reduced rows, HiGHS); the loop's solution mapped into the oracle's variables is
+         feasible and optimal to 1e-6, and every state hand-off is the 2-dp rounding of what the tracker realised the hour before;
+      2. against the committed FREE-RUN trajectory of the oracle for the same plants (tests/golden/rolling_year.npz): day-by-day
+         revenue, delivered energy and end-of-day state of charge.  The hourly LPs are degenerate (a fifth of the prices are exactly 0),
+         so two solvers may part at a tie; the test reports the days that agree to 1e-6 and requires the annual totals to 1e-3."""
+    import multiprocessing as mp
+    import os
+    import time
+    import torch
+    from dispatches_amd.rolling import PipelinedDoubleLoops
+    from tests._rolling_oracle import check_recorded_plant, column_maps
+    from tools.make_rolling_year_fixture import PLANTS
+    fx = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "rolling_year.npz"))
+    assert list(fx["plants"]) == PLANTS
+    B, days = 8192, int(os.environ.get("DSP_YEAR_DAYS", "366"))
+    assert days <= int(fx["days"])
+    loops = PipelinedDoubleLoops(B, device=0, record=(PLANTS, days))
+    t0 = time.perf_counter()
+    for _ in range(days):
+        loops.run_day()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    res, ok = loops.results()
+    assert ok, "a non-optimal solve entered the year"
+    assert int(loops.uncertified.item()) == 0
+    rec = loops.recorded()
+    assert list(rec["plants"]) == PLANTS and rec["state"].shape[0] == 24 * days
+    maps = column_maps(loops.loops[0])
+    # one task per (plant, block of days): the GPU box has far more cores than plants
+    block = 6
+    tasks = []
+    for j, k in enumerate(PLANTS):
+        mine = {key: np.ascontiguousarray(v[:, j]) for key, v in rec.items() if key != "plants"}
+        for d0 in range(0, days, block):
+            d1 = min(days, d0 + block)
+            # every task carries the hour before its block too (the hand-off into the block's first hour is checked against it)
+            h0, h1 = 24 * d0, 24 * d1
+            part = {key: (v[d0:d1] if key.startswith("da_") else v[max(h0 - 1, 0):h1]) for key, v in mine.items()}
+            tasks.append((k, j, d0, d1, part, h0))
+    t1 = time.perf_counter()
+    with mp.get_context("fork").Pool(min(len(tasks), max(1, (os.cpu_count() or 2) - 2))) as pool:
+        outs = pool.map(_year_block, [(t, maps) for t in tasks], chunksize=1)
+    check_wall = time.perf_counter() - t1
+    revenue, delivered, soc = (np.zeros((len(PLANTS), days)) for _ in range(3))
+    worst = dict(da=0.0, rt=0.0, tr=0.0)
+    hours = 0
+    for (k, j, d0, d1, _, _), o in zip(tasks, outs):
+        revenue[j, d0:d1], delivered[j, d0:d1], soc[j, d0:d1] = o["revenue"], o["delivered"], o["soc"]
+        hours += o["hours"]
+        for key in worst:
+            worst[key] = max(worst[key], o["worst"][key])
+    assert hours == len(PLANTS) * 24 * days
+    # the loop's own annual accumulators are the sums of what was recorded
+    total = res["obj"].cpu().numpy()[PLANTS]
+    assert np.allclose(total, revenue.sum(1), rtol=1e-9), (total, revenue.sum(1))
+    # 2. the oracle's free-run trajectory
+    rel = lambda a, b: np.abs(a - b) / np.maximum(1.0, np.abs(b))
+    day_err = rel(revenue, fx["revenue"][:, :days])
+    same = (day_err <= 1e-6) & (np.abs(soc - fx["soc"][:, :days]) <= 0.011)
+    first_split = [int(np.argmin(s)) if not s.all() else days for s in same]
+    annual = rel(revenue.sum(1), fx["revenue"][:, :days].sum(1))
+    energy = rel(delivered.sum(1), fx["delivered"][:, :days].sum(1))
+    print(f"\n[year] {B} plants x {days} days in {wall:.1f} s ({1e3 * wall / days:.1f} ms per simulated day, first day eager); {hours} recorded hours "
+          f"checked against the oracle in {check_wall:.0f} s: worst objective gap day-ahead {worst['da']:.2e}, real-time {worst['rt']:.2e}, tracking {worst['tr']:.2e}; "
+          f"free-run fixture: {int(same.sum())} of {same.size} plant-days agree to 1e-6 (first differing day per plant {first_split}), annual revenue within "
+          f"{annual.max():.2e}, delivered energy within {energy.max():.2e}")
+    assert annual.max() <= 1e-3 and energy.max() <= 1e-3, (annual, energy)
+
+
+def _year_block(arg):
+    from tests._rolling_oracle import check_recorded_plant
+    (k, j, d0, d1, part, h0), maps = arg
+    # re-base the block: the oracle check indexes hours / days from the plant's first recorded hour
+    lead = 1 if h0 > 0 else 0
+    return check_recorded_plant((k, 17, maps, part, range(h0, 24 * d1)), base_hour=h0 - lead, base_day=d0)
