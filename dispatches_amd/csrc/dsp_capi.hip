@@ -176,6 +176,7 @@ __global__ void __launch_bounds__(256) wb_rolling_kernel(dsp_wb_state s, dsp_wb_
     const dsp_wb_model &m = rt;
     const int known = min(m.T, 24 - k);
     double *c = m.c + (size_t)b * m.n, *lb = m.lb + (size_t)b * m.n, *ub = m.ub + (size_t)b * m.n;
+    double avail_sum = 0.0;
     for (int t = 0; t < m.T; ++t) {
       const double rtp = win(s.rt_series, t);
       const double dap = t < known ? s.da_prices[(size_t)b * 24 + k + t] : win(s.da_series, t);
@@ -183,23 +184,30 @@ __global__ void __launch_bounds__(256) wb_rolling_kernel(dsp_wb_state s, dsp_wb_
       c[m.pt_cols[t][0]] = __dsub_rn(m.base_c[m.pt_cols[t][0]], r3);
       c[m.pt_cols[t][1]] = __dsub_rn(m.base_c[m.pt_cols[t][1]], r3);
       c[m.pda_cols[t]] = __dsub_rn(m.base_c[m.pda_cols[t]], wb_opaque(__dsub_rn(dap, rtp)));
-      ub[m.wind_cols[t]] = __dmul_rn(m.wind_kw, win(s.cf_series, t));
+      const double avail = __dmul_rn(m.wind_kw, win(s.cf_series, t));
+      ub[m.wind_cols[t]] = avail;
+      avail_sum = t ? __dadd_rn(avail_sum, avail) : avail;
       const double fix = t < known ? s.da_offer[(size_t)b * 24 + k + t] : 0.0;
       lb[m.pda_cols[t]] = fix;
       ub[m.pda_cols[t]] = t < known ? fix : INFINITY;
     }
+    if (m.c0) m.c0[b] = __dadd_rn(m.c0_base, wb_opaque(__dmul_rn(m.waste_per_kw, avail_sum)));
     lb[m.soc_init] = s.soc[b]; ub[m.soc_init] = s.soc[b];
     lb[m.thr_init] = s.thr[b]; ub[m.thr_init] = s.thr[b];
   } else if (phase == 1) {
     const double *xr = rt.x + (size_t)b * rt.n;
     double *lb = tr.lb + (size_t)b * tr.n, *ub = tr.ub + (size_t)b * tr.n;
     double *rlo = tr.rlo + (size_t)b * tr.m, *rhi = tr.rhi + (size_t)b * tr.m;
+    double avail_sum = 0.0;
     for (int t = 0; t < tr.T; ++t) {
       const double offer = __dmul_rn(1e-3, wb_opaque(__dadd_rn(xr[rt.pt_cols[t][0]], xr[rt.pt_cols[t][1]])));
       rlo[tr.track_rows[t]] = offer;
       rhi[tr.track_rows[t]] = offer;
-      ub[tr.wind_cols[t]] = __dmul_rn(tr.wind_kw, win(s.cf_series, t));
+      const double avail = __dmul_rn(tr.wind_kw, win(s.cf_series, t));
+      ub[tr.wind_cols[t]] = avail;
+      avail_sum = t ? __dadd_rn(avail_sum, avail) : avail;
     }
+    if (tr.c0) tr.c0[b] = __dadd_rn(tr.c0_base, wb_opaque(__dmul_rn(tr.waste_per_kw, avail_sum)));
     lb[tr.soc_init] = s.soc[b]; ub[tr.soc_init] = s.soc[b];
     lb[tr.thr_init] = s.thr[b]; ub[tr.thr_init] = s.thr[b];
   } else {
@@ -214,6 +222,14 @@ __global__ void __launch_bounds__(256) wb_rolling_kernel(dsp_wb_state s, dsp_wb_
     s.revenue[b] = __dadd_rn(s.revenue[b], wb_opaque(__dadd_rn(t1, t2)));
     s.energy_mwh[b] = __dadd_rn(s.energy_mwh[b], delivered);
   }
+}
+
+// Zeroes the few ints of a work-queue slot before a solve.  A KERNEL, not hipMemsetAsync: captured into a hipGraph (the rolling loop
+// replays its days from graphs) the memset node did not reliably run again on replay (ROCm 7.2, round 6: profiles/r60b_graph_memset.log) -
+// the queue head then still held B + waves from the previous replay, every wave left at its first pull, and the day-ahead solve of
+// every later day silently returned the captured day's outputs.
+__global__ void queue_reset_kernel(int *q, int n) {
+  if ((int)threadIdx.x < n) q[threadIdx.x] = 0;
 }
 
 // the clock advances AFTER every plant has read it (own launch: stream order is the barrier)
@@ -275,6 +291,7 @@ void dsp_default_options(dsp_options *o) {
   o->no_rtc = 0;
   o->no_interior_point = 0;
   o->eps_infeasible = 1e-6;
+  o->recertify_passes = 0;
 }
 
 int dsp_version(void) { return DSP_VERSION; }
@@ -513,7 +530,7 @@ int dsp_solve(dsp_handle *h, const dsp_batch *batch, const dsp_options *opt, dsp
     const unsigned slot32 = h->queue_next.fetch_add(1u) % kQueueRing;
     a.queue = h->queue + (size_t)slot32 * kQueueStride;
     a.qp = qp;
-    HIP_TRY(hipMemsetAsync(a.queue, 0, 2 * sizeof(int), st));
+    hipLaunchKernelGGL(queue_reset_kernel, dim3(1), dim3(64), 0, st, a.queue, 2);
     const bool timed32 = stats && sync_stats;
     if (timed32) HIP_TRY(hipEventRecord(h->ev0, st));
     int grid32 = 0, threads32 = 0;
@@ -552,8 +569,9 @@ int dsp_solve(dsp_handle *h, const dsp_batch *batch, const dsp_options *opt, dsp
   a.queue = h->queue + (size_t)slot * kQueueStride;
   a.queue_base = 0u;
   a.unsolved = a.queue + 1;
-  a.suspects = a.queue + 2;                          // (+ 3: the work-queue head of the certificate pass)
-  HIP_TRY(hipMemsetAsync(a.queue, 0, 4 * sizeof(int), st));
+  a.suspects = a.queue + 2;                          // (+ 3: the work-queue head of the certificate pass; + 4: count of scenarios flagged
+                                                     //  DSP_FLAG_OBJ_WAIVED; + 5 .. 7: heads of the re-certification passes)
+  hipLaunchKernelGGL(queue_reset_kernel, dim3(1), dim3(64), 0, st, a.queue, 8);
   a.matreg = qp ? h->matreg_qp : h->matreg;
   a.qp = qp;
 #ifdef DSP_KKT_TRACE
@@ -627,6 +645,35 @@ int dsp_solve(dsp_handle *h, const dsp_batch *batch, const dsp_options *opt, dsp
       const int want = nsus > 0 ? (nsus + cert_wpb - 1) / cert_wpb : (cert_grid_env > 0 ? cert_grid_env : 8);
       const int grid2 = std::max(1, std::min(std::min((B + cert_wpb - 1) / cert_wpb, want), 2 * h->num_cus));
       HIP_TRY(launch_solve(h->cpl, h->rpl, c, dim3(grid2), dim3(64 * cert_wpb), cert_lds, st));
+    }
+  }
+  if (a.opt.recertify_passes > 0 && batch->flags) {
+    // Re-certification passes (dsp_options::recertify_passes): scenarios the passes above accepted with DSP_FLAG_OBJ_WAIVED - the objective-error
+    // bound stuck within 10 eps_obj while the objective itself had stopped - are solved again from a cold start under another restart
+    // cadence / weight controller, on the device, by the generic kernel; a certified optimum replaces the flagged point, anything else
+    // leaves it (and its flag) in place.  Each pass returns at its first line when the device-side count of flagged scenarios is 0:
+    // almost every batch (one flagged solve in the 147 M of a simulated year of the rolling loop).  What HipPdlpSolver._recertify does
+    // from the host for synchronous callers, for callers that never look (hipGraph replays, pipelined batches).
+    static const struct { double pid_kp, restart_artificial; int check_every; } kRecertify[3] = {{0.45, 0.3, 0}, {0.8, 0.15, 0}, {0.3, 0.5, 12}};
+    int rwpb = 0;
+    size_t rlds = 0;
+    for (int wpb = 1; wpb <= 4; ++wpb) {
+      const size_t l = lds_bytes(h->P, wpb, 0, h->cpl, h->rpl);
+      if (l <= (size_t)h->lds_limit) { rwpb = wpb; rlds = l; }
+    }
+    for (int v = 0; rwpb && v < std::min(a.opt.recertify_passes, 3); ++v) {
+      SolveArgs c = a;
+      c.matreg = 0;
+      c.skip_solved = 3;
+      c.queue = a.queue + 5 + v;
+      c.b.x0 = nullptr; c.b.y0 = nullptr;
+      c.waves_per_block = rwpb;
+      c.opt.pid_kp = kRecertify[v].pid_kp;
+      c.opt.restart_artificial = kRecertify[v].restart_artificial;
+      if (kRecertify[v].check_every) c.opt.check_every = kRecertify[v].check_every;
+      c.opt.polish_patience = std::max(c.opt.polish_patience, 1024);       // (a pass that waives as readily as the first certifies nothing)
+      const int rgrid = std::max(1, std::min((B + rwpb - 1) / rwpb, 64));
+      HIP_TRY(launch_solve(h->cpl, h->rpl, c, dim3(rgrid), dim3(64 * rwpb), rlds, st));
     }
   }
   if (timed) HIP_TRY(hipEventRecord(h->ev1, st));

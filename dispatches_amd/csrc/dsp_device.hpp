@@ -76,6 +76,8 @@ struct SolveArgs {
   dsp_batch b;
   int skip_solved;             // 1 = only scenarios whose status is DSP_STATUS_UNSOLVED are solved (after the simplex pass);
                                // 2 = only DSP_STATUS_SUSPECT ones, continued from the iterate in b.x / b.y (certificate pass)
+                               // 3 = only OPTIMAL ones flagged DSP_FLAG_OBJ_WAIVED, from a cold start; results replace the earlier
+                               //     ones only when certified (re-certification pass, dsp_options::recertify_passes)
   int waves_per_block;
   double eta;
   dsp_options opt;
@@ -86,7 +88,8 @@ struct SolveArgs {
   int qp;                      // 1 = soft rows present (b.row_compliance): QP instantiation
   double *trace;               // development (-DDSP_KKT_TRACE, DSP_TRACE_SCENARIO): [4096][12] KKT history of one scenario
   int trace_scenario;
-  int *suspects;               // scenarios the register-resident kernel left DSP_STATUS_SUSPECT (0 = the certificate pass has nothing to do)
+  int *suspects;               // scenarios the register-resident kernel left DSP_STATUS_SUSPECT (0 = the certificate pass has nothing to do);
+                               // suspects[2]: scenarios currently flagged DSP_FLAG_OBJ_WAIVED (0 = the re-certification passes have nothing to do)
 };
 
 // Layout token of the kernarg buffer: a run-time compiled kernel (dsp_rtc.hpp) receives SolveArgs as raw bytes and is compiled

@@ -214,6 +214,8 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
   if (a.skip_solved == 1 && __builtin_amdgcn_readfirstlane(*a.unsolved) == 0) return;
   // certificate pass (below: CERT) after a register-resident kernel that left no suspect: nothing to do either
   if (a.skip_solved == 2 && __builtin_amdgcn_readfirstlane(*a.suspects) == 0) return;
+  // re-certification pass (dsp_options::recertify_passes; generic kernels only) with no scenario left flagged DSP_FLAG_OBJ_WAIVED: nothing to do
+  if constexpr (!MATREG) if (a.skip_solved == 3 && __builtin_amdgcn_readfirstlane(a.suspects[2]) == 0) return;
   // Infeasibility / unboundedness certificates (dsp_options::eps_infeasible).  The generic kernels evaluate them themselves, at
   // restarts.  The register-resident kernels do NOT carry that code: on the 48-h shape - 246 of 256 VGPRs are live state - the two
   // extra products in a rare block made the allocator spill on the common paths (-10 % on the whole batch, -2 % on the 24-h
@@ -385,9 +387,13 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
     if ((unsigned)s >= (unsigned)b.B) break;
     if (a.skip_solved == 1 && __builtin_amdgcn_readfirstlane(b.status[s]) != DSP_STATUS_UNSOLVED) continue;
     if (a.skip_solved == 2 && __builtin_amdgcn_readfirstlane(b.status[s]) != DSP_STATUS_SUSPECT) continue;
-    // (certificate pass: the iterations the first pass spent on the scenario count; the limit covers both passes)
-    const int it_base = (a.skip_solved == 2 && b.iters) ? __builtin_amdgcn_readfirstlane(b.iters[s]) : 0;
-    const int max_it = max(a.opt.max_iter - it_base, 1);
+    // re-certification pass: only scenarios the earlier passes accepted WITHOUT a certified objective accuracy, from a cold start under
+    // this launch's options (another restart cadence / weight controller: dsp_capi.hip, kRecertify)
+    if constexpr (!MATREG) if (a.skip_solved == 3 && !(__builtin_amdgcn_readfirstlane(b.status[s]) == DSP_STATUS_OPTIMAL && (__builtin_amdgcn_readfirstlane(b.flags[s]) & DSP_FLAG_OBJ_WAIVED))) continue;
+    // (certificate pass: the iterations the first pass spent on the scenario count; the limit covers both passes.  Re-certification:
+    //  they count too, the limit is this pass's own)
+    const int it_base = ((MATREG ? a.skip_solved == 2 : a.skip_solved >= 2) && b.iters) ? __builtin_amdgcn_readfirstlane(b.iters[s]) : 0;
+    const int max_it = (!MATREG && a.skip_solved == 3) ? a.opt.max_iter : max(a.opt.max_iter - it_base, 1);
 
     // ---- load + scale this scenario's vectors (coalesced: lane-consecutive addresses) -----------------------
     double x[CPL], x0[CPL], c[CPL], lb[CPL], ub[CPL];
@@ -963,6 +969,12 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
 #undef DSP_HALPERN_STEP
 
     DSP_TRACE("[trace] store status=%d it=%d\n", status, it);
+    if constexpr (!MATREG) if (a.skip_solved == 3) {
+      // re-certification: only a CERTIFIED optimum replaces the point the earlier pass accepted; the work is accounted either way
+      if (lane == 0 && b.iters) b.iters[s] = it + it_base;
+      if (status != DSP_STATUS_OPTIMAL || waive_obj) continue;
+      if (lane == 0) atomicSub(a.suspects + 2, 1);
+    }
     // ---- store the scenario's result (unscaled) ----------------------------------------------------------
     if (status != DSP_STATUS_OPTIMAL) {
       double po = 0.0;
@@ -997,6 +1009,7 @@ __global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 
       b.status[s] = status;
       if (b.iters) b.iters[s] = it + it_base;
       if (status == DSP_STATUS_SUSPECT) atomicAdd(a.suspects, 1);
+      if (waive_obj && status == DSP_STATUS_OPTIMAL) atomicAdd(a.suspects + 2, 1);      // count of flagged scenarios (re-certification pass)
 #ifdef DSP_CLOCKS
       iters_done += it;
 #endif

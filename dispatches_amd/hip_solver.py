@@ -29,7 +29,7 @@ class DspOptions(C.Structure):
                 ("waves_per_block", C.c_int32), ("kkt_every", C.c_int32), ("no_matreg", C.c_int32), ("geo_iters", C.c_int32),
                 ("kkt_gate", C.c_double), ("stall_rescue", C.c_int32), ("no_simplex", C.c_int32),
                 ("jump_rel", C.c_double), ("precision", C.c_int32), ("polish_patience", C.c_int32), ("no_rtc", C.c_int32), ("no_interior_point", C.c_int32),
-                ("eps_infeasible", C.c_double)]
+                ("eps_infeasible", C.c_double), ("recertify_passes", C.c_int32), ("reserved0", C.c_int32)]
 
 
 class DspBatch(C.Structure):
@@ -69,7 +69,8 @@ class DspWbModel(C.Structure):
                 ("n", C.c_int32), ("m", C.c_int32), ("T", C.c_int32),
                 ("soc_init", C.c_int32), ("thr_init", C.c_int32), ("soc0", C.c_int32), ("thr0", C.c_int32),
                 ("wind_cols", C.c_int32 * 8), ("pt_cols", (C.c_int32 * 2) * 8), ("pda_cols", C.c_int32 * 8),
-                ("track_rows", C.c_int32 * 8), ("wind_kw", C.c_double)]
+                ("track_rows", C.c_int32 * 8), ("wind_kw", C.c_double),
+                ("c0", C.c_void_p), ("c0_base", C.c_double), ("waste_per_kw", C.c_double)]
 
 
 class DspWbState(C.Structure):
@@ -85,7 +86,7 @@ EXPORTED_SYMBOLS = ("dsp_default_options", "dsp_create", "dsp_solve", "dsp_spmv_
                     "dsp_rtc_compile_check", "dsp_rtc_message", "dsp_wb_rolling_update", "dsp_source_hash")
 
 
-ABI_VERSION = 10         # DSP_VERSION of the include/dsp_hip.h these structures mirror
+ABI_VERSION = 11         # DSP_VERSION of the include/dsp_hip.h these structures mirror
 
 
 BID_MAX_HOURS, BID_MAX_SCENARIOS = 64, 16384

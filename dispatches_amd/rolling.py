@@ -43,9 +43,19 @@ class _NoSolver:
 class _DeviceModel:
     """One of the three LPs on the device: handle + per-scenario tensors + the index sets the rolling updates touch."""
 
-    def __init__(self, model, B, dev, device_index, hints=None, lp_backend=None):
+    def __init__(self, model, B, dev, device_index, hints=None, lp_backend=None, waste_cost_per_kw=None, cf_template_sum=0.0):
         import torch
         self.lp = model.lp
+        # objective constant of every plant (dsp_batch::obj_offset: the scale of the solver's objective-accuracy test - the reference's
+        # objective INCLUDES the constants of tot_cost, wind_battery_double_loop.py:175-177, above all waste penalty x available wind,
+        # which is ~100 x the objective itself on a windy day): the template's constant with the template window's curtailment term
+        # swapped for the plant's own (scenarios._apply_cf_windows).  None = not maintained (LPs the simplex solves to a vertex).
+        self.c0 = None
+        if waste_cost_per_kw is not None:
+            self.c0 = torch.zeros(B, dtype=torch.float64, device=dev)
+            base = float(model.base_c0) if hasattr(model, "base_c0") else float(np.asarray(model.c0).ravel()[0])
+            self._c0_base = base - float(waste_cost_per_kw) * float(model.block.windBattery["wind_kw"]) * float(cf_template_sum)
+            self._waste_per_kw = float(waste_cost_per_kw)
         self.T = len(model.HOUR)
         t = lambda a, dt=torch.float64: torch.as_tensor(np.ascontiguousarray(a), dtype=dt, device=dev)
         lb, ub, rlo, rhi = model.block.current_bounds()
@@ -66,7 +76,9 @@ class _DeviceModel:
         # P_T[t] = 1e-3 (grid_elec[t] + elec_out[t]): the two columns of every hour
         self.pt_cols = idx([[p["grid_elec"].index, p["elec_out"].index] for p in per])       # [T, 2]
         if lp_backend is None:
-            self.opts = default_options(**(hints or {}))
+            # recertify: the loop never reads a flag back between solves (its days are hipGraph replays), so a solve accepted without a
+            # certified objective accuracy is re-solved on the device under other settings (dsp_options::recertify_passes)
+            self.opts = default_options(**{"recertify_passes": 3, **(hints or {})})
             self.dlp = DeviceLP(self.lp, device_index, self.opts)
             # output buffers with fixed addresses from the start (the fused update kernel and the hipGraphs hold pointers)
             n, m = self.lp.n, max(self.lp.m, 1)
@@ -104,6 +116,8 @@ class _DeviceModel:
             w.pda_cols[t] = pda[t] if t < len(pda) else -1
             w.track_rows[t] = trk[t] if t < len(trk) else -1
         w.wind_kw = self.wind_kw
+        if self.c0 is not None:
+            w.c0, w.c0_base, w.waste_per_kw = self.c0.data_ptr(), self._c0_base, self._waste_per_kw
         return w
 
     def power_output(self, x):
@@ -112,7 +126,7 @@ class _DeviceModel:
     def solve(self, B, x0=None, y0=None, primal_weight=None):
         self.out = self.dlp.solve(B, self.c, self.lb, self.ub, self.rlo if self.lp.m else None,
                                   self.rhi if self.lp.m else None, x0=x0, y0=y0, primal_weight=primal_weight,
-                                  options=self.opts, out=self.out, sync_stats=False)
+                                  options=self.opts, out=self.out, sync_stats=False, obj_offset=self.c0)
         return self.out
 
 
@@ -160,13 +174,19 @@ class BatchedWindBatteryDoubleLoop:
         tracker._pass_market_dispatch([0.0] * tracking_horizon)           # dispatch rows become equalities
         tr_model = tracker.model
         self.penalty = float(bidder.real_time_underbid_penalty)
-        self.da = _DeviceModel(da_model, B, dev, device, hints=getattr(da_model, "solver_hints", None), lp_backend=lp_backend)
-        self.rt = _DeviceModel(rt_model, B, dev, device, hints=getattr(rt_model, "solver_hints", None), lp_backend=lp_backend)
-        self.tr = _DeviceModel(tr_model, B, dev, device, hints=getattr(tr_model, "solver_hints", None), lp_backend=lp_backend)
+        self.da = _DeviceModel(da_model, B, dev, device, hints=getattr(da_model, "solver_hints", None), lp_backend=lp_backend,
+                               waste_cost_per_kw=bidder.bidding_model_object.wind_waste_penalty * 1e-3,
+                               cf_template_sum=float(np.sum(s["rt_cf"][:day_ahead_horizon])))
+        waste = bidder.bidding_model_object.wind_waste_penalty * 1e-3
+        self.rt = _DeviceModel(rt_model, B, dev, device, hints=getattr(rt_model, "solver_hints", None), lp_backend=lp_backend,
+                               waste_cost_per_kw=waste, cf_template_sum=float(np.sum(s["rt_cf"][:real_time_horizon])))
+        self.tr = _DeviceModel(tr_model, B, dev, device, hints=getattr(tr_model, "solver_hints", None), lp_backend=lp_backend,
+                               waste_cost_per_kw=waste, cf_template_sum=float(np.sum(s["rt_cf"][:tracking_horizon])))
         if self.tr.thr0 is None:
             raise ValueError("the tracking model must carry period 0's throughput as a column: the loop reads the realised state from it")
         idx = lambda cols: torch.as_tensor(np.asarray(cols, np.int64), device=dev)
         self.da.pda_cols, self.rt.pda_cols = idx(da_model.pda_cols), idx(rt_model.pda_cols)
+        self.da.u_cols, self.rt.u_cols = (idx([v.index for v in mm.real_time_underbid_power]) for mm in (da_model, rt_model))
         # column handles of the hourly models' periods (tests map device solutions into the oracle's variables through these)
         self.rt_periods, self.tr_periods = rt_model.block.windBattery["periods"], tr_model.block.windBattery["periods"]
         self.da_periods = da_model.block.windBattery["periods"]
@@ -278,7 +298,13 @@ class BatchedWindBatteryDoubleLoop:
         m.ub[:, m.soc_init] = self.soc
         m.lb[:, m.thr_init] = self.thr
         m.ub[:, m.thr_init] = self.thr
-        m.ub[:, m.wind_cols] = m.wind_kw * self._window(self.cf_series, m.T)
+        avail = m.wind_kw * self._window(self.cf_series, m.T)
+        m.ub[:, m.wind_cols] = avail
+        if m.c0 is not None:
+            total = avail[:, 0]
+            for t in range(1, m.T):                # (in the order of the fused kernel's loop: bit-identical constants)
+                total = total + avail[:, t]
+            m.c0.copy_(m._c0_base + m._waste_per_kw * total)
 
     def _check(self, out):
         self.bad |= (out["status"] != 0).any()

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define DSP_VERSION 10
+#define DSP_VERSION 11
 
 /* return codes (0 = ok, < 0 = API misuse / HIP error; text via dsp_strerror) */
 #define DSP_OK                 0
@@ -195,6 +195,15 @@ typedef struct dsp_options {
                                 certificate sequence the host enqueues at most every 16 check periods while suspects exist.  Reference
                                 behaviour: the solver's termination condition, on which the callers act (case_studies/renewables_case/
                                 solar_battery_hydrogen.py:451-458).  0 = off                                        default 1e-6 */
+  int32_t recertify_passes;       /* N = 1 .. 3 (ABI 11, fused path): scenarios the solve accepted WITHOUT a certified objective accuracy
+                                (DSP_FLAG_OBJ_WAIVED) are solved again ON THE DEVICE, from a cold start, under up to N other restart /
+                                weight-controller settings; a certified optimum replaces the flagged point and clears the flag, anything
+                                else leaves both in place.  Each pass is one more launch that returns at once while no scenario of the
+                                batch is flagged.  For callers that never read the flags back between solves - the rolling double loop
+                                replays its simulated days from hipGraphs; the reference re-solves nothing, its solver either converges
+                                or the run stops (idaes Bidder: `assert_optimal_termination`).  0 = off (a synchronous caller re-solves
+                                flagged scenarios itself: hip_solver.HipPdlpSolver)                                  default 0    */
+  int32_t reserved0;
 } dsp_options;
 
 /* The per-call data of B scenarios.  c is required; every other input may be NULL (= no bound: -inf / +inf,
@@ -316,6 +325,8 @@ typedef struct dsp_wb_model {
   int32_t pda_cols[8];                 /* day-ahead power column of every period (bidding models), -1 otherwise               */
   int32_t track_rows[8];               /* dispatch rows (tracking model), -1 otherwise                                        */
   double wind_kw;
+  double *c0;                          /* [B] objective constant of every plant (dsp_batch::obj_offset of its solves) or NULL    */
+  double c0_base, waste_per_kw;        /* c0 = c0_base + waste_per_kw * sum_t (wind availability of period t)   (ABI 11)         */
 } dsp_wb_model;
 
 typedef struct dsp_wb_state {

@@ -22,11 +22,13 @@ Two ways to run it:
   * free run (`roll`): the oracle's own trajectory from its own solutions.  The hourly LPs are DEGENERATE (a fifth of the prices are
     exactly zero; curtailment now or an hour later costs the same), so a second solver's trajectory may leave this one at a tie and
     never come back: free runs are compared in aggregate only.
-  * teacher forced (`check_trajectory`): a RECORDED trajectory (the GPU loop's state before every hour, its offers and what it delivered)
-    is checked hour by hour: each of its LPs is rebuilt here from the recorded state, solved by HiGHS, and the recorded objective must
-    reach the oracle's optimum to 1e-6 while the recorded hand-off (delivered power, next state) must lie on the oracle's optimal face
-    (re-solve with those quantities fixed: same optimum to 1e-6).  That is degeneracy-proof, and nothing of the product's formulation
-    enters it.
+    (`roll(..., interior_day_ahead=True)` shows it on the oracle alone: day-ahead offers from an interior point of the optimal face
+    instead of a vertex move 60 days of revenue by 9e-4 and leave 44 of 60 days identical.)
+  * teacher forced (tests/_rolling_oracle.py::check_recorded_plant): a RECORDED trajectory (the GPU loop's state before every hour and
+    its whole solutions) is checked hour by hour: each of its LPs is rebuilt from the recorded state by the functions below and solved
+    by HiGHS; the recorded solution, mapped into these un-reduced variables, must be feasible and reach the optimum to 1e-6, and every
+    state hand-off must be the 2-dp rounding of what the tracker realised.  That is degeneracy-proof, and nothing of the product's
+    formulation enters it.
 """
 from __future__ import annotations
 
@@ -96,8 +98,22 @@ def _pt(P, fs, x):
     return np.array([P.value(e, x) for e in fs["P_T"]])
 
 
-def roll(k, days, stride=17, series="rts_gmlc_309.npz", da_horizon=48, rt_horizon=4, year=None):
+def _solve_interior(P):
+    """An optimal point from the RELATIVE INTERIOR of the optimal face (HiGHS interior point, no crossover) instead of a vertex: what a
+    first-order method tends to return.  Used only to show how far two optimal trajectories of the SAME loop drift apart."""
+    from . import highs_direct as hd
+    M = hd.from_prepared(P, tol=1e-9)
+    M.h.setOptionValue("solver", "ipm")
+    M.h.setOptionValue("run_crossover", "off")
+    M.h.setOptionValue("ipm_optimality_tolerance", 1e-10)
+    x, f, _ = M.solve()
+    return x, f
+
+
+def roll(k, days, stride=17, series="rts_gmlc_309.npz", da_horizon=48, rt_horizon=4, year=None, interior_day_ahead=False):
     """Free run of plant k for `days` simulated days on the oracle's own solutions.
+    interior_day_ahead: take the day-ahead offers from an interior point of the optimal face instead of a simplex vertex (see
+    _solve_interior; the hourly LPs stay on the simplex).
     -> dict of per-day arrays: revenue [$], delivered [MWh], da_energy [MWh], soc / thr at the end of the day (2 dp),
        and per-hour soc / thr before the hour, delivered power."""
     da_s, rt_s, cf_s = load_year(series) if year is None else year
@@ -110,8 +126,8 @@ def roll(k, days, stride=17, series="rts_gmlc_309.npz", da_horizon=48, rt_horizo
         hour = 24 * d
         da, rt, cf = (window(s, start, hour, da_horizon) for s in (da_s, rt_s, cf_s))
         P, fs, pda, _ = day_ahead_lp(cf, da, rt, soc, thr)
-        x, _ = P.solve(tight=True)
-        offer, prices = x[pda][:24].copy(), da[:24].copy()
+        x, _ = _solve_interior(P) if interior_day_ahead else P.solve(tight=True)
+        offer, prices = np.maximum(x[pda][:24], 0.0), da[:24].copy()
         out["da_energy"][d] = offer.sum()
         for h in range(24):
             hour = 24 * d + h
@@ -135,93 +151,3 @@ def roll(k, days, stride=17, series="rts_gmlc_309.npz", da_horizon=48, rt_horizo
             out["delivered"][d] += delivered
         out["soc"][d], out["thr"][d] = soc, thr
     return out
-
-
-def _fixed(P, rows):
-    """P with extra equality rows (dict col -> coef, rhs): -> optimum of the restricted LP, inf when infeasible"""
-    import scipy.sparse as sp
-    from scipy.optimize import linprog
-    n = len(P.c)
-    A = sp.lil_matrix((len(rows), n))
-    b = np.zeros(len(rows))
-    for i, (d, rhs) in enumerate(rows):
-        for j, v in d.items():
-            A[i, j] = v
-        b[i] = rhs
-    Aeq = sp.vstack([P.A_eq, A.tocsr()]).tocsr() if P.A_eq is not None else A.tocsr()
-    beq = np.concatenate([P.b_eq, b]) if P.A_eq is not None else b
-    res = linprog(P.c, A_ub=P.A_ub, b_ub=P.b_ub, A_eq=Aeq, b_eq=beq, bounds=P.bounds, method="highs")
-    return float(res.fun + P.c0) if res.status == 0 else np.inf
-
-
-def check_trajectory(k, rec, hours=None, stride=17, series="rts_gmlc_309.npz", da_horizon=48, rt_horizon=4, tol=1e-6, year=None):
-    """Teacher-forced check of a recorded trajectory of plant k (see the module docstring).  `rec` holds, per simulated hour i:
-        soc[i], thr[i]                    state BEFORE the hour (what update_model fixed: 2-dp values)
-        rt_offer[i, 4]                    real-time offer = the dispatch handed to the tracker [MW]
-        delivered[i]                      P_T[0] of the tracking solution [MW]
-        soc_next[i], thr_next[i]          UN-rounded state of charge / throughput after the hour, from the tracking solution
-        rt_obj[i], tr_obj[i]              objectives of the two hourly LPs as the solver reported them
-      and per simulated day j: da_offer[j, 24], da_obj[j], da_soc[j], da_thr[j] (state the day-ahead LP was built from).
-    `hours`: iterable of hour indices to check (default: all recorded).  -> dict(max_err=..., worst=..., checked=...); raises
-    AssertionError on the first violation."""
-    da_s, rt_s, cf_s = load_year(series) if year is None else year
-    N = len(rt_s)
-    start = (stride * k) % N
-    n_hours = len(rec["soc"])
-    hours = range(n_hours) if hours is None else hours
-    worst = dict(da=0.0, rt=0.0, tr=0.0, face=0.0, state=0.0)
-    rel = lambda a, b: abs(a - b) / max(1.0, abs(b))
-    days_done = set()
-    checked = 0
-    for i in hours:
-        d, h = divmod(int(i), 24)
-        offer = rec["da_offer"][d]
-        if d not in days_done:
-            days_done.add(d)
-            da, rt, cf = (window(s, start, 24 * d, da_horizon) for s in (da_s, rt_s, cf_s))
-            P, fs, pda, _ = day_ahead_lp(cf, da, rt, float(rec["da_soc"][d]), float(rec["da_thr"][d]))
-            f = P.solve(tight=True)[1]
-            e = rel(rec["da_obj"][d], f)
-            worst["da"] = max(worst["da"], e)
-            assert e <= tol, ("day-ahead objective", k, d, rec["da_obj"][d], f)
-            # the offer the loop took from its solution is on the optimal face of the oracle's LP
-            g = _fixed(P, [({pda[t]: 1.0}, offer[t]) for t in range(24)])
-            e = rel(g, f)
-            worst["face"] = max(worst["face"], e)
-            assert e <= tol, ("day-ahead offer off the optimal face", k, d, g, f)
-        prices = window(da_s, start, 24 * d, 24)
-        rt, cf, daw = (window(s, start, i, rt_horizon) for s in (rt_s, cf_s, da_s))
-        known = min(rt_horizon, 24 - h)
-        daw = daw.copy()
-        daw[:known] = prices[h:h + known]
-        cleared = np.zeros(rt_horizon)
-        cleared[:known] = offer[h:h + known]
-        soc, thr = float(rec["soc"][i]), float(rec["thr"][i])
-        if i > 0 and (i - 1) in set(hours) if not isinstance(hours, range) else i > hours.start:
-            # the state the loop fixed = the previous hour's realised state, rounded as update_model does
-            e = max(abs(soc - round(float(rec["soc_next"][i - 1]), 2)), abs(thr - round(float(rec["thr_next"][i - 1]), 2)))
-            worst["state"] = max(worst["state"], e)
-            assert e <= 1e-9, ("state hand-off", k, i, soc, rec["soc_next"][i - 1], thr, rec["thr_next"][i - 1])
-        P, fs, _, _ = real_time_lp(cf, rt, daw, cleared, known, soc, thr)
-        f = P.solve(tight=True)[1]
-        e = rel(rec["rt_obj"][i], f)
-        worst["rt"] = max(worst["rt"], e)
-        assert e <= tol, ("real-time objective", k, i, rec["rt_obj"][i], f)
-        dispatch = np.asarray(rec["rt_offer"][i], float)
-        g = _fixed(P, [(fs["P_T"][t][0], dispatch[t] - fs["P_T"][t][1]) for t in range(rt_horizon)])
-        e = rel(g, f)
-        worst["face"] = max(worst["face"], e)
-        assert e <= tol, ("real-time offer off the optimal face", k, i, g, f)
-        P, fs, _, _ = tracking_lp(cf, dispatch, soc, thr)
-        f = P.solve(tight=True)[1]
-        e = rel(rec["tr_obj"][i], f)
-        worst["tr"] = max(worst["tr"], e)
-        assert e <= tol, ("tracking objective", k, i, rec["tr_obj"][i], f)
-        v = fs["vars"][0]
-        g = _fixed(P, [(fs["P_T"][0][0], rec["delivered"][i] - fs["P_T"][0][1]), ({v["S"]: 1.0}, rec["soc_next"][i]),
-                       ({v["E"]: 1.0}, rec["thr_next"][i])])
-        e = rel(g, f)
-        worst["face"] = max(worst["face"], e)
-        assert e <= tol, ("tracking hand-off off the optimal face", k, i, g, f)
-        checked += 1
-    return dict(worst=worst, checked=checked)

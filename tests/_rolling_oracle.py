@@ -74,7 +74,8 @@ def column_maps(loop):
     the checks below run in worker processes)."""
     per = lambda periods: np.array([[p[col].index for _, col in _PHYS] for p in periods], dtype=np.int64)
     return dict(da=per(loop.da_periods), rt=per(loop.rt_periods), tr=per(loop.tr_periods),
-                da_pda=loop.da.pda_cols.cpu().numpy().astype(np.int64), rt_pda=loop.rt.pda_cols.cpu().numpy().astype(np.int64))
+                da_pda=loop.da.pda_cols.cpu().numpy().astype(np.int64), rt_pda=loop.rt.pda_cols.cpu().numpy().astype(np.int64),
+                da_u=loop.da.u_cols.cpu().numpy().astype(np.int64), rt_u=loop.rt.u_cols.cpu().numpy().astype(np.int64))
 
 
 def _mapped(P, fs, cols, x, extra):
@@ -137,7 +138,11 @@ def check_recorded_plant(args, base_hour=0, base_day=0):
             P, fs, pda, u = dl.day_ahead_lp(cf, da, rt, float(soc), float(thr))
             ptd = pt(maps["da"], x_da)
             xp = x_da[maps["da_pda"]]
-            extra = [(pda[t], xp[t]) for t in range(Tda)] + [(u[t], max(0.0, xp[t] - ptd[t])) for t in range(Tda)]
+            # (the underbid slack is the solver's own column, not max(0, pda - P_T) recomputed: a row residual of 1e-6 MW inside the
+            #  solver's feasibility tolerance would enter the objective 1e4-fold through the penalty; the row test below still holds it
+            #  to 1e-7 of the solution's scale)
+            xu = x_da[maps["da_u"]]
+            extra = [(pda[t], xp[t]) for t in range(Tda)] + [(u[t], xu[t]) for t in range(Tda)]
             worst["da"] = max(worst["da"], _feasible_and_optimal(P, _mapped(P, fs, maps["da"], x_da, extra), ("da", k, d + base_day)))
             # the day starts from the state the loop carried there
             assert (rec["da_state"][d] == rec["state"][H(24 * (d + base_day))]).all(), ("day-ahead state", k, d + base_day)
@@ -160,8 +165,8 @@ def check_recorded_plant(args, base_hour=0, base_day=0):
         ptr = pt(maps["rt"], x)
         xp = x[maps["rt_pda"]]
         assert np.abs(xp[:known] - cleared[:known]).max() <= 1e-9 * 225, ("cleared day-ahead position", k, i)
-        pos = np.where(np.arange(T) < known, cleared, xp)
-        extra = [(u[t], max(0.0, pos[t] - ptr[t])) for t in range(T)] + [(pda[t], xp[t]) for t in range(known, T)]
+        xu = x[maps["rt_u"]]                       # (the solver's own slack columns, as for the day-ahead LP above)
+        extra = [(u[t], xu[t]) for t in range(T)] + [(pda[t], xp[t]) for t in range(known, T)]
         worst["rt"] = max(worst["rt"], _feasible_and_optimal(P, _mapped(P, fs, maps["rt"], x, extra), ("rt", k, i)))
         x = rec["tr_x"][H(i)]
         P, fs, under, over = dl.tracking_lp(cf, ptr, soc, thr)

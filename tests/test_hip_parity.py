@@ -529,3 +529,34 @@ def test_run_time_specialisation_of_a_qp_and_of_a_perturbed_lp():
         assert r.status == 0
         ref = r.fun + model.c0[k]
         assert abs(obj[k] - ref) <= 1e-6 * max(1.0, abs(ref)), (k, obj[k], ref)
+
+
+@gpu
+def test_device_side_recertification_passes():
+    """dsp_options::recertify_passes (ABI 11): scenarios the solve accepts WITHOUT a certified objective accuracy (DSP_FLAG_OBJ_WAIVED) are
+    solved again on the device under other settings, and only a certified optimum replaces the flagged point - what the rolling loop
+    relies on inside its hipGraph replays, where nobody reads a flag back between solves.  Flags are provoked by a polish patience of
+    8 iterations at an objective tolerance of 5e-9 (the first pass waives almost at once where the bound lingers: 14 of 1024); with the passes on, (almost) none is left, every scenario that lost its flag
+    meets the plain 1e-6 contract against the oracle fixture, untouched scenarios are bit-identical to the run without passes, and the
+    iterations of the extra passes are accounted."""
+    import os
+    from dispatches_amd import scenarios
+    B = 1024
+    fx = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "oracle_objectives.npz"))
+    ref = fx["wind_battery_48h"][:B]
+    runs = {}
+    for passes in (0, 3):
+        solver = _solver(recertify=0, polish_patience=8, eps_obj=5e-9, recertify_passes=passes)      # (recertify=0: no host-side re-solves either)
+        bidder, model = scenarios.make_batch("wind_battery_48h", B, solver)
+        solver.solve(model)
+        assert (model.status == 0).all()
+        runs[passes] = dict(obj=model.objective.copy(), flags=model.flags.copy(), iters=model.iterations.copy())
+    f0, f3 = (runs[0]["flags"] & 1) != 0, (runs[3]["flags"] & 1) != 0
+    assert f0.sum() >= 8, f"the provocation flagged only {int(f0.sum())} scenarios"
+    assert not (f3 & ~f0).any() and f3.sum() <= f0.sum() // 4, (int(f0.sum()), int(f3.sum()))
+    cleared = f0 & ~f3
+    err = np.abs(runs[3]["obj"] - ref) / np.maximum(1.0, np.abs(ref))
+    assert err[cleared].max() <= 1e-6, err[cleared].max()
+    assert (runs[3]["iters"][cleared] > runs[0]["iters"][cleared]).all()
+    assert np.array_equal(runs[3]["obj"][~f0], runs[0]["obj"][~f0]) and np.array_equal(runs[3]["iters"][~f0], runs[0]["iters"][~f0])
+    print(f"\n[recertify] flagged without passes {int(f0.sum())}, with 3 passes {int(f3.sum())}; worst error of the cleared scenarios {err[cleared].max():.2e}")

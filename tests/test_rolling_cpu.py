@@ -208,3 +208,19 @@ def test_year_fixture_wraps_the_data_end():
     assert (w[:15] == rt[8721:]).all() and (w[15:] == rt[:33]).all()
     out = dl.roll(513, 2)
     assert np.allclose(out["revenue"], fx["revenue"][j, :2], rtol=1e-12) and np.allclose(out["soc"], fx["soc"][j, :2])
+
+
+def test_two_optimal_trajectories_of_the_same_loop_drift_apart():
+    """Why the full-year GPU test compares FREE runs in aggregate only: the day-ahead LPs are degenerate (a fifth of the prices are exactly
+    0), and a run that takes its day-ahead offers from an interior point of the optimal face (HiGHS interior point without crossover -
+    what a first-order method tends to return) instead of a simplex vertex is every bit as optimal, hour by hour, yet leaves the vertex
+    trajectory within days - by the same 1e-3 of revenue the GPU loop differs from the fixture by."""
+    from oracle import double_loop_oracle as dl
+    fx = np.load(os.path.join(ROOT, "tests", "golden", "rolling_year.npz"))
+    days = 20
+    o = dl.roll(0, days, interior_day_ahead=True)
+    ref_rev, ref_mwh = fx["revenue"][0, :days], fx["delivered"][0, :days]
+    same = np.abs(o["revenue"] - ref_rev) <= 1e-6 * np.maximum(1.0, np.abs(ref_rev))
+    assert 0 < same.sum() < days                                   # parts, but not everywhere
+    assert abs(o["revenue"].sum() - ref_rev.sum()) <= 2.5e-3 * ref_rev.sum()
+    assert abs(o["delivered"].sum() - ref_mwh.sum()) <= 2e-4 * ref_mwh.sum()
