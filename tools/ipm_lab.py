@@ -32,7 +32,7 @@ def banded_from(N, w):
     return ab
 
 
-def solve(P, eps=1e-9, eps_obj=5e-7, max_iter=200, colscale=None, n_ruiz=10, dense_thr=16, verbose=0, reg=1e-12, prox=0.0, frac=0.99, refine=3, theta_cap=1e30, sigmin=0.05):
+def solve(P, eps=1e-9, eps_obj=5e-7, max_iter=200, colscale=None, n_ruiz=10, dense_thr=16, verbose=0, reg=1e-12, prox=0.0, frac=0.99, refine=3, theta_cap=1e30, sigmin=0.05, mu0=0.0, gondzio=0):
     """frac / sigmin: the product's settings since round 5's last commits (csrc/dsp_ipm.hip: 0.99 to the boundary, sigma >= 0.05); the first
     version ran 0.9995 / 0 (`frac=0.9995 sigmin=0` on the command line)"""
     A0 = sp.csr_matrix(P["A"])
@@ -74,6 +74,8 @@ def solve(P, eps=1e-9, eps_obj=5e-7, max_iter=200, colscale=None, n_ruiz=10, den
     v = np.where(hl & hu, 0.5 * (fin(l) + fin(u)), np.where(hl, fin(l) + 1.0, fin(u) - 1.0))
     y = np.zeros(m)
     z = np.where(hl, 1.0, 0.0); f = np.where(hu, 1.0, 0.0)
+    if mu0 > 0:                                               # centred start: every complementarity product = mu0 (experiment, round 6)
+        z = np.where(hl, mu0 / np.where(hl, v - fin(l), 1.0), 0.0); f = np.where(hu, mu0 / np.where(hu, fin(u) - v, 1.0), 0.0)
     A, AT = P["A"], sp.csr_matrix(P["A"].T)
     qn = np.sqrt(np.sum(np.maximum(np.abs(fin(P["rlo"])), np.abs(fin(P["rhi"]))) ** 2) + np.sum(fin(P["lb"]) ** 2 + fin(P["ub"]) ** 2))
     cn = np.linalg.norm(P["c"])
