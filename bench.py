@@ -317,7 +317,7 @@ def _price_taker_cpu_worker(args):
     from dispatches_amd import scenarios
     from oracle import dispatch_lp_oracle as orc
     cf, lmp = scenarios.price_taker_inputs(T)
-    bf, lm = scenarios.PRICE_TAKER_FAMILY[k % len(scenarios.PRICE_TAKER_FAMILY)]
+    bf, lm = scenarios.PRICE_TAKER_FAMILY_WIDE[k % len(scenarios.PRICE_TAKER_FAMILY_WIDE)]     # (members 0 .. 15 = PRICE_TAKER_FAMILY)
     t = time.perf_counter()
     P, _ = orc.wind_battery_price_taker(T, cf, lmp * lm, batt_cap_factor=bf)
     x, obj = P.solve(tight=True)
@@ -354,7 +354,10 @@ def bench_price_taker(args, rank, local_rank, world, dev):
     # the PDHG kernels and switch it off.
     ipm = bool(args.solve) and not getattr(args, "pdhg", False)
     thr = args.throughput or ("two_level" if args.workload == "price_taker" and not ipm else "chain")
-    build = {"price_taker": lambda s: scenarios.price_taker_batch(T, B, s, throughput=thr)[1],
+    # members of the wind + battery family: the 256 DISTINCT ones of scenarios.PRICE_TAKER_FAMILY_WIDE (round 6; the first 16 are the
+    # round-4 family, which a batch of 256 used to repeat 16 times)
+    family = getattr(args, "family", None) or "wide"
+    build = {"price_taker": lambda s: scenarios.price_taker_batch(T, B, s, throughput=thr, family=family)[1],
              "pem_price_taker": lambda s: scenarios.pem_price_taker_batch(T, B, s, inputs="rts303", throughput=thr)[1],
              "nuclear_price_taker": lambda s: scenarios.nuclear_price_taker_batch(T, B, s)[1]}[args.workload]
 
@@ -446,9 +449,21 @@ def bench_price_taker(args, rank, local_rank, world, dev):
             fx_path = os.path.join(ROOT, "tests", "golden", "oracle_price_taker.npz")
             if args.workload == "price_taker" and os.path.exists(fx_path):
                 fx = np.load(fx_path)
-                if f"T{T}/obj" in fx.files:
+                if f"T{T}/obj" in fx.files and family == "base":
                     ref = fx[f"T{T}/obj"][np.arange(B) % len(scenarios.PRICE_TAKER_FAMILY)]
                     line["config"]["max_rel_objective_error_vs_oracle_fixture"] = float((np.abs(model.objective - ref) / np.maximum(1.0, np.abs(ref))).max())
+                elif f"T{T}/obj" in fx.files:
+                    # wide family: the fixture holds members 0 .. 15 and every fourth one from 16 on (tools/make_price_taker_fixtures.py --wide)
+                    ks, ref = np.arange(16), fx[f"T{T}/obj"]
+                    if f"T{T}w/obj" in fx.files:
+                        ks, ref = np.concatenate([ks, fx[f"T{T}w/k"]]), np.concatenate([ref, fx[f"T{T}w/obj"]])
+                    keep = ks < B
+                    ks, ref = ks[keep], ref[keep]
+                    line["config"]["max_rel_objective_error_vs_oracle_fixture"] = float((np.abs(model.objective[ks] - ref) / np.maximum(1.0, np.abs(ref))).max())
+                    line["config"]["members_with_oracle_fixture"] = int(len(ks))
+            if args.workload == "price_taker":
+                line["config"]["distinct_members"] = int(len(set(model.family)))
+                line["config"]["ipm_solved"] = int(getattr(st, "ipm_solved", 0))
             if args.workload == "price_taker" and args.cpu_sample != 0:
                 # The WHOLE host beside the GPU: one HiGHS process per hardware thread (the reference's own sweep runs its members as
                 # a process pool: renewables_case/run_pricetaker_wind_PEM.py:106-107), each solving one member of the family - as many
@@ -464,7 +479,7 @@ def bench_price_taker(args, rank, local_rank, world, dev):
                 wall = time.perf_counter() - t1
                 err = max(abs(model.objective[k] - obj) / max(1.0, abs(obj)) for k, obj, _ in res)
                 line["cpu_baseline"] = {"value": nsample / wall, "unit": "LPs/s", "cores": nsample, "kind": "port", "host_threads": os.cpu_count(),
-                                        "sample": f"{nsample} members of the same batch (the {len(scenarios.PRICE_TAKER_FAMILY)}-member family repeated), one HiGHS process "
+                                        "sample": f"{nsample} members of the same batch, one HiGHS process "
                                                   f"each on {os.cpu_count()} hardware threads (oracle/dispatch_lp_oracle.py: the un-reduced LP, feasibility tolerances "
                                                   f"1e-9), wall {wall:.1f} s incl. process start, {np.mean([r[2] for r in res]):.1f} s per member (max {max(r[2] for r in res):.1f} s)",
                                         "max_rel_objective_difference_gpu_vs_these": float(err)}
@@ -841,10 +856,25 @@ def baseline_configs(args, local_rank, dev, budget_s=360.0, depth=8):
     leg("bidder_api", lambda: _condense("bidder_api", bench_bidder_api(sub(workload="bidder_api", batch=4096, steps=12, warmup=2), 0, local_rank, 1, dev),
                                         ("call_ms", "solver_solve_ms", "kernel_ms", "host_rest_ms", "optimal", "curve_points_per_hour",
                                          "bids_identical_to_numpy_path", "numpy_path_call_ms")))
-    leg("price_taker_solve", lambda: _condense("price_taker_solve", bench_price_taker(sub(workload="price_taker", batch=256, steps=1, warmup=1, solve=True, horizon=8736,
-                                                                                           throughput=None, cpu_sample=0, pdhg=False), 0, local_rank, 1, dev),
-                                               ("stream_form", "time_partitions", "solved_to_optimality", "newton_iterations_per_scenario", "max_newton_iterations", "seconds_per_batch",
-                                                "ms_per_newton_iteration_of_the_batch", "max_rel_objective_error_vs_oracle_fixture", "throughput_form")))
+    pt_keys = ("stream_form", "time_partitions", "solved_to_optimality", "distinct_members", "ipm_solved", "newton_iterations_per_scenario", "max_newton_iterations",
+               "seconds_per_batch", "ms_per_newton_iteration_of_the_batch", "max_rel_objective_error_vs_oracle_fixture", "members_with_oracle_fixture", "throughput_form",
+               "gpu_over_full_host")
+
+    def price_taker_solve(tag, batch, cpu_sample):
+        # (cpu_sample processes of HiGHS on as many members beside the GPU line: a BOUNDED sample - a member takes HiGHS 9 - 13 s alone and
+        #  longer in company; the whole-host figures - 16 / 64 / 256 processes: 0.37 / 0.92 / 0.88 LPs/s on 256 threads - are
+        #  profiles/r50d_solve256.json)
+        line = bench_price_taker(sub(workload="price_taker", batch=batch, steps=1, warmup=1, solve=True, horizon=8736, throughput=None, cpu_sample=cpu_sample,
+                                     pdhg=False, family="wide"), 0, local_rank, 1, dev)
+        e = _condense(tag, line, pt_keys)
+        if "cpu_baseline" in line:
+            e["cpu_baseline"] = line["cpu_baseline"]
+        return e
+    # the year-long design LPs as 256 DISTINCT members, and at the sizes of the reference's own sweeps (30 points: run_pricetaker_wind_PEM.py:99-107;
+    # 60 points: price_taker_analysis.py:358-359)
+    leg("price_taker_solve", lambda: price_taker_solve("price_taker_solve", 256, 24))
+    leg("price_taker_solve_60", lambda: price_taker_solve("price_taker_solve_60", 60, 0))
+    leg("price_taker_solve_30", lambda: price_taker_solve("price_taker_solve_30", 30, 0))
     leg("streaming", lambda: _condense("streaming", bench_price_taker(sub(workload="price_taker", batch=256, steps=50, warmup=1, solve=False, horizon=8736,
                                                                            throughput=None, cpu_sample=0), 0, local_rank, 1, dev),
                                        ("stream_form", "stream_phases", "iterations_per_scenario", "finished_before_the_cap", "us_per_batch_iteration")))
@@ -874,6 +904,8 @@ def main():
                     help="the burst of --steps steps is repeated until the timed bursts cover this many seconds; the median burst is reported")
     ap.add_argument("--max-bursts", type=int, default=500)
     ap.add_argument("--no-eps4", action="store_true", help="skip the extra eps_rel = 1e-4 (PDLP default tolerance) leg of the LP metric line")
+    ap.add_argument("--family", default=None, choices=["base", "wide"],
+                    help="--workload price_taker: members of the batch - wide (default) = the 256 distinct ones of scenarios.PRICE_TAKER_FAMILY_WIDE, base = the 16-member family cycled")
     ap.add_argument("--pdhg", action="store_true", help="--solve lines: the PDHG forms instead of the interior-point form (dsp_options::no_interior_point)")
     ap.add_argument("--solve", action="store_true", help="--workload price_taker / pem_price_taker / nuclear_price_taker: solve the batch to optimality (full-solve line)")
     ap.add_argument("--throughput", default=None, choices=["chain", "two_level", "hier"],

@@ -511,6 +511,7 @@ int dsp_solve(dsp_handle *h, const dsp_batch *batch, const dsp_options *opt, dsp
       stats->stream_bytes_per_iteration = (int64_t)stream_bytes_per_iteration(&h->stream);
       stats->stream_form = h->stream.last_form;
       stats->stream_phases = (h->stream.last_form == DSP_STREAM_FORM_LANE || h->stream.last_form == DSP_STREAM_FORM_IPM) ? h->stream.last_phases : 0;
+      stats->ipm_solved = h->stream.last_ipm_solved;
       if (sync_stats) {
         HIP_TRY(hipStreamSynchronize(st));
         HIP_TRY(hipEventElapsedTime(&stats->kernel_ms, h->ev0, h->ev1));

@@ -28,8 +28,8 @@
 // test) is elementwise over (chunk of indices) x (64 scenarios).  256 year-long scenarios: 13 ms per Newton iteration, ~50 GB of HBM traffic.
 //
 // Termination is the HBM-resident path's own test (control_decide, dsp_stream.hpp) evaluated on the unscaled problem; a scenario the
-// method does not finish (breakdown, 250 Newton iterations, free columns) is left to the PDHG forms, which start as if this file did
-// not exist.  dsp_options::no_interior_point = 1 switches it off; dsp_stats::stream_form = DSP_STREAM_FORM_IPM when it solved the batch,
+// method does not finish (breakdown, 250 Newton iterations, free columns) is left to the PDHG forms - that scenario alone: the ones this
+// file solved are exported and stay solved (round 6; round 5 re-ran the whole batch).  dsp_options::no_interior_point = 1 switches it off; dsp_stats::stream_form = DSP_STREAM_FORM_IPM when it solved the batch,
 // dsp_stats::stream_phases = the time partitions.
 #include <hip/hip_runtime.h>
 
@@ -47,6 +47,13 @@ namespace dsp {
 
 constexpr int kIpmMaxW = 8, kIpmMaxK = 4, kIpmSpan = 16, kIpmMaxNewton = 250;
 constexpr int kIpmNQ = 16;                 // partial-sum slots (the Woodbury matrix needs K * K)
+constexpr int kIpmMaxBlocks = 1024;        // blocks (of 4 waves) per lane group in the elementwise kernels, at most
+
+// Blocks per lane group of the elementwise kernels for G groups in use: enough waves to hide the gathers' latency (a wave owns a
+// chunk of indices and walks it with a few loads in flight) - 2048 blocks over the groups, at most kIpmMaxBlocks per group.  Round 5
+// stopped at 256: 1024 waves for a single group of 64 scenarios = one wave per SIMD, 7.6 ms per Newton iteration at 64 scenarios
+// against 13.1 ms at 256.  The partial sums are per block (ipm_put), so the finish kernels walk as many as before.
+static inline int ipm_blocks(int G) { return std::max(16, std::min(kIpmMaxBlocks, 2048 / std::max(G, 1))); }
 
 struct IpmPlan {                            // shared by all scenarios (device)
   int n, m, W, K, Mp;                       // Mp = m + W rows of the band arrays
@@ -64,11 +71,14 @@ struct IpmPlan {                            // shared by all scenarios (device)
 };
 
 // per-lane scalars
-enum { SC_MU = 0, SC_SIGMU, SC_AP, SC_AD, SC_CS, SC_NB, SC_APA, SC_ADA, SC_POBJ, SC_COUNT };
+enum { SC_MU = 0, SC_SIGMU, SC_AP, SC_AD, SC_CS, SC_NB, SC_APA, SC_ADA, SC_POBJ, SC_RPMIN, SC_COUNT };
 
 struct IpmWork {
-  size_t Bp;                                // lanes (batch rounded up to 64)
-  int B, nch;                               // scenarios, chunks of the elementwise kernels
+  size_t Bp;                                // lanes (batch rounded up to 64): the stride of every scenario-minor array
+  int B, nch;                               // scenarios, chunks of the elementwise kernels (one per wave: 4 x the blocks of their grids)
+  int G;                                    // groups of 64 lanes in use (Bp / 64 until lanes are packed: ipm_repack)
+  int *sid;                                 // [Bp] lane -> scenario (identity until lanes are packed)
+  int *perm;                                // [Bp] ipm_repack: new lane -> old lane
   double *v, *z, *f, *l, *u, *cb, *th, *rd, *dv, *dz, *df, *rt, *corl, *coru, *tn;      // [n + m][Bp]
   double *y, *dy, *rp, *rhs, *q, *res;      // [m][Bp]
   double *biad;                             // [K][m][Bp]
@@ -78,7 +88,7 @@ struct IpmWork {
   double *redf;                             // [P][W W + W (W + 1) / 2][Bp]  the reduced system's block factor
   double *bd;                               // [P][W][Bp]  border sums of a solve
   double *sc;                               // [SC_COUNT][Bp]
-  double *part;                             // [kIpmNQ][nch][Bp]
+  double *part;                             // [kIpmNQ][nch / 4][Bp]: one partial per BLOCK of the elementwise kernels (ipm_put)
   double *sinv, *tk;                        // [K * K][Bp], [K][Bp]
   double *wat;                              // [K][Bp] (Abar' vec) of the wide columns (k_ipm_wide_aty)
   int *state;                               // [Bp] 0 = iterating, 1 = solved, 2 = given up
@@ -97,6 +107,7 @@ struct IpmArgs {
   int max_it;                               // give up after this many (kIpmMaxNewton; development: DSP_IPM_MAXIT)
   double reftol, reftol_end;                // refinement of the Newton systems: |rhs - N dy| <= tol |rhs| (max norms), far out / in a scenario's end game
   double reg, step, sigmin;                 // primal regularisation of Theta (0: off), step to the boundary (0.99), floor of sigma (0.05); ipm_run
+  double thcap;                             // cap of Theta (k_ipm_resid)
 };
 
 struct IpmState {
@@ -105,6 +116,8 @@ struct IpmState {
   std::vector<void *> allocs, work_allocs;
   int work_B = 0;
   int *counts_host = nullptr;
+  int *perm_host = nullptr;                 // pinned, work_B rounded up to 64 ints (ipm_repack)
+  int last_repacks = 0;
 };
 
 __device__ __forceinline__ bool ipm_fin(double v) { return fabs(v) < INFINITY; }
@@ -124,7 +137,24 @@ __device__ __forceinline__ void ipm_chunk(int count, int nch, int cid, int &i0, 
   i0 = min(cid * per, count); i1 = min(i0 + per, count);
 }
 
-// sum (or minimum / maximum) over the chunks' partials part[q][chunk][lane], q < NQ, by a workgroup of 256 threads = 4 waves x the 64
+// partial q of this block: the four waves' values combined in LDS, one value per (block, lane) in part[q][block][lane] - a quarter of the
+// partials per wave that the finish kernels would otherwise walk (they are launched one workgroup per 64 scenarios).  Called by every
+// thread of the block that is still running (lanes of finished scenarios have left: on this hardware a barrier waits for the waves that
+// exist, and a lane is finished in all four waves or in none).
+template <int OP>                          // OP 0: sum, 1: min, 2: max
+__device__ __forceinline__ void ipm_put(const IpmArgs &a, int q, double val, size_t s) {
+  __shared__ double sh[4][64];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  __syncthreads();                         // (the previous partial's readers are done with sh)
+  sh[wv][lane] = val;
+  __syncthreads();
+  if (wv == 0) {
+    auto op = [](double x, double y) { return OP == 0 ? x + y : OP == 1 ? fmin(x, y) : fmax(x, y); };
+    a.w.part[((size_t)q * (a.w.nch / 4) + blockIdx.x) * a.w.Bp + s] = op(op(sh[0][lane], sh[1][lane]), op(sh[2][lane], sh[3][lane]));
+  }
+}
+
+// sum (or minimum / maximum) over the blocks' partials part[q][block][lane], q < NQ, by a workgroup of 256 threads = 4 waves x the 64
 // scenarios of the group: every wave takes a quarter of the chunks with four independent accumulators (the loads of a plain loop queue
 // up one memory latency each: a 512-chunk sum took 0.95 ms), LDS combines.  Every thread returns the result.
 template <int NQ, int OP>                  // OP 0: sum, 1: min, 2: max
@@ -157,14 +187,14 @@ __global__ __launch_bounds__(256) void k_ipm_cmax(IpmArgs a) {
   double mx = 0.0;
   const double *c = a.sw.c + s * a.P.n;
   for (int j = j0; j < j1; ++j) mx = fmax(mx, fabs(c[j]));
-  a.w.part[(size_t)cid * Bp + s] = mx;
+  ipm_put<2>(a, 0, mx, s);
 }
 
 __global__ __launch_bounds__(256) void k_ipm_cmax_finish(IpmArgs a) {
   const size_t s = (size_t)blockIdx.x * 64 + (threadIdx.x & 63), Bp = a.w.Bp;
   double mx[1];
-  ipm_finish<1, 2>(a.w.part, a.w.nch, Bp, s, mx);
-  if (threadIdx.x < 64 && a.w.state[s] == 0) a.w.sc[SC_CS * Bp + s] = mx[0] > 1e-300 ? mx[0] : 1.0;
+  ipm_finish<1, 2>(a.w.part, a.w.nch / 4, Bp, s, mx);
+  if (threadIdx.x < 64 && a.w.state[s] == 0) { a.w.sc[SC_CS * Bp + s] = mx[0] > 1e-300 ? mx[0] : 1.0; a.w.sc[SC_RPMIN * Bp + s] = 1e300; }
 }
 
 __global__ __launch_bounds__(256) void k_ipm_setup(IpmArgs a) {
@@ -230,13 +260,13 @@ __global__ __launch_bounds__(256) void k_ipm_wide_aty(IpmArgs a, const double *v
     double t = 0.0;
 #pragma unroll 4
     for (int p = p0; p < p1; ++p) t = fma(a.P.wval[p], vec[(size_t)a.P.wrow[p] * Bp + s], t);
-    a.w.part[((size_t)k * a.w.nch + cid) * Bp + s] = t;
+    ipm_put<0>(a, k, t, s);
   }
 }
 __global__ __launch_bounds__(256) void k_ipm_wide_aty_finish(IpmArgs a) {
   const size_t s = (size_t)blockIdx.x * 64 + (threadIdx.x & 63), Bp = a.w.Bp;
   double t[kIpmMaxK];
-  ipm_finish<kIpmMaxK, 0>(a.w.part, a.w.nch, Bp, s, t, a.P.K);
+  ipm_finish<kIpmMaxK, 0>(a.w.part, a.w.nch / 4, Bp, s, t, a.P.K);
   if (threadIdx.x >= 64 || a.w.state[s] != 0) return;
 #pragma unroll
   for (int k = 0; k < kIpmMaxK; ++k) if (k < a.P.K) a.w.wat[(size_t)k * Bp + s] = t[k];
@@ -259,12 +289,19 @@ __global__ __launch_bounds__(256) void k_ipm_resid(IpmArgs a) {
       if (hl) { const double wl = v - l; den += z / wl; comp += z * wl; cnt += 1.0; }
       if (hu) { const double tu = u - v; den += f / tu; comp += f * tu; cnt += 1.0; }
       th = (hl || hu) ? 1.0 / fmax(den + a.reg, 1e-300) : 1e20;               // (free slack = free row: dropped by a huge Theta)
+      // the cap (a.thcap, 1e11 in the scaled space): a BASIC column's Theta = distance / dual reaches 1e17 .. 1e19 at the mu the objective
+      // tolerance asks of LPs with a small objective (mu ~ lim / #bounds = 2e-9), the pivot of a row that shares such a column with its
+      // neighbour becomes the difference of two numbers of that size, and the step leaves a primal residual no later step removes
+      // (k_ipm_decide: `polluted`).  Capped, those columns carry a primal regularisation of 1 / cap: all 10 of the 256 distinct year-long
+      // members that ran into the iteration limit finish (62 - 115 Newton iterations), the others take the iterations they took
+      // (lab: tools/ipm_lab.py theta_cap=1e11, profiles/r61c_theta_cap_lab.log; 1e12 and above: failures remain, 1e10: 2 x the iterations)
+      if (hl || hu) th = fmin(th, a.thcap);
       th = fmin(th, 1e30);
     }
     a.w.th[at] = th;
   }
-  a.w.part[((size_t)0 * a.w.nch + cid) * Bp + s] = comp;
-  a.w.part[((size_t)1 * a.w.nch + cid) * Bp + s] = cnt;
+  ipm_put<0>(a, 0, comp, s);
+  ipm_put<0>(a, 1, cnt, s);
   int i0, i1; ipm_chunk(m, a.w.nch, cid, i0, i1);
   for (int i = i0; i < i1; ++i) a.w.rp[(size_t)i * Bp + s] = -ipm_au(a.P, a.w.v, i, Bp, s);
 }
@@ -272,7 +309,7 @@ __global__ __launch_bounds__(256) void k_ipm_resid(IpmArgs a) {
 __global__ __launch_bounds__(256) void k_ipm_mu(IpmArgs a) {
   const size_t s = (size_t)blockIdx.x * 64 + (threadIdx.x & 63), Bp = a.w.Bp;
   double t[2];
-  ipm_finish<2, 0>(a.w.part, a.w.nch, Bp, s, t);
+  ipm_finish<2, 0>(a.w.part, a.w.nch / 4, Bp, s, t);
   if (threadIdx.x < 64 && a.w.state[s] == 0) {
     a.w.sc[SC_MU * Bp + s] = t[0] / fmax(t[1], 1.0);
     a.w.sc[SC_NB * Bp + s] = t[1];
@@ -530,13 +567,13 @@ __global__ __launch_bounds__(256) void k_ipm_wood_part(IpmArgs a, int what) {   
         double t = 0.0;
 #pragma unroll 4
         for (int p = p0; p < p1; ++p) t = fma(a.P.wval[p], a.w.biad[((size_t)k2 * m + a.P.wrow[p]) * Bp + s], t);
-        a.w.part[((size_t)(k1 * K + k2) * a.w.nch + cid) * Bp + s] = t;
+        ipm_put<0>(a, k1 * K + k2, t, s);
       }
     } else {
       double t = 0.0;
 #pragma unroll 4
       for (int p = p0; p < p1; ++p) t = fma(a.P.wval[p], a.w.q[(size_t)a.P.wrow[p] * Bp + s], t);
-      a.w.part[((size_t)k1 * a.w.nch + cid) * Bp + s] = t;
+      ipm_put<0>(a, k1, t, s);
     }
   }
 }
@@ -546,7 +583,7 @@ __global__ __launch_bounds__(256) void k_ipm_wood_s(IpmArgs a) {
   const size_t s = (size_t)blockIdx.x * 64 + (threadIdx.x & 63), Bp = a.w.Bp;
   const int K = a.P.K;
   double sums[kIpmMaxK * kIpmMaxK];
-  ipm_finish<kIpmMaxK * kIpmMaxK, 0>(a.w.part, a.w.nch, Bp, s, sums, K * K);  // (slots beyond K * K: not summed, not looked at)
+  ipm_finish<kIpmMaxK * kIpmMaxK, 0>(a.w.part, a.w.nch / 4, Bp, s, sums, K * K);  // (slots beyond K * K: not summed, not looked at)
   if (threadIdx.x >= 64 || a.w.state[s] != 0) return;
   double S[kIpmMaxK][kIpmMaxK], I[kIpmMaxK][kIpmMaxK];
   bool dead[kIpmMaxK];
@@ -603,7 +640,7 @@ __global__ __launch_bounds__(256) void k_ipm_wood_g(IpmArgs a) {
   const size_t s = (size_t)blockIdx.x * 64 + (threadIdx.x & 63), Bp = a.w.Bp;
   const int K = a.P.K;
   double t[kIpmMaxK];
-  ipm_finish<kIpmMaxK, 0>(a.w.part, a.w.nch, Bp, s, t, K);
+  ipm_finish<kIpmMaxK, 0>(a.w.part, a.w.nch / 4, Bp, s, t, K);
   if (threadIdx.x >= 64 || a.w.state[s] != 0) return;
 #pragma unroll
   for (int k1 = 0; k1 < kIpmMaxK; ++k1) {
@@ -694,8 +731,8 @@ __global__ __launch_bounds__(256) void k_ipm_ref_rows(IpmArgs a) {
     a.w.q[at] = q;
     mq = fmax(mq, fabs(q)); mr = fmax(mr, fabs(r));
   }
-  a.w.part[((size_t)0 * a.w.nch + cid) * Bp + s] = mq;
-  a.w.part[((size_t)1 * a.w.nch + cid) * Bp + s] = mr;
+  ipm_put<2>(a, 0, mq, s);
+  ipm_put<2>(a, 1, mr, s);
 }
 
 // how well the Newton system is solved: max |rhs - N dy| against max |rhs| per scenario (partial maxima: k_ipm_ref_rows); a scenario beyond
@@ -703,7 +740,7 @@ __global__ __launch_bounds__(256) void k_ipm_ref_rows(IpmArgs a) {
 __global__ __launch_bounds__(256) void k_ipm_resflag(IpmArgs a, double tol) {
   const size_t s = (size_t)blockIdx.x * 64 + (threadIdx.x & 63), Bp = a.w.Bp;
   double t[2];
-  ipm_finish<2, 2>(a.w.part, a.w.nch, Bp, s, t);
+  ipm_finish<2, 2>(a.w.part, a.w.nch / 4, Bp, s, t);
   if (threadIdx.x >= 64 || a.w.state[s] != 0) return;
   if (!(t[0] <= (a.w.endg[s] ? a.reftol_end : tol) * t[1])) atomicAdd(a.w.counts + 3, 1);
 }
@@ -731,14 +768,14 @@ __global__ __launch_bounds__(256) void k_ipm_dir(IpmArgs a, int mode) {
     if (hl && dz < 0.0) ad = fmin(ad, -z / dz);
     if (hu && df < 0.0) ad = fmin(ad, -f / df);
   }
-  a.w.part[((size_t)0 * a.w.nch + cid) * Bp + s] = ap;
-  a.w.part[((size_t)1 * a.w.nch + cid) * Bp + s] = ad;
+  ipm_put<1>(a, 0, ap, s);
+  ipm_put<1>(a, 1, ad, s);
 }
 
 __global__ __launch_bounds__(256) void k_ipm_steps(IpmArgs a, int mode) {
   const size_t s = (size_t)blockIdx.x * 64 + (threadIdx.x & 63), Bp = a.w.Bp;
   double t[2];
-  ipm_finish<2, 1>(a.w.part, a.w.nch, Bp, s, t);
+  ipm_finish<2, 1>(a.w.part, a.w.nch / 4, Bp, s, t);
   if (threadIdx.x >= 64 || a.w.state[s] != 0) return;
   if (mode == 0) { a.w.sc[SC_APA * Bp + s] = fmin(t[0], 1.0); a.w.sc[SC_ADA * Bp + s] = fmin(t[1], 1.0); }
   else { a.w.sc[SC_AP * Bp + s] = fmin(1.0, a.step * t[0]); a.w.sc[SC_AD * Bp + s] = fmin(1.0, a.step * t[1]); }
@@ -762,13 +799,13 @@ __global__ __launch_bounds__(256) void k_ipm_muaff(IpmArgs a) {
     a.w.corl[at] = dv * dz;
     a.w.coru[at] = -dv * df;
   }
-  a.w.part[((size_t)0 * a.w.nch + cid) * Bp + s] = comp;
+  ipm_put<0>(a, 0, comp, s);
 }
 
 __global__ __launch_bounds__(256) void k_ipm_sigma(IpmArgs a) {
   const size_t s = (size_t)blockIdx.x * 64 + (threadIdx.x & 63), Bp = a.w.Bp;
   double t[1];
-  ipm_finish<1, 0>(a.w.part, a.w.nch, Bp, s, t);
+  ipm_finish<1, 0>(a.w.part, a.w.nch / 4, Bp, s, t);
   if (threadIdx.x >= 64 || a.w.state[s] != 0) return;
   const double mu = a.w.sc[SC_MU * Bp + s], mu_aff = t[0] / fmax(a.w.sc[SC_NB * Bp + s], 1.0);
   const double r = mu > 0.0 ? mu_aff / mu : 1.0;
@@ -825,15 +862,15 @@ __global__ __launch_bounds__(256) void k_ipm_check(IpmArgs a) {
     q[7] += lp * ipm_fin0(l) - lm * ipm_fin0(u);                                  // dual objective, bounds (x cs)
   }
 #pragma unroll
-  for (int k = 0; k < 8; ++k) a.w.part[((size_t)k * a.w.nch + cid) * Bp + s] = q[k];
+  for (int k = 0; k < 8; ++k) ipm_put<0>(a, k, q[k], s);
 }
 
 __global__ __launch_bounds__(256) void k_ipm_decide(IpmArgs a) {
   const size_t s = (size_t)blockIdx.x * 64 + (threadIdx.x & 63), Bp = a.w.Bp;
   double q[8];
-  ipm_finish<8, 0>(a.w.part, a.w.nch, Bp, s, q);
+  ipm_finish<8, 0>(a.w.part, a.w.nch / 4, Bp, s, q);
   if (threadIdx.x >= 64 || a.w.state[s] != 0) return;
-  StreamCtrl &c = a.sw.ctrl[s];
+  StreamCtrl &c = a.sw.ctrl[a.w.sid[s]];
   const dsp_options &o = a.opt;
   const double cs = a.w.sc[SC_CS * Bp + s];
   const double po = cs * q[5], dobj = cs * (q[2] + q[7]);
@@ -849,19 +886,35 @@ __global__ __launch_bounds__(256) void k_ipm_decide(IpmArgs a) {
   const double mu = a.w.sc[SC_MU * Bp + s];
   a.w.iters[s] = a.it;
   c.last_rp = rp; c.last_rd = rd; c.last_rg = gap / (1.0 + fabs(po) + fabs(dobj));
-  if (fin) {
-    a.w.sc[SC_POBJ * Bp + s] = po;
-    a.w.state[s] = 1;
-    atomicAdd(a.w.counts + 0, 1); atomicAdd(a.w.counts + 1, 1);
-  } else if (!(po == po) || !(mu == mu) || !(mu > 0.0) || a.it >= a.max_it ||
-             (a.w.stall[s] = (fmin(a.w.sc[SC_AP * Bp + s], a.w.sc[SC_AD * Bp + s]) < 1e-4 ? a.w.stall[s] + 1 : 0)) >= 12) {
-    // (steps that stay below 1e-4: an LP without a solution, or a breakdown - not this method's scenario)
-    a.w.state[s] = 2;                                                             // given up: the PDHG forms take the scenario
+  // The end game's failure mode (round 6, the 256 distinct members: 10 of them; lab trace tools/ipm_lab.py member 58): Theta reaches 1e17,
+  // the pivot of a row that shares a basic column with its neighbour is the difference of two numbers of that size - rounding noise -, the
+  // step leaves a primal residual in that row (1e-10 -> 5e-8 in one iteration) that no later step removes (refinement does not contract in
+  // that direction), while mu collapses at 20 x per iteration: the objective test passes, the feasibility test never does.  Such a lane stops
+  // HERE, with its iterate (objective within a few limits of the optimum, residual 1e-7): state 5 = given up WARM - the PDHG form it goes to
+  // starts from this point instead of from zero (k_ipm_export).
+  const double rpm = fmin(a.w.sc[SC_RPMIN * Bp + s], rp);
+  a.w.sc[SC_RPMIN * Bp + s] = rpm;
+  const bool finite = po == po && mu == mu && fabs(po) < 1e300;
+  const bool polluted = a.w.endg[s] && rp > 30.0 * o.eps_rel && rp > 1e3 * rpm;
+  const bool broken = !(po == po) || !(mu == mu) || !(mu > 0.0);
+  const bool limit = a.it >= a.max_it;
+  // (steps that stay below 1e-4: an LP without a solution, or a breakdown - not this method's scenario)
+  const int stalled = (!fin && !broken && fmin(a.w.sc[SC_AP * Bp + s], a.w.sc[SC_AD * Bp + s]) < 1e-4) ? a.w.stall[s] + 1 : 0;
+  a.w.stall[s] = stalled;
+  const double bound = gap + cs * (q[1] + q[4]), lim1 = fmax(o.eps_obj * (1.0 + fabs(po + c.c0)), 1e-300);
+  int state = 0;
+  if (fin) state = 1;
+  else if (finite && !broken && (polluted || limit)) state = 5;                   // given up warm
+  else if (broken || limit || stalled >= 12) state = 2;                          // given up: the PDHG forms take the scenario from their own start
+  if (state == 1) a.w.sc[SC_POBJ * Bp + s] = po;
+  if (state != 0) {
+    a.w.state[s] = state;
     atomicAdd(a.w.counts + 0, 1);
-  } else if (gap + cs * (q[1] + q[4]) <= 1e4 * fmax(o.eps_obj * (1.0 + fabs(po + c.c0)), 1e-300)) {
+    if (state == 1) atomicAdd(a.w.counts + 1, 1);
+  } else if (bound <= 1e4 * lim1) {
     a.w.endg[s] = 1;
     atomicAdd(a.w.counts + 2, 1);                                                 // end game: three refinement steps from here on
-  } else if (gap + cs * (q[1] + q[4]) <= 1e7 * fmax(o.eps_obj * (1.0 + fabs(po + c.c0)), 1e-300)) {
+  } else if (bound <= 1e7 * lim1) {
     atomicAdd(a.w.counts + 3, 1);                                                 // one refinement step (none while the iterate is far out)
   }
 }
@@ -874,6 +927,7 @@ __global__ void k_ipm_begin(IpmArgs a, int phase) {
     if (s >= (size_t)a.w.B) st = 2;
     else if (a.sw.ctrl[s].done) st = 2;
     a.w.state[s] = st;
+    a.w.sid[s] = (int)min(s, (size_t)max(a.w.B - 1, 0));
     a.w.iters[s] = 0;
     a.w.stall[s] = 0;
     a.w.endg[s] = 0;
@@ -884,23 +938,65 @@ __global__ void k_ipm_begin(IpmArgs a, int phase) {
   }
 }
 
-// solved scenarios: x+ / y+ of the scenario-major workspace (k_finalize unscales them)
+// solved scenarios: x+ / y+ of the scenario-major workspace (k_finalize unscales them).  Lanes in state 1 (solved, not exported yet); the
+// launch is followed by k_ipm_exported, which moves them to state 4 (every wave of a lane's column of blocks tests the state here).
 __global__ __launch_bounds__(256) void k_ipm_export(IpmArgs a) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const size_t Bp = a.w.Bp, s = (size_t)blockIdx.y * 64 + lane;
   const int cid = blockIdx.x * 4 + wv;
-  if (a.w.state[s] != 1) return;
+  const int state = a.w.state[s];
+  if (state != 1 && state != 5) return;
+  const size_t k = (size_t)a.w.sid[s];                                            // the scenario this lane carries
   const int n = a.P.n, m = a.P.m;
   const double cs = a.w.sc[SC_CS * Bp + s];
+  if (state == 5) {
+    // given up warm: the iterate becomes the PDHG forms' starting point and restart anchor (scaled space, as k_init would have left a
+    // caller's x0 / y0); the scenario's control block stays as k_init_control set it up
+    int j0, j1; ipm_chunk(n, a.w.nch, cid, j0, j1);
+    for (int j = j0; j < j1; ++j) {
+      const double v = fmin(fmax(a.w.v[(size_t)j * Bp + s], a.sw.lb[k * n + j]), a.sw.ub[k * n + j]);
+      a.sw.x[k * n + j] = v; a.sw.x0[k * n + j] = v; a.sw.xp[k * n + j] = v; a.sw.xbar[k * n + j] = v;
+    }
+    int i0, i1; ipm_chunk(m, a.w.nch, cid, i0, i1);
+    for (int i = i0; i < i1; ++i) {
+      double y = a.w.y[(size_t)i * Bp + s] * cs;
+      if (!ipm_fin(a.sw.rlo[k * m + i])) y = fmin(y, 0.0);                        // (dual-feasible in sign, as k_init leaves a caller's y0)
+      if (!ipm_fin(a.sw.rhi[k * m + i])) y = fmax(y, 0.0);
+      a.sw.y[k * m + i] = y; a.sw.y0[k * m + i] = y; a.sw.yp[k * m + i] = y;
+    }
+    return;
+  }
   if (cid == 0) {
-    StreamCtrl &c = a.sw.ctrl[s];
+    StreamCtrl &c = a.sw.ctrl[k];
     c.pobj = a.w.sc[SC_POBJ * Bp + s]; c.status = DSP_STATUS_OPTIMAL; c.done = 1; c.it = a.w.iters[s];
     atomicAdd(a.sw.ndone, 1);
   }
   int j0, j1; ipm_chunk(n, a.w.nch, cid, j0, j1);
-  for (int j = j0; j < j1; ++j) { const double v = a.w.v[(size_t)j * Bp + s]; a.sw.xp[s * n + j] = v; a.sw.x[s * n + j] = v; }
+  for (int j = j0; j < j1; ++j) { const double v = a.w.v[(size_t)j * Bp + s]; a.sw.xp[k * n + j] = v; a.sw.x[k * n + j] = v; }
   int i0, i1; ipm_chunk(m, a.w.nch, cid, i0, i1);
-  for (int i = i0; i < i1; ++i) { const double y = a.w.y[(size_t)i * Bp + s] * cs; a.sw.yp[s * m + i] = y; a.sw.y[s * m + i] = y; }
+  for (int i = i0; i < i1; ++i) { const double y = a.w.y[(size_t)i * Bp + s] * cs; a.sw.yp[k * m + i] = y; a.sw.y[k * m + i] = y; }
+}
+__global__ void k_ipm_exported(IpmArgs a) {
+  const size_t s = (size_t)blockIdx.x * 64 + threadIdx.x;
+  if (a.w.state[s] == 1) a.w.state[s] = 4;
+  else if (a.w.state[s] == 5) a.w.state[s] = 6;
+}
+
+// ---- packing the lanes still iterating into fewer groups (ipm_repack) ----------------------------------------------------------------
+// one block per row of a scenario-minor array: new lane t takes old lane perm[t]; in place (every source is read before any target is written)
+template <class T>
+__global__ void k_ipm_pack(T *arr, size_t Bp, const int *perm, int n_new) {
+  const size_t row = blockIdx.x;
+  const int t = threadIdx.x;
+  T val = T(0);
+  if (t < n_new) { const int src = perm[t]; if (src >= 0) val = arr[row * Bp + src]; }
+  __syncthreads();
+  if (t < n_new) arr[row * Bp + t] = val;
+}
+__global__ void k_ipm_after_pack(IpmArgs a, int active, int n_new) {
+  const int t = blockIdx.x * 64 + threadIdx.x;
+  if (t < n_new) a.w.state[t] = t < active ? 0 : 2;
+  if (t == 0) a.w.counts[0] = n_new - active;                                      // lanes of the groups in use that take no part
 }
 
 // ---- host --------------------------------------------------------------------------------------------------------------------------------
@@ -1029,6 +1125,7 @@ void ipm_destroy(StreamSolver *S) {
   for (void *p : I->allocs) (void)hipFree(p);
   for (void *p : I->work_allocs) (void)hipFree(p);
   if (I->counts_host) (void)hipHostFree(I->counts_host);
+  if (I->perm_host) (void)hipHostFree(I->perm_host);
   delete I;
   S->ipm = nullptr;
 }
@@ -1042,9 +1139,8 @@ static hipError_t ipm_workspace(IpmState *I, int B) {
   const IpmPlan &P = I->P;
   w.Bp = (size_t)((B + 63) / 64) * 64;
   w.B = B;
-  const int G = (int)(w.Bp / 64);
-  int nblk = std::max(16, std::min(256, 2048 / std::max(G, 1)));
-  w.nch = 4 * nblk;
+  w.G = (int)(w.Bp / 64);
+  w.nch = 4 * kIpmMaxBlocks;               // (capacity of `part`; the solve sets the chunks per group count: ipm_chunks)
   const size_t N = (size_t)P.n + P.m, M = P.m;
   hipError_t e;
   auto alloc = [&](size_t doubles, double **out) {
@@ -1068,7 +1164,7 @@ static hipError_t ipm_workspace(IpmState *I, int B) {
     if (alloc((size_t)P.parts.P * P.W * w.Bp, &w.bd) != hipSuccess) return e;
   }
   if (alloc((size_t)SC_COUNT * w.Bp, &w.sc) != hipSuccess) return e;
-  if (alloc((size_t)kIpmNQ * w.nch * w.Bp, &w.part) != hipSuccess) return e;
+  if (alloc((size_t)kIpmNQ * kIpmMaxBlocks * w.Bp, &w.part) != hipSuccess) return e;
   if (alloc((size_t)kIpmMaxK * kIpmMaxK * w.Bp, &w.sinv) != hipSuccess) return e;
   if (alloc((size_t)kIpmMaxK * w.Bp, &w.tk) != hipSuccess) return e;
   if (alloc((size_t)kIpmMaxK * w.Bp, &w.wat) != hipSuccess) return e;
@@ -1082,6 +1178,12 @@ static hipError_t ipm_workspace(IpmState *I, int B) {
   I->work_allocs.push_back(w.endg);
   if ((e = hipMalloc((void **)&w.counts, 4 * sizeof(int))) != hipSuccess) return e;
   I->work_allocs.push_back(w.counts);
+  if ((e = hipMalloc((void **)&w.sid, w.Bp * sizeof(int))) != hipSuccess) return e;
+  I->work_allocs.push_back(w.sid);
+  if ((e = hipMalloc((void **)&w.perm, w.Bp * sizeof(int))) != hipSuccess) return e;
+  I->work_allocs.push_back(w.perm);
+  if (I->perm_host) { (void)hipHostFree(I->perm_host); I->perm_host = nullptr; }
+  if ((e = hipHostMalloc((void **)&I->perm_host, w.Bp * sizeof(int))) != hipSuccess) return e;
   I->work_B = B;
   return hipSuccess;
 }
@@ -1096,7 +1198,7 @@ static hipError_t ipm_walk(const IpmArgs &a, SeqArgs<NS> q, const Body &body, in
   auto fn = k_seq<NS, R, Body, WV, SETS>;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(fn, dim3((unsigned)(a.w.Bp / 64), (unsigned)parts), dim3(64 * WV), lds, st, q, body);
+  hipLaunchKernelGGL(fn, dim3((unsigned)a.w.G, (unsigned)parts), dim3(64 * WV), lds, st, q, body);
   return hipGetLastError();
 }
 
@@ -1124,7 +1226,7 @@ static hipError_t ipm_factor(const IpmArgs &a, hipStream_t st) {
     q.outmask = ((1u << W) - 1u) << (W + 1);
     if ((e = ipm_walk<NS, R, SpikeBody<W>, WV, 1>(a, q, SpikeBody<W>{a.w.cfin, a.w.Bp, g}, g.P - 1, st)) != hipSuccess) return e;
   }
-  hipLaunchKernelGGL(k_ipm_red_factor<W>, dim3((unsigned)(a.w.Bp / 64)), dim3(64), 0, st, a);
+  hipLaunchKernelGGL(k_ipm_red_factor<W>, dim3((unsigned)a.w.G), dim3(64), 0, st, a);
   return hipGetLastError();
 }
 
@@ -1133,7 +1235,7 @@ template <int W>
 static hipError_t ipm_bsolve(const IpmArgs &a, double *x, hipStream_t st) {
   const IpmParts &g = a.P.parts;
   const size_t stride = (size_t)a.P.Mp * a.w.Bp;
-  const dim3 border((unsigned)std::max(g.P - 1, 1), (unsigned)(a.w.Bp / 64));
+  const dim3 border((unsigned)std::max(g.P - 1, 1), (unsigned)a.w.G);
   static const int one_set = getenv("DSP_IPM_SEQ_SETS") ? atoi(getenv("DSP_IPM_SEQ_SETS")) == 1 : 0;      // development
   hipError_t e;
   {
@@ -1148,7 +1250,7 @@ static hipError_t ipm_bsolve(const IpmArgs &a, double *x, hipStream_t st) {
   if (g.P > 1) {
     constexpr int DW = W <= 6 ? 16 : 8;
     hipLaunchKernelGGL((k_ipm_border_dot<W, DW>), border, dim3(64 * DW), 0, st, a, (const double *)x);
-    hipLaunchKernelGGL(k_ipm_red_solve<W>, dim3((unsigned)(a.w.Bp / 64)), dim3(64), 0, st, a, x);
+    hipLaunchKernelGGL(k_ipm_red_solve<W>, dim3((unsigned)a.w.G), dim3(64), 0, st, a, x);
     hipLaunchKernelGGL(k_ipm_border_apply<W>, border, dim3(64 * kIpmBorderWaves), 0, st, a, x);
   }
   {
@@ -1167,7 +1269,7 @@ static hipError_t ipm_bsolve(const IpmArgs &a, double *x, hipStream_t st) {
 // equations while some scenario's residual is above 1e-8 of its right-hand side (max norms) (at most 3 steps); returns the steps taken
 template <int W>
 static hipError_t ipm_nsolve(StreamSolver *S, const IpmArgs &a, hipStream_t st, int *steps) {
-  const dim3 blk(256), grid((unsigned)(a.w.nch / 4), (unsigned)(a.w.Bp / 64)), lanes((unsigned)(a.w.Bp / 64));
+  const dim3 blk(256), grid((unsigned)(a.w.nch / 4), (unsigned)a.w.G), lanes((unsigned)a.w.G);
   hipError_t e;
   *steps = 0;
   for (int r = 0; r <= 3; ++r) {
@@ -1215,10 +1317,48 @@ static void ipm_dump(const char *name, const double *dev, size_t rows, size_t Bp
     }                                                                                                                   \
   } while (0)
 
+// The scenarios still iterating (`active` of them) are packed into the first lanes: a Newton iteration costs what its lane groups cost, and
+// the members of a batch finish over a 3 x range of iteration counts (40 .. 144 on the year-long wind + battery family).  What persists
+// from one iteration to the next is packed - the iterate (v, z, f, y), the problem data (l, u, cb), the objective scale, the per-lane
+// counters and the lane -> scenario map; everything else (Theta, residuals, the band and its factor, the directions) is recomputed.
+// Solved lanes are exported first; the stride of the arrays (Bp) stays.
+static hipError_t ipm_repack(IpmState *I, IpmArgs &a, hipStream_t st, int active) {
+  const int n_old = a.w.G * 64, G_new = (active + 63) / 64, n_new = G_new * 64;
+  const dim3 blk(256), grid((unsigned)(a.w.nch / 4), (unsigned)a.w.G);
+  hipError_t e;
+  hipLaunchKernelGGL(k_ipm_export, grid, blk, 0, st, a);
+  hipLaunchKernelGGL(k_ipm_exported, dim3((unsigned)a.w.G), dim3(64), 0, st, a);
+  if ((e = hipMemcpyAsync(I->perm_host, a.w.state, (size_t)n_old * sizeof(int), hipMemcpyDeviceToHost, st)) != hipSuccess) return e;
+  if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;
+  std::vector<int> perm((size_t)n_new, -1);
+  int k = 0;
+  for (int t = 0; t < n_old; ++t) if (I->perm_host[t] == 0 && k < n_new) perm[(size_t)k++] = t;
+  if (k != active) return hipErrorUnknown;                                         // (the device's count and its states disagree)
+  for (int t = 0; t < n_new; ++t) I->perm_host[t] = perm[(size_t)t];
+  if ((e = hipMemcpyAsync(a.w.perm, I->perm_host, (size_t)n_new * sizeof(int), hipMemcpyHostToDevice, st)) != hipSuccess) return e;
+  const size_t N = (size_t)a.P.n + a.P.m, M = a.P.m;
+  const dim3 tb((unsigned)n_old);
+  for (double *arr : {a.w.v, a.w.z, a.w.f, a.w.l, a.w.u, a.w.cb}) hipLaunchKernelGGL(k_ipm_pack<double>, dim3((unsigned)N), tb, 0, st, arr, a.w.Bp, (const int *)a.w.perm, n_new);
+  hipLaunchKernelGGL(k_ipm_pack<double>, dim3((unsigned)M), tb, 0, st, a.w.y, a.w.Bp, (const int *)a.w.perm, n_new);
+  hipLaunchKernelGGL(k_ipm_pack<double>, dim3((unsigned)SC_COUNT), tb, 0, st, a.w.sc, a.w.Bp, (const int *)a.w.perm, n_new);
+  for (int *arr : {a.w.iters, a.w.stall, a.w.endg, a.w.sid}) hipLaunchKernelGGL(k_ipm_pack<int>, dim3(1), tb, 0, st, arr, a.w.Bp, (const int *)a.w.perm, n_new);
+  hipLaunchKernelGGL(k_ipm_after_pack, dim3((unsigned)G_new), dim3(64), 0, st, a, active, n_new);
+  if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;                      // (perm_host is reused by the next repack)
+  a.w.G = G_new;
+  a.w.nch = 4 * ipm_blocks(G_new);
+  return hipGetLastError();
+}
+
 template <int W>
-static hipError_t ipm_loop(StreamSolver *S, IpmArgs &a, hipStream_t st, bool *all_solved, int *newton) {
+static hipError_t ipm_loop(StreamSolver *S, IpmArgs &a, hipStream_t st, bool *all_solved, int *newton, int *n_solved) {
   IpmState *I = S->ipm;
-  const dim3 blk(256), grid((unsigned)(a.w.nch / 4), (unsigned)(a.w.Bp / 64)), lanes((unsigned)(a.w.Bp / 64));
+  a.w.G = (int)(a.w.Bp / 64);
+  a.w.nch = 4 * ipm_blocks(a.w.G);
+  const dim3 blk(256);
+  dim3 grid((unsigned)(a.w.nch / 4), (unsigned)a.w.G), lanes((unsigned)a.w.G);
+  // DSP_IPM_COMPACT=0: every scenario keeps its lane to the end of the solve (measurement); groups of more than 1024 lanes: not packed
+  const bool compact = !(getenv("DSP_IPM_COMPACT") && atoi(getenv("DSP_IPM_COMPACT")) == 0) && a.w.Bp <= 1024;
+  int repacks = 0;
   static const int trace = getenv("DSP_IPM_TRACE") ? atoi(getenv("DSP_IPM_TRACE")) : 0;
   g_ipm_debug = getenv("DSP_IPM_DEBUG") ? atoi(getenv("DSP_IPM_DEBUG")) : 0;
   hipError_t e;
@@ -1230,7 +1370,7 @@ static hipError_t ipm_loop(StreamSolver *S, IpmArgs &a, hipStream_t st, bool *al
   hipLaunchKernelGGL(k_ipm_begin, lanes, dim3(64), 0, st, a, 1);
   IPM_DBG("setup");
   int refine = 0, it = 0;
-  const int lanes_total = (int)a.w.Bp;
+  int lanes_total = (int)a.w.Bp;
   for (it = 1; it <= a.max_it; ++it) {
     a.it = it;
     if (a.P.K > 0) { hipLaunchKernelGGL(k_ipm_wide_aty, grid, blk, 0, st, a, (const double *)a.w.y); hipLaunchKernelGGL(k_ipm_wide_aty_finish, lanes, blk, 0, st, a); }
@@ -1315,7 +1455,18 @@ static hipError_t ipm_loop(StreamSolver *S, IpmArgs &a, hipStream_t st, bool *al
     }
     if (I->counts_host[0] >= lanes_total) break;
     refine = 0;
+    {
+      const int active = lanes_total - I->counts_host[0];
+      if (compact && a.w.G > 1 && active <= 64 * (a.w.G - 1) && it < a.max_it) {
+        if ((e = ipm_repack(I, a, st, active)) != hipSuccess) return e;
+        lanes_total = a.w.G * 64;
+        grid = dim3((unsigned)(a.w.nch / 4), (unsigned)a.w.G); lanes = dim3((unsigned)a.w.G);
+        ++repacks;
+        if (trace) fprintf(stderr, "[ipm] it %d: %d scenarios still iterating packed into %d group(s)\n", it, active, a.w.G);
+      }
+    }
   }
+  I->last_repacks = repacks;
   *newton = std::min(it, a.max_it);
   IPM_DBG("loop");
   if (trace) {
@@ -1326,16 +1477,18 @@ static hipError_t ipm_loop(StreamSolver *S, IpmArgs &a, hipStream_t st, bool *al
     for (int q = 0; q < a.w.B; ++q) fprintf(stderr, " %d:%d", hs[q], hi[q]);
     fprintf(stderr, "\n");
   }
-  // all or nothing: a batch with a scenario this method did not finish runs the PDHG forms as a whole, from their own start (they
-  // carry the certificates; nothing of this file's state reaches them)
+  // Per scenario: what this method solved is exported (ctrl.done = 1, x+ / y+ in the scenario-major workspace) and stays solved; the
+  // scenarios it gave up on (state 2: breakdown, steps that stay tiny - an LP without a solution -, the iteration limit, free columns)
+  // are untouched, and the caller hands exactly those to the PDHG forms, which carry the certificates (stream_solve_locked).
   *all_solved = I->counts_host[1] >= a.w.B;
-  if (*all_solved) hipLaunchKernelGGL(k_ipm_export, grid, blk, 0, st, a);
+  *n_solved = I->counts_host[1];
+  hipLaunchKernelGGL(k_ipm_export, grid, blk, 0, st, a);        // (lanes exported before a packing are in states 4 / 6; nothing to do: returns)
   IPM_DBG("export");
   return hipGetLastError();
 }
 
-hipError_t ipm_run(StreamSolver *S, StreamArgs &sa, hipStream_t st, bool *all_solved, int *newton) {
-  *all_solved = false; *newton = 0;
+hipError_t ipm_run(StreamSolver *S, StreamArgs &sa, hipStream_t st, bool *all_solved, int *newton, int *n_solved) {
+  *all_solved = false; *newton = 0; *n_solved = 0;
   IpmState *I = S->ipm;
   if (!I) return hipSuccess;
   hipError_t e = ipm_workspace(I, sa.b.B);
@@ -1343,12 +1496,14 @@ hipError_t ipm_run(StreamSolver *S, StreamArgs &sa, hipStream_t st, bool *all_so
   IpmArgs a{};
   a.P = I->P; a.w = I->w; a.sw = sa.W; a.opt = sa.opt; a.it = 0;
   a.max_it = getenv("DSP_IPM_MAXIT") ? std::max(1, std::min(atoi(getenv("DSP_IPM_MAXIT")), kIpmMaxNewton)) : kIpmMaxNewton;
+  a.max_it = std::max(1, std::min(a.max_it, sa.opt.max_iter));            // (dsp_options::max_iter caps the Newton iterations too)
   a.reg = getenv("DSP_IPM_REG") ? atof(getenv("DSP_IPM_REG")) : 0.0;
   a.step = getenv("DSP_IPM_STEP") ? atof(getenv("DSP_IPM_STEP")) : 0.99;
   a.sigmin = getenv("DSP_IPM_SIGMIN") ? atof(getenv("DSP_IPM_SIGMIN")) : 0.05;
+  a.thcap = getenv("DSP_IPM_THCAP") ? atof(getenv("DSP_IPM_THCAP")) : 1e11;
   a.reftol = getenv("DSP_IPM_REFTOL") ? atof(getenv("DSP_IPM_REFTOL")) : 1e-8;
   a.reftol_end = getenv("DSP_IPM_REFTOL_END") ? atof(getenv("DSP_IPM_REFTOL_END")) : 1e-11;
-  return I->P.W == 6 ? ipm_loop<6>(S, a, st, all_solved, newton) : ipm_loop<8>(S, a, st, all_solved, newton);
+  return I->P.W == 6 ? ipm_loop<6>(S, a, st, all_solved, newton, n_solved) : ipm_loop<8>(S, a, st, all_solved, newton, n_solved);
 }
 
 }  // namespace dsp

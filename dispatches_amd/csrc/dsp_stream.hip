@@ -1774,6 +1774,8 @@ hipError_t stream_solve(StreamSolver *S, const dsp_batch &batch, const dsp_optio
                         int *periods_run) {
   std::lock_guard<std::mutex> lock(S->mu);
   hipError_t e = stream_solve_locked(S, batch, opt, eta, st, periods_run);
+  // (the interior-point form solved part of the batch and a PDHG form the rest: reported as the former, dsp_stats::ipm_solved says how many)
+  if (e == hipSuccess && S->last_ipm_solved > 0) { S->last_form = DSP_STREAM_FORM_IPM; S->last_phases = ipm_partitions(S); }
   const hipError_t es = hipStreamSynchronize(st);
   return e != hipSuccess ? e : es;
 }
@@ -1797,9 +1799,13 @@ static hipError_t stream_solve_locked(StreamSolver *S, const dsp_batch &batch, c
   if ((e = hipMemsetAsync(a.W.partial, 0, (size_t)B * a.nblk_tot * kNQ * sizeof(double), st)) != hipSuccess) return e;
   // time-banded LPs: interior point with exact banded solves first (dsp_ipm.hip); what it does not finish continues below as before
   S->last_newton = 0;
+  S->last_ipm_solved = 0;
+  std::vector<int> left;                               // scenarios the interior-point form left (empty: it did not run, or solved nothing)
   if (S->ipm && !opt.no_interior_point && !batch.row_compliance) {
     bool all = false;
-    if ((e = ipm_run(S, a, st, &all, &S->last_newton)) != hipSuccess) return e;
+    int n_solved = 0;
+    if ((e = ipm_run(S, a, st, &all, &S->last_newton, &n_solved)) != hipSuccess) return e;
+    S->last_ipm_solved = n_solved;
     if (all) {
       S->last_form = DSP_STREAM_FORM_IPM;
       S->last_phases = ipm_partitions(S);
@@ -1808,7 +1814,23 @@ static hipError_t stream_solve_locked(StreamSolver *S, const dsp_batch &batch, c
       *periods_run = -1;
       return hipGetLastError();
     }
+    if (n_solved > 0) {
+      // Per-scenario fallback: the scenarios it solved are done (ctrl.done, x+ / y+ exported); only the others go on - packed into as
+      // few lane groups as they need when the lane form applies (its phases' slot -> scenario map), skipped by every other form
+      // (their kernels leave scenarios with ctrl.done alone).  One infeasible member of 256 then costs one lane group of PDHG
+      // iterations until its certificate, not the whole batch over again.
+      std::vector<StreamCtrl> hc((size_t)B);
+      if ((e = hipMemcpyAsync(hc.data(), a.W.ctrl, (size_t)B * sizeof(StreamCtrl), hipMemcpyDeviceToHost, st)) != hipSuccess) return e;
+      if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;
+      for (int s = 0; s < B; ++s) if (!hc[s].done) left.push_back(s);
+      if (left.empty()) {                              // (cannot happen: all == false; defensive)
+        hipLaunchKernelGGL(k_finalize, dim3(a.nblk, B), dim3(kTB), 0, st, a);
+        *periods_run = -1;
+        return hipGetLastError();
+      }
+    }
   }
+  const bool after_ipm = !left.empty();
   // mid-size LPs: the whole solve in ONE launch, one workgroup per scenario with its state in LDS
   {
     const size_t lds = ((size_t)7 * S->P.n + 7 * S->P.m + (1024 / 64) * kNQ + kNQ) * sizeof(double);
@@ -1828,7 +1850,7 @@ static hipError_t stream_solve_locked(StreamSolver *S, const dsp_batch &batch, c
   // banded matrix with a handful of long columns: the lane-per-scenario form (dsp_stream_lane.hip)
   {
     bool used = false;
-    if ((e = lane_run(S, a, st, periods_run, &used)) != hipSuccess) return e;
+    if ((e = lane_run(S, a, st, periods_run, &used, after_ipm ? &left : nullptr)) != hipSuccess) return e;
     if (used) {
       S->last_form = DSP_STREAM_FORM_LANE;
       hipLaunchKernelGGL(k_finalize, dim3(a.nblk, B), dim3(kTB), 0, st, a);

@@ -158,6 +158,7 @@ struct StreamSolver {
   LaneState *lane = nullptr;
   IpmState *ipm = nullptr;
   int last_newton = 0;                   // interior-point form: Newton iterations of the last solve
+  int last_ipm_solved = 0;               // ... and the scenarios it solved (the others went on to the PDHG forms)
   int last_form = 0;                     // DSP_STREAM_FORM_* of the last solve
   int last_phases = 0;                   // lane form: phases of the last solve (dsp_stats::stream_phases)
   size_t last_bytes_per_iteration = 0;   // algorithmic HBM bytes per scenario and plain iteration of the form the last solve ran
@@ -175,11 +176,11 @@ size_t stream_bytes_per_iteration(const StreamSolver *S);
 // dsp_stream_lane.hip
 hipError_t lane_create(const HostCSR &A_scaled, const HostCSR &AT_scaled, StreamSolver *S);
 void lane_destroy(StreamSolver *S);
-hipError_t lane_run(StreamSolver *S, StreamArgs &a, hipStream_t st, int *periods_run, bool *used);
+hipError_t lane_run(StreamSolver *S, StreamArgs &a, hipStream_t st, int *periods_run, bool *used, const std::vector<int> *only = nullptr);
 // dsp_ipm.hip: scenarios it solves get ctrl.done = 1 / status 0 and their x+ / y+ in the scenario-major workspace; the others are untouched
 hipError_t ipm_create(const HostCSR &A_scaled, const HostCSR &AT_scaled, StreamSolver *S);
 void ipm_destroy(StreamSolver *S);
-hipError_t ipm_run(StreamSolver *S, StreamArgs &a, hipStream_t st, bool *all_solved, int *newton);
+hipError_t ipm_run(StreamSolver *S, StreamArgs &a, hipStream_t st, bool *all_solved, int *newton, int *n_solved);
 int ipm_partitions(const StreamSolver *S);     // time partitions of its banded solves (1: sequential walks; 0: no interior-point plan)
 // certificate sequence on the scenario-major workspace (x, y = the current iterate): dsp_stream.hip
 hipError_t stream_certify(StreamSolver *S, StreamArgs &a, hipStream_t st);

@@ -588,7 +588,8 @@ static hipError_t lane_workspace(LaneState *L, int B, int nwg, bool per_scenario
 
 // Runs the iteration loop in the lane form on the state k_init / k_init_control left in the scenario-major workspace `a.W`, and leaves
 // x+, y+ and the control blocks there for k_finalize.  *used = false: not applicable to this batch (the caller goes on with its own forms).
-hipError_t lane_run(StreamSolver *S, StreamArgs &a, hipStream_t st, int *periods_run, bool *used) {
+// `only`: the scenarios to run (the rest of the batch is finished: the interior-point form solved it) - the first phase packs exactly those.
+hipError_t lane_run(StreamSolver *S, StreamArgs &a, hipStream_t st, int *periods_run, bool *used, const std::vector<int> *only) {
   *used = false;
   LaneState *L = S->lane;
   if (!L) return hipSuccess;
@@ -598,7 +599,11 @@ hipError_t lane_run(StreamSolver *S, StreamArgs &a, hipStream_t st, int *periods
   // 28 - 32 us (16) there; from 32 scenarios on the lane form is ahead (64: 42 vs 90 us, 256: 165 vs 407 us; profiles/r40h_lane_rates.log,
   // r41a_lane_variants.log).  DSP_LANE_MIN_B: the threshold (development).
   const int min_b = getenv("DSP_LANE_MIN_B") ? atoi(getenv("DSP_LANE_MIN_B")) : 32;
-  if (B < min_b) return hipSuccess;
+  // a subset worth packing: as many scenarios as the form wants of a batch; fewer go to the other forms, whose kernels leave the finished
+  // scenarios of the batch alone (one scenario: 10 us per iteration there against 36 us for a lane group here)
+  const bool subset = only && (int)only->size() >= min_b;
+  if (only && !subset) return hipSuccess;
+  if (!subset && B < min_b) return hipSuccess;
   const bool qp = a.b.row_compliance != nullptr;
   hipError_t e;
   const int rows_env = getenv("DSP_LANE_ROWS") ? atoi(getenv("DSP_LANE_ROWS")) : 0;          // rows per tile (development; read per solve)
@@ -620,6 +625,7 @@ hipError_t lane_run(StreamSolver *S, StreamArgs &a, hipStream_t st, int *periods
   // current phase (empty: identity).
   std::vector<int> ids;
   int nact = B, period = 0;
+  if (subset) { ids = *only; nact = (int)ids.size(); }
   S->last_phases = 0;
   bool shared = true, first = true;
   LaneTiling *Tprev = nullptr;            // the tiling the previous phase ran on

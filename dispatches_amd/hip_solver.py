@@ -53,7 +53,8 @@ class DspStats(C.Structure):
                 ("cols_per_lane", C.c_int32), ("rows_per_lane", C.c_int32), ("kernel_ms", C.c_float),
                 ("matreg", C.c_int32), ("lds_conflicts_identity", C.c_int32), ("lds_conflicts_chosen", C.c_int32),
                 ("simplex", C.c_int32), ("streaming", C.c_int32), ("stream_bytes_per_iteration", C.c_int64),
-                ("quadratic", C.c_int32), ("precision", C.c_int32), ("rtc", C.c_int32), ("stream_form", C.c_int32), ("stream_phases", C.c_int32)]
+                ("quadratic", C.c_int32), ("precision", C.c_int32), ("rtc", C.c_int32), ("stream_form", C.c_int32), ("stream_phases", C.c_int32),
+                ("ipm_solved", C.c_int32), ("reserved1", C.c_int32)]
 
 
 class DspLpDesc(C.Structure):

@@ -291,6 +291,11 @@ def hourly_tracking_batch(case, inp, solver):
 
 # ---- long-horizon price-taker design LPs: a scenario family sharing one constraint matrix ---------------
 PRICE_TAKER_FAMILY = [(bf, lm) for lm in (1.0, 1.5, 2.0, 3.0) for bf in (1.0, 0.5, 0.25, 0.1)]   # (battery capital-cost factor, LMP multiplier)
+# 256 DISTINCT members (round 6: a 256-scenario batch of the 16-member family is 16 LPs 16 times over - every 64-lane group then holds
+# every member, and the distribution of Newton iterations is that of 16 problems): the 16 above first (their fixtures stay valid), then
+# 15 LMP multipliers 1.15 .. 3.25 x 16 battery capital-cost factors 1 .. 0.104, none of which coincides with a member above
+PRICE_TAKER_FAMILY_WIDE = PRICE_TAKER_FAMILY + [(round(0.86 ** j, 6), round(1.0 + 0.15 * k, 2)) for k in range(1, 16) for j in range(16)]
+assert len(set(PRICE_TAKER_FAMILY_WIDE)) == 256
 
 
 def price_taker_inputs(T, series="rts_gmlc_303.npz", price_cap=200.0):
@@ -359,7 +364,7 @@ def nuclear_price_taker_batch(T, B, solver, market="RT", pem_capex=1200.0):
     return handles, model
 
 
-def price_taker_batch(T, B, solver, wind_mw=847.0, throughput="two_level", inputs="rts303", coarse_nodes=3):
+def price_taker_batch(T, B, solver, wind_mw=847.0, throughput="two_level", inputs="rts303", coarse_nodes=3, family="base"):
     """Wind + battery price-taker design LP over T hourly periods (reference wind_battery_optimize) for the first B members
     of PRICE_TAKER_FAMILY: scenarios differ in the objective only.  n = 6 T + 3, m = 6 T + 2: beyond the fused kernels for
     T >= 107, i.e. solved by the HBM-resident streaming PDLP.  `throughput`: the statement of the battery's accumulated-throughput
@@ -372,7 +377,8 @@ def price_taker_batch(T, B, solver, wind_mw=847.0, throughput="two_level", input
     block, objective, handles = wind_battery_price_taker(T, cf, lmp, wind_mw=wind_mw, throughput=throughput, coarse_nodes=coarse_nodes)
     model = ScenarioBatchModel(block, B, T, indexed=True)
     model.finalize(objective)
-    fam = [PRICE_TAKER_FAMILY[i % len(PRICE_TAKER_FAMILY)] for i in range(B)]
+    members = {"base": PRICE_TAKER_FAMILY, "wide": PRICE_TAKER_FAMILY_WIDE}[family]
+    fam = [members[i % len(members)] for i in range(B)]
     model.c = np.stack([handles["objective_vector"](model.lp.n, lmp_multiplier=lm, batt_cap_factor=bf) for bf, lm in fam])
     model.c0 = np.full(B, model.lp.c0)
     model.lp.col_scale = handles["column_scales"](model.lp.n)       # physical scaling factors of the flowsheet's variables

@@ -176,8 +176,10 @@ typedef struct dsp_options {
                                 Newton iterations instead of ~75 k first-order iterations; the factorisations and solves run
                                 TIME-PARALLEL from 512 rows on (up to 64 partitions of the horizon, their separators as a
                                 block-tridiagonal system: csrc/dsp_ipm_seq.hpp; dsp_stats::stream_phases = partitions).  Scenarios it does not finish (free columns,
-                                numerical breakdown, 250 iterations) and batches with soft rows run the PDHG forms as before; statuses
-                                2 / 3 come from those.  `iters` counts Newton iterations for scenarios it solved       default 0 */
+                                numerical breakdown, 250 iterations or dsp_options::max_iter if smaller) run the PDHG forms - those scenarios only,
+                                the ones it solved stay solved (dsp_stats::ipm_solved) -, batches with soft rows as before; statuses
+                                2 / 3 come from the PDHG forms.  `iters` counts Newton iterations for scenarios it solved; warm starts
+                                (x0 / y0) are ignored by this form                                                     default 0 */
   double  eps_infeasible;    /* > 0: infeasibility / unboundedness certificates (DSP_STATUS_PRIMAL_INFEASIBLE / DUAL_INFEASIBLE, ABI 9).  On
                                 an LP without a solution the PDHG operator has no fixed point, T(z) - z tends to a ray, one of the
                                 objectives runs away and the relative gap |c.x - dual objective| / (1 + |c.x| + |dual objective|) tends
@@ -272,6 +274,11 @@ typedef struct dsp_stats {
                                      still iterating were packed into fewer groups of 64 lanes after others had finished; interior-point form
                                      (round 5): the time partitions its banded factorisations and solves ran in (1 = sequential walks);
                                      0 otherwise */
+  int32_t ipm_solved;             /* streaming path (ABI 11): scenarios the interior-point form solved.  stream_form = DSP_STREAM_FORM_IPM with
+                                     ipm_solved < B: the others (given up on: an LP without a solution, a breakdown) were handed - they
+                                     alone, packed into as few lane groups as they need - to the PDHG forms, whose statuses and
+                                     certificates they carry; iters[] counts Newton iterations for the former, PDHG iterations for the latter */
+  int32_t reserved1;
 } dsp_stats;
 
 /* dsp_stats::stream_form */

@@ -122,6 +122,39 @@ def test_year_long_price_taker_lps_by_interior_point(B):
 
 
 @gpu
+def test_year_long_batch_of_256_distinct_lps():
+    """BASELINE.md's "256 year-long LPs" as 256 DISTINCT members (scenarios.PRICE_TAKER_FAMILY_WIDE: the 16 members of the round-4
+    fixture + 15 LMP multipliers x 16 battery capital-cost factors; round 5 ran the 16-member family 16 times over): all optimal by the
+    interior-point form, 76 of them against the HiGHS fixture of the oracle's un-reduced LP (members 0 - 15 and every fourth one from 16
+    on: tools/make_price_taker_fixtures.py --wide) to 1e-6, the optimal battery size within the reference test's tolerance."""
+    _need_gpu()
+    import time
+    from dispatches_amd import scenarios
+    from dispatches_amd.hip_solver import HipPdlpSolver
+    fx = np.load(os.path.join(GOLD, "oracle_price_taker.npz"))
+    T, B = 8736, 256
+    solver = HipPdlpSolver(device=0, check_every=64, max_iter=2_000_000)
+    handles, model = scenarios.price_taker_batch(T, B, solver, throughput="chain", family="wide")
+    assert len({tuple(np.round(c[:50], 12)) for c in model.c}) > 200 or len(set(model.family)) == B
+    t0 = time.perf_counter()
+    solver.solve(model, tee=True)
+    wall = time.perf_counter() - t0
+    st = solver.last_stats
+    assert st.stream_form == FORM_IPM and st.ipm_solved == B and (model.status == 0).all(), (st.stream_form, st.ipm_solved, np.bincount(model.status))
+    ks = np.concatenate([np.arange(16), fx["T8736w/k"]])
+    ref = np.concatenate([fx["T8736/obj"], fx["T8736w/obj"]])
+    batt_ref = np.concatenate([fx["T8736/batt_mw"], fx["T8736w/batt_mw"]])
+    assert len(ks) >= 64 + 12
+    err = np.abs(model.objective[ks] - ref) / np.maximum(1.0, np.abs(ref))
+    assert err.max() < 1e-6, (err.max(), ks[np.argmax(err)])
+    batt = model.x[:, handles["battery_system_capacity"].index] * 1e-3
+    np.testing.assert_allclose(batt[ks], batt_ref, rtol=2e-3, atol=1.0)
+    it = model.iterations
+    print(f"\n[ipm] 256 distinct year-long LPs: {wall:.2f} s (first call of the handle), Newton iterations min {it.min()} mean {it.mean():.1f} max {it.max()}, "
+          f"{len(ks)} members against HiGHS: max rel. objective error {err.max():.2e}")
+
+
+@gpu
 def test_year_long_pem_and_nuclear_families_by_interior_point():
     """The other two year-long families at the reference's own horizons, by the interior-point form in its time-parallel geometry (64
     partitions), against the fixtures the PDHG forms are pinned to (tests/test_hip_stream.py): LP #5 (wind + battery + PEM, 8736 h,
@@ -179,10 +212,11 @@ def test_nuclear_price_taker_enumeration_by_interior_point():
 
 
 @gpu
-def test_a_batch_with_an_infeasible_member_goes_to_the_pdhg_forms():
+def test_an_infeasible_member_alone_goes_to_the_pdhg_forms():
     """The interior-point form solves or gives up; it does not certify.  A member with an impossible power balance makes it give up
-    (steps that stay below 1e-4), the batch then runs the PDHG forms as a whole: status 2 with its certificate for that member, the
-    others optimal."""
+    (steps that stay below 1e-4) - that member ALONE: the others are exported as solved (dsp_stats::ipm_solved), the given-up one is
+    packed into a lane group of its own for the PDHG form, which ends it with status 2 and its certificate (round 5 re-ran the whole
+    batch; the reference's sweeps keep their other points when one fails, run_pricetaker_wind_PEM.py:106-107)."""
     _need_gpu()
     from dispatches_amd import scenarios
     from dispatches_amd.hip_solver import HipPdlpSolver
@@ -192,8 +226,46 @@ def test_a_batch_with_an_infeasible_member_goes_to_the_pdhg_forms():
     lb, ub, rlo, rhi = model.scenario_bounds()
     model.rlo, model.rhi = np.tile(rlo, (B, 1)), np.tile(rhi, (B, 1))
     row = next(i for i, nm in enumerate(model.lp.row_names) if nm.startswith("splitter.sum_split[5]"))
+    clean = model.rlo.copy(), model.rhi.copy()
     model.rlo[3, row] = model.rhi[3, row] = 1e9                                    # wind = grid + battery + 1e9 kW: impossible
     solver.solve(model)
     st = solver.last_stats
-    assert st.stream_form != FORM_IPM
+    assert st.stream_form == FORM_IPM and st.ipm_solved == B - 1, (st.stream_form, st.ipm_solved)
     assert model.status[3] == 2 and (np.delete(model.status, 3) == 0).all(), model.status
+    obj = model.objective.copy()
+    # the other members' results are those of the clean batch
+    model.rlo, model.rhi = clean
+    solver.solve(model)
+    assert solver.last_stats.ipm_solved == B and (model.status == 0).all()
+    keep = np.arange(B) != 3
+    np.testing.assert_allclose(obj[keep], model.objective[keep], rtol=1e-9)
+
+
+@gpu
+def test_year_long_batch_with_an_infeasible_member_costs_one_lane_group():
+    """The same at the reference's horizon and a full group of lanes: 64 year-long LPs (the first 64 DISTINCT members of the wide family),
+    one of them infeasible.  63 come back optimal from the interior-point form, the infeasible one with status 2 from the PDHG form, and
+    the call takes no more than 1.5 x the clean batch (round 5: 8 x - the whole batch over again in the PDHG forms)."""
+    _need_gpu()
+    import time
+    from dispatches_amd import scenarios
+    from dispatches_amd.hip_solver import HipPdlpSolver
+    T, B, bad = 8736, 64, 37
+    solver = HipPdlpSolver(device=0, check_every=64, max_iter=1_000_000)
+    handles, model = scenarios.price_taker_batch(T, B, solver, throughput="chain", family="wide")
+    lb, ub, rlo, rhi = model.scenario_bounds()
+    row = next(i for i, nm in enumerate(model.lp.row_names) if nm.startswith("splitter.sum_split[5]"))
+    solver.solve(model)                                                            # clean batch (also warms the handle up)
+    assert (model.status == 0).all() and solver.last_stats.ipm_solved == B
+    t0 = time.perf_counter(); solver.solve(model); t_clean = time.perf_counter() - t0
+    ref = model.objective.copy()
+    model.rlo, model.rhi = np.tile(rlo, (B, 1)), np.tile(rhi, (B, 1))
+    model.rlo[bad, row] = model.rhi[bad, row] = 1e9
+    t0 = time.perf_counter(); solver.solve(model); t_bad = time.perf_counter() - t0
+    st = solver.last_stats
+    assert st.stream_form == FORM_IPM and st.ipm_solved == B - 1, (st.stream_form, st.ipm_solved)
+    assert model.status[bad] == 2 and (np.delete(model.status, bad) == 0).all(), model.status
+    keep = np.arange(B) != bad
+    np.testing.assert_allclose(model.objective[keep], ref[keep], rtol=1e-7)
+    print(f"\n[ipm] 64 year-long LPs: clean {t_clean:.2f} s, with one infeasible member {t_bad:.2f} s ({t_bad / t_clean:.2f} x)")
+    assert t_bad <= 1.5 * t_clean, (t_bad, t_clean)

@@ -32,7 +32,7 @@ def banded_from(N, w):
     return ab
 
 
-def solve(P, eps=1e-9, eps_obj=5e-7, max_iter=200, colscale=None, n_ruiz=10, dense_thr=16, verbose=0, reg=1e-12, prox=0.0, frac=0.99, refine=3, theta_cap=1e30, sigmin=0.05, mu0=0.0, gondzio=0):
+def solve(P, eps=1e-9, eps_obj=5e-7, max_iter=200, colscale=None, n_ruiz=10, dense_thr=16, verbose=0, reg=1e-12, prox=0.0, frac=0.99, refine=3, theta_cap=1e30, sigmin=0.05, mu0=0.0, gondzio=0, pcg=0, pcg_tol=1e-11, prefine=0, absref=0, rpk=0.0):
     """frac / sigmin: the product's settings since round 5's last commits (csrc/dsp_ipm.hip: 0.99 to the boundary, sigma >= 0.05); the first
     version ran 0.9995 / 0 (`frac=0.9995 sigmin=0` on the command line)"""
     A0 = sp.csr_matrix(P["A"])
@@ -112,10 +112,57 @@ def solve(P, eps=1e-9, eps_obj=5e-7, max_iter=200, colscale=None, n_ruiz=10, den
             rt = rd - cz + cf
             rhs = rp + Abar @ (theta * rt)
             dy = nsolve(rhs)
-            for _ in range(int(refine)):                     # iterative refinement on the full normal equations
+            if pcg:
+                # preconditioned conjugate gradients on the full normal equations, the factorisation (band + Woodbury) as preconditioner
+                # (experiment, round 6): plain refinement is a Richardson iteration and stagnates where I - M^-1 N is not a contraction
+                Nmul = lambda d: Abar @ (theta * (Abar.T @ d)) + delta * d
+                r = rhs - Nmul(dy)
+                nr0 = np.abs(rhs).max()
+                zv = nsolve(r); pv = zv.copy(); rz = r @ zv
+                k = 0
+                while k < int(pcg) and np.abs(r).max() > pcg_tol * nr0:
+                    Np = Nmul(pv)
+                    al = rz / (pv @ Np)
+                    dy = dy + al * pv
+                    r = r - al * Np
+                    zv = nsolve(r)
+                    rz_new = r @ zv
+                    pv = zv + (rz_new / rz) * pv
+                    rz = rz_new
+                    k += 1
+                solve.pcg_steps = getattr(solve, "pcg_steps", 0) + k
+                solve.pcg_res = max(getattr(solve, "pcg_res", 0.0), np.abs(r).max() / nr0)
+            elif absref:
+                # refinement until every row's residual, UNSCALED, is a fraction of what the termination test allows that row (experiment,
+                # round 6): the relative test max |res| <= tol max |rhs| lets a row whose own right-hand side is 1e-10 keep an error of
+                # 1e-11 x the largest entry (Theta up to 1e17 makes those 1e6) - a primal residual of 4e-5 that comes back after every step
+                atol = absref * eps * (1.0 + qn) / np.sqrt(m)
+                k = 0
+                while k < 8:
+                    res = rhs - Abar @ (theta * (Abar.T @ dy)) - delta * dy
+                    if np.abs(res / dr).max() <= atol:
+                        break
+                    dy = dy + nsolve(res); k += 1
+                solve.ref_steps = getattr(solve, "ref_steps", 0) + k
+                solve.ref_max = max(getattr(solve, "ref_max", 0), k)
+            else:
+              for _ in range(int(refine)):                     # iterative refinement on the full normal equations
                 res = rhs - Abar @ (theta * (Abar.T @ dy)) - delta * dy
                 dy = dy + nsolve(res)
             dv = theta * (Abar.T @ dy - rt)
+            # refinement of the PRIMAL Newton equation Abar dv = rp on the direction as it was actually formed (experiment, round 6): for
+            # a basic column Theta ~ 1e13 multiplies a difference of O(1) numbers that is ~ dv / Theta - the rounding of that difference
+            # is an error of 1e-6 |dv| that the normal equations' residual never sees
+            if verbose > 1 and it >= 64:
+                resn = rhs - Abar @ (theta * (Abar.T @ dy)) - delta * dy
+                r1 = rp - Abar @ dv
+                i1 = int(np.argmax(np.abs(r1)))
+                print(f"      direction: normal-eq residual max {np.abs(resn).max():.2e} (|rhs| max {np.abs(rhs).max():.2e}); primal Newton residual |rp - Abar dv| max {np.abs(r1).max():.2e} at row {i1} (rp there {rp[i1]:.2e}, |rp| max {np.abs(rp).max():.2e}); |dv| max {np.abs(dv).max():.2e} |dy| max {np.abs(dy).max():.2e}")
+            for _ in range(int(prefine)):
+                r1 = rp - Abar @ dv
+                dy1 = nsolve(r1)
+                dv = dv + theta * (Abar.T @ dy1)
+                dy = dy + dy1
             dz = np.where(hl, cz - z / wl * dv, 0.0)
             df = np.where(hu, cf + f / tu * dv, 0.0)
             return dv, dy, dz, df
@@ -140,8 +187,32 @@ def solve(P, eps=1e-9, eps_obj=5e-7, max_iter=200, colscale=None, n_ruiz=10, den
         apa, ada = steps(dva, dza, dfa)
         mu_aff = ((z + ada * dza) @ ((wl + apa * dva) * hl) + (f + ada * dfa) @ ((tu - apa * dva) * hu)) / nb
         sigma = max((mu_aff / mu) ** 3, sigmin)
+        if rpk > 0:                                           # complementarity may not run ahead of primal feasibility (experiment, round 6)
+            sigma = min(1.0, max(sigma, rpk * np.abs(rp).max() / mu))
         dv, dy, dz, df = direction(sigma * mu, dva * dza, -dva * dfa)
         ap, ad = steps(dv, dz, df)
+        # Gondzio's multiple centrality correctors (experiment, round 6): aim at a longer step, push the complementarity products of the
+        # trial point back into [beta_min, beta_max] x sigma mu, keep the corrected direction if the step grows
+        ncorr = 0
+        for _ in range(int(gondzio)):
+            apt, adt = min(1.0, 1.3 * ap + 0.1), min(1.0, 1.3 * ad + 0.1)
+            tgt = sigma * mu
+            pl = (wl + apt * dv) * (z + adt * dz); pu = (tu - apt * dv) * (f + adt * df)
+            tl = np.clip(pl, 0.1 * tgt, 10.0 * tgt) - pl; tu_ = np.clip(pu, 0.1 * tgt, 10.0 * tgt) - pu
+            tl = np.maximum(tl, -10.0 * tgt); tu_ = np.maximum(tu_, -10.0 * tgt)
+            cz = np.where(hl, tl / wl, 0.0); cf = np.where(hu, tu_ / tu, 0.0)
+            rt = -cz + cf
+            dyc = nsolve(Abar @ (theta * rt))
+            dvc = theta * (Abar.T @ dyc - rt)
+            dzc = np.where(hl, cz - z / wl * dvc, 0.0); dfc = np.where(hu, cf + f / tu * dvc, 0.0)
+            ap2, ad2 = steps(dv + dvc, dz + dzc, df + dfc)
+            if min(ap2, ad2) >= min(ap, ad) * 1.01 or (ap2 + ad2) >= 1.05 * (ap + ad):
+                dv, dy, dz, df = dv + dvc, dy + dyc, dz + dzc, df + dfc
+                ap, ad = ap2, ad2
+                ncorr += 1
+            else:
+                break
+        solve.ncorr = getattr(solve, "ncorr", 0) + ncorr
         ap, ad = min(1.0, frac * ap), min(1.0, frac * ad)
         v = v + ap * dv; y = y + ad * dy; z = z + ad * dz; f = f + ad * df
         # termination on the unscaled problem, the streaming path's test
@@ -158,10 +229,17 @@ def solve(P, eps=1e-9, eps_obj=5e-7, max_iter=200, colscale=None, n_ruiz=10, den
         rpn, rdn = np.linalg.norm(viol) / (1 + qn), np.linalg.norm(dres) / (1 + cn)
         bound = abs(po - do) + np.sum(np.abs(Yu) * viol) + np.sum(np.abs(dres) * np.abs(Xu))
         lim = max(eps_obj * (1 + abs(po + P["c0"])), 1e-12 * np.sum(np.abs(P["c"] * Xu)))
+        if verbose > 1:
+            rpi = b - Abar @ v
+            iv = int(np.argmax(viol)); ir = int(np.argmax(np.abs(rpi)))
+            print(f"    internal |b - Abar v| max {np.abs(rpi).max():.2e} at row {ir} ({P['lp'].row_names[ir]}), dr {dr[ir]:.2e}; viol max {viol.max():.2e} at row {iv} ({P['lp'].row_names[iv]}) rlo {P['rlo'][iv]:.6g} rhi {P['rhi'][iv]:.6g} AX {AX[iv]:.9g} dr {dr[iv]:.2e} qn {qn:.3e}")
         if verbose:
             print(f"  it {it} mu {mu:.2e} sigma {sigma:.1e} ap {ap:.3f} ad {ad:.3f} rp {rpn:.2e} rd {rdn:.2e} bound/lim {bound/lim:.2e} obj {po + P['c0']:.10e} "
                   f"theta {theta.min():.1e}..{theta.max():.1e} t {time.time()-t0:.1f}s", flush=True)
         if rpn <= eps and rdn <= eps and bound <= lim:
+            if verbose or absref:
+                print(f"  [refinement steps total {getattr(solve, 'ref_steps', 0)} max {getattr(solve, 'ref_max', 0)} over {2 * it} systems]")
+            solve.ref_steps = 0; solve.ref_max = 0
             return Xu, Yu, it, True
     return Xu, Yu, int(max_iter), False
 

@@ -22,7 +22,7 @@ def one(args):
     from dispatches_amd import scenarios
     from oracle import dispatch_lp_oracle as orc
     cf, lmp = scenarios.price_taker_inputs(T)
-    bf, lm = scenarios.PRICE_TAKER_FAMILY[k]
+    bf, lm = scenarios.PRICE_TAKER_FAMILY_WIDE[k]                 # (members 0 .. 15 = PRICE_TAKER_FAMILY)
     t = time.time()
     P, info = orc.wind_battery_price_taker(T, cf, lmp * lm, batt_cap_factor=bf)
     x, obj = P.solve(tight=True)
@@ -89,9 +89,35 @@ def nuclear_fixtures(T, points):
     np.savez(path, **out)
 
 
+def wide_fixtures(T, members, procs):
+    """python tools/make_price_taker_fixtures.py --wide [T] [stride] [processes]: adds T<T>w/{k, obj, npv, batt_mw} for every `stride`-th
+    member from 16 on of the 256-member scenarios.PRICE_TAKER_FAMILY_WIDE (round 6: the year-long batch as 256 DISTINCT LPs; members
+    0 .. 15 are the T<T>/ entries)."""
+    import multiprocessing as mp
+    path = os.path.join(os.path.dirname(__file__), "..", "tests", "golden", "oracle_price_taker.npz")
+    out = dict(np.load(path)) if os.path.exists(path) else {}
+    with mp.get_context("spawn").Pool(procs) as pool:
+        res = []
+        for r in pool.imap_unordered(one, [(T, k) for k in members]):
+            res.append(r)
+            print(f"member {r[0]}: obj {r[1]:.6f} batt {r[3]:.2f} MW, HiGHS {r[4]:.0f} s", flush=True)
+    res.sort()
+    out[f"T{T}w/k"] = np.array([r[0] for r in res])
+    out[f"T{T}w/obj"] = np.array([r[1] for r in res])
+    out[f"T{T}w/npv"] = np.array([r[2] for r in res])
+    out[f"T{T}w/batt_mw"] = np.array([r[3] for r in res])
+    print(f"wide T={T}: {len(res)} members, HiGHS {np.mean([r[4] for r in res]):.1f} s per member", flush=True)
+    np.savez(path, **out)
+
+
 if __name__ == "__main__":
     import multiprocessing as mp
     from dispatches_amd import scenarios
+    if len(sys.argv) > 1 and sys.argv[1] == "--wide":
+        T = int(sys.argv[2]) if len(sys.argv) > 2 else 8736
+        stride = int(sys.argv[3]) if len(sys.argv) > 3 else 4
+        wide_fixtures(T, list(range(16, 256, stride)), int(sys.argv[4]) if len(sys.argv) > 4 else max(1, (os.cpu_count() or 2) - 2))
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "--nuclear":
         nuclear_fixtures(int(sys.argv[2]) if len(sys.argv) > 2 else 8784, [int(a) for a in sys.argv[3:]] or [0, 17, 34, 59])
         sys.exit(0)

@@ -18,7 +18,7 @@ import pdlp_proto as pp
 fin = lambda a: np.where(np.isfinite(a), a, 0.0)
 
 
-def build(T, member=0, degr=None, throughput="chain"):
+def build(T, member=0, degr=None, throughput="chain", family="base"):
     """price-taker LP #4 at horizon T for member `member` of the scenario family; returns dict(A, c, lb, ub, rlo, rhi, c0, names)"""
     from dispatches_amd import scenarios
     from dispatches_amd.flowsheets import parameters as prm
@@ -28,7 +28,7 @@ def build(T, member=0, degr=None, throughput="chain"):
     class Dummy:
         def solve(self, *a, **k):
             raise RuntimeError
-    handles, model = scenarios.price_taker_batch(T, max(member + 1, 1), Dummy(), throughput=throughput)
+    handles, model = scenarios.price_taker_batch(T, max(member + 1, 1), Dummy(), throughput=throughput, family=family)
     lp = model.lp
     lb, ub, rlo, rhi = model.scenario_bounds()
     pick = lambda a: (a[member] if a.ndim == 2 else a).astype(float)
