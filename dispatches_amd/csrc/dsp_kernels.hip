@@ -188,6 +188,9 @@ __device__ __forceinline__ void stage_entries(Entry *dst, const Entry *__restric
 #ifndef DSP_MIN_WAVES_SMALL
 #define DSP_MIN_WAVES_SMALL 2
 #endif
+#ifndef DSP_ONE_WAVE_FROM
+#define DSP_ONE_WAVE_FROM 99      /* CPL + RPL from which the kernel is compiled for ONE wave per SIMD (512 registers: 256 V + 256 A) */
+#endif
 // WC / WR != 0: the ELL part of A^T / A is register-resident (RegEll); the template value packs the per-slot
 // widths, 4 bits each, and ownership follows the sorted layout (P.mr_colat / P.mr_rowat);
 // WC = WR = 0: generic path, matrix in LDS with run-time uniform widths, identity ownership.
@@ -207,7 +210,7 @@ struct Rare {
 };
 
 template <int CPL, int RPL, bool LONG, unsigned WC, unsigned WR, bool QP = false>
-__global__ void __launch_bounds__(512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : 2) pdlp_solve_kernel(SolveArgs a) {
+__global__ void __launch_bounds__((CPL + RPL >= DSP_ONE_WAVE_FROM && WC != 0) ? 256 : 512, (CPL + RPL <= 6) ? DSP_MIN_WAVES_SMALL : ((CPL + RPL >= DSP_ONE_WAVE_FROM && WC != 0) ? 1 : 2)) pdlp_solve_kernel(SolveArgs a) {
   constexpr bool MATREG = WC != 0;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // after a simplex pass that certified every scenario there is nothing to do (one scalar load per wave)

@@ -15,7 +15,7 @@ template __global__ void pdlp_solve_kernel<1, 1, false, 0x3u, 0x4u, false>(Solve
 template __global__ void pdlp_solve_kernel<4, 2, false, 0u, 0u, false>(SolveArgs);                   // generic (LDS matrix, with certificates)
 }
 EOT
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -S --cuda-device-only -I$src -o $out/$tag.s $out/$tag.hip -Rpass-analysis=kernel-resource-usage 2> $out/$tag.res
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 $KRES_FLAGS -S --cuda-device-only -I$src -o $out/$tag.s $out/$tag.hip -Rpass-analysis=kernel-resource-usage 2> $out/$tag.res
 python - $out/$tag.s $out/$tag.res <<'PY'
 import re, sys
 src = open(sys.argv[1]).read(); res = open(sys.argv[2]).read()
