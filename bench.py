@@ -149,8 +149,18 @@ def bench_double_loop(args, rank, local_rank, world, dev):
     kw = {} if args.warm_start < 0 else {"warm_start": bool(args.warm_start)}
     # --groups G: the rank's plants as G independent loops on G HIP streams whose simulated days overlap (rolling.PipelinedDoubleLoops:
     # 8192 plants on one MI355X 44.2 -> 35.4 ms per simulated day with two groups; 0 = automatic: two from 1024 plants per rank on)
-    loop = PipelinedDoubleLoops(B, device=local_rank, first_scenario=lo, groups=int(getattr(args, "groups", 0) or 0), **kw)
-    G = loop.groups
+    flowsheet = getattr(args, "flowsheet", None) or "wind_battery"
+    if flowsheet == "wind_battery":
+        loop = PipelinedDoubleLoops(B, device=local_rank, first_scenario=lo, groups=int(getattr(args, "groups", 0) or 0), **kw)
+        G = loop.groups
+    else:
+        # the nuclear (BASELINE config 2 is a nuclear DOUBLE LOOP) and wind + PEM flowsheets: the loop written over a descriptor of the
+        # flowsheet's rolling state (dispatches_amd/rolling_flowsheets.py), one group
+        from dispatches_amd.rolling_flowsheets import BatchedDoubleLoop
+        loop = BatchedDoubleLoop(flowsheet, B, device=local_rank, first_scenario=lo)
+        loop.day_ahead_iterations = lambda: loop.da.out["iters"]
+        loop.warm_start = False
+        G = 1
     buffers = make_gather_buffers(world, per, dev, width=2) if world > 1 else None
     status_ok = torch.zeros(B, dtype=torch.float64, device=dev)
 
@@ -205,15 +215,16 @@ def bench_double_loop(args, rank, local_rank, world, dev):
         spans = [{"days": [a, b], "ms_per_day": events[a].elapsed_time(events[b]) / (b - a),
                   "day_ahead_iterations_mean": float(da_stats[a:b, 0].mean()), "day_ahead_iterations_max": int(da_stats[a:b, 1].max())} for a, b in cuts]
         line = ({
-            "metric": f"plant-days simulated/sec, RTS-GMLC rolling double loop (config 4), {total} plants", "value": total * days / elapsed,
+            "metric": f"plant-days simulated/sec, RTS-GMLC rolling double loop ({'config 4' if flowsheet == 'wind_battery' else flowsheet}), {total} plants", "value": total * days / elapsed,
             "unit": "plant-days/s", "n_gpus": world, "steps": days, "warmup": max(1, args.warmup), "ms_per_step": 1e3 * elapsed / days,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "world_size": world, "collective_backend": (("gloo on host copies (REHEARSAL: ranks share cuda:0)" if os.environ.get("DSP_BENCH_SHARE_GPU") == "1" else
                                                          f"nccl(RCCL) {'.'.join(map(str, torch.cuda.nccl.version()))}") if world > 1 else None),
             "rehearsal": os.environ.get("DSP_BENCH_SHARE_GPU") == "1", "dist_world_size": dist_world, "rank_devices": rank_devices,
             "distinct_gpus": len({d["uuid"] for d in rank_devices}),
-            "config": {"workload": f"double_loop: {total} wind+battery plants ({per} per GPU), per simulated day 1 x 48-h day-ahead LP (PDLP "
-                                   "kernel) + 24 x (4-h real-time LP + 4-h tracking LP) (in-wave simplex), stub market, state hand-off on device",
+            "config": {"workload": f"double_loop: {total} {flowsheet.replace('_', '+')} plants ({per} per GPU), per simulated day 1 x 48-h day-ahead LP (PDLP "
+                                   f"kernel) + 24 x ({12 if flowsheet == 'nuclear' else 4}-h real-time LP + 4-h tracking LP) (in-wave simplex), stub market, state hand-off on device",
+                       "flowsheet": flowsheet,
                        "lp_solves_per_s": total * days * 49 / elapsed, "all_optimal": bool(okt.item()), "uncertified_solves": int(unc.item()),
                        "day_ahead_warm_start": bool(loop.warm_start),
                        "groups_per_gpu": G,
@@ -837,17 +848,23 @@ def baseline_configs(args, local_rank, dev, budget_s=360.0, depth=8):
                 "iterations": int(m.iterations[0]), "optimal": int((m.status == 0).sum()), "flagged": int(m.uncertified.sum()),
                 "rel_obj_err_vs_oracle_fixture": float(abs(m.objective[0] - ref) / max(1.0, abs(ref)))}
     leg("1", config1)
-    # (steps = a multiple of the stream depth the headline chose in its warm-up: every stream gets the same number of launches)
-    leg("2", lambda: _fused_config_entry("2", "nuclear_24h", 256, local_rank, dev, steps=4 * depth, depth=depth))
-    leg("3", lambda: _fused_config_entry("3", "wind_pem_48h", 4096, local_rank, dev, steps=2 * depth, depth=depth))
-    leg("4-day-ahead", lambda: _fused_config_entry("4-day-ahead", "wind_battery_48h", 4096, local_rank, dev, steps=depth, depth=depth))
 
     def sub(**kw):
         a = copy.copy(args)
         for k, v in kw.items():
             setattr(a, k, v)
         return a
-    leg("4", lambda: _condense("4", bench_double_loop(sub(workload="double_loop", total=8192, steps=366, warmup=2, groups=0), 0, local_rank, 1, dev),
+    # (steps = a multiple of the stream depth the headline chose in its warm-up: every stream gets the same number of launches)
+    leg("2", lambda: _fused_config_entry("2", "nuclear_24h", 256, local_rank, dev, steps=4 * depth, depth=depth))
+    dl_keys = ("flowsheet", "days", "year_measured", "lp_solves", "lp_solves_per_s", "all_optimal", "uncertified_solves", "groups_per_gpu", "spans",
+               "day_ahead_iterations_per_day", "seconds_per_simulated_year", "mean_revenue_per_plant_day")
+    # config 2 is a DOUBLE LOOP: 256 nuclear plants through four simulated weeks (holdup hand-off on the device, 12-h real-time horizon)
+    leg("2-double-loop", lambda: _condense("2-double-loop", bench_double_loop(sub(workload="double_loop", flowsheet="nuclear", total=256, steps=28, warmup=2, groups=0),
+                                                                             0, local_rank, 1, dev), dl_keys))
+    leg("3", lambda: _fused_config_entry("3", "wind_pem_48h", 4096, local_rank, dev, steps=2 * depth, depth=depth))
+    leg("4-day-ahead", lambda: _fused_config_entry("4-day-ahead", "wind_battery_48h", 4096, local_rank, dev, steps=depth, depth=depth))
+
+    leg("4", lambda: _condense("4", bench_double_loop(sub(workload="double_loop", flowsheet="wind_battery", total=8192, steps=366, warmup=2, groups=0), 0, local_rank, 1, dev),
                                ("days", "year_measured", "lp_solves", "lp_solves_per_s", "all_optimal", "uncertified_solves", "groups_per_gpu", "spans",
                                 "day_ahead_iterations_per_day", "seconds_per_simulated_year", "mean_revenue_per_plant_day")))
     leg("5", lambda: _condense("5", bench_qp_sweep(sub(workload="qp_sweep", batch=4096, steps=12, warmup=3, no_sweep=True, cpu_sample=0, eps=None, streams=0),
@@ -904,6 +921,8 @@ def main():
                     help="the burst of --steps steps is repeated until the timed bursts cover this many seconds; the median burst is reported")
     ap.add_argument("--max-bursts", type=int, default=500)
     ap.add_argument("--no-eps4", action="store_true", help="skip the extra eps_rel = 1e-4 (PDLP default tolerance) leg of the LP metric line")
+    ap.add_argument("--flowsheet", default=None, choices=["wind_battery", "nuclear", "wind_pem"],
+                    help="--workload double_loop: the flowsheet of the plants (default wind_battery = BASELINE config 4; nuclear = config 2's double loop)")
     ap.add_argument("--family", default=None, choices=["base", "wide"],
                     help="--workload price_taker: members of the batch - wide (default) = the 256 distinct ones of scenarios.PRICE_TAKER_FAMILY_WIDE, base = the 16-member family cycled")
     ap.add_argument("--pdhg", action="store_true", help="--solve lines: the PDHG forms instead of the interior-point form (dsp_options::no_interior_point)")

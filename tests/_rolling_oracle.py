@@ -178,3 +178,59 @@ def check_recorded_plant(args, base_hour=0, base_day=0):
         if h == 23:
             soc_end[d] = round(float(x[maps["tr"][0, 4]]), 2)
     return dict(plant=k, worst=worst, hours=len(hours), revenue=revenue, delivered=delivered_mwh, soc=soc_end)
+
+
+# ---- the generic loop (dispatches_amd/rolling_flowsheets.py): nuclear and wind + PEM against the oracle's own hourly LPs ----------------
+def check_flowsheet_hours_against_the_oracle(loop, hours):
+    """First `hours` hours of a simulated day of a BatchedDoubleLoop for "nuclear" or "wind_pem": the oracle's real-time bidding LP and
+    tracking LP (oracle/dispatch_lp_oracle.py: nuclear_rt / nuclear_track, wind_pem_rt / wind_pem_track - un-reduced rows) are built from
+    the loop's state at that hour (realised holdup, windows, cleared day-ahead dispatch, the offer handed to the tracker) and their
+    optimal objectives (HiGHS) must equal the loop's (solver objective + the objective constant it maintains) to 1e-6; the state the
+    next hour starts from must be the tracker's realised value rounded as update_model does."""
+    from oracle import dispatch_lp_oracle as orc
+    B = loop.B
+    offers = loop.day_ahead().cpu().numpy()
+    da_prices = loop.da_prices.cpu().numpy()
+    rt_s = loop.rt_series.cpu().numpy()
+    cf_s = loop.cf_series.cpu().numpy() if loop.cf_series is not None else None
+    start = loop.start.cpu().numpy()
+    N = loop.N
+    Trt, Ttr = loop.rt.T, loop.tr.T
+    worst = 0.0
+    for h in range(hours):
+        assert h + Trt <= 24, "the oracle's real-time LP fixes every hour of its horizon: stay inside the cleared day"
+        state0 = loop.state.cpu().numpy().copy()
+        loop.hour_step()
+        x_rt = loop.rt.out["x"].cpu().numpy()
+        obj_rt = (loop.rt.out["obj"] + loop.rt.c0).cpu().numpy()
+        obj_tr = (loop.tr.out["obj"] + loop.tr.c0).cpu().numpy()
+        x_tr = loop.tr.out["x"].cpu().numpy()
+        assert int(loop.rt.out["status"].abs().sum().item()) == 0 and int(loop.tr.out["status"].abs().sum().item()) == 0
+        PT, PTc = loop.rt.PT.cpu().numpy(), loop.rt.PT_const.cpu().numpy()
+        for k in range(B):
+            idx = (start[k] + h + np.arange(Trt)) % N
+            rt = rt_s[idx]
+            cleared = offers[k, h:h + Trt]
+            offer = x_rt[k] @ PT.T + PTc                                         # what the loop handed to its tracker
+            if loop.flowsheet == "nuclear":
+                P = orc.nuclear_rt(Trt, rt, cleared, holdup0=float(state0[k, 0]))[0]
+                Q = orc.nuclear_track(Ttr, offer[:Ttr], holdup0=float(state0[k, 0]))[0]
+            else:
+                kw = loop.rt.wind[1]
+                P = orc.wind_pem_rt(Trt, cf_s[idx], rt, cleared, wind_kw=kw)[0]
+                Q = orc.wind_pem_track(Ttr, cf_s[idx][:Ttr], offer[:Ttr], wind_kw=kw)[0]
+            # (the product keeps day_ahead_power as a fixed column: its objective carries - DA x cleared, the oracle's A.4 RT form does not)
+            ref_rt = P.solve(tight=True)[1] - float(da_prices[k, h:h + Trt] @ cleared)
+            ref_tr = Q.solve(tight=True)[1]
+            for got, ref, what in ((obj_rt[k], ref_rt, "rt"), (obj_tr[k], ref_tr, "track")):
+                gap = abs(got - ref) / max(1.0, abs(ref))
+                worst = max(worst, gap)
+                assert gap <= 1e-6, (loop.flowsheet, what, h, k, got, ref)
+        state1 = loop.state.cpu().numpy()
+        for j, col in enumerate(loop.tr.state_real):
+            real = x_tr[:, col]
+            assert np.abs(state1[:, j] - real).max() <= 0.5 / loop.scale[j] + 1e-9 * max(1.0, np.abs(real).max()), (loop.flowsheet, "state hand-off", h)
+            assert np.abs(state1[:, j] * loop.scale[j] - np.round(state1[:, j] * loop.scale[j])).max() <= 1e-6 * max(1.0, np.abs(state1[:, j]).max() * loop.scale[j])
+    res, ok = loop.results()
+    assert ok
+    return worst

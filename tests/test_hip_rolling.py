@@ -255,3 +255,75 @@ def _year_block(arg):
     # re-base the block: the oracle check indexes hours / days from the plant's first recorded hour
     lead = 1 if h0 > 0 else 0
     return check_recorded_plant((k, 17, maps, part, range(h0, 24 * d1)), base_hour=h0 - lead, base_day=d0)
+
+
+@gpu
+@pytest.mark.parametrize("flowsheet", ["nuclear", "wind_pem"])
+def test_generic_double_loop_hours_are_optimal_for_the_oracles_lps(flowsheet):
+    """BASELINE config 2 is a nuclear DOUBLE LOOP: the device-resident loop over a descriptor of the flowsheet's rolling state
+    (dispatches_amd/rolling_flowsheets.py) for the nuclear (tank holdup handed on as round(holdup[-1]), 12-h real-time horizon) and
+    wind + PEM (capacity-factor shift only) flowsheets - every hourly objective of the first hours against the oracle's own un-reduced
+    LPs of the loop's state (HiGHS), 1e-6."""
+    from dispatches_amd.rolling_flowsheets import BatchedDoubleLoop
+    from tests._rolling_oracle import check_flowsheet_hours_against_the_oracle
+    loop = BatchedDoubleLoop(flowsheet, 6, device=0)
+    worst = check_flowsheet_hours_against_the_oracle(loop, 5)
+    assert worst <= 1e-6
+    print(f"\n[{flowsheet}] worst hourly objective gap against the oracle {worst:.2e}")
+
+
+@gpu
+@pytest.mark.parametrize("flowsheet", ["wind_battery", "nuclear", "wind_pem"])
+def test_batched_double_loop_of_every_flowsheet_matches_host_objects(flowsheet):
+    """The generic device loop against the product's own host objects (Bidder / Tracker on the flowsheet's model object, one scenario each,
+    the reference's call order: real-time bid -> tracking -> update_model on tracker and bidder): delivered power and realised state of
+    the first hours of a day; and the graph-replayed days equal the eagerly issued ones."""
+    import torch
+    from dispatches_amd import scenarios
+    from dispatches_amd.hip_solver import HipPdlpSolver
+    from dispatches_amd.rolling_flowsheets import BatchedDoubleLoop, _templates
+    from dispatches_amd.workflow import Bidder, Tracker
+    B, hours = 3, 5
+    loop = BatchedDoubleLoop(flowsheet, B, device=0)
+    offers = loop.day_ahead().cpu().numpy()
+    da_prices = loop.da_prices.cpu().numpy()
+    dev = dict(delivered=[], state=[])
+    for _ in range(hours):
+        dev["delivered"].append(loop.hour_step().cpu().numpy())
+        dev["state"].append(loop.state.cpu().numpy().copy())
+    assert loop.results()[1]
+    da_s, rt_s = loop.da_series.cpu().numpy(), loop.rt_series.cpu().numpy()
+    cf_s = loop.cf_series.cpu().numpy() if loop.cf_series is not None else None
+    for k in range(B):
+        start = int(loop.start[k].item())
+        fc = scenarios.WindowForecaster(da_s, rt_s, [start])
+        tmpl = _templates(flowsheet, 48, 4)[0].bidding_model_object
+        if flowsheet == "nuclear":
+            mk = lambda: tmpl.__class__(tmpl.model_data)
+        elif flowsheet == "wind_pem":
+            mk = lambda: tmpl.__class__(tmpl.model_data, wind_capacity_factors=list(np.roll(cf_s, -start)), wind_pmax_mw=tmpl._wind_pmax_mw, pem_pmax_mw=tmpl._pem_pmax_mw)
+        else:
+            mk = lambda: tmpl.__class__(model_data=tmpl.model_data, wind_capacity_factors=list(np.roll(cf_s, -start)), wind_pmax_mw=200.0,
+                                        battery_pmax_mw=25.0, battery_energy_capacity_mwh=100.0)
+        bidder = Bidder(mk(), day_ahead_horizon=48, real_time_horizon=loop.rt.T, n_scenario=1, solver=HipPdlpSolver(device=0), forecaster=fc)
+        tracker = Tracker(tracking_model_object=mk(), tracking_horizon=4, n_tracking_hour=1, solver=HipPdlpSolver(device=0))
+        for h in range(hours):
+            bidder.compute_real_time_bids("2020-01-02", h, list(da_prices[k]), list(offers[k]))
+            dispatch = [float(v) for v in bidder.real_time_model.expression_values("P_T")[0]][:4]
+            prof = tracker.track_market_dispatch(market_dispatch=dispatch, date="2020-01-02", hour=h)
+            delivered = tracker.get_last_delivered_power()
+            tracker.update_model(**prof)
+            bidder.update_real_time_model(**prof)
+            assert dev["delivered"][h][k] == pytest.approx(delivered, abs=1e-6 * 1000), (flowsheet, k, h)
+            for j, (key, scale) in enumerate(zip(prof, loop.scale)):
+                assert dev["state"][h][k, j] == pytest.approx(round(prof[key][-1], int(round(np.log10(scale)))), abs=1.01 / scale), (flowsheet, k, h, key)
+    # graphs: three days replayed = three days issued eagerly
+    res = {}
+    for graphs in (False, True):
+        l2 = BatchedDoubleLoop(flowsheet, 64, device=0, use_graphs=graphs)
+        for _ in range(3):
+            l2.run_day()
+        torch.cuda.synchronize()
+        res[graphs] = (l2.revenue.cpu().numpy().copy(), l2.state.cpu().numpy().copy(), l2.results()[1])
+    assert res[True][2] and res[False][2]
+    assert np.array_equal(res[True][0], res[False][0]) and np.array_equal(res[True][1], res[False][1])

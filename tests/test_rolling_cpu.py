@@ -224,3 +224,38 @@ def test_two_optimal_trajectories_of_the_same_loop_drift_apart():
     assert 0 < same.sum() < days                                   # parts, but not everywhere
     assert abs(o["revenue"].sum() - ref_rev.sum()) <= 2.5e-3 * ref_rev.sum()
     assert abs(o["delivered"].sum() - ref_mwh.sum()) <= 2e-4 * ref_mwh.sum()
+
+
+def test_generic_loop_reproduces_the_wind_battery_loop_on_cpu():
+    """dispatches_amd/rolling_flowsheets.py::BatchedDoubleLoop("wind_battery") - the loop written over a descriptor of the flowsheet's
+    rolling state - gives exactly the day of the specialised BatchedWindBatteryDoubleLoop (same windows, objective vectors and constants,
+    bounds, hand-off), on the HiGHS stand-in backend."""
+    from dispatches_amd.rolling import BatchedWindBatteryDoubleLoop
+    from dispatches_amd.rolling_flowsheets import BatchedDoubleLoop
+    from tests._highs_solver import HighsTensorLP
+    B = 3
+    a = BatchedWindBatteryDoubleLoop(B, lp_backend=HighsTensorLP)
+    g = BatchedDoubleLoop("wind_battery", B, lp_backend=HighsTensorLP)
+    a.run_day()
+    g.run_day()
+    # (power output as a dense row product there, as the sum of its two columns here: the last bits of the sums may differ)
+    assert np.allclose(a.revenue.numpy(), g.revenue.numpy(), rtol=1e-12) and np.allclose(a.energy_mwh.numpy(), g.energy_mwh.numpy(), rtol=1e-12)
+    assert np.array_equal(a.soc.numpy(), g.state.numpy()[:, 0]) and np.array_equal(a.thr.numpy(), g.state.numpy()[:, 1])
+    for x, y in ((a.da, g.da), (a.rt, g.rt), (a.tr, g.tr)):
+        assert np.allclose(x.c0.numpy(), y.c0.numpy(), rtol=1e-13) and np.allclose(x.c.numpy(), y.c.numpy(), rtol=1e-13, atol=1e-15)
+
+
+@pytest.mark.parametrize("flowsheet", ["nuclear", "wind_pem"])
+def test_generic_loop_hours_are_optimal_for_the_oracles_lps_on_cpu(flowsheet):
+    """The rolling double loop of the nuclear (config 2 is a nuclear DOUBLE LOOP: holdup hand-off `round(holdup[-1])`,
+    nuclear_flowsheet_multiperiod_class.py:218-239; 12-h real-time horizon) and wind + PEM (capacity-factor shift only,
+    wind_PEM_double_loop.py:185-204) flowsheets, on the HiGHS stand-in backend: hourly objectives against the oracle's own LPs."""
+    from dispatches_amd.rolling_flowsheets import BatchedDoubleLoop
+    from tests._highs_solver import HighsTensorLP
+    from tests._rolling_oracle import check_flowsheet_hours_against_the_oracle
+    loop = BatchedDoubleLoop(flowsheet, 3, lp_backend=HighsTensorLP)
+    assert loop.rt.T == (12 if flowsheet == "nuclear" else 4) and loop.tr.T == 4 and loop.state.shape == (3, 1 if flowsheet == "nuclear" else 0)
+    worst = check_flowsheet_hours_against_the_oracle(loop, 4)
+    assert worst <= 1e-6
+    if flowsheet == "nuclear":                                        # the tank fills: the hand-off is not the trivial zero
+        assert float(loop.state.abs().max()) > 0
