@@ -124,3 +124,52 @@ def curves(counts, U, M, p_min, pmin2):
     if W > 1:
         cost[:, 1:] = cost[:, :1] + np.cumsum(np.diff(U, axis=1) * M[:, 1:], axis=1)
     return n, U, cost
+
+
+
+class PairList:
+    """The (power, cost) pairs of ONE bid curve as the reference's consumers read them - a sequence of 2-tuples - held as the two
+    arrays the curve was computed in.  The tuples are made when somebody looks (iteration, indexing, comparison, repr): a 4096-scenario
+    day is 24 curves of ~1 300 points, and building 31 k tuples eagerly was a fifth of `compute_day_ahead_bids` although a market
+    reads one generator-hour at a time (and the records never read them: `_record_bids` takes the arrays)."""
+    __slots__ = ("power", "cost", "_pairs")
+
+    def __init__(self, power, cost):
+        self.power, self.cost, self._pairs = power, cost, None
+
+    def _list(self):
+        if self._pairs is None:
+            self._pairs = list(zip(self.power.tolist(), self.cost.tolist()))
+        return self._pairs
+
+    def __len__(self):
+        return len(self.power)
+
+    def __getitem__(self, i):
+        return self._list()[i]
+
+    def __iter__(self):
+        return iter(self._list())
+
+    def __eq__(self, other):
+        if isinstance(other, PairList):
+            other = other._list()
+        if isinstance(other, (list, tuple)):
+            return self._list() == list(other)
+        return NotImplemented
+
+    def __ne__(self, other):
+        r = self.__eq__(other)
+        return r if r is NotImplemented else not r
+
+    __hash__ = None
+
+    def __repr__(self):
+        return repr(self._list())
+
+    def __reduce__(self):                               # pickles / deep copies as the plain list
+        return (list, (self._list(),))
+
+
+import collections.abc as _abc
+_abc.Sequence.register(PairList)

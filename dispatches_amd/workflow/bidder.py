@@ -540,7 +540,7 @@ class Bidder(StochasticProgramBidder):
         for t_idx in model.HOUR:
             t = t_idx + hour
             up, cost = hours[t_idx]
-            p_cost = list(zip(up.tolist(), cost.tolist()))
+            p_cost = bc.PairList(up, cost)                 # a sequence of (power, cost) tuples, made when read
             p_max = float(up[-1])
             bids[t] = {gen: {"p_cost": p_cost, "p_min": md.p_min, "p_max": p_max,
                              "startup_capacity": p_max, "shutdown_capacity": p_max}}
@@ -553,18 +553,21 @@ class Bidder(StochasticProgramBidder):
         reference's layout); built as one array instead of row dictionaries."""
         keys = [(t, gen) for t in bids for gen in bids[t]]
         width = max([self.n_scenario] + [len(bids[t][gen]["p_cost"]) for t, gen in keys])
-        data = np.full((len(keys), 2 * width), np.nan)
         cached = getattr(self, "_curve_arrays", {})
-        for r, (t, gen) in enumerate(keys):
+        curves = []                        # the arrays of every curve, taken NOW (the caller may edit the bids later); the table is filled in frame()
+        for t, gen in keys:
             hit = cached.get((t, gen))
-            if hit is not None and hit[0] == id(bids[t][gen]["p_cost"]):      # the very list _assemble_bids built: its arrays
-                pw, pc = hit[1], hit[2]
+            if hit is not None and hit[0] == id(bids[t][gen]["p_cost"]):      # the very sequence _assemble_bids built: its arrays
+                curves.append((hit[1], hit[2]))
             else:                                                               # bids from elsewhere (or edited): parse them
-                arr = np.asarray(bids[t][gen]["p_cost"], float).reshape(-1, 2)
-                pw, pc = arr[:, 0], arr[:, 1]
-            data[r, 0:2 * len(pw):2] = pw
-            data[r, 1:2 * len(pw):2] = pc
+                arr = np.asarray(list(bids[t][gen]["p_cost"]), float).reshape(-1, 2)
+                curves.append((arr[:, 0], arr[:, 1]))
+
         def frame():                       # built once, in write_results
+            data = np.full((len(keys), 2 * width), np.nan)
+            for r, (pw, pc) in enumerate(curves):
+                data[r, 0:2 * len(pw):2] = pw
+                data[r, 1:2 * len(pw):2] = pc
             cols = [f"{kind} {k} [{unit}]" for k in range(width) for kind, unit in (("Power", "MW"), ("Cost", "$"))]
             head = pd.DataFrame({"Generator": [g for _, g in keys], "Date": date, "Hour": [t for t, _ in keys], **kwargs})
             return pd.concat([head, pd.DataFrame(data, columns=cols)], axis=1)
