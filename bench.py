@@ -289,7 +289,7 @@ def _ipm_roofline(B, m, parts):
     if parts <= 1:
         out.update(bound="latency", peak=None, unit=None)
         return out
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r5*_ipm_kernel_stats_T8736_B{B}.csv")), reverse=True):
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r[56]*_ipm_kernel_stats_T8736_B{B}.csv")), reverse=True):
         dur, W = {}, None
         for row in csv.DictReader(open(f)):
             nm = row["Name"]
@@ -307,7 +307,7 @@ def _ipm_roofline(B, m, parts):
             break
     # HBM bytes of the same five kernels per solve: FETCH_SIZE x 2 (gfx950: half the bytes of a coalesced streaming read are counted) + WRITE_SIZE,
     # KB, from the newest committed counter summary of this form at this batch (tools/gpu_ipm_pmc.sh: one --pmc pass per counter)
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r5*_ipm_pmc_summary_B{B}.csv")), reverse=True):
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r[56]*_ipm_pmc_summary_B{B}.csv")), reverse=True):
         tr = {}
         for row in csv.DictReader(open(f)):
             for key in ("ForwardBody", "BackwardBody", "k_ipm_border_dot", "k_ipm_red_solve", "k_ipm_border_apply"):
@@ -621,7 +621,7 @@ def bench_qp_sweep(args, rank, local_rank, world, dev):
     sweep = []
     if rank == 0 and not getattr(args, "no_sweep", False):
         for prec in (0, 1):
-            for eps in (1e-3, 1e-4, 1e-5, 1e-6, 1e-7, 1e-8, 1e-9):
+            for eps in (getattr(args, "sweep_rungs", None) or (1e-3, 1e-4, 1e-5, 1e-6, 1e-7, 1e-8, 1e-9)):
                 o = default_options(**{**hints, "precision": prec, "eps_rel": eps, "eps_obj": 0.0, "max_iter": args.sweep_max_iter})
                 lone(o)
                 sweep.append(dict(precision="f32" if prec else "f64", eps_rel=eps, **lone(o)))
@@ -867,9 +867,14 @@ def baseline_configs(args, local_rank, dev, budget_s=360.0, depth=8):
     leg("4", lambda: _condense("4", bench_double_loop(sub(workload="double_loop", flowsheet="wind_battery", total=8192, steps=366, warmup=2, groups=0), 0, local_rank, 1, dev),
                                ("days", "year_measured", "lp_solves", "lp_solves_per_s", "all_optimal", "uncertified_solves", "groups_per_gpu", "spans",
                                 "day_ahead_iterations_per_day", "seconds_per_simulated_year", "mean_revenue_per_plant_day")))
-    leg("5", lambda: _condense("5", bench_qp_sweep(sub(workload="qp_sweep", batch=4096, steps=12, warmup=3, no_sweep=True, cpu_sample=0, eps=None, streams=0),
-                                                   0, local_rank, 1, dev),
-                               ("eps_rel", "optimal", "flagged", "max_rel_obj_err_vs_oracle_bracket", "scenarios_beyond_1e-6", "lone_batch")))
+    def config5():
+        # the contract setting pipelined + the fp64 / fp32 tolerance ladder in three rungs (config 5's stated content; all seven: --workload qp_sweep)
+        line = bench_qp_sweep(sub(workload="qp_sweep", batch=4096, steps=12, warmup=3, no_sweep=False, sweep_rungs=(1e-4, 1e-6, 1e-9), cpu_sample=0, eps=None,
+                                  streams=0), 0, local_rank, 1, dev)
+        e = _condense("5", line, ("eps_rel", "optimal", "flagged", "max_rel_obj_err_vs_oracle_bracket", "scenarios_beyond_1e-6", "lone_batch"))
+        e["ladder"] = [{k: r.get(k) for k in ("precision", "eps_rel", "kernel_ms", "terminated", "mean_iterations", "obj_err_median", "obj_err_max")} for r in line.get("sweep", [])]
+        return e
+    leg("5", config5)
     leg("bidder_api", lambda: _condense("bidder_api", bench_bidder_api(sub(workload="bidder_api", batch=4096, steps=12, warmup=2), 0, local_rank, 1, dev),
                                         ("call_ms", "solver_solve_ms", "kernel_ms", "host_rest_ms", "optimal", "curve_points_per_hour",
                                          "bids_identical_to_numpy_path", "numpy_path_call_ms")))

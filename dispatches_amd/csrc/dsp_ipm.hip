@@ -157,9 +157,9 @@ __device__ __forceinline__ void ipm_put(const IpmArgs &a, int q, double val, siz
 // sum (or minimum / maximum) over the blocks' partials part[q][block][lane], q < NQ, by a workgroup of 256 threads = 4 waves x the 64
 // scenarios of the group: every wave takes a quarter of the chunks with four independent accumulators (the loads of a plain loop queue
 // up one memory latency each: a 512-chunk sum took 0.95 ms), LDS combines.  Every thread returns the result.
-template <int NQ, int OP>                  // OP 0: sum, 1: min, 2: max
-__device__ __forceinline__ void ipm_finish(const double *part, int nch, size_t Bp, size_t s, double (&out)[NQ], int nq = NQ) {
-  __shared__ double red[4][NQ][64];
+template <int NQ, int OP, int NW = 4>      // OP 0: sum, 1: min, 2: max; NW waves per workgroup (8 where NQ <= 8: with up to 1024 partials per lane
+__device__ __forceinline__ void ipm_finish(const double *part, int nch, size_t Bp, size_t s, double (&out)[NQ], int nq = NQ) {   // the walk is the kernel)
+  __shared__ double red[NW][NQ][64];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   auto op = [](double x, double y) { return OP == 0 ? x + y : OP == 1 ? fmin(x, y) : fmax(x, y); };
   const double e0 = OP == 0 ? 0.0 : OP == 1 ? 1e300 : -1e300;
@@ -168,17 +168,23 @@ __device__ __forceinline__ void ipm_finish(const double *part, int nch, size_t B
     double acc[4] = {e0, e0, e0, e0};
     if (q >= nq) { red[wv][q][lane] = e0; continue; }      // (slots nobody filled: K = 1 uses 1 of the Woodbury matrix's 16)
     int c = wv;
-    for (; c + 12 < nch; c += 16) {
+    for (; c + 3 * NW < nch; c += 4 * NW) {
 #pragma unroll
-      for (int u = 0; u < 4; ++u) acc[u] = op(acc[u], part[((size_t)q * nch + c + 4 * u) * Bp + s]);
+      for (int u = 0; u < 4; ++u) acc[u] = op(acc[u], part[((size_t)q * nch + c + NW * u) * Bp + s]);
     }
-    for (; c < nch; c += 4) acc[0] = op(acc[0], part[((size_t)q * nch + c) * Bp + s]);
+    for (; c < nch; c += NW) acc[0] = op(acc[0], part[((size_t)q * nch + c) * Bp + s]);
     red[wv][q][lane] = op(op(acc[0], acc[1]), op(acc[2], acc[3]));
   }
   __syncthreads();
 #pragma unroll
-  for (int q = 0; q < NQ; ++q) out[q] = op(op(red[0][q][lane], red[1][q][lane]), op(red[2][q][lane], red[3][q][lane]));
+  for (int q = 0; q < NQ; ++q) {
+    double t = red[0][q][lane];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) t = op(t, red[w][q][lane]);
+    out[q] = t;
+  }
 }
+constexpr int kFinW = 8;                   // waves of the finish kernels (all but the Woodbury matrix's, whose 16 slots x 8 waves would not fit)
 
 // ---- setup -------------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_ipm_cmax(IpmArgs a) {
@@ -190,10 +196,10 @@ __global__ __launch_bounds__(256) void k_ipm_cmax(IpmArgs a) {
   ipm_put<2>(a, 0, mx, s);
 }
 
-__global__ __launch_bounds__(256) void k_ipm_cmax_finish(IpmArgs a) {
+__global__ __launch_bounds__(64 * kFinW) void k_ipm_cmax_finish(IpmArgs a) {
   const size_t s = (size_t)blockIdx.x * 64 + (threadIdx.x & 63), Bp = a.w.Bp;
   double mx[1];
-  ipm_finish<1, 2>(a.w.part, a.w.nch / 4, Bp, s, mx);
+  ipm_finish<1, 2, kFinW>(a.w.part, a.w.nch / 4, Bp, s, mx);
   if (threadIdx.x < 64 && a.w.state[s] == 0) { a.w.sc[SC_CS * Bp + s] = mx[0] > 1e-300 ? mx[0] : 1.0; a.w.sc[SC_RPMIN * Bp + s] = 1e300; }
 }
 
@@ -263,10 +269,10 @@ __global__ __launch_bounds__(256) void k_ipm_wide_aty(IpmArgs a, const double *v
     ipm_put<0>(a, k, t, s);
   }
 }
-__global__ __launch_bounds__(256) void k_ipm_wide_aty_finish(IpmArgs a) {
+__global__ __launch_bounds__(64 * kFinW) void k_ipm_wide_aty_finish(IpmArgs a) {
   const size_t s = (size_t)blockIdx.x * 64 + (threadIdx.x & 63), Bp = a.w.Bp;
   double t[kIpmMaxK];
-  ipm_finish<kIpmMaxK, 0>(a.w.part, a.w.nch / 4, Bp, s, t, a.P.K);
+  ipm_finish<kIpmMaxK, 0, kFinW>(a.w.part, a.w.nch / 4, Bp, s, t, a.P.K);
   if (threadIdx.x >= 64 || a.w.state[s] != 0) return;
 #pragma unroll
   for (int k = 0; k < kIpmMaxK; ++k) if (k < a.P.K) a.w.wat[(size_t)k * Bp + s] = t[k];
@@ -306,10 +312,10 @@ __global__ __launch_bounds__(256) void k_ipm_resid(IpmArgs a) {
   for (int i = i0; i < i1; ++i) a.w.rp[(size_t)i * Bp + s] = -ipm_au(a.P, a.w.v, i, Bp, s);
 }
 
-__global__ __launch_bounds__(256) void k_ipm_mu(IpmArgs a) {
+__global__ __launch_bounds__(64 * kFinW) void k_ipm_mu(IpmArgs a) {
   const size_t s = (size_t)blockIdx.x * 64 + (threadIdx.x & 63), Bp = a.w.Bp;
   double t[2];
-  ipm_finish<2, 0>(a.w.part, a.w.nch / 4, Bp, s, t);
+  ipm_finish<2, 0, kFinW>(a.w.part, a.w.nch / 4, Bp, s, t);
   if (threadIdx.x < 64 && a.w.state[s] == 0) {
     a.w.sc[SC_MU * Bp + s] = t[0] / fmax(t[1], 1.0);
     a.w.sc[SC_NB * Bp + s] = t[1];
@@ -636,11 +642,11 @@ __global__ __launch_bounds__(256) void k_ipm_wood_s(IpmArgs a) {
 }
 
 // g = Sinv (Ad' q)
-__global__ __launch_bounds__(256) void k_ipm_wood_g(IpmArgs a) {
+__global__ __launch_bounds__(64 * kFinW) void k_ipm_wood_g(IpmArgs a) {
   const size_t s = (size_t)blockIdx.x * 64 + (threadIdx.x & 63), Bp = a.w.Bp;
   const int K = a.P.K;
   double t[kIpmMaxK];
-  ipm_finish<kIpmMaxK, 0>(a.w.part, a.w.nch / 4, Bp, s, t, K);
+  ipm_finish<kIpmMaxK, 0, kFinW>(a.w.part, a.w.nch / 4, Bp, s, t, K);
   if (threadIdx.x >= 64 || a.w.state[s] != 0) return;
 #pragma unroll
   for (int k1 = 0; k1 < kIpmMaxK; ++k1) {
@@ -737,10 +743,10 @@ __global__ __launch_bounds__(256) void k_ipm_ref_rows(IpmArgs a) {
 
 // how well the Newton system is solved: max |rhs - N dy| against max |rhs| per scenario (partial maxima: k_ipm_ref_rows); a scenario beyond
 // the tolerance asks for a (further) step of iterative refinement - of the whole batch: the solves cost the same for one lane as for 64
-__global__ __launch_bounds__(256) void k_ipm_resflag(IpmArgs a, double tol) {
+__global__ __launch_bounds__(64 * kFinW) void k_ipm_resflag(IpmArgs a, double tol) {
   const size_t s = (size_t)blockIdx.x * 64 + (threadIdx.x & 63), Bp = a.w.Bp;
   double t[2];
-  ipm_finish<2, 2>(a.w.part, a.w.nch / 4, Bp, s, t);
+  ipm_finish<2, 2, kFinW>(a.w.part, a.w.nch / 4, Bp, s, t);
   if (threadIdx.x >= 64 || a.w.state[s] != 0) return;
   if (!(t[0] <= (a.w.endg[s] ? a.reftol_end : tol) * t[1])) atomicAdd(a.w.counts + 3, 1);
 }
@@ -772,10 +778,10 @@ __global__ __launch_bounds__(256) void k_ipm_dir(IpmArgs a, int mode) {
   ipm_put<1>(a, 1, ad, s);
 }
 
-__global__ __launch_bounds__(256) void k_ipm_steps(IpmArgs a, int mode) {
+__global__ __launch_bounds__(64 * kFinW) void k_ipm_steps(IpmArgs a, int mode) {
   const size_t s = (size_t)blockIdx.x * 64 + (threadIdx.x & 63), Bp = a.w.Bp;
   double t[2];
-  ipm_finish<2, 1>(a.w.part, a.w.nch / 4, Bp, s, t);
+  ipm_finish<2, 1, kFinW>(a.w.part, a.w.nch / 4, Bp, s, t);
   if (threadIdx.x >= 64 || a.w.state[s] != 0) return;
   if (mode == 0) { a.w.sc[SC_APA * Bp + s] = fmin(t[0], 1.0); a.w.sc[SC_ADA * Bp + s] = fmin(t[1], 1.0); }
   else { a.w.sc[SC_AP * Bp + s] = fmin(1.0, a.step * t[0]); a.w.sc[SC_AD * Bp + s] = fmin(1.0, a.step * t[1]); }
@@ -802,10 +808,10 @@ __global__ __launch_bounds__(256) void k_ipm_muaff(IpmArgs a) {
   ipm_put<0>(a, 0, comp, s);
 }
 
-__global__ __launch_bounds__(256) void k_ipm_sigma(IpmArgs a) {
+__global__ __launch_bounds__(64 * kFinW) void k_ipm_sigma(IpmArgs a) {
   const size_t s = (size_t)blockIdx.x * 64 + (threadIdx.x & 63), Bp = a.w.Bp;
   double t[1];
-  ipm_finish<1, 0>(a.w.part, a.w.nch / 4, Bp, s, t);
+  ipm_finish<1, 0, kFinW>(a.w.part, a.w.nch / 4, Bp, s, t);
   if (threadIdx.x >= 64 || a.w.state[s] != 0) return;
   const double mu = a.w.sc[SC_MU * Bp + s], mu_aff = t[0] / fmax(a.w.sc[SC_NB * Bp + s], 1.0);
   const double r = mu > 0.0 ? mu_aff / mu : 1.0;
@@ -865,10 +871,10 @@ __global__ __launch_bounds__(256) void k_ipm_check(IpmArgs a) {
   for (int k = 0; k < 8; ++k) ipm_put<0>(a, k, q[k], s);
 }
 
-__global__ __launch_bounds__(256) void k_ipm_decide(IpmArgs a) {
+__global__ __launch_bounds__(64 * kFinW) void k_ipm_decide(IpmArgs a) {
   const size_t s = (size_t)blockIdx.x * 64 + (threadIdx.x & 63), Bp = a.w.Bp;
   double q[8];
-  ipm_finish<8, 0>(a.w.part, a.w.nch / 4, Bp, s, q);
+  ipm_finish<8, 0, kFinW>(a.w.part, a.w.nch / 4, Bp, s, q);
   if (threadIdx.x >= 64 || a.w.state[s] != 0) return;
   StreamCtrl &c = a.sw.ctrl[a.w.sid[s]];
   const dsp_options &o = a.opt;
@@ -1274,11 +1280,11 @@ static hipError_t ipm_nsolve(StreamSolver *S, const IpmArgs &a, hipStream_t st, 
   *steps = 0;
   for (int r = 0; r <= 3; ++r) {
     if (r > 0) {
-      if (a.P.K > 0) { hipLaunchKernelGGL(k_ipm_wide_aty, grid, blk, 0, st, a, (const double *)a.w.dy); hipLaunchKernelGGL(k_ipm_wide_aty_finish, lanes, blk, 0, st, a); }
+      if (a.P.K > 0) { hipLaunchKernelGGL(k_ipm_wide_aty, grid, blk, 0, st, a, (const double *)a.w.dy); hipLaunchKernelGGL(k_ipm_wide_aty_finish, lanes, dim3(64 * kFinW), 0, st, a); }
       hipLaunchKernelGGL(k_ipm_ref_cols, grid, blk, 0, st, a);
       hipLaunchKernelGGL(k_ipm_ref_rows, grid, blk, 0, st, a);
       if ((e = hipMemsetAsync(a.w.counts + 3, 0, sizeof(int), st)) != hipSuccess) return e;
-      hipLaunchKernelGGL(k_ipm_resflag, lanes, blk, 0, st, a, a.reftol);
+      hipLaunchKernelGGL(k_ipm_resflag, lanes, dim3(64 * kFinW), 0, st, a, a.reftol);
       if ((e = hipMemcpyAsync(S->ipm->counts_host + 3, a.w.counts + 3, sizeof(int), hipMemcpyDeviceToHost, st)) != hipSuccess) return e;
       if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;
       if (S->ipm->counts_host[3] == 0) break;
@@ -1287,7 +1293,7 @@ static hipError_t ipm_nsolve(StreamSolver *S, const IpmArgs &a, hipStream_t st, 
     if ((e = ipm_bsolve<W>(a, a.w.q, st)) != hipSuccess) return e;
     if (a.P.K > 0) {
       hipLaunchKernelGGL(k_ipm_wood_part, grid, blk, 0, st, a, 1);
-      hipLaunchKernelGGL(k_ipm_wood_g, lanes, blk, 0, st, a);
+      hipLaunchKernelGGL(k_ipm_wood_g, lanes, dim3(64 * kFinW), 0, st, a);
     }
     else if ((e = hipMemsetAsync(a.w.tk, 0, kIpmMaxK * a.w.Bp * sizeof(double), st)) != hipSuccess) return e;
     hipLaunchKernelGGL(k_ipm_wood_axpy, grid, blk, 0, st, a, r > 0 ? 1 : 0);
@@ -1365,7 +1371,7 @@ static hipError_t ipm_loop(StreamSolver *S, IpmArgs &a, hipStream_t st, bool *al
   if ((e = hipMemsetAsync(a.w.counts, 0, 4 * sizeof(int), st)) != hipSuccess) return e;
   hipLaunchKernelGGL(k_ipm_begin, lanes, dim3(64), 0, st, a, 0);
   hipLaunchKernelGGL(k_ipm_cmax, grid, blk, 0, st, a);
-  hipLaunchKernelGGL(k_ipm_cmax_finish, lanes, blk, 0, st, a);
+  hipLaunchKernelGGL(k_ipm_cmax_finish, lanes, dim3(64 * kFinW), 0, st, a);
   hipLaunchKernelGGL(k_ipm_setup, grid, blk, 0, st, a);
   hipLaunchKernelGGL(k_ipm_begin, lanes, dim3(64), 0, st, a, 1);
   IPM_DBG("setup");
@@ -1373,9 +1379,9 @@ static hipError_t ipm_loop(StreamSolver *S, IpmArgs &a, hipStream_t st, bool *al
   int lanes_total = (int)a.w.Bp;
   for (it = 1; it <= a.max_it; ++it) {
     a.it = it;
-    if (a.P.K > 0) { hipLaunchKernelGGL(k_ipm_wide_aty, grid, blk, 0, st, a, (const double *)a.w.y); hipLaunchKernelGGL(k_ipm_wide_aty_finish, lanes, blk, 0, st, a); }
+    if (a.P.K > 0) { hipLaunchKernelGGL(k_ipm_wide_aty, grid, blk, 0, st, a, (const double *)a.w.y); hipLaunchKernelGGL(k_ipm_wide_aty_finish, lanes, dim3(64 * kFinW), 0, st, a); }
     hipLaunchKernelGGL(k_ipm_resid, grid, blk, 0, st, a);
-    hipLaunchKernelGGL(k_ipm_mu, lanes, blk, 0, st, a);
+    hipLaunchKernelGGL(k_ipm_mu, lanes, dim3(64 * kFinW), 0, st, a);
     IPM_DBG("resid");
     hipLaunchKernelGGL(k_ipm_assemble, grid, blk, 0, st, a);
     IPM_DBG("assemble");
@@ -1414,7 +1420,7 @@ static hipError_t ipm_loop(StreamSolver *S, IpmArgs &a, hipStream_t st, bool *al
         ipm_dump("rt", a.w.rt, (size_t)a.P.n + a.P.m, a.w.Bp, trace - 1, st);
       }
       if (trace && g_ipm_debug) {                       // development: relative residual of the Newton system for the traced lane
-        if (a.P.K > 0) { hipLaunchKernelGGL(k_ipm_wide_aty, grid, blk, 0, st, a, (const double *)a.w.dy); hipLaunchKernelGGL(k_ipm_wide_aty_finish, lanes, blk, 0, st, a); }
+        if (a.P.K > 0) { hipLaunchKernelGGL(k_ipm_wide_aty, grid, blk, 0, st, a, (const double *)a.w.dy); hipLaunchKernelGGL(k_ipm_wide_aty_finish, lanes, dim3(64 * kFinW), 0, st, a); }
         hipLaunchKernelGGL(k_ipm_ref_cols, grid, blk, 0, st, a);
         hipLaunchKernelGGL(k_ipm_ref_rows, grid, blk, 0, st, a);
         std::vector<double> hq(a.P.m), hr(a.P.m), hd(a.P.m);
@@ -1426,22 +1432,22 @@ static hipError_t ipm_loop(StreamSolver *S, IpmArgs &a, hipStream_t st, bool *al
         for (int i = 0; i < a.P.m; ++i) { nq += hq[i] * hq[i]; nr += hr[i] * hr[i]; nd += hd[i] * hd[i]; }
         fprintf(stderr, "[ipm]   mode %d: |rhs| %.3e |dy| %.3e |rhs - N dy| / |rhs| %.3e\n", mode, sqrt(nr), sqrt(nd), sqrt(nq) / fmax(sqrt(nr), 1e-300));
       }
-      if (a.P.K > 0) { hipLaunchKernelGGL(k_ipm_wide_aty, grid, blk, 0, st, a, (const double *)a.w.dy); hipLaunchKernelGGL(k_ipm_wide_aty_finish, lanes, blk, 0, st, a); }
+      if (a.P.K > 0) { hipLaunchKernelGGL(k_ipm_wide_aty, grid, blk, 0, st, a, (const double *)a.w.dy); hipLaunchKernelGGL(k_ipm_wide_aty_finish, lanes, dim3(64 * kFinW), 0, st, a); }
       hipLaunchKernelGGL(k_ipm_dir, grid, blk, 0, st, a, mode);
-      hipLaunchKernelGGL(k_ipm_steps, lanes, blk, 0, st, a, mode);
+      hipLaunchKernelGGL(k_ipm_steps, lanes, dim3(64 * kFinW), 0, st, a, mode);
       if (mode == 0) {
         hipLaunchKernelGGL(k_ipm_muaff, grid, blk, 0, st, a);
-        hipLaunchKernelGGL(k_ipm_sigma, lanes, blk, 0, st, a);
+        hipLaunchKernelGGL(k_ipm_sigma, lanes, dim3(64 * kFinW), 0, st, a);
       }
     }
     IPM_DBG("direction");
     hipLaunchKernelGGL(k_ipm_update, grid, blk, 0, st, a);
     IPM_DBG("update");
     if ((e = hipMemsetAsync(a.w.counts + 2, 0, 2 * sizeof(int), st)) != hipSuccess) return e;
-    if (a.P.K > 0) { hipLaunchKernelGGL(k_ipm_wide_aty, grid, blk, 0, st, a, (const double *)a.w.y); hipLaunchKernelGGL(k_ipm_wide_aty_finish, lanes, blk, 0, st, a); }
+    if (a.P.K > 0) { hipLaunchKernelGGL(k_ipm_wide_aty, grid, blk, 0, st, a, (const double *)a.w.y); hipLaunchKernelGGL(k_ipm_wide_aty_finish, lanes, dim3(64 * kFinW), 0, st, a); }
     hipLaunchKernelGGL(k_ipm_check, grid, blk, 0, st, a);
     IPM_DBG("check");
-    hipLaunchKernelGGL(k_ipm_decide, lanes, blk, 0, st, a);
+    hipLaunchKernelGGL(k_ipm_decide, lanes, dim3(64 * kFinW), 0, st, a);
     IPM_DBG("decide");
     if ((e = hipMemcpyAsync(I->counts_host, a.w.counts, 4 * sizeof(int), hipMemcpyDeviceToHost, st)) != hipSuccess) return e;
     if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;

@@ -22,7 +22,7 @@ def build(solver):
         return scenarios.pem_price_taker_batch(T, B, solver, inputs="rts303")
     if fam == "nuclear":
         return scenarios.nuclear_price_taker_batch(T, B, solver)
-    return scenarios.price_taker_batch(T, B, solver, throughput="chain")
+    return scenarios.price_taker_batch(T, B, solver, throughput="chain", family=os.environ.get("IPM_CHECK_FAMILY", "wide"))
 
 
 out = {}
