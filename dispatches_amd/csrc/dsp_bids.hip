@@ -130,11 +130,9 @@ hipError_t launch_bid_points(const dsp_bid_request &rq, hipStream_t st) {
   int N = 64;
   while (N < rq.B) N <<= 1;
   const size_t lds = (size_t)N * sizeof(long long);
-  static bool raised = false;
-  if (lds > 64 * 1024 && !raised) {
+  if (lds > 64 * 1024) {       // (per call: the attribute belongs to the CURRENT device's code object - a process-wide flag left a second device at 64 KB)
     hipError_t e = hipFuncSetAttribute((const void *)bid_points_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
     if (e != hipSuccess) return e;
-    raised = true;
   }
   hipLaunchKernelGGL(bid_points_kernel, dim3(rq.T), dim3(1024), lds, st, rq, N);
   return hipGetLastError();

@@ -830,8 +830,19 @@ hipError_t lane_run(StreamSolver *S, StreamArgs &a, hipStream_t st, int *periods
     std::vector<int> done_h((size_t)G * 64);
     if ((e = hipMemcpyAsync(done_h.data(), W.done, done_h.size() * sizeof(int), hipMemcpyDeviceToHost, st)) != hipSuccess) return e;
     if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;
+    // (after a certificate sequence the verdicts are in the scenarios' control blocks, not in the lanes' flags: a scenario that was just
+    //  certified infeasible / unbounded must not take a lane in the next phase)
+    std::vector<StreamCtrl> hc;
+    if (certify) {
+      hc.resize((size_t)B);
+      if ((e = hipMemcpyAsync(hc.data(), a.W.ctrl, (size_t)B * sizeof(StreamCtrl), hipMemcpyDeviceToHost, st)) != hipSuccess) return e;
+      if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;
+    }
     std::vector<int> next;
-    for (int slot = 0; slot < nact; ++slot) if (!done_h[slot]) next.push_back(ids.empty() ? slot : ids[slot]);
+    for (int slot = 0; slot < nact; ++slot) {
+      const int sc = ids.empty() ? slot : ids[slot];
+      if (!done_h[slot] && !(certify && hc[(size_t)sc].done)) next.push_back(sc);
+    }
     if (next.empty()) break;
     ids.swap(next);
     nact = (int)ids.size();

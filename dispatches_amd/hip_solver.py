@@ -84,7 +84,7 @@ class DspWbState(C.Structure):
 
 EXPORTED_SYMBOLS = ("dsp_default_options", "dsp_create", "dsp_solve", "dsp_spmv_step", "dsp_get_dims",
                     "dsp_get_scaling", "dsp_destroy", "dsp_strerror", "dsp_last_hip_error", "dsp_version",
-                    "dsp_rtc_compile_check", "dsp_rtc_message", "dsp_wb_rolling_update", "dsp_source_hash")
+                    "dsp_rtc_compile_check", "dsp_rtc_message", "dsp_wb_rolling_update", "dsp_bid_points", "dsp_source_hash")
 
 
 ABI_VERSION = 11         # DSP_VERSION of the include/dsp_hip.h these structures mirror
@@ -133,6 +133,25 @@ def load_library(path: Optional[str] = None):
     except Exception:
         pass
     lib = C.CDLL(path)
+    # version and source checks FIRST: an older library lacks newer entry points, and touching one of those below would raise a bare
+    # AttributeError instead of the instruction to rebuild
+    lib.dsp_version.restype = C.c_int
+    if not hasattr(lib, "dsp_source_hash"):
+        raise RuntimeError(f"{path} predates ABI 9 (no dsp_source_hash): rebuild (python -c 'import __graft_entry__ as g; g.build(force=True)')")
+    lib.dsp_source_hash.restype = C.c_char_p
+    if lib.dsp_version() != ABI_VERSION:
+        # the ctypes structures below mirror ONE header version; a stale library would read them with another layout
+        raise RuntimeError(f"{path} has ABI version {lib.dsp_version()}, this binding mirrors include/dsp_hip.h version "
+                           f"{ABI_VERSION}: rebuild (python -c 'import __graft_entry__ as g; g.build(force=True)')")
+    # a binary that travelled with the tree (gpurun ships built .so files) must be the build of THESE sources: the driver's bench once
+    # timed a prebuilt library that no hash tied to the code next to it.  DSP_LIB builds (development variants) are exempt.
+    want, have = source_hash(), lib.dsp_source_hash().decode()
+    if want is not None and have != want and "DSP_LIB" not in os.environ and os.environ.get("DSP_ALLOW_STALE_LIB") != "1":
+        raise RuntimeError(f"{path} was built from other sources (library {have}, tree {want}): rebuild "
+                           f"(python -c 'import __graft_entry__ as g; g.build()')")
+    missing = [name for name in EXPORTED_SYMBOLS if not hasattr(lib, name)]
+    if missing:
+        raise RuntimeError(f"{path} lacks {missing}: rebuild (python -c 'import __graft_entry__ as g; g.build(force=True)')")
     vp, i32, i64, dp = C.c_void_p, C.c_int32, C.c_int64, C.c_void_p
     lib.dsp_default_options.argtypes = [C.POINTER(DspOptions)]
     lib.dsp_default_options.restype = None
@@ -159,20 +178,6 @@ def load_library(path: Optional[str] = None):
     lib.dsp_bid_points.argtypes = [C.POINTER(DspBidRequest), vp]
     lib.dsp_bid_points.restype = C.c_int
     lib.dsp_last_hip_error.restype = C.c_int
-    lib.dsp_version.restype = C.c_int
-    if not hasattr(lib, "dsp_source_hash"):
-        raise RuntimeError(f"{path} predates ABI 9 (no dsp_source_hash): rebuild (python -c 'import __graft_entry__ as g; g.build(force=True)')")
-    lib.dsp_source_hash.restype = C.c_char_p
-    if lib.dsp_version() != ABI_VERSION:
-        # the ctypes structures below mirror ONE header version; a stale library would read them with another layout
-        raise RuntimeError(f"{path} has ABI version {lib.dsp_version()}, this binding mirrors include/dsp_hip.h version "
-                           f"{ABI_VERSION}: rebuild (python -c 'import __graft_entry__ as g; g.build(force=True)')")
-    # a binary that travelled with the tree (gpurun ships built .so files) must be the build of THESE sources: the driver's bench once
-    # timed a prebuilt library that no hash tied to the code next to it.  DSP_LIB builds (development variants) are exempt.
-    want, have = source_hash(), lib.dsp_source_hash().decode()
-    if want is not None and have != want and "DSP_LIB" not in os.environ and os.environ.get("DSP_ALLOW_STALE_LIB") != "1":
-        raise RuntimeError(f"{path} was built from other sources (library {have}, tree {want}): rebuild "
-                           f"(python -c 'import __graft_entry__ as g; g.build()')")
     if path == _LIB_PATH:
         _lib = lib
     return lib

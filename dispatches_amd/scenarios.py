@@ -34,12 +34,14 @@ class WindowForecaster(AbstractPrescientPriceForecaster):
     def windows(self, series, hour, horizon, n_samples):
         # rows of a sliding-window view over the series continued by its own start (the windows wrap around the year): one gather of
         # n_samples rows instead of an [n_samples, horizon] index array, a modulo and an element-wise gather
+        # (the cache entry keeps the series it was built from and is used only for that very object: an id() alone is reused by a later
+        #  array; a horizon longer than the series wraps more than once: np.resize tiles it)
         cache = self.__dict__.setdefault("_views", {})
-        view = cache.get((id(series), horizon))
-        if view is None:
-            ext = np.concatenate([series, series[:horizon - 1]]) if horizon > 1 else series
-            view = cache[(id(series), horizon)] = np.lib.stride_tricks.sliding_window_view(ext, horizon)
-        return view[(self.start_hours[:n_samples] + int(hour)) % len(series)]
+        hit = cache.get((id(series), horizon))
+        if hit is None or hit[0] is not series:
+            ext = np.resize(series, len(series) + horizon - 1) if horizon > 1 else series
+            hit = cache[(id(series), horizon)] = (series, np.lib.stride_tricks.sliding_window_view(ext, horizon))
+        return hit[1][(self.start_hours[:n_samples] + int(hour)) % len(series)]
 
     def forecast_day_ahead_and_real_time_prices(self, date, hour, bus, horizon, n_samples):
         return self.windows(self.da, hour, horizon, n_samples), self.windows(self.rt, hour, horizon, n_samples)
