@@ -269,3 +269,32 @@ def test_year_long_batch_with_an_infeasible_member_costs_one_lane_group():
     np.testing.assert_allclose(model.objective[keep], ref[keep], rtol=1e-7)
     print(f"\n[ipm] 64 year-long LPs: clean {t_clean:.2f} s, with one infeasible member {t_bad:.2f} s ({t_bad / t_clean:.2f} x)")
     assert t_bad <= 1.5 * t_clean, (t_bad, t_clean)
+
+
+@gpu
+def test_warm_hand_off_of_scenarios_the_interior_point_form_gives_up_on(monkeypatch):
+    """Without the cap on Theta (DSP_IPM_THCAP=1e30: round 5's method) member 58 of the wide family - a small objective, hence a tiny mu at
+    the objective tolerance - has its primal residual polluted by pivot noise in the end game and never passes the feasibility test.  The form
+    now recognises that (a residual that jumped 1000 x in the end game, or the iteration limit), stops the lane THERE and hands its iterate to the
+    PDHG form as the starting point and restart anchor (state 5, k_ipm_export): the scenario comes back optimal from the fallback, the others
+    from the interior-point form, and the objective of the handed-over scenario equals the capped method's to 1e-6."""
+    _need_gpu()
+    from dispatches_amd import scenarios
+    from dispatches_amd.hip_solver import HipPdlpSolver
+    T, B = 8736, 64
+    solver = HipPdlpSolver(device=0, check_every=64, max_iter=2_000_000)
+    handles, model = scenarios.price_taker_batch(T, B, solver, throughput="chain", family="wide")
+    solver.solve(model)
+    assert solver.last_stats.ipm_solved == B and (model.status == 0).all()
+    ref = model.objective.copy()
+    monkeypatch.setenv("DSP_IPM_THCAP", "1e30")
+    solver.solve(model)
+    st = solver.last_stats
+    assert (model.status == 0).all(), np.bincount(model.status)
+    assert st.stream_form == FORM_IPM and 0 < st.ipm_solved < B, st.ipm_solved       # member 58 (at least) went on to the PDHG form
+    handed = model.iterations > 300                                                   # (PDHG iterations; the others count Newton iterations)
+    assert handed[58] and handed.sum() == B - st.ipm_solved, (np.nonzero(handed)[0], st.ipm_solved)
+    err = np.abs(model.objective - ref) / np.maximum(1.0, np.abs(ref))
+    assert err.max() <= 1e-6, (err.max(), int(np.argmax(err)))
+    print(f"\n[ipm] without the Theta cap: {B - st.ipm_solved} of {B} handed over warm ({np.nonzero(handed)[0].tolist()}), PDHG iterations {model.iterations[handed].tolist()}, "
+          f"objectives within {err.max():.1e} of the capped method's")
