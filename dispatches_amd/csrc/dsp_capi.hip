@@ -235,6 +235,74 @@ __global__ void queue_reset_kernel(int *q, int n) {
 // the clock advances AFTER every plant has read it (own launch: stream order is the barrier)
 __global__ void wb_clock_kernel(long long *hour) { *hour += 1; }
 
+// ---- the same hand-off for a flowsheet given by a descriptor (include/dsp_hip.h: dsp_loop_model / dsp_loop_state) ------------------------
+__device__ __forceinline__ double loop_power(const dsp_loop_model &m, const double *x, int t) {
+  double p = m.pt_const[t];
+  if (m.pt_cols[t][0] >= 0) p = fma(m.pt_coef[t][0], x[m.pt_cols[t][0]], p);
+  if (m.pt_cols[t][1] >= 0) p = fma(m.pt_coef[t][1], x[m.pt_cols[t][1]], p);
+  return p;
+}
+__device__ __forceinline__ void loop_state_and_wind(const dsp_loop_state &s, const dsp_loop_model &m, int b, long long h, long long st0, double c0) {
+  double *lb = m.lb + (size_t)b * m.n, *ub = m.ub + (size_t)b * m.n;
+  for (int j = 0; j < m.n_state; ++j) {
+    const double v = s.state[(size_t)b * m.n_state + j];
+    lb[m.state_init[j]] = v; ub[m.state_init[j]] = v;
+  }
+  if (m.wind_cols[0] >= 0) {
+    double sum = 0.0;
+    for (int t = 0; t < m.T; ++t) {
+      const double avail = m.wind_kw * s.cf_series[(st0 + h + t) % s.N];
+      ub[m.wind_cols[t]] = avail;
+      sum += avail;
+    }
+    c0 = fma(m.waste_per_kw, sum, c0);
+  }
+  m.c0[b] = c0;
+}
+__global__ void __launch_bounds__(256) loop_update_kernel(dsp_loop_state s, dsp_loop_model rt, dsp_loop_model tr, int phase, int k) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= s.B) return;
+  const long long h = *s.hour, st0 = s.start[b];
+  auto win = [&](const double *series, int t) { return series[(st0 + h + t) % s.N]; };
+  if (phase == 0) {
+    const dsp_loop_model &m = rt;
+    const int known = min(m.T, 24 - k);
+    double *c = m.c + (size_t)b * m.n, *lb = m.lb + (size_t)b * m.n, *ub = m.ub + (size_t)b * m.n;
+    double c0 = m.c0_base;
+    for (int t = 0; t < m.T; ++t) {
+      const double rtp = win(s.rt_series, t);
+      const double dap = t < known ? s.da_prices[(size_t)b * 24 + k + t] : win(s.da_series, t);
+      for (int e = 0; e < 2; ++e)
+        if (m.pt_cols[t][e] >= 0) c[m.pt_cols[t][e]] = fma(-rtp, m.pt_coef[t][e], m.base_c[m.pt_cols[t][e]]);
+      c[m.pda_cols[t]] = m.base_c[m.pda_cols[t]] - (dap - rtp);
+      c0 = fma(-rtp, m.pt_const[t], c0);
+      const double fix = t < known ? s.da_offer[(size_t)b * 24 + k + t] : 0.0;
+      lb[m.pda_cols[t]] = fix;
+      ub[m.pda_cols[t]] = t < known ? fix : INFINITY;
+    }
+    loop_state_and_wind(s, m, b, h, st0, c0);
+  } else if (phase == 1) {
+    const double *xr = rt.x + (size_t)b * rt.n;
+    double *rlo = tr.rlo + (size_t)b * tr.m, *rhi = tr.rhi + (size_t)b * tr.m;
+    for (int t = 0; t < tr.T; ++t) {
+      const double rhs = loop_power(rt, xr, t) - tr.pt_const[t];       // real-time offer = SCED dispatch in the stub market
+      rlo[tr.track_rows[t]] = rhs;
+      rhi[tr.track_rows[t]] = rhs;
+    }
+    loop_state_and_wind(s, tr, b, h, st0, tr.c0_base);
+  } else {
+    const double *x = tr.x + (size_t)b * tr.n;
+    const double delivered = loop_power(tr, x, 0);
+    const double rt0 = win(s.rt_series, 0);
+    s.delivered[b] = delivered;
+    for (int j = 0; j < tr.n_state; ++j)                              // implemented profile -> next hour's state, rounded as update_model does
+      s.state[(size_t)b * tr.n_state + j] = rint(x[tr.state_real[j]] * s.state_scale[j]) / s.state_scale[j];
+    const double dao = s.da_offer[(size_t)b * 24 + k], dap = s.da_prices[(size_t)b * 24 + k];
+    s.revenue[b] += delivered * rt0 + dao * (dap - rt0);
+    s.energy_mwh[b] += delivered;
+  }
+}
+
 extern "C" {
 
 int dsp_wb_rolling_update(const dsp_wb_state *st, const dsp_wb_model *rt, const dsp_wb_model *tr, int32_t phase, int32_t k,
@@ -244,6 +312,19 @@ int dsp_wb_rolling_update(const dsp_wb_state *st, const dsp_wb_model *rt, const 
   if (st->B == 0) return DSP_OK;
   hipStream_t s = (hipStream_t)hipStream;
   hipLaunchKernelGGL(wb_rolling_kernel, dim3((st->B + 255) / 256), dim3(256), 0, s, *st, *rt, *tr, (int)phase, (int)k);
+  if (phase == 2) hipLaunchKernelGGL(wb_clock_kernel, dim3(1), dim3(1), 0, s, (long long *)st->hour);
+  HIP_TRY(hipGetLastError());
+  return DSP_OK;
+}
+
+int dsp_loop_update(const dsp_loop_state *st, const dsp_loop_model *rt, const dsp_loop_model *tr, int32_t phase, int32_t k, void *hipStream) {
+  if (!st || !rt || !tr || st->B < 0 || phase < 0 || phase > 2 || k < 0 || k > 23 || rt->T < 1 || rt->T > DSP_LOOP_MAX_T || tr->T < 1 ||
+      tr->T > DSP_LOOP_MAX_T || rt->n_state < 0 || rt->n_state > 2 || tr->n_state != rt->n_state || !rt->c0 || !tr->c0 ||
+      ((rt->wind_cols[0] >= 0 || tr->wind_cols[0] >= 0) && !st->cf_series))
+    return DSP_ERR_INVALID;
+  if (st->B == 0) return DSP_OK;
+  hipStream_t s = (hipStream_t)hipStream;
+  hipLaunchKernelGGL(loop_update_kernel, dim3((st->B + 255) / 256), dim3(256), 0, s, *st, *rt, *tr, (int)phase, (int)k);
   if (phase == 2) hipLaunchKernelGGL(wb_clock_kernel, dim3(1), dim3(1), 0, s, (long long *)st->hour);
   HIP_TRY(hipGetLastError());
   return DSP_OK;

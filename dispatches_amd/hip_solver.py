@@ -82,9 +82,28 @@ class DspWbState(C.Structure):
                 ("delivered", C.c_void_p), ("revenue", C.c_void_p), ("energy_mwh", C.c_void_p)]
 
 
+class DspLoopModel(C.Structure):
+    """dsp_loop_model of include/dsp_hip.h: one LP of a flowsheet's rolling loop, by descriptor."""
+    _fields_ = [("c", C.c_void_p), ("lb", C.c_void_p), ("ub", C.c_void_p), ("rlo", C.c_void_p), ("rhi", C.c_void_p),
+                ("base_c", C.c_void_p), ("x", C.c_void_p), ("c0", C.c_void_p),
+                ("n", C.c_int32), ("m", C.c_int32), ("T", C.c_int32), ("n_state", C.c_int32),
+                ("pt_cols", (C.c_int32 * 2) * 16), ("pt_coef", (C.c_double * 2) * 16), ("pt_const", C.c_double * 16),
+                ("pda_cols", C.c_int32 * 16), ("track_rows", C.c_int32 * 16), ("wind_cols", C.c_int32 * 16),
+                ("state_init", C.c_int32 * 2), ("state_real", C.c_int32 * 2),
+                ("wind_kw", C.c_double), ("c0_base", C.c_double), ("waste_per_kw", C.c_double)]
+
+
+class DspLoopState(C.Structure):
+    """dsp_loop_state of include/dsp_hip.h."""
+    _fields_ = [("B", C.c_int32), ("N", C.c_int32), ("start", C.c_void_p), ("hour", C.c_void_p),
+                ("da_series", C.c_void_p), ("rt_series", C.c_void_p), ("cf_series", C.c_void_p),
+                ("state", C.c_void_p), ("state_scale", C.c_double * 2), ("da_offer", C.c_void_p), ("da_prices", C.c_void_p),
+                ("delivered", C.c_void_p), ("revenue", C.c_void_p), ("energy_mwh", C.c_void_p)]
+
+
 EXPORTED_SYMBOLS = ("dsp_default_options", "dsp_create", "dsp_solve", "dsp_spmv_step", "dsp_get_dims",
                     "dsp_get_scaling", "dsp_destroy", "dsp_strerror", "dsp_last_hip_error", "dsp_version",
-                    "dsp_rtc_compile_check", "dsp_rtc_message", "dsp_wb_rolling_update", "dsp_bid_points", "dsp_source_hash")
+                    "dsp_rtc_compile_check", "dsp_rtc_message", "dsp_wb_rolling_update", "dsp_loop_update", "dsp_bid_points", "dsp_source_hash")
 
 
 ABI_VERSION = 11         # DSP_VERSION of the include/dsp_hip.h these structures mirror
@@ -175,6 +194,8 @@ def load_library(path: Optional[str] = None):
     lib.dsp_rtc_message.restype = C.c_char_p
     lib.dsp_wb_rolling_update.argtypes = [C.POINTER(DspWbState), C.POINTER(DspWbModel), C.POINTER(DspWbModel), i32, i32, vp]
     lib.dsp_wb_rolling_update.restype = C.c_int
+    lib.dsp_loop_update.argtypes = [C.POINTER(DspLoopState), C.POINTER(DspLoopModel), C.POINTER(DspLoopModel), i32, i32, vp]
+    lib.dsp_loop_update.restype = C.c_int
     lib.dsp_bid_points.argtypes = [C.POINTER(DspBidRequest), vp]
     lib.dsp_bid_points.restype = C.c_int
     lib.dsp_last_hip_error.restype = C.c_int

@@ -118,9 +118,11 @@ def _templates(flowsheet, day_ahead_horizon, tracking_horizon):
 
 class BatchedDoubleLoop:
     def __init__(self, flowsheet, n_scenarios, device=0, first_scenario=0, day_ahead_horizon=48, tracking_horizon=4, lp_backend=None,
-                 use_graphs=True):
+                 use_graphs=True, use_fused=True):
         """flowsheet: "wind_battery", "wind_pem" or "nuclear".  Plant k sees the year that starts at hour (stride * k) mod N of its bus's
-        series (strides 17 / 37 / 29).  lp_backend: tests pass tests/_highs_solver.py::HighsTensorLP to run the same logic on CPU tensors."""
+        series (strides 17 / 37 / 29).  lp_backend: tests pass tests/_highs_solver.py::HighsTensorLP to run the same logic on CPU tensors.
+        use_fused: on the GPU the ~100 element-wise tensor operations of an hour step are THREE launches of one HIP kernel driven by the
+        descriptor (dsp_loop_update, include/dsp_hip.h) - the nuclear loop of 256 plants is launch-bound otherwise (21 ms per simulated day)."""
         import torch
         self.flowsheet = flowsheet
         self.B = B = int(n_scenarios)
@@ -163,6 +165,60 @@ class BatchedDoubleLoop:
         self.hour = self.solves = 0
         self.use_graphs = bool(use_graphs) and lp_backend is None
         self._graphs, self._warm = {}, False
+        self.use_fused = bool(use_fused) and lp_backend is None and self.rt.T <= 16 and self.tr.T <= 16 and len(self.scale) <= 2
+        if self.use_fused:
+            self._fused_setup()
+
+    def _fused_setup(self):
+        from .hip_solver import DspLoopModel, DspLoopState, load_library
+        self._lib = load_library()
+
+        def struct(m, pda=None, track=None, real=None):
+            w = DspLoopModel()
+            w.c, w.lb, w.ub, w.rlo, w.rhi = (t.data_ptr() for t in (m.c, m.lb, m.ub, m.rlo, m.rhi))
+            w.base_c, w.x, w.c0 = m.base_c.data_ptr(), m.out["x"].data_ptr(), m.c0.data_ptr()
+            w.n, w.m, w.T, w.n_state = m.lp.n, m.lp.m, m.T, len(self.scale)
+            PT, PTc = m.PT.cpu().numpy(), m.PT_const.cpu().numpy()
+            wind = m.wind[0].cpu().tolist() if m.wind is not None else []
+            for t in range(16):
+                nz = np.nonzero(PT[t])[0] if t < m.T else []
+                if len(nz) > 2:
+                    raise ValueError("the fused update kernel takes power outputs of at most two columns per period")
+                for e in range(2):
+                    w.pt_cols[t][e] = int(nz[e]) if e < len(nz) else -1
+                    w.pt_coef[t][e] = float(PT[t, nz[e]]) if e < len(nz) else 0.0
+                w.pt_const[t] = float(PTc[t]) if t < m.T else 0.0
+                w.pda_cols[t] = int(pda[t]) if pda is not None and t < len(pda) else -1
+                w.track_rows[t] = int(track[t]) if track is not None and t < len(track) else -1
+                w.wind_cols[t] = int(wind[t]) if t < len(wind) else -1
+            for j in range(2):
+                w.state_init[j] = m.state_init[j] if j < len(m.state_init) else 0
+                w.state_real[j] = real[j] if real is not None and j < len(real) else 0
+            w.wind_kw = m.wind[1] if m.wind is not None else 0.0
+            w.waste_per_kw = m.wind[2] if m.wind is not None else 0.0
+            w.c0_base = m.base_c0
+            return w
+        st = DspLoopState()
+        st.B, st.N = self.B, self.N
+        st.start, st.hour = self.start.data_ptr(), self.hour_t.data_ptr()
+        st.da_series, st.rt_series = self.da_series.data_ptr(), self.rt_series.data_ptr()
+        st.cf_series = self.cf_series.data_ptr() if self.cf_series is not None else None
+        st.state = self.state.data_ptr()
+        for j in range(2):
+            st.state_scale[j] = self.scale[j] if j < len(self.scale) else 1.0
+        st.da_offer, st.da_prices = self.da_offer.data_ptr(), self.da_prices.data_ptr()
+        st.delivered, st.revenue, st.energy_mwh = self.delivered.data_ptr(), self.revenue.data_ptr(), self.energy_mwh.data_ptr()
+        self._loop_state = st
+        self._loop_rt = struct(self.rt, pda=self.rt.pda_cols.cpu().tolist())
+        self._loop_tr = struct(self.tr, track=self.tr.track_rows.cpu().tolist(), real=self.tr.state_real)
+
+    def _fused(self, phase, k):
+        import ctypes as C
+        import torch
+        rc = self._lib.dsp_loop_update(C.byref(self._loop_state), C.byref(self._loop_rt), C.byref(self._loop_tr), phase, k,
+                                       C.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream))
+        if rc != 0:
+            raise RuntimeError(f"dsp_loop_update failed ({rc})")
 
     # -- pieces of a step (all capturable: persistent tensors, the clock read on the device) ---------------------------------------
     def _window(self, series, T):
@@ -208,6 +264,13 @@ class BatchedDoubleLoop:
 
     def _hour_step(self, k):
         import torch
+        if self.use_fused:
+            self._fused(0, k)
+            self._check(self.rt.solve(self.B))
+            self._fused(1, k)
+            self._check(self.tr.solve(self.B))
+            self._fused(2, k)
+            return
         m = self.rt
         rt = self._window(self.rt_series, m.T)
         da = self._window(self.da_series, m.T).clone()

@@ -353,6 +353,42 @@ typedef struct dsp_wb_state {
 int dsp_wb_rolling_update(const dsp_wb_state *st, const dsp_wb_model *rt, const dsp_wb_model *tr, int32_t phase, int32_t k,
                           void *hipStream);
 
+/* The same hour-by-hour hand-off for ANY flowsheet of the reference, described instead of hard-coded (round 6; dispatches_amd/rolling_flowsheets.py):
+ * power output P_T[t] = sum_e pt_coef[t][e] x[pt_cols[t][e]] + pt_const[t] (<= 2 terms per period: every P_T of the reference is one or two
+ * columns - wind_battery_double_loop.py:175, wind_PEM_double_loop.py:172, nuclear_flowsheet_multiperiod_class.py:211), up to two state
+ * columns re-fixed to the tracker's realised values rounded to `state_scale` (100: 2 dp, wind + battery :194-200; 1: an integer, the nuclear
+ * tank holdup :232; none: wind + PEM), optional wind availability columns with their curtailment constant, horizons up to 16 periods. */
+#define DSP_LOOP_MAX_T 16
+typedef struct dsp_loop_model {
+  double *c, *lb, *ub, *rlo, *rhi;     /* [B][n] / [B][m] per-plant vectors of the LP                                             */
+  const double *base_c;                /* [n] cost vector without prices                                                          */
+  const double *x;                     /* [B][n] solution of its last solve                                                       */
+  double *c0;                          /* [B] objective constant of every plant (dsp_batch::obj_offset)                           */
+  int32_t n, m, T, n_state;
+  int32_t pt_cols[16][2];  /* -1 = no such term                                                                       */
+  double  pt_coef[16][2];
+  double  pt_const[16];
+  int32_t pda_cols[16];    /* day-ahead power column of every period (bidding models), -1 otherwise                   */
+  int32_t track_rows[16];  /* dispatch rows (tracking model), -1 otherwise                                            */
+  int32_t wind_cols[16];   /* wind production column of every period, -1 = the flowsheet has no wind                  */
+  int32_t state_init[2], state_real[2];/* columns fixed to the realised state / holding it after the first period                */
+  double  wind_kw, c0_base, waste_per_kw;
+} dsp_loop_model;
+
+typedef struct dsp_loop_state {
+  int32_t B, N;
+  const int64_t *start;                /* [B]                                                                                    */
+  int64_t *hour;                       /* [1] the clock: advanced by phase 2                                                      */
+  const double *da_series, *rt_series, *cf_series;   /* [N] (cf_series NULL without wind)                                         */
+  double *state;                       /* [B][n_state] realised state                                                             */
+  double state_scale[2];
+  const double *da_offer, *da_prices;  /* [B][24]                                                                                */
+  double *delivered, *revenue, *energy_mwh;          /* [B]                                                                       */
+} dsp_loop_state;
+
+/* phases as dsp_wb_rolling_update: 0 before the real-time bidding solve of hour-of-day k, 1 between the solves, 2 after the tracking solve */
+int dsp_loop_update(const dsp_loop_state *st, const dsp_loop_model *rt, const dsp_loop_model *tr, int32_t phase, int32_t k, void *hipStream);
+
 /* The scenario half of the Bidder's bid assembly ON THE DEVICE (reference: idaes Bidder._assemble_bids as DISPATCHES drives it -
  * dispatches/workflow/coordinator.py hands its bids to Prescient; golden values
  * dispatches/case_studies/renewables_case/tests/test_multiperiod_wind_battery_doubleloop.py:245-250): per hour t the pairs

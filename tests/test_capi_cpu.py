@@ -34,7 +34,8 @@ def test_binding_mirrors_the_header(lib):
     assert int(re.search(r"#define DSP_VERSION (\d+)", hdr).group(1)) == hip_solver.ABI_VERSION == lib.dsp_version()
     for struct, cls in (("dsp_options", hip_solver.DspOptions), ("dsp_stats", hip_solver.DspStats),
                         ("dsp_lp_desc", hip_solver.DspLpDesc), ("dsp_batch", hip_solver.DspBatch),
-                        ("dsp_wb_model", hip_solver.DspWbModel), ("dsp_wb_state", hip_solver.DspWbState)):
+                        ("dsp_wb_model", hip_solver.DspWbModel), ("dsp_wb_state", hip_solver.DspWbState),
+                        ("dsp_loop_model", hip_solver.DspLoopModel), ("dsp_loop_state", hip_solver.DspLoopState)):
         body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (struct, struct), hdr, re.S).group(1)
         body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
         body = re.sub(r"\[[0-9\]\[]*\]", "", body)                     # array extents
