@@ -78,7 +78,9 @@ class _DeviceModel:
         if lp_backend is None:
             # recertify: the loop never reads a flag back between solves (its days are hipGraph replays), so a solve accepted without a
             # certified objective accuracy is re-solved on the device under other settings (dsp_options::recertify_passes)
-            self.opts = default_options(**{"recertify_passes": 3, **(hints or {})})
+            # (three passes for the day-ahead LP, which the PDLP kernel solves; one for the hourly LPs, which the in-wave simplex solves to a
+            #  vertex and which pay an empty launch per pass and solve, 49 solves per plant-day)
+            self.opts = default_options(**{"recertify_passes": 3 if self.T > 16 else 1, **(hints or {})})
             self.dlp = DeviceLP(self.lp, device_index, self.opts)
             # output buffers with fixed addresses from the start (the fused update kernel and the hipGraphs hold pointers)
             n, m = self.lp.n, max(self.lp.m, 1)
