@@ -166,6 +166,13 @@ static int solve_geometry(dsp_handle *h, int requested, int B, Geometry *g, int 
 // operators to the compiler and `#pragma clang fp contract(off)` did not keep it from fusing them): the results are
 // bit-identical to the element-wise tensor operations this kernel replaces (dispatches_amd/rolling.py, use_fused=False),
 // which is how it is tested.
+// outcome of the solve that has just finished, folded into the loop's device-side flags (what six tensor launches per solve did)
+template <class M, class S>
+__device__ __forceinline__ void loop_check(const S &s, const M &m, int b) {
+  if (m.status && s.bad && m.status[b] != 0) *s.bad = 1;
+  if (m.flags && s.uncertified && (m.flags[b] & DSP_FLAG_OBJ_WAIVED)) atomicAdd(reinterpret_cast<unsigned long long *>(s.uncertified), 1ull);
+}
+
 __device__ __forceinline__ double wb_opaque(double v) { asm volatile("" : "+v"(v)); return v; }
 __global__ void __launch_bounds__(256) wb_rolling_kernel(dsp_wb_state s, dsp_wb_model rt, dsp_wb_model tr, int phase, int k) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -195,6 +202,7 @@ __global__ void __launch_bounds__(256) wb_rolling_kernel(dsp_wb_state s, dsp_wb_
     lb[m.soc_init] = s.soc[b]; ub[m.soc_init] = s.soc[b];
     lb[m.thr_init] = s.thr[b]; ub[m.thr_init] = s.thr[b];
   } else if (phase == 1) {
+    loop_check(s, rt, b);
     const double *xr = rt.x + (size_t)b * rt.n;
     double *lb = tr.lb + (size_t)b * tr.n, *ub = tr.ub + (size_t)b * tr.n;
     double *rlo = tr.rlo + (size_t)b * tr.m, *rhi = tr.rhi + (size_t)b * tr.m;
@@ -211,6 +219,7 @@ __global__ void __launch_bounds__(256) wb_rolling_kernel(dsp_wb_state s, dsp_wb_
     lb[tr.soc_init] = s.soc[b]; ub[tr.soc_init] = s.soc[b];
     lb[tr.thr_init] = s.thr[b]; ub[tr.thr_init] = s.thr[b];
   } else {
+    loop_check(s, tr, b);
     const double *x = tr.x + (size_t)b * tr.n;
     const double delivered = wb_opaque(__dmul_rn(1e-3, wb_opaque(__dadd_rn(x[tr.pt_cols[0][0]], x[tr.pt_cols[0][1]]))));
     const double rt0 = win(s.rt_series, 0);
@@ -282,6 +291,7 @@ __global__ void __launch_bounds__(256) loop_update_kernel(dsp_loop_state s, dsp_
     }
     loop_state_and_wind(s, m, b, h, st0, c0);
   } else if (phase == 1) {
+    loop_check(s, rt, b);
     const double *xr = rt.x + (size_t)b * rt.n;
     double *rlo = tr.rlo + (size_t)b * tr.m, *rhi = tr.rhi + (size_t)b * tr.m;
     for (int t = 0; t < tr.T; ++t) {
@@ -291,6 +301,7 @@ __global__ void __launch_bounds__(256) loop_update_kernel(dsp_loop_state s, dsp_
     }
     loop_state_and_wind(s, tr, b, h, st0, tr.c0_base);
   } else {
+    loop_check(s, tr, b);
     const double *x = tr.x + (size_t)b * tr.n;
     const double delivered = loop_power(tr, x, 0);
     const double rt0 = win(s.rt_series, 0);

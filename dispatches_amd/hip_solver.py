@@ -71,7 +71,8 @@ class DspWbModel(C.Structure):
                 ("soc_init", C.c_int32), ("thr_init", C.c_int32), ("soc0", C.c_int32), ("thr0", C.c_int32),
                 ("wind_cols", C.c_int32 * 8), ("pt_cols", (C.c_int32 * 2) * 8), ("pda_cols", C.c_int32 * 8),
                 ("track_rows", C.c_int32 * 8), ("wind_kw", C.c_double),
-                ("c0", C.c_void_p), ("c0_base", C.c_double), ("waste_per_kw", C.c_double)]
+                ("c0", C.c_void_p), ("c0_base", C.c_double), ("waste_per_kw", C.c_double),
+                ("status", C.c_void_p), ("flags", C.c_void_p)]
 
 
 class DspWbState(C.Structure):
@@ -79,7 +80,8 @@ class DspWbState(C.Structure):
     _fields_ = [("B", C.c_int32), ("N", C.c_int32), ("start", C.c_void_p), ("hour", C.c_void_p),
                 ("da_series", C.c_void_p), ("rt_series", C.c_void_p), ("cf_series", C.c_void_p),
                 ("soc", C.c_void_p), ("thr", C.c_void_p), ("da_offer", C.c_void_p), ("da_prices", C.c_void_p),
-                ("delivered", C.c_void_p), ("revenue", C.c_void_p), ("energy_mwh", C.c_void_p)]
+                ("delivered", C.c_void_p), ("revenue", C.c_void_p), ("energy_mwh", C.c_void_p),
+                ("bad", C.c_void_p), ("uncertified", C.c_void_p)]
 
 
 class DspLoopModel(C.Structure):
@@ -90,7 +92,8 @@ class DspLoopModel(C.Structure):
                 ("pt_cols", (C.c_int32 * 2) * 16), ("pt_coef", (C.c_double * 2) * 16), ("pt_const", C.c_double * 16),
                 ("pda_cols", C.c_int32 * 16), ("track_rows", C.c_int32 * 16), ("wind_cols", C.c_int32 * 16),
                 ("state_init", C.c_int32 * 2), ("state_real", C.c_int32 * 2),
-                ("wind_kw", C.c_double), ("c0_base", C.c_double), ("waste_per_kw", C.c_double)]
+                ("wind_kw", C.c_double), ("c0_base", C.c_double), ("waste_per_kw", C.c_double),
+                ("status", C.c_void_p), ("flags", C.c_void_p)]
 
 
 class DspLoopState(C.Structure):
@@ -98,7 +101,8 @@ class DspLoopState(C.Structure):
     _fields_ = [("B", C.c_int32), ("N", C.c_int32), ("start", C.c_void_p), ("hour", C.c_void_p),
                 ("da_series", C.c_void_p), ("rt_series", C.c_void_p), ("cf_series", C.c_void_p),
                 ("state", C.c_void_p), ("state_scale", C.c_double * 2), ("da_offer", C.c_void_p), ("da_prices", C.c_void_p),
-                ("delivered", C.c_void_p), ("revenue", C.c_void_p), ("energy_mwh", C.c_void_p)]
+                ("delivered", C.c_void_p), ("revenue", C.c_void_p), ("energy_mwh", C.c_void_p),
+                ("bad", C.c_void_p), ("uncertified", C.c_void_p)]
 
 
 EXPORTED_SYMBOLS = ("dsp_default_options", "dsp_create", "dsp_solve", "dsp_spmv_step", "dsp_get_dims",

@@ -120,6 +120,7 @@ class _DeviceModel:
         w.wind_kw = self.wind_kw
         if self.c0 is not None:
             w.c0, w.c0_base, w.waste_per_kw = self.c0.data_ptr(), self._c0_base, self._waste_per_kw
+        w.status, w.flags = self.out["status"].data_ptr(), self.out["flags"].data_ptr()       # (folded into the loop's flags by the next phase)
         return w
 
     def power_output(self, x):
@@ -238,6 +239,7 @@ class BatchedWindBatteryDoubleLoop:
             st.soc, st.thr = self.soc.data_ptr(), self.thr.data_ptr()
             st.da_offer, st.da_prices = self.da_offer.data_ptr(), self.da_prices.data_ptr()
             st.delivered, st.revenue, st.energy_mwh = self.delivered.data_ptr(), self.revenue.data_ptr(), self.energy_mwh.data_ptr()
+            st.bad, st.uncertified = self.bad.data_ptr(), self.uncertified.data_ptr()
             self._wb_state, self._wb_rt, self._wb_tr = st, self.rt.wb_struct(needs_state=False), self.tr.wb_struct()
         self._graphs = {}                                                  # "da" / hour of day -> captured hipGraph
         self._rec = None
@@ -357,9 +359,9 @@ class BatchedWindBatteryDoubleLoop:
             if self._rec is not None:
                 self._record("state", torch.stack([self.soc, self.thr], 1))
             self._fused(0, k)
-            self._check(self.rt.solve(self.B))
+            self.rt.solve(self.B)                       # (status / flags of the two solves: checked by the kernel's next phase)
             self._fused(1, k)
-            self._check(self.tr.solve(self.B))
+            self.tr.solve(self.B)
             if self._rec is not None:
                 for key, m in (("rt", self.rt), ("tr", self.tr)):
                     self._record(key + "_x", m.out["x"])

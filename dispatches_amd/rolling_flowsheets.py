@@ -197,6 +197,7 @@ class BatchedDoubleLoop:
             w.wind_kw = m.wind[1] if m.wind is not None else 0.0
             w.waste_per_kw = m.wind[2] if m.wind is not None else 0.0
             w.c0_base = m.base_c0
+            w.status, w.flags = m.out["status"].data_ptr(), m.out["flags"].data_ptr()
             return w
         st = DspLoopState()
         st.B, st.N = self.B, self.N
@@ -208,6 +209,7 @@ class BatchedDoubleLoop:
             st.state_scale[j] = self.scale[j] if j < len(self.scale) else 1.0
         st.da_offer, st.da_prices = self.da_offer.data_ptr(), self.da_prices.data_ptr()
         st.delivered, st.revenue, st.energy_mwh = self.delivered.data_ptr(), self.revenue.data_ptr(), self.energy_mwh.data_ptr()
+        st.bad, st.uncertified = self.bad.data_ptr(), self.uncertified.data_ptr()
         self._loop_state = st
         self._loop_rt = struct(self.rt, pda=self.rt.pda_cols.cpu().tolist())
         self._loop_tr = struct(self.tr, track=self.tr.track_rows.cpu().tolist(), real=self.tr.state_real)
@@ -266,9 +268,9 @@ class BatchedDoubleLoop:
         import torch
         if self.use_fused:
             self._fused(0, k)
-            self._check(self.rt.solve(self.B))
+            self.rt.solve(self.B)                       # (status / flags: checked by the kernel's next phase)
             self._fused(1, k)
-            self._check(self.tr.solve(self.B))
+            self.tr.solve(self.B)
             self._fused(2, k)
             return
         m = self.rt

@@ -334,6 +334,8 @@ typedef struct dsp_wb_model {
   double wind_kw;
   double *c0;                          /* [B] objective constant of every plant (dsp_batch::obj_offset of its solves) or NULL    */
   double c0_base, waste_per_kw;        /* c0 = c0_base + waste_per_kw * sum_t (wind availability of period t)   (ABI 11)         */
+  const int32_t *status, *flags;       /* [B] outputs of its last solve or NULL: the phase after the solve folds them into
+                                          dsp_wb_state::bad / uncertified (ABI 11; six tensor launches per solve otherwise)       */
 } dsp_wb_model;
 
 typedef struct dsp_wb_state {
@@ -344,6 +346,8 @@ typedef struct dsp_wb_state {
   double *soc, *thr;                   /* [B] realised state                                                                  */
   const double *da_offer, *da_prices;  /* [B][24] cleared day-ahead dispatch and prices of the current day                    */
   double *delivered, *revenue, *energy_mwh;          /* [B]                                                                   */
+  uint8_t *bad;                        /* [1] or NULL: set to 1 when a solve left a status other than optimal                     */
+  int64_t *uncertified;                /* [1] or NULL: + the scenarios a solve left flagged DSP_FLAG_OBJ_WAIVED                   */
 } dsp_wb_state;
 
 /* phase 0: before the real-time bidding solve of hour-of-day k  (prices, state, wind availability, day-ahead power fixed to the
@@ -373,6 +377,7 @@ typedef struct dsp_loop_model {
   int32_t wind_cols[16];   /* wind production column of every period, -1 = the flowsheet has no wind                  */
   int32_t state_init[2], state_real[2];/* columns fixed to the realised state / holding it after the first period                */
   double  wind_kw, c0_base, waste_per_kw;
+  const int32_t *status, *flags;       /* [B] outputs of its last solve or NULL (as dsp_wb_model)                                 */
 } dsp_loop_model;
 
 typedef struct dsp_loop_state {
@@ -384,6 +389,8 @@ typedef struct dsp_loop_state {
   double state_scale[2];
   const double *da_offer, *da_prices;  /* [B][24]                                                                                */
   double *delivered, *revenue, *energy_mwh;          /* [B]                                                                       */
+  uint8_t *bad;                        /* as dsp_wb_state                                                                         */
+  int64_t *uncertified;
 } dsp_loop_state;
 
 /* phases as dsp_wb_rolling_update: 0 before the real-time bidding solve of hour-of-day k, 1 between the solves, 2 after the tracking solve */

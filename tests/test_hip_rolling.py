@@ -354,3 +354,24 @@ def test_generic_fused_update_kernel_matches_the_tensor_operations(flowsheet):
     for a, b in zip(res[True]["c0"], res[False]["c0"]):
         assert np.allclose(a, b, rtol=1e-12)
     assert np.abs(res[True]["obj"]).max() > 0
+
+
+@gpu
+@pytest.mark.parametrize("which", ["specialised", "generic"])
+def test_fused_update_kernels_report_a_solve_that_did_not_finish(which):
+    """The fused update kernels fold the outcome of the hourly solves into the loop's device-side flags (status != optimal -> `bad`; flagged
+    DSP_FLAG_OBJ_WAIVED -> `uncertified`) instead of six tensor launches per solve: a tracking LP with crossed bounds on one plant (status 2:
+    invalid input) must make `results()` report it, on both loops."""
+    from dispatches_amd.rolling import BatchedWindBatteryDoubleLoop
+    from dispatches_amd.rolling_flowsheets import BatchedDoubleLoop
+    loop = BatchedWindBatteryDoubleLoop(8, device=0, use_graphs=False) if which == "specialised" else BatchedDoubleLoop("nuclear", 8, device=0, use_graphs=False)
+    assert loop.use_fused
+    loop.day_ahead()
+    loop.hour_step()
+    assert loop.results()[1]
+    import torch
+    col = int(loop.tr.pt_cols[3, 0]) if which == "specialised" else int(torch.nonzero(loop.tr.PT[3])[0, 0])      # a column the update never rewrites
+    loop.tr.lb[5, col], loop.tr.ub[5, col] = 1e9, 0.0
+    loop.hour_step()
+    assert int(loop.tr.out["status"][5].item()) != 0
+    assert not loop.results()[1]
