@@ -55,7 +55,8 @@ class _Model:
             self.wind = (idx(cols), float(kw), float(per_kw))
             self.base_c0 -= float(per_kw) * float(template_sum)           # the template's curtailment constant leaves; the window's enters
         if lp_backend is None:
-            self.opts = default_options(**{"recertify_passes": 3 if self.T > 16 else 1, **(getattr(model, "solver_hints", None) or {})})
+            extra = {"recertify_passes": 3} if self.T > 16 else {"recertify_passes": 0, "eps_infeasible": 0.0}     # (as rolling.py)
+            self.opts = default_options(**{**extra, **(getattr(model, "solver_hints", None) or {})})
             self.dlp = DeviceLP(self.lp, device_index, self.opts)
             m = max(self.lp.m, 1)
             self.out = dict(x=torch.zeros((B, n), dtype=torch.float64, device=dev), y=torch.zeros((B, m), dtype=torch.float64, device=dev),
