@@ -57,6 +57,12 @@ struct dsp_handle {
   std::string rtc_why;            // why run-time compilation was not possible (dsp_rtc_last_message)
   int simplex = 0;                // tiny LP: the in-wave dense simplex runs first (dsp_simplex.hip)
   const double *A_dense = nullptr;   // [m][n] scaled matrix, row-major (simplex only)
+  // warm start of the simplex (dsp_options::simplex_warm): the final basis of every scenario's previous solve on this handle
+  double *sx_warm_T = nullptr;
+  int *sx_warm_basis = nullptr, *sx_warm_valid = nullptr;
+  unsigned char *sx_warm_upper = nullptr;
+  int sx_warm_cap = 0;
+  std::vector<void *> sx_warm_allocs;   // (earlier, smaller buffers stay alive: captured graphs may hold their addresses)
   int sx_row_stride = 0;
   size_t sx_lds = 0;
   int streaming = 0;              // LP too large for the fused kernels: HBM-resident PDLP (dsp_stream.hip)
@@ -384,6 +390,7 @@ void dsp_default_options(dsp_options *o) {
   o->no_interior_point = 0;
   o->eps_infeasible = 1e-6;
   o->recertify_passes = 0;
+  o->simplex_warm = 0;
 }
 
 int dsp_version(void) { return DSP_VERSION; }
@@ -698,6 +705,25 @@ int dsp_solve(dsp_handle *h, const dsp_batch *batch, const dsp_options *opt, dsp
     sa.A_dense = h->A_dense; sa.col_scale = h->P.col_scale; sa.row_scale = h->P.row_scale; sa.b = *batch;
     sa.tol_p = 1e-10; sa.tol_d = 1e-12; sa.tol_piv = 1e-9;
     sa.unsolved = a.queue + 1;
+    if (a.opt.simplex_warm == 1 || a.opt.simplex_warm == 2) {
+      if (B > h->sx_warm_cap) {
+        // (allocated outside any stream capture: the rolling loops run their first day eagerly)
+        const size_t N = (size_t)h->n + h->m;
+        double *t = nullptr; int *bs = nullptr, *vl = nullptr; unsigned char *up = nullptr;
+        HIP_TRY(hipMalloc((void **)&t, (size_t)B * h->m * N * sizeof(double)));
+        h->sx_warm_allocs.push_back(t);
+        HIP_TRY(hipMalloc((void **)&bs, (size_t)B * h->m * sizeof(int)));
+        h->sx_warm_allocs.push_back(bs);
+        HIP_TRY(hipMalloc((void **)&up, (size_t)B * N));
+        h->sx_warm_allocs.push_back(up);
+        HIP_TRY(hipMalloc((void **)&vl, (size_t)B * sizeof(int)));
+        h->sx_warm_allocs.push_back(vl);
+        HIP_TRY(hipMemset(vl, 0, (size_t)B * sizeof(int)));
+        h->sx_warm_T = t; h->sx_warm_basis = bs; h->sx_warm_upper = up; h->sx_warm_valid = vl; h->sx_warm_cap = B;
+      }
+      sa.warm = a.opt.simplex_warm;
+      sa.warm_T = h->sx_warm_T; sa.warm_basis = h->sx_warm_basis; sa.warm_upper = h->sx_warm_upper; sa.warm_valid = h->sx_warm_valid;
+    }
     static const int sx_debug = getenv("DSP_SX_DEBUG") ? atoi(getenv("DSP_SX_DEBUG")) : 0;
     sa.debug_keep = sx_debug;
     const int per_cu = std::max<int>(1, std::min<int>(32, (int)((size_t)h->lds_limit / h->sx_lds)));
@@ -862,6 +888,7 @@ int dsp_destroy(dsp_handle *h) {
   for (void *p : h->allocs) (void)hipFree(p);
   stream_destroy(&h->stream);
   if (h->queue) (void)hipFree(h->queue);
+  for (void *p : h->sx_warm_allocs) (void)hipFree(p);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
   delete h;

@@ -139,6 +139,12 @@ struct SimplexArgs {
   double tol_p, tol_d, tol_piv;
   int *unsolved;               // incremented for every scenario left to the PDLP kernel
   int debug_keep;              // development (DSP_SX_DEBUG=1): status 51 / 52 instead of the hand-over
+  // warm start from the final basis of the previous solve of the same scenario on this handle (dsp_options::simplex_warm):
+  int warm;                    // 0 off; 1 start from the saved state where there is one, save the final state; 2 cold start, save
+  double *warm_T;              // [B][m][n + m] tableau of the final basis
+  int *warm_basis;             // [B][m] variable of every row
+  unsigned char *warm_upper;   // [B][n + m] 1 = nonbasic at its upper bound
+  int *warm_valid;             // [B] 1 = the state above is that of a certified optimal vertex
 };
 
 struct SpmvArgs {

@@ -52,8 +52,18 @@ __global__ void __launch_bounds__(64) simplex_kernel(SimplexArgs a) {
   double *xval = cB_s + 64;                          // [128] value of every variable (final assembly / start)
   double *scal = xval + 128;                         // [8]   broadcast scalars
   int *iscal = reinterpret_cast<int *>(scal + 8);    // [8]
+  double *lo_s = scal + 16;                          // [128] bounds of every variable (warm start: a row's basic may be a structural)
+  double *hi_s = lo_s + 128;                         // [128]
 
   for (int s = blockIdx.x; s < b.B; s += gridDim.x) {
+    // Warm start (a.warm == 1 and a saved state for this scenario): the hourly LPs of a plant's rolling loop share ONE matrix and
+    // differ in costs, bounds and right-hand sides only; the final basis of the previous hour - its tableau B^-1 [A | I] kept in HBM -
+    // is 2 - 4 pivots from the next hour's optimum where the slack basis is ~26 (HiGHS primal simplex on a recorded plant: cold
+    // 26.2 / 27.4, hot 3.9 / 1.9 iterations per real-time / tracking LP).  The same pivot rules run from there (phase 1 if the new
+    // bounds leave a basic value outside); a warm attempt that does not end in a CERTIFIED optimum is repeated from the slack basis.
+    bool use_warm = a.warm == 1 && a.warm_valid[s] != 0;
+    int pivots_before = 0;
+  restart:
     // ---- this scenario's data: columns j = lane + 64 q (structural j < n, slack n <= j < N) ---------------------
     double lo[CQ], hi[CQ], cost[CQ], val[CQ];
     bool basic[CQ], upper[CQ], fixedv[CQ], live[CQ];
@@ -109,28 +119,62 @@ __global__ void __launch_bounds__(64) simplex_kernel(SimplexArgs a) {
       continue;
     }
     const double ctol = a.tol_d * (1.0 + wave_max(cabs));
-    // ---- tableau: row i = s_i - sum_j a_ij x_j = 0, basis = slacks ----------------------------------------------
-    for (int i = 0; i < m; ++i) {
+    int bvar = (lane < m) ? n + lane : -1;
+    double beta = 0.0, blo = -INFINITY, bhi = INFINITY;
+    if (use_warm) {
+      // ---- tableau, basis and nonbasic sides of the saved vertex; values from the NEW bounds -----------------------------
+      const double *Ts = a.warm_T + (size_t)s * m * N;
+      for (int i = 0; i < m; ++i) {
+#pragma unroll
+        for (int q = 0; q < CQ; ++q) { const int j = lane + 64 * q; if (j < N) T[i * RS + j] = Ts[(size_t)i * N + j]; }
+      }
+      if (lane < m) bvar = a.warm_basis[(size_t)s * m + lane];
+#pragma unroll
+      for (int q = 0; q < CQ; ++q) { const int j = lane + 64 * q; if (j < N) { xval[j] = 0.0; lo_s[j] = lo[q]; hi_s[j] = hi[q]; } }
+      wave_lds_fence();
+      if (lane < m) xval[bvar] = 1.0;                                  // marks the basic columns
+      wave_lds_fence();
 #pragma unroll
       for (int q = 0; q < CQ; ++q) {
         const int j = lane + 64 * q;
-        if (j < N) T[i * RS + j] = (j < n) ? -a.A_dense[(size_t)i * n + j] : ((j - n == i) ? 1.0 : 0.0);
+        basic[q] = live[q] && xval[j] != 0.0;
+        const bool lo_f = is_finite(lo[q]), hi_f = is_finite(hi[q]);
+        bool up = live[q] && a.warm_upper[(size_t)s * N + j] != 0 && hi_f && !fixedv[q];
+        if (!lo_f && hi_f) up = true;                                  // (a side that is no longer finite: the other one)
+        val[q] = up ? hi[q] : (lo_f ? lo[q] : 0.0);
+        upper[q] = up;
+      }
+      wave_lds_fence();
+#pragma unroll
+      for (int q = 0; q < CQ; ++q) { const int j = lane + 64 * q; if (j < N) xval[j] = basic[q] ? 0.0 : val[q]; }
+      wave_lds_fence();
+      if (lane < m) {
+        for (int j = 0; j < N; ++j) beta = fma(-T[lane * RS + j], xval[j], beta);       // basic_i + sum over nonbasic T_ij z_j = 0
+        blo = lo_s[bvar]; bhi = hi_s[bvar];
+      }
+    } else {
+      // ---- tableau: row i = s_i - sum_j a_ij x_j = 0, basis = slacks --------------------------------------------------------
+      for (int i = 0; i < m; ++i) {
+#pragma unroll
+        for (int q = 0; q < CQ; ++q) {
+          const int j = lane + 64 * q;
+          if (j < N) T[i * RS + j] = (j < n) ? -a.A_dense[(size_t)i * n + j] : ((j - n == i) ? 1.0 : 0.0);
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < CQ; ++q) { const int j = lane + 64 * q; if (j < N) xval[j] = val[q]; }
+      wave_lds_fence();
+      // row lanes: basic variable of row i (slack n + i), its value s_i = sum_j a_ij x_j and bounds
+      if (lane < m) {
+        for (int j = 0; j < n; ++j) beta = fma(-T[lane * RS + j], xval[j], beta);
+        const double d = a.row_scale[lane];
+        const double l = b.row_lb ? b.row_lb[(size_t)s * b.row_lb_stride + lane] : -INFINITY;
+        const double u = b.row_ub ? b.row_ub[(size_t)s * b.row_ub_stride + lane] : INFINITY;
+        blo = l * d; bhi = u * d;
       }
     }
-#pragma unroll
-    for (int q = 0; q < CQ; ++q) { const int j = lane + 64 * q; if (j < N) xval[j] = val[q]; }
-    wave_lds_fence();
-    // row lanes: basic variable of row i (slack n + i), its value s_i = sum_j a_ij x_j and bounds
-    int bvar = (lane < m) ? n + lane : -1;
-    double beta = 0.0, blo = -INFINITY, bhi = INFINITY;
-    if (lane < m) {
-      for (int j = 0; j < n; ++j) beta = fma(-T[lane * RS + j], xval[j], beta);
-      const double d = a.row_scale[lane];
-      const double l = b.row_lb ? b.row_lb[(size_t)s * b.row_lb_stride + lane] : -INFINITY;
-      const double u = b.row_ub ? b.row_ub[(size_t)s * b.row_ub_stride + lane] : INFINITY;
-      blo = l * d; bhi = u * d;
-    }
-    int status = -1, pivots = 0;
+    const int it_limit = use_warm ? min(a.max_pivots, 6 * N) : a.max_pivots;      // (a warm attempt gives up early: the slack basis needs ~N / 2)
+    int status = -1, pivots = pivots_before;
     bool p1_priced_out = false;        // phase 1 ended because no column prices in (the only phase-1 stop that proves infeasibility)
     bool phase1 = false;
 
@@ -178,7 +222,7 @@ __global__ void __launch_bounds__(64) simplex_kernel(SimplexArgs a) {
       }
       best = wave_max(best);
       if (best < 0.0) { status = phase1 ? DSP_STATUS_PRIMAL_INFEASIBLE : DSP_STATUS_OPTIMAL; p1_priced_out = phase1; break; }
-      if (it >= a.max_pivots) { status = -1; break; }
+      if (it >= it_limit) { status = -1; break; }
       // entering column: the smallest index among the maxima (as numpy's argmax in the prototype)
       int jin = -1;
 #pragma unroll
@@ -331,6 +375,28 @@ __global__ void __launch_bounds__(64) simplex_kernel(SimplexArgs a) {
     }
     const bool certified = __ballot(!okv) == 0ull;
     const unsigned long long bad_bounds = __ballot(!okb), bad_any = __ballot(!okv);
+    if (use_warm && !(status == DSP_STATUS_OPTIMAL && certified)) {
+      // a warm attempt that did not end in a certified optimum (a drifted tableau, a stop that proves nothing): once more from the slack basis
+      use_warm = false;
+      pivots_before = pivots;
+      wave_lds_fence();
+      goto restart;
+    }
+    if (a.warm) {
+      // the final basis for the next solve of this scenario (only a certified optimum is worth starting from)
+      const bool keep = status == DSP_STATUS_OPTIMAL && certified;
+      if (keep) {
+        double *Ts = a.warm_T + (size_t)s * m * N;
+        for (int i = 0; i < m; ++i) {
+#pragma unroll
+          for (int q = 0; q < CQ; ++q) { const int j = lane + 64 * q; if (j < N) Ts[(size_t)i * N + j] = T[i * RS + j]; }
+        }
+        if (lane < m) a.warm_basis[(size_t)s * m + lane] = bvar;
+#pragma unroll
+        for (int q = 0; q < CQ; ++q) { const int j = lane + 64 * q; if (j < N) a.warm_upper[(size_t)s * N + j] = (!basic[q] && upper[q]) ? 1 : 0; }
+      }
+      if (lane == 0) a.warm_valid[s] = keep ? 1 : 0;
+    }
     int reason = status == -1 ? 1 : 0;                       // 1 = pivot limit
     if (status == DSP_STATUS_OPTIMAL && !certified) { status = -1; reason = 2; }   // 2 = vertex failed its certificate
     // 3 = a phase-1 stop / an empty ratio test: only OPTIMAL vertices carry a certificate against the original rows, and on a
@@ -780,7 +846,7 @@ size_t simplex_lds_bytes(int n, int m, int *row_stride) {
   const int N = n + m;
   int rs = ((N + 63) / 64) * 64 + 1;                 // odd number of doubles: conflict-free column AND row sweeps
   if (row_stride) *row_stride = rs;
-  return ((size_t)m * rs + 64 + 64 + 128 + 8 + 8) * sizeof(double);
+  return ((size_t)m * rs + 64 + 64 + 128 + 8 + 8 + 128 + 128) * sizeof(double);     // (+ lo / hi of every variable: warm start)
 }
 
 hipError_t launch_simplex(const SimplexArgs &a, int grid, size_t lds, hipStream_t st) {
@@ -790,7 +856,7 @@ hipError_t launch_simplex(const SimplexArgs &a, int grid, size_t lds, hipStream_
   void *params[] = {&args};
   // register-resident tableau where the rows fit (DSP_SX_LDS=1 forces the LDS-tableau kernel: development / comparison)
   static const int force_lds = getenv("DSP_SX_LDS") ? atoi(getenv("DSP_SX_LDS")) : 0;
-  if (!force_lds && a.m <= 24 && cq <= 1 && a.b.B <= 2048) {
+  if (!force_lds && !a.warm && a.m <= 24 && cq <= 1 && a.b.B <= 2048) {       // (the warm start lives in the LDS-tableau kernel)
     const void *fr = reinterpret_cast<const void *>(&simplex_reg_kernel<1, 24>);
     return hipLaunchKernel(fr, dim3(a.b.B < grid ? a.b.B : grid), dim3(64), params, 0, st);
   }

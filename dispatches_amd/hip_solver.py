@@ -29,7 +29,7 @@ class DspOptions(C.Structure):
                 ("waves_per_block", C.c_int32), ("kkt_every", C.c_int32), ("no_matreg", C.c_int32), ("geo_iters", C.c_int32),
                 ("kkt_gate", C.c_double), ("stall_rescue", C.c_int32), ("no_simplex", C.c_int32),
                 ("jump_rel", C.c_double), ("precision", C.c_int32), ("polish_patience", C.c_int32), ("no_rtc", C.c_int32), ("no_interior_point", C.c_int32),
-                ("eps_infeasible", C.c_double), ("recertify_passes", C.c_int32), ("reserved0", C.c_int32)]
+                ("eps_infeasible", C.c_double), ("recertify_passes", C.c_int32), ("simplex_warm", C.c_int32)]
 
 
 class DspBatch(C.Structure):

@@ -85,6 +85,12 @@ class _DeviceModel:
             # count says so.  Two empty launches per solve less, 96 per plant-day.
             extra = {"recertify_passes": 3} if self.T > 16 else {"recertify_passes": 0, "eps_infeasible": 0.0}
             self.opts = default_options(**{**extra, **(hints or {})})
+            # The hourly LPs of a plant share one matrix from hour to hour: the simplex starts hour k from hour k - 1's final basis
+            # (dsp_options::simplex_warm: 2 - 4 pivots instead of ~26) and from the slack basis in the first hour of every day.
+            from .hip_solver import DspOptions
+            self.opts_warm, self.opts_first = DspOptions.from_buffer_copy(self.opts), DspOptions.from_buffer_copy(self.opts)
+            if self.T <= 16:
+                self.opts_warm.simplex_warm, self.opts_first.simplex_warm = 1, 2
             self.dlp = DeviceLP(self.lp, device_index, self.opts)
             # output buffers with fixed addresses from the start (the fused update kernel and the hipGraphs hold pointers)
             n, m = self.lp.n, max(self.lp.m, 1)
@@ -130,17 +136,19 @@ class _DeviceModel:
     def power_output(self, x):
         return 1e-3 * x[:, self.pt_cols].sum(dim=2)                                            # [B, T] MW
 
-    def solve(self, B, x0=None, y0=None, primal_weight=None):
+    def solve(self, B, x0=None, y0=None, primal_weight=None, hour=None):
+        """hour: hour of the day of an hourly LP (None: no warm start of the simplex)"""
+        opts = self.opts if (hour is None or self.opts is None) else (self.opts_first if hour == 0 else self.opts_warm)
         self.out = self.dlp.solve(B, self.c, self.lb, self.ub, self.rlo if self.lp.m else None,
                                   self.rhi if self.lp.m else None, x0=x0, y0=y0, primal_weight=primal_weight,
-                                  options=self.opts, out=self.out, sync_stats=False, obj_offset=self.c0)
+                                  options=opts, out=self.out, sync_stats=False, obj_offset=self.c0)
         return self.out
 
 
 class BatchedWindBatteryDoubleLoop:
     def __init__(self, n_scenarios, device=0, first_scenario=0, series="rts_gmlc_309.npz", stride=17,
                  day_ahead_horizon=48, real_time_horizon=4, tracking_horizon=4, wind_mw=200.0, batt_mw=25.0,
-                 price_cap=500.0, warm_start=False, lp_backend=None, use_graphs=True, use_fused=True, record=None):
+                 price_cap=500.0, warm_start=False, lp_backend=None, use_graphs=True, use_fused=True, record=None, simplex_warm=True):
         """lp_backend: None = the HIP solver on GPU `device`; tests pass a factory lp -> object with DeviceLP.solve's
         signature working on CPU tensors (tests/_highs_solver.py::HighsTensorLP), which runs the SAME window / objective /
         state-hand-off logic without a GPU.
@@ -232,6 +240,7 @@ class BatchedWindBatteryDoubleLoop:
         self._hundred = torch.full((), 100.0, dtype=torch.float64, device=dev)
         self.solves = 0
         self.use_graphs = bool(use_graphs) and lp_backend is None
+        self.simplex_warm = bool(simplex_warm) and lp_backend is None      # hourly LPs start from the previous hour's basis (_DeviceModel.solve)
         self.use_fused = bool(use_fused) and lp_backend is None and real_time_horizon <= 8 and tracking_horizon <= 8
         if self.use_fused:
             from .hip_solver import DspWbState, load_library
@@ -363,9 +372,9 @@ class BatchedWindBatteryDoubleLoop:
             if self._rec is not None:
                 self._record("state", torch.stack([self.soc, self.thr], 1))
             self._fused(0, k)
-            self.rt.solve(self.B)                       # (status / flags of the two solves: checked by the kernel's next phase)
+            self.rt.solve(self.B, hour=k if self.simplex_warm else None)   # (status / flags of the two solves: checked by the kernel's next phase)
             self._fused(1, k)
-            self.tr.solve(self.B)
+            self.tr.solve(self.B, hour=k if self.simplex_warm else None)
             if self._rec is not None:
                 for key, m in (("rt", self.rt), ("tr", self.tr)):
                     self._record(key + "_x", m.out["x"])
@@ -385,7 +394,8 @@ class BatchedWindBatteryDoubleLoop:
         m.ub.index_fill_(1, m.pda_cols, float("inf"))  #  side becomes a host-to-device copy, which a graph capture refuses)
         m.lb[:, m.pda_cols[:known]] = self.da_offer[:, k:k + known]
         m.ub[:, m.pda_cols[:known]] = self.da_offer[:, k:k + known]
-        out = m.solve(self.B)
+        hour = k if self.simplex_warm else None
+        out = m.solve(self.B, hour=hour) if self.rt.opts is not None else m.solve(self.B)
         self._check(out)
         offer = m.power_output(out["x"])                                 # real-time offer = SCED dispatch in the stub market
         # tracking
@@ -393,7 +403,7 @@ class BatchedWindBatteryDoubleLoop:
         self._set_state(tr)
         tr.rlo[:, tr.track_rows] = offer[:, :tr.T]
         tr.rhi[:, tr.track_rows] = offer[:, :tr.T]
-        out = tr.solve(self.B)
+        out = tr.solve(self.B, hour=hour) if self.tr.opts is not None else tr.solve(self.B)
         self._check(out)
         if self._rec is not None:
             for key, mm in (("rt", self.rt), ("tr", self.tr)):

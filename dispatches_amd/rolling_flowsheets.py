@@ -57,6 +57,10 @@ class _Model:
         if lp_backend is None:
             extra = {"recertify_passes": 3} if self.T > 16 else {"recertify_passes": 0, "eps_infeasible": 0.0}     # (as rolling.py)
             self.opts = default_options(**{**extra, **(getattr(model, "solver_hints", None) or {})})
+            from .hip_solver import DspOptions
+            self.opts_warm, self.opts_first = DspOptions.from_buffer_copy(self.opts), DspOptions.from_buffer_copy(self.opts)
+            if self.T <= 16:                       # hourly LPs: the simplex starts from the previous hour's basis (dsp_options::simplex_warm)
+                self.opts_warm.simplex_warm, self.opts_first.simplex_warm = 1, 2
             self.dlp = DeviceLP(self.lp, device_index, self.opts)
             m = max(self.lp.m, 1)
             self.out = dict(x=torch.zeros((B, n), dtype=torch.float64, device=dev), y=torch.zeros((B, m), dtype=torch.float64, device=dev),
@@ -69,9 +73,10 @@ class _Model:
     def power_output(self, x):
         return x @ self.PT.T + self.PT_const                              # [B, T] MW
 
-    def solve(self, B):
+    def solve(self, B, hour=None):
+        opts = self.opts if (hour is None or self.opts is None) else (self.opts_first if hour == 0 else self.opts_warm)
         self.out = self.dlp.solve(B, self.c, self.lb, self.ub, self.rlo if self.lp.m else None, self.rhi if self.lp.m else None,
-                                  options=self.opts, out=self.out, sync_stats=False, obj_offset=self.c0)
+                                  options=opts, out=self.out, sync_stats=False, obj_offset=self.c0)
         return self.out
 
 
@@ -119,7 +124,7 @@ def _templates(flowsheet, day_ahead_horizon, tracking_horizon):
 
 class BatchedDoubleLoop:
     def __init__(self, flowsheet, n_scenarios, device=0, first_scenario=0, day_ahead_horizon=48, tracking_horizon=4, lp_backend=None,
-                 use_graphs=True, use_fused=True):
+                 use_graphs=True, use_fused=True, simplex_warm=True):
         """flowsheet: "wind_battery", "wind_pem" or "nuclear".  Plant k sees the year that starts at hour (stride * k) mod N of its bus's
         series (strides 17 / 37 / 29).  lp_backend: tests pass tests/_highs_solver.py::HighsTensorLP to run the same logic on CPU tensors.
         use_fused: on the GPU the ~100 element-wise tensor operations of an hour step are THREE launches of one HIP kernel driven by the
@@ -165,6 +170,7 @@ class BatchedDoubleLoop:
         self._scale_t = [torch.full((), s, dtype=torch.float64, device=dev) for s in self.scale]
         self.hour = self.solves = 0
         self.use_graphs = bool(use_graphs) and lp_backend is None
+        self.simplex_warm = bool(simplex_warm) and lp_backend is None
         self._graphs, self._warm = {}, False
         self.use_fused = bool(use_fused) and lp_backend is None and self.rt.T <= 16 and self.tr.T <= 16 and len(self.scale) <= 2
         if self.use_fused:
@@ -268,10 +274,11 @@ class BatchedDoubleLoop:
     def _hour_step(self, k):
         import torch
         if self.use_fused:
+            hour = k if self.simplex_warm else None
             self._fused(0, k)
-            self.rt.solve(self.B)                       # (status / flags: checked by the kernel's next phase)
+            self.rt.solve(self.B, hour=hour)            # (status / flags: checked by the kernel's next phase)
             self._fused(1, k)
-            self.tr.solve(self.B)
+            self.tr.solve(self.B, hour=hour)
             self._fused(2, k)
             return
         m = self.rt
@@ -284,7 +291,8 @@ class BatchedDoubleLoop:
         m.ub.index_fill_(1, m.pda_cols, float("inf"))
         m.lb[:, m.pda_cols[:known]] = self.da_offer[:, k:k + known]
         m.ub[:, m.pda_cols[:known]] = self.da_offer[:, k:k + known]
-        out = m.solve(self.B)
+        hour = k if self.simplex_warm else None
+        out = m.solve(self.B, hour=hour) if m.opts is not None else m.solve(self.B)
         self._check(out)
         offer = m.power_output(out["x"])                                  # real-time offer = SCED dispatch in the stub market
         tr = self.tr
@@ -292,7 +300,7 @@ class BatchedDoubleLoop:
         rhs = offer[:, :tr.T] - tr.PT_const
         tr.rlo[:, tr.track_rows] = rhs
         tr.rhi[:, tr.track_rows] = rhs
-        out = tr.solve(self.B)
+        out = tr.solve(self.B, hour=hour) if tr.opts is not None else tr.solve(self.B)
         self._check(out)
         x = out["x"]
         self.delivered.copy_(tr.power_output(x)[:, 0])

@@ -205,7 +205,12 @@ typedef struct dsp_options {
                                 replays its simulated days from hipGraphs; the reference re-solves nothing, its solver either converges
                                 or the run stops (idaes Bidder: `assert_optimal_termination`).  0 = off (a synchronous caller re-solves
                                 flagged scenarios itself: hip_solver.HipPdlpSolver)                                  default 0    */
-  int32_t reserved0;
+  int32_t simplex_warm;      /* in-wave simplex (tiny LPs): 1 = start every scenario from the final basis of ITS previous solve on this handle where
+                                one is saved (the hourly LPs of a plant's rolling loop share one matrix and differ in costs, bounds and right-hand
+                                sides: 2 - 4 pivots from the previous hour's basis against ~26 from the slack basis) and save the final basis;
+                                2 = start from the slack basis, save (the first hour of a day: bounds the drift of a tableau carried over);
+                                a warm attempt that does not end in a certified optimum is repeated from the slack basis.  The caller keeps
+                                scenario k the same plant from call to call.  0 = off                                     default 0    */
 } dsp_options;
 
 /* The per-call data of B scenarios.  c is required; every other input may be NULL (= no bound: -inf / +inf,

@@ -183,8 +183,10 @@ def test_full_year_double_loop_8192_plants_against_the_oracle():
          two optimal trajectories part at the first tie and never meet again: the ORACLE ALONE, taking its day-ahead offers from an
          interior point of the optimal face instead of a vertex, moves 60 days of revenue by 9e-4 (tests/test_rolling_cpu.py::
          test_two_optimal_trajectories_of_the_same_loop_drift_apart).  Measured for the GPU loop (profiles/r60c_rolling_tests.log):
-         3426 of 5856 plant-days agree to 1e-6, annual revenue within 1.2e-3, delivered energy within 4.5e-5.  The test reports the
-         agreeing days and requires the annual totals within 2.5e-3 / 2e-4: a check of the aggregate, the parity claim is check 1."""
+         3426 of 5856 plant-days agree to 1e-6, annual revenue within 1.2e-3, delivered energy within 4.5e-5 with every hourly LP solved
+         from the slack basis; 2675 plant-days, 2.7e-3 and 1.3e-4 with the simplex started from the previous hour's basis (another sequence
+         of optimal vertices; `r67a_rolling_tests.log`).  The test reports the agreeing days and requires the annual totals within 6e-3 /
+         5e-4: a check of the aggregate, the parity claim is check 1."""
     import multiprocessing as mp
     import os
     import time
@@ -246,7 +248,7 @@ def test_full_year_double_loop_8192_plants_against_the_oracle():
           f"checked against the oracle in {check_wall:.0f} s: worst objective gap day-ahead {worst['da']:.2e}, real-time {worst['rt']:.2e}, tracking {worst['tr']:.2e}; "
           f"free-run fixture: {int(same.sum())} of {same.size} plant-days agree to 1e-6 (first differing day per plant {first_split}), annual revenue within "
           f"{annual.max():.2e}, delivered energy within {energy.max():.2e}")
-    assert annual.max() <= 2.5e-3 and energy.max() <= 2e-4, (annual, energy)
+    assert annual.max() <= 6e-3 and energy.max() <= 5e-4, (annual, energy)
 
 
 def _year_block(arg):
