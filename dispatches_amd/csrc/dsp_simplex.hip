@@ -40,20 +40,21 @@ __device__ __forceinline__ double lds_d(const double *base, int idx) { return ba
 __device__ __forceinline__ int first_lane(unsigned long long mask) { return __ffsll((long long)mask) - 1; }
 
 template <int CQ>
-__global__ void __launch_bounds__(64) simplex_kernel(SimplexArgs a) {
+__global__ void __launch_bounds__(64, CQ == 1 ? 4 : 3) simplex_kernel(SimplexArgs a) {
+  // CQ == 1 (the 4-h wind + battery LPs, 20 x 54): 128 VGPRs and 9.5 KB of LDS -> 4 waves per SIMD, 16 per CU: a 4096-plant batch is ONE
+  // round of waves over the 256 CUs (at 137 VGPRs / 14.6 KB it was 12 per CU, a full round and a quarter-full one)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const dsp_batch &b = a.b;
   const int lane = threadIdx.x;
   const int n = a.n, m = a.m, N = n + m;
   const int RS = a.row_stride;                       // odd number of doubles per tableau row
   double *T = reinterpret_cast<double *>(smem);      // [m][RS]
-  double *alpha_s = T + (size_t)m * RS;              // [64]  entering column
-  double *cB_s = alpha_s + 64;                       // [64]  cost of each row's basic variable (current phase)
-  double *xval = cB_s + 64;                          // [128] value of every variable (final assembly / start)
-  double *scal = xval + 128;                         // [8]   broadcast scalars
+  const int mp = (m + 1) & ~1, Np = (N + 1) & ~1;
+  double *alpha_s = T + (size_t)m * RS;              // [mp]  entering column
+  double *cB_s = alpha_s + mp;                       // [mp]  cost of each row's basic variable (current phase)
+  double *xval = cB_s + mp;                          // [Np]  value of every variable (final assembly / start)
+  double *scal = xval + Np;                          // [8]   broadcast scalars
   int *iscal = reinterpret_cast<int *>(scal + 8);    // [8]
-  double *lo_s = scal + 16;                          // [128] bounds of every variable (warm start: a row's basic may be a structural)
-  double *hi_s = lo_s + 128;                         // [128]
 
   for (int s = blockIdx.x; s < b.B; s += gridDim.x) {
     // Warm start (a.warm == 1 and a saved state for this scenario): the hourly LPs of a plant's rolling loop share ONE matrix and
@@ -124,13 +125,36 @@ __global__ void __launch_bounds__(64) simplex_kernel(SimplexArgs a) {
     if (use_warm) {
       // ---- tableau, basis and nonbasic sides of the saved vertex; values from the NEW bounds -----------------------------
       const double *Ts = a.warm_T + (size_t)s * m * N;
-      for (int i = 0; i < m; ++i) {
-#pragma unroll
-        for (int q = 0; q < CQ; ++q) { const int j = lane + 64 * q; if (j < N) T[i * RS + j] = Ts[(size_t)i * N + j]; }
-      }
       if (lane < m) bvar = a.warm_basis[(size_t)s * m + lane];
+      for (int i0 = 0; i0 < m; i0 += 4) {                              // four rows' loads in flight together (HBM latency, not bytes)
+        double tv[4][CQ];
 #pragma unroll
-      for (int q = 0; q < CQ; ++q) { const int j = lane + 64 * q; if (j < N) { xval[j] = 0.0; lo_s[j] = lo[q]; hi_s[j] = hi[q]; } }
+        for (int u = 0; u < 4; ++u) {
+          const int i = min(i0 + u, m - 1);
+#pragma unroll
+          for (int q = 0; q < CQ; ++q) { const int j = lane + 64 * q; tv[u][q] = (j < N) ? Ts[(size_t)i * N + j] : 0.0; }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if (i0 + u < m) {
+#pragma unroll
+            for (int q = 0; q < CQ; ++q) { const int j = lane + 64 * q; if (j < N) T[(i0 + u) * RS + j] = tv[u][q]; }
+          }
+        }
+      }
+      // bounds of each row's basic variable (may be a structural): looked up through the value buffer, lower then upper
+#pragma unroll
+      for (int q = 0; q < CQ; ++q) { const int j = lane + 64 * q; if (j < N) xval[j] = lo[q]; }
+      wave_lds_fence();
+      if (lane < m) blo = xval[bvar];
+      wave_lds_fence();
+#pragma unroll
+      for (int q = 0; q < CQ; ++q) { const int j = lane + 64 * q; if (j < N) xval[j] = hi[q]; }
+      wave_lds_fence();
+      if (lane < m) bhi = xval[bvar];
+      wave_lds_fence();
+#pragma unroll
+      for (int q = 0; q < CQ; ++q) { const int j = lane + 64 * q; if (j < N) xval[j] = 0.0; }
       wave_lds_fence();
       if (lane < m) xval[bvar] = 1.0;                                  // marks the basic columns
       wave_lds_fence();
@@ -149,16 +173,25 @@ __global__ void __launch_bounds__(64) simplex_kernel(SimplexArgs a) {
       for (int q = 0; q < CQ; ++q) { const int j = lane + 64 * q; if (j < N) xval[j] = basic[q] ? 0.0 : val[q]; }
       wave_lds_fence();
       if (lane < m) {
+#pragma unroll 8
         for (int j = 0; j < N; ++j) beta = fma(-T[lane * RS + j], xval[j], beta);       // basic_i + sum over nonbasic T_ij z_j = 0
-        blo = lo_s[bvar]; bhi = hi_s[bvar];
       }
     } else {
       // ---- tableau: row i = s_i - sum_j a_ij x_j = 0, basis = slacks --------------------------------------------------------
-      for (int i = 0; i < m; ++i) {
+      for (int i0 = 0; i0 < m; i0 += 4) {
+        double tv[4][CQ];
 #pragma unroll
-        for (int q = 0; q < CQ; ++q) {
-          const int j = lane + 64 * q;
-          if (j < N) T[i * RS + j] = (j < n) ? -a.A_dense[(size_t)i * n + j] : ((j - n == i) ? 1.0 : 0.0);
+        for (int u = 0; u < 4; ++u) {
+          const int i = min(i0 + u, m - 1);
+#pragma unroll
+          for (int q = 0; q < CQ; ++q) { const int j = lane + 64 * q; tv[u][q] = (j < n) ? -a.A_dense[(size_t)i * n + j] : ((j - n == i) ? 1.0 : 0.0); }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if (i0 + u < m) {
+#pragma unroll
+            for (int q = 0; q < CQ; ++q) { const int j = lane + 64 * q; if (j < N) T[(i0 + u) * RS + j] = tv[u][q]; }
+          }
         }
       }
 #pragma unroll
@@ -166,6 +199,7 @@ __global__ void __launch_bounds__(64) simplex_kernel(SimplexArgs a) {
       wave_lds_fence();
       // row lanes: basic variable of row i (slack n + i), its value s_i = sum_j a_ij x_j and bounds
       if (lane < m) {
+#pragma unroll 8
         for (int j = 0; j < n; ++j) beta = fma(-T[lane * RS + j], xval[j], beta);
         const double d = a.row_scale[lane];
         const double l = b.row_lb ? b.row_lb[(size_t)s * b.row_lb_stride + lane] : -INFINITY;
@@ -365,6 +399,7 @@ __global__ void __launch_bounds__(64) simplex_kernel(SimplexArgs a) {
       double res = 0.0, mag = 0.0;
       if (lane < m) {
         res = -xval[n + lane]; mag = fabs(xval[n + lane]);
+#pragma unroll 8
         for (int j = 0; j < n; ++j) {
           const double t = a.A_dense[(size_t)lane * n + j] * xval[j];
           res += t; mag += fabs(t);
@@ -844,9 +879,10 @@ __global__ void __launch_bounds__(64, 2) simplex_reg_kernel(SimplexArgs a) {
 
 size_t simplex_lds_bytes(int n, int m, int *row_stride) {
   const int N = n + m;
-  int rs = ((N + 63) / 64) * 64 + 1;                 // odd number of doubles: conflict-free column AND row sweeps
+  int rs = N | 1;                                    // odd number of doubles: conflict-free column AND row sweeps
   if (row_stride) *row_stride = rs;
-  return ((size_t)m * rs + 64 + 64 + 128 + 8 + 8 + 128 + 128) * sizeof(double);     // (+ lo / hi of every variable: warm start)
+  const int mp = (m + 1) & ~1, Np = (N + 1) & ~1;
+  return ((size_t)m * rs + mp + mp + Np + 8 + 8) * sizeof(double);
 }
 
 hipError_t launch_simplex(const SimplexArgs &a, int grid, size_t lds, hipStream_t st) {
