@@ -96,8 +96,14 @@ struct IpmWork {
   int *stall;                               // [Bp] consecutive Newton iterations with a step below 1e-4
   int *endg;                                // [Bp] 1 = the scenario is in its end game (k_ipm_decide): its Newton systems are refined further
   int *counts;                              // [4]: finished (solved or given up), solved, lanes in the end game
+  int ls;                                   // the walks and the reduced solve split a lane group over this many workgroups (1, 2, 4): a workgroup pulls
+                                            //  ~35 - 50 GB/s from HBM whatever it asks for, and ONE lane group's walk is 64 of them on 256 CUs; the lanes of
+                                            //  a wave then work in duplicate (64 / ls distinct scenarios: same addresses, same values - the loads coalesce)
+  int bz;                                   // the border kernels split a partition's rows over this many workgroups (1 .. kIpmBorderSplit): few lane
+                                            //  groups leave (P - 1) G workgroups on 256 CUs, each bound by what ONE CU pulls from HBM; bd holds bz partial sets
 };
 
+constexpr int kIpmBorderSplit = 4;
 struct IpmArgs {
   IpmPlan P;
   IpmWork w;
@@ -374,6 +380,7 @@ struct SeqArgs {
   size_t Bp;
   unsigned outmask;
   const int *state;                        // groups whose 64 lanes have all finished are skipped
+  int lsplit;                              // (IpmWork::ls) grid.x = groups x lsplit
   int dev_mode;                            // development (DSP_IPM_SEQ_MODE): 1 = no compute, 2 = no data movement after the first chunk
 };
 
@@ -391,7 +398,12 @@ template <int NS, int R, class Body, int WAVES, int SETS>
 __global__ __launch_bounds__(64 * WAVES) void k_seq(SeqArgs<NS> a, Body body) {
   extern __shared__ double lds[];          // [2][R][NS][64]
   const int t = threadIdx.x, lane = t & 63, w4 = t >> 6;
-  const size_t g0 = (size_t)blockIdx.x * 64 + lane;
+  // lane split (SeqArgs::lsplit = ls > 1): this workgroup walks lw = 64 / ls scenarios of its group; a mover's lanes are ls ROW slots x lw
+  // scenarios - one load instruction carries ls rows of a stream (a wave-wide load costs the CU's address path ~20 cycles whatever its
+  // lanes ask for, and at one lane group the walks were bound by exactly that: 98 / 113 us with the arithmetic switched off, 59 / 69 us
+  // with the data movement switched off, profiles/r68f) -, the computing wave's lanes work in duplicate (lane -> scenario lane % lw)
+  const int ls = a.lsplit, lw = 64 / ls, sc = lane & (lw - 1), el = lane / lw;
+  const size_t g0 = (size_t)((int)blockIdx.x / ls) * 64 + ((int)blockIdx.x % ls) * lw + sc;
   {
     __shared__ int any;
     if (t == 0) any = 0;
@@ -407,20 +419,23 @@ __global__ __launch_bounds__(64 * WAVES) void k_seq(SeqArgs<NS> a, Body body) {
   constexpr int CH = R * NS, RP = (R + N0 - 1) / N0, E = RP * NS;        // a mover serves the rows r = mi, mi + nset, ... of a chunk, all streams
   const int nch = (rows + R - 1) / R;
   const int mv = w4 - 1;                   // mover index (wave 0: -1)
-  const int sx = (SETS == 2 && mv >= N0) ? 1 : 0, nset = SETS == 1 ? MOV : (sx ? N1 : N0), mi = sx ? mv - N0 : mv;
+  const int sx = (SETS == 2 && mv >= N0) ? 1 : 0, nset = (SETS == 1 ? MOV : (sx ? N1 : N0)) * ls, mi = (sx ? mv - N0 : mv) * ls + el;
+  const bool packed = ls > 1;              // (rows beyond the chunk are then SKIPPED - whole instructions for most movers -, not clipped duplicates)
   auto phys = [&](int lr) { return row0 + (size_t)(a.reverse ? rows - 1 - lr : lr); };
 #define SEQ_PTR(q) ((q) < a.nband ? a.band + (size_t)(q) * a.stride : a.x + (size_t)((q) - a.nband) * a.xstride)
 #define SEQ_LOAD(c)                                                                                                    \
   _Pragma("unroll") for (int rr = 0; rr < RP; ++rr) {                                                                  \
     const int r = min(mi + nset * rr, R - 1), lr = min((c) * R + r, rows - 1);                                         \
     const size_t off = phys(lr) * a.Bp + g0;                                                                           \
-    _Pragma("unroll") for (int q = 0; q < NS; ++q) reg[rr * NS + q] = SEQ_PTR(q)[off];                                 \
+    if (!packed || mi + nset * rr < R) {                                                                               \
+      _Pragma("unroll") for (int q = 0; q < NS; ++q) reg[rr * NS + q] = SEQ_PTR(q)[off];                               \
+    }                                                                                                                  \
   }
 #define SEQ_PUT(buf)                                                                                                   \
   _Pragma("unroll") for (int rr = 0; rr < RP; ++rr) {                                                                  \
     const int r = mi + nset * rr;            /* (no clipped duplicates here: another wave may still be reading that row's results) */ \
     if (r < R) {                                                                                                       \
-      _Pragma("unroll") for (int q = 0; q < NS; ++q) lds[((size_t)(buf) * CH + r * NS + q) * 64 + lane] = reg[rr * NS + q]; \
+      _Pragma("unroll") for (int q = 0; q < NS; ++q) lds[((size_t)(buf) * CH + r * NS + q) * 64 + sc] = reg[rr * NS + q]; \
     }                                                                                                                  \
   }
 #define SEQ_STORE(c, buf, SRC)                                                                                         \
@@ -449,12 +464,12 @@ __global__ __launch_bounds__(64 * WAVES) void k_seq(SeqArgs<NS> a, Body body) {
 #pragma unroll
             for (int rr = 0; rr < RP; ++rr)
 #pragma unroll
-              for (int q = 0; q < NS; ++q) fl[rr * NS + q] = lds[((size_t)(buf ^ 1) * CH + min(mi + nset * rr, R - 1) * NS + q) * 64 + lane];
+              for (int q = 0; q < NS; ++q) fl[rr * NS + q] = lds[((size_t)(buf ^ 1) * CH + min(mi + nset * rr, R - 1) * NS + q) * 64 + sc];
           }
           if (c + 1 < nch) { SEQ_PUT(buf ^ 1) }
           if (c >= 1) { SEQ_STORE(c - 1, buf ^ 1, fl[rr * NS + q]) }
         } else {                             // two sets: a set has two chunks' time per turn - the stores may complete first (no second register array)
-          if (c >= 1) { SEQ_STORE(c - 1, buf ^ 1, (lds[((size_t)(buf ^ 1) * CH + r * NS + q) * 64 + lane])) }
+          if (c >= 1) { SEQ_STORE(c - 1, buf ^ 1, (lds[((size_t)(buf ^ 1) * CH + r * NS + q) * 64 + sc])) }
           if (c + 1 < nch) { SEQ_PUT(buf ^ 1) }
         }
         if (c + 1 + SETS < nch) { SEQ_LOAD(c + 1 + SETS) }
@@ -463,7 +478,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_seq(SeqArgs<NS> a, Body body) {
     }
     if (a.dev_mode != 2 && sx == 0) {
       const int c = nch - 1, buf = c & 1;
-      SEQ_STORE(c, buf, (lds[((size_t)buf * CH + r * NS + q) * 64 + lane]))
+      SEQ_STORE(c, buf, (lds[((size_t)buf * CH + r * NS + q) * 64 + sc]))
     }
   } else {
     __syncthreads();
@@ -471,7 +486,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_seq(SeqArgs<NS> a, Body body) {
     body.init(st, part);
     for (int c = 0; c < nch; ++c) {
       if (a.dev_mode != 1) {
-        double *base = lds + (size_t)(c & 1) * CH * 64 + lane;
+        double *base = lds + (size_t)(c & 1) * CH * 64 + sc;
         const int rmax = min(R, rows - c * R);
         int r = 0;
         for (; r + 2 <= rmax; r += 2) {
@@ -505,16 +520,179 @@ __global__ __launch_bounds__(64) void k_ipm_red_solve(IpmArgs a, double *x) {
   if (a.w.state[s] != 0) return;
   ipm_red_solve_lane<W>(a.P.parts, a.w.redf, a.w.bd, x, a.w.Bp, s);
 }
+// The same solve with the chain FED: ipm_red_solve_lane is one wave walking 2 (P - 1) dependent block steps, each waiting for its own
+// loads (36 + 12 doubles per lane forward, 57 + 6 backward): 136 us for 63 blocks whatever the batch - 1.1 us per step, a memory round
+// trip - where the arithmetic of a step is ~100 FMAs.  Here wave 0 computes and kRedMovers waves feed it, as in k_seq: mover k owns the
+// steps u = k, k + M, ...; it requests ALL of step u + M's data right after it has put step u's into the LDS slot of its parity, which
+// is one barrier before wave 0 reads it - the requests have M - 1 steps to arrive, and the only vector-memory operations a mover has
+// outstanding when it waits are the ones it needs.  A lane group is split over kRedLaneSplit workgroups of LW = 16 scenarios, and a
+// mover's load instruction carries 64 / LW = 4 ELEMENTS of those 16 scenarios (lane = element slot x scenario): 17 - 19 instructions per
+// step instead of 63 - a wave-wide load costs ~16 cycles of address processing whatever its lanes ask for, and with one element per
+// instruction the mover on turn held every barrier for 0.9 us (first version of this kernel: 119 us, no better than the lone wave).
+// Same operations in the same order as the lane function (the CPU harness' reference): identical results.  The backward steps read the
+// separator rows the forward steps of THIS kernel wrote: the two phases are separated by a barrier after a device-scope fence, and those
+// rows are loaded past the CU's vector cache.
+constexpr int kRedMovers = 15;
+constexpr int kRedLaneSplit = 4;
+template <int W>
+__global__ __launch_bounds__(64 * (kRedMovers + 1)) void k_ipm_red_solve_fed(IpmArgs a, double *x) {
+  constexpr int NK = IpmRed<W>::NK, NR = IpmRed<W>::NR, M = kRedMovers;
+  constexpr int LS = kRedLaneSplit, LW = 64 / LS, EPL = LS;      // scenarios per workgroup; elements per load instruction
+  constexpr int ES = NR + W;                                     // slot: forward K (NK), w rows (W), border sums (W); backward K | LDL' (NR), rows (W)
+  constexpr int NLK = (NK + EPL - 1) / EPL, NLW = (W + EPL - 1) / EPL, NLR = (NR + EPL - 1) / EPL;
+  __shared__ double slot[3 * ES * LW];                           // [3][ES][LW]: the step being computed, the one before (its K block is
+                                                                 //  the backward step's coupling: no copy of it in wave 0's registers), the next
+  const int t = threadIdx.x, lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int sc = lane & (LW - 1), el = lane / LW;                // scenario of the workgroup's LW; element slot of a load
+  const int ln = ((int)blockIdx.x % LS) * LW + sc;
+  const size_t Bp = a.w.Bp, s0 = (size_t)((int)blockIdx.x / LS) * 64, s = s0 + ln;
+  {
+    __shared__ int any;
+    if (t == 0) any = 0;
+    __syncthreads();
+    if (t < 64 && a.w.state[s] == 0) any = 1;
+    __syncthreads();
+    if (!any) return;
+  }
+  const IpmParts g = a.P.parts;
+  const int nb = g.P - 1;
+  if (nb <= 0) return;
+  const int Z = a.w.bz;
+  const double *redf = a.w.redf, *bd = a.w.bd;
+  const size_t bdset = (size_t)g.P * W * Bp;
+#define RED_SLOT(buf, e) slot[((buf) * ES + (e)) * LW + sc]
+  if (wv > 0) {
+    const int k = wv - 1;
+    // this lane's part of load j of an array of `cnt` elements (rows of Bp doubles from `base`): element min(j EPL + el, cnt - 1)
+    auto elem = [&](int j, int cnt) { return min(j * EPL + el, cnt - 1); };
+    double rk[NLR], rx[NLW], rb[kIpmBorderSplit][NLW];
+    // ---- forward steps ----
+    auto request_f = [&](int u) {
+      const double *in = redf + (size_t)u * NR * Bp + s0;
+#pragma unroll
+      for (int j = 0; j < NLK; ++j) rk[j] = (in + (size_t)elem(j, NK) * Bp)[ln];
+      const size_t e0 = (size_t)(g.start(u) + g.interior(u));
+#pragma unroll
+      for (int j = 0; j < NLW; ++j) rx[j] = (x + (e0 + elem(j, W)) * Bp + s0)[ln];
+#pragma unroll
+      for (int z = 0; z < kIpmBorderSplit; ++z)
+#pragma unroll
+        for (int j = 0; j < NLW; ++j)      // (sets beyond Z: set 0 again - no select on the VALUE, which would wait for it here)
+          rb[z][j] = (bd + (size_t)(z < Z ? z : 0) * bdset + ((size_t)(u + 1) * W + elem(j, W)) * Bp + s0)[ln];
+    };
+    int mine = k;
+    if (mine < nb) request_f(mine);
+    for (int it = -1; it < nb; ++it) {
+      if (it + 1 == mine) {
+        const int buf = mine % 3;
+#pragma unroll
+        for (int j = 0; j < NLK; ++j) { const int e = j * EPL + el; if (e < NK) slot[(buf * ES + e) * LW + sc] = rk[j]; }
+#pragma unroll
+        for (int j = 0; j < NLW; ++j) {
+          const int i = j * EPL + el;
+          double b = rb[0][j];
+#pragma unroll
+          for (int z = 1; z < kIpmBorderSplit; ++z) if (z < Z) b += rb[z][j];         // (partial border sums in a fixed order)
+          if (i < W) { slot[(buf * ES + NK + i) * LW + sc] = rx[j]; slot[(buf * ES + NK + W + i) * LW + sc] = b; }
+        }
+        mine += M;
+        if (mine < nb) request_f(mine);
+      }
+      __syncthreads();
+    }
+    __syncthreads();                                               // (wave 0's fence: the forward results are in memory)
+    // ---- backward steps: step u is block nb - 1 - u ----
+    auto request_b = [&](int u) {
+      const int sg = nb - 1 - u;
+      const double *in = redf + (size_t)sg * NR * Bp + s0;
+#pragma unroll
+      for (int j = 0; j < NLR; ++j) rk[j] = (in + (size_t)elem(j, NR) * Bp)[ln];
+      const size_t e0 = (size_t)(g.start(sg) + g.interior(sg));
+#pragma unroll
+      for (int j = 0; j < NLW; ++j) rx[j] = __hip_atomic_load(x + (e0 + elem(j, W)) * Bp + s0 + ln, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    mine = k;
+    if (mine < nb) request_b(mine);
+    for (int it = -1; it < nb; ++it) {
+      if (it + 1 == mine) {
+        const int buf = mine % 3;
+#pragma unroll
+        for (int j = 0; j < NLR; ++j) { const int e = j * EPL + el; if (e < NR) slot[(buf * ES + e) * LW + sc] = rk[j]; }
+#pragma unroll
+        for (int j = 0; j < NLW; ++j) { const int i = j * EPL + el; if (i < W) slot[(buf * ES + NR + i) * LW + sc] = rx[j]; }
+        mine += M;
+        if (mine < nb) request_b(mine);
+      }
+      __syncthreads();
+    }
+  } else {
+    const bool live = a.w.state[s] == 0;
+    double wp[W];
+#pragma unroll
+    for (int j = 0; j < W; ++j) wp[j] = 0.0;
+    for (int it = -1; it < nb; ++it) {
+      if (it >= 0) {
+        const int buf = it % 3;
+        const size_t e0 = (size_t)(g.start(it) + g.interior(it));
+        double w[W];
+#pragma unroll
+        for (int i = 0; i < W; ++i) {
+          double v = RED_SLOT(buf, NK + i) - RED_SLOT(buf, NK + W + i);
+#pragma unroll
+          for (int j = 0; j < W; ++j) v = fma(-RED_SLOT(buf, i * W + j), wp[j], v);
+          w[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < W; ++i) { if (live) x[(e0 + i) * Bp + s] = w[i]; wp[i] = w[i]; }
+      }
+      __syncthreads();
+    }
+    __threadfence();
+    __syncthreads();
+    double xn[W];
+#pragma unroll
+    for (int j = 0; j < W; ++j) xn[j] = 0.0;
+    for (int it = -1; it < nb; ++it) {
+      if (it >= 0) {
+        const int buf = it % 3, prev = (it + 2) % 3, sg = nb - 1 - it;
+        const size_t e0 = (size_t)(g.start(sg) + g.interior(sg));
+        double Lt[W][W], dinv[W], u[W];
+#pragma unroll
+        for (int i = 0; i < W; ++i)
+#pragma unroll
+          for (int b = 0; b < W; ++b) {
+            if (b < i) Lt[i][b] = RED_SLOT(buf, NK + ipm_tri(i, b));
+            else { Lt[i][b] = 0.0; if (b == i) dinv[i] = RED_SLOT(buf, NK + ipm_tri(i, i)); }
+          }
+#pragma unroll
+        for (int i = 0; i < W; ++i) u[i] = RED_SLOT(buf, NR + i);
+        ipm_red_ldl_solve<W>(Lt, dinv, u);
+#pragma unroll
+        for (int j = 0; j < W; ++j) {
+          double v = u[j];
+#pragma unroll
+          for (int i = 0; i < W; ++i) v = fma(-(it > 0 ? RED_SLOT(prev, i * W + j) : 0.0), xn[i], v);      // K of block sigma + 1 (none above the last block)
+          u[j] = v;
+        }
+#pragma unroll
+        for (int j = 0; j < W; ++j) { if (live) x[(e0 + j) * Bp + s] = u[j]; xn[j] = u[j]; }
+      }
+      __syncthreads();
+    }
+  }
+#undef RED_SLOT
+}
 constexpr int kIpmBorderWaves = 8;
-// border sums of partition blockIdx.x + 1: NWV waves take every NWV-th interior row, LDS combines (W = 6: 16 waves - with 8 the kernel ran
-// at 3.1 TB/s next to the correction's 5.4 on the same streams; W = 8: 8, the combine buffer must stay under 64 KB)
+// border sums of partition blockIdx.x / bz + 1: NWV waves (x bz workgroups) take every (NWV bz)-th interior row, LDS combines (W = 6: 16
+// waves - with 8 the kernel ran at 3.1 TB/s next to the correction's 5.4 on the same streams; W = 8: 8, the combine buffer must stay
+// under 64 KB); workgroup z of a partition leaves its sums in partial set z of bd (summed in a fixed order by the reduced solve)
 template <int W, int NWV>
 __global__ __launch_bounds__(64 * NWV) void k_ipm_border_dot(IpmArgs a, const double *z) {
   __shared__ double red[NWV][W][64];
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, p = (int)blockIdx.x + 1;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, p = (int)blockIdx.x / a.w.bz + 1, zi = (int)blockIdx.x % a.w.bz;
   const size_t s = (size_t)blockIdx.y * 64 + lane;
   double acc[W];
-  ipm_border_dot_lane<W>(a.P.parts, p, wv, NWV, a.w.gs, (size_t)a.P.Mp * a.w.Bp, z, a.w.Bp, s, acc);
+  ipm_border_dot_lane<W>(a.P.parts, p, zi * NWV + wv, NWV * a.w.bz, a.w.gs, (size_t)a.P.Mp * a.w.Bp, z, a.w.Bp, s, acc);
 #pragma unroll
   for (int j = 0; j < W; ++j) red[wv][j][lane] = acc[j];
   __syncthreads();
@@ -524,16 +702,16 @@ __global__ __launch_bounds__(64 * NWV) void k_ipm_border_dot(IpmArgs a, const do
       double t = 0.0;
 #pragma unroll
       for (int v = 0; v < NWV; ++v) t += red[v][j][lane];
-      a.w.bd[((size_t)p * W + j) * a.w.Bp + s] = t;
+      a.w.bd[(size_t)zi * a.P.parts.P * W * a.w.Bp + ((size_t)p * W + j) * a.w.Bp + s] = t;
     }
   }
 }
 template <int W>
 __global__ __launch_bounds__(64 * kIpmBorderWaves) void k_ipm_border_apply(IpmArgs a, double *x) {
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, p = (int)blockIdx.x + 1;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, p = (int)blockIdx.x / a.w.bz + 1, zi = (int)blockIdx.x % a.w.bz;
   const size_t s = (size_t)blockIdx.y * 64 + lane;
   if (a.w.state[s] != 0) return;
-  ipm_border_apply_lane<W>(a.P.parts, p, wv, kIpmBorderWaves, a.w.gs, (size_t)a.P.Mp * a.w.Bp, a.w.band, x, a.w.Bp, s);
+  ipm_border_apply_lane<W>(a.P.parts, p, zi * kIpmBorderWaves + wv, kIpmBorderWaves * a.w.bz, a.w.gs, (size_t)a.P.Mp * a.w.Bp, a.w.band, x, a.w.Bp, s);
 }
 
 // ---- Woodbury ------------------------------------------------------------------------------------------------------------------------
@@ -1167,7 +1345,7 @@ static hipError_t ipm_workspace(IpmState *I, int B) {
     if (alloc((size_t)P.parts.P * NT * w.Bp, &w.sfin) != hipSuccess) return e;
     if (alloc((size_t)P.parts.P * NT * w.Bp, &w.cfin) != hipSuccess) return e;
     if (alloc((size_t)P.parts.P * NR * w.Bp, &w.redf) != hipSuccess) return e;
-    if (alloc((size_t)P.parts.P * P.W * w.Bp, &w.bd) != hipSuccess) return e;
+    if (alloc((size_t)kIpmBorderSplit * P.parts.P * P.W * w.Bp, &w.bd) != hipSuccess) return e;
   }
   if (alloc((size_t)SC_COUNT * w.Bp, &w.sc) != hipSuccess) return e;
   if (alloc((size_t)kIpmNQ * kIpmMaxBlocks * w.Bp, &w.part) != hipSuccess) return e;
@@ -1199,12 +1377,12 @@ static int ipm_seq_mode() { static const int v = getenv("DSP_IPM_SEQ_MODE") ? at
 // one walk: `parts` partitions starting with partition `part0` (grid.y), `rows` rows each (`last_rows` for the last one of the `nparts`)
 template <int NS, int R, class Body, int WV, int SETS>
 static hipError_t ipm_walk(const IpmArgs &a, SeqArgs<NS> q, const Body &body, int parts, hipStream_t st) {
-  q.Bp = a.w.Bp; q.state = a.w.state; q.dev_mode = ipm_seq_mode();
+  q.Bp = a.w.Bp; q.state = a.w.state; q.lsplit = a.w.ls; q.dev_mode = ipm_seq_mode();
   const size_t lds = (size_t)2 * R * NS * 64 * sizeof(double);
   auto fn = k_seq<NS, R, Body, WV, SETS>;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(fn, dim3((unsigned)a.w.G, (unsigned)parts), dim3(64 * WV), lds, st, q, body);
+  hipLaunchKernelGGL(fn, dim3((unsigned)(a.w.G * a.w.ls), (unsigned)parts), dim3(64 * WV), lds, st, q, body);
   return hipGetLastError();
 }
 
@@ -1236,12 +1414,18 @@ static hipError_t ipm_factor(const IpmArgs &a, hipStream_t st) {
   return hipGetLastError();
 }
 
+static bool ipm_red_fed(int W) {
+  // (0: the one-wave reduced solve - comparison; half-bandwidth 8: 108 doubles per step do not fit a mover's registers)
+  return W <= 6 && !(getenv("DSP_IPM_RED_FED") && atoi(getenv("DSP_IPM_RED_FED")) == 0);
+}
+
 // x := B^-1 x for the [m][Bp] vector `x` (in place)
 template <int W>
 static hipError_t ipm_bsolve(const IpmArgs &a, double *x, hipStream_t st) {
   const IpmParts &g = a.P.parts;
   const size_t stride = (size_t)a.P.Mp * a.w.Bp;
-  const dim3 border((unsigned)std::max(g.P - 1, 1), (unsigned)a.w.G);
+  const dim3 border((unsigned)(std::max(g.P - 1, 1) * a.w.bz), (unsigned)a.w.G);
+  const bool fed = ipm_red_fed(W);
   static const int one_set = getenv("DSP_IPM_SEQ_SETS") ? atoi(getenv("DSP_IPM_SEQ_SETS")) == 1 : 0;      // development
   hipError_t e;
   {
@@ -1256,7 +1440,8 @@ static hipError_t ipm_bsolve(const IpmArgs &a, double *x, hipStream_t st) {
   if (g.P > 1) {
     constexpr int DW = W <= 6 ? 16 : 8;
     hipLaunchKernelGGL((k_ipm_border_dot<W, DW>), border, dim3(64 * DW), 0, st, a, (const double *)x);
-    hipLaunchKernelGGL(k_ipm_red_solve<W>, dim3((unsigned)a.w.G), dim3(64), 0, st, a, x);
+    if constexpr (W <= 6) if (fed) hipLaunchKernelGGL(k_ipm_red_solve_fed<W>, dim3((unsigned)(a.w.G * kRedLaneSplit)), dim3(64 * (kRedMovers + 1)), 0, st, a, x);
+    if (!fed) hipLaunchKernelGGL(k_ipm_red_solve<W>, dim3((unsigned)a.w.G), dim3(64), 0, st, a, x);
     hipLaunchKernelGGL(k_ipm_border_apply<W>, border, dim3(64 * kIpmBorderWaves), 0, st, a, x);
   }
   {
@@ -1323,6 +1508,19 @@ static void ipm_dump(const char *name, const double *dev, size_t rows, size_t Bp
     }                                                                                                                   \
   } while (0)
 
+// workgroups per partition of the border kernels: enough of them for the chip while the lane groups are few (IpmWork::bz)
+static int ipm_lane_split(int G, int P) {
+  int ls = 1;
+  if (getenv("DSP_IPM_LS")) ls = atoi(getenv("DSP_IPM_LS"));
+  else while (ls < 4 && 2 * ls * G * std::max(P, 1) <= 256) ls *= 2;
+  return ls == 2 || ls == 4 ? ls : 1;
+}
+static int ipm_border_split(int G, int P, int W) {
+  if (!ipm_red_fed(W)) return 1;                                                          // (the one-wave reduced solve reads partial set 0 only)
+  if (getenv("DSP_IPM_BZ")) return std::min(std::max(atoi(getenv("DSP_IPM_BZ")), 1), kIpmBorderSplit);
+  return std::min(std::max(256 / (std::max(P - 1, 1) * std::max(G, 1)), 1), kIpmBorderSplit);
+}
+
 // The scenarios still iterating (`active` of them) are packed into the first lanes: a Newton iteration costs what its lane groups cost, and
 // the members of a batch finish over a 3 x range of iteration counts (40 .. 144 on the year-long wind + battery family).  What persists
 // from one iteration to the next is packed - the iterate (v, z, f, y), the problem data (l, u, cb), the objective scale, the per-lane
@@ -1352,6 +1550,8 @@ static hipError_t ipm_repack(IpmState *I, IpmArgs &a, hipStream_t st, int active
   if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;                      // (perm_host is reused by the next repack)
   a.w.G = G_new;
   a.w.nch = 4 * ipm_blocks(G_new);
+  a.w.bz = ipm_border_split(G_new, a.P.parts.P, a.P.W);
+  a.w.ls = ipm_lane_split(G_new, a.P.parts.P);
   return hipGetLastError();
 }
 
@@ -1360,6 +1560,8 @@ static hipError_t ipm_loop(StreamSolver *S, IpmArgs &a, hipStream_t st, bool *al
   IpmState *I = S->ipm;
   a.w.G = (int)(a.w.Bp / 64);
   a.w.nch = 4 * ipm_blocks(a.w.G);
+  a.w.bz = ipm_border_split(a.w.G, a.P.parts.P, a.P.W);
+  a.w.ls = ipm_lane_split(a.w.G, a.P.parts.P);
   const dim3 blk(256);
   dim3 grid((unsigned)(a.w.nch / 4), (unsigned)a.w.G), lanes((unsigned)a.w.G);
   // DSP_IPM_COMPACT=0: every scenario keeps its lane to the end of the solve (measurement); groups of more than 1024 lanes: not packed
