@@ -53,7 +53,11 @@ constexpr int kIpmMaxBlocks = 1024;        // blocks (of 4 waves) per lane group
 // chunk of indices and walks it with a few loads in flight) - 2048 blocks over the groups, at most kIpmMaxBlocks per group.  Round 5
 // stopped at 256: 1024 waves for a single group of 64 scenarios = one wave per SIMD, 7.6 ms per Newton iteration at 64 scenarios
 // against 13.1 ms at 256.  The partial sums are per block (ipm_put), so the finish kernels walk as many as before.
-static inline int ipm_blocks(int G) { return std::max(16, std::min(kIpmMaxBlocks, 2048 / std::max(G, 1))); }
+static inline int ipm_blocks(int G) {
+  static const int cap = getenv("DSP_IPM_MAXBLK") ? std::min(std::max(atoi(getenv("DSP_IPM_MAXBLK")), 16), kIpmMaxBlocks) : kIpmMaxBlocks;      // (development)
+  static const int tot = getenv("DSP_IPM_TOTBLK") ? atoi(getenv("DSP_IPM_TOTBLK")) : 2048;
+  return std::max(16, std::min(cap, tot / std::max(G, 1)));
+}
 
 struct IpmPlan {                            // shared by all scenarios (device)
   int n, m, W, K, Mp;                       // Mp = m + W rows of the band arrays
@@ -171,15 +175,22 @@ __device__ __forceinline__ void ipm_finish(const double *part, int nch, size_t B
   const double e0 = OP == 0 ? 0.0 : OP == 1 ? 1e300 : -1e300;
 #pragma unroll
   for (int q = 0; q < NQ; ++q) {
-    double acc[4] = {e0, e0, e0, e0};
+    constexpr int U = 16;                                  // loads in flight per thread (4: 128 partials per wave = 32 memory round trips per quantity)
+    double acc[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) acc[u] = e0;
     if (q >= nq) { red[wv][q][lane] = e0; continue; }      // (slots nobody filled: K = 1 uses 1 of the Woodbury matrix's 16)
     int c = wv;
-    for (; c + 3 * NW < nch; c += 4 * NW) {
+    for (; c + (U - 1) * NW < nch; c += U * NW) {
 #pragma unroll
-      for (int u = 0; u < 4; ++u) acc[u] = op(acc[u], part[((size_t)q * nch + c + NW * u) * Bp + s]);
+      for (int u = 0; u < U; ++u) acc[u] = op(acc[u], part[((size_t)q * nch + c + NW * u) * Bp + s]);
     }
     for (; c < nch; c += NW) acc[0] = op(acc[0], part[((size_t)q * nch + c) * Bp + s]);
-    red[wv][q][lane] = op(op(acc[0], acc[1]), op(acc[2], acc[3]));
+#pragma unroll
+    for (int w = U / 2; w >= 1; w /= 2)
+#pragma unroll
+      for (int u = 0; u < w; ++u) acc[u] = op(acc[u], acc[u + w]);
+    red[wv][q][lane] = acc[0];
   }
   __syncthreads();
 #pragma unroll

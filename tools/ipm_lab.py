@@ -32,7 +32,7 @@ def banded_from(N, w):
     return ab
 
 
-def solve(P, eps=1e-9, eps_obj=5e-7, max_iter=200, colscale=None, n_ruiz=10, dense_thr=16, verbose=0, reg=1e-12, prox=0.0, frac=0.99, refine=3, theta_cap=1e30, sigmin=0.05, mu0=0.0, gondzio=0, pcg=0, pcg_tol=1e-11, prefine=0, absref=0, rpk=0.0):
+def solve(P, eps=1e-9, eps_obj=5e-7, max_iter=200, colscale=None, n_ruiz=10, dense_thr=16, verbose=0, reg=1e-12, prox=0.0, frac=0.99, refine=3, theta_cap=1e30, sigmin=0.05, mu0=0.0, gondzio=0, pcg=0, pcg_tol=1e-11, prefine=0, absref=0, rpk=0.0, nbhd=0.0, nb_back=0.8, samestep=0):
     """frac / sigmin: the product's settings since round 5's last commits (csrc/dsp_ipm.hip: 0.99 to the boundary, sigma >= 0.05); the first
     version ran 0.9995 / 0 (`frac=0.9995 sigmin=0` on the command line)"""
     A0 = sp.csr_matrix(P["A"])
@@ -214,6 +214,18 @@ def solve(P, eps=1e-9, eps_obj=5e-7, max_iter=200, colscale=None, n_ruiz=10, den
                 break
         solve.ncorr = getattr(solve, "ncorr", 0) + ncorr
         ap, ad = min(1.0, frac * ap), min(1.0, frac * ad)
+        if samestep:
+            ap = ad = min(ap, ad)
+        if nbhd > 0:
+            # wide neighbourhood N_-inf(gamma): back off until every complementarity product of the trial point is at least gamma x their mean
+            # (experiment, round 6: the slow members take steps of 0.01 - 0.3 for a hundred iterations - a few products run ahead to zero)
+            for _ in range(40):
+                pl = np.where(hl, (wl + ap * dv) * (z + ad * dz), np.inf); pu = np.where(hu, (tu - ap * dv) * (f + ad * df), np.inf)
+                mu_t = (pl[hl].sum() + pu[hu].sum()) / nb
+                if min(pl.min(), pu.min()) >= nbhd * mu_t:
+                    break
+                ap *= nb_back; ad *= nb_back
+            solve.nb_backs = getattr(solve, "nb_backs", 0) + _
         v = v + ap * dv; y = y + ad * dy; z = z + ad * dz; f = f + ad * df
         # termination on the unscaled problem, the streaming path's test
         xs = xfix.copy(); xs[cols] = v[:len(cols)]
@@ -247,10 +259,10 @@ def solve(P, eps=1e-9, eps_obj=5e-7, max_iter=200, colscale=None, n_ruiz=10, den
 if __name__ == "__main__":
     kw = dict(a.split("=") for a in sys.argv[1:])
     T = int(kw.pop("T", 672)); members = [int(k) for k in kw.pop("member", "5").split(",")]
-    cs = kw.pop("colscale", "phys")
+    cs = kw.pop("colscale", "phys"); fam = kw.pop("family", "base")
     opts = {k: float(v) for k, v in kw.items()}
     for member in members:
-        P = lab.build(T, member, None, "chain")
+        P = lab.build(T, member, None, "chain", family=fam)
         ref, xr, th = lab.highs(P)
         print(f"T={T} member={member} n={P['lp'].n} m={P['lp'].m} nnz={P['lp'].nnz} HiGHS {ref:.10e} ({th:.1f}s)", flush=True)
         if cs == "phys":
