@@ -391,6 +391,7 @@ void dsp_default_options(dsp_options *o) {
   o->eps_infeasible = 1e-6;
   o->recertify_passes = 0;
   o->simplex_warm = 0;
+  o->warm_patience = 0;
 }
 
 int dsp_version(void) { return DSP_VERSION; }

@@ -13,8 +13,9 @@
 //     wide columns (span > 16 rows: design variables, periodic conditions; K <= 4) through Sherman-Morrison-Woodbury, K x K per scenario
 //     iterative refinement on the full normal equations: to 1e-8 of the right-hand side (max norms), to 1e-11 once a scenario is in its end
 //     game (within four decades of its objective tolerance), three steps at most
-//     steps 0.99 to the boundary, sigma = max((mu_aff / mu)^3, 0.05): the two settings (with the end-game refinement) under which every
-//     horizon, family and elimination order tried finishes (DESIGN.md 4f "Robustness, measured": mu must not collapse under the solve error)
+//     steps 0.99 to the boundary (0.9 where the boundary is closer than half the Newton step: round 6, the slow members' hundred blocked
+//     steps get fewer), sigma = max((mu_aff / mu)^3, 0.05): the settings (with the end-game refinement) under which every horizon, family
+//     and elimination order tried finishes (profiles/HISTORY.md "Robustness, measured": mu must not collapse under the solve error)
 // ONE LANE PER SCENARIO: every array is scenario-minor ([index][scenario], 64 scenarios = one 512-byte line per index), all lanes walk the
 // same rows, and the structure (ELLs of the scaled matrix, the band's product lists) is read through uniform addresses.
 // The banded factorisation and solves are chains of dependent rows.  SEQUENTIAL form (below 512 rows; DSP_IPM_PARTS=1): one wave per 64
@@ -116,6 +117,7 @@ struct IpmArgs {
   int it;                                   // Newton iteration (1-based)
   int max_it;                               // give up after this many (kIpmMaxNewton; development: DSP_IPM_MAXIT)
   double reftol, reftol_end;                // refinement of the Newton systems: |rhs - N dy| <= tol |rhs| (max norms), far out / in a scenario's end game
+  double step_blocked, step_thr;            // (k_ipm_steps)
   double reg, step, sigmin;                 // primal regularisation of Theta (0: off), step to the boundary (0.99), floor of sigma (0.05); ipm_run
   double thcap;                             // cap of Theta (k_ipm_resid)
 };
@@ -973,7 +975,12 @@ __global__ __launch_bounds__(64 * kFinW) void k_ipm_steps(IpmArgs a, int mode) {
   ipm_finish<2, 1, kFinW>(a.w.part, a.w.nch / 4, Bp, s, t);
   if (threadIdx.x >= 64 || a.w.state[s] != 0) return;
   if (mode == 0) { a.w.sc[SC_APA * Bp + s] = fmin(t[0], 1.0); a.w.sc[SC_ADA * Bp + s] = fmin(t[1], 1.0); }
-  else { a.w.sc[SC_AP * Bp + s] = fmin(1.0, a.step * t[0]); a.w.sc[SC_AD * Bp + s] = fmin(1.0, a.step * t[1]); }
+  else {
+    // fraction of the way to the boundary: a.step (0.99) for a long step, a.step_blocked where the boundary is closer than a.step_thr of the
+    // Newton step - the slow members of the wind + battery family take a hundred such steps, and staying further inside shortens that phase
+    a.w.sc[SC_AP * Bp + s] = fmin(1.0, (t[0] < a.step_thr ? a.step_blocked : a.step) * t[0]);
+    a.w.sc[SC_AD * Bp + s] = fmin(1.0, (t[1] < a.step_thr ? a.step_blocked : a.step) * t[1]);
+  }
 }
 
 // mu of the affine step; the second-order terms of the corrector
@@ -1718,6 +1725,8 @@ hipError_t ipm_run(StreamSolver *S, StreamArgs &sa, hipStream_t st, bool *all_so
   a.max_it = std::max(1, std::min(a.max_it, sa.opt.max_iter));            // (dsp_options::max_iter caps the Newton iterations too)
   a.reg = getenv("DSP_IPM_REG") ? atof(getenv("DSP_IPM_REG")) : 0.0;
   a.step = getenv("DSP_IPM_STEP") ? atof(getenv("DSP_IPM_STEP")) : 0.99;
+  a.step_blocked = getenv("DSP_IPM_STEP_BLOCKED") ? atof(getenv("DSP_IPM_STEP_BLOCKED")) : 0.9;
+  a.step_thr = getenv("DSP_IPM_STEP_THR") ? atof(getenv("DSP_IPM_STEP_THR")) : 0.5;      // (sweep: profiles/r69a_ipm_step_sweep.log)
   a.sigmin = getenv("DSP_IPM_SIGMIN") ? atof(getenv("DSP_IPM_SIGMIN")) : 0.05;
   a.thcap = getenv("DSP_IPM_THCAP") ? atof(getenv("DSP_IPM_THCAP")) : 1e11;
   a.reftol = getenv("DSP_IPM_REFTOL") ? atof(getenv("DSP_IPM_REFTOL")) : 1e-8;

@@ -500,15 +500,19 @@ __global__ void __launch_bounds__((CPL + RPL >= DSP_ONE_WAVE_FROM && WC != 0) ? 
     w_lo.set(a.opt.weight_guard > 0.0 ? a.opt.weight_guard * eta * 1.1e-16 * cmax / (eps * (1.0 + qall)) : 0.0);
     w_hi.set((a.opt.weight_guard > 0.0 && qmax > 0.0)
                  ? eps * (1.0 + cs) / (a.opt.weight_guard * eta * 1.1e-16 * qmax) : INFINITY);
+    w_init.set(w);                   // the AUTOMATIC weight: what a stalled weight is pulled back to, and where a given-up warm start starts again
     if (b.primal_weight) {
       const double wi = b.primal_weight[s];
       if (wi > 0.0 && is_finite(wi)) w = wi;
     }
+    // warm start on patience (dsp_options::warm_patience): started from the caller's point, not terminated after that many iterations ->
+    // once more from the cold point at the next check (the restart block)
+    bool warm = a.opt.warm_patience > 0 && a.skip_solved == 0 && (b.x0 != nullptr || b.y0 != nullptr);      // (first pass only: the later passes' x0 is the pass before)
 
-    w_init.set(w);
     DSP_TRACE("[trace] loaded w=%g\n", w);
     int k = 0;                       // iterations since the last restart
     int it = 0;
+    int it0 = 0;                     // iteration the current start was made at (> 0: a warm start given up, dsp_options::warm_patience)
     int njump = 0;
     int ncheck = 0, last_kkt = 0;
     double gate2 = 0.0;              // the next gated KKT test runs once r^2 <= gate2
@@ -779,8 +783,9 @@ __global__ void __launch_bounds__((CPL + RPL >= DSP_ONE_WAVE_FROM && WC != 0) ? 
         // ---- restart test (r0 = residual at the first check after a restart) ----------------------------------
         const bool first = !(r0 < INFINITY);
         const bool decayed = (r <= beta_s2 * r0) || (r <= beta_n2 * r0 && r > rprev);
-        const bool artificial = (double)k >= a.opt.restart_artificial * (double)(it + 1);
-        const bool do_restart = (!first && (decayed || artificial)) || boost_now;
+        const bool artificial = (double)k >= a.opt.restart_artificial * (double)(it - it0 + 1);
+        const bool give_up_warm = warm && it >= a.opt.warm_patience;
+        const bool do_restart = (!first && (decayed || artificial)) || boost_now || give_up_warm;
         // no decay for >= stall_rescue iterations: the iteration sits on its rounding floor (dsp_options::stall_rescue).
         // First time, with the weight within 30x of its rounding guard: the controller has driven the weight away, reset
         // it.  From the second time on: nothing more to gain, the eps_obj tests are waived (the eps_rel tests stay).
@@ -806,7 +811,16 @@ __global__ void __launch_bounds__((CPL + RPL >= DSP_ONE_WAVE_FROM && WC != 0) ? 
           for (int q = 0; q < RPL; ++q) { const double t = yp[q] - y0[q]; dd[1] = fma(t, t, dd[1]); }
           wave_sums<2>(dd);
           const double w_was = w;
-          if (stalled) {
+          if (give_up_warm) {
+            // the cold point: x = clamp(0), y = 0, the automatic weight; every piece of history the controllers keep starts over
+#pragma unroll
+            for (int q = 0; q < CPL; ++q) xp[q] = clampd(0.0, lb[q], ub[q]);
+#pragma unroll
+            for (int q = 0; q < RPL; ++q) yp[q] = 0.0;
+            w = w_init.get();
+            warm = false; it0 = it; stalls = 0; waive_obj = false; suspect = false; nsus = 0; gate2 = 0.0; last_kkt = ncheck;
+            pol_best.set(INFINITY); pol_it = it; nboost = 0; pol_tried = false;
+          } else if (stalled) {
             w = sqrt(w * w_init.get());
           } else if (dd[0] > 1e-28 && dd[1] > 1e-28) {
             // log(w |dx| / |dy|) and the exponential in single precision (hardware v_log_f32 / v_exp_f32): the weight

@@ -29,7 +29,7 @@ class DspOptions(C.Structure):
                 ("waves_per_block", C.c_int32), ("kkt_every", C.c_int32), ("no_matreg", C.c_int32), ("geo_iters", C.c_int32),
                 ("kkt_gate", C.c_double), ("stall_rescue", C.c_int32), ("no_simplex", C.c_int32),
                 ("jump_rel", C.c_double), ("precision", C.c_int32), ("polish_patience", C.c_int32), ("no_rtc", C.c_int32), ("no_interior_point", C.c_int32),
-                ("eps_infeasible", C.c_double), ("recertify_passes", C.c_int32), ("simplex_warm", C.c_int32)]
+                ("eps_infeasible", C.c_double), ("recertify_passes", C.c_int32), ("simplex_warm", C.c_int32), ("warm_patience", C.c_int32)]
 
 
 class DspBatch(C.Structure):
@@ -110,7 +110,7 @@ EXPORTED_SYMBOLS = ("dsp_default_options", "dsp_create", "dsp_solve", "dsp_spmv_
                     "dsp_rtc_compile_check", "dsp_rtc_message", "dsp_wb_rolling_update", "dsp_loop_update", "dsp_bid_points", "dsp_source_hash")
 
 
-ABI_VERSION = 11         # DSP_VERSION of the include/dsp_hip.h these structures mirror
+ABI_VERSION = 12         # DSP_VERSION of the include/dsp_hip.h these structures mirror
 
 
 BID_MAX_HOURS, BID_MAX_SCENARIOS = 64, 16384

@@ -148,7 +148,7 @@ class _DeviceModel:
 class BatchedWindBatteryDoubleLoop:
     def __init__(self, n_scenarios, device=0, first_scenario=0, series="rts_gmlc_309.npz", stride=17,
                  day_ahead_horizon=48, real_time_horizon=4, tracking_horizon=4, wind_mw=200.0, batt_mw=25.0,
-                 price_cap=500.0, warm_start=False, lp_backend=None, use_graphs=True, use_fused=True, record=None, simplex_warm=True):
+                 price_cap=500.0, warm_start=False, lp_backend=None, use_graphs=True, use_fused=True, record=None, simplex_warm=True, warm_patience=6000):
         """lp_backend: None = the HIP solver on GPU `device`; tests pass a factory lp -> object with DeviceLP.solve's
         signature working on CPU tensors (tests/_highs_solver.py::HighsTensorLP), which runs the SAME window / objective /
         state-hand-off logic without a GPU.
@@ -221,6 +221,11 @@ class BatchedWindBatteryDoubleLoop:
         cmap, rmap = period_shift_maps(da_model.lp, 24)
         self.da_cmap, self.da_rmap = idx(cmap), idx(rmap)
         if self.warm_start:
+            # ... on patience (dsp_options::warm_patience, ABI 12): a plant whose day-ahead solve has not finished after `warm_patience`
+            # iterations from yesterday's point starts again from the cold point inside the same launch
+            if lp_backend is None and self.da.opts is not None:
+                import os
+                self.da.opts.warm_patience = int(os.environ.get("DSP_WARM_PATIENCE", warm_patience))
             self.da_x0 = torch.zeros((B, da_model.lp.n), dtype=torch.float64, device=dev)
             self.da_y0 = torch.zeros((B, max(da_model.lp.m, 1)), dtype=torch.float64, device=dev)
         self.tr.track_rows = idx([tr_model.block.kept_row_index(r) for r in tr_model.tracking_rows])

@@ -1,0 +1,13 @@
+#!/bin/bash
+repo="$(cd "$(dirname "$0")/../.." && pwd)"; cd "$repo"
+line() { python -c "
+import json, sys
+d = json.loads(sys.stdin.read()); c = d['config']
+print('$1', '| s/batch', round(c.get('seconds_per_batch'), 3), '| newton mean', round(c.get('newton_iterations_per_scenario'), 1), 'max', c.get('max_newton_iterations'), '| err', c.get('max_rel_objective_error_vs_oracle_fixture'), '| solved', c.get('solved_to_optimality'))"; }
+for cfg in $1; do
+  lo=${cfg%%:*}; thr=${cfg##*:}
+  export DSP_IPM_STEP_BLOCKED=$lo DSP_IPM_STEP_THR=$thr
+  for B in 256 60; do timeout 300 python bench.py --workload price_taker --batch $B --solve --warmup 1 --cpu-sample 0 2>/dev/null | tail -1 | line "blocked $lo thr $thr price_taker B=$B"; done
+  timeout 300 python bench.py --workload pem_price_taker --batch 64 --solve --warmup 1 --cpu-sample 0 2>/dev/null | tail -1 | line "blocked $lo thr $thr pem B=64"
+  timeout 300 python bench.py --workload nuclear_price_taker --batch 60 --horizon 8784 --solve --warmup 1 --cpu-sample 0 2>/dev/null | tail -1 | line "blocked $lo thr $thr nuclear B=60"
+done
