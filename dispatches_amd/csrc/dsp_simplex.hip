@@ -213,6 +213,8 @@ __global__ void __launch_bounds__(64, CQ == 1 ? 4 : 3) simplex_kernel(SimplexArg
     bool phase1 = false;
 
     int refines = 0;
+    double res_c = 0.0, mag_c = 0.0;   // the refinement's row residual (and the magnitude of its terms): the certificate's, unless pivots followed
+    bool res_valid = false;
     bool tight = false;                // after a refinement of the basic values: feasibility to 1e-3 of the working tolerance (below)
   pivot:
     for (int it = 0;; ++it) {
@@ -385,11 +387,16 @@ __global__ void __launch_bounds__(64, CQ == 1 ? 4 : 3) simplex_kernel(SimplexArg
       if (lane < m) xval[bvar] = beta;
       wave_lds_fence();
       if (lane < m) {
-        double res = -xval[n + lane];
+        double res = -xval[n + lane], mag = fabs(xval[n + lane]);
 #pragma unroll 8
-        for (int j = 0; j < n; ++j) res = fma(a.A_dense[(size_t)lane * n + j], xval[j], res);
+        for (int j = 0; j < n; ++j) {
+          const double t = a.A_dense[(size_t)lane * n + j] * xval[j];
+          res += t; mag += fabs(t);
+        }
         cB_s[lane] = res;
+        res_c = res; mag_c = mag;
       }
+      res_valid = true;
       wave_lds_fence();
       bool out = false;
       if (lane < m) {
@@ -401,7 +408,7 @@ __global__ void __launch_bounds__(64, CQ == 1 ? 4 : 3) simplex_kernel(SimplexArg
         out = beta < blo - tt || beta > bhi + tt;
       }
       wave_lds_fence();
-      if (__ballot(out) != 0ull) { tight = true; status = -1; goto pivot; }
+      if (__ballot(out) != 0ull) { tight = true; status = -1; res_valid = false; goto pivot; }
     }
 
     // ---- assemble the vertex, certify it against the original rows, store ----------------------------------------
@@ -433,8 +440,9 @@ __global__ void __launch_bounds__(64, CQ == 1 ? 4 : 3) simplex_kernel(SimplexArg
       // basic values carry an ABSOLUTE drift of ~1e-11 x the largest number in the tableau (1e5 kWh states), which lands
       // on rows whose own terms may all be ~0 (seen: 4.9e-6 on such a row, 5e-11 of the state-of-charge scale).  The
       // certificate is there to catch a broken tableau, not rounding.
-      double res = 0.0, mag = 0.0;
-      if (lane < m) {
+      // (a vertex that was refined and not pivoted on since: the residual BEFORE the correction is the statement about the tableau)
+      double res = res_c, mag = mag_c;
+      if (lane < m && !res_valid) {
         res = -xval[n + lane]; mag = fabs(xval[n + lane]);
 #pragma unroll 8
         for (int j = 0; j < n; ++j) {
