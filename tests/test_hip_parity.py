@@ -607,3 +607,51 @@ def test_simplex_warm_start_from_the_previous_solves_basis():
     assert np.allclose(warm_obj, ref_obj, rtol=1e-9, atol=1e-7 * np.abs(ref_obj).max())
     assert warm_piv.mean() < 0.5 * ref_piv.mean(), (warm_piv.mean(), ref_piv.mean())
     print(f"\n[simplex] pivots from the slack basis {ref_piv.mean():.1f}, from the previous basis {warm_piv.mean():.1f} (same data again: {again_piv.max()})")
+
+
+@gpu
+def test_warm_start_on_patience():
+    """dsp_options::warm_patience (ABI 12): a scenario started from the caller's point (dsp_batch::x0 / y0) that has not terminated after that
+    many iterations starts again from the cold point inside the same launch.  512 wind + battery 48-h bidding LPs from a BAD start (yesterday's
+    solution of ANOTHER plant, duals of the wrong sign pattern): without patience the slowest need several times the cold solve's iterations;
+    with a patience of 3000 every scenario is optimal within the 1e-6 contract, none runs beyond patience + the slowest cold solve by much,
+    and scenarios that finish inside the patience are bit-identical to the run without it."""
+    import os
+    import torch
+    from dispatches_amd import scenarios
+    from dispatches_amd.hip_solver import DeviceLP, default_options
+    B = 512
+    bidder, model = scenarios.make_batch("wind_battery_48h", B, _solver())
+    lp = model.lp
+    hints = getattr(model, "solver_hints", None) or {}
+    up = lambda a: torch.as_tensor(np.array(a, np.float64, order="C")).cuda()
+    dlp = DeviceLP(lp, 0, default_options(**hints))
+    lb_, ub_, rlo_, rhi_ = model.scenario_bounds()
+    c, lb, ub, rlo, rhi = up(model.c), up(lb_), up(ub_), up(rlo_), up(rhi_)
+    c0 = up(np.broadcast_to(np.asarray(getattr(model, "c0", lp.c0), float), (B,)))
+
+    def solve(patience, x0=None, y0=None):
+        o = default_options(**{**hints, "warm_patience": patience})
+        out = dlp.solve(B, c, lb, ub, rlo, rhi, x0=x0, y0=y0, options=o, obj_offset=c0)
+        return {k: out[k].cpu().numpy().copy() for k in ("obj", "status", "iters", "x", "y")}
+    cold = solve(0)
+    assert (cold["status"] == 0).all()
+    # a bad start: every plant gets the solution of the plant 37 places on, its duals negated
+    x0, y0 = up(np.roll(cold["x"], 37, axis=0)), up(-np.roll(cold["y"], 37, axis=0))
+    plain = solve(0, x0, y0)
+    pat = 3000
+    patient = solve(pat, x0, y0)
+    assert (patient["status"] == 0).all()
+    # (each solve certifies its objective to 5e-7 of its own value; the cold solve's against the oracle fixture is test_full_batch_parity's)
+    err = np.abs(patient["obj"] - cold["obj"]) / np.maximum(1.0, np.abs(cold["obj"]))
+    assert err.max() <= 1e-6, err.max()
+    inside = plain["iters"] < pat - 64
+    assert inside.any() and np.array_equal(patient["obj"][inside], plain["obj"][inside]) and np.array_equal(patient["iters"][inside], plain["iters"][inside])
+    beyond = ~inside
+    assert beyond.sum() >= 4, "the bad start did not slow anything down: no test"
+    assert patient["iters"].max() <= pat + 1.5 * cold["iters"].max(), (patient["iters"].max(), cold["iters"].max())
+    # with patience 0 and no start the option changes nothing
+    again = solve(pat)
+    assert np.array_equal(again["obj"], cold["obj"]) and np.array_equal(again["iters"], cold["iters"])
+    print(f"\n[patience] cold: mean {cold['iters'].mean():.0f} max {cold['iters'].max()}; bad start: mean {plain['iters'].mean():.0f} max {plain['iters'].max()} "
+          f"({int((plain['status'] != 0).sum())} not optimal); with patience {pat}: mean {patient['iters'].mean():.0f} max {patient['iters'].max()}, {int(beyond.sum())} restarted, worst error {err.max():.2e}")
