@@ -184,8 +184,8 @@ def test_full_year_double_loop_8192_plants_against_the_oracle():
          interior point of the optimal face instead of a vertex, moves 60 days of revenue by 9e-4 (tests/test_rolling_cpu.py::
          test_two_optimal_trajectories_of_the_same_loop_drift_apart).  Measured for the GPU loop (profiles/r60c_rolling_tests.log):
          3426 of 5856 plant-days agree to 1e-6, annual revenue within 1.2e-3, delivered energy within 4.5e-5 with every hourly LP solved
-         from the slack basis; 2675 plant-days, 2.7e-3 and 1.3e-4 with the simplex started from the previous hour's basis (another sequence
-         of optimal vertices; `r67a_rolling_tests.log`).  The test reports the agreeing days and requires the annual totals within 6e-3 /
+         from the slack basis; 2793 plant-days, 4.1e-3 and 1.4e-4 with the simplex started from the previous hour's basis and the day-ahead solve from
+         yesterday's shifted solution (other sequences of optimal points; `profiles/r69a_rolling_tests.log`).  The test reports the agreeing days and requires the annual totals within 6e-3 /
          5e-4: a check of the aggregate, the parity claim is check 1."""
     import multiprocessing as mp
     import os
