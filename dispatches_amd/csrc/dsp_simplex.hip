@@ -675,8 +675,11 @@ __global__ void __launch_bounds__(64, 2) simplex_reg_kernel(SimplexArgs a) {
     bool p1_priced_out = false;        // phase 1 ended because no column prices in (the only phase-1 stop that proves infeasibility)
     bool phase1 = false;
 
+    int refines = 0;
+    bool tight = false;                // (see the LDS-tableau kernel: refinement of an optimal vertex' basic values)
+  pivot:
     for (int it = 0;; ++it) {
-      const double ptol = a.tol_p * (1.0 + fmax(fabs(finite_or_zero(blo)), fabs(finite_or_zero(bhi))));
+      const double ptol = (tight ? 1e-3 : 1.0) * a.tol_p * (1.0 + fmax(fabs(finite_or_zero(blo)), fabs(finite_or_zero(bhi))));
       const bool below = lane < m && beta < blo - ptol;
       const bool above = lane < m && beta > bhi + ptol;
       phase1 = __ballot(below || above) != 0ull;
@@ -805,6 +808,62 @@ __global__ void __launch_bounds__(64, 2) simplex_reg_kernel(SimplexArgs a) {
         for (int q = 0; q < CQ; ++q) T[i][q] = (i == r) ? prow[q] : fma(-ai, prow[q], T[i][q]);
       }
       ++pivots;
+    }
+
+    // ---- refinement of an optimal vertex' basic values (as in the LDS-tableau kernel): residual of the original rows, correction by
+    // B^-1 = the slack COLUMNS of the tableau, which here are the registers of lanes n .. N - 1 -----------------------------------------
+    if (status == DSP_STATUS_OPTIMAL && refines < 2) {
+      ++refines;
+#pragma unroll
+      for (int q = 0; q < CQ; ++q) { const int j = lane + 64 * q; if (j < N) xval[j] = val[q]; }
+      wave_lds_fence();
+      if (lane < m) xval[bvar] = beta;
+      wave_lds_fence();
+      double xr[CQ];
+#pragma unroll
+      for (int q = 0; q < CQ; ++q) { const int j = lane + 64 * q; xr[q] = (j < N) ? xval[j] : 0.0; }
+      double res = 0.0;
+      for (int i0 = 0; i0 < m; i0 += 4) {
+        double part[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int i = i0 + u;
+          if (i < m) {
+#pragma unroll
+            for (int q = 0; q < CQ; ++q) { const int j = lane + 64 * q; if (j < n) part[u] = fma(a.A_dense[(size_t)i * n + j], xr[q], part[u]); }
+          }
+        }
+        wave_sums<4>(part);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) if (lane == i0 + u) res = part[u] - xval[n + lane];
+      }
+      wave_lds_fence();
+      if (lane < m) xval[n + lane] = res;                       // residual of row i where column n + i's lane finds it
+      wave_lds_fence();
+      double rj[CQ];
+#pragma unroll
+      for (int q = 0; q < CQ; ++q) { const int j = lane + 64 * q; rj[q] = (j >= n && j < N) ? xval[j] : 0.0; }
+#pragma unroll
+      for (int i0 = 0; i0 < MR; i0 += 4) {
+        double part[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          double t = 0.0;
+#pragma unroll
+          for (int q = 0; q < CQ; ++q) t = fma(T[i0 + u][q], rj[q], t);
+          part[u] = t;
+        }
+        wave_sums<4>(part);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) if (lane == i0 + u && lane < m) beta += part[u];
+      }
+      wave_lds_fence();
+      bool out = false;
+      if (lane < m) {
+        const double tt = 1e-3 * a.tol_p * (1.0 + fmax(fabs(finite_or_zero(blo)), fabs(finite_or_zero(bhi))));
+        out = beta < blo - tt || beta > bhi + tt;
+      }
+      if (__ballot(out) != 0ull) { tight = true; status = -1; goto pivot; }
     }
 
     // ---- assemble the vertex, certify it against the original rows, store -----------------------------------------------
