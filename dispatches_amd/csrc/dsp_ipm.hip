@@ -11,10 +11,13 @@
 //                                                                     fixed columns / equality rows simply carry Theta = 0)
 //     (A_s Theta_s A_s' + Theta_r) dy = rhs    banded LDL' (no pivoting; relative diagonal regularisation 1e-12), half-bandwidth W <= 8
 //     wide columns (span > 16 rows: design variables, periodic conditions; K <= 4) through Sherman-Morrison-Woodbury, K x K per scenario
-//     iterative refinement on the full normal equations: to 1e-8 of the right-hand side (max norms), to 1e-11 once a scenario is in its end
-//     game (within four decades of its objective tolerance), three steps at most
+//     iterative refinement on the full normal equations where the solve leaves more than 1e-6 of the right-hand side (max norms; it rarely
+//     does), three steps at most.  A step after which the primal residual JUMPS (1000 x its best so far and past the tolerance: the solve
+//     error of a near-unit step while mu collapses) is TAKEN BACK (k_ipm_undo: the directions are still in place) and the scenario goes on
+//     with its systems refined to 1e-8 / 1e-11 (far out / in its end game: round 5's tolerances for everybody, 2.4 extra solves per Newton
+//     iteration; profiles/r70*_reftol.log)
 //     steps 0.99 to the boundary (0.9 where the boundary is closer than half the Newton step: round 6, the slow members' hundred blocked
-//     steps get fewer), sigma = max((mu_aff / mu)^3, 0.05): the settings (with the end-game refinement) under which every horizon, family
+//     steps get fewer), sigma = max((mu_aff / mu)^3, 0.05): the settings under which every horizon, family
 //     and elimination order tried finishes (profiles/HISTORY.md "Robustness, measured": mu must not collapse under the solve error)
 // ONE LANE PER SCENARIO: every array is scenario-minor ([index][scenario], 64 scenarios = one 512-byte line per index), all lanes walk the
 // same rows, and the structure (ELLs of the scaled matrix, the band's product lists) is read through uniform addresses.
@@ -76,7 +79,7 @@ struct IpmPlan {                            // shared by all scenarios (device)
 };
 
 // per-lane scalars
-enum { SC_MU = 0, SC_SIGMU, SC_AP, SC_AD, SC_CS, SC_NB, SC_APA, SC_ADA, SC_POBJ, SC_RPMIN, SC_COUNT };
+enum { SC_MU = 0, SC_SIGMU, SC_AP, SC_AD, SC_CS, SC_NB, SC_APA, SC_ADA, SC_POBJ, SC_RPMIN, SC_STRICT, SC_UNDO, SC_COUNT };
 
 struct IpmWork {
   size_t Bp;                                // lanes (batch rounded up to 64): the stride of every scenario-minor array
@@ -100,7 +103,7 @@ struct IpmWork {
   int *iters;                               // [Bp]
   int *stall;                               // [Bp] consecutive Newton iterations with a step below 1e-4
   int *endg;                                // [Bp] 1 = the scenario is in its end game (k_ipm_decide): its Newton systems are refined further
-  int *counts;                              // [4]: finished (solved or given up), solved, lanes in the end game
+  int *counts;                              // [8]: finished (solved or given up), solved, lanes in the end game, (refinement flag), steps to take back
   int ls;                                   // the walks and the reduced solve split a lane group over this many workgroups (1, 2, 4): a workgroup pulls
                                             //  ~35 - 50 GB/s from HBM whatever it asks for, and ONE lane group's walk is 64 of them on 256 CUs; the lanes of
                                             //  a wave then work in duplicate (64 / ls distinct scenarios: same addresses, same values - the loads coalesce)
@@ -120,6 +123,8 @@ struct IpmArgs {
   double step_blocked, step_thr;            // (k_ipm_steps)
   double reg, step, sigmin;                 // primal regularisation of Theta (0: off), step to the boundary (0.99), floor of sigma (0.05); ipm_run
   double thcap;                             // cap of Theta (k_ipm_resid)
+  double reftol_strict, reftol_strict_end;  // the tolerances of a scenario whose step was taken back (k_ipm_decide: SC_STRICT)
+  int max_undo;                             // steps a scenario may take back before it is given up warm (state 5)
 };
 
 struct IpmState {
@@ -219,7 +224,7 @@ __global__ __launch_bounds__(64 * kFinW) void k_ipm_cmax_finish(IpmArgs a) {
   const size_t s = (size_t)blockIdx.x * 64 + (threadIdx.x & 63), Bp = a.w.Bp;
   double mx[1];
   ipm_finish<1, 2, kFinW>(a.w.part, a.w.nch / 4, Bp, s, mx);
-  if (threadIdx.x < 64 && a.w.state[s] == 0) { a.w.sc[SC_CS * Bp + s] = mx[0] > 1e-300 ? mx[0] : 1.0; a.w.sc[SC_RPMIN * Bp + s] = 1e300; }
+  if (threadIdx.x < 64 && a.w.state[s] == 0) { a.w.sc[SC_CS * Bp + s] = mx[0] > 1e-300 ? mx[0] : 1.0; a.w.sc[SC_RPMIN * Bp + s] = 1e300; a.w.sc[SC_STRICT * Bp + s] = 0.0; a.w.sc[SC_UNDO * Bp + s] = 0.0; }
 }
 
 __global__ __launch_bounds__(256) void k_ipm_setup(IpmArgs a) {
@@ -939,7 +944,9 @@ __global__ __launch_bounds__(64 * kFinW) void k_ipm_resflag(IpmArgs a, double to
   double t[2];
   ipm_finish<2, 2, kFinW>(a.w.part, a.w.nch / 4, Bp, s, t);
   if (threadIdx.x >= 64 || a.w.state[s] != 0) return;
-  if (!(t[0] <= (a.w.endg[s] ? a.reftol_end : tol) * t[1])) atomicAdd(a.w.counts + 3, 1);
+  const bool strict = a.w.sc[SC_STRICT * Bp + s] > 0.0;
+  const double lim = a.w.endg[s] ? (strict ? a.reftol_strict_end : a.reftol_end) : (strict ? a.reftol_strict : tol);
+  if (!(t[0] <= lim * t[1])) atomicAdd(a.w.counts + 3, 1);
 }
 
 // dv, dz, df from dy; partial minima of the step lengths
@@ -1031,6 +1038,30 @@ __global__ __launch_bounds__(256) void k_ipm_update(IpmArgs a) {
   for (int i = i0; i < i1; ++i) a.w.y[(size_t)i * Bp + s] += ad * a.w.dy[(size_t)i * Bp + s];
 }
 
+// A step that polluted the primal residual (k_ipm_decide) is taken back: the directions and step lengths of the iteration are still in
+// place, and the scenario's next Newton systems are refined to the strict tolerances.  Launched only when some lane asked for it.
+__global__ __launch_bounds__(256) void k_ipm_undo(IpmArgs a) {
+  IPM_LANE();
+  if (!(a.w.sc[SC_UNDO * Bp + s] > 0.0)) return;
+  const int N = a.P.n + a.P.m;
+  const double ap = a.w.sc[SC_AP * Bp + s], ad = a.w.sc[SC_AD * Bp + s];
+  int j0, j1; ipm_chunk(N, a.w.nch, cid, j0, j1);
+#pragma unroll 2
+  for (int j = j0; j < j1; ++j) {
+    const size_t at = (size_t)j * Bp + s;
+    if (!(a.w.th[at] > 0.0)) continue;
+    a.w.v[at] -= ap * a.w.dv[at];
+    a.w.z[at] -= ad * a.w.dz[at];
+    a.w.f[at] -= ad * a.w.df[at];
+  }
+  int i0, i1; ipm_chunk(a.P.m, a.w.nch, cid, i0, i1);
+  for (int i = i0; i < i1; ++i) a.w.y[(size_t)i * Bp + s] -= ad * a.w.dy[(size_t)i * Bp + s];
+}
+__global__ void k_ipm_undone(IpmArgs a) {
+  const size_t s = (size_t)blockIdx.x * 64 + threadIdx.x;
+  a.w.sc[SC_UNDO * a.w.Bp + s] = 0.0;
+}
+
 // ---- termination: the HBM-resident path's KKT test on the unscaled problem (control_decide, dsp_stream.hpp) ------------------------------
 __global__ __launch_bounds__(256) void k_ipm_check(IpmArgs a) {
   IPM_LANE();
@@ -1105,7 +1136,17 @@ __global__ __launch_bounds__(64 * kFinW) void k_ipm_decide(IpmArgs a) {
   a.w.stall[s] = stalled;
   const double bound = gap + cs * (q[1] + q[4]), lim1 = fmax(o.eps_obj * (1.0 + fabs(po + c.c0)), 1e-300);
   int state = 0;
+  // a polluted step is taken back (k_ipm_undo) and the scenario goes on under the strict refinement tolerances - a.max_undo times
+  // (seen at once, not only in the end game: rp falls monotonically on this method's path; a jump of 1000 x past the tolerance is the pollution)
+  const bool jumped = rp > 30.0 * o.eps_rel && rp > 1e3 * rpm;
+  const bool undo = !fin && finite && !broken && jumped && !limit && a.w.sc[SC_STRICT * Bp + s] < (double)a.max_undo;
+  if (undo) {
+    a.w.sc[SC_STRICT * Bp + s] += 1.0;
+    a.w.sc[SC_UNDO * Bp + s] = 1.0;
+    atomicAdd(a.w.counts + 4, 1);
+  }
   if (fin) state = 1;
+  else if (undo) state = 0;
   else if (finite && !broken && (polluted || limit)) state = 5;                   // given up warm
   else if (broken || limit || stalled >= 12) state = 2;                          // given up: the PDHG forms take the scenario from their own start
   if (state == 1) a.w.sc[SC_POBJ * Bp + s] = po;
@@ -1314,7 +1355,7 @@ hipError_t ipm_create(const HostCSR &A, const HostCSR &AT, StreamSolver *S) {
     delete I;
     return e;
   }
-  if ((e = hipHostMalloc((void **)&I->counts_host, 4 * sizeof(int))) != hipSuccess) { for (void *p : I->allocs) (void)hipFree(p); delete I; return e; }
+  if ((e = hipHostMalloc((void **)&I->counts_host, 8 * sizeof(int))) != hipSuccess) { for (void *p : I->allocs) (void)hipFree(p); delete I; return e; }
   S->ipm = I;
   return hipSuccess;
 }
@@ -1378,7 +1419,7 @@ static hipError_t ipm_workspace(IpmState *I, int B) {
   I->work_allocs.push_back(w.stall);
   if ((e = hipMalloc((void **)&w.endg, w.Bp * sizeof(int))) != hipSuccess) return e;
   I->work_allocs.push_back(w.endg);
-  if ((e = hipMalloc((void **)&w.counts, 4 * sizeof(int))) != hipSuccess) return e;
+  if ((e = hipMalloc((void **)&w.counts, 8 * sizeof(int))) != hipSuccess) return e;
   I->work_allocs.push_back(w.counts);
   if ((e = hipMalloc((void **)&w.sid, w.Bp * sizeof(int))) != hipSuccess) return e;
   I->work_allocs.push_back(w.sid);
@@ -1475,7 +1516,7 @@ static hipError_t ipm_bsolve(const IpmArgs &a, double *x, hipStream_t st) {
 }
 
 // dy = (A Theta A')^-1 rhs (a.w.q holds the right-hand side on entry and is overwritten); iterative refinement on the full normal
-// equations while some scenario's residual is above 1e-8 of its right-hand side (max norms) (at most 3 steps); returns the steps taken
+// equations while some scenario's residual is above ITS tolerance (k_ipm_resflag; max norms) (at most 3 steps); returns the steps taken
 template <int W>
 static hipError_t ipm_nsolve(StreamSolver *S, const IpmArgs &a, hipStream_t st, int *steps) {
   const dim3 blk(256), grid((unsigned)(a.w.nch / 4), (unsigned)a.w.G), lanes((unsigned)a.w.G);
@@ -1585,17 +1626,17 @@ static hipError_t ipm_loop(StreamSolver *S, IpmArgs &a, hipStream_t st, bool *al
   // DSP_IPM_COMPACT=0: every scenario keeps its lane to the end of the solve (measurement); groups of more than 1024 lanes: not packed
   const bool compact = !(getenv("DSP_IPM_COMPACT") && atoi(getenv("DSP_IPM_COMPACT")) == 0) && a.w.Bp <= 1024;
   int repacks = 0;
-  static const int trace = getenv("DSP_IPM_TRACE") ? atoi(getenv("DSP_IPM_TRACE")) : 0;
+  const int trace = getenv("DSP_IPM_TRACE") ? atoi(getenv("DSP_IPM_TRACE")) : 0;      // (development; read at every solve: tests switch it on)
   g_ipm_debug = getenv("DSP_IPM_DEBUG") ? atoi(getenv("DSP_IPM_DEBUG")) : 0;
   hipError_t e;
-  if ((e = hipMemsetAsync(a.w.counts, 0, 4 * sizeof(int), st)) != hipSuccess) return e;
+  if ((e = hipMemsetAsync(a.w.counts, 0, 8 * sizeof(int), st)) != hipSuccess) return e;
   hipLaunchKernelGGL(k_ipm_begin, lanes, dim3(64), 0, st, a, 0);
   hipLaunchKernelGGL(k_ipm_cmax, grid, blk, 0, st, a);
   hipLaunchKernelGGL(k_ipm_cmax_finish, lanes, dim3(64 * kFinW), 0, st, a);
   hipLaunchKernelGGL(k_ipm_setup, grid, blk, 0, st, a);
   hipLaunchKernelGGL(k_ipm_begin, lanes, dim3(64), 0, st, a, 1);
   IPM_DBG("setup");
-  int refine = 0, it = 0;
+  int refine = 0, it = 0, undone = 0;
   int lanes_total = (int)a.w.Bp;
   for (it = 1; it <= a.max_it; ++it) {
     a.it = it;
@@ -1663,14 +1704,20 @@ static hipError_t ipm_loop(StreamSolver *S, IpmArgs &a, hipStream_t st, bool *al
     IPM_DBG("direction");
     hipLaunchKernelGGL(k_ipm_update, grid, blk, 0, st, a);
     IPM_DBG("update");
-    if ((e = hipMemsetAsync(a.w.counts + 2, 0, 2 * sizeof(int), st)) != hipSuccess) return e;
+    if ((e = hipMemsetAsync(a.w.counts + 2, 0, 3 * sizeof(int), st)) != hipSuccess) return e;
     if (a.P.K > 0) { hipLaunchKernelGGL(k_ipm_wide_aty, grid, blk, 0, st, a, (const double *)a.w.y); hipLaunchKernelGGL(k_ipm_wide_aty_finish, lanes, dim3(64 * kFinW), 0, st, a); }
     hipLaunchKernelGGL(k_ipm_check, grid, blk, 0, st, a);
     IPM_DBG("check");
     hipLaunchKernelGGL(k_ipm_decide, lanes, dim3(64 * kFinW), 0, st, a);
     IPM_DBG("decide");
-    if ((e = hipMemcpyAsync(I->counts_host, a.w.counts, 4 * sizeof(int), hipMemcpyDeviceToHost, st)) != hipSuccess) return e;
+    if ((e = hipMemcpyAsync(I->counts_host, a.w.counts, 5 * sizeof(int), hipMemcpyDeviceToHost, st)) != hipSuccess) return e;
     if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;
+    if (I->counts_host[4] > 0) {                        // steps taken back (k_ipm_decide)
+      hipLaunchKernelGGL(k_ipm_undo, grid, blk, 0, st, a);
+      hipLaunchKernelGGL(k_ipm_undone, lanes, dim3(64), 0, st, a);
+      undone += I->counts_host[4];
+      if (trace) fprintf(stderr, "[ipm] it %d: %d step(s) taken back\n", it, I->counts_host[4]);
+    }
     if (trace) {
       double sc[SC_COUNT];
       for (int q = 0; q < SC_COUNT; ++q) (void)hipMemcpy(&sc[q], a.w.sc + (size_t)q * a.w.Bp + (trace - 1), sizeof(double), hipMemcpyDeviceToHost);
@@ -1699,6 +1746,7 @@ static hipError_t ipm_loop(StreamSolver *S, IpmArgs &a, hipStream_t st, bool *al
     std::vector<int> hs(a.w.Bp), hi(a.w.Bp);
     (void)hipMemcpy(hs.data(), a.w.state, a.w.Bp * sizeof(int), hipMemcpyDeviceToHost);
     (void)hipMemcpy(hi.data(), a.w.iters, a.w.Bp * sizeof(int), hipMemcpyDeviceToHost);
+    fprintf(stderr, "[ipm] steps taken back: %d\n", undone);
     fprintf(stderr, "[ipm] lanes (state:newton iterations):");
     for (int q = 0; q < a.w.B; ++q) fprintf(stderr, " %d:%d", hs[q], hi[q]);
     fprintf(stderr, "\n");
@@ -1729,8 +1777,10 @@ hipError_t ipm_run(StreamSolver *S, StreamArgs &sa, hipStream_t st, bool *all_so
   a.step_thr = getenv("DSP_IPM_STEP_THR") ? atof(getenv("DSP_IPM_STEP_THR")) : 0.5;      // (sweep: profiles/r69a_ipm_step_sweep.log)
   a.sigmin = getenv("DSP_IPM_SIGMIN") ? atof(getenv("DSP_IPM_SIGMIN")) : 0.05;
   a.thcap = getenv("DSP_IPM_THCAP") ? atof(getenv("DSP_IPM_THCAP")) : 1e11;
-  a.reftol = getenv("DSP_IPM_REFTOL") ? atof(getenv("DSP_IPM_REFTOL")) : 1e-8;
-  a.reftol_end = getenv("DSP_IPM_REFTOL_END") ? atof(getenv("DSP_IPM_REFTOL_END")) : 1e-11;
+  a.reftol = getenv("DSP_IPM_REFTOL") ? atof(getenv("DSP_IPM_REFTOL")) : 1e-6;
+  a.reftol_end = getenv("DSP_IPM_REFTOL_END") ? atof(getenv("DSP_IPM_REFTOL_END")) : 1e-6;
+  a.reftol_strict = 1e-8; a.reftol_strict_end = 1e-11;
+  a.max_undo = getenv("DSP_IPM_MAX_UNDO") ? atoi(getenv("DSP_IPM_MAX_UNDO")) : 3;
   return I->P.W == 6 ? ipm_loop<6>(S, a, st, all_solved, newton, n_solved) : ipm_loop<8>(S, a, st, all_solved, newton, n_solved);
 }
 

@@ -122,12 +122,17 @@ def test_year_long_price_taker_lps_by_interior_point(B):
 
 
 @gpu
-def test_year_long_batch_of_256_distinct_lps():
+@pytest.mark.parametrize("knobs", [{}, {"DSP_IPM_REFTOL_END": "1e-7", "DSP_IPM_TRACE": "1"}], ids=["default", "steps_taken_back"])
+def test_year_long_batch_of_256_distinct_lps(knobs, monkeypatch, capfd):
     """BASELINE.md's "256 year-long LPs" as 256 DISTINCT members (scenarios.PRICE_TAKER_FAMILY_WIDE: the 16 members of the round-4
     fixture + 15 LMP multipliers x 16 battery capital-cost factors; round 5 ran the 16-member family 16 times over): all optimal by the
     interior-point form, 76 of them against the HiGHS fixture of the oracle's un-reduced LP (members 0 - 15 and every fourth one from 16
-    on: tools/make_price_taker_fixtures.py --wide) to 1e-6, the optimal battery size within the reference test's tolerance."""
+    on: tools/make_price_taker_fixtures.py --wide) to 1e-6, the optimal battery size within the reference test's tolerance.
+    Second case: under an end-game refinement tolerance of 1e-7 eleven members used to be handed to the PDHG forms with a polluted primal
+    residual (profiles/r70b_reftol.log: 21.9 s); the steps that pollute it are taken back (k_ipm_undo) and all 256 stay with this form."""
     _need_gpu()
+    for k, v in knobs.items():
+        monkeypatch.setenv(k, v)
     import time
     from dispatches_amd import scenarios
     from dispatches_amd.hip_solver import HipPdlpSolver
@@ -141,6 +146,10 @@ def test_year_long_batch_of_256_distinct_lps():
     wall = time.perf_counter() - t0
     st = solver.last_stats
     assert st.stream_form == FORM_IPM and st.ipm_solved == B and (model.status == 0).all(), (st.stream_form, st.ipm_solved, np.bincount(model.status))
+    if knobs:
+        import re
+        back = [int(n) for n in re.findall(r"steps taken back: (\d+)", capfd.readouterr().err)]
+        assert back and back[-1] >= 1, back
     ks = np.concatenate([np.arange(16), fx["T8736w/k"]])
     ref = np.concatenate([fx["T8736/obj"], fx["T8736w/obj"]])
     batt_ref = np.concatenate([fx["T8736/batt_mw"], fx["T8736w/batt_mw"]])
