@@ -1518,11 +1518,11 @@ static hipError_t ipm_bsolve(const IpmArgs &a, double *x, hipStream_t st) {
 // dy = (A Theta A')^-1 rhs (a.w.q holds the right-hand side on entry and is overwritten); iterative refinement on the full normal
 // equations while some scenario's residual is above ITS tolerance (k_ipm_resflag; max norms) (at most 3 steps); returns the steps taken
 template <int W>
-static hipError_t ipm_nsolve(StreamSolver *S, const IpmArgs &a, hipStream_t st, int *steps) {
+static hipError_t ipm_nsolve(StreamSolver *S, const IpmArgs &a, hipStream_t st, int *steps, bool check = true) {
   const dim3 blk(256), grid((unsigned)(a.w.nch / 4), (unsigned)a.w.G), lanes((unsigned)a.w.G);
   hipError_t e;
   *steps = 0;
-  for (int r = 0; r <= 3; ++r) {
+  for (int r = 0; r <= (check ? 3 : 0); ++r) {
     if (r > 0) {
       if (a.P.K > 0) { hipLaunchKernelGGL(k_ipm_wide_aty, grid, blk, 0, st, a, (const double *)a.w.dy); hipLaunchKernelGGL(k_ipm_wide_aty_finish, lanes, dim3(64 * kFinW), 0, st, a); }
       hipLaunchKernelGGL(k_ipm_ref_cols, grid, blk, 0, st, a);
@@ -1637,6 +1637,9 @@ static hipError_t ipm_loop(StreamSolver *S, IpmArgs &a, hipStream_t st, bool *al
   hipLaunchKernelGGL(k_ipm_begin, lanes, dim3(64), 0, st, a, 1);
   IPM_DBG("setup");
   int refine = 0, it = 0, undone = 0;
+  // the predictor's system (it only sets sigma and the second-order terms) is checked / refined once some scenario runs under the strict
+  // tolerances, not before: its check is 3 - 4 % of the solve and has never asked for a step (profiles/r70i_check_pred.log)
+  const int check_pred_env = getenv("DSP_IPM_CHECK_PRED") ? atoi(getenv("DSP_IPM_CHECK_PRED")) : -1;
   int lanes_total = (int)a.w.Bp;
   for (it = 1; it <= a.max_it; ++it) {
     a.it = it;
@@ -1674,7 +1677,7 @@ static hipError_t ipm_loop(StreamSolver *S, IpmArgs &a, hipStream_t st, bool *al
       hipLaunchKernelGGL(k_ipm_rt, grid, blk, 0, st, a, mode);
       hipLaunchKernelGGL(k_ipm_rhs, grid, blk, 0, st, a);
       IPM_DBG("rhs");
-      { int steps = 0; if ((e = ipm_nsolve<W>(S, a, st, &steps)) != hipSuccess) return e; refine = std::max(refine, steps); }
+      { int steps = 0; if ((e = ipm_nsolve<W>(S, a, st, &steps, mode == 1 || (check_pred_env >= 0 ? check_pred_env != 0 : undone > 0))) != hipSuccess) return e; refine = std::max(refine, steps); }
       IPM_DBG("nsolve");
       if (it == 1 && trace && mode == 0) {
         ipm_dump("rhs", a.w.rhs, a.P.m, a.w.Bp, trace - 1, st); ipm_dump("dy", a.w.dy, a.P.m, a.w.Bp, trace - 1, st);
