@@ -312,7 +312,8 @@ __global__ __launch_bounds__(256) void k_ipm_resid(IpmArgs a) {
     const size_t at = (size_t)j * Bp + s;
     const double l = a.w.l[at], u = a.w.u[at], v = a.w.v[at], z = a.w.z[at], f = a.w.f[at];
     const bool hl = ipm_fin(l), hu = ipm_fin(u), fixed = hl && hu && l == u;
-    a.w.rd[at] = a.w.cb[at] - ipm_aty(a.P, a.w.y, a.w.wat, j, Bp, s) - z + f;
+    const double rd = a.w.cb[at] - ipm_aty(a.P, a.w.y, a.w.wat, j, Bp, s) - z + f;
+    a.w.rd[at] = rd;
     double th = 0.0;
     if (!fixed) {
       double den = 0.0;
@@ -329,6 +330,11 @@ __global__ __launch_bounds__(256) void k_ipm_resid(IpmArgs a) {
       th = fmin(th, 1e30);
     }
     a.w.th[at] = th;
+    // the predictor's rt / tn (k_ipm_rt's mode 0: targets cz = -z, cf = -f) while everything is in registers: seven array reads less
+    const double cz = (hl && th > 0.0) ? 0.0 / (v - l) - z : 0.0, cf = (hu && th > 0.0) ? 0.0 / (u - v) - f : 0.0;
+    const double rt = rd - cz + cf;
+    a.w.rt[at] = rt;
+    a.w.tn[at] = th * rt;
   }
   ipm_put<0>(a, 0, comp, s);
   ipm_put<0>(a, 1, cnt, s);
@@ -954,7 +960,7 @@ __global__ __launch_bounds__(256) void k_ipm_dir(IpmArgs a, int mode) {
   IPM_LANE();
   const int N = a.P.n + a.P.m;
   int j0, j1; ipm_chunk(N, a.w.nch, cid, j0, j1);
-  double ap = 1e300, ad = 1e300;
+  double ap = 1e300, ad = 1e300, q1 = 0.0, q2 = 0.0, q3 = 0.0;
 #pragma unroll 2
   for (int j = j0; j < j1; ++j) {
     const size_t at = (size_t)j * Bp + s;
@@ -966,7 +972,19 @@ __global__ __launch_bounds__(256) void k_ipm_dir(IpmArgs a, int mode) {
     const double dv = th * (ipm_aty(a.P, a.w.dy, a.w.wat, j, Bp, s) - a.w.rt[at]);
     const double dz = hl ? cz - z / wl * dv : 0.0;
     const double df = hu ? cf + f / tu * dv : 0.0;
-    a.w.dv[at] = dv; a.w.dz[at] = dz; a.w.df[at] = df;
+    if (mode == 0) {
+      // the predictor's direction is used for two things only: mu after the affine step - a bilinear form in the two step lengths,
+      //   sum (z + ad dz)(w + ap dv) + sum (f + ad df)(t - ap dv) = mu nb + ap q1 + ad q2 + ap ad q3,
+      // so its three sums are taken HERE, before the step lengths exist (k_ipm_steps finishes them into sigma) - and the second-order
+      // terms of the corrector.  Nothing reads the predictor's dv / dz / df afterwards: they are not stored (round 6: the separate
+      // k_ipm_muaff pass read nine arrays to do this)
+      if (hl) { q1 += z * dv; q2 += wl * dz; q3 += dz * dv; }
+      if (hu) { q1 -= f * dv; q2 += tu * df; q3 -= df * dv; }
+      a.w.corl[at] = dv * dz;
+      a.w.coru[at] = -dv * df;
+    } else {
+      a.w.dv[at] = dv; a.w.dz[at] = dz; a.w.df[at] = df;
+    }
     if (hl && dv < 0.0) ap = fmin(ap, -wl / dv);
     if (hu && dv > 0.0) ap = fmin(ap, tu / dv);
     if (hl && dz < 0.0) ad = fmin(ad, -z / dz);
@@ -974,51 +992,34 @@ __global__ __launch_bounds__(256) void k_ipm_dir(IpmArgs a, int mode) {
   }
   ipm_put<1>(a, 0, ap, s);
   ipm_put<1>(a, 1, ad, s);
+  if (mode == 0) {
+    ipm_put<0>(a, 2, q1, s);
+    ipm_put<0>(a, 3, q2, s);
+    ipm_put<0>(a, 4, q3, s);
+  }
 }
 
 __global__ __launch_bounds__(64 * kFinW) void k_ipm_steps(IpmArgs a, int mode) {
   const size_t s = (size_t)blockIdx.x * 64 + (threadIdx.x & 63), Bp = a.w.Bp;
   double t[2];
   ipm_finish<2, 1, kFinW>(a.w.part, a.w.nch / 4, Bp, s, t);
+  double q[3] = {0.0, 0.0, 0.0};
+  if (mode == 0) ipm_finish<3, 0, kFinW>(a.w.part + (size_t)2 * (a.w.nch / 4) * Bp, a.w.nch / 4, Bp, s, q);      // (uniform branch: every thread of the block)
   if (threadIdx.x >= 64 || a.w.state[s] != 0) return;
-  if (mode == 0) { a.w.sc[SC_APA * Bp + s] = fmin(t[0], 1.0); a.w.sc[SC_ADA * Bp + s] = fmin(t[1], 1.0); }
-  else {
+  if (mode == 0) {
+    const double apa = fmin(t[0], 1.0), ada = fmin(t[1], 1.0);
+    a.w.sc[SC_APA * Bp + s] = apa; a.w.sc[SC_ADA * Bp + s] = ada;
+    // sigma from mu after the affine step (k_ipm_dir's three sums; the cancellation as both steps approach 1 is 1e-16 of mu: sigma has a floor)
+    const double mu = a.w.sc[SC_MU * Bp + s], nb = fmax(a.w.sc[SC_NB * Bp + s], 1.0);
+    const double mu_aff = fmax((mu * a.w.sc[SC_NB * Bp + s] + apa * q[0] + ada * q[1] + apa * ada * q[2]) / nb, 0.0);
+    const double r = mu > 0.0 ? mu_aff / mu : 1.0;
+    a.w.sc[SC_SIGMU * Bp + s] = fmin(fmax(r * r * r, a.sigmin), 1.0) * mu;
+  } else {
     // fraction of the way to the boundary: a.step (0.99) for a long step, a.step_blocked where the boundary is closer than a.step_thr of the
     // Newton step - the slow members of the wind + battery family take a hundred such steps, and staying further inside shortens that phase
     a.w.sc[SC_AP * Bp + s] = fmin(1.0, (t[0] < a.step_thr ? a.step_blocked : a.step) * t[0]);
     a.w.sc[SC_AD * Bp + s] = fmin(1.0, (t[1] < a.step_thr ? a.step_blocked : a.step) * t[1]);
   }
-}
-
-// mu of the affine step; the second-order terms of the corrector
-__global__ __launch_bounds__(256) void k_ipm_muaff(IpmArgs a) {
-  IPM_LANE();
-  const int N = a.P.n + a.P.m;
-  int j0, j1; ipm_chunk(N, a.w.nch, cid, j0, j1);
-  const double apa = a.w.sc[SC_APA * Bp + s], ada = a.w.sc[SC_ADA * Bp + s];
-  double comp = 0.0;
-#pragma unroll 2
-  for (int j = j0; j < j1; ++j) {
-    const size_t at = (size_t)j * Bp + s;
-    const double l = a.w.l[at], u = a.w.u[at], v = a.w.v[at], th = a.w.th[at];
-    const bool hl = ipm_fin(l) && th > 0.0, hu = ipm_fin(u) && th > 0.0;
-    const double dv = a.w.dv[at], dz = a.w.dz[at], df = a.w.df[at];
-    if (hl) comp += (a.w.z[at] + ada * dz) * (v - l + apa * dv);
-    if (hu) comp += (a.w.f[at] + ada * df) * (u - v - apa * dv);
-    a.w.corl[at] = dv * dz;
-    a.w.coru[at] = -dv * df;
-  }
-  ipm_put<0>(a, 0, comp, s);
-}
-
-__global__ __launch_bounds__(64 * kFinW) void k_ipm_sigma(IpmArgs a) {
-  const size_t s = (size_t)blockIdx.x * 64 + (threadIdx.x & 63), Bp = a.w.Bp;
-  double t[1];
-  ipm_finish<1, 0, kFinW>(a.w.part, a.w.nch / 4, Bp, s, t);
-  if (threadIdx.x >= 64 || a.w.state[s] != 0) return;
-  const double mu = a.w.sc[SC_MU * Bp + s], mu_aff = t[0] / fmax(a.w.sc[SC_NB * Bp + s], 1.0);
-  const double r = mu > 0.0 ? mu_aff / mu : 1.0;
-  a.w.sc[SC_SIGMU * Bp + s] = fmin(fmax(r * r * r, a.sigmin), 1.0) * mu;
 }
 
 __global__ __launch_bounds__(256) void k_ipm_update(IpmArgs a) {
@@ -1674,7 +1675,7 @@ static hipError_t ipm_loop(StreamSolver *S, IpmArgs &a, hipStream_t st, bool *al
       ipm_dump("sinv", a.w.sinv, (size_t)kIpmMaxK * kIpmMaxK, a.w.Bp, trace - 1, st);
     }
     for (int mode = 0; mode < 2; ++mode) {
-      hipLaunchKernelGGL(k_ipm_rt, grid, blk, 0, st, a, mode);
+      if (mode == 1) hipLaunchKernelGGL(k_ipm_rt, grid, blk, 0, st, a, mode);      // (mode 0: written by k_ipm_resid)
       hipLaunchKernelGGL(k_ipm_rhs, grid, blk, 0, st, a);
       IPM_DBG("rhs");
       { int steps = 0; if ((e = ipm_nsolve<W>(S, a, st, &steps, mode == 1 || (check_pred_env >= 0 ? check_pred_env != 0 : undone > 0))) != hipSuccess) return e; refine = std::max(refine, steps); }
@@ -1699,10 +1700,6 @@ static hipError_t ipm_loop(StreamSolver *S, IpmArgs &a, hipStream_t st, bool *al
       if (a.P.K > 0) { hipLaunchKernelGGL(k_ipm_wide_aty, grid, blk, 0, st, a, (const double *)a.w.dy); hipLaunchKernelGGL(k_ipm_wide_aty_finish, lanes, dim3(64 * kFinW), 0, st, a); }
       hipLaunchKernelGGL(k_ipm_dir, grid, blk, 0, st, a, mode);
       hipLaunchKernelGGL(k_ipm_steps, lanes, dim3(64 * kFinW), 0, st, a, mode);
-      if (mode == 0) {
-        hipLaunchKernelGGL(k_ipm_muaff, grid, blk, 0, st, a);
-        hipLaunchKernelGGL(k_ipm_sigma, lanes, dim3(64 * kFinW), 0, st, a);
-      }
     }
     IPM_DBG("direction");
     hipLaunchKernelGGL(k_ipm_update, grid, blk, 0, st, a);
