@@ -183,12 +183,26 @@ def bench_double_loop(args, rank, local_rank, world, dev):
     events = {d: torch.cuda.Event(enable_timing=True) for d in marks}
     da_stats = []                                   # per day, on the device: mean / max day-ahead iterations (no host sync inside the year)
     t0 = time.perf_counter()
-    for d in range(days):
-        if d in events:
-            events[d].record()
-        step()
-        it = loop.day_ahead_iterations().float()
-        da_stats.append(torch.stack([it.mean(), it.max()]))
+    free = world == 1 and G > 1 and not getattr(args, "join_days", False)
+    if free:
+        # one GPU: nothing is exchanged between the days, so the groups run FREE (PipelinedDoubleLoops.run_days: joined at the quarter
+        # marks only); the per-day statistics are taken per group, on its stream
+        gstats = [[] for _ in range(G)]
+
+        def per_day(g, l):
+            it = l.da.out["iters"].float()
+            gstats[g].append(torch.stack([it.sum(), it.max()]))
+        for a_, b_ in zip(marks[:-1], marks[1:]):
+            events[a_].record()
+            loop.run_days(b_ - a_, per_day)
+        da_stats = [torch.stack([sum(gs[d][0] for gs in gstats) / B, torch.stack([gs[d][1] for gs in gstats]).max()]) for d in range(days)]
+    else:
+        for d in range(days):
+            if d in events:
+                events[d].record()
+            step()
+            it = loop.day_ahead_iterations().float()
+            da_stats.append(torch.stack([it.mean(), it.max()]))
     events[days].record()
     torch.cuda.synchronize()
     if world > 1:
@@ -227,7 +241,7 @@ def bench_double_loop(args, rank, local_rank, world, dev):
                        "flowsheet": flowsheet,
                        "lp_solves_per_s": total * days * 49 / elapsed, "all_optimal": bool(okt.item()), "uncertified_solves": int(unc.item()),
                        "day_ahead_warm_start": bool(loop.warm_start),
-                       "groups_per_gpu": G,
+                       "groups_per_gpu": G, "groups_joined": "at the quarter marks" if free else "every day",
                        "day_ahead_iterations_last_day": {"mean": float(da_iters.mean().item()), "max": int(da_iters.max().item())},
                        "days": days, "year_measured": days >= 366, "lp_solves": total * days * 49,
                        "seconds_per_simulated_year": elapsed if days == 366 else 366 * elapsed / days,
@@ -940,6 +954,7 @@ def main():
     ap.add_argument("--groups", type=int, default=0,
                     help="--workload double_loop: the rank's plants as this many independent loops on as many HIP streams (their days overlap); "
                          "0 = automatic (2 from 1024 plants per rank on)")
+    ap.add_argument("--join-days", action="store_true", help="--workload double_loop on one GPU: join the groups after every simulated day instead of letting them run free")
     ap.add_argument("--no-configs", action="store_true", help="default line only: skip the `configs` array (the other BASELINE configs measured in the same run)")
     ap.add_argument("--no-sweep", action="store_true", help="--workload qp_sweep: the contract entry only, without the fp64 / fp32 tolerance ladder")
     ap.add_argument("--no-spmv", action="store_true", help="skip the streaming SpMV-step roofline measurement")

@@ -505,6 +505,33 @@ class PipelinedDoubleLoops:
         for s in self.streams:
             cur.wait_stream(s)
 
+    def run_days(self, n, per_day=None):
+        """`n` simulated days with the groups FREE-RUNNING: every group enqueues its days on its own stream and the groups are joined
+        once, at the end - `run_day` joins them after every day, so each day costs what its slowest group costs (the day-ahead solve
+        ends with its slowest plant: 9 - 27 k iterations at a mean of 2.2 k).  Plants do not interact; the results are those of
+        `run_day` bit for bit.  `per_day(g, loop)`, if given, is called after each day of group g inside that group's stream.
+        8192 plants, one MI355X, the whole year (profiles/r70o_year_free.log, r70p_year_groups_366.log): 2 groups 7.02 -> 6.86 s; 4 groups
+        are faster over 60 days (18.4 ms per day) and slower over the year (25 ms: ONE host thread feeds all streams, and once a
+        group's queue is full it waits on that group while the others run dry)."""
+        import torch
+        if self.groups == 1:
+            for _ in range(n):
+                self.loops[0].run_day()
+                if per_day is not None:
+                    per_day(0, self.loops[0])
+            return
+        cur = torch.cuda.current_stream(self.dev)
+        for s in self.streams:
+            s.wait_stream(cur)
+        for _ in range(n):
+            for g, (loop, s) in enumerate(zip(self.loops, self.streams)):
+                with torch.cuda.stream(s):
+                    loop.run_day()
+                    if per_day is not None:
+                        per_day(g, loop)
+        for s in self.streams:
+            cur.wait_stream(s)
+
     def reset(self):
         for l in self.loops:
             l.reset()
