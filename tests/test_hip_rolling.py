@@ -155,16 +155,21 @@ def test_pipelined_groups_reproduce_the_single_loop():
     one = BatchedWindBatteryDoubleLoop(n, device=0, first_scenario=5)
     two = PipelinedDoubleLoops(n, device=0, first_scenario=5, groups=2)
     assert two.groups == 2 and PipelinedDoubleLoops(8, device=0, groups=0).groups == 1
+    free = PipelinedDoubleLoops(n, device=0, first_scenario=5, groups=2)
+    seen = []
     for _ in range(days):
         one.run_day()
         two.run_day()
+    free.run_days(days, per_day=lambda g, l: seen.append(g))           # the groups free-running on their streams, joined once (bench.py's year)
     torch.cuda.synchronize()
     r1, ok1 = one.results()
     r2, ok2 = two.results()
-    assert ok1 and ok2
+    r3, ok3 = free.results()
+    assert ok1 and ok2 and ok3 and seen == [0, 1] * days
     for k in ("obj", "energy_mwh", "soc", "throughput"):
         assert torch.equal(r1[k], r2[k]), k
-    assert int(two.uncertified) == int(one.uncertified) == 0
+        assert torch.equal(r1[k], r3[k]), k
+    assert int(two.uncertified) == int(one.uncertified) == int(free.uncertified) == 0
 
 
 @gpu
