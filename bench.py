@@ -821,6 +821,8 @@ def baseline_configs(args, local_rank, dev, budget_s=360.0, depth=8):
         +  the HBM-bound streaming path: year-long price-taker design LPs, 256 scenarios, iteration rate over 50 check periods
     Entries are skipped (and say so) once `budget_s` seconds have gone, so that the whole command stays within a few minutes."""
     import copy
+    import gc
+    import torch
     t_start = time.perf_counter()
     out = []
 
@@ -828,6 +830,8 @@ def baseline_configs(args, local_rank, dev, budget_s=360.0, depth=8):
         if time.perf_counter() - t_start > budget_s:
             out.append({"config": tag, "skipped": f"time budget of {budget_s:.0f} s for the configs array spent"})
             return
+        gc.collect()                                       # (the previous leg's handles, streams and hipGraphs go before this one is timed)
+        torch.cuda.empty_cache()
         t0 = time.perf_counter()
         try:
             e = fn()
