@@ -224,7 +224,7 @@ __global__ __launch_bounds__(64 * kFinW) void k_ipm_cmax_finish(IpmArgs a) {
   const size_t s = (size_t)blockIdx.x * 64 + (threadIdx.x & 63), Bp = a.w.Bp;
   double mx[1];
   ipm_finish<1, 2, kFinW>(a.w.part, a.w.nch / 4, Bp, s, mx);
-  if (threadIdx.x < 64 && a.w.state[s] == 0) { a.w.sc[SC_CS * Bp + s] = mx[0] > 1e-300 ? mx[0] : 1.0; a.w.sc[SC_RPMIN * Bp + s] = 1e300; a.w.sc[SC_STRICT * Bp + s] = 0.0; a.w.sc[SC_UNDO * Bp + s] = 0.0; }
+  if (threadIdx.x < 64 && a.w.state[s] == 0) { a.w.sc[SC_CS * Bp + s] = mx[0] > 1e-300 ? mx[0] : 1.0; a.w.sc[SC_RPMIN * Bp + s] = 1e300; a.w.sc[SC_STRICT * Bp + s] = 0.0; a.w.sc[SC_UNDO * Bp + s] = 0.0; a.w.sc[SC_AP * Bp + s] = 1.0; a.w.sc[SC_AD * Bp + s] = 1.0; }
 }
 
 __global__ __launch_bounds__(256) void k_ipm_setup(IpmArgs a) {
@@ -307,13 +307,30 @@ __global__ __launch_bounds__(256) void k_ipm_resid(IpmArgs a) {
   const int n = a.P.n, m = a.P.m, N = n + m;
   int j0, j1; ipm_chunk(N, a.w.nch, cid, j0, j1);
   double comp = 0.0, cnt = 0.0;
+  // q[0 .. 7]: the sums of the HBM-resident path's KKT test on the unscaled problem (control_decide, dsp_stream.hpp) for THIS iterate - the
+  // one the previous iteration's update left; k_ipm_decide finishes them.  They ride on this kernel's two gathers (A' y, A v): the separate
+  // pass that took them right after the update (k_ipm_check, until round 6) read the same arrays once more.
+  double q[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const double cs = a.w.sc[SC_CS * Bp + s];
 #pragma unroll 2
   for (int j = j0; j < j1; ++j) {
     const size_t at = (size_t)j * Bp + s;
     const double l = a.w.l[at], u = a.w.u[at], v = a.w.v[at], z = a.w.z[at], f = a.w.f[at];
     const bool hl = ipm_fin(l), hu = ipm_fin(u), fixed = hl && hu && l == u;
-    const double rd = a.w.cb[at] - ipm_aty(a.P, a.w.y, a.w.wat, j, Bp, s) - z + f;
+    const double cb = a.w.cb[at], aty = ipm_aty(a.P, a.w.y, a.w.wat, j, Bp, s);
+    const double rd = cb - aty - z + f;
     a.w.rd[at] = rd;
+    if (j < n) {
+      const double rc = cb - aty;
+      const double lp = hl ? fmax(rc, 0.0) : 0.0, lm = hu ? fmax(-rc, 0.0) : 0.0;
+      const double dres = rc - lp + lm;
+      const double du = dres * cs / a.P.col_scale[j];
+      q[3] += du * du;                                                              // ||dual residual||^2, unscaled
+      q[4] += fabs(dres) * fabs(v);                                                 // (x cs)
+      q[5] += cb * v;                                                               // primal objective      (x cs)
+      q[6] += fabs(cb * v);
+      q[7] += lp * ipm_fin0(l) - lm * ipm_fin0(u);                                  // dual objective, bounds (x cs)
+    }
     double th = 0.0;
     if (!fixed) {
       double den = 0.0;
@@ -336,10 +353,23 @@ __global__ __launch_bounds__(256) void k_ipm_resid(IpmArgs a) {
     a.w.rt[at] = rt;
     a.w.tn[at] = th * rt;
   }
+  int i0, i1; ipm_chunk(m, a.w.nch, cid, i0, i1);
+  for (int i = i0; i < i1; ++i) {
+    const size_t ar = (size_t)(n + i) * Bp + s;
+    const double au = ipm_au(a.P, a.w.v, i, Bp, s);
+    a.w.rp[(size_t)i * Bp + s] = -au;
+    const double rlo = a.w.l[ar], rhi = a.w.u[ar], y = a.w.y[(size_t)i * Bp + s];
+    const double ax = au + a.w.v[ar];                                               // (A_s x)_i
+    const double viol = fmax(rlo - ax, 0.0) + fmax(ax - rhi, 0.0);
+    const double vu = viol / a.P.row_scale[i];
+    q[0] += vu * vu;                                                                // ||row violation||^2, unscaled
+    q[1] += fabs(y) * viol;                                                         // |y| . violation       (x cs)
+    q[2] += fmax(y, 0.0) * ipm_fin0(rlo) - fmax(-y, 0.0) * ipm_fin0(rhi);            // dual objective, rows  (x cs)
+  }
   ipm_put<0>(a, 0, comp, s);
   ipm_put<0>(a, 1, cnt, s);
-  int i0, i1; ipm_chunk(m, a.w.nch, cid, i0, i1);
-  for (int i = i0; i < i1; ++i) a.w.rp[(size_t)i * Bp + s] = -ipm_au(a.P, a.w.v, i, Bp, s);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) ipm_put<0>(a, 2 + k, q[k], s);
 }
 
 __global__ __launch_bounds__(64 * kFinW) void k_ipm_mu(IpmArgs a) {
@@ -1064,45 +1094,10 @@ __global__ void k_ipm_undone(IpmArgs a) {
 }
 
 // ---- termination: the HBM-resident path's KKT test on the unscaled problem (control_decide, dsp_stream.hpp) ------------------------------
-__global__ __launch_bounds__(256) void k_ipm_check(IpmArgs a) {
-  IPM_LANE();
-  const int n = a.P.n, m = a.P.m;
-  double q[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  int i0, i1; ipm_chunk(m, a.w.nch, cid, i0, i1);
-  for (int i = i0; i < i1; ++i) {
-    const size_t ar = (size_t)(n + i) * Bp + s;
-    const double rlo = a.w.l[ar], rhi = a.w.u[ar], y = a.w.y[(size_t)i * Bp + s];
-    const double ax = ipm_au(a.P, a.w.v, i, Bp, s) + a.w.v[ar];                  // (A_s x)_i
-    const double viol = fmax(rlo - ax, 0.0) + fmax(ax - rhi, 0.0);
-    const double vu = viol / a.P.row_scale[i];
-    q[0] += vu * vu;                                                              // ||row violation||^2, unscaled
-    q[1] += fabs(y) * viol;                                                       // |y| . violation       (x cs)
-    q[2] += fmax(y, 0.0) * ipm_fin0(rlo) - fmax(-y, 0.0) * ipm_fin0(rhi);          // dual objective, rows  (x cs)
-  }
-  int j0, j1; ipm_chunk(n, a.w.nch, cid, j0, j1);
-  const double cs = a.w.sc[SC_CS * Bp + s];
-#pragma unroll 2
-  for (int j = j0; j < j1; ++j) {
-    const size_t at = (size_t)j * Bp + s;
-    const double l = a.w.l[at], u = a.w.u[at], v = a.w.v[at], cb = a.w.cb[at];
-    const double rc = cb - ipm_aty(a.P, a.w.y, a.w.wat, j, Bp, s);
-    const double lp = ipm_fin(l) ? fmax(rc, 0.0) : 0.0, lm = ipm_fin(u) ? fmax(-rc, 0.0) : 0.0;
-    const double dres = rc - lp + lm;
-    const double du = dres * cs / a.P.col_scale[j];
-    q[3] += du * du;                                                              // ||dual residual||^2, unscaled
-    q[4] += fabs(dres) * fabs(v);                                                 // (x cs)
-    q[5] += cb * v;                                                               // primal objective      (x cs)
-    q[6] += fabs(cb * v);
-    q[7] += lp * ipm_fin0(l) - lm * ipm_fin0(u);                                  // dual objective, bounds (x cs)
-  }
-#pragma unroll
-  for (int k = 0; k < 8; ++k) ipm_put<0>(a, k, q[k], s);
-}
-
 __global__ __launch_bounds__(64 * kFinW) void k_ipm_decide(IpmArgs a) {
   const size_t s = (size_t)blockIdx.x * 64 + (threadIdx.x & 63), Bp = a.w.Bp;
   double q[8];
-  ipm_finish<8, 0, kFinW>(a.w.part, a.w.nch / 4, Bp, s, q);
+  ipm_finish<8, 0, kFinW>(a.w.part + (size_t)2 * (a.w.nch / 4) * Bp, a.w.nch / 4, Bp, s, q);      // (k_ipm_resid's partials 2 .. 9)
   if (threadIdx.x >= 64 || a.w.state[s] != 0) return;
   StreamCtrl &c = a.sw.ctrl[a.w.sid[s]];
   const dsp_options &o = a.opt;
@@ -1118,7 +1113,7 @@ __global__ __launch_bounds__(64 * kFinW) void k_ipm_decide(IpmArgs a) {
     fin = rp <= o.eps_rel && rd <= o.eps_rel && gap / (1.0 + fabs(po) + fabs(dobj)) <= o.eps_rel;
   }
   const double mu = a.w.sc[SC_MU * Bp + s];
-  a.w.iters[s] = a.it;
+  a.w.iters[s] = a.it - 1;                                                        // (the test of iteration `it` is on the iterate `it - 1` steps left)
   c.last_rp = rp; c.last_rd = rd; c.last_rg = gap / (1.0 + fabs(po) + fabs(dobj));
   // The end game's failure mode (round 6, the 256 distinct members: 10 of them; lab trace tools/ipm_lab.py member 58): Theta reaches 1e17,
   // the pivot of a row that shares a basic column with its neighbour is the difference of two numbers of that size - rounding noise -, the
@@ -1131,7 +1126,7 @@ __global__ __launch_bounds__(64 * kFinW) void k_ipm_decide(IpmArgs a) {
   const bool finite = po == po && mu == mu && fabs(po) < 1e300;
   const bool polluted = a.w.endg[s] && rp > 30.0 * o.eps_rel && rp > 1e3 * rpm;
   const bool broken = !(po == po) || !(mu == mu) || !(mu > 0.0);
-  const bool limit = a.it >= a.max_it;
+  const bool limit = a.it - 1 >= a.max_it;
   // (steps that stay below 1e-4: an LP without a solution, or a breakdown - not this method's scenario)
   const int stalled = (!fin && !broken && fmin(a.w.sc[SC_AP * Bp + s], a.w.sc[SC_AD * Bp + s]) < 1e-4) ? a.w.stall[s] + 1 : 0;
   a.w.stall[s] = stalled;
@@ -1642,12 +1637,53 @@ static hipError_t ipm_loop(StreamSolver *S, IpmArgs &a, hipStream_t st, bool *al
   // tolerances, not before: its check is 3 - 4 % of the solve and has never asked for a step (profiles/r70i_check_pred.log)
   const int check_pred_env = getenv("DSP_IPM_CHECK_PRED") ? atoi(getenv("DSP_IPM_CHECK_PRED")) : -1;
   int lanes_total = (int)a.w.Bp;
-  for (it = 1; it <= a.max_it; ++it) {
-    a.it = it;
+  // Pass `it` opens with the residuals of the iterate that `it - 1` steps have left AND its KKT sums (k_ipm_resid), decides on them - a
+  // scenario that passes leaves here -, and only then takes step `it`: the test rides on the residual kernel's gathers instead of a pass
+  // of its own after the update.  A step taken back or a packing of the lanes changes what the residual kernel saw: it runs again.
+  auto residual = [&]() {
     if (a.P.K > 0) { hipLaunchKernelGGL(k_ipm_wide_aty, grid, blk, 0, st, a, (const double *)a.w.y); hipLaunchKernelGGL(k_ipm_wide_aty_finish, lanes, dim3(64 * kFinW), 0, st, a); }
     hipLaunchKernelGGL(k_ipm_resid, grid, blk, 0, st, a);
     hipLaunchKernelGGL(k_ipm_mu, lanes, dim3(64 * kFinW), 0, st, a);
+  };
+  for (it = 1; it <= a.max_it + 1; ++it) {
+    a.it = it;
+    residual();
     IPM_DBG("resid");
+    if ((e = hipMemsetAsync(a.w.counts + 2, 0, 3 * sizeof(int), st)) != hipSuccess) return e;
+    hipLaunchKernelGGL(k_ipm_decide, lanes, dim3(64 * kFinW), 0, st, a);
+    IPM_DBG("decide");
+    if ((e = hipMemcpyAsync(I->counts_host, a.w.counts, 5 * sizeof(int), hipMemcpyDeviceToHost, st)) != hipSuccess) return e;
+    if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;
+    bool again = false;
+    if (I->counts_host[4] > 0) {                        // steps taken back (k_ipm_decide; the directions of the previous pass are still in place)
+      hipLaunchKernelGGL(k_ipm_undo, grid, blk, 0, st, a);
+      hipLaunchKernelGGL(k_ipm_undone, lanes, dim3(64), 0, st, a);
+      undone += I->counts_host[4];
+      again = true;
+      if (trace) fprintf(stderr, "[ipm] it %d: %d step(s) taken back\n", it - 1, I->counts_host[4]);
+    }
+    if (trace) {
+      double sc[SC_COUNT];
+      for (int q = 0; q < SC_COUNT; ++q) (void)hipMemcpy(&sc[q], a.w.sc + (size_t)q * a.w.Bp + (trace - 1), sizeof(double), hipMemcpyDeviceToHost);
+      StreamCtrl c0{};
+      (void)hipMemcpy(&c0, a.sw.ctrl + (trace - 1), sizeof(StreamCtrl), hipMemcpyDeviceToHost);
+      fprintf(stderr, "[ipm] it %d lane %d: mu %.3e sigma*mu %.3e ap %.3f ad %.3f rp %.2e rd %.2e rg %.2e | finished %d solved %d endgame %d refine %d\n", it - 1, trace - 1,
+              sc[SC_MU], sc[SC_SIGMU], sc[SC_AP], sc[SC_AD], c0.last_rp, c0.last_rd, c0.last_rg, I->counts_host[0], I->counts_host[1], I->counts_host[2], refine);
+    }
+    if (I->counts_host[0] >= lanes_total || it > a.max_it) break;
+    refine = 0;
+    {
+      const int active = lanes_total - I->counts_host[0];
+      if (compact && a.w.G > 1 && active <= 64 * (a.w.G - 1)) {
+        if ((e = ipm_repack(I, a, st, active)) != hipSuccess) return e;
+        lanes_total = a.w.G * 64;
+        grid = dim3((unsigned)(a.w.nch / 4), (unsigned)a.w.G); lanes = dim3((unsigned)a.w.G);
+        ++repacks;
+        again = true;
+        if (trace) fprintf(stderr, "[ipm] it %d: %d scenarios still iterating packed into %d group(s)\n", it - 1, active, a.w.G);
+      }
+    }
+    if (again) residual();
     hipLaunchKernelGGL(k_ipm_assemble, grid, blk, 0, st, a);
     IPM_DBG("assemble");
     if (it == 1 && trace) {
@@ -1704,43 +1740,9 @@ static hipError_t ipm_loop(StreamSolver *S, IpmArgs &a, hipStream_t st, bool *al
     IPM_DBG("direction");
     hipLaunchKernelGGL(k_ipm_update, grid, blk, 0, st, a);
     IPM_DBG("update");
-    if ((e = hipMemsetAsync(a.w.counts + 2, 0, 3 * sizeof(int), st)) != hipSuccess) return e;
-    if (a.P.K > 0) { hipLaunchKernelGGL(k_ipm_wide_aty, grid, blk, 0, st, a, (const double *)a.w.y); hipLaunchKernelGGL(k_ipm_wide_aty_finish, lanes, dim3(64 * kFinW), 0, st, a); }
-    hipLaunchKernelGGL(k_ipm_check, grid, blk, 0, st, a);
-    IPM_DBG("check");
-    hipLaunchKernelGGL(k_ipm_decide, lanes, dim3(64 * kFinW), 0, st, a);
-    IPM_DBG("decide");
-    if ((e = hipMemcpyAsync(I->counts_host, a.w.counts, 5 * sizeof(int), hipMemcpyDeviceToHost, st)) != hipSuccess) return e;
-    if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;
-    if (I->counts_host[4] > 0) {                        // steps taken back (k_ipm_decide)
-      hipLaunchKernelGGL(k_ipm_undo, grid, blk, 0, st, a);
-      hipLaunchKernelGGL(k_ipm_undone, lanes, dim3(64), 0, st, a);
-      undone += I->counts_host[4];
-      if (trace) fprintf(stderr, "[ipm] it %d: %d step(s) taken back\n", it, I->counts_host[4]);
-    }
-    if (trace) {
-      double sc[SC_COUNT];
-      for (int q = 0; q < SC_COUNT; ++q) (void)hipMemcpy(&sc[q], a.w.sc + (size_t)q * a.w.Bp + (trace - 1), sizeof(double), hipMemcpyDeviceToHost);
-      StreamCtrl c0{};
-      (void)hipMemcpy(&c0, a.sw.ctrl + (trace - 1), sizeof(StreamCtrl), hipMemcpyDeviceToHost);
-      fprintf(stderr, "[ipm] it %d lane %d: mu %.3e sigma*mu %.3e ap %.3f ad %.3f rp %.2e rd %.2e rg %.2e | finished %d solved %d endgame %d refine %d\n", it, trace - 1,
-              sc[SC_MU], sc[SC_SIGMU], sc[SC_AP], sc[SC_AD], c0.last_rp, c0.last_rd, c0.last_rg, I->counts_host[0], I->counts_host[1], I->counts_host[2], refine);
-    }
-    if (I->counts_host[0] >= lanes_total) break;
-    refine = 0;
-    {
-      const int active = lanes_total - I->counts_host[0];
-      if (compact && a.w.G > 1 && active <= 64 * (a.w.G - 1) && it < a.max_it) {
-        if ((e = ipm_repack(I, a, st, active)) != hipSuccess) return e;
-        lanes_total = a.w.G * 64;
-        grid = dim3((unsigned)(a.w.nch / 4), (unsigned)a.w.G); lanes = dim3((unsigned)a.w.G);
-        ++repacks;
-        if (trace) fprintf(stderr, "[ipm] it %d: %d scenarios still iterating packed into %d group(s)\n", it, active, a.w.G);
-      }
-    }
   }
   I->last_repacks = repacks;
-  *newton = std::min(it, a.max_it);
+  *newton = std::min(it - 1, a.max_it);
   IPM_DBG("loop");
   if (trace) {
     std::vector<int> hs(a.w.Bp), hi(a.w.Bp);
