@@ -27,9 +27,10 @@
 // whatever the batch.  TIME-PARALLEL form (default; dsp_ipm_seq.hpp): the rows are cut into up to 64 partitions whose interiors are
 // eliminated at once (k_seq with grid.y = partitions), the W columns coupling an interior to the separator on its left are carried as
 // spikes, the separators form a block-tridiagonal system solved per lane (k_ipm_red_factor / k_ipm_red_solve), border sums and corrections
-// (k_ipm_border_dot / k_ipm_border_apply) connect the two: a solve is then five bandwidth-bound kernels (3.5 GB at 256 scenarios, 0.54 of
+// (k_ipm_border_dot / k_ipm_border_apply) connect the two: a solve is then five bandwidth-bound kernels (3.5 GB at 256 scenarios, 0.59 of
 // the HBM peak) instead of two latency chains.  Everything else (residuals, Theta, assembly of the band, directions, step lengths, KKT
-// test) is elementwise over (chunk of indices) x (64 scenarios).  256 year-long scenarios: 13 ms per Newton iteration, ~50 GB of HBM traffic.
+// test) is elementwise over (chunk of indices) x (64 scenarios).  256 year-long scenarios: 13 ms per Newton iteration and ~50 GB of HBM traffic
+// in round 5; 4.9 ms and ~21 GB at the end of round 6 (lane packing, refinement on demand, fused elementwise passes: DESIGN.md 4f).
 //
 // Termination is the HBM-resident path's own test (control_decide, dsp_stream.hpp) evaluated on the unscaled problem; a scenario the
 // method does not finish (breakdown, 250 Newton iterations, free columns) is left to the PDHG forms - that scenario alone: the ones this
