@@ -917,32 +917,16 @@ __device__ __forceinline__ void ipm_targets(const IpmArgs &a, size_t at, size_t 
   cf = hu ? (sm - (mode ? a.w.coru[at] : 0.0)) / tu - f : 0.0;
 }
 
-// rt = rd - cz + cf ; tn = theta rt
-__global__ __launch_bounds__(256) void k_ipm_rt(IpmArgs a, int mode) {
-  IPM_LANE();
-  const int N = a.P.n + a.P.m;
-  int j0, j1; ipm_chunk(N, a.w.nch, cid, j0, j1);
-#pragma unroll 2
-  for (int j = j0; j < j1; ++j) {
-    const size_t at = (size_t)j * Bp + s;
-    const double l = a.w.l[at], u = a.w.u[at], v = a.w.v[at], th = a.w.th[at];
-    const bool hl = ipm_fin(l) && th > 0.0, hu = ipm_fin(u) && th > 0.0;
-    double cz, cf;
-    ipm_targets(a, at, s, mode, hl, hu, v - l, u - v, a.w.z[at], a.w.f[at], cz, cf);
-    const double rt = a.w.rd[at] - cz + cf;
-    a.w.rt[at] = rt;
-    a.w.tn[at] = th * rt;
-  }
-}
-
-// rhs = rp + Abar tn
-__global__ __launch_bounds__(256) void k_ipm_rhs(IpmArgs a) {
+// rhs = rp + Abar tn   (mode 0: tn of the predictor, k_ipm_resid; mode 1: tn = th ta + sigma mu th tb, k_ipm_dir's mode 0)
+__global__ __launch_bounds__(256) void k_ipm_rhs(IpmArgs a, int mode) {
   IPM_LANE();
   int i0, i1; ipm_chunk(a.P.m, a.w.nch, cid, i0, i1);
+  const double sm = a.w.sc[SC_SIGMU * Bp + s];
 #pragma unroll 2
   for (int i = i0; i < i1; ++i) {
     const size_t at = (size_t)i * Bp + s;
-    const double r = a.w.rp[at] + ipm_au(a.P, a.w.tn, i, Bp, s);
+    const double r = mode == 0 ? a.w.rp[at] + ipm_au(a.P, a.w.tn, i, Bp, s)
+                               : a.w.rp[at] + (ipm_au(a.P, a.w.rt, i, Bp, s) + sm * ipm_au(a.P, a.w.dz, i, Bp, s));
     a.w.rhs[at] = r;
     a.w.q[at] = r;
   }
@@ -1000,7 +984,10 @@ __global__ __launch_bounds__(256) void k_ipm_dir(IpmArgs a, int mode) {
     const double wl = v - l, tu = u - v;
     double cz, cf;
     ipm_targets(a, at, s, mode, hl, hu, wl, tu, z, f, cz, cf);
-    const double dv = th * (ipm_aty(a.P, a.w.dy, a.w.wat, j, Bp, s) - a.w.rt[at]);
+    // mode 0: rt holds the predictor's rt; mode 1: the corrector's rt = ta + sigma mu tb was never formed - rt holds th ta, dz holds th tb
+    // (written below by mode 0), and dv = th (A' dy) - th rt
+    const double aty = ipm_aty(a.P, a.w.dy, a.w.wat, j, Bp, s);
+    const double dv = mode == 0 ? th * (aty - a.w.rt[at]) : th * aty - (a.w.rt[at] + a.w.sc[SC_SIGMU * Bp + s] * a.w.dz[at]);
     const double dz = hl ? cz - z / wl * dv : 0.0;
     const double df = hu ? cf + f / tu * dv : 0.0;
     if (mode == 0) {
@@ -1011,8 +998,18 @@ __global__ __launch_bounds__(256) void k_ipm_dir(IpmArgs a, int mode) {
       // k_ipm_muaff pass read nine arrays to do this)
       if (hl) { q1 += z * dv; q2 += wl * dz; q3 += dz * dv; }
       if (hu) { q1 -= f * dv; q2 += tu * df; q3 -= df * dv; }
-      a.w.corl[at] = dv * dz;
-      a.w.coru[at] = -dv * df;
+      const double corl = dv * dz, coru = -dv * df;
+      a.w.corl[at] = corl;
+      a.w.coru[at] = coru;
+      // The corrector's rt = rd - cz + cf is LINEAR in sigma mu, which does not exist before this kernel's sums are finished:
+      //   rt = ta + sigma mu tb,   ta = rd + (corl / w + z) - (coru / t + f),   tb = -1 / w + 1 / t        (terms of the bounds that exist)
+      // th ta goes where the predictor's rt was, th tb into dz's slot (free until mode 1 writes dz at this very index): k_ipm_rhs forms
+      // rp + Abar (th ta) + sigma mu Abar (th tb), mode 1 reads the two - the pass that formed rt / tn (nine arrays read) is gone
+      double ta = a.w.rd[at], tb = 0.0;
+      if (hl) { ta += corl / wl + z; tb -= 1.0 / wl; }
+      if (hu) { ta -= coru / tu + f; tb += 1.0 / tu; }
+      a.w.rt[at] = th * ta;
+      a.w.dz[at] = th * tb;
     } else {
       a.w.dv[at] = dv; a.w.dz[at] = dz; a.w.df[at] = df;
     }
@@ -1712,8 +1709,7 @@ static hipError_t ipm_loop(StreamSolver *S, IpmArgs &a, hipStream_t st, bool *al
       ipm_dump("sinv", a.w.sinv, (size_t)kIpmMaxK * kIpmMaxK, a.w.Bp, trace - 1, st);
     }
     for (int mode = 0; mode < 2; ++mode) {
-      if (mode == 1) hipLaunchKernelGGL(k_ipm_rt, grid, blk, 0, st, a, mode);      // (mode 0: written by k_ipm_resid)
-      hipLaunchKernelGGL(k_ipm_rhs, grid, blk, 0, st, a);
+      hipLaunchKernelGGL(k_ipm_rhs, grid, blk, 0, st, a, mode);                     // (rt / tn: mode 0 by k_ipm_resid, mode 1 by k_ipm_dir's mode 0)
       IPM_DBG("rhs");
       { int steps = 0; if ((e = ipm_nsolve<W>(S, a, st, &steps, mode == 1 || (check_pred_env >= 0 ? check_pred_env != 0 : undone > 0))) != hipSuccess) return e; refine = std::max(refine, steps); }
       IPM_DBG("nsolve");
