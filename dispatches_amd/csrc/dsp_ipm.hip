@@ -30,7 +30,7 @@
 // (k_ipm_border_dot / k_ipm_border_apply) connect the two: a solve is then five bandwidth-bound kernels (3.5 GB at 256 scenarios, 0.59 of
 // the HBM peak) instead of two latency chains.  Everything else (residuals, Theta, assembly of the band, directions, step lengths, KKT
 // test) is elementwise over (chunk of indices) x (64 scenarios).  256 year-long scenarios: 13 ms per Newton iteration and ~50 GB of HBM traffic
-// in round 5; 4.9 ms and ~21 GB at the end of round 6 (lane packing, refinement on demand, fused elementwise passes: DESIGN.md 4f).
+// in round 5; 4.6 ms and ~18 GB at the end of round 6 (lane packing, refinement on demand, fused elementwise passes: DESIGN.md 4f).
 //
 // Termination is the HBM-resident path's own test (control_decide, dsp_stream.hpp) evaluated on the unscaled problem; a scenario the
 // method does not finish (breakdown, 250 Newton iterations, free columns) is left to the PDHG forms - that scenario alone: the ones this
